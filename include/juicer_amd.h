@@ -1,0 +1,223 @@
+/*
+ * juicer_amd.h - C ABI of the MI355X-native WFST Viterbi decoder.
+ *
+ * This is the drop-in boundary for ONE path of idiap/juicer: the
+ * WFSTDecoderLite token-passing search + HTKFlatModels diagonal-GMM scoring,
+ * behind Juicer's IDecoder / DecoderBatchTest seam.  Every entry point cites
+ * the reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every function that can fail returns 0 on success or a negative JD_E*
+ *     code; jd_last_error() returns a human readable message for the calling
+ *     thread's most recent failure.  (The reference calls Torch3 error() =
+ *     print + exit(); a library must not exit, so the same conditions are
+ *     reported as codes instead.)
+ *   - All "host" pointers are only read during the call; nothing is retained.
+ *   - There is NO CPU fallback: if no gfx950 device / HIP runtime is usable
+ *     jd_dec_create() fails with JD_ENODEV.
+ */
+#ifndef JUICER_AMD_H
+#define JUICER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JD_OK        0
+#define JD_EINVAL   -1   /* bad argument                                        */
+#define JD_ENODEV   -2   /* no usable HIP device                                */
+#define JD_EHIP     -3   /* HIP runtime call failed                             */
+#define JD_ENOMEM   -4   /* a device arena (slots/paths/frontier) overflowed     */
+#define JD_EHIST    -5   /* Histogram::addScore - score > maxScore
+                            (Histogram.cpp:78-79 is fatal in the reference)     */
+#define JD_ESTATE   -6   /* call order violated (e.g. push before init)          */
+#define JD_EFORMAT  -7   /* text loader: malformed FSM / MMF input               */
+
+/* LOG_ZERO of the reference: Torch3 defines it as -FLT_MAX (not -inf). */
+#define JD_LOG_ZERO (-3.402823466e+38f)
+
+typedef struct jd_net jd_net;   /* replaces Juicer::WFSTNetwork  (WFSTNetwork.h:110-245)   */
+typedef struct jd_am  jd_am;    /* replaces Juicer::HTKFlatModels (HTKFlatModels.h)         */
+typedef struct jd_dec jd_dec;   /* replaces Juicer::WFSTDecoderLite (WFSTDecoderLite.h:77) */
+
+/* ------------------------------------------------------------------ network */
+
+/*
+ * Build a network from arcs in FSM *file order* with the raw file weights,
+ * applying the load-time arithmetic of WFSTNetwork::WFSTNetwork(text)
+ * (WFSTNetwork.cpp:371-616):
+ *     weight = (float)(-w_file * lm_scale); if (out > 0) weight += ins_penalty
+ *     final weight = (float)(-w_file * lm_scale)
+ *     initial state = source state of the first arc
+ * Arcs of one source state must be contiguous (getTransitions(),
+ * WFSTNetwork.cpp:709-721, returns "first arc + count"); JD_EFORMAT otherwise.
+ * in/out labels are integers; 0 is epsilon; in-label i>0 selects HMM i-1
+ * (WFSTDecoderLite.cpp:754).  Auxiliary symbols must already be removed.
+ */
+int jd_net_create_arcs(jd_net **out, int64_t n_arcs,
+                       const int32_t *from, const int32_t *to,
+                       const int32_t *in, const int32_t *outl,
+                       const float *w_file,
+                       int32_t n_final, const int32_t *fstate, const float *fweight_file,
+                       float lm_scale, float ins_penalty);
+
+/*
+ * Build a network from an already prepared CSR (weights are used as given,
+ * i.e. they are the reference's in-memory transitions[].weight values).
+ * row_ptr has n_states+1 entries.
+ */
+int jd_net_create_csr(jd_net **out, int32_t n_states, int32_t init_state,
+                      const int32_t *row_ptr, const int32_t *to, const float *w,
+                      const int32_t *in, const int32_t *outl,
+                      int32_t n_final, const int32_t *fstate, const float *fweight);
+
+/* AT&T text FSM file (WFSTNetwork.cpp:403-560); symbol files are optional and
+ * only used for the range checks of WFSTNetwork.cpp:566-584. */
+int jd_net_load_fsm(jd_net **out, const char *fsm_path, const char *insyms_path,
+                    const char *outsyms_path, float lm_scale, float ins_penalty);
+
+int64_t jd_net_num_arcs(const jd_net *n);     /* WFSTNetwork::getNumTransitions */
+int32_t jd_net_num_states(const jd_net *n);   /* WFSTNetwork::getNumStates      */
+int32_t jd_net_init_state(const jd_net *n);   /* WFSTNetwork::getInitState      */
+void    jd_net_destroy(jd_net *n);
+
+/* ---------------------------------------------------------- acoustic models */
+
+/*
+ * Build models from HTK-level parameters, applying the load-time arithmetic of
+ * HTKModels::addVarVec (HTKModels.cpp:835-870), addGMM (:600-676),
+ * addTransMatrix (:873-974), addHMM tee detection (:581-593),
+ * createTrPandSEIndex (:2330-2390) and HTKFlatModels::init
+ * (HTKFlatModels.cpp:94-177):
+ *     det  = -0.5*(D*LOG_2_PI + sum_k logf(var_k))  [float accumulation] + logf(weight)
+ *     ivar = (float)(1.0/var)
+ *     trP[i][j] = logf(a_ij) if a_ij > 0 else LOG_ZERO; SEIndex; teeWeight
+ * Layout: weight[n_gmm*max_mix], mean/var[n_gmm*max_mix*D] (component major),
+ * n_mix[n_gmm]; hmm_nstates[n_hmm] (incl. entry+exit), hmm_gmm[n_hmm*max_n]
+ * (gmm id per state, -1 for entry/exit), hmm_tm[n_hmm]; tm_nstates[n_tm],
+ * transp[n_tm*max_n*max_n] row-major a_ij.
+ */
+int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t max_mix,
+                     const int32_t *n_mix, const float *weight,
+                     const float *mean, const float *var,
+                     int32_t n_hmm, int32_t max_n, const int32_t *hmm_nstates,
+                     const int32_t *hmm_gmm, const int32_t *hmm_tm,
+                     int32_t n_tm, const int32_t *tm_nstates, const float *transp);
+
+int32_t jd_am_num_hmms(const jd_am *a);       /* IModels::getNumHMMs       (Models.h:57) */
+int32_t jd_am_num_gmms(const jd_am *a);
+int32_t jd_am_vec_size(const jd_am *a);       /* IModels::getInputVecSize  (Models.h:60) */
+int32_t jd_am_max_states(const jd_am *a);
+/* Read back prepared parameters (host copies) - used by parity tests. */
+int jd_am_get_flat(const jd_am *a, float *det, float *mean, float *ivar);
+int jd_am_get_trans(const jd_am *a, float *trP, int16_t *se, float *tee);
+void jd_am_destroy(jd_am *a);
+
+/* ------------------------------------------------------------------ decoder */
+
+typedef struct jd_stats {          /* WFSTDecoderLite.cpp:231-241 + build counters */
+    int32_t n_frames;
+    int64_t tot_active_emit_hyps;  /* totalActiveEmitHyps */
+    int64_t tot_active_end_hyps;   /* totalActiveEndHyps  */
+    int64_t tot_active_models;     /* totalActiveModels   */
+    int64_t tot_proc_emit_hyps;    /* totalProcEmitHyps   */
+    int64_t tot_proc_end_hyps;     /* totalProcEndHyps    */
+    int64_t tot_arcs_visited;      /* out-arcs visited by propagateToken (A)      */
+    int64_t tot_paths;             /* Path records created (Wd)                    */
+    int64_t tot_insts_in;          /* instances processed by internal propagation (Mdl) */
+    int64_t ties;                  /* equal-score recombinations seen (oracle only; 0 on GPU) */
+} jd_stats;
+
+/*
+ * 1-best result: the DecHyp / DecHypHist chain of recognitionFinish()
+ * (WFSTDecoderLite.cpp:262-308, DecHypHistPool.h:38-49,146-165) flattened to
+ * arrays in CHAIN order: index 0 is hyp->hist (the newest word), index n-1 the
+ * oldest.  label = DecHypHist::state (= output label = word id + 1), time =
+ * DecHypHist::time.  Entry 0 and the totals carry the final-state weight.
+ * n == -1 means "no token survived" (the reference returns NULL + warning).
+ * Storage is owned by the decoder and valid until the next init of that stream.
+ */
+typedef struct jd_hyp {
+    int32_t  n;
+    const int32_t *label;
+    const int32_t *time;
+    const float   *score;
+    const float   *ac;
+    const float   *lm;
+    float tot_score, tot_ac, tot_lm;
+    jd_stats stats;
+} jd_hyp;
+
+/*
+ * WFSTDecoderLite::WFSTDecoderLite(network, models, phoneStartPruneWin,
+ * emitPruneWin, phoneEndPruneWin, wordPruneWin, maxEmitHyps)
+ * (WFSTDecoderLite.h:81-89).  A window is enabled iff > 0; max_hyps == 0
+ * disables the histogram (WFSTDecoderLite.cpp:76-82).  block_size mirrors
+ * IModels::setBlockSize (1..20, juicer.cpp:255); it never changes results.
+ * device = HIP device ordinal; max_streams = utterances decoded concurrently.
+ */
+int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am,
+                  float start_beam, float main_beam, float end_beam, float word_beam,
+                  int32_t max_hyps, int32_t block_size, int32_t device, int32_t max_streams);
+void jd_dec_destroy(jd_dec *d);
+
+/* Capacity knobs (call before first init; defaults sized from the network). */
+int jd_dec_set_capacity(jd_dec *d, int64_t max_slots, int64_t max_paths, int64_t max_items);
+
+/* IDecoder::init() (Decoder.h:26) for stream s. */
+int jd_stream_init(jd_dec *d, int32_t s);
+/* IDecoder::processFrame() x n_frames (Decoder.h:27): frames is n_frames x D
+ * contiguous HOST floats; the look-ahead rows of the reference protocol
+ * (DecoderSingleTest.cpp:267-295) carry no information beyond the frames
+ * themselves, so the adapter folds them into pushes. */
+int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t n_frames);
+/* IDecoder::finish() (Decoder.h:28). */
+int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out);
+
+/*
+ * DecoderBatchTest::run() inner loop (DecoderBatchTest.cpp:738-771) for a
+ * batch: decodes n_utts utterances (n_utts may exceed max_streams; they are
+ * processed in waves of max_streams).  feats[u] = n_frames[u] x D host floats.
+ */
+int jd_decode_batch(jd_dec *d, int32_t n_utts, const float *const *feats,
+                    const int32_t *n_frames, jd_hyp *out);
+
+/*
+ * Same, with features already resident in device memory (bench path: inputs
+ * in HBM before the timed region).  d_feats is one device buffer holding all
+ * utterances back to back; offs[u] is the frame offset of utterance u
+ * (n_utts+1 entries).  hip_stream is a hipStream_t (or NULL for the default
+ * stream).  Results are valid after the call returns (it synchronises).
+ */
+int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
+                           const int64_t *offs, void *hip_stream, jd_hyp *out);
+
+/* Durations (ms, HIP events on the decoder's own streams) of the kernels of
+ * the most recent jd_decode_batch*(): total GMM-kernel time, total search-
+ * kernel time, number of launches of each, wall time of the whole call. */
+typedef struct jd_timing {
+    double gmm_ms, search_ms, total_ms;
+    int32_t gmm_launches, search_launches;
+    int64_t gmm_frames;       /* stream-frames scored                           */
+    int64_t gmm_states;       /* tied states scored per frame                    */
+} jd_timing;
+int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
+
+/*
+ * Companion kernel on its own: HTKFlatModels::calcGMMOutput
+ * (HTKFlatModels.cpp:226-262) for every tied state of every frame.
+ * frames: n_frames x D host floats; out: n_frames x n_gmm host floats.
+ */
+int jd_am_score_frames(const jd_am *a, int32_t device, const float *frames,
+                       int32_t n_frames, float *out);
+
+const char *jd_last_error(void);
+const char *jd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JUICER_AMD_H */

@@ -1,0 +1,320 @@
+"""ctypes binding of the C ABI in include/juicer_amd.h (libjuicer_amd.so).
+
+The library is the product; this module only marshals numpy arrays and raw
+device pointers into it.  There is no CPU fallback anywhere: if the shared
+library is missing or no HIP device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjuicer_amd.so")
+
+JD_OK, JD_EINVAL, JD_ENODEV, JD_EHIP, JD_ENOMEM, JD_EHIST, JD_ESTATE, JD_EFORMAT = 0, -1, -2, -3, -4, -5, -6, -7
+LOG_ZERO = float(np.float32(-3.402823466e+38))
+
+
+class JuicerAmdError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("juicer_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_frames", C.c_int32),
+                ("tot_active_emit_hyps", C.c_int64), ("tot_active_end_hyps", C.c_int64),
+                ("tot_active_models", C.c_int64), ("tot_proc_emit_hyps", C.c_int64),
+                ("tot_proc_end_hyps", C.c_int64), ("tot_arcs_visited", C.c_int64),
+                ("tot_paths", C.c_int64), ("tot_insts_in", C.c_int64), ("ties", C.c_int64)]
+
+
+class CHyp(C.Structure):
+    _fields_ = [("n", C.c_int32),
+                ("label", C.POINTER(C.c_int32)), ("time", C.POINTER(C.c_int32)),
+                ("score", C.POINTER(C.c_float)), ("ac", C.POINTER(C.c_float)), ("lm", C.POINTER(C.c_float)),
+                ("tot_score", C.c_float), ("tot_ac", C.c_float), ("tot_lm", C.c_float),
+                ("stats", Stats)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("gmm_ms", C.c_double), ("search_ms", C.c_double), ("total_ms", C.c_double),
+                ("gmm_launches", C.c_int32), ("search_launches", C.c_int32),
+                ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64)]
+
+
+@dataclass
+class Hyp:
+    """1-best in DecHyp chain order (index 0 = newest word)."""
+    n: int
+    label: np.ndarray
+    time: np.ndarray
+    score: np.ndarray
+    ac: np.ndarray
+    lm: np.ndarray
+    tot_score: float
+    tot_ac: float
+    tot_lm: float
+    stats: dict
+
+
+# every symbol include/juicer_amd.h declares
+EXPORTS = [
+    "jd_net_create_arcs", "jd_net_create_csr", "jd_net_load_fsm", "jd_net_num_arcs", "jd_net_num_states",
+    "jd_net_init_state", "jd_net_destroy", "jd_am_create_htk", "jd_am_num_hmms", "jd_am_num_gmms",
+    "jd_am_vec_size", "jd_am_max_states", "jd_am_get_flat", "jd_am_get_trans", "jd_am_destroy",
+    "jd_dec_create", "jd_dec_destroy", "jd_dec_set_capacity", "jd_stream_init", "jd_stream_push",
+    "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
+    "jd_am_score_frames", "jd_last_error", "jd_version",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libjuicer_amd.so; fail loudly when the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JuicerAmdError(JD_ENODEV, "HIP extension %s is not built (run python -m juicer_amd.build); "
+                                 "there is no CPU fallback" % LIB_PATH)
+        try:                      # share torch's HIP runtime when torch is in the process
+            import torch  # noqa: F401
+        except Exception:
+            pass
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        L.jd_last_error.restype = C.c_char_p
+        L.jd_version.restype = C.c_char_p
+        L.jd_net_num_arcs.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise JuicerAmdError(rc, lib().jd_last_error().decode())
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _hyp_from_c(h: CHyp) -> Hyp:
+    k = max(int(h.n), 0)
+
+    def arr(ptr, dt):
+        if k == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(ptr, shape=(k,)).astype(dt, copy=True)
+    st = {f: int(getattr(h.stats, f)) for f, _ in Stats._fields_}
+    return Hyp(n=int(h.n), label=arr(h.label, np.int32), time=arr(h.time, np.int32),
+               score=arr(h.score, np.float32), ac=arr(h.ac, np.float32), lm=arr(h.lm, np.float32),
+               tot_score=float(h.tot_score), tot_ac=float(h.tot_ac), tot_lm=float(h.tot_lm), stats=st)
+
+
+class Network:
+    """WFSTNetwork counterpart: CSR arc table (16-byte arc records) for HBM."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_arcs(cls, src, dst, ilab, olab, w_file, fstate, fweight_file, lm_scale=1.0, ins_penalty=0.0):
+        L = lib()
+        h = C.c_void_p()
+        src, dst, il, ol = _i32(src), _i32(dst), _i32(ilab), _i32(olab)
+        wf, fs, fw = _f32(w_file), _i32(fstate), _f32(fweight_file)
+        _check(L.jd_net_create_arcs(C.byref(h), C.c_int64(src.shape[0]), _p(src, C.c_int32), _p(dst, C.c_int32),
+                                    _p(il, C.c_int32), _p(ol, C.c_int32), _p(wf, C.c_float),
+                                    C.c_int32(fs.shape[0]), _p(fs, C.c_int32), _p(fw, C.c_float),
+                                    C.c_float(lm_scale), C.c_float(ins_penalty)))
+        return cls(h)
+
+    @classmethod
+    def from_synth(cls, net, lm_scale=1.0, ins_penalty=0.0):
+        return cls.from_arcs(net.src, net.dst, net.ilab, net.olab, net.w_file, net.fstate, net.fweight_file,
+                             lm_scale, ins_penalty)
+
+    @classmethod
+    def from_csr(cls, n_states, init_state, row_ptr, to, w, ilab, olab, fstate, fweight):
+        L = lib()
+        h = C.c_void_p()
+        rp, to_, il, ol = _i32(row_ptr), _i32(to), _i32(ilab), _i32(olab)
+        w_, fs, fw = _f32(w), _i32(fstate), _f32(fweight)
+        _check(L.jd_net_create_csr(C.byref(h), C.c_int32(n_states), C.c_int32(init_state), _p(rp, C.c_int32),
+                                   _p(to_, C.c_int32), _p(w_, C.c_float), _p(il, C.c_int32), _p(ol, C.c_int32),
+                                   C.c_int32(fs.shape[0]), _p(fs, C.c_int32), _p(fw, C.c_float)))
+        return cls(h)
+
+    @classmethod
+    def from_fsm_file(cls, fsm_path, insyms_path=None, outsyms_path=None, lm_scale=1.0, ins_penalty=0.0):
+        L = lib()
+        h = C.c_void_p()
+        enc = lambda s: None if s is None else os.fsencode(s)
+        _check(L.jd_net_load_fsm(C.byref(h), enc(fsm_path), enc(insyms_path), enc(outsyms_path),
+                                 C.c_float(lm_scale), C.c_float(ins_penalty)))
+        return cls(h)
+
+    @property
+    def n_arcs(self):
+        return int(lib().jd_net_num_arcs(self.h))
+
+    @property
+    def n_states(self):
+        return int(lib().jd_net_num_states(self.h))
+
+    @property
+    def init_state(self):
+        return int(lib().jd_net_init_state(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.jd_net_destroy(self.h)
+            self.h = None
+
+
+class Models:
+    """HTKFlatModels counterpart (IModels, Models.h:29-67)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_htk(cls, am):
+        L = lib()
+        h = C.c_void_p()
+        nm, wt, mu, var = _i32(am.n_mix), _f32(am.weight), _f32(am.mean), _f32(am.var)
+        hn, hg, ht = _i32(am.hmm_nstates), _i32(am.hmm_gmm), _i32(am.hmm_tm)
+        tn, tp = _i32(am.tm_nstates), _f32(am.transp)
+        _check(L.jd_am_create_htk(C.byref(h), C.c_int32(am.D), C.c_int32(am.n_gmm), C.c_int32(am.max_mix),
+                                  _p(nm, C.c_int32), _p(wt, C.c_float), _p(mu, C.c_float), _p(var, C.c_float),
+                                  C.c_int32(am.n_hmm), C.c_int32(am.max_n), _p(hn, C.c_int32), _p(hg, C.c_int32),
+                                  _p(ht, C.c_int32), C.c_int32(am.n_tm), _p(tn, C.c_int32), _p(tp, C.c_float)))
+        m = cls(h)
+        m.n_tm = int(am.n_tm)
+        m.max_mix = int(am.max_mix)
+        return m
+
+    @property
+    def n_hmms(self):
+        return int(lib().jd_am_num_hmms(self.h))
+
+    @property
+    def n_gmms(self):
+        return int(lib().jd_am_num_gmms(self.h))
+
+    @property
+    def vec_size(self):
+        return int(lib().jd_am_vec_size(self.h))
+
+    @property
+    def max_states(self):
+        return int(lib().jd_am_max_states(self.h))
+
+    def flat(self):
+        G, M, D = self.n_gmms, self.max_mix, self.vec_size
+        det = np.zeros((G, M), np.float32)
+        mean = np.zeros((G, M, D), np.float32)
+        ivar = np.zeros((G, M, D), np.float32)
+        _check(lib().jd_am_get_flat(self.h, _p(det, C.c_float), _p(mean, C.c_float), _p(ivar, C.c_float)))
+        return det, mean, ivar
+
+    def trans(self):
+        MN = self.max_states
+        trP = np.zeros((self.n_tm, MN, MN), np.float32)
+        se = np.zeros((self.n_tm, MN, 2), np.int16)
+        tee = np.zeros(self.n_hmms, np.float32)
+        _check(lib().jd_am_get_trans(self.h, _p(trP, C.c_float), _p(se, C.c_int16), _p(tee, C.c_float)))
+        return trP, se, tee
+
+    def score_frames(self, frames, device: int = 0):
+        """Companion GMM kernel on its own: [T, D] -> [T, n_gmm] log-likelihoods."""
+        x = _f32(frames)
+        out = np.zeros((x.shape[0], self.n_gmms), np.float32)
+        _check(lib().jd_am_score_frames(self.h, C.c_int32(device), _p(x, C.c_float), C.c_int32(x.shape[0]),
+                                        _p(out, C.c_float)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.jd_am_destroy(self.h)
+            self.h = None
+
+
+class Decoder:
+    """WFSTDecoderLite counterpart over the C ABI (one jd_dec)."""
+
+    def __init__(self, net: Network, models: Models, start_beam=0.0, main_beam=0.0, end_beam=0.0,
+                 word_beam=0.0, max_hyps=0, block_size=5, device=0, max_streams=1,
+                 max_slots=0, max_paths=0, max_items=0):
+        L = lib()
+        self.net, self.models = net, models       # keep alive: the decoder does not own them
+        self.max_streams = int(max_streams)
+        self.h = C.c_void_p()
+        _check(L.jd_dec_create(C.byref(self.h), net.h, models.h, C.c_float(start_beam), C.c_float(main_beam),
+                               C.c_float(end_beam), C.c_float(word_beam), C.c_int32(max_hyps),
+                               C.c_int32(block_size), C.c_int32(device), C.c_int32(max_streams)))
+        if max_slots or max_paths or max_items:
+            _check(L.jd_dec_set_capacity(self.h, C.c_int64(max_slots), C.c_int64(max_paths), C.c_int64(max_items)))
+
+    # -- IDecoder protocol on one stream
+    def stream_init(self, s: int = 0):
+        _check(lib().jd_stream_init(self.h, C.c_int32(s)))
+
+    def stream_push(self, s: int, frames):
+        x = _f32(frames)
+        _check(lib().jd_stream_push(self.h, C.c_int32(s), _p(x, C.c_float), C.c_int32(x.shape[0])))
+
+    def stream_finish(self, s: int = 0) -> Hyp:
+        h = CHyp()
+        _check(lib().jd_stream_finish(self.h, C.c_int32(s), C.byref(h)))
+        return _hyp_from_c(h)
+
+    # -- DecoderBatchTest inner loop
+    def decode_batch(self, feats: Sequence[np.ndarray]) -> List[Hyp]:
+        n = len(feats)
+        xs = [_f32(f) for f in feats]
+        ptrs = (C.POINTER(C.c_float) * n)(*[_p(x, C.c_float) for x in xs])
+        nfr = _i32([x.shape[0] for x in xs])
+        hyps = (CHyp * n)()
+        rc = lib().jd_decode_batch(self.h, C.c_int32(n), ptrs, _p(nfr, C.c_int32), hyps)
+        _check(rc)
+        return [_hyp_from_c(hyps[i]) for i in range(n)]
+
+    def decode_batch_device(self, d_feats_ptr: int, offs, hip_stream: int = 0, raw: bool = False):
+        """Features already in HBM: d_feats_ptr = device address of [total_frames, D] floats."""
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        n = offs.shape[0] - 1
+        hyps = (CHyp * n)()
+        rc = lib().jd_decode_batch_device(self.h, C.c_int32(n), C.c_void_p(d_feats_ptr), _p(offs, C.c_int64),
+                                          C.c_void_p(hip_stream), hyps)
+        _check(rc)
+        if raw:
+            return hyps
+        return [_hyp_from_c(hyps[i]) for i in range(n)]
+
+    def last_timing(self) -> dict:
+        t = Timing()
+        _check(lib().jd_dec_last_timing(self.h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in Timing._fields_}
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.jd_dec_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,40 @@
+// jd_internal.h - shared between the host-side model/network preparation
+// (jd_host.cpp) and the HIP decoder (jd_device.hip).  Not part of the C ABI.
+#ifndef JD_INTERNAL_H
+#define JD_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "juicer_amd.h"
+
+#define JD_MAXN 8          // max HMM states (incl. entry/exit) the search kernel handles
+
+// 16-byte arc record: one coalesced load per visited arc (WFSTTransition,
+// WFSTNetwork.h:41-52, minus id/hook).
+struct JdArc { int32_t to; float w; int32_t in; int32_t out; };
+
+struct jd_net {
+    int32_t n_states = 0, init = 0, n_final = 0;
+    int64_t n_arcs = 0;
+    std::vector<int32_t> row_ptr;      // n_states+1 (CSR)
+    std::vector<JdArc> arcs;           // sorted by source state, file order within a state
+    std::vector<float> fin_w;          // per state; +inf when not final
+    int32_t max_in = 0;
+};
+
+struct jd_am {
+    int32_t D = 0, n_gmm = 0, max_mix = 0, n_hmm = 0, max_n = 0, n_tm = 0;
+    std::vector<int32_t> n_mix;
+    std::vector<float> det, mean, ivar;           // reference layout [g][m], [g][m][D]
+    std::vector<int32_t> hmm_n, hmm_gmm, hmm_tm;  // [h], [h][max_n], [h]
+    std::vector<float> hmm_tee;
+    std::vector<int32_t> tm_n;
+    std::vector<float> trP;                       // [tm][max_n][max_n]
+    std::vector<int16_t> se;                      // [tm][max_n][2]
+};
+
+int jd_fail(int code, const char *fmt, ...);      // sets jd_last_error(), returns code
+
+#endif

@@ -1,0 +1,281 @@
+"""Deterministic synthetic decoding problems (the build's own generators).
+
+The reference ships no data, so BASELINE.json's configs are synthesised:
+a C.L.G-shaped transducer in AT&T arc-list form, an HTK-style HMM/GMM set,
+and 39-dim feature streams sampled from the models along a random accepted
+word sequence (unmatched random features leave no final-state token alive at
+realistic beams - SURVEY.md Appendix C).
+
+Rules forced by the reference's behaviour (cited so the generators stay legal):
+  * arcs of one source state contiguous, first arc's source = initial state
+    (WFSTNetwork.cpp:455-456, 709-721);
+  * in-label i>0 selects HMM i-1 (WFSTDecoderLite.cpp:754), 0 = epsilon;
+  * file weights are -log probabilities, negated at load (WFSTNetwork.cpp:481);
+  * per-frame log-likelihoods must stay below the histogram's +200 ceiling
+    relative to the best score (Histogram.cpp:78-79).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+
+@dataclass
+class SynthAM:
+    """HTK-level acoustic model parameters (input of jd_am_create_htk)."""
+    D: int
+    n_gmm: int
+    max_mix: int
+    n_mix: np.ndarray        # int32 [n_gmm]
+    weight: np.ndarray       # float32 [n_gmm, max_mix]
+    mean: np.ndarray         # float32 [n_gmm, max_mix, D]
+    var: np.ndarray          # float32 [n_gmm, max_mix, D]
+    n_hmm: int
+    max_n: int
+    hmm_nstates: np.ndarray  # int32 [n_hmm]
+    hmm_gmm: np.ndarray      # int32 [n_hmm, max_n]  (-1 for entry/exit)
+    hmm_tm: np.ndarray       # int32 [n_hmm]
+    n_tm: int
+    tm_nstates: np.ndarray   # int32 [n_tm]
+    transp: np.ndarray       # float32 [n_tm, max_n, max_n]
+    sp_hmm: int = -1         # index of the tee "sp" model, -1 if none
+
+
+@dataclass
+class SynthNet:
+    """Arc list in FSM file order (input of jd_net_create_arcs)."""
+    n_states: int
+    src: np.ndarray          # int32 [n_arcs]
+    dst: np.ndarray          # int32
+    ilab: np.ndarray         # int32
+    olab: np.ndarray         # int32
+    w_file: np.ndarray       # float32 (-log prob, as written in an FSM file)
+    fstate: np.ndarray       # int32 [n_final]
+    fweight_file: np.ndarray  # float32
+    # generator bookkeeping used by sample_utterance()
+    n_words: int = 0
+    prons: List[np.ndarray] = field(default_factory=list)   # per word: 0-based hmm ids
+    succ: Optional[np.ndarray] = None                       # int32 [n_words+1, K] bigram successors
+    sp_hmm: int = -1
+
+    @property
+    def n_arcs(self) -> int:
+        return int(self.src.shape[0])
+
+
+def make_models(seed: int, n_gmm: int, n_hmm: int, n_mix: int, D: int = 39,
+                n_tm: int = 16, sep: float = 1.0, with_tee: bool = False,
+                with_skip: bool = True) -> SynthAM:
+    """Left-to-right 5-state (3 emitting) HMMs over a pool of tied states."""
+    rng = np.random.default_rng(seed)
+    max_n = 5
+    centre = rng.normal(0.0, sep, size=(n_gmm, 1, D))
+    mean = (centre + rng.normal(0.0, 0.5 * sep, size=(n_gmm, n_mix, D))).astype(np.float32)
+    var = rng.uniform(0.3, 3.0, size=(n_gmm, n_mix, D)).astype(np.float32)
+    wraw = rng.gamma(2.0, 1.0, size=(n_gmm, n_mix))
+    wraw = wraw / wraw.sum(axis=1, keepdims=True)
+    wraw = np.maximum(wraw, 1e-3)
+    weight = (wraw / wraw.sum(axis=1, keepdims=True)).astype(np.float32)
+    if n_mix == 1:
+        weight[:] = 1.0
+
+    n_tm_tot = n_tm + (1 if with_tee else 0)
+    transp = np.zeros((n_tm_tot, max_n, max_n), dtype=np.float32)
+    tm_nstates = np.full(n_tm_tot, 5, dtype=np.int32)
+    for t in range(n_tm):
+        p = rng.uniform(0.55, 0.85, size=3)
+        transp[t, 0, 1] = 1.0
+        for k, j in enumerate((1, 2, 3)):
+            transp[t, j, j] = p[k]
+            transp[t, j, j + 1] = 1.0 - p[k]
+        if with_skip and t % 4 == 3:
+            # a skip 1->3 so that some states have three predecessors
+            s = 0.25 * (1.0 - p[0])
+            transp[t, 1, 2] = np.float32(1.0 - p[0] - s)
+            transp[t, 1, 3] = np.float32(s)
+    hmm_nstates = np.full(n_hmm, 5, dtype=np.int32)
+    hmm_gmm = np.full((n_hmm, max_n), -1, dtype=np.int32)
+    # every tied state is used at least once, the rest at random
+    pool = np.concatenate([rng.permutation(n_gmm),
+                           rng.integers(0, n_gmm, size=max(0, 3 * n_hmm - n_gmm))])[:3 * n_hmm]
+    if pool.shape[0] < 3 * n_hmm:
+        pool = np.concatenate([pool, rng.integers(0, n_gmm, size=3 * n_hmm - pool.shape[0])])
+    pool = rng.permutation(pool)
+    hmm_gmm[:, 1:4] = pool.reshape(n_hmm, 3)
+    hmm_tm = rng.integers(0, n_tm, size=n_hmm).astype(np.int32)
+    sp = -1
+    if with_tee:
+        # a 3-state tee model "sp": entry -> emitting (0.6) or straight to exit (0.4)
+        t = n_tm
+        tm_nstates[t] = 3
+        transp[t, 0, 1] = 0.6
+        transp[t, 0, 2] = 0.4
+        transp[t, 1, 1] = 0.7
+        transp[t, 1, 2] = 0.3
+        sp = n_hmm - 1
+        hmm_nstates[sp] = 3
+        hmm_gmm[sp, :] = -1
+        hmm_gmm[sp, 1] = int(rng.integers(0, n_gmm))
+        hmm_tm[sp] = t
+    return SynthAM(D=D, n_gmm=n_gmm, max_mix=n_mix,
+                   n_mix=np.full(n_gmm, n_mix, dtype=np.int32),
+                   weight=weight, mean=mean, var=var, n_hmm=n_hmm, max_n=max_n,
+                   hmm_nstates=hmm_nstates, hmm_gmm=hmm_gmm, hmm_tm=hmm_tm,
+                   n_tm=n_tm_tot, tm_nstates=tm_nstates, transp=transp, sp_hmm=sp)
+
+
+def make_wfst(seed: int, am: SynthAM, n_words: int, n_succ: int,
+              pron_len=(2, 5), with_sp: bool = False) -> SynthNet:
+    """Bigram-shaped C.L.G: state 0 = <s> history (initial), states 1..V = word
+    histories (all final), state V+1 = unigram hub reached by back-off epsilon
+    arcs.  Every (history, successor word) pair owns an un-shared chain of phone
+    arcs; hub words start with an eps:word arc (word label on an epsilon input).
+    """
+    rng = np.random.default_rng(seed)
+    V, K = n_words, min(n_succ, n_words)
+    n_real_hmm = am.n_hmm - (1 if am.sp_hmm >= 0 else 0)
+    plen = rng.integers(pron_len[0], pron_len[1] + 1, size=V)
+    prons = [rng.integers(0, n_real_hmm, size=int(l)).astype(np.int32) for l in plen]
+    hub = V + 1
+    nxt = V + 2                       # next free chain state id
+    src, dst, il, ol, wf = [], [], [], [], []
+    use_sp = with_sp and am.sp_hmm >= 0
+
+    succ = np.zeros((V + 1, K), dtype=np.int32)
+    for h in range(V + 1):
+        succ[h] = rng.choice(V, size=K, replace=False)
+
+    def add_chain(s0: int, w: int, cost: float, label_first: bool, eps_word: bool):
+        nonlocal nxt
+        pr = prons[w]
+        cur = s0
+        if eps_word:
+            src.append(cur); dst.append(nxt); il.append(0); ol.append(w + 1); wf.append(cost)
+            cur = nxt; nxt += 1
+            cost = 0.0
+        L = len(pr)
+        for k in range(L):
+            last = (k == L - 1)
+            lab = 0
+            if not eps_word and ((label_first and k == 0) or (not label_first and last)):
+                lab = w + 1
+            if last and not use_sp:
+                to = 1 + w
+            else:
+                to = nxt; nxt += 1
+            src.append(cur); dst.append(to); il.append(int(pr[k]) + 1); ol.append(lab)
+            wf.append(cost if k == 0 else 0.0)
+            cur = to
+        if use_sp:
+            src.append(cur); dst.append(1 + w); il.append(am.sp_hmm + 1); ol.append(0); wf.append(0.0)
+
+    lm_cost = rng.uniform(0.5, 8.0, size=(V + 1, K))
+    label_first = rng.random(size=(V + 1, K)) < 0.5
+    for h in range(V + 1):
+        for k in range(K):
+            add_chain(h, int(succ[h, k]), float(lm_cost[h, k]), bool(label_first[h, k]), False)
+        src.append(h); dst.append(hub); il.append(0); ol.append(0); wf.append(float(rng.uniform(1.0, 4.0)))
+    uni = rng.uniform(4.0, 12.0, size=V)
+    for w in range(V):
+        add_chain(hub, w, float(uni[w]), True, True)
+
+    src = np.asarray(src, dtype=np.int32); dst = np.asarray(dst, dtype=np.int32)
+    il = np.asarray(il, dtype=np.int32); ol = np.asarray(ol, dtype=np.int32)
+    wf = np.asarray(wf, dtype=np.float32)
+    order = np.argsort(src, kind="stable")          # group by source; state 0 (initial) first
+    fstate = np.arange(1, V + 1, dtype=np.int32)
+    fweight = rng.uniform(0.0, 2.0, size=V).astype(np.float32)
+    return SynthNet(n_states=int(nxt), src=src[order], dst=dst[order], ilab=il[order],
+                    olab=ol[order], w_file=wf[order], fstate=fstate, fweight_file=fweight,
+                    n_words=V, prons=prons, succ=succ, sp_hmm=am.sp_hmm if use_sp else -1)
+
+
+def make_wfst_sized(seed: int, am: SynthAM, target_arcs: int, n_words: int,
+                    pron_len=(2, 5), with_sp: bool = False) -> SynthNet:
+    """Pick the bigram fan-out so that the graph has about target_arcs arcs."""
+    mean_len = 0.5 * (pron_len[0] + pron_len[1]) + (1.0 if with_sp else 0.0)
+    k = int(round((target_arcs - n_words * (mean_len + 2.0)) / ((n_words + 1) * mean_len)))
+    k = max(1, min(k, n_words))
+    return make_wfst(seed, am, n_words, k, pron_len=pron_len, with_sp=with_sp)
+
+
+def sample_utterance(seed: int, net: SynthNet, am: SynthAM, n_words: int,
+                     p_backoff: float = 0.2, noise: float = 1.0):
+    """Random accepted word sequence -> (features [T, D] float32, word labels)."""
+    rng = np.random.default_rng(seed)
+    words, gmm_seq = [], []
+    h = 0
+    for _ in range(n_words):
+        if rng.random() < p_backoff:
+            w = int(rng.integers(0, net.n_words))
+        else:
+            w = int(net.succ[h, rng.integers(0, net.succ.shape[1])])
+        words.append(w)
+        models = list(net.prons[w])
+        if net.sp_hmm >= 0:
+            models.append(net.sp_hmm)
+        for hm in models:
+            n = int(am.hmm_nstates[hm]); tm = am.transp[am.hmm_tm[hm]]
+            s = 0
+            while True:
+                p = tm[s, :n].astype(np.float64)
+                s2 = int(rng.choice(n, p=p / p.sum()))
+                if s2 == n - 1:
+                    break
+                gmm_seq.append(int(am.hmm_gmm[hm, s2]))
+                s = s2
+        h = 1 + w
+    g = np.asarray(gmm_seq, dtype=np.int64)
+    T = g.shape[0]
+    cw = np.cumsum(am.weight[g].astype(np.float64), axis=1)
+    u = rng.random(size=(T, 1)) * cw[:, -1:]
+    m = np.minimum((u > cw).sum(axis=1), am.max_mix - 1)
+    mu = am.mean[g, m]
+    sd = np.sqrt(am.var[g, m])
+    x = (mu + noise * sd * rng.normal(size=mu.shape)).astype(np.float32)
+    return x, np.asarray(words, dtype=np.int32) + 1
+
+
+# ------------------------------------------------------------------ named configs
+
+def config_toy(seed: int = 1):
+    """BASELINE.json configs[0]: ~16-state 3-word toy, 10 tied states, M=2, one
+    100-frame utterance (the look-ahead/plumbing case; includes the tee model)."""
+    am = make_models(seed, n_gmm=10, n_hmm=5, n_mix=2, n_tm=3, sep=1.0, with_tee=True)
+    net = make_wfst(seed + 100, am, n_words=3, n_succ=1, pron_len=(1, 2), with_sp=False)
+    # grow the utterance until it has at least 100 frames, then keep the words
+    for nw in range(4, 40):
+        x, words = sample_utterance(seed + 200, net, am, nw)
+        if x.shape[0] >= 100:
+            break
+    return am, net, [x], [words]
+
+
+def config_small(seed: int = 7, n_utts: int = 4, with_sp: bool = True, sep: float = 0.6,
+                 n_words: int = 60, n_succ: int = 6, n_gmm: int = 90, n_hmm: int = 41,
+                 n_mix: int = 4, utt_words=(6, 14)):
+    """~10k-arc regression case with the tee model between words."""
+    am = make_models(seed, n_gmm=n_gmm, n_hmm=n_hmm, n_mix=n_mix, n_tm=8, sep=sep, with_tee=with_sp)
+    net = make_wfst(seed + 100, am, n_words=n_words, n_succ=n_succ, with_sp=with_sp)
+    rng = np.random.default_rng(seed + 300)
+    feats, words = [], []
+    for u in range(n_utts):
+        x, w = sample_utterance(seed + 1000 + u, net, am, int(rng.integers(utt_words[0], utt_words[1] + 1)))
+        feats.append(x); words.append(w)
+    return am, net, feats, words
+
+
+def config_c2(seed: int = 0, n_utts: int = 64, target_arcs: int = 1_000_000, n_gmm: int = 3000,
+              n_hmm: int = 8000, n_mix: int = 16, n_words: int = 5000, sep: float = 0.35,
+              utt_words=(9, 28)):
+    """BASELINE.json configs[1]/[2]: ~1M-arc graph, 3k tied states x 16 mix."""
+    am = make_models(seed, n_gmm=n_gmm, n_hmm=n_hmm, n_mix=n_mix, n_tm=48, sep=sep)
+    net = make_wfst_sized(seed + 100, am, target_arcs, n_words)
+    rng = np.random.default_rng(seed + 300)
+    feats, words = [], []
+    for u in range(n_utts):
+        x, w = sample_utterance(seed + 1000 + u, net, am, int(rng.integers(utt_words[0], utt_words[1] + 1)))
+        feats.append(x); words.append(w)
+    return am, net, feats, words

@@ -1,0 +1,89 @@
+/*
+ * juicer_oracle.h - CPU ORACLE for the juicer_amd parity tests.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under juicer_amd/ or include/ may link,
+ * import or call this; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / reported CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (idiap/juicer) ships no tests, fixtures or
+ * golden vectors for this path, and its sources cannot be compiled in this
+ * image (they need the absent Torch3 and Tracter headers plus a bison/flex
+ * generated parser; writing stand-ins for those is not a reference build).
+ * This file is therefore a line-by-line *restatement* of the reference
+ * algorithm, each function citing the reference file:line it follows.
+ * Third-party constants it depends on (Torch3 >= 3.1, configure.ac:42, not in
+ * the tree): real = float, LOG_ZERO = -FLT_MAX, LOG_2_PI = 1.83787706640934548355.
+ */
+#ifndef JUICER_ORACLE_H
+#define JUICER_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jo_net jo_net;
+typedef struct jo_am  jo_am;
+typedef struct jo_dec jo_dec;
+
+typedef struct jo_stats {
+    int32_t n_frames;
+    int64_t tot_active_emit_hyps, tot_active_end_hyps, tot_active_models;
+    int64_t tot_proc_emit_hyps, tot_proc_end_hyps;
+    int64_t tot_arcs_visited, tot_paths, tot_insts_in, ties;
+} jo_stats;
+
+typedef struct jo_hyp {
+    int32_t n;                 /* -1: no surviving token (reference returns NULL) */
+    const int32_t *label, *time;
+    const float *score, *ac, *lm;
+    float tot_score, tot_ac, tot_lm;
+    jo_stats stats;
+} jo_hyp;
+
+int jo_net_create_arcs(jo_net **out, int64_t n_arcs, const int32_t *from, const int32_t *to,
+                       const int32_t *in, const int32_t *outl, const float *w_file,
+                       int32_t n_final, const int32_t *fstate, const float *fweight_file,
+                       float lm_scale, float ins_penalty);
+int jo_net_create_csr(jo_net **out, int32_t n_states, int32_t init_state,
+                      const int32_t *row_ptr, const int32_t *to, const float *w,
+                      const int32_t *in, const int32_t *outl,
+                      int32_t n_final, const int32_t *fstate, const float *fweight);
+int64_t jo_net_num_arcs(const jo_net *n);
+int32_t jo_net_num_states(const jo_net *n);
+int32_t jo_net_init_state(const jo_net *n);
+/* prepared arrays in file order (for loader parity tests) */
+int jo_net_get(const jo_net *n, int32_t *first, int32_t *cnt, int32_t *to, float *w,
+               int32_t *in, int32_t *outl, int32_t *final_ind, float *final_w);
+void jo_net_destroy(jo_net *n);
+
+int jo_am_create_htk(jo_am **out, int32_t D, int32_t n_gmm, int32_t max_mix,
+                     const int32_t *n_mix, const float *weight, const float *mean, const float *var,
+                     int32_t n_hmm, int32_t max_n, const int32_t *hmm_nstates,
+                     const int32_t *hmm_gmm, const int32_t *hmm_tm,
+                     int32_t n_tm, const int32_t *tm_nstates, const float *transp);
+int jo_am_get_flat(const jo_am *a, float *det, float *mean, float *ivar);
+int jo_am_get_trans(const jo_am *a, float *trP, int16_t *se, float *tee);
+/* HTKFlatModels::calcGMMOutput for every tied state of every frame, no cache */
+int jo_am_score_frames(const jo_am *a, const float *frames, int32_t n_frames, float *out);
+void jo_am_destroy(jo_am *a);
+
+int jo_dec_create(jo_dec **out, const jo_net *net, const jo_am *am,
+                  float start_beam, float main_beam, float end_beam, float word_beam,
+                  int32_t max_hyps, int32_t block_size);
+void jo_dec_destroy(jo_dec *d);
+int jo_init(jo_dec *d);
+/* rows[0] = frame `frame`, rows[1..n_avail-1] = look-ahead rows */
+int jo_process_frame(jo_dec *d, const float *const *rows, int32_t frame, int32_t n_avail);
+int jo_finish(jo_dec *d, jo_hyp *out);
+/* DecoderSingleTest::decodeUtterance loop (DecoderSingleTest.cpp:259-298);
+ * *cpu_seconds receives clock()-based CPU time like decodeTime (:299-300). */
+int jo_decode_utt(jo_dec *d, const float *feats, int32_t n_frames, jo_hyp *out, double *cpu_seconds);
+/* per-frame trace for debugging parity: bestEmitScore after each frame */
+int jo_set_trace(jo_dec *d, float *best_emit_per_frame, int32_t cap);
+
+const char *jo_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,200 @@
+"""ctypes wrapper of the CPU oracle (oracle/juicer_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg - never by juicer_amd/.  PARITY UNPINNED (see the
+header of juicer_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libjuicer_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "juicer_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB_PATH
+
+
+class _Stats(C.Structure):
+    _fields_ = [("n_frames", C.c_int32),
+                ("tot_active_emit_hyps", C.c_int64), ("tot_active_end_hyps", C.c_int64),
+                ("tot_active_models", C.c_int64), ("tot_proc_emit_hyps", C.c_int64),
+                ("tot_proc_end_hyps", C.c_int64), ("tot_arcs_visited", C.c_int64),
+                ("tot_paths", C.c_int64), ("tot_insts_in", C.c_int64), ("ties", C.c_int64)]
+
+
+class _Hyp(C.Structure):
+    _fields_ = [("n", C.c_int32),
+                ("label", C.POINTER(C.c_int32)), ("time", C.POINTER(C.c_int32)),
+                ("score", C.POINTER(C.c_float)), ("ac", C.POINTER(C.c_float)), ("lm", C.POINTER(C.c_float)),
+                ("tot_score", C.c_float), ("tot_ac", C.c_float), ("tot_lm", C.c_float),
+                ("stats", _Stats)]
+
+
+@dataclass
+class OracleHyp:
+    n: int                      # -1 = no surviving token
+    label: np.ndarray           # chain order: newest first
+    time: np.ndarray
+    score: np.ndarray
+    ac: np.ndarray
+    lm: np.ndarray
+    tot_score: float
+    tot_ac: float
+    tot_lm: float
+    stats: dict
+    cpu_seconds: float = 0.0
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.jo_last_error.restype = C.c_char_p
+        L.jo_net_num_arcs.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("oracle error %d: %s" % (rc, lib().jo_last_error().decode()))
+
+
+class OracleNet:
+    def __init__(self, net, lm_scale: float = 1.0, ins_penalty: float = 0.0):
+        L = lib()
+        self.h = C.c_void_p()
+        src, dst, il, ol = _i32(net.src), _i32(net.dst), _i32(net.ilab), _i32(net.olab)
+        wf, fs, fw = _f32(net.w_file), _i32(net.fstate), _f32(net.fweight_file)
+        _check(L.jo_net_create_arcs(C.byref(self.h), C.c_int64(src.shape[0]), _p(src, C.c_int32),
+                                    _p(dst, C.c_int32), _p(il, C.c_int32), _p(ol, C.c_int32),
+                                    _p(wf, C.c_float), C.c_int32(fs.shape[0]), _p(fs, C.c_int32),
+                                    _p(fw, C.c_float), C.c_float(lm_scale), C.c_float(ins_penalty)))
+        self.n_arcs = int(L.jo_net_num_arcs(self.h))
+        self.n_states = int(L.jo_net_num_states(self.h))
+
+    def arrays(self):
+        L = lib()
+        first = np.zeros(self.n_states, np.int32); cnt = np.zeros(self.n_states, np.int32)
+        to = np.zeros(self.n_arcs, np.int32); w = np.zeros(self.n_arcs, np.float32)
+        il = np.zeros(self.n_arcs, np.int32); ol = np.zeros(self.n_arcs, np.int32)
+        fi = np.zeros(self.n_states, np.int32)
+        nfin = int((np.unique(fi).shape[0]))  # placeholder, final_w sized generously below
+        fw = np.zeros(self.n_states, np.float32)
+        L.jo_net_get(self.h, _p(first, C.c_int32), _p(cnt, C.c_int32), _p(to, C.c_int32), _p(w, C.c_float),
+                     _p(il, C.c_int32), _p(ol, C.c_int32), _p(fi, C.c_int32), None)
+        del nfin, fw
+        return dict(first=first, cnt=cnt, to=to, w=w, ilab=il, olab=ol, final_ind=fi)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.jo_net_destroy(self.h)
+            self.h = None
+
+
+class OracleAM:
+    def __init__(self, am):
+        L = lib()
+        self.h = C.c_void_p()
+        self.D, self.n_gmm, self.max_mix = am.D, am.n_gmm, am.max_mix
+        self.n_hmm, self.max_n, self.n_tm = am.n_hmm, am.max_n, am.n_tm
+        nm, wt, mu, var = _i32(am.n_mix), _f32(am.weight), _f32(am.mean), _f32(am.var)
+        hn, hg, ht = _i32(am.hmm_nstates), _i32(am.hmm_gmm), _i32(am.hmm_tm)
+        tn, tp = _i32(am.tm_nstates), _f32(am.transp)
+        _check(L.jo_am_create_htk(C.byref(self.h), C.c_int32(am.D), C.c_int32(am.n_gmm), C.c_int32(am.max_mix),
+                                  _p(nm, C.c_int32), _p(wt, C.c_float), _p(mu, C.c_float), _p(var, C.c_float),
+                                  C.c_int32(am.n_hmm), C.c_int32(am.max_n), _p(hn, C.c_int32),
+                                  _p(hg, C.c_int32), _p(ht, C.c_int32), C.c_int32(am.n_tm),
+                                  _p(tn, C.c_int32), _p(tp, C.c_float)))
+
+    def flat(self):
+        det = np.zeros((self.n_gmm, self.max_mix), np.float32)
+        mean = np.zeros((self.n_gmm, self.max_mix, self.D), np.float32)
+        ivar = np.zeros_like(mean)
+        lib().jo_am_get_flat(self.h, _p(det, C.c_float), _p(mean, C.c_float), _p(ivar, C.c_float))
+        return det, mean, ivar
+
+    def trans(self):
+        trP = np.zeros((self.n_tm, self.max_n, self.max_n), np.float32)
+        se = np.zeros((self.n_tm, self.max_n, 2), np.int16)
+        tee = np.zeros(self.n_hmm, np.float32)
+        lib().jo_am_get_trans(self.h, _p(trP, C.c_float), _p(se, C.c_int16), _p(tee, C.c_float))
+        return trP, se, tee
+
+    def score_frames(self, frames):
+        x = _f32(frames)
+        out = np.zeros((x.shape[0], self.n_gmm), np.float32)
+        lib().jo_am_score_frames(self.h, _p(x, C.c_float), C.c_int32(x.shape[0]), _p(out, C.c_float))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.jo_am_destroy(self.h)
+            self.h = None
+
+
+class OracleDecoder:
+    """Restated WFSTDecoderLite; decode() follows DecoderSingleTest's frame loop."""
+
+    def __init__(self, net: OracleNet, am: OracleAM, start_beam=0.0, main_beam=0.0, end_beam=0.0,
+                 word_beam=0.0, max_hyps=0, block_size=5):
+        L = lib()
+        self.net, self.am = net, am
+        self.h = C.c_void_p()
+        _check(L.jo_dec_create(C.byref(self.h), net.h, am.h, C.c_float(start_beam), C.c_float(main_beam),
+                               C.c_float(end_beam), C.c_float(word_beam), C.c_int32(max_hyps),
+                               C.c_int32(block_size)))
+
+    def decode(self, feats, trace: Optional[np.ndarray] = None) -> OracleHyp:
+        L = lib()
+        x = _f32(feats)
+        if trace is not None:
+            L.jo_set_trace(self.h, _p(trace, C.c_float), C.c_int32(trace.shape[0]))
+        else:
+            L.jo_set_trace(self.h, None, C.c_int32(0))
+        hyp = _Hyp()
+        secs = C.c_double(0.0)
+        _check(L.jo_decode_utt(self.h, _p(x, C.c_float), C.c_int32(x.shape[0]), C.byref(hyp), C.byref(secs)))
+        n = hyp.n
+        k = max(n, 0)
+
+        def arr(ptr, dt):
+            return np.array([ptr[i] for i in range(k)], dtype=dt)
+        st = {f: getattr(hyp.stats, f) for f, _ in _Stats._fields_}
+        return OracleHyp(n=n, label=arr(hyp.label, np.int32), time=arr(hyp.time, np.int32),
+                         score=arr(hyp.score, np.float32), ac=arr(hyp.ac, np.float32),
+                         lm=arr(hyp.lm, np.float32), tot_score=float(hyp.tot_score),
+                         tot_ac=float(hyp.tot_ac), tot_lm=float(hyp.tot_lm), stats=st,
+                         cpu_seconds=float(secs.value))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.jo_dec_destroy(self.h)
+            self.h = None

@@ -1,0 +1,41 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+
+# north_star: labels/times bit-exact, path/acoustic scores within 1e-4 relative
+SCORE_RTOL = 1e-4
+
+STAT_KEYS = ["n_frames", "tot_active_emit_hyps", "tot_active_end_hyps", "tot_active_models",
+             "tot_proc_emit_hyps", "tot_proc_end_hyps", "tot_arcs_visited", "tot_paths", "tot_insts_in"]
+
+
+def rel_close(a, b, rtol=SCORE_RTOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b)))
+
+
+def assert_hyp_matches(gpu, ora, what="", check_stats=True):
+    """gpu: juicer_amd.capi.Hyp, ora: oracle.OracleHyp (or anything with the same fields)."""
+    assert gpu.n == ora.n, "%s: n %d vs oracle %d" % (what, gpu.n, ora.n)
+    if ora.n > 0:
+        assert np.array_equal(gpu.label, ora.label), "%s: labels differ\n%s\n%s" % (what, gpu.label, ora.label)
+        assert np.array_equal(gpu.time, ora.time), "%s: times differ\n%s\n%s" % (what, gpu.time, ora.time)
+        for f in ("score", "ac", "lm"):
+            assert rel_close(getattr(gpu, f), getattr(ora, f)), "%s: %s differ" % (what, f)
+        for f in ("tot_score", "tot_ac", "tot_lm"):
+            assert rel_close(getattr(gpu, f), getattr(ora, f)), "%s: %s differ" % (what, f)
+    if check_stats:
+        for k in STAT_KEYS:
+            assert gpu.stats[k] == ora.stats[k], "%s: stat %s %d vs oracle %d" % (what, k, gpu.stats[k], ora.stats[k])
+
+
+def bit_exact(gpu, ora):
+    if gpu.n != ora.n:
+        return False
+    if ora.n <= 0:
+        return True
+    ok = np.array_equal(gpu.label, ora.label) and np.array_equal(gpu.time, ora.time)
+    for f in ("score", "ac", "lm"):
+        ok = ok and np.array_equal(np.asarray(getattr(gpu, f), np.float32).view(np.uint32),
+                                   np.asarray(getattr(ora, f), np.float32).view(np.uint32))
+    return bool(ok)
