@@ -194,13 +194,32 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
     }
 }
 
-// ---------------------------------------------------------------- search kernel
+// --------------------------------------------------------------- search kernels
+//
+// Lock-step frontier design.  All utterance streams of a batch advance one
+// frame per "step"; each phase of WFSTDecoderLite::processFrame is ONE kernel
+// whose work items are flattened over every stream (so the whole chip works on
+// every phase, and kernel boundaries are the phase barriers):
+//
+//   k_boundary   per stream: epilogue of frame f-1 (free list, bestFinal, stats)
+//                + thresholds / histogram threshold of frame f         (:311-339)
+//   k_phase_a    HMM-internal propagation over all active arc instances
+//                (GS lanes per instance), ballot+scan compaction         (:376-484, :899-935)
+//   k_expand<r>  frontier expansion rounds 0 and 1 over the CSR arc table,
+//                64-bit atomic-max recombination per arc                 (:491-605, :937-982)
+//   k_expand_tail  remaining epsilon/tee closure rounds (rare), one block per stream
+//   k_resolve    winners become entry tokens; new instances attached     (:560-582, :751-774)
+
+#define TEE_FLAG 0x40000000          // bit 30 of the device arc's in-label: the arc's HMM is a tee model
+#define KT 256                       // threads per block of every search kernel
+#define EG 16                        // lanes cooperating on one frontier item
+#define MAX_B 1024                   // max concurrent streams
 
 struct DecConst {
     // network (CSR in HBM)
     const int *row_ptr; const JdArc *arcs; const float *fin_w; int init_state;
     // models
-    int G, max_n;
+    int G, max_n, n_tm;
     const int *hmm_n, *hmm_tm, *hmm_gmm; const float *hmm_tee; const float *trP; const int *se32;
     // pruning (WFSTDecoderLite ctor, WFSTDecoderLite.cpp:38-82)
     float start_win, emit_win, end_win, word_win;
@@ -211,26 +230,58 @@ struct DecConst {
 
 enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_INSTS, ST_N };
 
-struct StreamDev {
-    // persistent scalars
+// Everything phase A needs to know about an active arc instance (NetInst,
+// WFSTDecoderLite.h:66-75) in one 48-byte record: one hop from the active list.
+struct __align__(16) SlotMeta {
+    int arc, hmm, n_tm, out;          // n_tm = nStates | transMat << 8
+    int to, g0, g1, g2;               // g*: tied-state ids of emitting states 1..6
+    int g3, g4, g5, pad;
+};
+
+// hot per-stream scalars.  Line 0 is read-mostly while the frame kernels run (written by
+// k_boundary); every atomically updated counter sits on its own 128-byte line so that the
+// L2 never serialises unrelated atomics (or readers of line 0) behind each other.
+#define PK_SHIFT1 21
+#define PK_SHIFT2 42
+#define PK_MASK 0x1fffffULL
+struct __align__(128) StreamCtl {
+    // ---- line 0: persistent / per-frame constants
     int par;            // token-half parity: tokens of slot s live at tok[(s*2+par)*max_n ..]
     int lst;            // which active list is current
     int n_act;          // entries in the current active list
     int hw;             // slot high-water mark
     int n_free;         // entries on the free-slot stack
-    int n_paths;
     int frame;          // next frame to process
-    int error;
-    int needs_init;
-    int hist_count_unused;
-    float best_emit;    // bestEmitScore left by the previous frame
-    float pad0;
-    Tok best_final;     // bestFinalToken of the last processed frame
+    int T;              // frames available
+    int error, needs_init, active, started;
+    float best_emit;    // bestEmitScore left by the previous frame (:321)
+    float normalise, emitTh, startTh;
+    int pad0[17];
+    // ---- one line per atomic counter
+    __align__(128) unsigned long long pkA;   // phase A: nB | cnt0 << 21 | ndead << 42
+    __align__(128) unsigned best;            // ordered-uint bestEmitScore of this frame
+    __align__(128) int cnt1;                 // items produced by frontier round 0
+    __align__(128) int cnt2;                 // items produced by frontier round 1
+    __align__(128) int cnt_tail;             // items produced by the tail rounds
+    __align__(128) int n_touched;
+    __align__(128) int n_alloc;              // instances attached this frame (= new active entries)
+    __align__(128) int n_paths;
+    __align__(128) unsigned long long final_key;
+    __align__(128) int fr[ST_N];             // per-frame work counters (flushed per block run)
+    // ---- cold: touched by k_boundary / finish only
+    __align__(128) Tok best_final;           // bestFinalToken of the last processed frame
     long long st[ST_N];
-    // arenas
-    Tok *tok; int *slot_arc; int *slot_hmm; int *act[2]; int *free_stk; int *waste;
-    unsigned long long *ekey; int *map;
-    Tok *item_tok; int *item_arc; Tok *cand_tok; int *cand_arc;
+};
+__device__ __forceinline__ int pk_nB(unsigned long long v) { return (int)(v & PK_MASK); }
+__device__ __forceinline__ int pk_cnt0(unsigned long long v) { return (int)((v >> PK_SHIFT1) & PK_MASK); }
+__device__ __forceinline__ int pk_ndead(unsigned long long v) { return (int)((v >> PK_SHIFT2) & PK_MASK); }
+
+struct StreamDev {      // per-stream arenas (cold)
+    Tok *tok; SlotMeta *meta; int *act[2]; int *free_stk;
+    unsigned long long *ekey;         // per ARC: best entry-token candidate of this frame (0 = none)
+    int *map;                         // per ARC: instance slot or -1 (WFSTTransition::hook)
+    int *touched;                     // arcs whose ekey became non-zero this frame
+    Tok *item_tok; int4 *item_info;   // frontier items: token + {arc, outLabel, toState, -}
     PathRec *paths; int *hist;
     // result of jd_finish_kernel
     int res_n; int *res_label; int *res_time; float *res_score, *res_ac, *res_lm; int res_cap;
@@ -238,7 +289,7 @@ struct StreamDev {
 
 __device__ __forceinline__ Tok null_tok() { Tok t; t.score = LZ; t.ac = LZ; t.lm = LZ; t.path = -1; return t; }
 
-// exclusive block scan of a small per-thread count (sum over block < 2^31)
+// exclusive block scan (KT threads) of a per-thread count
 __device__ __forceinline__ int block_excl_scan(int v, int *sh_w, int &total)
 {
     const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -261,495 +312,705 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh_w, int &total)
     return base + x - v;
 }
 
-struct FrameShared {
-    int wsum[32];
-    unsigned long long wsum3[NT / 64];
-    unsigned best;                      // ordered-uint bestEmitScore of this frame
-    int n_items, n_paths, n_alloc, n_waste, n_newact, err, new_live;
-    unsigned long long final_key;
-    float emit_th;
-    int hist[HIST_MAX_BINS];
-};
-
-// Frontier expansion to epsilon/tee closure + entry-token resolve.
-// propagateToken (WFSTDecoderLite.cpp:491-605) for every item in item[0, n0):
-// an item is a token that has just traversed arc item_arc (or -1 = the NULL
-// transition of recognitionStart, :226).
-__device__ void expand_and_resolve(const DecConst &C, StreamDev &S, FrameShared &F, char *sh_raw, int frame,
-                                   float endTh, float wordTh, int par_next, int *act_next, int nB, int n0,
-                                   int nfree0, int hw0, int *cnt)
+// wave-aggregated append: returns this lane's index (or -1 when !want)
+__device__ __forceinline__ int wave_append(bool want, int *counter)
 {
-    const int tid = threadIdx.x, lane = lane_id();
-    const int MN = C.max_n;
-    Tok *sh_itok = (Tok *)sh_raw;                     // [NT]
-    int *sh_off = (int *)(sh_raw + NT * sizeof(Tok)); // [NT+1]
-    int *sh_rs = sh_off + NT + 8;                     // [NT]
-    const float INF = __builtin_inff();
-
-    int r0 = 0, r1 = n0;
-    while (r1 > r0) {
-        for (int cb = r0; cb < r1; cb += NT) {
-            // ---- P1: arrive at the arc: word boundary (:497-509), final state (:513-520)
-            const int i = cb + tid;
-            int deg = 0, rs = 0;
-            Tok t = null_tok();
-            if (i < r1) {
-                t = S.item_tok[i];
-                const int a = S.item_arc[i];
-                int state = C.init_state;
-                if (a >= 0) {
-                    const JdArc A = C.arcs[a];
-                    if (A.out != 0) {
-                        int p = atomicAdd(&F.n_paths, 1);
-                        if (p < C.cap_paths) {
-                            PathRec pr;
-                            pr.prev = t.path; pr.frame = frame; pr.label = A.out; pr.pad0 = 0;
-                            pr.score = t.score; pr.ac = t.ac; pr.lm = t.lm; pr.pad1 = 0.0f;
-                            S.paths[p] = pr;
-                            t.path = p;
-                            S.item_tok[i].path = p;
-                            cnt[ST_PATHS]++;
-                        } else F.err = JD_ENOMEM;
-                    }
-                    const float fw = C.fin_w[A.to];
-                    if (fw < INF) {
-                        const float c = t.score + fw;
-                        if (c > LZ) atomicMax(&F.final_key, ((unsigned long long)f2o(c) << 32) | (unsigned)i);
-                    }
-                    state = A.to;
-                }
-                rs = C.row_ptr[state];
-                deg = C.row_ptr[state + 1] - rs;
-            }
-            sh_itok[tid] = t;
-            sh_rs[tid] = rs;
-            int total;
-            const int off = block_excl_scan(deg, F.wsum, total);
-            sh_off[tid] = off;
-            if (tid == 0) sh_off[NT] = total;
-            __syncthreads();
-            // ---- P2: one (item, out-arc) pair per thread, load balanced over the flattened range
-            for (int v0 = 0; v0 < total; v0 += NT) {
-                const int v = v0 + tid;
-                const bool act = v < total;
-                bool mk = false;
-                Tok u = null_tok();
-                int ub = -1;
-                if (act) {
-                    int lo = 0, hi = NT;
-                    while (hi - lo > 1) {
-                        int mid = (lo + hi) >> 1;
-                        if (sh_off[mid] <= v) lo = mid; else hi = mid;
-                    }
-                    const int j = lo;
-                    const int b = sh_rs[j] + (v - sh_off[j]);
-                    const Tok tj = sh_itok[j];
-                    const int ii = cb + j;
-                    const JdArc B = C.arcs[b];
-                    cnt[ST_ARCS]++;
-                    if (B.in == 0) {                                   // :533-540 epsilon input
-                        u = tj;
-                        u.score = tj.score + B.w;
-                        u.lm = tj.lm + B.w;
-                        mk = u.score > endTh;
-                        ub = b;
-                    } else {                                           // :544-582 entry-token recombination
-                        const float ns = tj.score + B.w;
-                        const int hm = B.in - 1;
-                        int slot = __hip_atomic_load(&S.map[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (slot < 0) {
-                            const int k = atomicAdd(&F.n_alloc, 1);
-                            const int ns_ = (k < nfree0) ? S.free_stk[nfree0 - 1 - k] : hw0 + (k - nfree0);
-                            if (ns_ >= C.cap_slots) {
-                                F.err = JD_ENOMEM;
-                            } else {
-                                const int old = atomicCAS(&S.map[b], -1, ns_);
-                                if (old == -1) {                       // attachNetInst :751-774
-                                    slot = ns_;
-                                    S.slot_arc[slot] = b;
-                                    S.slot_hmm[slot] = hm;
-                                    const int n = C.hmm_n[hm];
-                                    Tok *tp = S.tok + ((size_t)slot * 2 + par_next) * MN;
-                                    for (int q = 0; q < n; ++q) tp[q] = null_tok();
-                                    const int pos = atomicAdd(&F.n_newact, 1);
-                                    act_next[nB + pos] = slot;
-                                } else {
-                                    slot = old;
-                                    const int wq = atomicAdd(&F.n_waste, 1);
-                                    S.waste[wq] = ns_;
-                                }
-                            }
-                        }
-                        if (slot >= 0)
-                            atomicMax(&S.ekey[slot], ((unsigned long long)f2o(ns) << 32) | (unsigned)ii);
-                        const float tee = C.hmm_tee[hm];
-                        if (tee > LZ) {                                // :584-600 tee model
-                            const float ns2 = ns + tee;
-                            u.score = ns2;
-                            u.ac = tj.ac + tee;
-                            u.lm = tj.lm + B.w;
-                            u.path = tj.path;
-                            mk = ns2 > ((B.out != 0) ? wordTh : endTh);
-                            ub = b;
-                        }
-                    }
-                }
-                const unsigned long long bal = __ballot(mk);
-                if (bal) {
-                    int base = 0;
-                    const int first = __ffsll((long long)bal) - 1;
-                    if (lane == first) base = atomicAdd(&F.n_items, __popcll(bal));
-                    base = __shfl(base, first);
-                    if (mk) {
-                        const int idx = base + rank_in(bal);
-                        if (idx < C.cap_items) { S.item_tok[idx] = u; S.item_arc[idx] = ub; }
-                        else F.err = JD_ENOMEM;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        r0 = r1;
-        r1 = F.n_items < C.cap_items ? F.n_items : C.cap_items;
-        __syncthreads();
-    }
-
-    // ---- resolve: winning candidate of every touched instance becomes its entry token
-    const int n_act = nB + F.n_newact;
-    for (int q = tid; q < n_act; q += NT) {
-        const int slot = act_next[q];
-        const unsigned long long key = atomicExch(&S.ekey[slot], 0ULL);
-        if (key != 0ULL) {
-            const float sc = o2f((unsigned)(key >> 32));
-            if (sc > LZ) {
-                const int ii = (int)(unsigned)(key & 0xffffffffULL);
-                const Tok it = S.item_tok[ii];
-                const JdArc B = C.arcs[S.slot_arc[slot]];
-                Tok e;
-                e.score = sc; e.ac = it.ac; e.lm = it.lm + B.w; e.path = it.path;
-                S.tok[((size_t)slot * 2 + par_next) * MN] = e;
-                atomicMax(&F.best, f2o(sc));                           // :572-573
-                if (q >= nB) atomicAdd(&F.new_live, 1);
-            }
-        }
-    }
-    __syncthreads();
+    const unsigned long long bal = __ballot(want);
+    if (!bal) return -1;
+    const int first = __ffsll((long long)bal) - 1;
+    int base = 0;
+    if (lane_id() == first) base = atomicAdd(counter, __popcll(bal));
+    base = __shfl(base, first);
+    return want ? base + rank_in(bal) : -1;
 }
 
-__global__ __launch_bounds__(NT) void jd_search_kernel(DecConst C, StreamDev *streams, int s0,
-                                                       const int *__restrict__ Tarr,
-                                                       const float *__restrict__ ll, long long ll_stride,
-                                                       int f0, int Fc)
+__device__ __forceinline__ int wave_sum(int v)
 {
-    __shared__ __align__(16) char sh_raw[NT * JD_MAXN * 4];            // 32 KB, phase-aliased
-    __shared__ FrameShared F;
-    __shared__ long long sh_stats[ST_N];
-    StreamDev &S = streams[s0 + blockIdx.x];
-    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const int MN = C.max_n;
-    const int T = Tarr[s0 + blockIdx.x];
-    int cnt[ST_N];
 #pragma unroll
-    for (int k = 0; k < ST_N; ++k) cnt[k] = 0;
-    if (tid < ST_N) sh_stats[tid] = 0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
-    // persistent scalars (uniform registers)
-    int par = S.par, lst = S.lst, n_act = S.n_act, hw = S.hw, n_free = S.n_free;
-    int frame = S.frame;
-    float best_emit = S.best_emit;
-    Tok best_final = S.best_final;
+// Work-unit map: every kernel flattens "units" (fixed-size groups of work items)
+// over the streams.  sh_pre[s] = units of streams < s.  Returns total units.
+template <typename F>
+__device__ int build_unit_map(int B, int *sh_pre, int *sh_w, F units_of)
+{
+    const int E = (B + KT - 1) / KT;
+    int loc[(MAX_B + KT - 1) / KT];
+    int sum = 0;
+#pragma unroll
+    for (int e = 0; e < (MAX_B + KT - 1) / KT; ++e) {
+        const int s = threadIdx.x * E + e;
+        loc[e] = (e < E && s < B) ? units_of(s) : 0;
+        sum += loc[e];
+    }
+    int total;
+    int pre = block_excl_scan(sum, sh_w, total);
+#pragma unroll
+    for (int e = 0; e < (MAX_B + KT - 1) / KT; ++e) {
+        const int s = threadIdx.x * E + e;
+        if (e < E && s < B) { sh_pre[s] = pre; pre += loc[e]; }
+    }
+    if (threadIdx.x == 0) sh_pre[B] = total;
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ int find_stream(const int *sh_pre, int B, int u)
+{
+    int lo = 0, hi = B;                 // sh_pre[lo] <= u < sh_pre[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sh_pre[mid] <= u) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- per-stream frame boundary: epilogue of the frame just processed + start of the next
+// mode 0: normal step.  mode 1: recognitionStart (:139-228) part 1 (before the start-token
+// expansion).  mode 2: recognitionStart part 2 (after it).
+__global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int mode)
+{
+    const int s = s0 + blockIdx.x, lane = threadIdx.x;
+    StreamCtl &c = ctl[s];
+    StreamDev &S = streams[s];
+    __shared__ int sh_hist[HIST_MAX_BINS];
     const bool use_hist = C.max_hyps > 0;
 
-    if (tid == 0) { F.err = 0; F.n_paths = S.n_paths; }
-    for (int b = tid; b < C.hist_nbins; b += NT) F.hist[b] = use_hist ? S.hist[b] : 0;
-    __syncthreads();
-
-    // ------------------------------------------------ recognitionStart (:139-228)
-    if (S.needs_init) {
-        int *actc = S.act[lst];
-        for (int q = tid; q < n_act; q += NT) S.map[S.slot_arc[actc[q]]] = -1;
-        for (int b = tid; b < C.hist_nbins; b += NT) F.hist[b] = 0;
-        if (tid == 0) {
-            F.n_paths = 0; F.best = f2o(LZ); F.n_items = 1; F.n_alloc = 0; F.n_waste = 0; F.n_newact = 0;
-            F.new_live = 0; F.final_key = 0ULL;
-            Tok z; z.score = 0.0f; z.ac = 0.0f; z.lm = 0.0f; z.path = -1;
-            S.item_tok[0] = z; S.item_arc[0] = -1;
+    if (mode == 1) {
+        if (!c.needs_init) return;
+        // drop whatever the previous utterance left behind
+        const int *actc = S.act[c.lst];
+        for (int q = lane; q < c.n_act; q += 64) S.map[S.meta[actc[q]].arc] = -1;
+        if (use_hist) for (int b = lane; b < C.hist_nbins; b += 64) S.hist[b] = 0;
+        __syncthreads();
+        if (lane == 0) {
+            c.n_act = 0; c.hw = 0; c.n_free = 0; c.n_paths = 0; c.frame = 0; c.error = 0;
+            c.best_emit = LZ; c.normalise = 0.0f; c.emitTh = LZ; c.startTh = LZ;
+            c.best = f2o(LZ); c.pkA = 1ULL << PK_SHIFT1;                         // cnt0 = 1: the start token
+            c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
+            c.n_alloc = 0; c.n_touched = 0; c.final_key = 0ULL;
+            for (int k = 0; k < ST_N; ++k) { c.fr[k] = 0; c.st[k] = 0; }
+            c.best_final = null_tok();
+            Tok z; z.score = 0.0f; z.ac = 0.0f; z.lm = 0.0f; z.path = -1;       // :221-226
+            S.item_tok[0] = z; S.item_info[0] = make_int4(-1, 0, 0, 0);
+            c.active = 2;                                                        // 2 = initialising
         }
-        __syncthreads();
-        n_act = 0; hw = 0; n_free = 0; frame = 0;
-        expand_and_resolve(C, S, F, sh_raw, 0, LZ, LZ, par ^ 1, S.act[lst ^ 1], 0, 1, 0, 0, cnt);
-        n_act = F.n_newact;
-        hw = F.n_alloc;
-        // wasted slots go straight to the free stack
-        for (int q = tid; q < F.n_waste; q += NT) S.free_stk[q] = S.waste[q];
-        n_free = F.n_waste;
-        best_emit = o2f(F.best);
-        best_final = null_tok();
-        par ^= 1; lst ^= 1;
-        __syncthreads();
+        return;
+    }
+    if (mode == 2) {
+        if (c.active != 2) return;
+        if (lane == 0) {
+            c.n_act = c.n_alloc; c.hw = c.n_alloc;
+            c.best_emit = o2f(c.best);
+            c.par ^= 1; c.lst ^= 1;
+            for (int k = 0; k < ST_N; ++k) { c.st[k] += c.fr[k]; c.fr[k] = 0; }
+            c.st[ST_MODELS] = 0;
+            c.needs_init = 0; c.active = 0;
+            c.best_final = null_tok();
+        }
+        return;
     }
 
-    const int fend = (f0 + Fc < T) ? f0 + Fc : T;
-    for (; frame < fend && F.err == 0; ++frame) {
-        const float *llrow = ll + (size_t)blockIdx.x * ll_stride + (size_t)(frame - f0) * C.G;
-        int *act_cur = S.act[lst], *act_next = S.act[lst ^ 1];
-        // ---- thresholds (:318-339)
-        const float normalise = (best_emit > LZ) ? best_emit : 0.0f;
-        if (use_hist) {
-            if (wid == 0) {                                            // Histogram::calcThresh, Histogram.cpp:134-158
-                const int nb = C.hist_nbins, K = (nb + 63) >> 6;
-                const int hi = nb - 1 - lane * K;
-                int sum = 0;
-                for (int k = 0; k < K; ++k) { int b = hi - k; if (b >= 0) sum += F.hist[b]; }
-                int inc = sum;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(inc, o); if (lane >= o) inc += y; }
-                const int total = __shfl(inc, 63);
-                float th;
-                if (total <= C.max_hyps) th = (float)C.hist_min - 0.5f;
-                else {
-                    const unsigned long long m = __ballot(inc >= C.max_hyps);
-                    const int L = __ffsll((long long)m) - 1;
-                    int res = 0;
-                    if (lane == L) {
-                        int acc = inc - sum;
-                        for (int k = 0; k < K; ++k) {
-                            int b = hi - k;
-                            if (b < 0) break;
-                            acc += F.hist[b];
-                            res = b;
-                            if (acc >= C.max_hyps) break;
-                        }
-                    }
-                    res = __shfl(res, L);
-                    th = (float)(res + C.hist_min) - 0.5f;
-                }
-                th -= normalise;                                        // :325
-                if (C.emit_win > 0.0f && th < -C.emit_win) th = -C.emit_win;   // :326-327
-                if (lane == 0) F.emit_th = th;
-            }
-            __syncthreads();
-        }
-        const float emitTh = use_hist ? F.emit_th : (C.emit_win > 0.0f ? -C.emit_win : LZ);
-        const float startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;   // :337
-        __syncthreads();
-        if (use_hist) for (int b = tid; b < C.hist_nbins; b += NT) F.hist[b] = 0;     // :329
-        if (tid == 0) {
-            F.best = f2o(LZ); F.n_items = 0; F.n_alloc = 0; F.n_waste = 0; F.n_newact = 0;
-            F.new_live = 0; F.final_key = 0ULL;                        // :316 bestFinalToken = nullToken
-        }
-        __syncthreads();
-
-        // ---- phase A: doHMMInternalPropagation (:899-935) + HMMInternalPropagation (:376-484)
-        float (*sh_sc)[NT] = (float (*)[NT])sh_raw;                    // old scores [state][thread]
-        int nB = 0;                                                    // survivors written so far
-        int ncand = 0;                                                 // live exit tokens so far
-        for (int base = 0; base < n_act; base += NT) {
-            const int q = base + tid;
-            bool live = false, dead = false, has_exit = false;
-            int slot = -1, a = -1;
-            Tok ex = null_tok();
-            if (q < n_act) {
-                slot = act_cur[q];
-                a = S.slot_arc[slot];
-                const int h = S.slot_hmm[slot];
-                const int n = C.hmm_n[h], tm = C.hmm_tm[h];
-                const Tok *told = S.tok + ((size_t)slot * 2 + par) * MN;
-                Tok *tnew = S.tok + ((size_t)slot * 2 + (par ^ 1)) * MN;
-                for (int i = 0; i < n; ++i) sh_sc[i][tid] = told[i].score;
-                {                                                      // :915-918 start-threshold pruning
-                    const float es = sh_sc[0][tid];
-                    if (es > LZ && es < startTh) sh_sc[0][tid] = LZ;
-                }
-                cnt[ST_INSTS]++;
-                const float *trP = C.trP + (size_t)tm * MN * MN;
-                const int *se = C.se32 + (size_t)tm * MN;
-                Tok nw[JD_MAXN];
-                nw[0] = null_tok();
-                int n_live_emit = 0;
-#pragma unroll
-                for (int j = 1; j < JD_MAXN - 1; ++j) {
-                    nw[j] = null_tok();
-                    if (j < n - 1) {                                   // :387-424 emitting state j
-                        const int sev = se[j];
-                        const int st = sev & 0xffff, en = sev >> 16;
-                        float tp = trP[st * MN + j];
-                        float best = sh_sc[st][tid] + tp;
-                        float btp = tp;
-                        int bi = st;
-                        for (int i = st + 1; i < en; ++i) {
-                            tp = trP[i * MN + j];
-                            const float tmp = sh_sc[i][tid] + tp;
-                            if (tmp > best) { best = tmp; bi = i; btp = tp; }
-                        }
-                        float sc = best - normalise;                   // :408
-                        if (sc > emitTh) {                             // :409
-                            cnt[ST_PEMIT]++;
-                            const Tok src = told[bi];
-                            const float outp = llrow[C.hmm_gmm[(size_t)h * MN + j]];   // :411
-                            Tok r;
-                            r.score = sc + outp;
-                            r.ac = (src.ac + btp) + outp;
-                            r.lm = src.lm;
-                            r.path = src.path;
-                            nw[j] = r;
-                            ++n_live_emit;
-                            if (use_hist) {                            // Histogram::addScore, Histogram.cpp:64-100
-                                const double ds = (double)r.score;
-                                const int sci = (r.score < 0.0f) ? (int)(ds - 0.5) : (int)(ds + 0.5);
-                                if (sci > C.hist_max) F.err = JD_EHIST;
-                                else if (sci >= C.hist_min) atomicAdd(&F.hist[sci - C.hist_min], 1);
-                            }
-                            atomicMax(&F.best, f2o(r.score));          // :417-418
-                        }
-                    }
-                }
-                // exit state (:443-483) from the NEW emitting tokens
-                {
-                    const int sev = se[n - 1];
-                    const int st = sev & 0xffff, en = sev >> 16;
-                    bool first = true;
-#pragma unroll
-                    for (int i = 0; i < JD_MAXN - 1; ++i) {
-                        if (i == st || (i > st && i < en)) {
-                            const float tp = trP[i * MN + (n - 1)];
-                            const float tmp = nw[i].score + tp;
-                            if (first || tmp > ex.score) {
-                                ex = nw[i];
-                                ex.score = tmp;
-                                ex.ac = nw[i].ac + tp;
-                                first = false;
-                            }
-                        }
-                    }
-                    if (first || !(ex.score > LZ)) ex = null_tok();
-                    has_exit = ex.score > LZ;
-                }
-                cnt[ST_EMIT] += n_live_emit;
-                cnt[ST_END] += has_exit ? 1 : 0;
-                live = n_live_emit > 0;
-                dead = !live;
-                if (live) {
-#pragma unroll
-                    for (int j = 0; j < JD_MAXN - 1; ++j)
-                        if (j < n - 1) tnew[j] = nw[j];
-                    tnew[n - 1] = null_tok();                          // :964 exit token leaves the instance
-                }
-            }
-            // ballot + scan compaction of survivors / exit candidates / dead instances
-            const unsigned long long bl = __ballot(live), be = __ballot(has_exit), bd = __ballot(dead);
-            if (lane == 0)
-                F.wsum3[wid] = (unsigned long long)__popcll(bl) | ((unsigned long long)__popcll(be) << 16) |
-                               ((unsigned long long)__popcll(bd) << 32);
-            __syncthreads();
-            unsigned long long pre = 0, tot = 0;
-            for (int w = 0; w < (NT >> 6); ++w) { const unsigned long long sv = F.wsum3[w]; if (w < wid) pre += sv; tot += sv; }
-            const int pl = (int)(pre & 0xffff), pe = (int)((pre >> 16) & 0xffff), pd = (int)((pre >> 32) & 0xffff);
-            if (live) act_next[nB + pl + rank_in(bl)] = slot;
-            if (has_exit) {
-                const int k = ncand + pe + rank_in(be);
-                S.cand_tok[k] = ex;
-                S.cand_arc[k] = a;
-            }
-            if (dead) {                                                // returnNetInst :777-797
-                S.free_stk[n_free + pd + rank_in(bd)] = slot;
-                S.map[a] = -1;
-            }
-            nB += (int)(tot & 0xffff);
-            ncand += (int)((tot >> 16) & 0xffff);
-            n_free += (int)((tot >> 32) & 0xffff);
-            __syncthreads();
-        }
-        __syncthreads();
-        const float bestA = o2f(F.best);
-        const float endTh = (C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;       // :349
-        const float wordTh = (C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;    // :350
-
-        // ---- phase B round 0: doHMMExternalPropagation (:937-982) selects exit tokens
-        for (int base = 0; base < ncand; base += NT) {
-            const int k = base + tid;
-            bool pass = false;
-            Tok t = null_tok();
-            int a = -1;
-            if (k < ncand) {
-                t = S.cand_tok[k];
-                a = S.cand_arc[k];
-                const int outl = C.arcs[a].out;
-                pass = t.score > ((outl != 0) ? wordTh : endTh);       // :952-962
-            }
-            const unsigned long long bp = __ballot(pass);
-            if (bp) {
-                int b0 = 0;
-                const int first = __ffsll((long long)bp) - 1;
-                if (lane == first) b0 = atomicAdd(&F.n_items, __popcll(bp));
-                b0 = __shfl(b0, first);
-                if (pass) {
-                    const int idx = b0 + rank_in(bp);
-                    if (idx < C.cap_items) { S.item_tok[idx] = t; S.item_arc[idx] = a; cnt[ST_PEND]++; }
-                    else F.err = JD_ENOMEM;
-                }
-            }
-        }
-        __syncthreads();
-        const int n0 = F.n_items < C.cap_items ? F.n_items : C.cap_items;
-        const int nfree0 = n_free, hw0 = hw;
-        expand_and_resolve(C, S, F, sh_raw, frame, endTh, wordTh, par ^ 1, act_next, nB, n0, nfree0, hw0, cnt);
-
-        // ---- frame epilogue (uniform)
-        const int k_alloc = F.n_alloc, n_waste = F.n_waste;
-        const int from_free = k_alloc < nfree0 ? k_alloc : nfree0;
-        n_free = nfree0 - from_free;
-        hw = hw0 + (k_alloc - from_free);
-        for (int q = tid; q < n_waste; q += NT) S.free_stk[n_free + q] = S.waste[q];
-        n_free += n_waste;
-        n_act = nB + F.n_newact;
-        best_emit = o2f(F.best);
-        {
-            const unsigned long long key = F.final_key;
+    // ---- epilogue of the frame processed in this step's predecessor kernels
+    if (c.active == 1) {
+        if (lane == 0) {
+            const unsigned long long pk = c.pkA;
+            const int nfree0 = c.n_free + pk_ndead(pk);
+            const int from_free = c.n_alloc < nfree0 ? c.n_alloc : nfree0;
+            c.n_free = nfree0 - from_free;
+            c.hw += c.n_alloc - from_free;
+            c.n_act = pk_nB(pk) + c.n_alloc;
+            c.best_emit = o2f(c.best);
+            const unsigned long long key = c.final_key;
             if (key != 0ULL) {
                 const int ii = (int)(unsigned)(key & 0xffffffffULL);
                 const Tok it = S.item_tok[ii];
-                const float fw = C.fin_w[C.arcs[S.item_arc[ii]].to];
-                best_final.score = o2f((unsigned)(key >> 32));
-                best_final.ac = it.ac;
-                best_final.lm = it.lm + fw;
-                best_final.path = it.path;
-            } else best_final = null_tok();
+                const float fw = C.fin_w[S.item_info[ii].z];
+                Tok bf;
+                bf.score = o2f((unsigned)(key >> 32)); bf.ac = it.ac; bf.lm = it.lm + fw; bf.path = it.path;
+                c.best_final = bf;
+            } else c.best_final = null_tok();
+            c.fr[ST_MODELS] = pk_nB(pk) + c.n_alloc;                             // :981
+            for (int k = 0; k < ST_N; ++k) { c.st[k] += c.fr[k]; c.fr[k] = 0; }
+            c.par ^= 1; c.lst ^= 1;
+            c.frame += 1;
+            if (c.n_paths > C.cap_paths) c.n_paths = C.cap_paths;
         }
-        if (tid == 0) cnt[ST_MODELS] += nB + F.new_live;               // :981 totalActiveModels
-        par ^= 1; lst ^= 1;
         __syncthreads();
     }
-
-    // ---- write back persistent state
+    // ---- start of the next frame (:311-339)
+    const bool go = c.started && !c.needs_init && c.error == 0 && c.frame < c.T;
+    if (!go) { if (lane == 0) c.active = 0; return; }
+    const float best_emit = c.best_emit;
+    const float normalise = (best_emit > LZ) ? best_emit : 0.0f;                 // :321
+    float emitTh = (C.emit_win > 0.0f ? -C.emit_win : LZ);                       // :331
+    if (use_hist) {                                                              // Histogram::calcThresh, Histogram.cpp:134-158
+        const int nb = C.hist_nbins;
+        for (int b = lane; b < nb; b += 64) { sh_hist[b] = S.hist[b]; S.hist[b] = 0; }   // :329 reset
+        __syncthreads();
+        const int K = (nb + 63) >> 6;
+        const int hi = nb - 1 - lane * K;
+        int sum = 0;
+        for (int k = 0; k < K; ++k) { int b = hi - k; if (b >= 0) sum += sh_hist[b]; }
+        int inc = sum;
 #pragma unroll
-    for (int k = 0; k < ST_N; ++k) {
-        long long v = cnt[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if (lane == 0 && v) atomicAdd((unsigned long long *)&sh_stats[k], (unsigned long long)v);
+        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+        const int total = __shfl(inc, 63);
+        float th;
+        if (total <= C.max_hyps) th = (float)C.hist_min - 0.5f;
+        else {
+            const unsigned long long m = __ballot(inc >= C.max_hyps);
+            const int L = __ffsll((long long)m) - 1;
+            int res = 0;
+            if (lane == L) {
+                int acc = inc - sum;
+                for (int k = 0; k < K; ++k) {
+                    int b = hi - k;
+                    if (b < 0) break;
+                    acc += sh_hist[b];
+                    res = b;
+                    if (acc >= C.max_hyps) break;
+                }
+            }
+            res = __shfl(res, L);
+            th = (float)(res + C.hist_min) - 0.5f;
+        }
+        th -= normalise;                                                         // :325
+        if (C.emit_win > 0.0f && th < -C.emit_win) th = -C.emit_win;             // :326-327
+        emitTh = th;
     }
-    if (use_hist) for (int b = tid; b < C.hist_nbins; b += NT) S.hist[b] = F.hist[b];
-    __syncthreads();
-    if (tid == 0) {
-        const bool did_init = S.needs_init != 0;
-        S.par = par; S.lst = lst; S.n_act = n_act; S.hw = hw; S.n_free = n_free;
-        S.n_paths = F.n_paths < C.cap_paths ? F.n_paths : C.cap_paths;
-        S.frame = frame; S.best_emit = best_emit; S.best_final = best_final;
-        if (F.err) S.error = F.err;
-        S.needs_init = 0;
-        for (int k = 0; k < ST_N; ++k) S.st[k] = (did_init ? 0 : S.st[k]) + sh_stats[k];
+    if (lane == 0) {
+        c.normalise = normalise; c.emitTh = emitTh;
+        c.startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;       // :337
+        c.best = f2o(LZ); c.pkA = 0ULL;                                          // :905
+        c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
+        c.n_alloc = 0; c.n_touched = 0;
+        c.final_key = 0ULL;                                                      // :316 bestFinalToken = nullToken
+        c.active = 1;
     }
 }
 
+// ---- phase A: doHMMInternalPropagation (:899-935) + HMMInternalPropagation (:376-484)
+// GS consecutive lanes own one arc instance; lane r updates emitting state r+1, lane GS-1
+// builds the exit token from its neighbours' results (intra-group shuffles).  Each block
+// walks a CONTIGUOUS range of units, so its work counters are flushed once per stream run.
+template <int GS>
+__global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B,
+                                                const float *__restrict__ ll, long long ll_stride, int f0)
+{
+    __shared__ int sh_pre[MAX_B + 1];
+    __shared__ int sh_w[8];
+    __shared__ unsigned long long sh_w3[KT / 64];
+    __shared__ unsigned long long sh_pk;
+    __shared__ int sh_acc[2][5];                                       // [run parity][PEMIT, EMIT, INSTS, END, best]
+    constexpr int PER = KT / GS;                                       // instances per unit
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int MN = C.max_n;
+    if (tid < 10) (&sh_acc[0][0])[tid] = 0;
+    const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
+        const StreamCtl &c = ctl[s0 + s];
+        return c.active == 1 ? (c.n_act + PER - 1) / PER : 0;
+    });
+    const int r = tid & (GS - 1), gb = lane & ~(GS - 1);
+    const bool use_hist = C.max_hyps > 0;
+    const int upb = (total + gridDim.x - 1) / gridDim.x;
+    const int u0 = blockIdx.x * upb, u1 = (u0 + upb < total) ? u0 + upb : total;
+    int cur_s = -1, run = 0;
+    auto flush = [&](int sidx, int buf) {                              // thread 0 only
+        StreamCtl &cf = ctl[sidx];
+        int *a = sh_acc[buf];
+        if (a[0]) atomicAdd(&cf.fr[ST_PEMIT], a[0]);
+        if (a[1]) atomicAdd(&cf.fr[ST_EMIT], a[1]);
+        if (a[2]) atomicAdd(&cf.fr[ST_INSTS], a[2]);
+        if (a[3]) atomicAdd(&cf.fr[ST_END], a[3]);
+        if (a[4]) atomicMax(&cf.best, (unsigned)a[4]);                 // :417-418
+        a[0] = a[1] = a[2] = a[3] = a[4] = 0;
+    };
+    for (int u = u0; u < u1; ++u) {
+        const int sl = find_stream(sh_pre, B, u);
+        const int s = s0 + sl;
+        if (s != cur_s) {
+            if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
+            cur_s = s; ++run;
+        }
+        int *acc = sh_acc[run & 1];
+        StreamCtl &c = ctl[s];
+        const StreamDev &S = streams[s];
+        const int n_act = c.n_act, par = c.par;
+        const float normalise = c.normalise, emitTh = c.emitTh, startTh = c.startTh;
+        const int *act_cur = S.act[c.lst];
+        int *act_next = S.act[c.lst ^ 1];
+        const float *llrow = ll + (size_t)sl * ll_stride + (size_t)(c.frame - f0) * C.G;
+        const int q = (u - sh_pre[sl]) * PER + (tid / GS);
+        const bool valid = q < n_act;
+        bool emit_live = false, has_exit = false, pemit = false;
+        int slot = -1, arc = -1, n = 0;
+        Tok nw = null_tok(), ex = null_tok();
+        int4 exinfo = make_int4(-1, 0, 0, 0);
+        Tok *tnew = nullptr;
+        const float *trP = C.trP;
+        const int *se = C.se32;
+        if (valid) {
+            slot = act_cur[q];
+            const int4 *mp = (const int4 *)(S.meta + slot);
+            const int4 m0 = mp[0], m1 = mp[1];
+            arc = m0.x;
+            n = m0.z & 0xff;
+            const int tm = m0.z >> 8;
+            const Tok *told = S.tok + ((size_t)slot * 2 + par) * MN;
+            tnew = S.tok + ((size_t)slot * 2 + (par ^ 1)) * MN;
+            trP = C.trP + (size_t)tm * MN * MN;
+            se = C.se32 + (size_t)tm * MN;
+            exinfo = make_int4(arc, m0.w, m1.x, 0);
+            const int j = r + 1;
+            if (j < n - 1) {                                           // :387-424 emitting state j
+                int gmj;
+                if (GS == 4) gmj = (r == 0) ? m1.y : (r == 1) ? m1.z : m1.w;
+                else {
+                    const int4 m2 = mp[2];
+                    gmj = (r == 0) ? m1.y : (r == 1) ? m1.z : (r == 2) ? m1.w : (r == 3) ? m2.x : (r == 4) ? m2.y : m2.z;
+                }
+                const float outp = llrow[gmj];                         // :411
+                const int sev = se[j];
+                const int st = sev & 0xffff, en = sev >> 16;
+                Tok src = told[st];
+                if (st == 0 && src.score > LZ && src.score < startTh) src = null_tok();   // :915-918
+                float btp = trP[st * MN + j];
+                float best = src.score + btp;
+                for (int i = st + 1; i < en; ++i) {
+                    const Tok cnd = told[i];
+                    const float tp = trP[i * MN + j];
+                    const float tmp = cnd.score + tp;
+                    if (tmp > best) { best = tmp; btp = tp; src = cnd; }
+                }
+                const float sc = best - normalise;                     // :408
+                if (sc > emitTh) {                                     // :409
+                    pemit = true;
+                    nw.score = sc + outp;
+                    nw.ac = (src.ac + btp) + outp;
+                    nw.lm = src.lm;
+                    nw.path = src.path;
+                    emit_live = true;
+                    if (use_hist) {                                    // Histogram::addScore, Histogram.cpp:64-100
+                        const double ds = (double)nw.score;
+                        const int sci = (nw.score < 0.0f) ? (int)(ds - 0.5) : (int)(ds + 0.5);
+                        if (sci > C.hist_max) c.error = JD_EHIST;
+                        else if (sci >= C.hist_min) atomicAdd(&S.hist[sci - C.hist_min], 1);
+                    }
+                }
+            }
+        }
+        // exit state (:443-483): lane GS-1 of the group reads the NEW tokens of its neighbours
+        {
+            int st = 0, en = 0;
+            const bool is_exit_lane = valid && (r == GS - 1);
+            if (is_exit_lane) { const int sev = se[n - 1]; st = sev & 0xffff; en = sev >> 16; }
+            bool first = true;
+#pragma unroll
+            for (int i = 1; i < GS; ++i) {
+                Tok ti;
+                ti.score = __shfl(nw.score, gb + i - 1);
+                ti.ac = __shfl(nw.ac, gb + i - 1);
+                ti.lm = __shfl(nw.lm, gb + i - 1);
+                ti.path = __shfl(nw.path, gb + i - 1);
+                if (is_exit_lane && (i == st || (i > st && i < en))) {
+                    const float tp = trP[i * MN + (n - 1)];
+                    const float tmp = ti.score + tp;
+                    if (first || tmp > ex.score) {
+                        ex = ti;
+                        ex.score = tmp;
+                        ex.ac = ti.ac + tp;
+                        first = false;
+                    }
+                }
+            }
+            if (first || !(ex.score > LZ)) ex = null_tok();
+            has_exit = ex.score > LZ;
+        }
+        const unsigned long long bemit = __ballot(emit_live);
+        const bool slot_live = ((bemit >> gb) & ((1ull << GS) - 1ull)) != 0ull;
+        if (valid && slot_live) {
+            if (r + 1 < n - 1) tnew[r + 1] = nw;
+            if (r == GS - 1) { tnew[0] = null_tok(); tnew[n - 1] = null_tok(); }   // :428-436, :964
+        }
+        const bool live = valid && r == 0 && slot_live;
+        const bool dead = valid && r == 0 && !slot_live;
+        // block-level compaction: ONE packed returning atomic per unit
+        const unsigned long long bl = __ballot(live), be = __ballot(has_exit), bd = __ballot(dead);
+        {
+            unsigned mo = emit_live ? f2o(nw.score) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_xor(mo, o); mo = y > mo ? y : mo; }
+            const int c_pemit = __popcll(__ballot(pemit));
+            if (lane == 0) {
+                sh_w3[wid] = (unsigned long long)__popcll(bl) | ((unsigned long long)__popcll(be) << PK_SHIFT1) |
+                             ((unsigned long long)__popcll(bd) << PK_SHIFT2);
+                if (c_pemit) atomicAdd(&acc[0], c_pemit);
+                if (bemit) atomicAdd(&acc[1], __popcll(bemit));
+                if (mo) atomicMax((unsigned *)&acc[4], mo);
+            }
+        }
+        __syncthreads();
+        unsigned long long pre = 0, tot = 0;
+        for (int w = 0; w < (KT >> 6); ++w) { const unsigned long long sv = sh_w3[w]; if (w < wid) pre += sv; tot += sv; }
+        if (tid == 0) {
+            sh_pk = tot ? atomicAdd(&c.pkA, tot) : 0ULL;
+            acc[2] += pk_nB(tot) + pk_ndead(tot);
+            acc[3] += pk_cnt0(tot);
+        }
+        __syncthreads();
+        const unsigned long long bs = sh_pk;
+        if (live) act_next[pk_nB(bs) + pk_nB(pre) + rank_in(bl)] = slot;
+        if (has_exit) {
+            const int k = pk_cnt0(bs) + pk_cnt0(pre) + rank_in(be);
+            if (k < C.cap_items) { S.item_tok[k] = ex; S.item_info[k] = exinfo; }
+            else c.error = -42;
+        }
+        if (dead) {                                                    // returnNetInst :777-797
+            S.free_stk[c.n_free + pk_ndead(bs) + pk_ndead(pre) + rank_in(bd)] = slot;
+            S.map[arc] = -1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
+}
+
+// One frontier item = a token that has just traversed arc info.x (-1 = the NULL transition
+// of recognitionStart).  Body of propagateToken (WFSTDecoderLite.cpp:491-605), executed by a
+// group of EG lanes: lane 0 records the word boundary / final state, all lanes walk the
+// out-arcs of the destination state (coalesced 16-byte arc records).  First-touched arcs are
+// staged in a per-wave LDS buffer and appended to the stream's list with one atomic per flush.
+#define TB_CAP 1024
+struct WaveStage { int n; int buf[TB_CAP]; };
+
+__device__ __forceinline__ void stage_flush(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &w)
+{
+    const int lane = lane_id();
+    const int n = w.n;
+    if (n == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&c.n_touched, n);
+    base = __shfl(base, 0);
+    for (int k = lane; k < n; k += 64) {
+        if (base + k < C.cap_items) S.touched[base + k] = w.buf[k]; else c.error = -42;
+    }
+    if (lane == 0) w.n = 0;
+}
+
+__device__ __forceinline__ void expand_item(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &stage,
+                                            int frame, float endTh, float wordTh, bool have, int ii,
+                                            int *items_counter, int items_base, int &n_arcs, int &n_paths_made)
+{
+    const int lane = lane_id();
+    const int er = lane & (EG - 1), eb = lane & ~(EG - 1);
+    const float INF = __builtin_inff();
+    Tok t = null_tok();
+    int rs = 0, deg = 0;
+    if (have) {
+        t = S.item_tok[ii];
+        const int4 info = S.item_info[ii];
+        int state = C.init_state;
+        if (info.x >= 0) {
+            if (info.y != 0) {                                         // :497-509 word boundary
+                int p = 0;
+                if (er == 0) p = atomicAdd(&c.n_paths, 1);
+                p = __shfl(p, eb);
+                if (p < C.cap_paths) {
+                    if (er == 0) {
+                        PathRec pr;
+                        pr.prev = t.path; pr.frame = frame; pr.label = info.y; pr.pad0 = 0;
+                        pr.score = t.score; pr.ac = t.ac; pr.lm = t.lm; pr.pad1 = 0.0f;
+                        S.paths[p] = pr;
+                        S.item_tok[ii].path = p;
+                        ++n_paths_made;
+                    }
+                    t.path = p;
+                } else c.error = -43;
+            }
+            state = info.z;
+            if (er == 0) {                                             // :513-520 final state
+                const float fw = C.fin_w[state];
+                if (fw < INF) {
+                    const float cs = t.score + fw;
+                    if (cs > LZ) atomicMax(&c.final_key, ((unsigned long long)f2o(cs) << 32) | (unsigned)ii);
+                }
+            }
+        }
+        rs = C.row_ptr[state];
+        deg = C.row_ptr[state + 1] - rs;
+    }
+    // the group with the largest degree in the wave sets the trip count
+    int maxdeg = deg;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(maxdeg, o); maxdeg = y > maxdeg ? y : maxdeg; }
+    for (int k0 = 0; k0 < maxdeg; k0 += EG) {
+        const int k = k0 + er;
+        bool mk = false, touch = false;
+        Tok u = null_tok();
+        int4 uinfo = make_int4(-1, 0, 0, 0);
+        int tb = -1;
+        if (k < deg) {
+            const int b = rs + k;
+            const JdArc Bk = C.arcs[b];
+            ++n_arcs;
+            const int inl = Bk.in & ~TEE_FLAG;
+            if (inl == 0) {                                            // :533-540 epsilon input
+                u = t;
+                u.score = t.score + Bk.w;
+                u.lm = t.lm + Bk.w;
+                mk = u.score > endTh;
+                uinfo = make_int4(b, Bk.out, Bk.to, 0);
+            } else {                                                   // :560-582 entry-token recombination
+                const float ns = t.score + Bk.w;
+                const unsigned long long key = ((unsigned long long)f2o(ns) << 32) | (unsigned)ii;
+                const unsigned long long old = atomicMax(&S.ekey[b], key);
+                touch = (old == 0ULL);
+                tb = b;
+                if (Bk.in & TEE_FLAG) {                                // :584-600 tee model
+                    const float tee = C.hmm_tee[inl - 1];
+                    const float ns2 = ns + tee;
+                    u.score = ns2;
+                    u.ac = t.ac + tee;
+                    u.lm = t.lm + Bk.w;
+                    u.path = t.path;
+                    mk = ns2 > ((Bk.out != 0) ? wordTh : endTh);
+                    uinfo = make_int4(b, Bk.out, Bk.to, 0);
+                }
+            }
+        }
+        // first-touched arcs -> per-wave LDS stage (flushed when nearly full)
+        const unsigned long long bt = __ballot(touch);
+        if (bt) {
+            const int base = stage.n;                                  // wave-private: uniform read
+            if (touch) stage.buf[base + rank_in(bt)] = tb;
+            if (lane == 0) stage.n = base + __popcll(bt);
+            if (base + __popcll(bt) > TB_CAP - 64) stage_flush(C, c, S, stage);
+        }
+        const int idx = wave_append(mk, items_counter);
+        if (mk) {
+            const int pos = items_base + idx;
+            if (pos < C.cap_items) { S.item_tok[pos] = u; S.item_info[pos] = uinfo; }
+            else c.error = -42;
+        }
+    }
+}
+
+// frontier rounds 0 and 1, flattened over all streams.  ROUND 0 reads the live exit tokens
+// written by phase A and applies the end/word threshold (doHMMExternalPropagation :946-962).
+// A unit is 64 items: each wave takes 16 of them, 4 at a time (EG lanes per item).
+template <int ROUND>
+__global__ __launch_bounds__(KT) void k_expand(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B)
+{
+    __shared__ int sh_pre[MAX_B + 1];
+    __shared__ int sh_w[8];
+    __shared__ WaveStage sh_stage[KT / 64];
+    constexpr int GPW = 64 / EG;                                       // items per wave-iteration
+    constexpr int IPW = 16;                                            // items per wave per unit
+    constexpr int PER = IPW * (KT / 64);                               // items per unit
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    if (lane == 0) sh_stage[wid].n = 0;
+    const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
+        const StreamCtl &c = ctl[s0 + s];
+        if (c.active == 0) return 0;
+        const int n = (ROUND == 0) ? pk_cnt0(c.pkA) : c.cnt1;
+        return (n + PER - 1) / PER;
+    });
+    WaveStage &stage = sh_stage[wid];
+    const int upb = (total + gridDim.x - 1) / gridDim.x;
+    const int u0 = blockIdx.x * upb, u1 = (u0 + upb < total) ? u0 + upb : total;
+    int cur_s = -1;
+    int n_arcs = 0, n_paths_made = 0, n_pend = 0;
+    auto flush = [&](int sidx) {                                       // per wave
+        StreamCtl &cf = ctl[sidx];
+        stage_flush(C, cf, streams[sidx], stage);
+        n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
+        if (lane == 0) {
+            if (n_arcs) atomicAdd(&cf.fr[ST_ARCS], n_arcs);
+            if (n_paths_made) atomicAdd(&cf.fr[ST_PATHS], n_paths_made);
+            if (n_pend) atomicAdd(&cf.fr[ST_PEND], n_pend);
+        }
+        n_arcs = 0; n_paths_made = 0; n_pend = 0;
+    };
+    for (int u = u0; u < u1; ++u) {
+        const int sl = find_stream(sh_pre, B, u);
+        const int s = s0 + sl;
+        if (s != cur_s) {
+            if (cur_s >= 0) flush(cur_s);
+            cur_s = s;
+        }
+        StreamCtl &c = ctl[s];
+        const StreamDev &S = streams[s];
+        const float bestA = o2f(c.best);
+        const bool init = c.active == 2;
+        const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;      // :349
+        const float wordTh = (!init && C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;   // :350
+        const int cnt0 = pk_cnt0(c.pkA);
+        const int nin = (ROUND == 0) ? cnt0 : c.cnt1;
+        const int in_base = (ROUND == 0) ? 0 : cnt0;
+        const int out_base = (ROUND == 0) ? cnt0 : cnt0 + c.cnt1;
+        const int kbase = (u - sh_pre[sl]) * PER + wid * IPW;
+        for (int it = 0; it < IPW; it += GPW) {
+            const int k = kbase + it + (lane / EG);
+            bool have = k < nin;
+            const int ii = in_base + k;
+            if (ROUND == 0 && have && !init) {                         // :952-962 threshold on the exit token
+                const float sc = S.item_tok[ii].score;
+                const int outl = S.item_info[ii].y;
+                have = sc > ((outl != 0) ? wordTh : endTh);
+                if (have && (lane & (EG - 1)) == 0) ++n_pend;
+            }
+            if (!__any(have)) continue;
+            expand_item(C, c, S, stage, c.frame, endTh, wordTh, have, ii, (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base,
+                        n_arcs, n_paths_made);
+        }
+    }
+    if (cur_s >= 0) flush(cur_s);
+}
+
+// remaining closure rounds (items produced by round 1 and later): rare, one block per stream
+__global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0)
+{
+    StreamCtl &c = ctl[s0 + blockIdx.x];
+    if (c.active == 0 || c.cnt2 == 0) return;
+    __shared__ WaveStage sh_stage[KT / 64];
+    const StreamDev &S = streams[s0 + blockIdx.x];
+    constexpr int PER = KT / EG;
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    if (lane == 0) sh_stage[wid].n = 0;
+    WaveStage &stage = sh_stage[wid];
+    const float bestA = o2f(c.best);
+    const bool init = c.active == 2;
+    const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;
+    const float wordTh = (!init && C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;
+    const int base = pk_cnt0(c.pkA) + c.cnt1;
+    int r0 = 0, r1 = c.cnt2;                       // window within the tail region [base + r0, base + r1)
+    const int tail_base = base + c.cnt2;           // items appended here: tail_base + cnt_tail++
+    int n_arcs = 0, n_paths_made = 0;
+    while (r1 > r0) {
+        for (int k0 = r0; k0 < r1; k0 += PER) {
+            const int k = k0 + (tid / EG);
+            expand_item(C, c, S, stage, c.frame, endTh, wordTh, k < r1, base + k, &c.cnt_tail, tail_base, n_arcs,
+                        n_paths_made);
+        }
+        __syncthreads();
+        r0 = r1;
+        r1 = c.cnt2 + __hip_atomic_load(&c.cnt_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (base + r1 > C.cap_items) r1 = C.cap_items - base;
+        __syncthreads();
+    }
+    stage_flush(C, c, S, stage);
+    n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made);
+    if (lane == 0) {
+        if (n_arcs) atomicAdd(&c.fr[ST_ARCS], n_arcs);
+        if (n_paths_made) atomicAdd(&c.fr[ST_PATHS], n_paths_made);
+    }
+}
+
+// ---- resolve: the winning candidate of every touched arc becomes the entry token of its
+// instance; missing instances are attached here (attachNetInst :751-774), one lane per arc.
+__global__ __launch_bounds__(KT) void k_resolve(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B)
+{
+    __shared__ int sh_pre[MAX_B + 1];
+    __shared__ int sh_w[8];
+    __shared__ int sh_base;
+    __shared__ unsigned sh_best[2];
+    const int tid = threadIdx.x, lane = lane_id();
+    const int MN = C.max_n;
+    if (tid < 2) sh_best[tid] = 0u;
+    const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
+        const StreamCtl &c = ctl[s0 + s];
+        if (c.active == 0) return 0;
+        const int nt = c.n_touched < C.cap_items ? c.n_touched : C.cap_items;
+        return (nt + KT - 1) / KT;
+    });
+    const int upb = (total + gridDim.x - 1) / gridDim.x;
+    const int u0 = blockIdx.x * upb, u1 = (u0 + upb < total) ? u0 + upb : total;
+    int cur_s = -1, run = 0;
+    for (int u = u0; u < u1; ++u) {
+        const int sl = find_stream(sh_pre, B, u);
+        const int s = s0 + sl;
+        if (s != cur_s) {
+            if (tid == 0 && cur_s >= 0 && sh_best[run & 1]) { atomicMax(&ctl[cur_s].best, sh_best[run & 1]); sh_best[run & 1] = 0u; }
+            cur_s = s; ++run;
+        }
+        StreamCtl &c = ctl[s];
+        const StreamDev &S = streams[s];
+        const int nt = c.n_touched < C.cap_items ? c.n_touched : C.cap_items;
+        const int q = (u - sh_pre[sl]) * KT + tid;
+        const int par_next = c.par ^ 1;
+        int *act_next = S.act[c.lst ^ 1];
+        const unsigned long long pk = c.pkA;
+        const int nfree0 = c.n_free + pk_ndead(pk), hw0 = c.hw, nB = pk_nB(pk);
+        bool need = false, win = false;
+        int b = -1, slot = -1, ii = 0;
+        float sc = LZ;
+        JdArc Bk{0, 0.0f, 0, 0};
+        if (q < nt) {
+            b = S.touched[q];
+            const unsigned long long key = atomicExch(&S.ekey[b], 0ULL);
+            sc = o2f((unsigned)(key >> 32));
+            if (sc > LZ) {
+                win = true;
+                ii = (int)(unsigned)(key & 0xffffffffULL);
+                Bk = C.arcs[b];
+                slot = S.map[b];
+                need = slot < 0;
+            }
+        }
+        // block-aggregated allocation: one returning atomic per unit
+        int tot_need;
+        const int myk = block_excl_scan(need ? 1 : 0, sh_w, tot_need);
+        if (tid == 0) sh_base = tot_need ? atomicAdd(&c.n_alloc, tot_need) : 0;
+        __syncthreads();
+        if (need) {
+            const int k = sh_base + myk;
+            const int ns_ = (k < nfree0) ? S.free_stk[nfree0 - 1 - k] : hw0 + (k - nfree0);
+            if (ns_ >= C.cap_slots) { c.error = -41; slot = -1; }
+            else {
+                slot = ns_;
+                const int hm = (Bk.in & ~TEE_FLAG) - 1;
+                const int n = C.hmm_n[hm];
+                const int *hg = C.hmm_gmm + (size_t)hm * MN;
+                SlotMeta m;
+                m.arc = b; m.hmm = hm; m.n_tm = n | (C.hmm_tm[hm] << 8); m.out = Bk.out; m.to = Bk.to;
+                m.g0 = (1 < n - 1) ? hg[1] : 0; m.g1 = (2 < n - 1) ? hg[2] : 0; m.g2 = (3 < n - 1) ? hg[3] : 0;
+                m.g3 = (4 < n - 1) ? hg[4] : 0; m.g4 = (5 < n - 1) ? hg[5] : 0; m.g5 = (6 < n - 1) ? hg[6] : 0;
+                m.pad = 0;
+                S.meta[slot] = m;
+                Tok *tp = S.tok + ((size_t)slot * 2 + par_next) * MN;
+                for (int qq = 1; qq < n; ++qq) tp[qq] = null_tok();
+                S.map[b] = slot;
+                act_next[nB + k] = slot;
+            }
+        }
+        unsigned mo = 0u;
+        if (win && slot >= 0) {
+            const Tok it = S.item_tok[ii];
+            Tok e;
+            e.score = sc; e.ac = it.ac; e.lm = it.lm + Bk.w; e.path = it.path;
+            S.tok[((size_t)slot * 2 + par_next) * MN] = e;
+            mo = f2o(sc);                                              // :572-573
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_xor(mo, o); mo = y > mo ? y : mo; }
+        if (lane == 0 && mo) atomicMax(&sh_best[run & 1], mo);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0 && cur_s >= 0 && sh_best[run & 1]) atomicMax(&ctl[cur_s].best, sh_best[run & 1]);
+}
+
 // recognitionFinish (:230-309): walk the Path chain of bestFinalToken.
-__global__ void jd_finish_kernel(StreamDev *streams, int s0, int n)
+__global__ void jd_finish_kernel(StreamCtl *ctl, StreamDev *streams, int s0, int n)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     StreamDev &S = streams[s0 + s];
-    const Tok best = S.best_final;
-    if (!(best.score > LZ) || S.frame == 0) { S.res_n = -1; return; }
+    const StreamCtl &c = ctl[s0 + s];
+    const Tok best = c.best_final;
+    if (!(best.score > LZ) || c.frame == 0) { S.res_n = -1; return; }
     int k = 0;
     for (int p = best.path; p >= 0; p = S.paths[p].prev) {
         if (k < S.res_cap) {
@@ -761,6 +1022,18 @@ __global__ void jd_finish_kernel(StreamDev *streams, int s0, int n)
         ++k;
     }
     S.res_n = k;
+}
+
+__global__ void jd_mark_init_kernel(StreamCtl *ctl, int s0, int n)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) { ctl[s0 + s].needs_init = 1; ctl[s0 + s].started = 1; ctl[s0 + s].error = 0; ctl[s0 + s].T = 0; }
+}
+
+__global__ void jd_set_T_kernel(StreamCtl *ctl, int s0, int n, const int *T)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) ctl[s0 + s].T = T[s];
 }
 
 // --------------------------------------------------------------- host runtime
@@ -870,7 +1143,8 @@ struct jd_dec {
     float *d_hmm_tee = nullptr, *d_trP = nullptr;
     // per-stream state
     StreamDev *d_streams = nullptr;
-    std::vector<StreamDev> h_streams;          // host mirror (pointers + scalars)
+    StreamCtl *d_ctl = nullptr;
+    std::vector<StreamDev> h_streams;          // host mirror (arena pointers)
     std::vector<void *> allocs;
     bool arenas_ready = false;
     int64_t cap_slots = 0, cap_paths = 0, cap_items = 0;
@@ -963,7 +1237,12 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     }
 #define TRY(x) do { rc = (x); if (rc) { jd_dec_destroy(d); return rc; } } while (0)
     TRY(dupload(d, &d->d_row_ptr, net->row_ptr.data(), net->row_ptr.size()));
-    TRY(dupload(d, &d->d_arcs, net->arcs.data(), net->arcs.size()));
+    {   // device arc table: bit 30 of the in-label marks arcs whose HMM is a tee model
+        std::vector<JdArc> darcs(net->arcs);
+        for (JdArc &a : darcs)
+            if (a.in > 0 && am->hmm_tee[(size_t)a.in - 1] > LZ) a.in |= TEE_FLAG;
+        TRY(dupload(d, &d->d_arcs, darcs.data(), darcs.size()));
+    }
     TRY(dupload(d, &d->d_fin_w, net->fin_w.data(), net->fin_w.size()));
     TRY(dupload(d, &d->d_hmm_n, am->hmm_n.data(), am->hmm_n.size()));
     TRY(dupload(d, &d->d_hmm_tm, am->hmm_tm.data(), am->hmm_tm.size()));
@@ -976,13 +1255,13 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     TRY(dupload(d, &d->d_se32, se32.data(), se32.size()));
     TRY(upload_am_gmm(am, d->amb));
     C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init;
-    C.G = am->n_gmm; C.max_n = am->max_n;
+    C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
     C.hmm_n = d->d_hmm_n; C.hmm_tm = d->d_hmm_tm; C.hmm_gmm = d->d_hmm_gmm; C.hmm_tee = d->d_hmm_tee;
     C.trP = d->d_trP; C.se32 = d->d_se32;
     // default arena sizes: sized for 288 GB of HBM, not for frugality
-    d->cap_slots = std::min<int64_t>(net->n_arcs + 1024, 1 << 19);
+    d->cap_slots = std::min<int64_t>(net->n_arcs + 1024, 1 << 18);
     d->cap_items = 1 << 18;
-    d->cap_paths = 1 << 21;
+    d->cap_paths = 1 << 22;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&d->s_gmm, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&d->s_search, hipStreamNonBlocking)) != hipSuccess) {
@@ -1022,24 +1301,21 @@ static int ensure_arenas(jd_dec *d)
     for (int s = 0; s < B; ++s) {
         StreamDev &S = d->h_streams[(size_t)s];
         memset(&S, 0, sizeof S);
-        S.needs_init = 1;
-        S.best_emit = LZ;
-        S.best_final.score = LZ; S.best_final.ac = LZ; S.best_final.lm = LZ; S.best_final.path = -1;
 #define A(p, n) do { rc = dmalloc(d, &(p), (size_t)(n)); if (rc) return rc; } while (0)
         A(S.tok, d->cap_slots * 2 * MN);
-        A(S.slot_arc, d->cap_slots); A(S.slot_hmm, d->cap_slots);
+        A(S.meta, d->cap_slots);
         A(S.act[0], d->cap_slots); A(S.act[1], d->cap_slots);
-        A(S.free_stk, d->cap_slots); A(S.waste, d->cap_slots);
-        A(S.ekey, d->cap_slots); A(S.map, d->net->n_arcs);
-        A(S.item_tok, d->cap_items); A(S.item_arc, d->cap_items);
-        A(S.cand_tok, d->cap_slots); A(S.cand_arc, d->cap_slots);
+        A(S.free_stk, d->cap_slots);
+        A(S.ekey, d->net->n_arcs); A(S.map, d->net->n_arcs);
+        A(S.touched, d->cap_items);
+        A(S.item_tok, d->cap_items); A(S.item_info, d->cap_items);
         A(S.paths, d->cap_paths);
         A(S.hist, HIST_MAX_BINS);
         A(S.res_label, d->res_cap); A(S.res_time, d->res_cap);
         A(S.res_score, d->res_cap); A(S.res_ac, d->res_cap); A(S.res_lm, d->res_cap);
 #undef A
         S.res_cap = d->res_cap;
-        HIPCHK(hipMemset(S.ekey, 0, (size_t)d->cap_slots * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(S.ekey, 0, (size_t)d->net->n_arcs * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.map, 0xff, (size_t)d->net->n_arcs * sizeof(int)));
         HIPCHK(hipMemset(S.hist, 0, HIST_MAX_BINS * sizeof(int)));
     }
@@ -1048,6 +1324,17 @@ static int ensure_arenas(jd_dec *d)
     HIPCHK(hipMemcpy(d->d_streams, d->h_streams.data(), (size_t)B * sizeof(StreamDev), hipMemcpyHostToDevice));
     rc = dmalloc(d, &d->d_T, (size_t)B);
     if (rc) return rc;
+    rc = dmalloc(d, &d->d_ctl, (size_t)B);
+    if (rc) return rc;
+    {
+        std::vector<StreamCtl> hc((size_t)B);
+        memset(hc.data(), 0, hc.size() * sizeof(StreamCtl));
+        for (auto &c : hc) {
+            c.needs_init = 1; c.best_emit = LZ;
+            c.best_final.score = LZ; c.best_final.ac = LZ; c.best_final.lm = LZ; c.best_final.path = -1;
+        }
+        HIPCHK(hipMemcpy(d->d_ctl, hc.data(), hc.size() * sizeof(StreamCtl), hipMemcpyHostToDevice));
+    }
     for (int i = 0; i < 2; ++i)
         HIPCHK(hipMalloc(&d->d_ll[i], (size_t)B * d->Fc * d->am->n_gmm * sizeof(float)));
     HIPCHK(hipDeviceSynchronize());
@@ -1055,16 +1342,10 @@ static int ensure_arenas(jd_dec *d)
     return JD_OK;
 }
 
-__global__ void jd_mark_init_kernel(StreamDev *streams, int s0, int n)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) { streams[s0 + s].needs_init = 1; streams[s0 + s].error = 0; }
-}
-
 // mark streams [s0, s0+n) for re-initialisation (IDecoder::init)
 static int mark_init(jd_dec *d, int s0, int n, hipStream_t st)
 {
-    hipLaunchKernelGGL(jd_mark_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d->d_streams, s0, n);
+    hipLaunchKernelGGL(jd_mark_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d->d_ctl, s0, n);
     HIPCHK(hipGetLastError());
     return JD_OK;
 }
@@ -1072,36 +1353,43 @@ static int mark_init(jd_dec *d, int s0, int n, hipStream_t st)
 static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
 {
     std::vector<StreamDev> hs((size_t)n);
+    std::vector<StreamCtl> hc((size_t)n);
     HIPCHK(hipMemcpy(hs.data(), d->d_streams + s0, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hc.data(), d->d_ctl + s0, (size_t)n * sizeof(StreamCtl), hipMemcpyDeviceToHost));
     int first_err = JD_OK;
     for (int i = 0; i < n; ++i) {
         const StreamDev &S = hs[(size_t)i];
+        const StreamCtl &K = hc[(size_t)i];
         HostResult &R = d->results[(size_t)(out0 + i)];
         jd_hyp &H = out[out0 + i];
         memset(&H, 0, sizeof H);
-        if (S.error && first_err == JD_OK) {
-            first_err = S.error;
-            if (S.error == JD_EHIST) jd_fail(JD_EHIST, "Histogram::addScore - score > maxScore (stream %d)", s0 + i);
-            else jd_fail(S.error, "stream %d: device arena overflow (slots %lld / items %lld / paths %lld): "
-                         "raise jd_dec_set_capacity", s0 + i, (long long)d->cap_slots, (long long)d->cap_items,
-                         (long long)d->cap_paths);
+        if (K.error && first_err == JD_OK) {
+            if (K.error == JD_EHIST)
+                first_err = jd_fail(JD_EHIST, "Histogram::addScore - score > maxScore (stream %d)", s0 + i);
+            else {
+                const char *what = K.error == -41 ? "instance slots" : K.error == -42 ? "frontier items"
+                                 : K.error == -43 ? "Path records" : "arena";
+                const long long cap = K.error == -41 ? d->cap_slots : K.error == -42 ? d->cap_items : d->cap_paths;
+                first_err = jd_fail(JD_ENOMEM, "stream %d: device arena overflow at frame %d: %s (capacity %lld); "
+                                    "raise it with jd_dec_set_capacity", s0 + i, K.frame, what, cap);
+            }
         }
-        if (S.error) {      // arenas may be inconsistent after an abort: wipe them for the next init
-            HIPCHK(hipMemset(S.ekey, 0, (size_t)d->cap_slots * sizeof(unsigned long long)));
+        if (K.error) {      // arenas may be inconsistent after an abort: wipe them for the next init
+            HIPCHK(hipMemset(S.ekey, 0, (size_t)d->net->n_arcs * sizeof(unsigned long long)));
             HIPCHK(hipMemset(S.map, 0xff, (size_t)d->net->n_arcs * sizeof(int)));
             const int zero = 0;
-            HIPCHK(hipMemcpy((char *)(d->d_streams + s0 + i) + offsetof(StreamDev, n_act), &zero, sizeof(int),
+            HIPCHK(hipMemcpy((char *)(d->d_ctl + s0 + i) + offsetof(StreamCtl, n_act), &zero, sizeof(int),
                              hipMemcpyHostToDevice));
         }
-        H.stats.n_frames = S.frame;
-        H.stats.tot_active_emit_hyps = S.st[ST_EMIT];
-        H.stats.tot_active_end_hyps = S.st[ST_END];
-        H.stats.tot_active_models = S.st[ST_MODELS];
-        H.stats.tot_proc_emit_hyps = S.st[ST_PEMIT];
-        H.stats.tot_proc_end_hyps = S.st[ST_PEND];
-        H.stats.tot_arcs_visited = S.st[ST_ARCS];
-        H.stats.tot_paths = S.st[ST_PATHS];
-        H.stats.tot_insts_in = S.st[ST_INSTS];
+        H.stats.n_frames = K.frame;
+        H.stats.tot_active_emit_hyps = K.st[ST_EMIT];
+        H.stats.tot_active_end_hyps = K.st[ST_END];
+        H.stats.tot_active_models = K.st[ST_MODELS];
+        H.stats.tot_proc_emit_hyps = K.st[ST_PEMIT];
+        H.stats.tot_proc_end_hyps = K.st[ST_PEND];
+        H.stats.tot_arcs_visited = K.st[ST_ARCS];
+        H.stats.tot_paths = K.st[ST_PATHS];
+        H.stats.tot_insts_in = K.st[ST_INSTS];
         H.stats.ties = 0;
         int k = S.res_n;
         if (k > d->res_cap) {
@@ -1120,10 +1408,46 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
         }
         H.label = R.label.data(); H.time = R.time.data();
         H.score = R.score.data(); H.ac = R.ac.data(); H.lm = R.lm.data();
-        if (kk) { H.tot_score = S.best_final.score; H.tot_ac = S.best_final.ac; H.tot_lm = S.best_final.lm; }
+        if (kk) { H.tot_score = K.best_final.score; H.tot_ac = K.best_final.ac; H.tot_lm = K.best_final.lm; }
         else { H.tot_score = LZ; H.tot_ac = LZ; H.tot_lm = LZ; }      // DecHyp() defaults, DecHypHistPool.h
     }
     return first_err;
+}
+
+#define GRID_A 2048
+#define GRID_X 1024
+
+// recognitionStart for every stream of [s0, s0+nb) that is flagged needs_init
+static void launch_init(jd_dec *d, int nb, int s0, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 1);
+    hipLaunchKernelGGL(k_expand<0>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_expand<1>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
+    hipLaunchKernelGGL(k_resolve, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 2);
+}
+
+// one lock-step frame for streams [s0, s0+nb)
+static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll_stride, int f0, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 0);
+    if (d->am->max_n <= 5)
+        hipLaunchKernelGGL(k_phase_a<4>, dim3(GRID_A), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb, ll,
+                           ll_stride, f0);
+    else
+        hipLaunchKernelGGL(k_phase_a<8>, dim3(GRID_A), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb, ll,
+                           ll_stride, f0);
+    hipLaunchKernelGGL(k_expand<0>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_expand<1>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
+    hipLaunchKernelGGL(k_resolve, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+}
+
+// closes the last frame of a run of steps (epilogue only: no stream has frames left)
+static void launch_close(jd_dec *d, int nb, int s0, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 0);
 }
 
 // Decode one wave of nb <= max_streams utterances held in device memory.
@@ -1160,6 +1484,9 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
     HIPCHK(hipMemcpyAsync(d->d_T, T.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, d->s_search));
     int rc = mark_init(d, 0, nb, d->s_search);
     if (rc) return rc;
+    hipLaunchKernelGGL(jd_set_T_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, 0, nb, d->d_T);
+    launch_init(d, nb, 0, d->s_search);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(d->s_gmm));
     HIPCHK(hipStreamSynchronize(d->s_search));
 
@@ -1179,13 +1506,16 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
         HIPCHK(hipEventRecord(d->ev_gmm[buf], d->s_gmm));
         HIPCHK(hipStreamWaitEvent(d->s_search, d->ev_gmm[buf], 0));
         HIPCHK(hipEventRecord(ss[(size_t)c], d->s_search));
-        hipLaunchKernelGGL(jd_search_kernel, dim3(nb), dim3(NT), 0, d->s_search, d->C, d->d_streams, 0, d->d_T,
-                           d->d_ll[buf], (long long)Fc * G, c * Fc, Fc);
+        {
+            const int nsteps = std::min(Fc, maxT - c * Fc);
+            for (int k = 0; k < nsteps; ++k) launch_step(d, nb, 0, d->d_ll[buf], (long long)Fc * G, c * Fc, d->s_search);
+            if (c == n_chunks - 1) launch_close(d, nb, 0, d->s_search);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(se[(size_t)c], d->s_search));
         HIPCHK(hipEventRecord(d->ev_search[buf], d->s_search));
     }
-    hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_streams, 0, nb);
+    hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, 0, nb);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(d->s_gmm));
     HIPCHK(hipStreamSynchronize(d->s_search));
@@ -1296,10 +1626,12 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
         const int f0 = d->stream_T[(size_t)s];
         const int Tnew = f0 + n;
         HIPCHK(hipMemcpyAsync(d->d_T + s, &Tnew, sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(jd_set_T_kernel, dim3(1), dim3(64), 0, st, d->d_ctl, s, 1, d->d_T + s);
         rc = launch_gmm(d->am, d->amb, d->d_push, d->d_row_src, n, d->d_ll[0], st);
         if (rc) return rc;
-        hipLaunchKernelGGL(jd_search_kernel, dim3(1), dim3(NT), 0, st, d->C, d->d_streams, s, d->d_T, d->d_ll[0],
-                           (long long)Fc * G, f0, Fc);
+        launch_init(d, 1, s, st);                      // no-op unless the stream is flagged needs_init
+        for (int k = 0; k < n; ++k) launch_step(d, 1, s, d->d_ll[0], (long long)Fc * G, f0, st);
+        launch_close(d, 1, s, st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
         d->stream_T[(size_t)s] = Tnew;
@@ -1313,14 +1645,8 @@ extern "C" int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out)
     if (!d->stream_started[(size_t)s]) return jd_fail(JD_ESTATE, "jd_stream_finish before jd_stream_init");
     int rc = check_device(d->device);
     if (rc) return rc;
-    if (d->stream_T[(size_t)s] == 0) {
-        // init() immediately followed by finish(): run the pending init so state is defined
-        const int zero = 0;
-        HIPCHK(hipMemcpyAsync(d->d_T + s, &zero, sizeof(int), hipMemcpyHostToDevice, d->s_search));
-        hipLaunchKernelGGL(jd_search_kernel, dim3(1), dim3(NT), 0, d->s_search, d->C, d->d_streams, s, d->d_T,
-                           d->d_ll[0], 0LL, 0, d->Fc);
-    }
-    hipLaunchKernelGGL(jd_finish_kernel, dim3(1), dim3(64), 0, d->s_search, d->d_streams, s, 1);
+    if (d->stream_T[(size_t)s] == 0) launch_init(d, 1, s, d->s_search);   // init() directly followed by finish()
+    hipLaunchKernelGGL(jd_finish_kernel, dim3(1), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, s, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(d->s_search));
     // results of stream s are stored at result slot s

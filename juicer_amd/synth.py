@@ -127,17 +127,34 @@ def make_models(seed: int, n_gmm: int, n_hmm: int, n_mix: int, D: int = 39,
 
 
 def make_wfst(seed: int, am: SynthAM, n_words: int, n_succ: int,
-              pron_len=(2, 5), with_sp: bool = False) -> SynthNet:
+              pron_len=(2, 5), with_sp: bool = False, hub: str = "flat",
+              n_phones: int = 40, eps_word_frac: float = 0.02) -> SynthNet:
     """Bigram-shaped C.L.G: state 0 = <s> history (initial), states 1..V = word
     histories (all final), state V+1 = unigram hub reached by back-off epsilon
     arcs.  Every (history, successor word) pair owns an un-shared chain of phone
-    arcs; hub words start with an eps:word arc (word label on an epsilon input).
+    arcs.  hub="flat": every hub word starts with an eps:word arc (word label on
+    an epsilon input; a stress case).  hub="tree": the hub is a lexicon prefix
+    tree with tropical weight pushing, as det(L.G) gives a back-off state; word
+    labels sit on the per-word last phone arc (a fraction eps_word_frac of the
+    words get an eps:word arc instead).
     """
     rng = np.random.default_rng(seed)
     V, K = n_words, min(n_succ, n_words)
     n_real_hmm = am.n_hmm - (1 if am.sp_hmm >= 0 else 0)
     plen = rng.integers(pron_len[0], pron_len[1] + 1, size=V)
-    prons = [rng.integers(0, n_real_hmm, size=int(l)).astype(np.int32) for l in plen]
+    if hub == "tree":
+        # triphone-like naming: word-initial model = base phone, later ones hashed from (prev, cur)
+        P = min(n_phones, max(2, n_real_hmm // 2))
+        prons = []
+        for l in plen:
+            ph = rng.integers(0, P, size=int(l))
+            hm = [int(ph[0])]
+            for k in range(1, int(l)):
+                hm.append(P + (int(ph[k - 1]) * 7919 + int(ph[k]) * 104729 + k * 31) % (n_real_hmm - P))
+            prons.append(np.asarray(hm, dtype=np.int32))
+    else:
+        prons = [rng.integers(0, n_real_hmm, size=int(l)).astype(np.int32) for l in plen]
+    hub_kind = hub
     hub = V + 1
     nxt = V + 2                       # next free chain state id
     src, dst, il, ol, wf = [], [], [], [], []
@@ -178,8 +195,57 @@ def make_wfst(seed: int, am: SynthAM, n_words: int, n_succ: int,
             add_chain(h, int(succ[h, k]), float(lm_cost[h, k]), bool(label_first[h, k]), False)
         src.append(h); dst.append(hub); il.append(0); ol.append(0); wf.append(float(rng.uniform(1.0, 4.0)))
     uni = rng.uniform(4.0, 12.0, size=V)
-    for w in range(V):
-        add_chain(hub, w, float(uni[w]), True, True)
+    if hub_kind == "flat":
+        for w in range(V):
+            add_chain(hub, w, float(uni[w]), True, True)
+    else:
+        # prefix tree over the first L-1 models of each word; the last model arc is per word
+        children = {}                     # (node, hmm) -> child node
+        node_words = {hub: []}            # node -> words ending right below it
+        node_min = {}
+        def child(nd, hm):
+            nonlocal nxt
+            key = (nd, hm)
+            if key not in children:
+                children[key] = nxt; node_words[nxt] = []; nxt += 1
+            return children[key]
+        ends = []
+        for w in range(V):
+            nd = hub
+            for hm in prons[w][:-1]:
+                nd = child(nd, int(hm))
+            node_words[nd].append(w)
+        kids = {}
+        for (nd, hm), ch in children.items():
+            kids.setdefault(nd, []).append((hm, ch))
+        def min_cost(nd):                 # tropical "distance to the cheapest word" below nd
+            if nd in node_min:
+                return node_min[nd]
+            m = min([float(uni[w]) for w in node_words[nd]] + [min_cost(ch) for _, ch in kids.get(nd, [])])
+            node_min[nd] = m
+            return m
+        import sys as _sys
+        _sys.setrecursionlimit(max(10000, _sys.getrecursionlimit()))
+        eps_w = rng.random(size=V) < eps_word_frac
+        stack = [hub]
+        while stack:
+            nd = stack.pop()
+            base = min_cost(nd)
+            for hm, ch in sorted(kids.get(nd, [])):
+                src.append(nd); dst.append(ch); il.append(hm + 1); ol.append(0); wf.append(min_cost(ch) - base)
+                stack.append(ch)
+            for w in node_words[nd]:
+                cur, cost = nd, float(uni[w]) - base
+                if eps_w[w]:
+                    src.append(cur); dst.append(nxt); il.append(0); ol.append(w + 1); wf.append(cost)
+                    cur = nxt; nxt += 1; cost = 0.0
+                lab = 0 if eps_w[w] else w + 1
+                if use_sp:
+                    src.append(cur); dst.append(nxt); il.append(int(prons[w][-1]) + 1); ol.append(lab); wf.append(cost)
+                    src.append(nxt); dst.append(1 + w); il.append(am.sp_hmm + 1); ol.append(0); wf.append(0.0)
+                    nxt += 1
+                else:
+                    src.append(cur); dst.append(1 + w); il.append(int(prons[w][-1]) + 1); ol.append(lab); wf.append(cost)
 
     src = np.asarray(src, dtype=np.int32); dst = np.asarray(dst, dtype=np.int32)
     il = np.asarray(il, dtype=np.int32); ol = np.asarray(ol, dtype=np.int32)
@@ -193,12 +259,12 @@ def make_wfst(seed: int, am: SynthAM, n_words: int, n_succ: int,
 
 
 def make_wfst_sized(seed: int, am: SynthAM, target_arcs: int, n_words: int,
-                    pron_len=(2, 5), with_sp: bool = False) -> SynthNet:
+                    pron_len=(2, 5), with_sp: bool = False, hub: str = "tree") -> SynthNet:
     """Pick the bigram fan-out so that the graph has about target_arcs arcs."""
     mean_len = 0.5 * (pron_len[0] + pron_len[1]) + (1.0 if with_sp else 0.0)
     k = int(round((target_arcs - n_words * (mean_len + 2.0)) / ((n_words + 1) * mean_len)))
     k = max(1, min(k, n_words))
-    return make_wfst(seed, am, n_words, k, pron_len=pron_len, with_sp=with_sp)
+    return make_wfst(seed, am, n_words, k, pron_len=pron_len, with_sp=with_sp, hub=hub)
 
 
 def sample_utterance(seed: int, net: SynthNet, am: SynthAM, n_words: int,
@@ -268,14 +334,16 @@ def config_small(seed: int = 7, n_utts: int = 4, with_sp: bool = True, sep: floa
 
 
 def config_c2(seed: int = 0, n_utts: int = 64, target_arcs: int = 1_000_000, n_gmm: int = 3000,
-              n_hmm: int = 8000, n_mix: int = 16, n_words: int = 5000, sep: float = 0.35,
-              utt_words=(9, 28)):
-    """BASELINE.json configs[1]/[2]: ~1M-arc graph, 3k tied states x 16 mix."""
+              n_hmm: int = 8000, n_mix: int = 16, n_words: int = 5000, sep: float = 1.0,
+              utt_words=(9, 28), utt_offset: int = 0):
+    """BASELINE.json configs[1]/[2]: ~1M-arc graph, 3k tied states x 16 mix.
+    The graph and models depend on `seed` only; utterance u of the global batch
+    is drawn from seed + 1000 + utt_offset + u, so ranks can own disjoint shards."""
     am = make_models(seed, n_gmm=n_gmm, n_hmm=n_hmm, n_mix=n_mix, n_tm=48, sep=sep)
     net = make_wfst_sized(seed + 100, am, target_arcs, n_words)
-    rng = np.random.default_rng(seed + 300)
     feats, words = [], []
-    for u in range(n_utts):
+    for u in range(utt_offset, utt_offset + n_utts):
+        rng = np.random.default_rng(seed + 300 + u)
         x, w = sample_utterance(seed + 1000 + u, net, am, int(rng.integers(utt_words[0], utt_words[1] + 1)))
         feats.append(x); words.append(w)
     return am, net, feats, words

@@ -81,7 +81,10 @@ def test_small_decode_batch(small, bi):
     from oracle.oracle import OracleDecoder
     gnet, gam, onet, oam, feats, words = small
     kw = BEAMS[bi]
-    gd = capi.Decoder(gnet, gam, max_streams=len(feats), **kw)
+    # without a (tight) beam every word-end token writes a Path per hub word: tens of
+    # millions of records (the reference garbage-collects them); size the arena for it
+    big = (1 << 25) if kw.get("main_beam", 0.0) in (0.0, 200.0) and not kw.get("max_hyps") else 0
+    gd = capi.Decoder(gnet, gam, max_streams=len(feats), max_paths=big, **kw)
     od = OracleDecoder(onet, oam, **kw)
     gs = gd.decode_batch(feats)
     nexact = 0
