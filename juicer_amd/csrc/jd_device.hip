@@ -280,6 +280,7 @@ struct StreamDev {      // per-stream arenas (cold)
     Tok *tok; SlotMeta *meta; int *act[2]; int *free_stk;
     unsigned long long *ekey;         // per ARC: best entry-token candidate of this frame (0 = none)
     int *map;                         // per ARC: instance slot or -1 (WFSTTransition::hook)
+    unsigned long long *skey[2];      // per STATE: best frontier item arriving there (round parity)
     int *touched;                     // arcs whose ekey became non-zero this frame
     Tok *item_tok; int4 *item_info;   // frontier items: token + {arc, outLabel, toState, -}
     PathRec *paths; int *hist;
@@ -700,7 +701,7 @@ __device__ __forceinline__ void stage_flush(const DecConst &C, StreamCtl &c, con
 }
 
 __device__ __forceinline__ void expand_item(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &stage,
-                                            int frame, float endTh, float wordTh, bool have, int ii,
+                                            int frame, float endTh, float wordTh, bool have, int ii, int parity,
                                             int *items_counter, int items_base, int &n_arcs, int &n_paths_made)
 {
     const int lane = lane_id();
@@ -708,9 +709,21 @@ __device__ __forceinline__ void expand_item(const DecConst &C, StreamCtl &c, con
     const float INF = __builtin_inff();
     Tok t = null_tok();
     int rs = 0, deg = 0;
+    int4 info = make_int4(-1, 0, 0, 0);
+    if (have) {
+        info = S.item_info[ii];
+        if (info.x >= 0) {
+            // State-level recombination: of all items that reached state info.z in this round only
+            // the best one is expanded (every item would add the same arc weights, so by
+            // monotonicity of float addition no other item can win anything downstream).
+            unsigned long long *sk = S.skey[parity] + info.z;
+            const unsigned long long kv = __hip_atomic_load(sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have = (unsigned)(kv & 0xffffffffULL) == (unsigned)ii && kv != 0ULL;
+            if (have && er == 0) __hip_atomic_store(sk, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (have) {
         t = S.item_tok[ii];
-        const int4 info = S.item_info[ii];
         int state = C.init_state;
         if (info.x >= 0) {
             if (info.y != 0) {                                         // :497-509 word boundary
@@ -791,9 +804,43 @@ __device__ __forceinline__ void expand_item(const DecConst &C, StreamCtl &c, con
         const int idx = wave_append(mk, items_counter);
         if (mk) {
             const int pos = items_base + idx;
-            if (pos < C.cap_items) { S.item_tok[pos] = u; S.item_info[pos] = uinfo; }
-            else c.error = -42;
+            if (pos < C.cap_items) {
+                S.item_tok[pos] = u; S.item_info[pos] = uinfo;
+                atomicMax(S.skey[parity ^ 1] + uinfo.z, ((unsigned long long)f2o(u.score) << 32) | (unsigned)pos);
+            } else c.error = -42;
         }
+    }
+}
+
+// doHMMExternalPropagation (:937-982), selection part: every live exit token that beats its
+// end/word threshold (:952-962) is a frontier item; it bids for its destination state.
+__global__ __launch_bounds__(KT) void k_select0(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B)
+{
+    __shared__ int sh_pre[MAX_B + 1];
+    __shared__ int sh_w[8];
+    const int tid = threadIdx.x, lane = lane_id();
+    const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
+        const StreamCtl &c = ctl[s0 + s];
+        return c.active == 1 ? (pk_cnt0(c.pkA) + KT - 1) / KT : 0;
+    });
+    for (int u = blockIdx.x; u < total; u += gridDim.x) {
+        const int sl = find_stream(sh_pre, B, u);
+        StreamCtl &c = ctl[s0 + sl];
+        const StreamDev &S = streams[s0 + sl];
+        const float bestA = o2f(c.best);
+        const float endTh = (C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;       // :349
+        const float wordTh = (C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;    // :350
+        const int n = pk_cnt0(c.pkA);
+        const int k = (u - sh_pre[sl]) * KT + tid;
+        bool pass = false;
+        if (k < n) {
+            const float sc = S.item_tok[k].score;
+            const int4 info = S.item_info[k];
+            pass = sc > ((info.y != 0) ? wordTh : endTh);
+            if (pass) atomicMax(S.skey[0] + info.z, ((unsigned long long)f2o(sc) << 32) | (unsigned)k);
+        }
+        const int np = __popcll(__ballot(pass));
+        if (lane == 0 && np) atomicAdd(&c.fr[ST_PEND], np);
     }
 }
 
@@ -807,7 +854,7 @@ __global__ __launch_bounds__(KT) void k_expand(DecConst C, StreamCtl *ctl, Strea
     __shared__ int sh_w[8];
     __shared__ WaveStage sh_stage[KT / 64];
     constexpr int GPW = 64 / EG;                                       // items per wave-iteration
-    constexpr int IPW = 16;                                            // items per wave per unit
+    constexpr int IPW = GPW;                                           // items per wave per unit
     constexpr int PER = IPW * (KT / 64);                               // items per unit
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     if (lane == 0) sh_stage[wid].n = 0;
@@ -853,17 +900,11 @@ __global__ __launch_bounds__(KT) void k_expand(DecConst C, StreamCtl *ctl, Strea
         const int kbase = (u - sh_pre[sl]) * PER + wid * IPW;
         for (int it = 0; it < IPW; it += GPW) {
             const int k = kbase + it + (lane / EG);
-            bool have = k < nin;
+            const bool have = k < nin;
             const int ii = in_base + k;
-            if (ROUND == 0 && have && !init) {                         // :952-962 threshold on the exit token
-                const float sc = S.item_tok[ii].score;
-                const int outl = S.item_info[ii].y;
-                have = sc > ((outl != 0) ? wordTh : endTh);
-                if (have && (lane & (EG - 1)) == 0) ++n_pend;
-            }
             if (!__any(have)) continue;
-            expand_item(C, c, S, stage, c.frame, endTh, wordTh, have, ii, (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base,
-                        n_arcs, n_paths_made);
+            expand_item(C, c, S, stage, c.frame, endTh, wordTh, have, ii, ROUND & 1, (ROUND == 0) ? &c.cnt1 : &c.cnt2,
+                        out_base, n_arcs, n_paths_made);
         }
     }
     if (cur_s >= 0) flush(cur_s);
@@ -887,13 +928,14 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
     const int base = pk_cnt0(c.pkA) + c.cnt1;
     int r0 = 0, r1 = c.cnt2;                       // window within the tail region [base + r0, base + r1)
     const int tail_base = base + c.cnt2;           // items appended here: tail_base + cnt_tail++
-    int n_arcs = 0, n_paths_made = 0;
+    int n_arcs = 0, n_paths_made = 0, parity = 0;
     while (r1 > r0) {
         for (int k0 = r0; k0 < r1; k0 += PER) {
             const int k = k0 + (tid / EG);
-            expand_item(C, c, S, stage, c.frame, endTh, wordTh, k < r1, base + k, &c.cnt_tail, tail_base, n_arcs,
-                        n_paths_made);
+            expand_item(C, c, S, stage, c.frame, endTh, wordTh, k < r1, base + k, parity, &c.cnt_tail, tail_base,
+                        n_arcs, n_paths_made);
         }
+        parity ^= 1;
         __syncthreads();
         r0 = r1;
         r1 = c.cnt2 + __hip_atomic_load(&c.cnt_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1307,6 +1349,7 @@ static int ensure_arenas(jd_dec *d)
         A(S.act[0], d->cap_slots); A(S.act[1], d->cap_slots);
         A(S.free_stk, d->cap_slots);
         A(S.ekey, d->net->n_arcs); A(S.map, d->net->n_arcs);
+        A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states);
         A(S.touched, d->cap_items);
         A(S.item_tok, d->cap_items); A(S.item_info, d->cap_items);
         A(S.paths, d->cap_paths);
@@ -1317,6 +1360,8 @@ static int ensure_arenas(jd_dec *d)
         S.res_cap = d->res_cap;
         HIPCHK(hipMemset(S.ekey, 0, (size_t)d->net->n_arcs * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.map, 0xff, (size_t)d->net->n_arcs * sizeof(int)));
+        HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.hist, 0, HIST_MAX_BINS * sizeof(int)));
     }
     rc = dmalloc(d, &d->d_streams, (size_t)B);
@@ -1377,6 +1422,8 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
         if (K.error) {      // arenas may be inconsistent after an abort: wipe them for the next init
             HIPCHK(hipMemset(S.ekey, 0, (size_t)d->net->n_arcs * sizeof(unsigned long long)));
             HIPCHK(hipMemset(S.map, 0xff, (size_t)d->net->n_arcs * sizeof(int)));
+            HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
             const int zero = 0;
             HIPCHK(hipMemcpy((char *)(d->d_ctl + s0 + i) + offsetof(StreamCtl, n_act), &zero, sizeof(int),
                              hipMemcpyHostToDevice));
@@ -1414,8 +1461,9 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
     return first_err;
 }
 
-#define GRID_A 2048
-#define GRID_X 1024
+#define GRID_A 4096
+#define GRID_X 2048
+#define GRID_S 512
 
 // recognitionStart for every stream of [s0, s0+nb) that is flagged needs_init
 static void launch_init(jd_dec *d, int nb, int s0, hipStream_t st)
@@ -1438,6 +1486,7 @@ static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll
     else
         hipLaunchKernelGGL(k_phase_a<8>, dim3(GRID_A), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb, ll,
                            ll_stride, f0);
+    hipLaunchKernelGGL(k_select0, dim3(GRID_S), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
     hipLaunchKernelGGL(k_expand<0>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
     hipLaunchKernelGGL(k_expand<1>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
     hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
