@@ -220,7 +220,8 @@ struct DecConst {
     const int *row_ptr; const JdArc *arcs; const float *fin_w; int init_state;
     // models
     int G, max_n, n_tm;
-    const int *hmm_n, *hmm_tm, *hmm_gmm; const float *hmm_tee; const float *trP; const int *se32;
+    const int *hmm_n, *hmm_tm, *hmm_gmm; const float *hmm_tee; const float *hmm_tmax0;
+    const float *trP; const int *se32;
     // pruning (WFSTDecoderLite ctor, WFSTDecoderLite.cpp:38-82)
     float start_win, emit_win, end_win, word_win;
     int max_hyps, hist_min, hist_max, hist_nbins;
@@ -230,13 +231,18 @@ struct DecConst {
 
 enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_INSTS, ST_N };
 
-// Everything phase A needs to know about an active arc instance (NetInst,
-// WFSTDecoderLite.h:66-75) in one 48-byte record: one hop from the active list.
-struct __align__(16) SlotMeta {
-    int arc, hmm, n_tm, out;          // n_tm = nStates | transMat << 8
-    int to, g0, g1, g2;               // g*: tied-state ids of emitting states 1..6
-    int g3, g4, g5, pad;
+// An active arc instance (NetInst, WFSTDecoderLite.h:66-75) is ONE self-contained record,
+// updated in place: header (arc, topology, tied-state ids) + its tokens.  With <= 5 HMM
+// states it is exactly one 128-byte HBM line (REC_INTS = 32); up to 8 states take two lines.
+//   ints [0..3]  = arc, nStates | transMat << 8, outLabel, toState
+//   ints [4..7]  = g0, g1, g2, hmm          (tied-state ids of emitting states 1..3)
+//   GS == 4: tokens at int offset 8;  GS == 8: ints [8..11] = g3, g4, g5, -, tokens at 12
+template <int GS> struct RecLayout {
+    static constexpr int REC_INTS = (GS == 4) ? 32 : 64;
+    static constexpr int TOK_OFF = (GS == 4) ? 8 : 12;
 };
+// per-arc search state: recombination key of this frame + the instance slot (hook)
+struct __align__(16) ArcState { unsigned long long key; int slot; int pad; };
 
 // hot per-stream scalars.  Line 0 is read-mostly while the frame kernels run (written by
 // k_boundary); every atomically updated counter sits on its own 128-byte line so that the
@@ -246,7 +252,7 @@ struct __align__(16) SlotMeta {
 #define PK_MASK 0x1fffffULL
 struct __align__(128) StreamCtl {
     // ---- line 0: persistent / per-frame constants
-    int par;            // token-half parity: tokens of slot s live at tok[(s*2+par)*max_n ..]
+    int skipped_prev;   // instances whose creation was skipped last frame (still counted, see k_resolve)
     int lst;            // which active list is current
     int n_act;          // entries in the current active list
     int hw;             // slot high-water mark
@@ -265,6 +271,7 @@ struct __align__(128) StreamCtl {
     __align__(128) int cnt_tail;             // items produced by the tail rounds
     __align__(128) int n_touched;
     __align__(128) int n_alloc;              // instances attached this frame (= new active entries)
+    __align__(128) int n_skipped;            // hopeless instances not materialised this frame
     __align__(128) int n_paths;
     __align__(128) unsigned long long final_key;
     __align__(128) int fr[ST_N];             // per-frame work counters (flushed per block run)
@@ -277,9 +284,9 @@ __device__ __forceinline__ int pk_cnt0(unsigned long long v) { return (int)((v >
 __device__ __forceinline__ int pk_ndead(unsigned long long v) { return (int)((v >> PK_SHIFT2) & PK_MASK); }
 
 struct StreamDev {      // per-stream arenas (cold)
-    Tok *tok; SlotMeta *meta; int *act[2]; int *free_stk;
-    unsigned long long *ekey;         // per ARC: best entry-token candidate of this frame (0 = none)
-    int *map;                         // per ARC: instance slot or -1 (WFSTTransition::hook)
+    int *rec;                         // instance records (RecLayout), cap_slots of them
+    int *act[2]; int *free_stk;
+    ArcState *ast;                    // per ARC: {best entry-token candidate of this frame, slot}
     unsigned long long *skey[2];      // per STATE: best frontier item arriving there (round parity)
     int *touched;                     // arcs whose ekey became non-zero this frame
     Tok *item_tok; int4 *item_info;   // frontier items: token + {arc, outLabel, toState, -}
@@ -383,7 +390,8 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         if (!c.needs_init) return;
         // drop whatever the previous utterance left behind
         const int *actc = S.act[c.lst];
-        for (int q = lane; q < c.n_act; q += 64) S.map[S.meta[actc[q]].arc] = -1;
+        const int rec_ints = (C.max_n <= 5) ? 32 : 64;
+        for (int q = lane; q < c.n_act; q += 64) S.ast[S.rec[(size_t)actc[q] * rec_ints]].slot = -1;
         if (use_hist) for (int b = lane; b < C.hist_nbins; b += 64) S.hist[b] = 0;
         __syncthreads();
         if (lane == 0) {
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
             c.best_emit = LZ; c.normalise = 0.0f; c.emitTh = LZ; c.startTh = LZ;
             c.best = f2o(LZ); c.pkA = 1ULL << PK_SHIFT1;                         // cnt0 = 1: the start token
             c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
-            c.n_alloc = 0; c.n_touched = 0; c.final_key = 0ULL;
+            c.n_alloc = 0; c.n_touched = 0; c.final_key = 0ULL; c.n_skipped = 0; c.skipped_prev = 0;
             for (int k = 0; k < ST_N; ++k) { c.fr[k] = 0; c.st[k] = 0; }
             c.best_final = null_tok();
             Tok z; z.score = 0.0f; z.ac = 0.0f; z.lm = 0.0f; z.path = -1;       // :221-226
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         if (lane == 0) {
             c.n_act = c.n_alloc; c.hw = c.n_alloc;
             c.best_emit = o2f(c.best);
-            c.par ^= 1; c.lst ^= 1;
+            c.lst ^= 1;
             for (int k = 0; k < ST_N; ++k) { c.st[k] += c.fr[k]; c.fr[k] = 0; }
             c.st[ST_MODELS] = 0;
             c.needs_init = 0; c.active = 0;
@@ -433,9 +441,11 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
                 bf.score = o2f((unsigned)(key >> 32)); bf.ac = it.ac; bf.lm = it.lm + fw; bf.path = it.path;
                 c.best_final = bf;
             } else c.best_final = null_tok();
-            c.fr[ST_MODELS] = pk_nB(pk) + c.n_alloc;                             // :981
+            c.fr[ST_MODELS] = pk_nB(pk) + c.n_alloc + c.n_skipped;               // :981
+            c.fr[ST_INSTS] += c.skipped_prev;       // skipped instances would have been processed (and died) now
+            c.skipped_prev = c.n_skipped;
             for (int k = 0; k < ST_N; ++k) { c.st[k] += c.fr[k]; c.fr[k] = 0; }
-            c.par ^= 1; c.lst ^= 1;
+            c.lst ^= 1;
             c.frame += 1;
             if (c.n_paths > C.cap_paths) c.n_paths = C.cap_paths;
         }
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         c.startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;       // :337
         c.best = f2o(LZ); c.pkA = 0ULL;                                          // :905
         c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
-        c.n_alloc = 0; c.n_touched = 0;
+        c.n_alloc = 0; c.n_touched = 0; c.n_skipped = 0;
         c.final_key = 0ULL;                                                      // :316 bestFinalToken = nullToken
         c.active = 1;
     }
@@ -507,6 +517,7 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
     __shared__ unsigned long long sh_pk;
     __shared__ int sh_acc[2][5];                                       // [run parity][PEMIT, EMIT, INSTS, END, best]
     constexpr int PER = KT / GS;                                       // instances per unit
+    typedef RecLayout<GS> RL;
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int MN = C.max_n;
     if (tid < 10) (&sh_acc[0][0])[tid] = 0;
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
         int *acc = sh_acc[run & 1];
         StreamCtl &c = ctl[s];
         const StreamDev &S = streams[s];
-        const int n_act = c.n_act, par = c.par;
+        const int n_act = c.n_act;
         const float normalise = c.normalise, emitTh = c.emitTh, startTh = c.startTh;
         const int *act_cur = S.act[c.lst];
         int *act_next = S.act[c.lst ^ 1];
@@ -550,38 +561,37 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
         int slot = -1, arc = -1, n = 0;
         Tok nw = null_tok(), ex = null_tok();
         int4 exinfo = make_int4(-1, 0, 0, 0);
-        Tok *tnew = nullptr;
+        Tok *tk = nullptr;                                             // the instance's tokens (updated in place)
         const float *trP = C.trP;
         const int *se = C.se32;
         if (valid) {
             slot = act_cur[q];
-            const int4 *mp = (const int4 *)(S.meta + slot);
-            const int4 m0 = mp[0], m1 = mp[1];
-            arc = m0.x;
-            n = m0.z & 0xff;
-            const int tm = m0.z >> 8;
-            const Tok *told = S.tok + ((size_t)slot * 2 + par) * MN;
-            tnew = S.tok + ((size_t)slot * 2 + (par ^ 1)) * MN;
+            int *rec = S.rec + (size_t)slot * RL::REC_INTS;
+            const int4 h0 = *(const int4 *)rec, h1 = *(const int4 *)(rec + 4);
+            arc = h0.x;
+            n = h0.y & 0xff;
+            const int tm = h0.y >> 8;
+            tk = (Tok *)(rec + RL::TOK_OFF);
             trP = C.trP + (size_t)tm * MN * MN;
             se = C.se32 + (size_t)tm * MN;
-            exinfo = make_int4(arc, m0.w, m1.x, 0);
+            exinfo = make_int4(arc, h0.z, h0.w, 0);
             const int j = r + 1;
             if (j < n - 1) {                                           // :387-424 emitting state j
                 int gmj;
-                if (GS == 4) gmj = (r == 0) ? m1.y : (r == 1) ? m1.z : m1.w;
+                if (GS == 4) gmj = (r == 0) ? h1.x : (r == 1) ? h1.y : h1.z;
                 else {
-                    const int4 m2 = mp[2];
-                    gmj = (r == 0) ? m1.y : (r == 1) ? m1.z : (r == 2) ? m1.w : (r == 3) ? m2.x : (r == 4) ? m2.y : m2.z;
+                    const int4 h2 = *(const int4 *)(rec + 8);
+                    gmj = (r == 0) ? h1.x : (r == 1) ? h1.y : (r == 2) ? h1.z : (r == 3) ? h2.x : (r == 4) ? h2.y : h2.z;
                 }
                 const float outp = llrow[gmj];                         // :411
                 const int sev = se[j];
                 const int st = sev & 0xffff, en = sev >> 16;
-                Tok src = told[st];
+                Tok src = tk[st];
                 if (st == 0 && src.score > LZ && src.score < startTh) src = null_tok();   // :915-918
                 float btp = trP[st * MN + j];
                 float best = src.score + btp;
                 for (int i = st + 1; i < en; ++i) {
-                    const Tok cnd = told[i];
+                    const Tok cnd = tk[i];
                     const float tp = trP[i * MN + j];
                     const float tmp = cnd.score + tp;
                     if (tmp > best) { best = tmp; btp = tp; src = cnd; }
@@ -632,9 +642,11 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
         }
         const unsigned long long bemit = __ballot(emit_live);
         const bool slot_live = ((bemit >> gb) & ((1ull << GS) - 1ull)) != 0ull;
+        // in-place update: every load of the group's old tokens precedes these stores in the
+        // wave's instruction stream (the shuffles above consumed them)
         if (valid && slot_live) {
-            if (r + 1 < n - 1) tnew[r + 1] = nw;
-            if (r == GS - 1) { tnew[0] = null_tok(); tnew[n - 1] = null_tok(); }   // :428-436, :964
+            if (r + 1 < n - 1) tk[r + 1] = nw;
+            if (r == GS - 1) { tk[0] = null_tok(); tk[n - 1] = null_tok(); }       // :428-436, :964
         }
         const bool live = valid && r == 0 && slot_live;
         const bool dead = valid && r == 0 && !slot_live;
@@ -671,7 +683,7 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
         }
         if (dead) {                                                    // returnNetInst :777-797
             S.free_stk[c.n_free + pk_ndead(bs) + pk_ndead(pre) + rank_in(bd)] = slot;
-            S.map[arc] = -1;
+            S.ast[arc].slot = -1;
         }
     }
     __syncthreads();
@@ -778,7 +790,7 @@ __device__ __forceinline__ void expand_item(const DecConst &C, StreamCtl &c, con
             } else {                                                   // :560-582 entry-token recombination
                 const float ns = t.score + Bk.w;
                 const unsigned long long key = ((unsigned long long)f2o(ns) << 32) | (unsigned)ii;
-                const unsigned long long old = atomicMax(&S.ekey[b], key);
+                const unsigned long long old = atomicMax(&S.ast[b].key, key);
                 touch = (old == 0ULL);
                 tb = b;
                 if (Bk.in & TEE_FLAG) {                                // :584-600 tee model
@@ -960,6 +972,7 @@ __global__ __launch_bounds__(KT) void k_resolve(DecConst C, StreamCtl *ctl, Stre
     __shared__ unsigned sh_best[2];
     const int tid = threadIdx.x, lane = lane_id();
     const int MN = C.max_n;
+    const int rec_ints = (MN <= 5) ? 32 : 64, tok_off = (MN <= 5) ? 8 : 12;
     if (tid < 2) sh_best[tid] = 0u;
     const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
         const StreamCtl &c = ctl[s0 + s];
@@ -981,59 +994,70 @@ __global__ __launch_bounds__(KT) void k_resolve(DecConst C, StreamCtl *ctl, Stre
         const StreamDev &S = streams[s];
         const int nt = c.n_touched < C.cap_items ? c.n_touched : C.cap_items;
         const int q = (u - sh_pre[sl]) * KT + tid;
-        const int par_next = c.par ^ 1;
         int *act_next = S.act[c.lst ^ 1];
         const unsigned long long pk = c.pkA;
         const int nfree0 = c.n_free + pk_ndead(pk), hw0 = c.hw, nB = pk_nB(pk);
-        bool need = false, win = false;
+        // An instance whose entry token provably fails next frame's emit threshold is not
+        // materialised: next frame normalises by bestEmitScore >= bestA (the phase-A best, final
+        // now) and emitTh >= -mainBeam, and float add/sub are monotone, so
+        //     (entry + max_j trP[0][j]) - bestA <= -mainBeam   ==>   pruned at :409 next frame.
+        // The reference would attach it, count it and let it die; we only count it.
+        const float bestA = o2f(c.best);
+        const bool can_skip = C.emit_win > 0.0f && bestA > LZ && c.active == 1;
+        bool need = false, win = false, skip = false;
         int b = -1, slot = -1, ii = 0;
         float sc = LZ;
         JdArc Bk{0, 0.0f, 0, 0};
         if (q < nt) {
             b = S.touched[q];
-            const unsigned long long key = atomicExch(&S.ekey[b], 0ULL);
+            ArcState *as = S.ast + b;
+            const unsigned long long key = atomicExch(&as->key, 0ULL);
             sc = o2f((unsigned)(key >> 32));
             if (sc > LZ) {
                 win = true;
                 ii = (int)(unsigned)(key & 0xffffffffULL);
                 Bk = C.arcs[b];
-                slot = S.map[b];
+                slot = as->slot;
                 need = slot < 0;
+                if (need && can_skip) {
+                    const float tmax = C.hmm_tmax0[(Bk.in & ~TEE_FLAG) - 1];
+                    if ((sc + tmax) - bestA <= -C.emit_win) { skip = true; need = false; }
+                }
             }
         }
+        const int nskip = __popcll(__ballot(skip));
+        if (lane == 0 && nskip) atomicAdd(&c.n_skipped, nskip);
         // block-aggregated allocation: one returning atomic per unit
         int tot_need;
         const int myk = block_excl_scan(need ? 1 : 0, sh_w, tot_need);
         if (tid == 0) sh_base = tot_need ? atomicAdd(&c.n_alloc, tot_need) : 0;
         __syncthreads();
+        unsigned mo = win ? f2o(sc) : 0u;                              // :572-573 (skipped ones can never raise it)
         if (need) {
             const int k = sh_base + myk;
             const int ns_ = (k < nfree0) ? S.free_stk[nfree0 - 1 - k] : hw0 + (k - nfree0);
             if (ns_ >= C.cap_slots) { c.error = -41; slot = -1; }
-            else {
+            else {                                                     // attachNetInst :751-774
                 slot = ns_;
                 const int hm = (Bk.in & ~TEE_FLAG) - 1;
                 const int n = C.hmm_n[hm];
                 const int *hg = C.hmm_gmm + (size_t)hm * MN;
-                SlotMeta m;
-                m.arc = b; m.hmm = hm; m.n_tm = n | (C.hmm_tm[hm] << 8); m.out = Bk.out; m.to = Bk.to;
-                m.g0 = (1 < n - 1) ? hg[1] : 0; m.g1 = (2 < n - 1) ? hg[2] : 0; m.g2 = (3 < n - 1) ? hg[3] : 0;
-                m.g3 = (4 < n - 1) ? hg[4] : 0; m.g4 = (5 < n - 1) ? hg[5] : 0; m.g5 = (6 < n - 1) ? hg[6] : 0;
-                m.pad = 0;
-                S.meta[slot] = m;
-                Tok *tp = S.tok + ((size_t)slot * 2 + par_next) * MN;
+                int *rec = S.rec + (size_t)slot * rec_ints;
+                *(int4 *)rec = make_int4(b, n | (C.hmm_tm[hm] << 8), Bk.out, Bk.to);
+                *(int4 *)(rec + 4) = make_int4((1 < n - 1) ? hg[1] : 0, (2 < n - 1) ? hg[2] : 0, (3 < n - 1) ? hg[3] : 0, hm);
+                if (rec_ints == 64)
+                    *(int4 *)(rec + 8) = make_int4((4 < n - 1) ? hg[4] : 0, (5 < n - 1) ? hg[5] : 0, (6 < n - 1) ? hg[6] : 0, 0);
+                Tok *tp = (Tok *)(rec + tok_off);
                 for (int qq = 1; qq < n; ++qq) tp[qq] = null_tok();
-                S.map[b] = slot;
+                S.ast[b].slot = slot;
                 act_next[nB + k] = slot;
             }
         }
-        unsigned mo = 0u;
         if (win && slot >= 0) {
             const Tok it = S.item_tok[ii];
             Tok e;
             e.score = sc; e.ac = it.ac; e.lm = it.lm + Bk.w; e.path = it.path;
-            S.tok[((size_t)slot * 2 + par_next) * MN] = e;
-            mo = f2o(sc);                                              // :572-573
+            *(Tok *)(S.rec + (size_t)slot * rec_ints + tok_off) = e;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_xor(mo, o); mo = y > mo ? y : mo; }
@@ -1182,7 +1206,7 @@ struct jd_dec {
     // device copies of static data
     int *d_row_ptr = nullptr; JdArc *d_arcs = nullptr; float *d_fin_w = nullptr;
     int *d_hmm_n = nullptr, *d_hmm_tm = nullptr, *d_hmm_gmm = nullptr, *d_se32 = nullptr;
-    float *d_hmm_tee = nullptr, *d_trP = nullptr;
+    float *d_hmm_tee = nullptr, *d_trP = nullptr, *d_hmm_tmax0 = nullptr;
     // per-stream state
     StreamDev *d_streams = nullptr;
     StreamCtl *d_ctl = nullptr;
@@ -1290,6 +1314,14 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     TRY(dupload(d, &d->d_hmm_tm, am->hmm_tm.data(), am->hmm_tm.size()));
     TRY(dupload(d, &d->d_hmm_gmm, am->hmm_gmm.data(), am->hmm_gmm.size()));
     TRY(dupload(d, &d->d_hmm_tee, am->hmm_tee.data(), am->hmm_tee.size()));
+    {   // largest log transition probability out of the entry state of every HMM (see k_resolve)
+        std::vector<float> tmax((size_t)am->n_hmm, LZ);
+        for (int h = 0; h < am->n_hmm; ++h) {
+            const float *t0 = am->trP.data() + (size_t)am->hmm_tm[(size_t)h] * am->max_n * am->max_n;
+            for (int j = 0; j < am->hmm_n[(size_t)h]; ++j) tmax[(size_t)h] = std::max(tmax[(size_t)h], t0[j]);
+        }
+        TRY(dupload(d, &d->d_hmm_tmax0, tmax.data(), tmax.size()));
+    }
     TRY(dupload(d, &d->d_trP, am->trP.data(), am->trP.size()));
     std::vector<int> se32((size_t)am->n_tm * am->max_n);
     for (size_t i = 0; i < se32.size(); ++i)
@@ -1299,6 +1331,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init;
     C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
     C.hmm_n = d->d_hmm_n; C.hmm_tm = d->d_hmm_tm; C.hmm_gmm = d->d_hmm_gmm; C.hmm_tee = d->d_hmm_tee;
+    C.hmm_tmax0 = d->d_hmm_tmax0;
     C.trP = d->d_trP; C.se32 = d->d_se32;
     // default arena sizes: sized for 288 GB of HBM, not for frugality
     d->cap_slots = std::min<int64_t>(net->n_arcs + 1024, 1 << 18);
@@ -1340,15 +1373,15 @@ static int ensure_arenas(jd_dec *d)
     const int B = d->max_streams, MN = d->am->max_n;
     d->C.cap_slots = (int)d->cap_slots; d->C.cap_items = (int)d->cap_items; d->C.cap_paths = (int)d->cap_paths;
     d->h_streams.assign((size_t)B, StreamDev());
+    std::vector<ArcState> ast0((size_t)d->net->n_arcs, ArcState{0ULL, -1, 0});
     for (int s = 0; s < B; ++s) {
         StreamDev &S = d->h_streams[(size_t)s];
         memset(&S, 0, sizeof S);
 #define A(p, n) do { rc = dmalloc(d, &(p), (size_t)(n)); if (rc) return rc; } while (0)
-        A(S.tok, d->cap_slots * 2 * MN);
-        A(S.meta, d->cap_slots);
+        A(S.rec, d->cap_slots * ((MN <= 5) ? 32 : 64));
         A(S.act[0], d->cap_slots); A(S.act[1], d->cap_slots);
         A(S.free_stk, d->cap_slots);
-        A(S.ekey, d->net->n_arcs); A(S.map, d->net->n_arcs);
+        A(S.ast, d->net->n_arcs);
         A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states);
         A(S.touched, d->cap_items);
         A(S.item_tok, d->cap_items); A(S.item_info, d->cap_items);
@@ -1358,8 +1391,7 @@ static int ensure_arenas(jd_dec *d)
         A(S.res_score, d->res_cap); A(S.res_ac, d->res_cap); A(S.res_lm, d->res_cap);
 #undef A
         S.res_cap = d->res_cap;
-        HIPCHK(hipMemset(S.ekey, 0, (size_t)d->net->n_arcs * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(S.map, 0xff, (size_t)d->net->n_arcs * sizeof(int)));
+        HIPCHK(hipMemcpy(S.ast, ast0.data(), (size_t)d->net->n_arcs * sizeof(ArcState), hipMemcpyHostToDevice));
         HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.hist, 0, HIST_MAX_BINS * sizeof(int)));
@@ -1420,8 +1452,10 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
             }
         }
         if (K.error) {      // arenas may be inconsistent after an abort: wipe them for the next init
-            HIPCHK(hipMemset(S.ekey, 0, (size_t)d->net->n_arcs * sizeof(unsigned long long)));
-            HIPCHK(hipMemset(S.map, 0xff, (size_t)d->net->n_arcs * sizeof(int)));
+            {
+                std::vector<ArcState> ast0((size_t)d->net->n_arcs, ArcState{0ULL, -1, 0});
+                HIPCHK(hipMemcpy(S.ast, ast0.data(), ast0.size() * sizeof(ArcState), hipMemcpyHostToDevice));
+            }
             HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
             HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
             const int zero = 0;
