@@ -79,6 +79,11 @@ int jd_net_create_csr(jd_net **out, int32_t n_states, int32_t init_state,
 int jd_net_load_fsm(jd_net **out, const char *fsm_path, const char *insyms_path,
                     const char *outsyms_path, float lm_scale, float ins_penalty);
 
+/* Read back the prepared CSR (host copies; any pointer may be NULL) - used by parity tests.
+ * fin_w has n_states entries, +inf for non-final states. */
+int jd_net_get_csr(const jd_net *n, int32_t *row_ptr, int32_t *to, float *w, int32_t *in, int32_t *outl,
+                   float *fin_w);
+
 int64_t jd_net_num_arcs(const jd_net *n);     /* WFSTNetwork::getNumTransitions */
 int32_t jd_net_num_states(const jd_net *n);   /* WFSTNetwork::getNumStates      */
 int32_t jd_net_init_state(const jd_net *n);   /* WFSTNetwork::getInitState      */

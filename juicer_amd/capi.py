@@ -66,7 +66,7 @@ class Hyp:
 # every symbol include/juicer_amd.h declares
 EXPORTS = [
     "jd_net_create_arcs", "jd_net_create_csr", "jd_net_load_fsm", "jd_net_num_arcs", "jd_net_num_states",
-    "jd_net_init_state", "jd_net_destroy", "jd_am_create_htk", "jd_am_num_hmms", "jd_am_num_gmms",
+    "jd_net_init_state", "jd_net_destroy", "jd_net_get_csr", "jd_am_create_htk", "jd_am_num_hmms", "jd_am_num_gmms",
     "jd_am_vec_size", "jd_am_max_states", "jd_am_get_flat", "jd_am_get_trans", "jd_am_destroy",
     "jd_dec_create", "jd_dec_destroy", "jd_dec_set_capacity", "jd_stream_init", "jd_stream_push",
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
@@ -167,6 +167,14 @@ class Network:
         _check(L.jd_net_load_fsm(C.byref(h), enc(fsm_path), enc(insyms_path), enc(outsyms_path),
                                  C.c_float(lm_scale), C.c_float(ins_penalty)))
         return cls(h)
+
+    def csr(self):
+        ns, na = self.n_states, self.n_arcs
+        rp = np.zeros(ns + 1, np.int32); to = np.zeros(na, np.int32); w = np.zeros(na, np.float32)
+        il = np.zeros(na, np.int32); ol = np.zeros(na, np.int32); fw = np.zeros(ns, np.float32)
+        _check(lib().jd_net_get_csr(self.h, _p(rp, C.c_int32), _p(to, C.c_int32), _p(w, C.c_float),
+                                    _p(il, C.c_int32), _p(ol, C.c_int32), _p(fw, C.c_float)))
+        return dict(row_ptr=rp, to=to, w=w, ilab=il, olab=ol, fin_w=fw)
 
     @property
     def n_arcs(self):

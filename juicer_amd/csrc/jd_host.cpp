@@ -200,6 +200,22 @@ extern "C" int jd_net_load_fsm(jd_net **out, const char *fsm_path, const char *i
                               (int32_t)fstate.size(), fstate.data(), fw.data(), lm_scale, ins_penalty);
 }
 
+extern "C" int jd_net_get_csr(const jd_net *n, int32_t *row_ptr, int32_t *to, float *w, int32_t *in, int32_t *outl,
+                              float *fin_w)
+{
+    if (!n) return jd_fail(JD_EINVAL, "jd_net_get_csr: null");
+    if (row_ptr) memcpy(row_ptr, n->row_ptr.data(), n->row_ptr.size() * sizeof(int32_t));
+    for (int64_t i = 0; i < n->n_arcs; ++i) {
+        const JdArc &a = n->arcs[(size_t)i];
+        if (to) to[i] = a.to;
+        if (w) w[i] = a.w;
+        if (in) in[i] = a.in;
+        if (outl) outl[i] = a.out;
+    }
+    if (fin_w) memcpy(fin_w, n->fin_w.data(), n->fin_w.size() * sizeof(float));
+    return JD_OK;
+}
+
 extern "C" int64_t jd_net_num_arcs(const jd_net *n) { return n ? n->n_arcs : 0; }
 extern "C" int32_t jd_net_num_states(const jd_net *n) { return n ? n->n_states : 0; }
 extern "C" int32_t jd_net_init_state(const jd_net *n) { return n ? n->init : -1; }

@@ -73,11 +73,11 @@ def gather_hyps(hyps: Sequence, per_rank: int, max_words: int = 256, device=None
     tf = torch.from_numpy(flts)
     if device is not None:
         ti, tf = ti.to(device), tf.to(device)
-    gi = torch.empty((world,) + tuple(ti.shape), dtype=ti.dtype, device=ti.device)
-    gf = torch.empty((world,) + tuple(tf.shape), dtype=tf.dtype, device=tf.device)
-    dist.all_gather_into_tensor(gi, ti)
-    dist.all_gather_into_tensor(gf, tf)
-    gi = gi.reshape(-1, ints.shape[1]).cpu().numpy()
-    gf = gf.reshape(-1, flts.shape[1]).cpu().numpy()
+    li = [torch.empty_like(ti) for _ in range(world)]
+    lf = [torch.empty_like(tf) for _ in range(world)]
+    dist.all_gather(li, ti)          # the one collective of the whole path (RCCL over xGMI on GPUs)
+    dist.all_gather(lf, tf)
+    gi = torch.cat(li).cpu().numpy()
+    gf = torch.cat(lf).cpu().numpy()
     keep = gi[:, 0] != -2
     return unpack_hyps(gi[keep], gf[keep], max_words)

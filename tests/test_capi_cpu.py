@@ -1,0 +1,123 @@
+"""CPU-side tests of the C ABI library: it loads, exports every declared symbol, the host
+preparation arithmetic equals the oracle's, and compute entry points fail loudly without a
+GPU (no fallback).  No kernel is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol(built):
+    from juicer_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "juicer_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(jd_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    L = capi.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTS) == declared
+    assert b"gfx950" in L.jd_version()
+
+
+def test_am_preparation_matches_oracle(built):
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM
+    for am in (synth.config_small()[0], synth.make_models(3, n_gmm=40, n_hmm=30, n_mix=5, D=13, n_tm=7, with_tee=True)):
+        g, o = capi.Models.from_htk(am), OracleAM(am)
+        for a, b in zip(g.flat(), o.flat()):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        gt, ot = g.trans(), o.trans()
+        assert np.array_equal(gt[0].view(np.uint32), ot[0].view(np.uint32))
+        assert np.array_equal(gt[1], ot[1]) and np.array_equal(gt[2].view(np.uint32), ot[2].view(np.uint32))
+        assert (g.n_hmms, g.n_gmms, g.vec_size, g.max_states) == (am.n_hmm, am.n_gmm, am.D, am.max_n)
+
+
+def test_net_preparation_matches_oracle(built):
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleNet
+    _, net, _, _ = synth.config_small()
+    for scale, pen in ((1.0, 0.0), (7.5, -3.25)):
+        g = capi.Network.from_synth(net, scale, pen)
+        o = OracleNet(net, scale, pen).arrays()
+        c = g.csr()
+        assert g.n_arcs == net.n_arcs and g.init_state == int(net.src[0])
+        # synthetic arcs are sorted by source state, so oracle file order == CSR order
+        assert np.array_equal(c["row_ptr"][:-1], o["first"]) and np.array_equal(np.diff(c["row_ptr"]), o["cnt"])
+        assert np.array_equal(c["to"], o["to"]) and np.array_equal(c["ilab"], o["ilab"])
+        assert np.array_equal(c["olab"], o["olab"])
+        assert np.array_equal(c["w"].view(np.uint32), o["w"].view(np.uint32))
+        assert np.array_equal(np.isfinite(c["fin_w"]), o["final_ind"] >= 0)
+
+
+def test_fsm_text_loader(built, tmp_path):
+    """AT&T text FSM (WFSTNetwork.cpp:414-447 sscanf cascade): 5/4-field arcs, 2/1-field finals."""
+    from juicer_amd import capi, synth
+    _, net, _, _ = synth.config_toy()
+    p = tmp_path / "toy.fsm"
+    with open(p, "w") as f:
+        for i in range(net.n_arcs):
+            if net.w_file[i] == 0.0:
+                f.write("%d %d %d %d\n" % (net.src[i], net.dst[i], net.ilab[i], net.olab[i]))
+            else:
+                f.write("%d %d %d %d %.9g\n" % (net.src[i], net.dst[i], net.ilab[i], net.olab[i], net.w_file[i]))
+        for s, w in zip(net.fstate, net.fweight_file):
+            f.write("%d %.9g\n" % (s, w))
+        f.write("\n# trailing junk line\n")
+    insyms = tmp_path / "in.syms"
+    insyms.write_text("<eps> 0\n" + "".join("h%d %d\n" % (i, i) for i in range(1, 6)))
+    a = capi.Network.from_fsm_file(str(p), str(insyms), None, 2.0, -1.0).csr()
+    b = capi.Network.from_synth(net, 2.0, -1.0).csr()
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k],
+                              b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
+    bad = tmp_path / "aux.syms"
+    bad.write_text("<eps> 0\n#0 1\nh 9\n")
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        capi.Network.from_fsm_file(str(p), str(bad), None)
+    assert ei.value.code == capi.JD_EFORMAT
+
+
+def test_errors_are_codes_not_exits(built):
+    from juicer_amd import capi, synth
+    am, net, _, _ = synth.config_toy()
+    import copy
+    bad = copy.deepcopy(net)
+    for f in ("src", "dst", "ilab", "olab", "w_file"):    # first arc moved to the end: state 0 is split
+        a = getattr(bad, f); setattr(bad, f, np.concatenate([a[1:], a[:1]]))
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        capi.Network.from_synth(bad)
+    assert ei.value.code == capi.JD_EFORMAT
+    bad_am = copy.deepcopy(am)
+    bad_am.hmm_gmm[0, 1] = 999
+    with pytest.raises(capi.JuicerAmdError):
+        capi.Models.from_htk(bad_am)
+
+
+def test_no_cpu_fallback(built):
+    """Without a GPU the product path must refuse to run (JD_ENODEV), never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from juicer_amd import capi, synth
+    am, net, feats, _ = synth.config_toy()
+    g, m = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        capi.Decoder(g, m)
+    assert ei.value.code == capi.JD_ENODEV
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        m.score_frames(feats[0][:4])
+    assert ei.value.code == capi.JD_ENODEV
+
+
+def test_product_does_not_reference_oracle():
+    """The product package and headers never import / link the oracle."""
+    for base in ("juicer_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    assert "juicer_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn

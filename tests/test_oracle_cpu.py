@@ -1,0 +1,101 @@
+"""CPU tests of the oracle itself (no GPU): frozen regression vectors + an independent
+cross-check of its semantics.  PARITY UNPINNED - see tests/golden/make_golden.py."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "oracle_golden.json")) as f:
+        return json.load(f)
+
+
+def _hex32(a):
+    return [np.float32(v).tobytes().hex() for v in a]
+
+
+@pytest.mark.parametrize("case", ["toy", "small"])
+def test_oracle_matches_golden(built, golden, case):
+    import make_golden
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    mk, _ = make_golden.CASES[case]
+    am, net, feats, _ = mk()
+    g = golden[case]
+    assert make_golden.input_digest(am, net, feats) == g["input_sha256"], "synthetic generator changed"
+    onet, oam = OracleNet(net), OracleAM(am)
+    ll = oam.score_frames(np.concatenate(feats)[:64])
+    assert make_golden.digest(ll) == g["gmm_ll_sha256"]
+    for run in g["runs"]:
+        od = OracleDecoder(onet, oam, **run["beams"])
+        for f, e in zip(feats, run["utts"]):
+            h = od.decode(f)
+            assert h.n == e["n"]
+            assert h.label.tolist() == e["label"] and h.time.tolist() == e["time"]
+            assert _hex32(h.score) == e["score_hex"] and _hex32(h.ac) == e["ac_hex"] and _hex32(h.lm) == e["lm_hex"]
+            assert _hex32([h.tot_score, h.tot_ac, h.tot_lm]) == e["tot"]
+            assert {k: int(v) for k, v in h.stats.items()} == e["stats"]
+
+
+def _check_indep(am, net, x, **net_kw):
+    from indep_viterbi import viterbi
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    oam = OracleAM(am)
+    ll = oam.score_frames(x).astype(np.float64)
+    ref = viterbi(net, am, ll, **{k: v for k, v in net_kw.items()})
+    h = OracleDecoder(OracleNet(net, **net_kw), oam).decode(x)        # every beam disabled
+    if ref is None:
+        assert h.n == -1
+        return
+    assert h.n == len(ref[1])
+    assert list(zip(h.label[::-1].tolist(), h.time[::-1].tolist())) == list(ref[1])
+    assert abs((h.tot_ac + h.tot_lm) - ref[0]) <= 2e-5 * abs(ref[0])
+
+
+def test_oracle_vs_independent_viterbi_toy(built):
+    """Un-pruned decode == textbook full-trellis Viterbi (float64, different formulation)."""
+    from juicer_amd import synth
+    am, net, feats, _ = synth.config_toy()
+    _check_indep(am, net, feats[0])
+    _check_indep(am, net, feats[0][:37])                  # ends mid-word or not: both must agree
+    _check_indep(am, net, feats[0], lm_scale=3.0, ins_penalty=-2.5)
+
+
+def test_oracle_vs_independent_viterbi_tee(built):
+    """Graph with the tee 'sp' model between words and eps:word hub arcs."""
+    from juicer_amd import synth
+    am = synth.make_models(11, n_gmm=12, n_hmm=6, n_mix=2, n_tm=3, sep=1.0, with_tee=True)
+    net = synth.make_wfst(12, am, n_words=4, n_succ=2, pron_len=(1, 2), with_sp=True)
+    x, _ = synth.sample_utterance(13, net, am, 5)
+    _check_indep(am, net, x[:60])
+
+
+def test_oracle_logadd_properties(built):
+    """GMM scores: single-mixture GMM equals the closed form; logAdd is order sensitive only
+    below float resolution (sanity of the restated arithmetic)."""
+    from juicer_amd import synth
+    from oracle.oracle import OracleAM
+    am = synth.make_models(5, n_gmm=6, n_hmm=3, n_mix=1, D=7, n_tm=2)
+    x = np.random.default_rng(1).normal(size=(9, 7)).astype(np.float32)
+    ll = OracleAM(am).score_frames(x)
+    mu, var = am.mean[:, 0].astype(np.float64), am.var[:, 0].astype(np.float64)
+    ref = -0.5 * (7 * np.log(2 * np.pi) + np.log(var).sum(1)[None] + (((x[:, None] - mu[None]) ** 2) / var[None]).sum(2))
+    assert np.allclose(ll, ref, rtol=2e-5, atol=2e-4)
+
+
+def test_oracle_rejects_bad_input(built):
+    from juicer_amd import synth
+    from oracle.oracle import OracleNet
+    am, net, _, _ = synth.config_toy()
+    import copy
+    bad = copy.deepcopy(net)
+    for f in ("src", "dst", "ilab", "olab", "w_file"):    # first arc moved to the end: state 0 is split
+        a = getattr(bad, f); setattr(bad, f, np.concatenate([a[1:], a[:1]]))
+    with pytest.raises(RuntimeError):
+        OracleNet(bad)

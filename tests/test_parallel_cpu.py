@@ -1,0 +1,79 @@
+"""world_size-2 gloo test of the multi-GPU layer: utterance sharding + the single gather of
+padded 1-best records (RCCL on GPUs, gloo here)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, n_utts, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from juicer_amd import parallel, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small(n_utts=n_utts)
+    lo, hi = parallel.shard_range(n_utts, rank, world)
+    od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=150.0)   # stand-in producer of hyps on CPU
+    mine = [od.decode(feats[u]) for u in range(lo, hi)]
+    per_rank = (n_utts + world - 1) // world
+    allh = parallel.gather_hyps(mine, per_rank, max_words=64)
+    if rank == 0:
+        q.put([(h["n"], h["label"].tolist(), h["time"].tolist(), float(h["tot_score"])) for h in allh])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    from juicer_amd import parallel
+    for n in (0, 1, 5, 64, 513):
+        for w in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_pack_unpack_roundtrip(built):
+    from juicer_amd import parallel, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_toy()
+    h = OracleDecoder(OracleNet(net), OracleAM(am)).decode(feats[0])
+    none = OracleDecoder(OracleNet(net), OracleAM(am)).decode(feats[0][:1])
+    ints, flts = parallel.pack_hyps([h, none], 16)
+    back = parallel.unpack_hyps(ints, flts, 16)
+    assert back[0]["n"] == h.n and back[0]["label"].tolist() == h.label.tolist()
+    assert np.array_equal(back[0]["score"], h.score) and back[1]["n"] == -1
+    with pytest.raises(ValueError):
+        parallel.pack_hyps([h], 2)
+
+
+@pytest.mark.timeout(300)
+def test_gather_world_size_2(built):
+    import torch.multiprocessing as mp
+    from juicer_amd import synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    n_utts = 5                                             # ragged: shards of 3 and 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_utts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    am, net, feats, _ = synth.config_small(n_utts=n_utts)
+    od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=150.0)
+    want = [od.decode(f) for f in feats]
+    assert len(got) == n_utts
+    for g, w in zip(got, want):
+        assert g[0] == w.n and g[1] == w.label.tolist() and g[2] == w.time.tolist()
+        assert g[3] == pytest.approx(w.tot_score, rel=1e-6)
