@@ -16,8 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libjuicer_amd.so")
+BATCH_TEST = os.path.join(HERE, "jd_batch_test")
+BATCH_SRC = os.path.join(CSRC, "jd_batch_test.cpp")
 SOURCES = [os.path.join(CSRC, "jd_host.cpp"), os.path.join(CSRC, "jd_device.hip")]
-HEADERS = [os.path.join(CSRC, "jd_internal.h"), os.path.join(ROOT, "include", "juicer_amd.h")]
+HEADERS = [os.path.join(CSRC, "jd_internal.h"), os.path.join(ROOT, "include", "juicer_amd.h"),
+           os.path.join(ROOT, "include", "juicer_amd_decoder.hpp"), BATCH_SRC]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
@@ -30,7 +33,7 @@ def hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(BATCH_TEST):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + [__file__])
@@ -43,6 +46,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    # the DecoderBatchTest counterpart (C++ host over the C ABI + the IDecoder adapter)
+    cmd2 = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", BATCH_TEST, BATCH_SRC,
+            "-L", HERE, "-ljuicer_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd2), file=sys.stderr)
+    subprocess.check_call(cmd2)
     return LIB
 
 

@@ -1,0 +1,160 @@
+// jd_batch_test - counterpart of Juicer's DecoderBatchTest harness for the GPU decoder.
+//
+//   DecoderBatchTest::configureTests  list file, one path per line, '#'/blank skipped  (DecoderBatchTest.cpp:822-844)
+//   DecoderBatchTest::run             decode, output, "CPU time .. speech time .. RT factor" (:738-777)
+//   DecoderBatchTest::outputResult    DBT_OUTPUT_REF: words separated by ' '           (:339-344)
+//   DecoderSingleTest::extractResultsFromHypWordMode  label-1, start/end frames       (DecoderSingleTest.cpp:403-468)
+//
+// Tracter (feature files) and Torch3 (CmdLine, vocabulary files) are not in the tree, so this
+// harness reads the build's own containers:
+//   .jdam  int32 magic 'JDAM', D,n_gmm,max_mix,n_hmm,max_n,n_tm, then the jd_am_create_htk arrays
+//   .jdf   int32 T, int32 D, then T*D float32 (one utterance)
+// and prints integer word ids (outLabel-1), which is what vocab->words[] is indexed by.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "juicer_amd.h"
+#include "juicer_amd_decoder.hpp"
+
+static void die(const char *what) { fprintf(stderr, "jd_batch_test: %s: %s\n", what, jd_last_error()); exit(1); }
+
+template <typename T> static std::vector<T> rd(FILE *f, size_t n)
+{
+    std::vector<T> v(n);
+    if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "jd_batch_test: short read\n"); exit(1); }
+    return v;
+}
+
+static jd_am *load_jdam(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "jd_batch_test: cannot open %s\n", path); exit(1); }
+    std::vector<int32_t> h = rd<int32_t>(f, 7);
+    if (h[0] != 0x4d41444a) { fprintf(stderr, "jd_batch_test: %s is not a .jdam file\n", path); exit(1); }
+    const int D = h[1], G = h[2], M = h[3], H = h[4], MN = h[5], NT = h[6];
+    std::vector<int32_t> n_mix = rd<int32_t>(f, G);
+    std::vector<float> wt = rd<float>(f, (size_t)G * M), mu = rd<float>(f, (size_t)G * M * D), var = rd<float>(f, (size_t)G * M * D);
+    std::vector<int32_t> hn = rd<int32_t>(f, H), hg = rd<int32_t>(f, (size_t)H * MN), ht = rd<int32_t>(f, H), tn = rd<int32_t>(f, NT);
+    std::vector<float> tp = rd<float>(f, (size_t)NT * MN * MN);
+    fclose(f);
+    jd_am *am = 0;
+    if (jd_am_create_htk(&am, D, G, M, n_mix.data(), wt.data(), mu.data(), var.data(), H, MN, hn.data(), hg.data(),
+                         ht.data(), NT, tn.data(), tp.data()))
+        die("jd_am_create_htk");
+    return am;
+}
+
+int main(int argc, char **argv)
+{
+    const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *list = 0;
+    float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
+    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
+        if (a == "-fsmFName") fsm = nxt(); else if (a == "-inSymsFName") insyms = nxt();
+        else if (a == "-outSymsFName") outsyms = nxt(); else if (a == "-modelsFName") amf = nxt();
+        else if (a == "-inputFName") list = nxt(); else if (a == "-mainBeam") mainBeam = (float)atof(nxt());
+        else if (a == "-phoneStartBeam") startBeam = (float)atof(nxt()); else if (a == "-phoneEndBeam") endBeam = (float)atof(nxt());
+        else if (a == "-wordEmitBeam") wordBeam = (float)atof(nxt()); else if (a == "-maxHyps") maxHyps = atoi(nxt());
+        else if (a == "-lmScaleFactor") lmScale = (float)atof(nxt()); else if (a == "-insPenalty") insPen = (float)atof(nxt());
+        else if (a == "-framesPerSec") framesPerSec = atoi(nxt()); else if (a == "-device") device = atoi(nxt());
+        else if (a == "-batch") batch = atoi(nxt()); else if (a == "-perFrameAdapter") useAdapter = 1;
+        else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (!fsm || !amf || !list) {
+        fprintf(stderr, "usage: jd_batch_test -fsmFName F -modelsFName M.jdam -inputFName LIST [-mainBeam b] [-phoneStartBeam b]\n"
+                        "       [-phoneEndBeam b] [-wordEmitBeam b] [-maxHyps n] [-lmScaleFactor s] [-insPenalty p] [-batch n] [-perFrameAdapter]\n");
+        return 2;
+    }
+    jd_net *net = 0;
+    if (jd_net_load_fsm(&net, fsm, insyms, outsyms, lmScale, insPen)) die("jd_net_load_fsm");
+    jd_am *am = load_jdam(amf);
+    const int D = jd_am_vec_size(am);
+
+    // configureTests: list of input files
+    std::vector<std::string> files;
+    {
+        FILE *f = fopen(list, "rb");
+        if (!f) { fprintf(stderr, "DecoderBatchTest::configureTests - error opening input file\n"); return 1; }
+        char line[100000];
+        while (fgets(line, sizeof line, f)) {
+            if (line[0] == '#' || line[0] == '\n' || line[0] == '\r' || line[0] == ' ' || line[0] == '\t' || !line[0]) continue;
+            line[strcspn(line, "\r\n")] = 0;
+            files.push_back(line);
+        }
+        fclose(f);
+    }
+    std::vector<std::vector<float>> feats(files.size());
+    std::vector<int32_t> nfr(files.size());
+    for (size_t u = 0; u < files.size(); ++u) {
+        FILE *f = fopen(files[u].c_str(), "rb");
+        if (!f) { fprintf(stderr, "jd_batch_test: cannot open %s\n", files[u].c_str()); return 1; }
+        std::vector<int32_t> h = rd<int32_t>(f, 2);
+        if (h[1] != D) { fprintf(stderr, "jd_batch_test: %s has vecSize %d, models want %d\n", files[u].c_str(), h[1], D); return 1; }
+        nfr[u] = h[0];
+        feats[u] = rd<float>(f, (size_t)h[0] * D);
+        fclose(f);
+    }
+
+    double decodeTime = 0.0, speechTime = 0.0;
+    auto print_utt = [&](size_t u, int n, const int32_t *label, const int32_t *time, double decTime) {
+        printf("File: %s\n", files[u].c_str());
+        // extractResultsFromHypWordMode: chain is newest first; word index = state - 1
+        for (int k = n - 1; k >= 0; --k) printf("%d ", label[k] - 1);
+        printf("\n");
+        printf("  [ ");
+        for (int k = n - 1; k >= 0; --k) printf("%d ", time[k] + 1);
+        printf("(%d) ]\n", nfr[u]);
+        const double uttTime = (double)nfr[u] / framesPerSec;
+        printf("CPU time %.3f  speech time %.3f  RT factor %.3f\n", decTime, uttTime, uttTime > 0 ? decTime / uttTime : 0.0);
+        decodeTime += decTime; speechTime += uttTime;
+    };
+
+    if (useAdapter) {
+        // the reference's serial protocol: one IDecoder, frame by frame with 20-row look-ahead
+        JuicerAmd::GpuWFSTDecoder dec(net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, device);
+        for (size_t u = 0; u < files.size(); ++u) {
+            auto t0 = std::chrono::steady_clock::now();
+            dec.init();
+            std::vector<float *> rows(nfr[u]);
+            for (int t = 0; t < nfr[u]; ++t) rows[t] = feats[u].data() + (size_t)t * D;
+            int nFrames = 0, nData = nfr[u] < 20 ? nfr[u] : 20;          // DecoderSingleTest.cpp:267-295
+            while (nData > 0) {
+                dec.processFrame(&rows[nFrames], nFrames, nData);
+                ++nFrames;
+                if (nFrames + nData - 1 >= nfr[u]) --nData;
+            }
+            JuicerAmd::DecHyp *hyp = dec.finish();
+            std::vector<int32_t> lab, tim;
+            for (JuicerAmd::DecHypHist *h = hyp ? hyp->hist : 0; h; h = h->prev) { lab.push_back(h->state); tim.push_back(h->time); }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            print_utt(u, (int)lab.size(), lab.data(), tim.data(), dt);
+        }
+    } else {
+        jd_dec *dec = 0;
+        if (jd_dec_create(&dec, net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, 5, device, batch)) die("jd_dec_create");
+        std::vector<const float *> ptr(files.size());
+        for (size_t u = 0; u < files.size(); ++u) ptr[u] = feats[u].data();
+        std::vector<jd_hyp> hyps(files.size());
+        auto t0 = std::chrono::steady_clock::now();
+        if (jd_decode_batch(dec, (int)files.size(), ptr.data(), nfr.data(), hyps.data())) die("jd_decode_batch");
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        long tot = 0;
+        for (size_t u = 0; u < files.size(); ++u) tot += nfr[u];
+        for (size_t u = 0; u < files.size(); ++u) {
+            if (hyps[u].n < 0) fprintf(stderr, "WARNING: no token survived at the end of decoding\n");
+            print_utt(u, hyps[u].n > 0 ? hyps[u].n : 0, hyps[u].label, hyps[u].time, tot ? dt * nfr[u] / tot : 0.0);
+        }
+        jd_dec_destroy(dec);
+    }
+    printf("\n\nTotal CPU time %.3f  Total speech time %.3f  Avg. RT factor %.3f\n", decodeTime, speechTime,
+           speechTime > 0 ? decodeTime / speechTime : 0.0);
+    jd_am_destroy(am);
+    jd_net_destroy(net);
+    return 0;
+}

@@ -200,3 +200,39 @@ def test_histogram_ceiling_is_an_error(built):
     with pytest.raises(capi.JuicerAmdError) as ei:
         gd.decode_batch([x])
     assert ei.value.code == capi.JD_EHIST
+
+
+def test_batch_test_cli(small, tmp_path):
+    """DecoderBatchTest counterpart (C++ host over the C ABI): list file in, ref-format lines +
+    RT factor out; both the batched path and the frame-by-frame IDecoder adapter."""
+    import subprocess
+    from juicer_amd import build as jbuild, io as jio, synth
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    am, net, _, _ = synth.config_small()
+    jio.write_fsm(tmp_path / "g.fsm", net)
+    jio.write_jdam(tmp_path / "m.jdam", am)
+    lst = tmp_path / "list.txt"
+    with open(lst, "w") as f:
+        f.write("# comment line\n\n")
+        for u, x in enumerate(feats):
+            jio.write_jdf(tmp_path / ("u%d.jdf" % u), x)
+            f.write("%s\n" % (tmp_path / ("u%d.jdf" % u)))
+    od = OracleDecoder(onet, oam, main_beam=150.0, max_hyps=200)
+    want = [od.decode(x) for x in feats]
+    for extra in ([], ["-perFrameAdapter"]):
+        out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-modelsFName",
+                              str(tmp_path / "m.jdam"), "-inputFName", str(lst), "-mainBeam", "150",
+                              "-maxHyps", "200"] + extra, capture_output=True, text=True, timeout=240)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.splitlines()
+        files = [i for i, l in enumerate(lines) if l.startswith("File: ")]
+        assert len(files) == len(feats)
+        for u, i in enumerate(files):
+            words = [int(w) for w in lines[i + 1].split()]
+            assert words == (want[u].label[::-1] - 1).tolist()
+            times = lines[i + 2].replace("[", "").replace("]", "").replace("(", "").replace(")", "").split()
+            assert [int(t) for t in times[:-1]] == (want[u].time[::-1] + 1).tolist()
+            assert int(times[-1]) == feats[u].shape[0]
+            assert lines[i + 3].startswith("CPU time ") and "RT factor" in lines[i + 3]
+        assert lines[-1].startswith("Total CPU time ")
