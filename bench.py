@@ -88,13 +88,16 @@ def main():
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     gmm_ms = search_ms = 0.0
-    gmm_launches = search_launches = 0
+    gmm_launches = search_steps = ksamples = 0
+    kernel_us = [0.0] * 7
     hyps = None
     for _ in range(args.steps):
         hyps, allh = step()
         tm = dec.last_timing()
         gmm_ms += tm["gmm_ms"]; search_ms += tm["search_ms"]
-        gmm_launches += tm["gmm_launches"]; search_launches += tm["search_launches"]
+        gmm_launches += tm["gmm_launches"]; search_steps += tm["search_steps"]
+        ksamples += tm["kernel_samples"]
+        kernel_us = [a + b for a, b in zip(kernel_us, tm["kernel_us"])]
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -112,29 +115,46 @@ def main():
 
     steps = args.steps
     fps = frames_total * steps / elapsed
-    # ---- roofline of the dominant kernel (algorithmic bytes: SURVEY.md section 8d / DESIGN.md)
+    # ---- roofline of the dominant kernel.  Algorithmic bytes per stream-frame (SURVEY.md 8d,
+    # DESIGN.md 5) from the decoder's own work counters; durations from HIP events recorded on
+    # the decoder's streams inside the timed region (every 16th lock-step frame is bracketed
+    # kernel by kernel; the GMM kernel is bracketed on every launch).
     D, G, M, MN = am.D, am.n_gmm, am.max_mix, am.max_n
-    st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}
+    st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals
+    lock_steps = max(1, search_steps // steps)                            # launches of each search kernel per step
+    gmm_l = max(1, gmm_launches // steps)
+    per_launch_bytes = {
+        # token read + write (16-B tokens), arc->hmm lookup, likelihood gather
+        "k_phase_a": ((32.0 * MN + 4.0) * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]) / lock_steps,
+        # exit token + CSR bounds, arc records + slot map, Path records
+        "k_expand<0>": (24.0 * st["tot_proc_end_hyps"] + 20.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"]) / lock_steps,
+        # destination entry-token read-modify-write
+        "k_resolve": 32.0 * st["tot_arcs_visited"] / lock_steps,
+        # parameters once per launch + features
+        "jd_gmm_kernel": G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / gmm_l,
+    }
+    names = ["k_boundary", "k_phase_a", "k_select0", "k_expand<0>", "k_expand<1>", "k_expand_tail", "k_resolve"]
+    avg_us = {n: (kernel_us[i] / ksamples if ksamples else 0.0) for i, n in enumerate(names)}
+    avg_us["jd_gmm_kernel"] = 1e3 * gmm_ms / max(1, gmm_launches)
+    # share of a step's GPU time: sampled average x launches per step
+    tot_ms = {n: avg_us[n] * lock_steps / 1e3 for n in names}
+    tot_ms["jd_gmm_kernel"] = gmm_ms / steps
+    dom = max(per_launch_bytes, key=lambda k: tot_ms[k])
+    achieved = per_launch_bytes[dom] / (avg_us[dom] * 1e-6) / 1e9 if avg_us[dom] > 0 else 0.0
     search_bytes = (32.0 * MN * st["tot_insts_in"] + 4.0 * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]
                     + 24.0 * st["tot_proc_end_hyps"] + 52.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"])
-    gmm_l = max(1, gmm_launches // steps)
-    gmm_bytes = gmm_l * G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0
-    kernels = {
-        "jd_search_kernel": dict(bytes_per_launch=search_bytes / max(1, search_launches // steps),
-                                 ms_per_launch=search_ms / max(1, search_launches), total_ms=search_ms / steps),
-        "jd_gmm_kernel": dict(bytes_per_launch=gmm_bytes / gmm_l,
-                              ms_per_launch=gmm_ms / max(1, gmm_launches), total_ms=gmm_ms / steps),
-    }
-    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
-    kd = kernels[dom]
-    achieved = kd["bytes_per_launch"] / (kd["ms_per_launch"] * 1e-3) / 1e9 if kd["ms_per_launch"] > 0 else 0.0
     gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "algorithmic_bytes_per_launch": round(kd["bytes_per_launch"], 1),
-                "avg_launch_ms": round(kd["ms_per_launch"], 4),
-                "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in kernels.items()},
-                "gmm_valu_tflops": round(gmm_flops / max(kernels["jd_gmm_kernel"]["total_ms"], 1e-9) / 1e9, 3)}
+                "algorithmic_bytes_per_launch": round(per_launch_bytes[dom], 1),
+                "avg_launch_us": round(avg_us[dom], 3), "launches_per_step": lock_steps if dom != "jd_gmm_kernel" else gmm_l,
+                "sampled_launches": ksamples if dom != "jd_gmm_kernel" else gmm_launches,
+                "kernels_ms_per_step": {k: round(v, 3) for k, v in tot_ms.items()},
+                "kernels_avg_us": {k: round(v, 2) for k, v in avg_us.items()},
+                "search_all_kernels": {"algorithmic_GB_per_step": round(search_bytes / 1e9, 3),
+                                       "ms_per_step": round(search_ms / steps, 3),
+                                       "GBps": round(search_bytes / max(search_ms / steps, 1e-9) / 1e6, 1)},
+                "gmm_valu_tflops": round(gmm_flops / max(tot_ms["jd_gmm_kernel"], 1e-9) / 1e9, 3)}
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample
     cpu = None

@@ -200,14 +200,19 @@ int jd_decode_batch(jd_dec *d, int32_t n_utts, const float *const *feats,
 int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
                            const int64_t *offs, void *hip_stream, jd_hyp *out);
 
-/* Durations (ms, HIP events on the decoder's own streams) of the kernels of
- * the most recent jd_decode_batch*(): total GMM-kernel time, total search-
- * kernel time, number of launches of each, wall time of the whole call. */
+/* Durations (HIP events on the decoder's own streams) of the kernels of the most recent
+ * jd_decode_batch*(): total GMM-kernel time, total search time (all kernels of all steps),
+ * wall time of the call, and per-kernel durations on every 16th step. */
 typedef struct jd_timing {
     double gmm_ms, search_ms, total_ms;
-    int32_t gmm_launches, search_launches;
+    int32_t gmm_launches, search_launches;   /* chunk-level launches (search: runs of steps)    */
     int64_t gmm_frames;       /* stream-frames scored                           */
     int64_t gmm_states;       /* tied states scored per frame                    */
+    int64_t search_steps;     /* lock-step frames executed                        */
+    /* summed duration (us) of each search kernel over the sampled steps, in launch order:
+     * k_boundary, k_phase_a, k_select0, k_expand<0>, k_expand<1>, k_expand_tail, k_resolve */
+    double kernel_us[7];
+    int32_t kernel_samples;   /* number of sampled steps                          */
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 

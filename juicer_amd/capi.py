@@ -45,7 +45,10 @@ class CHyp(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("gmm_ms", C.c_double), ("search_ms", C.c_double), ("total_ms", C.c_double),
                 ("gmm_launches", C.c_int32), ("search_launches", C.c_int32),
-                ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64)]
+                ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64), ("search_steps", C.c_int64),
+                ("kernel_us", C.c_double * 7), ("kernel_samples", C.c_int32)]
+
+KERNEL_NAMES = ["k_boundary", "k_phase_a", "k_select0", "k_expand<0>", "k_expand<1>", "k_expand_tail", "k_resolve"]
 
 
 @dataclass
@@ -317,7 +320,9 @@ class Decoder:
     def last_timing(self) -> dict:
         t = Timing()
         _check(lib().jd_dec_last_timing(self.h, C.byref(t)))
-        return {f: getattr(t, f) for f, _ in Timing._fields_}
+        out = {f: getattr(t, f) for f, _ in Timing._fields_}
+        out["kernel_us"] = [float(v) for v in t.kernel_us]
+        return out
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

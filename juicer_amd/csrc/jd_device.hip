@@ -1222,6 +1222,9 @@ struct jd_dec {
     int *d_T = nullptr;
     hipStream_t s_gmm = nullptr, s_search = nullptr;
     hipEvent_t ev_gmm[2] = {nullptr, nullptr}, ev_search[2] = {nullptr, nullptr};
+    // sampled per-kernel timing: every KSAMPLE_EVERY-th step records events around each launch
+    std::vector<hipEvent_t> kev;               // KSAMPLE_MAX x 8 events
+    int kev_used = 0;
     // streaming API state
     std::vector<int> stream_T;                 // frames pushed so far
     std::vector<int> stream_started;
@@ -1266,6 +1269,7 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     }
     if (d->d_row_src) (void)hipFree(d->d_row_src);
     if (d->d_push) (void)hipFree(d->d_push);
+    for (auto &e : d->kev) (void)hipEventDestroy(e);
     if (d->s_gmm) (void)hipStreamDestroy(d->s_gmm);
     if (d->s_search) (void)hipStreamDestroy(d->s_search);
     delete d;
@@ -1495,6 +1499,8 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
     return first_err;
 }
 
+#define KSAMPLE_EVERY 16
+#define KSAMPLE_MAX 96
 #define GRID_A 4096
 #define GRID_X 2048
 #define GRID_S 512
@@ -1510,21 +1516,32 @@ static void launch_init(jd_dec *d, int nb, int s0, hipStream_t st)
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 2);
 }
 
-// one lock-step frame for streams [s0, s0+nb)
-static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll_stride, int f0, hipStream_t st)
+// one lock-step frame for streams [s0, s0+nb); ev != nullptr: 8 events bracketing the 7 launches
+static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll_stride, int f0, hipStream_t st,
+                        hipEvent_t *ev = nullptr)
 {
+#define EV(i) do { if (ev) (void)hipEventRecord(ev[i], st); } while (0)
+    EV(0);
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 0);
+    EV(1);
     if (d->am->max_n <= 5)
         hipLaunchKernelGGL(k_phase_a<4>, dim3(GRID_A), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb, ll,
                            ll_stride, f0);
     else
         hipLaunchKernelGGL(k_phase_a<8>, dim3(GRID_A), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb, ll,
                            ll_stride, f0);
+    EV(2);
     hipLaunchKernelGGL(k_select0, dim3(GRID_S), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    EV(3);
     hipLaunchKernelGGL(k_expand<0>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    EV(4);
     hipLaunchKernelGGL(k_expand<1>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    EV(5);
     hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
+    EV(6);
     hipLaunchKernelGGL(k_resolve, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    EV(7);
+#undef EV
 }
 
 // closes the last frame of a run of steps (epilogue only: no stream has frames left)
@@ -1591,7 +1608,17 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
         HIPCHK(hipEventRecord(ss[(size_t)c], d->s_search));
         {
             const int nsteps = std::min(Fc, maxT - c * Fc);
-            for (int k = 0; k < nsteps; ++k) launch_step(d, nb, 0, d->d_ll[buf], (long long)Fc * G, c * Fc, d->s_search);
+            for (int k = 0; k < nsteps; ++k) {
+                hipEvent_t *ev = nullptr;
+                if (((c * Fc + k) % KSAMPLE_EVERY) == KSAMPLE_EVERY / 2 && d->kev_used < KSAMPLE_MAX) {
+                    if (d->kev.empty()) {
+                        d->kev.resize((size_t)KSAMPLE_MAX * 8);
+                        for (auto &e : d->kev) (void)hipEventCreate(&e);
+                    }
+                    ev = d->kev.data() + (size_t)d->kev_used++ * 8;
+                }
+                launch_step(d, nb, 0, d->d_ll[buf], (long long)Fc * G, c * Fc, d->s_search, ev);
+            }
             if (c == n_chunks - 1) launch_close(d, nb, 0, d->s_search);
         }
         HIPCHK(hipGetLastError());
@@ -1611,6 +1638,15 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
         (void)hipEventDestroy(gs[(size_t)c]); (void)hipEventDestroy(ge[(size_t)c]);
         (void)hipEventDestroy(ss[(size_t)c]); (void)hipEventDestroy(se[(size_t)c]);
     }
+    for (int i = 0; i < d->kev_used; ++i)
+        for (int k = 0; k < 7; ++k) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, d->kev[(size_t)i * 8 + k], d->kev[(size_t)i * 8 + k + 1]) == hipSuccess)
+                d->timing.kernel_us[k] += 1e3 * ms;
+        }
+    d->timing.kernel_samples += d->kev_used;
+    d->kev_used = 0;
+    d->timing.search_steps += maxT;
     d->timing.gmm_launches += n_chunks;
     d->timing.search_launches += n_chunks;
     for (int u = 0; u < nb; ++u) d->timing.gmm_frames += T[(size_t)u];
