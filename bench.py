@@ -89,7 +89,7 @@ def main():
     t0 = time.perf_counter()
     gmm_ms = search_ms = 0.0
     gmm_launches = search_steps = ksamples = 0
-    kernel_us = [0.0] * 7
+    kernel_us = [0.0] * 6
     hyps = None
     for _ in range(args.steps):
         hyps, allh = step()
@@ -133,7 +133,7 @@ def main():
         # parameters once per launch + features
         "jd_gmm_kernel": G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / gmm_l,
     }
-    names = ["k_boundary", "k_phase_a", "k_select0", "k_expand<0>", "k_expand<1>", "k_expand_tail", "k_resolve"]
+    names = list(capi.KERNEL_NAMES)
     avg_us = {n: (kernel_us[i] / ksamples if ksamples else 0.0) for i, n in enumerate(names)}
     avg_us["jd_gmm_kernel"] = 1e3 * gmm_ms / max(1, gmm_launches)
     # share of a step's GPU time: sampled average x launches per step

@@ -210,8 +210,8 @@ typedef struct jd_timing {
     int64_t gmm_states;       /* tied states scored per frame                    */
     int64_t search_steps;     /* lock-step frames executed                        */
     /* summed duration (us) of each search kernel over the sampled steps, in launch order:
-     * k_boundary, k_phase_a, k_select0, k_expand<0>, k_expand<1>, k_expand_tail, k_resolve */
-    double kernel_us[7];
+     * k_boundary, k_phase_a, k_expand<0>, k_expand<1>, k_expand_tail, k_resolve */
+    double kernel_us[6];
     int32_t kernel_samples;   /* number of sampled steps                          */
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);

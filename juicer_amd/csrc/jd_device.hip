@@ -288,6 +288,7 @@ struct StreamDev {      // per-stream arenas (cold)
     int *act[2]; int *free_stk;
     ArcState *ast;                    // per ARC: {best entry-token candidate of this frame, slot}
     unsigned long long *skey[2];      // per STATE: best frontier item arriving there (round parity)
+    unsigned long long *skeyL;        // round 0 only: items whose arc carries a word label (own threshold)
     int *touched;                     // arcs whose ekey became non-zero this frame
     Tok *item_tok; int4 *item_info;   // frontier items: token + {arc, outLabel, toState, -}
     PathRec *paths; int *hist;
@@ -678,8 +679,13 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
         if (live) act_next[pk_nB(bs) + pk_nB(pre) + rank_in(bl)] = slot;
         if (has_exit) {
             const int k = pk_cnt0(bs) + pk_cnt0(pre) + rank_in(be);
-            if (k < C.cap_items) { S.item_tok[k] = ex; S.item_info[k] = exinfo; }
-            else c.error = -42;
+            if (k < C.cap_items) {
+                S.item_tok[k] = ex; S.item_info[k] = exinfo;
+                // bid for the destination state (state-level recombination, see expand_item); tokens
+                // leaving word-labelled arcs face their own threshold (:952-962) -> own key class
+                atomicMax((exinfo.y != 0 ? S.skeyL : S.skey[0]) + exinfo.z,
+                          ((unsigned long long)f2o(ex.score) << 32) | (unsigned)k);
+            } else c.error = -42;
         }
         if (dead) {                                                    // returnNetInst :777-797
             S.free_stk[c.n_free + pk_ndead(bs) + pk_ndead(pre) + rank_in(bd)] = slot;
@@ -690,83 +696,60 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
     if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
 }
 
-// One frontier item = a token that has just traversed arc info.x (-1 = the NULL transition
-// of recognitionStart).  Body of propagateToken (WFSTDecoderLite.cpp:491-605), executed by a
-// group of EG lanes: lane 0 records the word boundary / final state, all lanes walk the
-// out-arcs of the destination state (coalesced 16-byte arc records).  First-touched arcs are
-// staged in a per-wave LDS buffer and appended to the stream's list with one atomic per flush.
-#define TB_CAP 1024
-struct WaveStage { int n; int buf[TB_CAP]; };
+// ---- frontier expansion: propagateToken (WFSTDecoderLite.cpp:491-605).
+// One frontier item = a token that has just traversed arc info.x (-1 = the NULL transition of
+// recognitionStart).  A group of EG lanes owns one item: lane 0 records the word boundary /
+// final state, all lanes walk the out-arcs of the destination state (coalesced 16-byte arc
+// records).  State-level recombination: of all items that reached a state in one round only the
+// best one (per threshold class) is expanded - every item would add the same arc weights, so by
+// monotonicity of float addition no other item can win anything downstream.
+// Block-level aggregation: Path records are allocated with one atomic per unit, first-touched
+// arcs are staged in LDS and appended to the stream's list with one atomic per unit.
+#define TBS_CAP 4096
+struct BlockStage { int n; int fb; int buf[TBS_CAP]; };
 
-__device__ __forceinline__ void stage_flush(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &w)
+__device__ __forceinline__ void stage_touch(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st,
+                                            bool touch, int tb)
 {
-    const int lane = lane_id();
-    const int n = w.n;
-    if (n == 0) return;
+    const unsigned long long bt = __ballot(touch);
+    if (!bt) return;
+    const int first = __ffsll((long long)bt) - 1;
     int base = 0;
-    if (lane == 0) base = atomicAdd(&c.n_touched, n);
-    base = __shfl(base, 0);
-    for (int k = lane; k < n; k += 64) {
-        if (base + k < C.cap_items) S.touched[base + k] = w.buf[k]; else c.error = -42;
+    if (lane_id() == first) base = atomicAdd(&st.n, __popcll(bt));
+    base = __shfl(base, first);
+    if (touch) {
+        const int pos = base + rank_in(bt);
+        if (pos < TBS_CAP) st.buf[pos] = tb;
+        else {                                                         // stage full: straight to the list
+            const int gi = atomicAdd(&c.n_touched, 1);
+            if (gi < C.cap_items) S.touched[gi] = tb; else c.error = -42;
+        }
     }
-    if (lane == 0) w.n = 0;
 }
 
-__device__ __forceinline__ void expand_item(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &stage,
-                                            int frame, float endTh, float wordTh, bool have, int ii, int parity,
-                                            int *items_counter, int items_base, int &n_arcs, int &n_paths_made)
+// all threads of the block; leaves the stage empty and synchronised
+__device__ __forceinline__ void stage_flush_block(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st)
 {
-    const int lane = lane_id();
-    const int er = lane & (EG - 1), eb = lane & ~(EG - 1);
-    const float INF = __builtin_inff();
-    Tok t = null_tok();
-    int rs = 0, deg = 0;
-    int4 info = make_int4(-1, 0, 0, 0);
-    if (have) {
-        info = S.item_info[ii];
-        if (info.x >= 0) {
-            // State-level recombination: of all items that reached state info.z in this round only
-            // the best one is expanded (every item would add the same arc weights, so by
-            // monotonicity of float addition no other item can win anything downstream).
-            unsigned long long *sk = S.skey[parity] + info.z;
-            const unsigned long long kv = __hip_atomic_load(sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            have = (unsigned)(kv & 0xffffffffULL) == (unsigned)ii && kv != 0ULL;
-            if (have && er == 0) __hip_atomic_store(sk, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    __syncthreads();
+    const int n = st.n < TBS_CAP ? st.n : TBS_CAP;
+    if (threadIdx.x == 0) st.fb = n ? atomicAdd(&c.n_touched, n) : 0;
+    __syncthreads();
+    const int fb = st.fb;
+    for (int k = threadIdx.x; k < n; k += KT) {
+        if (fb + k < C.cap_items) S.touched[fb + k] = st.buf[k]; else c.error = -42;
     }
-    if (have) {
-        t = S.item_tok[ii];
-        int state = C.init_state;
-        if (info.x >= 0) {
-            if (info.y != 0) {                                         // :497-509 word boundary
-                int p = 0;
-                if (er == 0) p = atomicAdd(&c.n_paths, 1);
-                p = __shfl(p, eb);
-                if (p < C.cap_paths) {
-                    if (er == 0) {
-                        PathRec pr;
-                        pr.prev = t.path; pr.frame = frame; pr.label = info.y; pr.pad0 = 0;
-                        pr.score = t.score; pr.ac = t.ac; pr.lm = t.lm; pr.pad1 = 0.0f;
-                        S.paths[p] = pr;
-                        S.item_tok[ii].path = p;
-                        ++n_paths_made;
-                    }
-                    t.path = p;
-                } else c.error = -43;
-            }
-            state = info.z;
-            if (er == 0) {                                             // :513-520 final state
-                const float fw = C.fin_w[state];
-                if (fw < INF) {
-                    const float cs = t.score + fw;
-                    if (cs > LZ) atomicMax(&c.final_key, ((unsigned long long)f2o(cs) << 32) | (unsigned)ii);
-                }
-            }
-        }
-        rs = C.row_ptr[state];
-        deg = C.row_ptr[state + 1] - rs;
-    }
-    // the group with the largest degree in the wave sets the trip count
+    __syncthreads();
+    if (threadIdx.x == 0) st.n = 0;
+    __syncthreads();
+}
+
+// arc walk of one wave (GPW items, EG lanes each)
+__device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
+                                            const Tok &t, int ii, int rs, int deg, float endTh, float wordTh,
+                                            unsigned long long *sk_out, int *items_counter, int items_base,
+                                            int &n_arcs)
+{
+    const int er = lane_id() & (EG - 1);
     int maxdeg = deg;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(maxdeg, o); maxdeg = y > maxdeg ? y : maxdeg; }
@@ -805,100 +788,127 @@ __device__ __forceinline__ void expand_item(const DecConst &C, StreamCtl &c, con
                 }
             }
         }
-        // first-touched arcs -> per-wave LDS stage (flushed when nearly full)
-        const unsigned long long bt = __ballot(touch);
-        if (bt) {
-            const int base = stage.n;                                  // wave-private: uniform read
-            if (touch) stage.buf[base + rank_in(bt)] = tb;
-            if (lane == 0) stage.n = base + __popcll(bt);
-            if (base + __popcll(bt) > TB_CAP - 64) stage_flush(C, c, S, stage);
-        }
+        stage_touch(C, c, S, stage, touch, tb);
         const int idx = wave_append(mk, items_counter);
         if (mk) {
             const int pos = items_base + idx;
             if (pos < C.cap_items) {
                 S.item_tok[pos] = u; S.item_info[pos] = uinfo;
-                atomicMax(S.skey[parity ^ 1] + uinfo.z, ((unsigned long long)f2o(u.score) << 32) | (unsigned)pos);
+                atomicMax(sk_out + uinfo.z, ((unsigned long long)f2o(u.score) << 32) | (unsigned)pos);
             } else c.error = -42;
         }
     }
 }
 
-// doHMMExternalPropagation (:937-982), selection part: every live exit token that beats its
-// end/word threshold (:952-962) is a frontier item; it bids for its destination state.
-__global__ __launch_bounds__(KT) void k_select0(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B)
+// One unit = KT/EG items of one stream.  All threads of the block call this.
+//   sk_in_u / sk_in_l : per-state key arrays of this round (unlabelled / word-labelled class)
+//   check_th          : apply the end/word threshold of doHMMExternalPropagation (:952-962) (round 0)
+__device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
+                                            int *sh_w, int *sh_pb, int frame, float endTh, float wordTh, bool check_th,
+                                            bool have, int ii, unsigned long long *sk_in_u,
+                                            unsigned long long *sk_in_l, unsigned long long *sk_out,
+                                            int *items_counter, int items_base, int &n_arcs, int &n_paths_made,
+                                            int &n_pend)
 {
-    __shared__ int sh_pre[MAX_B + 1];
-    __shared__ int sh_w[8];
-    const int tid = threadIdx.x, lane = lane_id();
-    const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
-        const StreamCtl &c = ctl[s0 + s];
-        return c.active == 1 ? (pk_cnt0(c.pkA) + KT - 1) / KT : 0;
-    });
-    for (int u = blockIdx.x; u < total; u += gridDim.x) {
-        const int sl = find_stream(sh_pre, B, u);
-        StreamCtl &c = ctl[s0 + sl];
-        const StreamDev &S = streams[s0 + sl];
-        const float bestA = o2f(c.best);
-        const float endTh = (C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;       // :349
-        const float wordTh = (C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;    // :350
-        const int n = pk_cnt0(c.pkA);
-        const int k = (u - sh_pre[sl]) * KT + tid;
-        bool pass = false;
-        if (k < n) {
-            const float sc = S.item_tok[k].score;
-            const int4 info = S.item_info[k];
-            pass = sc > ((info.y != 0) ? wordTh : endTh);
-            if (pass) atomicMax(S.skey[0] + info.z, ((unsigned long long)f2o(sc) << 32) | (unsigned)k);
+    const int lane = lane_id();
+    const int er = lane & (EG - 1);
+    const float INF = __builtin_inff();
+    Tok t = null_tok();
+    int4 info = make_int4(-1, 0, 0, 0);
+    if (have) {
+        info = S.item_info[ii];
+        t = S.item_tok[ii];
+        if (info.x >= 0) {
+            if (check_th) {                                            // :952-962
+                have = t.score > ((info.y != 0) ? wordTh : endTh);
+                if (have && er == 0) ++n_pend;
+            }
+            unsigned long long *sk = ((info.y != 0) ? sk_in_l : sk_in_u) + info.z;
+            const unsigned long long kv = __hip_atomic_load(sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool winner = (unsigned)(kv & 0xffffffffULL) == (unsigned)ii && kv != 0ULL;
+            if (winner && er == 0) __hip_atomic_store(sk, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have = have && winner;
         }
-        const int np = __popcll(__ballot(pass));
-        if (lane == 0 && np) atomicAdd(&c.fr[ST_PEND], np);
     }
+    // Path records (:497-509): one atomic per unit
+    const bool need_path = have && info.x >= 0 && info.y != 0;
+    int tot_paths;
+    const int mypath = block_excl_scan((need_path && er == 0) ? 1 : 0, sh_w, tot_paths);
+    if (threadIdx.x == 0) *sh_pb = tot_paths ? atomicAdd(&c.n_paths, tot_paths) : 0;
+    __syncthreads();
+    int rs = 0, deg = 0;
+    if (have) {
+        int state = C.init_state;
+        if (info.x >= 0) {
+            if (need_path) {
+                int p = *sh_pb + mypath;                               // valid on the group's lane 0
+                p = __shfl(p, lane & ~(EG - 1));
+                if (p < C.cap_paths) {
+                    if (er == 0) {
+                        PathRec pr;
+                        pr.prev = t.path; pr.frame = frame; pr.label = info.y; pr.pad0 = 0;
+                        pr.score = t.score; pr.ac = t.ac; pr.lm = t.lm; pr.pad1 = 0.0f;
+                        S.paths[p] = pr;
+                        S.item_tok[ii].path = p;
+                        ++n_paths_made;
+                    }
+                    t.path = p;
+                } else c.error = -43;
+            }
+            state = info.z;
+            if (er == 0) {                                             // :513-520 final state
+                const float fw = C.fin_w[state];
+                if (fw < INF) {
+                    const float cs = t.score + fw;
+                    if (cs > LZ) atomicMax(&c.final_key, ((unsigned long long)f2o(cs) << 32) | (unsigned)ii);
+                }
+            }
+        }
+        rs = C.row_ptr[state];
+        deg = C.row_ptr[state + 1] - rs;
+    }
+    expand_arcs(C, c, S, stage, t, ii, rs, deg, endTh, wordTh, sk_out, items_counter, items_base, n_arcs);
 }
 
 // frontier rounds 0 and 1, flattened over all streams.  ROUND 0 reads the live exit tokens
-// written by phase A and applies the end/word threshold (doHMMExternalPropagation :946-962).
-// A unit is 64 items: each wave takes 16 of them, 4 at a time (EG lanes per item).
+// written (and bid for their destination states) by phase A.
 template <int ROUND>
 __global__ __launch_bounds__(KT) void k_expand(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B)
 {
     __shared__ int sh_pre[MAX_B + 1];
     __shared__ int sh_w[8];
-    __shared__ WaveStage sh_stage[KT / 64];
-    constexpr int GPW = 64 / EG;                                       // items per wave-iteration
-    constexpr int IPW = GPW;                                           // items per wave per unit
-    constexpr int PER = IPW * (KT / 64);                               // items per unit
-    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    if (lane == 0) sh_stage[wid].n = 0;
+    __shared__ int sh_pb;
+    __shared__ BlockStage stage;
+    __shared__ int sh_acc[2][3];                                       // [run parity][ARCS, PATHS, PEND]
+    constexpr int PER = KT / EG;                                       // items per unit
+    const int tid = threadIdx.x, lane = lane_id();
+    if (tid == 0) stage.n = 0;
+    if (tid < 6) (&sh_acc[0][0])[tid] = 0;
     const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
         const StreamCtl &c = ctl[s0 + s];
         if (c.active == 0) return 0;
         const int n = (ROUND == 0) ? pk_cnt0(c.pkA) : c.cnt1;
         return (n + PER - 1) / PER;
     });
-    WaveStage &stage = sh_stage[wid];
     const int upb = (total + gridDim.x - 1) / gridDim.x;
     const int u0 = blockIdx.x * upb, u1 = (u0 + upb < total) ? u0 + upb : total;
-    int cur_s = -1;
-    int n_arcs = 0, n_paths_made = 0, n_pend = 0;
-    auto flush = [&](int sidx) {                                       // per wave
+    int cur_s = -1, run = 0;
+    auto flush = [&](int sidx, int buf) {                              // thread 0 only
         StreamCtl &cf = ctl[sidx];
-        stage_flush(C, cf, streams[sidx], stage);
-        n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
-        if (lane == 0) {
-            if (n_arcs) atomicAdd(&cf.fr[ST_ARCS], n_arcs);
-            if (n_paths_made) atomicAdd(&cf.fr[ST_PATHS], n_paths_made);
-            if (n_pend) atomicAdd(&cf.fr[ST_PEND], n_pend);
-        }
-        n_arcs = 0; n_paths_made = 0; n_pend = 0;
+        int *a = sh_acc[buf];
+        if (a[0]) atomicAdd(&cf.fr[ST_ARCS], a[0]);
+        if (a[1]) atomicAdd(&cf.fr[ST_PATHS], a[1]);
+        if (a[2]) atomicAdd(&cf.fr[ST_PEND], a[2]);
+        a[0] = a[1] = a[2] = 0;
     };
     for (int u = u0; u < u1; ++u) {
         const int sl = find_stream(sh_pre, B, u);
         const int s = s0 + sl;
         if (s != cur_s) {
-            if (cur_s >= 0) flush(cur_s);
-            cur_s = s;
+            if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
+            cur_s = s; ++run;
         }
+        int *acc = sh_acc[run & 1];
         StreamCtl &c = ctl[s];
         const StreamDev &S = streams[s];
         const float bestA = o2f(c.best);
@@ -909,17 +919,21 @@ __global__ __launch_bounds__(KT) void k_expand(DecConst C, StreamCtl *ctl, Strea
         const int nin = (ROUND == 0) ? cnt0 : c.cnt1;
         const int in_base = (ROUND == 0) ? 0 : cnt0;
         const int out_base = (ROUND == 0) ? cnt0 : cnt0 + c.cnt1;
-        const int kbase = (u - sh_pre[sl]) * PER + wid * IPW;
-        for (int it = 0; it < IPW; it += GPW) {
-            const int k = kbase + it + (lane / EG);
-            const bool have = k < nin;
-            const int ii = in_base + k;
-            if (!__any(have)) continue;
-            expand_item(C, c, S, stage, c.frame, endTh, wordTh, have, ii, ROUND & 1, (ROUND == 0) ? &c.cnt1 : &c.cnt2,
-                        out_base, n_arcs, n_paths_made);
+        const int k = (u - sh_pre[sl]) * PER + (tid / EG);
+        int n_arcs = 0, n_paths_made = 0, n_pend = 0;
+        expand_unit(C, c, S, stage, sh_w, &sh_pb, c.frame, endTh, wordTh, ROUND == 0 && !init, k < nin, in_base + k,
+                    S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], S.skey[(ROUND & 1) ^ 1],
+                    (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base, n_arcs, n_paths_made, n_pend);
+        n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
+        if (lane == 0) {
+            if (n_arcs) atomicAdd(&acc[0], n_arcs);
+            if (n_paths_made) atomicAdd(&acc[1], n_paths_made);
+            if (n_pend) atomicAdd(&acc[2], n_pend);
         }
+        stage_flush_block(C, c, S, stage);
     }
-    if (cur_s >= 0) flush(cur_s);
+    __syncthreads();
+    if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
 }
 
 // remaining closure rounds (items produced by round 1 and later): rare, one block per stream
@@ -927,12 +941,14 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
 {
     StreamCtl &c = ctl[s0 + blockIdx.x];
     if (c.active == 0 || c.cnt2 == 0) return;
-    __shared__ WaveStage sh_stage[KT / 64];
+    __shared__ int sh_w[8];
+    __shared__ int sh_pb;
+    __shared__ BlockStage stage;
     const StreamDev &S = streams[s0 + blockIdx.x];
     constexpr int PER = KT / EG;
-    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    if (lane == 0) sh_stage[wid].n = 0;
-    WaveStage &stage = sh_stage[wid];
+    const int tid = threadIdx.x, lane = lane_id();
+    if (tid == 0) stage.n = 0;
+    __syncthreads();
     const float bestA = o2f(c.best);
     const bool init = c.active == 2;
     const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;
@@ -940,12 +956,13 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
     const int base = pk_cnt0(c.pkA) + c.cnt1;
     int r0 = 0, r1 = c.cnt2;                       // window within the tail region [base + r0, base + r1)
     const int tail_base = base + c.cnt2;           // items appended here: tail_base + cnt_tail++
-    int n_arcs = 0, n_paths_made = 0, parity = 0;
+    int n_arcs = 0, n_paths_made = 0, n_pend = 0, parity = 0;
     while (r1 > r0) {
         for (int k0 = r0; k0 < r1; k0 += PER) {
             const int k = k0 + (tid / EG);
-            expand_item(C, c, S, stage, c.frame, endTh, wordTh, k < r1, base + k, parity, &c.cnt_tail, tail_base,
-                        n_arcs, n_paths_made);
+            expand_unit(C, c, S, stage, sh_w, &sh_pb, c.frame, endTh, wordTh, false, k < r1, base + k, S.skey[parity],
+                        S.skey[parity], S.skey[parity ^ 1], &c.cnt_tail, tail_base, n_arcs, n_paths_made, n_pend);
+            stage_flush_block(C, c, S, stage);
         }
         parity ^= 1;
         __syncthreads();
@@ -954,7 +971,6 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
         if (base + r1 > C.cap_items) r1 = C.cap_items - base;
         __syncthreads();
     }
-    stage_flush(C, c, S, stage);
     n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made);
     if (lane == 0) {
         if (n_arcs) atomicAdd(&c.fr[ST_ARCS], n_arcs);
@@ -1386,7 +1402,7 @@ static int ensure_arenas(jd_dec *d)
         A(S.act[0], d->cap_slots); A(S.act[1], d->cap_slots);
         A(S.free_stk, d->cap_slots);
         A(S.ast, d->net->n_arcs);
-        A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states);
+        A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states);
         A(S.touched, d->cap_items);
         A(S.item_tok, d->cap_items); A(S.item_info, d->cap_items);
         A(S.paths, d->cap_paths);
@@ -1398,6 +1414,7 @@ static int ensure_arenas(jd_dec *d)
         HIPCHK(hipMemcpy(S.ast, ast0.data(), (size_t)d->net->n_arcs * sizeof(ArcState), hipMemcpyHostToDevice));
         HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(S.skeyL, 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.hist, 0, HIST_MAX_BINS * sizeof(int)));
     }
     rc = dmalloc(d, &d->d_streams, (size_t)B);
@@ -1462,6 +1479,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
             }
             HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
             HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(S.skeyL, 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
             const int zero = 0;
             HIPCHK(hipMemcpy((char *)(d->d_ctl + s0 + i) + offsetof(StreamCtl, n_act), &zero, sizeof(int),
                              hipMemcpyHostToDevice));
@@ -1516,7 +1534,7 @@ static void launch_init(jd_dec *d, int nb, int s0, hipStream_t st)
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 2);
 }
 
-// one lock-step frame for streams [s0, s0+nb); ev != nullptr: 8 events bracketing the 7 launches
+// one lock-step frame for streams [s0, s0+nb); ev != nullptr: 7 events bracketing the 6 launches
 static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll_stride, int f0, hipStream_t st,
                         hipEvent_t *ev = nullptr)
 {
@@ -1531,16 +1549,14 @@ static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll
         hipLaunchKernelGGL(k_phase_a<8>, dim3(GRID_A), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb, ll,
                            ll_stride, f0);
     EV(2);
-    hipLaunchKernelGGL(k_select0, dim3(GRID_S), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
-    EV(3);
     hipLaunchKernelGGL(k_expand<0>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
-    EV(4);
+    EV(3);
     hipLaunchKernelGGL(k_expand<1>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
-    EV(5);
+    EV(4);
     hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
-    EV(6);
+    EV(5);
     hipLaunchKernelGGL(k_resolve, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
-    EV(7);
+    EV(6);
 #undef EV
 }
 
@@ -1639,7 +1655,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
         (void)hipEventDestroy(ss[(size_t)c]); (void)hipEventDestroy(se[(size_t)c]);
     }
     for (int i = 0; i < d->kev_used; ++i)
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < 6; ++k) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, d->kev[(size_t)i * 8 + k], d->kev[(size_t)i * 8 + k + 1]) == hipSuccess)
                 d->timing.kernel_us[k] += 1e3 * ms;
