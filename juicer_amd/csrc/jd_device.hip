@@ -211,13 +211,15 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 //   k_resolve    winners become entry tokens; new instances attached     (:560-582, :751-774)
 
 #define TEE_FLAG 0x40000000          // bit 30 of the device arc's in-label: the arc's HMM is a tee model
-#define KT 256                       // threads per block of every search kernel
+#define KT 256                       // threads per block of the small search kernels (tail)
+#define KTB 256                      // threads per block of the flattened kernels (phase A, expand, resolve)
 #define EG 16                        // lanes cooperating on one frontier item
 #define MAX_B 1024                   // max concurrent streams
 
 struct DecConst {
     // network (CSR in HBM)
     const int *row_ptr; const JdArc *arcs; const float *fin_w; int init_state;
+    const int *aux;     // per arc: {tmax0 bits, nStates|transMat<<8, hmm, g0, g1, g2, [g3, g4, g5], pad..}
     // models
     int G, max_n, n_tm;
     const int *hmm_n, *hmm_tm, *hmm_gmm; const float *hmm_tee; const float *hmm_tmax0;
@@ -274,6 +276,7 @@ struct __align__(128) StreamCtl {
     __align__(128) int n_skipped;            // hopeless instances not materialised this frame
     __align__(128) int n_paths;
     __align__(128) unsigned long long final_key;
+    __align__(128) unsigned long long pkE;   // phase A: emit hyps processed | live emitting tokens << 32
     __align__(128) int fr[ST_N];             // per-frame work counters (flushed per block run)
     // ---- cold: touched by k_boundary / finish only
     __align__(128) Tok best_final;           // bestFinalToken of the last processed frame
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
             c.n_act = 0; c.hw = 0; c.n_free = 0; c.n_paths = 0; c.frame = 0; c.error = 0;
             c.best_emit = LZ; c.normalise = 0.0f; c.emitTh = LZ; c.startTh = LZ;
             c.best = f2o(LZ); c.pkA = 1ULL << PK_SHIFT1;                         // cnt0 = 1: the start token
+            c.pkE = 0ULL;
             c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
             c.n_alloc = 0; c.n_touched = 0; c.final_key = 0ULL; c.n_skipped = 0; c.skipped_prev = 0;
             for (int k = 0; k < ST_N; ++k) { c.fr[k] = 0; c.st[k] = 0; }
@@ -423,39 +427,51 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         return;
     }
 
-    // ---- epilogue of the frame processed in this step's predecessor kernels
-    if (c.active == 1) {
+    // ---- epilogue of the frame processed in this step's predecessor kernels.  Every counter
+    // lives on its own cache line: fetch them all first (independent loads in flight together).
+    const int v_active = c.active, v_nfree = c.n_free, v_hw = c.hw, v_nalloc = c.n_alloc, v_nskip = c.n_skipped;
+    const int v_skprev = c.skipped_prev, v_lst = c.lst, v_frame = c.frame, v_npaths = c.n_paths;
+    const int v_started = c.started, v_needs_init = c.needs_init, v_error = c.error, v_T = c.T;
+    const unsigned long long v_pk = c.pkA, v_pe = c.pkE, v_fkey = c.final_key;
+    const unsigned v_best = c.best;
+    int v_fr = (lane < ST_N) ? c.fr[lane] : 0;
+    long long v_st = (lane < ST_N) ? c.st[lane] : 0;
+    float best_emit = c.best_emit;
+    int frame_now = v_frame;
+    if (v_active == 1) {
+        const int nfree0 = v_nfree + pk_ndead(v_pk);
+        const int from_free = v_nalloc < nfree0 ? v_nalloc : nfree0;
+        best_emit = o2f(v_best);
+        frame_now = v_frame + 1;
+        // per-frame statistics: lane k owns counter k
+        if (lane == ST_MODELS) v_fr = pk_nB(v_pk) + v_nalloc + v_nskip;                     // :981
+        if (lane == ST_INSTS) v_fr = pk_nB(v_pk) + pk_ndead(v_pk) + v_skprev;               // skipped ones die "now"
+        if (lane == ST_END) v_fr = pk_cnt0(v_pk);
+        if (lane == ST_PEMIT) v_fr = (int)(v_pe & 0xffffffffULL);
+        if (lane == ST_EMIT) v_fr = (int)(v_pe >> 32);
+        if (lane < ST_N) { c.st[lane] = v_st + v_fr; c.fr[lane] = 0; }
         if (lane == 0) {
-            const unsigned long long pk = c.pkA;
-            const int nfree0 = c.n_free + pk_ndead(pk);
-            const int from_free = c.n_alloc < nfree0 ? c.n_alloc : nfree0;
             c.n_free = nfree0 - from_free;
-            c.hw += c.n_alloc - from_free;
-            c.n_act = pk_nB(pk) + c.n_alloc;
-            c.best_emit = o2f(c.best);
-            const unsigned long long key = c.final_key;
-            if (key != 0ULL) {
-                const int ii = (int)(unsigned)(key & 0xffffffffULL);
+            c.hw = v_hw + (v_nalloc - from_free);
+            c.n_act = pk_nB(v_pk) + v_nalloc;
+            c.best_emit = best_emit;
+            if (v_fkey != 0ULL) {
+                const int ii = (int)(unsigned)(v_fkey & 0xffffffffULL);
                 const Tok it = S.item_tok[ii];
                 const float fw = C.fin_w[S.item_info[ii].z];
                 Tok bf;
-                bf.score = o2f((unsigned)(key >> 32)); bf.ac = it.ac; bf.lm = it.lm + fw; bf.path = it.path;
+                bf.score = o2f((unsigned)(v_fkey >> 32)); bf.ac = it.ac; bf.lm = it.lm + fw; bf.path = it.path;
                 c.best_final = bf;
             } else c.best_final = null_tok();
-            c.fr[ST_MODELS] = pk_nB(pk) + c.n_alloc + c.n_skipped;               // :981
-            c.fr[ST_INSTS] += c.skipped_prev;       // skipped instances would have been processed (and died) now
-            c.skipped_prev = c.n_skipped;
-            for (int k = 0; k < ST_N; ++k) { c.st[k] += c.fr[k]; c.fr[k] = 0; }
-            c.lst ^= 1;
-            c.frame += 1;
-            if (c.n_paths > C.cap_paths) c.n_paths = C.cap_paths;
+            c.skipped_prev = v_nskip;
+            c.lst = v_lst ^ 1;
+            c.frame = frame_now;
+            if (v_npaths > C.cap_paths) c.n_paths = C.cap_paths;
         }
-        __syncthreads();
     }
     // ---- start of the next frame (:311-339)
-    const bool go = c.started && !c.needs_init && c.error == 0 && c.frame < c.T;
-    if (!go) { if (lane == 0) c.active = 0; return; }
-    const float best_emit = c.best_emit;
+    const bool go = v_started && !v_needs_init && v_error == 0 && frame_now < v_T;
+    if (!go) { if (lane == 0 && v_active != 0) c.active = 0; return; }
     const float normalise = (best_emit > LZ) ? best_emit : 0.0f;                 // :321
     float emitTh = (C.emit_win > 0.0f ? -C.emit_win : LZ);                       // :331
     if (use_hist) {                                                              // Histogram::calcThresh, Histogram.cpp:134-158
@@ -496,11 +512,11 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
     if (lane == 0) {
         c.normalise = normalise; c.emitTh = emitTh;
         c.startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;       // :337
-        c.best = f2o(LZ); c.pkA = 0ULL;                                          // :905
+        c.best = f2o(LZ); c.pkA = 0ULL; c.pkE = 0ULL;                            // :905
         c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
         c.n_alloc = 0; c.n_touched = 0; c.n_skipped = 0;
         c.final_key = 0ULL;                                                      // :316 bestFinalToken = nullToken
-        c.active = 1;
+        if (v_active != 1) c.active = 1;
     }
 }
 
@@ -509,54 +525,36 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
 // builds the exit token from its neighbours' results (intra-group shuffles).  Each block
 // walks a CONTIGUOUS range of units, so its work counters are flushed once per stream run.
 template <int GS>
-__global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B,
+__global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS,
                                                 const float *__restrict__ ll, long long ll_stride, int f0)
 {
-    __shared__ int sh_pre[MAX_B + 1];
-    __shared__ int sh_w[8];
-    __shared__ unsigned long long sh_w3[KT / 64];
+    __shared__ unsigned long long sh_w3[KTB / 64];
     __shared__ unsigned long long sh_pk;
-    __shared__ int sh_acc[2][5];                                       // [run parity][PEMIT, EMIT, INSTS, END, best]
-    constexpr int PER = KT / GS;                                       // instances per unit
+    __shared__ unsigned long long sh_pe;                               // pemit | emit << 32 of this block
+    __shared__ unsigned sh_bb;                                         // best emitting score of this block
+    constexpr int PER = KTB / GS;                                      // instances per unit
     typedef RecLayout<GS> RL;
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int MN = C.max_n;
-    if (tid < 10) (&sh_acc[0][0])[tid] = 0;
-    const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
-        const StreamCtl &c = ctl[s0 + s];
-        return c.active == 1 ? (c.n_act + PER - 1) / PER : 0;
-    });
+    // static block -> stream assignment: no unit map, no search, one stream per block
+    const int sl = blockIdx.x / BPS, j0 = blockIdx.x - sl * BPS;
+    const int s = s0 + sl;
+    StreamCtl &c = ctl[s];
+    if (c.active != 1) return;
+    const StreamDev &S = streams[s];
+    const int units = (c.n_act + PER - 1) / PER;
+    if (j0 >= units) return;
+    if (tid == 0) { sh_pe = 0ULL; sh_bb = 0u; }
+    __syncthreads();
     const int r = tid & (GS - 1), gb = lane & ~(GS - 1);
     const bool use_hist = C.max_hyps > 0;
-    const int upb = (total + gridDim.x - 1) / gridDim.x;
-    const int u0 = blockIdx.x * upb, u1 = (u0 + upb < total) ? u0 + upb : total;
-    int cur_s = -1, run = 0;
-    auto flush = [&](int sidx, int buf) {                              // thread 0 only
-        StreamCtl &cf = ctl[sidx];
-        int *a = sh_acc[buf];
-        if (a[0]) atomicAdd(&cf.fr[ST_PEMIT], a[0]);
-        if (a[1]) atomicAdd(&cf.fr[ST_EMIT], a[1]);
-        if (a[2]) atomicAdd(&cf.fr[ST_INSTS], a[2]);
-        if (a[3]) atomicAdd(&cf.fr[ST_END], a[3]);
-        if (a[4]) atomicMax(&cf.best, (unsigned)a[4]);                 // :417-418
-        a[0] = a[1] = a[2] = a[3] = a[4] = 0;
-    };
-    for (int u = u0; u < u1; ++u) {
-        const int sl = find_stream(sh_pre, B, u);
-        const int s = s0 + sl;
-        if (s != cur_s) {
-            if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
-            cur_s = s; ++run;
-        }
-        int *acc = sh_acc[run & 1];
-        StreamCtl &c = ctl[s];
-        const StreamDev &S = streams[s];
+    for (int u = j0; u < units; u += BPS) {
         const int n_act = c.n_act;
         const float normalise = c.normalise, emitTh = c.emitTh, startTh = c.startTh;
         const int *act_cur = S.act[c.lst];
         int *act_next = S.act[c.lst ^ 1];
         const float *llrow = ll + (size_t)sl * ll_stride + (size_t)(c.frame - f0) * C.G;
-        const int q = (u - sh_pre[sl]) * PER + (tid / GS);
+        const int q = u * PER + (tid / GS);
         const bool valid = q < n_act;
         bool emit_live = false, has_exit = false, pemit = false;
         int slot = -1, arc = -1, n = 0;
@@ -573,6 +571,8 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
             n = h0.y & 0xff;
             const int tm = h0.y >> 8;
             tk = (Tok *)(rec + RL::TOK_OFF);
+            // speculative: left-to-right HMMs read states r and r+1; issued together with the header
+            const Tok spec0 = tk[r], spec1 = tk[(r + 1 < MN) ? r + 1 : r];
             trP = C.trP + (size_t)tm * MN * MN;
             se = C.se32 + (size_t)tm * MN;
             exinfo = make_int4(arc, h0.z, h0.w, 0);
@@ -587,12 +587,12 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
                 const float outp = llrow[gmj];                         // :411
                 const int sev = se[j];
                 const int st = sev & 0xffff, en = sev >> 16;
-                Tok src = tk[st];
+                Tok src = (st == r) ? spec0 : (st == r + 1) ? spec1 : tk[st];
                 if (st == 0 && src.score > LZ && src.score < startTh) src = null_tok();   // :915-918
                 float btp = trP[st * MN + j];
                 float best = src.score + btp;
                 for (int i = st + 1; i < en; ++i) {
-                    const Tok cnd = tk[i];
+                    const Tok cnd = (i == r) ? spec0 : (i == r + 1) ? spec1 : tk[i];
                     const float tp = trP[i * MN + j];
                     const float tmp = cnd.score + tp;
                     if (tmp > best) { best = tmp; btp = tp; src = cnd; }
@@ -661,19 +661,15 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
             if (lane == 0) {
                 sh_w3[wid] = (unsigned long long)__popcll(bl) | ((unsigned long long)__popcll(be) << PK_SHIFT1) |
                              ((unsigned long long)__popcll(bd) << PK_SHIFT2);
-                if (c_pemit) atomicAdd(&acc[0], c_pemit);
-                if (bemit) atomicAdd(&acc[1], __popcll(bemit));
-                if (mo) atomicMax((unsigned *)&acc[4], mo);
+                const unsigned long long pe = (unsigned long long)c_pemit | ((unsigned long long)__popcll(bemit) << 32);
+                if (pe) atomicAdd(&sh_pe, pe);
+                if (mo) atomicMax(&sh_bb, mo);
             }
         }
         __syncthreads();
         unsigned long long pre = 0, tot = 0;
-        for (int w = 0; w < (KT >> 6); ++w) { const unsigned long long sv = sh_w3[w]; if (w < wid) pre += sv; tot += sv; }
-        if (tid == 0) {
-            sh_pk = tot ? atomicAdd(&c.pkA, tot) : 0ULL;
-            acc[2] += pk_nB(tot) + pk_ndead(tot);
-            acc[3] += pk_cnt0(tot);
-        }
+        for (int w = 0; w < (KTB >> 6); ++w) { const unsigned long long sv = sh_w3[w]; if (w < wid) pre += sv; tot += sv; }
+        if (tid == 0) sh_pk = tot ? atomicAdd(&c.pkA, tot) : 0ULL;
         __syncthreads();
         const unsigned long long bs = sh_pk;
         if (live) act_next[pk_nB(bs) + pk_nB(pre) + rank_in(bl)] = slot;
@@ -693,7 +689,10 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
         }
     }
     __syncthreads();
-    if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
+    if (tid == 0) {
+        if (sh_pe) atomicAdd(&c.pkE, sh_pe);
+        if (sh_bb) atomicMax(&c.best, sh_bb);                          // :417-418
+    }
 }
 
 // ---- frontier expansion: propagateToken (WFSTDecoderLite.cpp:491-605).
@@ -705,8 +704,8 @@ __global__ __launch_bounds__(KT) void k_phase_a(DecConst C, StreamCtl *ctl, Stre
 // monotonicity of float addition no other item can win anything downstream.
 // Block-level aggregation: Path records are allocated with one atomic per unit, first-touched
 // arcs are staged in LDS and appended to the stream's list with one atomic per unit.
-#define TBS_CAP 4096
-struct BlockStage { int n; int fb; int buf[TBS_CAP]; };
+#define TBS_CAP 1536
+struct BlockStage { int n; int fb; int np; int pb; int buf[TBS_CAP]; };
 
 __device__ __forceinline__ void stage_touch(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st,
                                             bool touch, int tb)
@@ -735,11 +734,11 @@ __device__ __forceinline__ void stage_flush_block(const DecConst &C, StreamCtl &
     if (threadIdx.x == 0) st.fb = n ? atomicAdd(&c.n_touched, n) : 0;
     __syncthreads();
     const int fb = st.fb;
-    for (int k = threadIdx.x; k < n; k += KT) {
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
         if (fb + k < C.cap_items) S.touched[fb + k] = st.buf[k]; else c.error = -42;
     }
     __syncthreads();
-    if (threadIdx.x == 0) st.n = 0;
+    if (threadIdx.x == 0) { st.n = 0; st.np = 0; }
     __syncthreads();
 }
 
@@ -804,20 +803,45 @@ __device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, con
 //   sk_in_u / sk_in_l : per-state key arrays of this round (unlabelled / word-labelled class)
 //   check_th          : apply the end/word threshold of doHMMExternalPropagation (:952-962) (round 0)
 __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
-                                            int *sh_w, int *sh_pb, int frame, float endTh, float wordTh, bool check_th,
+                                            int frame, bool last_frame, float endTh, float wordTh, bool check_th,
                                             bool have, int ii, unsigned long long *sk_in_u,
                                             unsigned long long *sk_in_l, unsigned long long *sk_out,
                                             int *items_counter, int items_base, int &n_arcs, int &n_paths_made,
                                             int &n_pend)
 {
     const int lane = lane_id();
-    const int er = lane & (EG - 1);
+    const int er = lane & (EG - 1), eb = lane & ~(EG - 1);
     const float INF = __builtin_inff();
     Tok t = null_tok();
     int4 info = make_int4(-1, 0, 0, 0);
+    int rs = 0, rs1 = 0;
     if (have) {
         info = S.item_info[ii];
         t = S.item_tok[ii];
+    }
+    // Path records (:497-509) are reserved per BLOCK as soon as the labels are known (one
+    // returning atomic per unit, overlapped with the loads below); the index of an item that
+    // turns out not to be expanded is simply left unused.
+    int p = -1;
+    {
+        const bool labelled = have && info.x >= 0 && info.y != 0 && er == 0;
+        const unsigned long long bl = __ballot(labelled);
+        int wb = 0;
+        if (bl) {
+            const int first = __ffsll((long long)bl) - 1;
+            if (lane == first) wb = atomicAdd(&stage.np, __popcll(bl));          // LDS
+            wb = __shfl(wb, first);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { const int np = stage.np; stage.pb = np ? atomicAdd(&c.n_paths, np) : 0; }
+        __syncthreads();
+        p = labelled ? stage.pb + wb + rank_in(bl) : -1;
+        p = __shfl(p, eb);
+    }
+    if (have) {
+        const int state = (info.x >= 0) ? info.z : C.init_state;
+        rs = C.row_ptr[state];                                         // issued before the winner is known
+        rs1 = C.row_ptr[state + 1];
         if (info.x >= 0) {
             if (check_th) {                                            // :952-962
                 have = t.score > ((info.y != 0) ? wordTh : endTh);
@@ -830,19 +854,10 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
             have = have && winner;
         }
     }
-    // Path records (:497-509): one atomic per unit
-    const bool need_path = have && info.x >= 0 && info.y != 0;
-    int tot_paths;
-    const int mypath = block_excl_scan((need_path && er == 0) ? 1 : 0, sh_w, tot_paths);
-    if (threadIdx.x == 0) *sh_pb = tot_paths ? atomicAdd(&c.n_paths, tot_paths) : 0;
-    __syncthreads();
-    int rs = 0, deg = 0;
+    int deg = 0;
     if (have) {
-        int state = C.init_state;
         if (info.x >= 0) {
-            if (need_path) {
-                int p = *sh_pb + mypath;                               // valid on the group's lane 0
-                p = __shfl(p, lane & ~(EG - 1));
+            if (info.y != 0) {
                 if (p < C.cap_paths) {
                     if (er == 0) {
                         PathRec pr;
@@ -855,17 +870,17 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
                     t.path = p;
                 } else c.error = -43;
             }
-            state = info.z;
-            if (er == 0) {                                             // :513-520 final state
-                const float fw = C.fin_w[state];
+            // :513-520 final state.  bestFinalToken is reset every frame (:316) and only read by
+            // finish(), so it only has to be evaluated on the last frame that is available.
+            if (er == 0 && last_frame) {
+                const float fw = C.fin_w[info.z];
                 if (fw < INF) {
                     const float cs = t.score + fw;
                     if (cs > LZ) atomicMax(&c.final_key, ((unsigned long long)f2o(cs) << 32) | (unsigned)ii);
                 }
             }
         }
-        rs = C.row_ptr[state];
-        deg = C.row_ptr[state + 1] - rs;
+        deg = rs1 - rs;
     }
     expand_arcs(C, c, S, stage, t, ii, rs, deg, endTh, wordTh, sk_out, items_counter, items_base, n_arcs);
 }
@@ -873,44 +888,22 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
 // frontier rounds 0 and 1, flattened over all streams.  ROUND 0 reads the live exit tokens
 // written (and bid for their destination states) by phase A.
 template <int ROUND>
-__global__ __launch_bounds__(KT) void k_expand(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B)
+__global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS)
 {
-    __shared__ int sh_pre[MAX_B + 1];
-    __shared__ int sh_w[8];
-    __shared__ int sh_pb;
     __shared__ BlockStage stage;
-    __shared__ int sh_acc[2][3];                                       // [run parity][ARCS, PATHS, PEND]
-    constexpr int PER = KT / EG;                                       // items per unit
+    __shared__ int sh_acc[3];                                          // ARCS, PATHS, PEND of this block
+    constexpr int PER = KTB / EG;                                      // items per unit
     const int tid = threadIdx.x, lane = lane_id();
-    if (tid == 0) stage.n = 0;
-    if (tid < 6) (&sh_acc[0][0])[tid] = 0;
-    const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
-        const StreamCtl &c = ctl[s0 + s];
-        if (c.active == 0) return 0;
-        const int n = (ROUND == 0) ? pk_cnt0(c.pkA) : c.cnt1;
-        return (n + PER - 1) / PER;
-    });
-    const int upb = (total + gridDim.x - 1) / gridDim.x;
-    const int u0 = blockIdx.x * upb, u1 = (u0 + upb < total) ? u0 + upb : total;
-    int cur_s = -1, run = 0;
-    auto flush = [&](int sidx, int buf) {                              // thread 0 only
-        StreamCtl &cf = ctl[sidx];
-        int *a = sh_acc[buf];
-        if (a[0]) atomicAdd(&cf.fr[ST_ARCS], a[0]);
-        if (a[1]) atomicAdd(&cf.fr[ST_PATHS], a[1]);
-        if (a[2]) atomicAdd(&cf.fr[ST_PEND], a[2]);
-        a[0] = a[1] = a[2] = 0;
-    };
-    for (int u = u0; u < u1; ++u) {
-        const int sl = find_stream(sh_pre, B, u);
-        const int s = s0 + sl;
-        if (s != cur_s) {
-            if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
-            cur_s = s; ++run;
-        }
-        int *acc = sh_acc[run & 1];
-        StreamCtl &c = ctl[s];
-        const StreamDev &S = streams[s];
+    const int sl = blockIdx.x / BPS, j0 = blockIdx.x - sl * BPS;
+    const int s = s0 + sl;
+    StreamCtl &c = ctl[s];
+    if (c.active == 0) return;
+    const StreamDev &S = streams[s];
+    const int units = (((ROUND == 0) ? pk_cnt0(c.pkA) : c.cnt1) + PER - 1) / PER;
+    if (j0 >= units) return;
+    if (tid == 0) { stage.n = 0; stage.np = 0; sh_acc[0] = sh_acc[1] = sh_acc[2] = 0; }
+    __syncthreads();
+    for (int u = j0; u < units; u += BPS) {
         const float bestA = o2f(c.best);
         const bool init = c.active == 2;
         const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;      // :349
@@ -919,35 +912,38 @@ __global__ __launch_bounds__(KT) void k_expand(DecConst C, StreamCtl *ctl, Strea
         const int nin = (ROUND == 0) ? cnt0 : c.cnt1;
         const int in_base = (ROUND == 0) ? 0 : cnt0;
         const int out_base = (ROUND == 0) ? cnt0 : cnt0 + c.cnt1;
-        const int k = (u - sh_pre[sl]) * PER + (tid / EG);
+        const int k = u * PER + (tid / EG);
         int n_arcs = 0, n_paths_made = 0, n_pend = 0;
-        expand_unit(C, c, S, stage, sh_w, &sh_pb, c.frame, endTh, wordTh, ROUND == 0 && !init, k < nin, in_base + k,
+        expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, endTh, wordTh, ROUND == 0 && !init, k < nin,
+                    in_base + k,
                     S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], S.skey[(ROUND & 1) ^ 1],
                     (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base, n_arcs, n_paths_made, n_pend);
         n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
         if (lane == 0) {
-            if (n_arcs) atomicAdd(&acc[0], n_arcs);
-            if (n_paths_made) atomicAdd(&acc[1], n_paths_made);
-            if (n_pend) atomicAdd(&acc[2], n_pend);
+            if (n_arcs) atomicAdd(&sh_acc[0], n_arcs);
+            if (n_paths_made) atomicAdd(&sh_acc[1], n_paths_made);
+            if (n_pend) atomicAdd(&sh_acc[2], n_pend);
         }
         stage_flush_block(C, c, S, stage);
     }
     __syncthreads();
-    if (tid == 0 && cur_s >= 0) flush(cur_s, run & 1);
+    if (tid == 0) {
+        if (sh_acc[0]) atomicAdd(&c.fr[ST_ARCS], sh_acc[0]);
+        if (sh_acc[1]) atomicAdd(&c.fr[ST_PATHS], sh_acc[1]);
+        if (sh_acc[2]) atomicAdd(&c.fr[ST_PEND], sh_acc[2]);
+    }
 }
 
 // remaining closure rounds (items produced by round 1 and later): rare, one block per stream
 __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0)
 {
     StreamCtl &c = ctl[s0 + blockIdx.x];
-    if (c.active == 0 || c.cnt2 == 0) return;
-    __shared__ int sh_w[8];
-    __shared__ int sh_pb;
+    if ((c.active == 0) | (c.cnt2 == 0)) return;
     __shared__ BlockStage stage;
     const StreamDev &S = streams[s0 + blockIdx.x];
     constexpr int PER = KT / EG;
     const int tid = threadIdx.x, lane = lane_id();
-    if (tid == 0) stage.n = 0;
+    if (tid == 0) { stage.n = 0; stage.np = 0; }
     __syncthreads();
     const float bestA = o2f(c.best);
     const bool init = c.active == 2;
@@ -960,7 +956,8 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
     while (r1 > r0) {
         for (int k0 = r0; k0 < r1; k0 += PER) {
             const int k = k0 + (tid / EG);
-            expand_unit(C, c, S, stage, sh_w, &sh_pb, c.frame, endTh, wordTh, false, k < r1, base + k, S.skey[parity],
+            expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, endTh, wordTh, false, k < r1, base + k,
+                        S.skey[parity],
                         S.skey[parity], S.skey[parity ^ 1], &c.cnt_tail, tail_base, n_arcs, n_paths_made, n_pend);
             stage_flush_block(C, c, S, stage);
         }
@@ -980,36 +977,27 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
 
 // ---- resolve: the winning candidate of every touched arc becomes the entry token of its
 // instance; missing instances are attached here (attachNetInst :751-774), one lane per arc.
-__global__ __launch_bounds__(KT) void k_resolve(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int B)
+__global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS)
 {
-    __shared__ int sh_pre[MAX_B + 1];
-    __shared__ int sh_w[8];
+    __shared__ int sh_w[KTB / 64];
     __shared__ int sh_base;
-    __shared__ unsigned sh_best[2];
+    __shared__ unsigned sh_best;
+    __shared__ int sh_skip;
     const int tid = threadIdx.x, lane = lane_id();
     const int MN = C.max_n;
-    const int rec_ints = (MN <= 5) ? 32 : 64, tok_off = (MN <= 5) ? 8 : 12;
-    if (tid < 2) sh_best[tid] = 0u;
-    const int total = build_unit_map(B, sh_pre, sh_w, [&](int s) {
-        const StreamCtl &c = ctl[s0 + s];
-        if (c.active == 0) return 0;
-        const int nt = c.n_touched < C.cap_items ? c.n_touched : C.cap_items;
-        return (nt + KT - 1) / KT;
-    });
-    const int upb = (total + gridDim.x - 1) / gridDim.x;
-    const int u0 = blockIdx.x * upb, u1 = (u0 + upb < total) ? u0 + upb : total;
-    int cur_s = -1, run = 0;
-    for (int u = u0; u < u1; ++u) {
-        const int sl = find_stream(sh_pre, B, u);
-        const int s = s0 + sl;
-        if (s != cur_s) {
-            if (tid == 0 && cur_s >= 0 && sh_best[run & 1]) { atomicMax(&ctl[cur_s].best, sh_best[run & 1]); sh_best[run & 1] = 0u; }
-            cur_s = s; ++run;
-        }
-        StreamCtl &c = ctl[s];
-        const StreamDev &S = streams[s];
-        const int nt = c.n_touched < C.cap_items ? c.n_touched : C.cap_items;
-        const int q = (u - sh_pre[sl]) * KT + tid;
+    const int rec_ints = (MN <= 5) ? 32 : 64, tok_off = (MN <= 5) ? 8 : 12, aux_ints = (MN <= 5) ? 8 : 12;
+    const int sl = blockIdx.x / BPS, j0 = blockIdx.x - sl * BPS;
+    const int s = s0 + sl;
+    StreamCtl &c = ctl[s];
+    if (c.active == 0) return;
+    const StreamDev &S = streams[s];
+    const int nt = c.n_touched < C.cap_items ? c.n_touched : C.cap_items;
+    const int units = (nt + KTB - 1) / KTB;
+    if (j0 >= units) return;
+    if (tid == 0) { sh_best = 0u; sh_skip = 0; }
+    __syncthreads();
+    for (int u = j0; u < units; u += BPS) {
+        const int q = u * KTB + tid;
         int *act_next = S.act[c.lst ^ 1];
         const unsigned long long pk = c.pkA;
         const int nfree0 = c.n_free + pk_ndead(pk), hw0 = c.hw, nB = pk_nB(pk);
@@ -1024,25 +1012,30 @@ __global__ __launch_bounds__(KT) void k_resolve(DecConst C, StreamCtl *ctl, Stre
         int b = -1, slot = -1, ii = 0;
         float sc = LZ;
         JdArc Bk{0, 0.0f, 0, 0};
+        int4 ax0 = make_int4(0, 0, 0, 0), ax1 = make_int4(0, 0, 0, 0), ax2 = make_int4(0, 0, 0, 0);
         if (q < nt) {
             b = S.touched[q];
             ArcState *as = S.ast + b;
+            // one hop from the arc id: key (exchanged), slot, arc record and instance template together
             const unsigned long long key = atomicExch(&as->key, 0ULL);
+            slot = as->slot;
+            Bk = C.arcs[b];
+            const int4 *ap = (const int4 *)(C.aux + (size_t)b * aux_ints);
+            ax0 = ap[0]; ax1 = ap[1];
+            if (aux_ints == 12) ax2 = ap[2];
             sc = o2f((unsigned)(key >> 32));
             if (sc > LZ) {
                 win = true;
                 ii = (int)(unsigned)(key & 0xffffffffULL);
-                Bk = C.arcs[b];
-                slot = as->slot;
                 need = slot < 0;
                 if (need && can_skip) {
-                    const float tmax = C.hmm_tmax0[(Bk.in & ~TEE_FLAG) - 1];
+                    const float tmax = __int_as_float(ax0.x);
                     if ((sc + tmax) - bestA <= -C.emit_win) { skip = true; need = false; }
                 }
-            }
+            } else slot = -1;
         }
         const int nskip = __popcll(__ballot(skip));
-        if (lane == 0 && nskip) atomicAdd(&c.n_skipped, nskip);
+        if (lane == 0 && nskip) atomicAdd(&sh_skip, nskip);
         // block-aggregated allocation: one returning atomic per unit
         int tot_need;
         const int myk = block_excl_scan(need ? 1 : 0, sh_w, tot_need);
@@ -1055,14 +1048,14 @@ __global__ __launch_bounds__(KT) void k_resolve(DecConst C, StreamCtl *ctl, Stre
             if (ns_ >= C.cap_slots) { c.error = -41; slot = -1; }
             else {                                                     // attachNetInst :751-774
                 slot = ns_;
-                const int hm = (Bk.in & ~TEE_FLAG) - 1;
-                const int n = C.hmm_n[hm];
-                const int *hg = C.hmm_gmm + (size_t)hm * MN;
+                const int n = ax0.y & 0xff;
                 int *rec = S.rec + (size_t)slot * rec_ints;
-                *(int4 *)rec = make_int4(b, n | (C.hmm_tm[hm] << 8), Bk.out, Bk.to);
-                *(int4 *)(rec + 4) = make_int4((1 < n - 1) ? hg[1] : 0, (2 < n - 1) ? hg[2] : 0, (3 < n - 1) ? hg[3] : 0, hm);
-                if (rec_ints == 64)
-                    *(int4 *)(rec + 8) = make_int4((4 < n - 1) ? hg[4] : 0, (5 < n - 1) ? hg[5] : 0, (6 < n - 1) ? hg[6] : 0, 0);
+                *(int4 *)rec = make_int4(b, ax0.y, Bk.out, Bk.to);
+                if (rec_ints == 32) *(int4 *)(rec + 4) = make_int4(ax0.w, ax1.x, ax1.y, ax0.z);
+                else {
+                    *(int4 *)(rec + 4) = make_int4(ax0.w, ax1.x, ax1.y, ax0.z);
+                    *(int4 *)(rec + 8) = make_int4(ax1.z, ax1.w, ax2.x, 0);
+                }
                 Tok *tp = (Tok *)(rec + tok_off);
                 for (int qq = 1; qq < n; ++qq) tp[qq] = null_tok();
                 S.ast[b].slot = slot;
@@ -1077,11 +1070,14 @@ __global__ __launch_bounds__(KT) void k_resolve(DecConst C, StreamCtl *ctl, Stre
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_xor(mo, o); mo = y > mo ? y : mo; }
-        if (lane == 0 && mo) atomicMax(&sh_best[run & 1], mo);
+        if (lane == 0 && mo) atomicMax(&sh_best, mo);
         __syncthreads();
     }
     __syncthreads();
-    if (tid == 0 && cur_s >= 0 && sh_best[run & 1]) atomicMax(&ctl[cur_s].best, sh_best[run & 1]);
+    if (tid == 0) {
+        if (sh_best) atomicMax(&c.best, sh_best);
+        if (sh_skip) atomicAdd(&c.n_skipped, sh_skip);
+    }
 }
 
 // recognitionFinish (:230-309): walk the Path chain of bestFinalToken.
@@ -1220,7 +1216,7 @@ struct jd_dec {
     DecConst C{};
     AmDevBuf amb;
     // device copies of static data
-    int *d_row_ptr = nullptr; JdArc *d_arcs = nullptr; float *d_fin_w = nullptr;
+    int *d_row_ptr = nullptr; JdArc *d_arcs = nullptr; float *d_fin_w = nullptr; int *d_aux = nullptr;
     int *d_hmm_n = nullptr, *d_hmm_tm = nullptr, *d_hmm_gmm = nullptr, *d_se32 = nullptr;
     float *d_hmm_tee = nullptr, *d_trP = nullptr, *d_hmm_tmax0 = nullptr;
     // per-stream state
@@ -1352,6 +1348,25 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
     C.hmm_n = d->d_hmm_n; C.hmm_tm = d->d_hmm_tm; C.hmm_gmm = d->d_hmm_gmm; C.hmm_tee = d->d_hmm_tee;
     C.hmm_tmax0 = d->d_hmm_tmax0;
+    {   // per-arc instance template: everything k_resolve needs to attach an instance, one hop from the arc id
+        const int AI = (am->max_n <= 5) ? 8 : 12;
+        std::vector<int> aux((size_t)net->n_arcs * AI, 0);
+        for (int64_t b = 0; b < net->n_arcs; ++b) {
+            const int in = net->arcs[(size_t)b].in;
+            if (in <= 0) continue;
+            const int hm = in - 1, n = am->hmm_n[(size_t)hm];
+            const float *t0 = am->trP.data() + (size_t)am->hmm_tm[(size_t)hm] * am->max_n * am->max_n;
+            float tmax = LZ;
+            for (int j = 0; j < n; ++j) tmax = std::max(tmax, t0[j]);
+            int *a = aux.data() + (size_t)b * AI;
+            memcpy(&a[0], &tmax, sizeof(float));
+            a[1] = n | (am->hmm_tm[(size_t)hm] << 8);
+            a[2] = hm;
+            for (int j = 1; j < n - 1 && j <= (AI == 8 ? 3 : 6); ++j) a[2 + j] = am->hmm_gmm[(size_t)hm * am->max_n + j];
+        }
+        TRY(dupload(d, &d->d_aux, aux.data(), aux.size()));
+        C.aux = d->d_aux;
+    }
     C.trP = d->d_trP; C.se32 = d->d_se32;
     // default arena sizes: sized for 288 GB of HBM, not for frugality
     d->cap_slots = std::min<int64_t>(net->n_arcs + 1024, 1 << 18);
@@ -1519,18 +1534,18 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
 
 #define KSAMPLE_EVERY 16
 #define KSAMPLE_MAX 96
-#define GRID_A 4096
-#define GRID_X 2048
-#define GRID_S 512
+#define BPS_A 128      // blocks per stream: phase A (64 instances per unit; blocks loop beyond 8k instances)
+#define BPS_X 64       // frontier rounds (16 items per unit)
+#define BPS_R 64       // resolve (256 touched arcs per unit)
 
 // recognitionStart for every stream of [s0, s0+nb) that is flagged needs_init
 static void launch_init(jd_dec *d, int nb, int s0, hipStream_t st)
 {
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 1);
-    hipLaunchKernelGGL(k_expand<0>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
-    hipLaunchKernelGGL(k_expand<1>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_expand<0>, dim3(nb * BPS_X), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_X);
+    hipLaunchKernelGGL(k_expand<1>, dim3(nb * BPS_X), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_X);
     hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
-    hipLaunchKernelGGL(k_resolve, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_resolve, dim3(nb * BPS_R), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_R);
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 2);
 }
 
@@ -1543,19 +1558,19 @@ static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 0);
     EV(1);
     if (d->am->max_n <= 5)
-        hipLaunchKernelGGL(k_phase_a<4>, dim3(GRID_A), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb, ll,
+        hipLaunchKernelGGL(k_phase_a<4>, dim3(nb * BPS_A), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_A, ll,
                            ll_stride, f0);
     else
-        hipLaunchKernelGGL(k_phase_a<8>, dim3(GRID_A), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb, ll,
+        hipLaunchKernelGGL(k_phase_a<8>, dim3(nb * BPS_A), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_A, ll,
                            ll_stride, f0);
     EV(2);
-    hipLaunchKernelGGL(k_expand<0>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_expand<0>, dim3(nb * BPS_X), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_X);
     EV(3);
-    hipLaunchKernelGGL(k_expand<1>, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_expand<1>, dim3(nb * BPS_X), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_X);
     EV(4);
     hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
     EV(5);
-    hipLaunchKernelGGL(k_resolve, dim3(GRID_X), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0, nb);
+    hipLaunchKernelGGL(k_resolve, dim3(nb * BPS_R), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_R);
     EV(6);
 #undef EV
 }
