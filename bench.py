@@ -144,8 +144,20 @@ def main():
     search_bytes = (32.0 * MN * st["tot_insts_in"] + 4.0 * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]
                     + 24.0 * st["tot_proc_end_hyps"] + 52.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"])
     gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
+    # HBM traffic per launch of that kernel from the committed PMC passes (profiles/, same
+    # workload; separate --pmc runs).  (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 FETCH_SIZE reports
+    # half of a wide read (MI355X_MICROARCH.md, HBM); only valid for the default workload.
+    traffic = None
+    try:
+        default_cfg = (args.arcs == 1_000_000 and args.beam == 150.0 and args.max_hyps == 0 and U == 64 and args.seed == 0)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_pmc_summary.json")))
+        key = {"k_phase_a": "k_phase_a<4>", "jd_gmm_kernel": "jd_gmm_kernel<39>"}.get(dom, dom)
+        if default_cfg and key in pmc:
+            traffic = round((2.0 * pmc[key]["FETCH_SIZE"]["mean"] + pmc[key]["WRITE_SIZE"]["mean"]) * 1024.0, 1)
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(per_launch_bytes[dom], 1),
                 "avg_launch_us": round(avg_us[dom], 3), "launches_per_step": lock_steps if dom != "jd_gmm_kernel" else gmm_l,
                 "sampled_launches": ksamples if dom != "jd_gmm_kernel" else gmm_launches,

@@ -112,10 +112,20 @@ int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t max_mix,
                      const int32_t *hmm_gmm, const int32_t *hmm_tm,
                      int32_t n_tm, const int32_t *tm_nstates, const float *transp);
 
+/* HTK MMF text (HTKModels::Load, HTKModels.cpp:221-282): the subset the reference's
+ * flex/bison front-end accepts (htkparse.l.lpp:21-268, htkparse.y.ypp:113-147,414-685):
+ * ~o, ~v (ignored), ~s, ~t, ~h with shared or inline states / <TRANSP>, <NUMMIXES>/<MIXTURE>
+ * or the implicit single mixture, optional <GCONST>.  HMM index = order of the ~h macros. */
+int jd_am_load_mmf(jd_am **out, const char *mmf_path);
+
 int32_t jd_am_num_hmms(const jd_am *a);       /* IModels::getNumHMMs       (Models.h:57) */
 int32_t jd_am_num_gmms(const jd_am *a);
 int32_t jd_am_vec_size(const jd_am *a);       /* IModels::getInputVecSize  (Models.h:60) */
 int32_t jd_am_max_states(const jd_am *a);
+int32_t jd_am_max_mix(const jd_am *a);
+int32_t jd_am_num_transmats(const jd_am *a);
+/* topology read-back: hmm_nstates[n_hmm], hmm_gmm[n_hmm*max_states], hmm_tm[n_hmm], n_mix[n_gmm] */
+int jd_am_get_topology(const jd_am *a, int32_t *hmm_nstates, int32_t *hmm_gmm, int32_t *hmm_tm, int32_t *n_mix);
 /* Read back prepared parameters (host copies) - used by parity tests. */
 int jd_am_get_flat(const jd_am *a, float *det, float *mean, float *ivar);
 int jd_am_get_trans(const jd_am *a, float *trP, int16_t *se, float *tee);

@@ -70,7 +70,7 @@ class Hyp:
 EXPORTS = [
     "jd_net_create_arcs", "jd_net_create_csr", "jd_net_load_fsm", "jd_net_num_arcs", "jd_net_num_states",
     "jd_net_init_state", "jd_net_destroy", "jd_net_get_csr", "jd_am_create_htk", "jd_am_num_hmms", "jd_am_num_gmms",
-    "jd_am_vec_size", "jd_am_max_states", "jd_am_get_flat", "jd_am_get_trans", "jd_am_destroy",
+    "jd_am_vec_size", "jd_am_max_states", "jd_am_max_mix", "jd_am_num_transmats", "jd_am_get_topology", "jd_am_load_mmf", "jd_am_get_flat", "jd_am_get_trans", "jd_am_destroy",
     "jd_dec_create", "jd_dec_destroy", "jd_dec_set_capacity", "jd_stream_init", "jd_stream_push",
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version",
@@ -214,10 +214,14 @@ class Models:
                                   _p(nm, C.c_int32), _p(wt, C.c_float), _p(mu, C.c_float), _p(var, C.c_float),
                                   C.c_int32(am.n_hmm), C.c_int32(am.max_n), _p(hn, C.c_int32), _p(hg, C.c_int32),
                                   _p(ht, C.c_int32), C.c_int32(am.n_tm), _p(tn, C.c_int32), _p(tp, C.c_float)))
-        m = cls(h)
-        m.n_tm = int(am.n_tm)
-        m.max_mix = int(am.max_mix)
-        return m
+        return cls(h)
+
+    @classmethod
+    def from_mmf_file(cls, path):
+        L = lib()
+        h = C.c_void_p()
+        _check(L.jd_am_load_mmf(C.byref(h), os.fsencode(path)))
+        return cls(h)
 
     @property
     def n_hmms(self):
@@ -234,6 +238,22 @@ class Models:
     @property
     def max_states(self):
         return int(lib().jd_am_max_states(self.h))
+
+    @property
+    def max_mix(self):
+        return int(lib().jd_am_max_mix(self.h))
+
+    @property
+    def n_tm(self):
+        return int(lib().jd_am_num_transmats(self.h))
+
+    def topology(self):
+        H, MN, G = self.n_hmms, self.max_states, self.n_gmms
+        hn = np.zeros(H, np.int32); hg = np.zeros((H, MN), np.int32); ht = np.zeros(H, np.int32)
+        nm = np.zeros(G, np.int32)
+        _check(lib().jd_am_get_topology(self.h, _p(hn, C.c_int32), _p(hg, C.c_int32), _p(ht, C.c_int32),
+                                        _p(nm, C.c_int32)))
+        return hn, hg, ht, nm
 
     def flat(self):
         G, M, D = self.n_gmms, self.max_mix, self.vec_size

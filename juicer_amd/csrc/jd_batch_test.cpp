@@ -50,7 +50,7 @@ static jd_am *load_jdam(const char *path)
 
 int main(int argc, char **argv)
 {
-    const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *list = 0;
+    const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *mmf = 0, *list = 0;
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
     int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0;
     for (int i = 1; i < argc; ++i) {
@@ -58,6 +58,7 @@ int main(int argc, char **argv)
         auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "-fsmFName") fsm = nxt(); else if (a == "-inSymsFName") insyms = nxt();
         else if (a == "-outSymsFName") outsyms = nxt(); else if (a == "-modelsFName") amf = nxt();
+        else if (a == "-htkModelsFName") mmf = nxt();
         else if (a == "-inputFName") list = nxt(); else if (a == "-mainBeam") mainBeam = (float)atof(nxt());
         else if (a == "-phoneStartBeam") startBeam = (float)atof(nxt()); else if (a == "-phoneEndBeam") endBeam = (float)atof(nxt());
         else if (a == "-wordEmitBeam") wordBeam = (float)atof(nxt()); else if (a == "-maxHyps") maxHyps = atoi(nxt());
@@ -66,14 +67,16 @@ int main(int argc, char **argv)
         else if (a == "-batch") batch = atoi(nxt()); else if (a == "-perFrameAdapter") useAdapter = 1;
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
-    if (!fsm || !amf || !list) {
-        fprintf(stderr, "usage: jd_batch_test -fsmFName F -modelsFName M.jdam -inputFName LIST [-mainBeam b] [-phoneStartBeam b]\n"
+    if (!fsm || (!amf && !mmf) || !list) {
+        fprintf(stderr, "usage: jd_batch_test -fsmFName F (-htkModelsFName M.mmf | -modelsFName M.jdam) -inputFName LIST [-mainBeam b] [-phoneStartBeam b]\n"
                         "       [-phoneEndBeam b] [-wordEmitBeam b] [-maxHyps n] [-lmScaleFactor s] [-insPenalty p] [-batch n] [-perFrameAdapter]\n");
         return 2;
     }
     jd_net *net = 0;
     if (jd_net_load_fsm(&net, fsm, insyms, outsyms, lmScale, insPen)) die("jd_net_load_fsm");
-    jd_am *am = load_jdam(amf);
+    jd_am *am = 0;
+    if (mmf) { if (jd_am_load_mmf(&am, mmf)) die("jd_am_load_mmf"); }      // -htkModelsFName, juicer.cpp:196
+    else am = load_jdam(amf);
     const int D = jd_am_vec_size(am);
 
     // configureTests: list of input files

@@ -316,6 +316,17 @@ extern "C" int32_t jd_am_num_hmms(const jd_am *a) { return a ? a->n_hmm : 0; }
 extern "C" int32_t jd_am_num_gmms(const jd_am *a) { return a ? a->n_gmm : 0; }
 extern "C" int32_t jd_am_vec_size(const jd_am *a) { return a ? a->D : 0; }
 extern "C" int32_t jd_am_max_states(const jd_am *a) { return a ? a->max_n : 0; }
+extern "C" int32_t jd_am_max_mix(const jd_am *a) { return a ? a->max_mix : 0; }
+extern "C" int32_t jd_am_num_transmats(const jd_am *a) { return a ? a->n_tm : 0; }
+extern "C" int jd_am_get_topology(const jd_am *a, int32_t *hmm_nstates, int32_t *hmm_gmm, int32_t *hmm_tm, int32_t *n_mix)
+{
+    if (!a) return jd_fail(JD_EINVAL, "jd_am_get_topology: null");
+    if (hmm_nstates) memcpy(hmm_nstates, a->hmm_n.data(), a->hmm_n.size() * sizeof(int32_t));
+    if (hmm_gmm) memcpy(hmm_gmm, a->hmm_gmm.data(), a->hmm_gmm.size() * sizeof(int32_t));
+    if (hmm_tm) memcpy(hmm_tm, a->hmm_tm.data(), a->hmm_tm.size() * sizeof(int32_t));
+    if (n_mix) memcpy(n_mix, a->n_mix.data(), a->n_mix.size() * sizeof(int32_t));
+    return JD_OK;
+}
 
 extern "C" int jd_am_get_flat(const jd_am *a, float *det, float *mean, float *ivar)
 {
@@ -336,3 +347,246 @@ extern "C" int jd_am_get_trans(const jd_am *a, float *trP, int16_t *se, float *t
 }
 
 extern "C" void jd_am_destroy(jd_am *a) { delete a; }
+
+// ------------------------------------------------------------ HTK MMF text loader
+//
+// The subset of HTK's MMF format that the reference's flex/bison front-end accepts
+// (src/htkparse.l.lpp:21-268, src/htkparse.y.ypp:113-147, 414-685): global options (~o with
+// <STREAMINFO>/<VECSIZE>/parameter-kind tags), ~v (ignored with a warning, like the reference),
+// shared states ~s, shared transition matrices ~t, HMM definitions ~h with shared (~s/~t) or
+// inline states / <TRANSP>, <NUMMIXES>/<MIXTURE> or the implicit single-mixture form, optional
+// <GCONST> (parsed, ignored: HTKModels.cpp:835-870 recomputes it).  Numbers go through
+// (float)atof exactly as htkparse.l.lpp:38-41.  Tied-mixture pools (~m / <TMIX>) are rejected:
+// HTKFlatModels assumes mixtureInd == gmmInd (HTKFlatModels.h:61-63).
+// Index order follows HTKModels::initFromHTKParseResult: shared transition matrices and shared
+// states in file order first, then per HMM (file order = in-label order, WFSTDecoderLite.cpp:754)
+// its inline states / matrix.
+namespace {
+struct MmfTok { std::string s; };
+struct MmfLexer {
+    std::vector<std::string> t; size_t p = 0;
+    bool load(const char *path)
+    {
+        FILE *f = fopen(path, "rb");
+        if (!f) return false;
+        std::string cur; int c; bool inq = false, intag = false;
+        auto flush = [&]() { if (!cur.empty()) { t.push_back(cur); cur.clear(); } };
+        while ((c = fgetc(f)) != EOF) {
+            if (inq) { cur.push_back((char)c); if (c == '"') { inq = false; flush(); } continue; }
+            if (intag) { cur.push_back((char)c); if (c == '>') { intag = false; flush(); } continue; }
+            if (c == '"') { flush(); cur.push_back('"'); inq = true; continue; }
+            if (c == '<') { flush(); cur.push_back('<'); intag = true; continue; }
+            if (c == ' ' || c == '\t' || c == '\r' || c == '\n') { flush(); continue; }
+            cur.push_back((char)c);
+        }
+        flush();
+        fclose(f);
+        return true;
+    }
+    bool end() const { return p >= t.size(); }
+    const std::string &peek() const { static const std::string e; return end() ? e : t[p]; }
+    std::string next() { return end() ? std::string() : t[p++]; }
+};
+std::string upper(std::string s) { for (auto &ch : s) ch = (char)toupper((unsigned char)ch); return s; }
+std::string unquote(const std::string &s) { return (s.size() >= 2 && s[0] == '"') ? s.substr(1, s.size() - 2) : s; }
+bool is_num(const std::string &s)
+{
+    if (s.empty()) return false;
+    char *e = nullptr;
+    (void)strtod(s.c_str(), &e);
+    return e && *e == 0;
+}
+struct MmfState { std::vector<float> w, mu, var; int n_mix = 0; };
+struct MmfTm { int n = 0; std::vector<float> a; };
+}  // namespace
+
+extern "C" int jd_am_load_mmf(jd_am **out, const char *mmf_path)
+{
+    if (!out || !mmf_path) return jd_fail(JD_EINVAL, "jd_am_load_mmf: null argument");
+    MmfLexer L;
+    if (!L.load(mmf_path)) return jd_fail(JD_EFORMAT, "HTKModels::Load - error opening %s", mmf_path);
+    int D = -1;
+    std::vector<MmfState> states;                    // GMMs in index order
+    std::vector<std::string> sh_state_names;
+    std::vector<MmfTm> tms;
+    std::vector<std::string> sh_tm_names;
+    struct Hmm { int n; std::vector<int> gmm; int tm; };
+    std::vector<Hmm> hmms;
+#define MMF_FAIL(...) return jd_fail(JD_EFORMAT, __VA_ARGS__)
+    auto tag_int = [&](const std::string &tagname, int *v) -> bool {   // "<TAG> int" (htkparse.l: tag + INT is one token)
+        if (upper(L.peek()) != tagname) return false;
+        L.next();
+        if (!is_num(L.peek())) return false;
+        *v = atoi(L.next().c_str());
+        return true;
+    };
+    auto rvector = [&](int n, std::vector<float> &dst) -> bool {
+        for (int i = 0; i < n; ++i) {
+            if (!is_num(L.peek())) return false;
+            dst.push_back((float)atof(L.next().c_str()));              // htkparse.l.lpp:38-41
+        }
+        return true;
+    };
+    // mixpdf: <MEAN> n v.. <VARIANCE> n v.. [<GCONST> x]   (htkparse.y.ypp mixpdf/meanvec/variancevec/gconst)
+    auto mixpdf = [&](MmfState &st) -> int {
+        int n = 0;
+        if (!tag_int("<MEAN>", &n)) return jd_fail(JD_EFORMAT, "MMF: <MEAN> expected near token %zu ('%s')", L.p, L.peek().c_str());
+        if (n != D) return jd_fail(JD_EFORMAT, "HTKPARSE:meanvec - MEAN value did not match global vec size");
+        if (!rvector(n, st.mu)) return jd_fail(JD_EFORMAT, "HTKPARSE:meanvec - n_elems did not match MEAN value");
+        if (!tag_int("<VARIANCE>", &n)) return jd_fail(JD_EFORMAT, "MMF: <VARIANCE> expected (only diagonal covariances are supported)");
+        if (n != D) return jd_fail(JD_EFORMAT, "HTKPARSE:variancevec - VARIANCE value did not match global vec size");
+        if (!rvector(n, st.var)) return jd_fail(JD_EFORMAT, "HTKPARSE:variancevec - n_elems did not match VARIANCE value");
+        if (upper(L.peek()) == "<GCONST>") { L.next(); if (is_num(L.peek())) L.next(); }
+        return JD_OK;
+    };
+    // state body after <STATE> i / ~s "name": [<NUMMIXES> n] (<MIXTURE> i w mixpdf)+ | mixpdf
+    auto state_body = [&](MmfState &st) -> int {
+        int nm = 0;
+        (void)tag_int("<NUMMIXES>", &nm);
+        if (upper(L.peek()) == "<TMIX>") return jd_fail(JD_EFORMAT, "MMF: tied-mixture (<TMIX>) states are not supported by the flat models");
+        if (upper(L.peek()) == "<MIXTURE>") {
+            while (upper(L.peek()) == "<MIXTURE>") {
+                L.next();
+                if (!is_num(L.peek())) return jd_fail(JD_EFORMAT, "MMF: <MIXTURE> index expected");
+                L.next();
+                if (!is_num(L.peek())) return jd_fail(JD_EFORMAT, "MMF: <MIXTURE> weight expected");
+                st.w.push_back((float)atof(L.next().c_str()));
+                int rc = mixpdf(st);
+                if (rc) return rc;
+                ++st.n_mix;
+            }
+        } else {                                       // implicit single mixture, weight 1.0 (mixturedef: mixpdf)
+            st.w.push_back(1.0f);
+            int rc = mixpdf(st);
+            if (rc) return rc;
+            st.n_mix = 1;
+        }
+        return JD_OK;
+    };
+    auto transp = [&](MmfTm &tm) -> int {
+        int n = 0;
+        if (!tag_int("<TRANSP>", &n)) return jd_fail(JD_EFORMAT, "MMF: <TRANSP> expected near '%s'", L.peek().c_str());
+        tm.n = n;
+        if (!rvector(n * n, tm.a)) return jd_fail(JD_EFORMAT, "HTKPARSE:transp - vec n_elems did not match TRANSP value");
+        return JD_OK;
+    };
+    auto find = [](const std::vector<std::string> &v, const std::string &s) {
+        for (size_t i = 0; i < v.size(); ++i) if (v[i] == s) return (int)i;
+        return -1;
+    };
+
+    while (!L.end()) {
+        std::string m = L.next();
+        if (m == "~o" || m == "~O") {
+            while (!L.end() && L.peek()[0] != '~') {
+                std::string tg = upper(L.next());
+                if (tg == "<VECSIZE>") { if (!is_num(L.peek())) MMF_FAIL("MMF: <VECSIZE> value expected"); D = atoi(L.next().c_str()); }
+                else if (tg == "<STREAMINFO>") {
+                    if (!is_num(L.peek())) MMF_FAIL("MMF: <STREAMINFO> count expected");
+                    int ns = atoi(L.next().c_str());
+                    if (ns != 1) MMF_FAIL("MMF: only single-stream models are supported");
+                    if (is_num(L.peek())) { int w = atoi(L.next().c_str()); if (D < 0) D = w; }
+                } else if (tg == "<HMMSETID>") { L.next(); }
+                // parameter kind / covariance kind / duration kind tags carry no values
+            }
+        } else if (m == "~v" || m == "~V") {
+            fprintf(stderr, "htkparse: ~v macros not supported - ignoring ~v %s definition\n", L.peek().c_str());
+            L.next();
+            int n = 0;
+            if (!tag_int("<VARIANCE>", &n)) MMF_FAIL("MMF: ~v without <VARIANCE>");
+            std::vector<float> tmp;
+            if (!rvector(n, tmp)) MMF_FAIL("MMF: ~v vector too short");
+        } else if (m == "~s" || m == "~S") {
+            if (D <= 0) MMF_FAIL("MMF: ~s before the global <VECSIZE>");
+            sh_state_names.push_back(unquote(L.next()));
+            states.emplace_back();
+            int rc = state_body(states.back());
+            if (rc) return rc;
+        } else if (m == "~t" || m == "~T") {
+            sh_tm_names.push_back(unquote(L.next()));
+            tms.emplace_back();
+            int rc = transp(tms.back());
+            if (rc) return rc;
+        } else if (m == "~m" || m == "~M") {
+            MMF_FAIL("MMF: ~m tied-mixture pools are not supported by the flat models (HTKFlatModels.h:61-63)");
+        } else if (m == "~h" || m == "~H") {
+            if (D <= 0) MMF_FAIL("MMF: ~h before the global <VECSIZE>");
+            L.next();                                  // name (HMM index = order of appearance)
+            if (upper(L.next()) != "<BEGINHMM>") MMF_FAIL("MMF: <BEGINHMM> expected");
+            Hmm h; h.n = 0; h.tm = -1;
+            if (!tag_int("<NUMSTATES>", &h.n) || h.n < 3) MMF_FAIL("MMF: <NUMSTATES> expected");
+            h.gmm.assign((size_t)h.n, -1);
+            while (upper(L.peek()) == "<VECSIZE>" || (L.peek().size() > 1 && L.peek()[0] == '<' && upper(L.peek()) != "<STATE>" &&
+                   upper(L.peek()) != "<TRANSP>")) {   // optglobopts inside the HMM
+                std::string tg = upper(L.next());
+                if (tg == "<VECSIZE>" || tg == "<STREAMINFO>") while (is_num(L.peek())) L.next();
+            }
+            int n_emit = 0;
+            while (upper(L.peek()) == "<STATE>") {
+                L.next();
+                if (!is_num(L.peek())) MMF_FAIL("MMF: <STATE> index expected");
+                int si = atoi(L.next().c_str());
+                if (si < 2 || si > h.n - 1) MMF_FAIL("MMF: <STATE> %d out of range", si);
+                if (L.peek() == "~s" || L.peek() == "~S") {
+                    L.next();
+                    int g = find(sh_state_names, unquote(L.next()));
+                    if (g < 0) MMF_FAIL("HTKPARSE:statedef - SMACRO string not found in htk_def");
+                    h.gmm[(size_t)si - 1] = g;
+                } else {
+                    states.emplace_back();
+                    sh_state_names.push_back(std::string());
+                    int rc = state_body(states.back());
+                    if (rc) return rc;
+                    h.gmm[(size_t)si - 1] = (int)states.size() - 1;
+                }
+                ++n_emit;
+            }
+            if (n_emit != h.n - 2) MMF_FAIL("HTKPARSE:hmmdef - hmmstatelist n_elems did not match n_states");
+            if (L.peek() == "~t" || L.peek() == "~T") {
+                L.next();
+                h.tm = find(sh_tm_names, unquote(L.next()));
+                if (h.tm < 0) MMF_FAIL("HTKPARSE:transmatdef - SMACRO string not found in htk_def");
+            } else {
+                tms.emplace_back();
+                sh_tm_names.push_back(std::string());
+                int rc = transp(tms.back());
+                if (rc) return rc;
+                h.tm = (int)tms.size() - 1;
+            }
+            if (tms[(size_t)h.tm].n != h.n) MMF_FAIL("HTKModels::addHMM - curr->nStates != hmm->transmat->n_states");
+            if (upper(L.next()) != "<ENDHMM>") MMF_FAIL("MMF: <ENDHMM> expected");
+            hmms.push_back(h);
+        } else {
+            MMF_FAIL("MMF: unexpected token '%s'", m.c_str());
+        }
+    }
+#undef MMF_FAIL
+    if (hmms.empty() || states.empty() || D <= 0) return jd_fail(JD_EFORMAT, "%s: no HMM definitions", mmf_path);
+    int max_mix = 0, max_n = 0;
+    for (auto &s : states) max_mix = std::max(max_mix, s.n_mix);
+    for (auto &t : tms) max_n = std::max(max_n, t.n);
+    const int G = (int)states.size(), H = (int)hmms.size(), NT = (int)tms.size();
+    std::vector<int32_t> n_mix((size_t)G), hn((size_t)H), hg((size_t)H * max_n, -1), ht((size_t)H), tn((size_t)NT);
+    std::vector<float> wt((size_t)G * max_mix, 0.0f), mu((size_t)G * max_mix * D, 0.0f), var((size_t)G * max_mix * D, 1.0f);
+    std::vector<float> tp((size_t)NT * max_n * max_n, 0.0f);
+    for (int g = 0; g < G; ++g) {
+        n_mix[(size_t)g] = states[(size_t)g].n_mix;
+        for (int m = 0; m < states[(size_t)g].n_mix; ++m) {
+            wt[(size_t)g * max_mix + m] = states[(size_t)g].w[(size_t)m];
+            memcpy(&mu[((size_t)g * max_mix + m) * D], &states[(size_t)g].mu[(size_t)m * D], sizeof(float) * D);
+            memcpy(&var[((size_t)g * max_mix + m) * D], &states[(size_t)g].var[(size_t)m * D], sizeof(float) * D);
+        }
+    }
+    for (int t = 0; t < NT; ++t) {
+        tn[(size_t)t] = tms[(size_t)t].n;
+        for (int i = 0; i < tms[(size_t)t].n; ++i)
+            for (int j = 0; j < tms[(size_t)t].n; ++j)
+                tp[((size_t)t * max_n + i) * max_n + j] = tms[(size_t)t].a[(size_t)i * tms[(size_t)t].n + j];
+    }
+    for (int h = 0; h < H; ++h) {
+        hn[(size_t)h] = hmms[(size_t)h].n; ht[(size_t)h] = hmms[(size_t)h].tm;
+        for (int j = 0; j < hmms[(size_t)h].n; ++j) hg[(size_t)h * max_n + j] = hmms[(size_t)h].gmm[(size_t)j];
+    }
+    return jd_am_create_htk(out, D, G, max_mix, n_mix.data(), wt.data(), mu.data(), var.data(), H, max_n, hn.data(),
+                            hg.data(), ht.data(), NT, tn.data(), tp.data());
+}

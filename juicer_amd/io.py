@@ -30,3 +30,49 @@ def write_jdf(path, feats):
     with open(path, "wb") as f:
         np.asarray([x.shape[0], x.shape[1]], np.int32).tofile(f)
         x.tofile(f)
+
+
+def write_mmf(path, am, inline_every: int = 0):
+    """HTK MMF text with shared states (~s) and transition matrices (~t).  inline_every > 0 writes
+    every inline_every-th HMM with inline states / <TRANSP> instead (other grammar branch)."""
+    def vec(v):
+        return " ".join("%.9g" % float(x) for x in v)
+    with open(path, "w") as f:
+        f.write("~o\n<STREAMINFO> 1 %d\n<VECSIZE> %d<NULLD><MFCC_E_D_A><DIAGC>\n" % (am.D, am.D))
+        f.write('~v "varFloor1"\n<VARIANCE> %d\n %s\n' % (am.D, vec(np.full(am.D, 0.01))))
+        for t in range(am.n_tm):
+            n = int(am.tm_nstates[t])
+            f.write('~t "T_%d"\n<TRANSP> %d\n' % (t, n))
+            for i in range(n):
+                f.write(" " + vec(am.transp[t, i, :n]) + "\n")
+
+        def state_body(g):
+            nm = int(am.n_mix[g])
+            out = []
+            if nm > 1:
+                out.append("<NUMMIXES> %d" % nm)
+            for m in range(nm):
+                if nm > 1:
+                    out.append("<MIXTURE> %d %.9g" % (m + 1, float(am.weight[g, m])))
+                out.append("<MEAN> %d\n %s" % (am.D, vec(am.mean[g, m])))
+                out.append("<VARIANCE> %d\n %s" % (am.D, vec(am.var[g, m])))
+                out.append("<GCONST> %.6e" % 0.0)
+            return "\n".join(out) + "\n"
+        for g in range(am.n_gmm):
+            f.write('~s "s_%d"\n' % g + state_body(g))
+        for h in range(am.n_hmm):
+            n = int(am.hmm_nstates[h])
+            inline = inline_every > 0 and h % inline_every == inline_every - 1
+            f.write('~h "h_%d"\n<BEGINHMM>\n<NUMSTATES> %d\n' % (h, n))
+            for j in range(1, n - 1):
+                g = int(am.hmm_gmm[h, j])
+                f.write("<STATE> %d\n" % (j + 1))
+                f.write(state_body(g) if inline else '~s "s_%d"\n' % g)
+            t = int(am.hmm_tm[h])
+            if inline:
+                f.write("<TRANSP> %d\n" % n)
+                for i in range(n):
+                    f.write(" " + vec(am.transp[t, i, :n]) + "\n")
+            else:
+                f.write('~t "T_%d"\n' % t)
+            f.write("<ENDHMM>\n")

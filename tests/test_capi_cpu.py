@@ -121,3 +121,58 @@ def test_product_does_not_reference_oracle():
                 if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                     txt = open(os.path.join(dp, fn), errors="ignore").read()
                     assert "juicer_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_mmf_text_loader_shared_macros(built, tmp_path):
+    """HTK MMF text -> same prepared parameters as the array entry point (bit-exact)."""
+    from juicer_amd import capi, io as jio, synth
+    am = synth.make_models(21, n_gmm=30, n_hmm=14, n_mix=3, D=13, n_tm=5, with_tee=True)
+    p = tmp_path / "m.mmf"
+    jio.write_mmf(p, am)
+    a, b = capi.Models.from_mmf_file(str(p)), capi.Models.from_htk(am)
+    assert (a.n_hmms, a.n_gmms, a.vec_size, a.max_states, a.max_mix, a.n_tm) == \
+           (b.n_hmms, b.n_gmms, b.vec_size, b.max_states, b.max_mix, b.n_tm)
+    for x, y in zip(a.flat(), b.flat()):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    for x, y in zip(a.trans(), b.trans()):
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                              y.view(np.uint32) if y.dtype == np.float32 else y)
+    for x, y in zip(a.topology(), b.topology()):
+        assert np.array_equal(x, y)
+
+
+def test_mmf_text_loader_inline_and_single_mixture(built, tmp_path):
+    """Inline states / <TRANSP>, and the implicit single-mixture form (no <NUMMIXES>/<MIXTURE>)."""
+    from juicer_amd import capi, io as jio, synth
+    am = synth.make_models(22, n_gmm=12, n_hmm=9, n_mix=1, D=5, n_tm=3)
+    p = tmp_path / "m.mmf"
+    jio.write_mmf(p, am, inline_every=3)
+    a, b = capi.Models.from_mmf_file(str(p)), capi.Models.from_htk(am)
+    assert a.n_hmms == b.n_hmms and a.n_gmms == b.n_gmms + 3 * 3      # 3 inline HMMs x 3 states duplicated
+    (adet, amu, aiv), (bdet, bmu, biv) = a.flat(), b.flat()
+    (atrp, ase, atee), (btrp, bse, btee) = a.trans(), b.trans()
+    ahn, ahg, aht, _ = a.topology()
+    bhn, bhg, bht, _ = b.topology()
+    assert np.array_equal(ahn, bhn) and np.array_equal(atee.view(np.uint32), btee.view(np.uint32))
+    for h in range(a.n_hmms):
+        for j in range(1, ahn[h] - 1):
+            ga, gb = ahg[h, j], bhg[h, j]
+            assert np.array_equal(adet[ga].view(np.uint32), bdet[gb].view(np.uint32))
+            assert np.array_equal(amu[ga], bmu[gb]) and np.array_equal(aiv[ga].view(np.uint32), biv[gb].view(np.uint32))
+        n = ahn[h]
+        assert np.array_equal(atrp[aht[h]][:n, :n].view(np.uint32), btrp[bht[h]][:n, :n].view(np.uint32))
+        assert np.array_equal(ase[aht[h]][:n], bse[bht[h]][:n])
+
+
+def test_mmf_text_loader_errors(built, tmp_path):
+    from juicer_amd import capi
+    p = tmp_path / "bad.mmf"
+    p.write_text('~o <VECSIZE> 3 <USER><DIAGC>\n~m "mix1" <MEAN> 3 0 0 0 <VARIANCE> 3 1 1 1\n')
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        capi.Models.from_mmf_file(str(p))
+    assert ei.value.code == capi.JD_EFORMAT
+    p.write_text('~o <VECSIZE> 3 <USER><DIAGC>\n~h "a" <BEGINHMM> <NUMSTATES> 3 <STATE> 2 <MEAN> 2 0 0 <VARIANCE> 2 1 1\n')
+    with pytest.raises(capi.JuicerAmdError):
+        capi.Models.from_mmf_file(str(p))
+    with pytest.raises(capi.JuicerAmdError):
+        capi.Models.from_mmf_file(str(tmp_path / "missing.mmf"))

@@ -1,0 +1,102 @@
+"""GPU tests at BASELINE.json configs[1] size (~1M-arc graph, 3000 tied states x 16 mixtures):
+oracle parity on a few utterances (the oracle needs ~1 s per utterance at beam 150) plus
+size-independent properties on the batch."""
+import numpy as np
+import pytest
+
+from helpers import assert_hyp_matches, bit_exact
+
+pytestmark = pytest.mark.gpu
+
+N_UTTS = 12
+
+
+@pytest.fixture(scope="module")
+def c2(built):
+    from juicer_amd import capi, synth
+    am, net, feats, words = synth.config_c2(n_utts=N_UTTS)
+    return dict(am=am, net=net, feats=feats, words=words,
+                gnet=capi.Network.from_synth(net), gam=capi.Models.from_htk(am))
+
+
+def test_fullsize_oracle_parity(c2):
+    from juicer_amd import capi
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    kw = dict(main_beam=150.0)
+    gd = capi.Decoder(c2["gnet"], c2["gam"], max_streams=N_UTTS, **kw)
+    gs = gd.decode_batch(c2["feats"])
+    od = OracleDecoder(OracleNet(c2["net"]), OracleAM(c2["am"]), **kw)
+    checked = exact = 0
+    for u in range(6):
+        o = od.decode(c2["feats"][u])
+        if o.stats["ties"]:
+            # equal-score recombinations: the winner is order dependent in the reference too;
+            # labels/times must still agree unless the tie sat on the best path
+            if not (gs[u].n == o.n and np.array_equal(gs[u].label, o.label)):
+                continue
+        assert_hyp_matches(gs[u], o, "c2 utt %d" % u, check_stats=(o.stats["ties"] == 0))
+        checked += 1
+        exact += bit_exact(gs[u], o)
+    print("checked %d utterances, %d bit-exact incl. scores" % (checked, exact))
+    assert checked >= 4
+
+
+def test_fullsize_histogram_pruning_parity(c2):
+    from juicer_amd import capi
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    kw = dict(main_beam=200.0, max_hyps=3000, end_beam=150.0, word_beam=120.0)
+    gd = capi.Decoder(c2["gnet"], c2["gam"], max_streams=4, **kw)
+    gs = gd.decode_batch(c2["feats"][:4])
+    od = OracleDecoder(OracleNet(c2["net"]), OracleAM(c2["am"]), **kw)
+    ok = 0
+    for u in range(4):
+        o = od.decode(c2["feats"][u])
+        if o.stats["ties"] == 0:
+            assert_hyp_matches(gs[u], o, "c2 hist utt %d" % u)
+            ok += 1
+    assert ok >= 2
+
+
+def test_fullsize_properties(c2):
+    """Decoding is deterministic, independent of batch composition / stream slot, and mostly finds
+    the generating word sequence of the model-sampled utterances."""
+    from juicer_amd import capi
+    kw = dict(main_beam=150.0)
+    gd = capi.Decoder(c2["gnet"], c2["gam"], max_streams=N_UTTS, **kw)
+    a = gd.decode_batch(c2["feats"])
+    b = gd.decode_batch(c2["feats"])                      # same decoder, second pass
+    perm = list(range(N_UTTS))[::-1]
+    c = gd.decode_batch([c2["feats"][i] for i in perm])   # different slots, different neighbours
+    gd1 = capi.Decoder(c2["gnet"], c2["gam"], max_streams=1, **kw)
+    d = gd1.decode_batch(c2["feats"][:3])                 # one stream at a time
+    # the synthetic lexicon has homophones, so the generating words are only mostly recovered
+    same = sum(int(np.array_equal(a[u].label[::-1], c2["words"][u])) for u in range(N_UTTS))
+    assert same >= N_UTTS // 2
+    for u in range(N_UTTS):
+        assert a[u].n > 0
+        for other in (b[u], c[perm.index(u)]):
+            assert other.n == a[u].n and np.array_equal(other.label, a[u].label)
+            assert np.array_equal(other.time, a[u].time)
+            assert np.array_equal(other.score.view(np.uint32), a[u].score.view(np.uint32))
+            assert other.stats == a[u].stats
+    for u in range(3):
+        assert np.array_equal(d[u].label, a[u].label) and np.array_equal(d[u].time, a[u].time)
+        assert np.array_equal(d[u].ac.view(np.uint32), a[u].ac.view(np.uint32))
+    # word-end frames are increasing and inside the utterance; totals are consistent
+    for u in range(N_UTTS):
+        t = a[u].time[::-1]
+        assert np.all(np.diff(t) >= 0) and t[-1] == c2["feats"][u].shape[0] - 1
+        assert a[u].tot_ac == a[u].ac[0] and a[u].tot_lm == a[u].lm[0]
+        assert np.all(np.diff(a[u].ac[::-1]) < 0)          # cumulative acoustic log-likelihood decreases
+
+
+def test_fullsize_gmm_tile_parity(c2):
+    """Companion kernel on the full 3000 x 16 x 39 model, ragged row count (not a multiple of 64)."""
+    from oracle.oracle import OracleAM
+    x = np.concatenate(c2["feats"][:2])[:333]
+    g = c2["gam"].score_frames(x)
+    o = OracleAM(c2["am"]).score_frames(x)
+    diff = g.view(np.uint32) != o.view(np.uint32)
+    print("gmm mismatches %d of %d" % (diff.sum(), diff.size))
+    assert diff.mean() <= 1e-5
+    assert np.abs(g.view(np.int32).astype(np.int64) - o.view(np.int32).astype(np.int64)).max() <= 1

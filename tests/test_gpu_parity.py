@@ -212,6 +212,7 @@ def test_batch_test_cli(small, tmp_path):
     am, net, _, _ = synth.config_small()
     jio.write_fsm(tmp_path / "g.fsm", net)
     jio.write_jdam(tmp_path / "m.jdam", am)
+    jio.write_mmf(tmp_path / "m.mmf", am)
     lst = tmp_path / "list.txt"
     with open(lst, "w") as f:
         f.write("# comment line\n\n")
@@ -220,10 +221,11 @@ def test_batch_test_cli(small, tmp_path):
             f.write("%s\n" % (tmp_path / ("u%d.jdf" % u)))
     od = OracleDecoder(onet, oam, main_beam=150.0, max_hyps=200)
     want = [od.decode(x) for x in feats]
-    for extra in ([], ["-perFrameAdapter"]):
-        out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-modelsFName",
-                              str(tmp_path / "m.jdam"), "-inputFName", str(lst), "-mainBeam", "150",
-                              "-maxHyps", "200"] + extra, capture_output=True, text=True, timeout=240)
+    for extra in (["-modelsFName", str(tmp_path / "m.jdam")], ["-htkModelsFName", str(tmp_path / "m.mmf")],
+                  ["-htkModelsFName", str(tmp_path / "m.mmf"), "-perFrameAdapter"]):
+        out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-inputFName", str(lst),
+                              "-mainBeam", "150", "-maxHyps", "200"] + extra, capture_output=True, text=True,
+                             timeout=240)
         assert out.returncode == 0, out.stderr
         lines = out.stdout.splitlines()
         files = [i for i, l in enumerate(lines) if l.startswith("File: ")]
