@@ -274,7 +274,8 @@ struct __align__(128) StreamCtl {
     __align__(128) int n_touched;
     __align__(128) int n_alloc;              // instances attached this frame (= new active entries)
     __align__(128) int n_skipped;            // hopeless instances not materialised this frame
-    __align__(128) int n_paths;
+    __align__(128) int n_paths;              // Path records in use at frame start (updated by k_boundary)
+    __align__(128) int n_paths_extra;        // Path records taken by frontier rounds >= 1 this frame
     __align__(128) unsigned long long final_key;
     __align__(128) unsigned long long pkE;   // phase A: emit hyps processed | live emitting tokens << 32
     __align__(128) int fr[ST_N];             // per-frame work counters (flushed per block run)
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
             c.pkE = 0ULL;
             c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
             c.n_alloc = 0; c.n_touched = 0; c.final_key = 0ULL; c.n_skipped = 0; c.skipped_prev = 0;
+            c.n_paths_extra = 0;
             for (int k = 0; k < ST_N; ++k) { c.fr[k] = 0; c.st[k] = 0; }
             c.best_final = null_tok();
             Tok z; z.score = 0.0f; z.ac = 0.0f; z.lm = 0.0f; z.path = -1;       // :221-226
@@ -418,6 +420,8 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         if (lane == 0) {
             c.n_act = c.n_alloc; c.hw = c.n_alloc;
             c.best_emit = o2f(c.best);
+            c.n_paths = c.n_paths + pk_cnt0(c.pkA) + c.n_paths_extra;
+            c.n_paths_extra = 0;
             c.lst ^= 1;
             for (int k = 0; k < ST_N; ++k) { c.st[k] += c.fr[k]; c.fr[k] = 0; }
             c.st[ST_MODELS] = 0;
@@ -430,7 +434,8 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
     // ---- epilogue of the frame processed in this step's predecessor kernels.  Every counter
     // lives on its own cache line: fetch them all first (independent loads in flight together).
     const int v_active = c.active, v_nfree = c.n_free, v_hw = c.hw, v_nalloc = c.n_alloc, v_nskip = c.n_skipped;
-    const int v_skprev = c.skipped_prev, v_lst = c.lst, v_frame = c.frame, v_npaths = c.n_paths;
+    const int v_skprev = c.skipped_prev, v_lst = c.lst, v_frame = c.frame;
+    const int v_npaths = c.n_paths + pk_cnt0(c.pkA) + c.n_paths_extra;
     const int v_started = c.started, v_needs_init = c.needs_init, v_error = c.error, v_T = c.T;
     const unsigned long long v_pk = c.pkA, v_pe = c.pkE, v_fkey = c.final_key;
     const unsigned v_best = c.best;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
             c.skipped_prev = v_nskip;
             c.lst = v_lst ^ 1;
             c.frame = frame_now;
-            if (v_npaths > C.cap_paths) c.n_paths = C.cap_paths;
+            c.n_paths = v_npaths < C.cap_paths ? v_npaths : C.cap_paths;
         }
     }
     // ---- start of the next frame (:311-339)
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         c.startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;       // :337
         c.best = f2o(LZ); c.pkA = 0ULL; c.pkE = 0ULL;                            // :905
         c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
-        c.n_alloc = 0; c.n_touched = 0; c.n_skipped = 0;
+        c.n_alloc = 0; c.n_touched = 0; c.n_skipped = 0; c.n_paths_extra = 0;
         c.final_key = 0ULL;                                                      // :316 bestFinalToken = nullToken
         if (v_active != 1) c.active = 1;
     }
@@ -537,6 +542,8 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int MN = C.max_n;
     // static block -> stream assignment: no unit map, no search, one stream per block
+    // stream-major block order: consecutive blocks (= consecutive XCDs) share a stream, so every
+    // stream is spread over all 8 XCDs.  (Measured: packing a stream onto one XCD is 2.4x slower.)
     const int sl = blockIdx.x / BPS, j0 = blockIdx.x - sl * BPS;
     const int s = s0 + sl;
     StreamCtl &c = ctl[s];
@@ -803,7 +810,8 @@ __device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, con
 //   sk_in_u / sk_in_l : per-state key arrays of this round (unlabelled / word-labelled class)
 //   check_th          : apply the end/word threshold of doHMMExternalPropagation (:952-962) (round 0)
 __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
-                                            int frame, bool last_frame, float endTh, float wordTh, bool check_th,
+                                            int frame, bool last_frame, bool path_direct, int path_base_extra,
+                                            float endTh, float wordTh, bool check_th,
                                             bool have, int ii, unsigned long long *sk_in_u,
                                             unsigned long long *sk_in_l, unsigned long long *sk_out,
                                             int *items_counter, int items_base, int &n_arcs, int &n_paths_made,
@@ -819,11 +827,14 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
         info = S.item_info[ii];
         t = S.item_tok[ii];
     }
-    // Path records (:497-509) are reserved per BLOCK as soon as the labels are known (one
-    // returning atomic per unit, overlapped with the loads below); the index of an item that
-    // turns out not to be expanded is simply left unused.
+    // Path records (:497-509).  Round-0 items (exit tokens of phase A) own the record
+    // n_paths + <their index>: no allocation at all (records of unlabelled / unexpanded tokens
+    // stay unused; k_boundary advances n_paths by the number of exit tokens).  Items of later
+    // rounds (rare: word labels on epsilon / tee arcs) reserve per block with one atomic.
     int p = -1;
-    {
+    if (path_direct) {
+        p = c.n_paths + ii;
+    } else {
         const bool labelled = have && info.x >= 0 && info.y != 0 && er == 0;
         const unsigned long long bl = __ballot(labelled);
         int wb = 0;
@@ -833,9 +844,9 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
             wb = __shfl(wb, first);
         }
         __syncthreads();
-        if (threadIdx.x == 0) { const int np = stage.np; stage.pb = np ? atomicAdd(&c.n_paths, np) : 0; }
+        if (threadIdx.x == 0) { const int np = stage.np; stage.pb = np ? atomicAdd(&c.n_paths_extra, np) : 0; }
         __syncthreads();
-        p = labelled ? stage.pb + wb + rank_in(bl) : -1;
+        p = labelled ? c.n_paths + path_base_extra + stage.pb + wb + rank_in(bl) : -1;
         p = __shfl(p, eb);
     }
     if (have) {
@@ -894,6 +905,8 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
     __shared__ int sh_acc[3];                                          // ARCS, PATHS, PEND of this block
     constexpr int PER = KTB / EG;                                      // items per unit
     const int tid = threadIdx.x, lane = lane_id();
+    // stream-major block order: consecutive blocks (= consecutive XCDs) share a stream, so every
+    // stream is spread over all 8 XCDs.  (Measured: packing a stream onto one XCD is 2.4x slower.)
     const int sl = blockIdx.x / BPS, j0 = blockIdx.x - sl * BPS;
     const int s = s0 + sl;
     StreamCtl &c = ctl[s];
@@ -914,8 +927,8 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
         const int out_base = (ROUND == 0) ? cnt0 : cnt0 + c.cnt1;
         const int k = u * PER + (tid / EG);
         int n_arcs = 0, n_paths_made = 0, n_pend = 0;
-        expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, endTh, wordTh, ROUND == 0 && !init, k < nin,
-                    in_base + k,
+        expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, ROUND == 0 && !init, cnt0, endTh, wordTh,
+                    ROUND == 0 && !init, k < nin, in_base + k,
                     S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], S.skey[(ROUND & 1) ^ 1],
                     (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base, n_arcs, n_paths_made, n_pend);
         n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
@@ -956,8 +969,8 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
     while (r1 > r0) {
         for (int k0 = r0; k0 < r1; k0 += PER) {
             const int k = k0 + (tid / EG);
-            expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, endTh, wordTh, false, k < r1, base + k,
-                        S.skey[parity],
+            expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, false, pk_cnt0(c.pkA), endTh, wordTh, false,
+                        k < r1, base + k, S.skey[parity],
                         S.skey[parity], S.skey[parity ^ 1], &c.cnt_tail, tail_base, n_arcs, n_paths_made, n_pend);
             stage_flush_block(C, c, S, stage);
         }
@@ -986,6 +999,8 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
     const int tid = threadIdx.x, lane = lane_id();
     const int MN = C.max_n;
     const int rec_ints = (MN <= 5) ? 32 : 64, tok_off = (MN <= 5) ? 8 : 12, aux_ints = (MN <= 5) ? 8 : 12;
+    // stream-major block order: consecutive blocks (= consecutive XCDs) share a stream, so every
+    // stream is spread over all 8 XCDs.  (Measured: packing a stream onto one XCD is 2.4x slower.)
     const int sl = blockIdx.x / BPS, j0 = blockIdx.x - sl * BPS;
     const int s = s0 + sl;
     StreamCtl &c = ctl[s];

@@ -85,7 +85,7 @@ def test_fullsize_properties(c2):
     # word-end frames are increasing and inside the utterance; totals are consistent
     for u in range(N_UTTS):
         t = a[u].time[::-1]
-        assert np.all(np.diff(t) >= 0) and t[-1] == c2["feats"][u].shape[0] - 1
+        assert np.all(np.diff(t) >= 0) and t[-1] <= c2["feats"][u].shape[0] - 1
         assert a[u].tot_ac == a[u].ac[0] and a[u].tot_lm == a[u].lm[0]
         assert np.all(np.diff(a[u].ac[::-1]) < 0)          # cumulative acoustic log-likelihood decreases
 
