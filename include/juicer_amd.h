@@ -226,6 +226,11 @@ typedef struct jd_timing {
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 
+/* Diagnostics: per-block wall-clock stamps (100 MHz: start, after setup, after work, end) of
+ * k_phase_a (blocks [0,65536)) and k_expand<0> (blocks [65536,131072)) at lock-step frame `frame`
+ * of the following decodes; `fetch` (2*65536*4 int64, may be NULL) receives the last recording. */
+int jd_dec_debug_trace(jd_dec *d, int32_t frame, int64_t *fetch);
+
 /*
  * Companion kernel on its own: HTKFlatModels::calcGMMOutput
  * (HTKFlatModels.cpp:226-262) for every tied state of every frame.

@@ -73,7 +73,7 @@ EXPORTS = [
     "jd_am_vec_size", "jd_am_max_states", "jd_am_max_mix", "jd_am_num_transmats", "jd_am_get_topology", "jd_am_load_mmf", "jd_am_get_flat", "jd_am_get_trans", "jd_am_destroy",
     "jd_dec_create", "jd_dec_destroy", "jd_dec_set_capacity", "jd_stream_init", "jd_stream_push",
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
-    "jd_am_score_frames", "jd_last_error", "jd_version",
+    "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace",
 ]
 
 _lib = None
@@ -343,6 +343,11 @@ class Decoder:
         out = {f: getattr(t, f) for f, _ in Timing._fields_}
         out["kernel_us"] = [float(v) for v in t.kernel_us]
         return out
+
+    def debug_trace(self, frame: int, fetch: bool = False):
+        buf = np.zeros((2, 65536, 4), np.int64) if fetch else None
+        _check(lib().jd_dec_debug_trace(self.h, C.c_int32(frame), None if buf is None else _p(buf, C.c_int64)))
+        return buf
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

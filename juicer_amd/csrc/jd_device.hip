@@ -229,6 +229,8 @@ struct DecConst {
     int max_hyps, hist_min, hist_max, hist_nbins;
     // arena capacities (per stream)
     int cap_slots, cap_items, cap_paths;
+    // diagnostics (jd_dec_debug_trace): per-block wall_clock64 stamps of one chosen frame
+    long long *dbg; int dbg_frame;
 };
 
 enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_INSTS, ST_N };
@@ -547,9 +549,12 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
     const int sl = blockIdx.x / BPS, j0 = blockIdx.x - sl * BPS;
     const int s = s0 + sl;
     StreamCtl &c = ctl[s];
+    const long long t_start = wall_clock64();
     if (c.active != 1) return;
     const StreamDev &S = streams[s];
     const int units = (c.n_act + PER - 1) / PER;
+    const bool dbg = C.dbg && c.frame == C.dbg_frame && tid == 0;
+    if (dbg) { long long *d = C.dbg + (size_t)blockIdx.x * 4; d[0] = t_start; d[1] = wall_clock64(); d[2] = 0; d[3] = (j0 >= units) ? -1 : 0; }
     if (j0 >= units) return;
     if (tid == 0) { sh_pe = 0ULL; sh_bb = 0u; }
     __syncthreads();
@@ -697,8 +702,10 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
     }
     __syncthreads();
     if (tid == 0) {
+        if (dbg) C.dbg[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
         if (sh_pe) atomicAdd(&c.pkE, sh_pe);
         if (sh_bb) atomicMax(&c.best, sh_bb);                          // :417-418
+        if (dbg) C.dbg[(size_t)blockIdx.x * 4 + 3] = wall_clock64();
     }
 }
 
@@ -910,9 +917,13 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
     const int sl = blockIdx.x / BPS, j0 = blockIdx.x - sl * BPS;
     const int s = s0 + sl;
     StreamCtl &c = ctl[s];
+    const long long t_start = wall_clock64();
     if (c.active == 0) return;
     const StreamDev &S = streams[s];
     const int units = (((ROUND == 0) ? pk_cnt0(c.pkA) : c.cnt1) + PER - 1) / PER;
+    const bool dbg = ROUND == 0 && C.dbg && c.frame == C.dbg_frame && tid == 0;
+    long long *dbp = C.dbg + ((size_t)65536 + blockIdx.x) * 4;
+    if (dbg) { dbp[0] = t_start; dbp[1] = wall_clock64(); dbp[2] = 0; dbp[3] = (j0 >= units) ? -1 : 0; }
     if (j0 >= units) return;
     if (tid == 0) { stage.n = 0; stage.np = 0; sh_acc[0] = sh_acc[1] = sh_acc[2] = 0; }
     __syncthreads();
@@ -931,6 +942,7 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
                     ROUND == 0 && !init, k < nin, in_base + k,
                     S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], S.skey[(ROUND & 1) ^ 1],
                     (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base, n_arcs, n_paths_made, n_pend);
+        if (dbg) dbp[2] = wall_clock64();
         n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
         if (lane == 0) {
             if (n_arcs) atomicAdd(&sh_acc[0], n_arcs);
@@ -944,6 +956,7 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
         if (sh_acc[0]) atomicAdd(&c.fr[ST_ARCS], sh_acc[0]);
         if (sh_acc[1]) atomicAdd(&c.fr[ST_PATHS], sh_acc[1]);
         if (sh_acc[2]) atomicAdd(&c.fr[ST_PEND], sh_acc[2]);
+        if (dbg) dbp[3] = wall_clock64();
     }
 }
 
@@ -1819,6 +1832,27 @@ extern "C" int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out)
     rc = fetch_results(d, s, 1, tmp.data(), s);
     *out = tmp[(size_t)s];
     return rc;
+}
+
+// Diagnostics: record per-block wall-clock stamps (100 MHz) of k_phase_a and k_expand<0> for
+// lock-step frame `frame` of subsequent decodes; fetch copies 2 x 65536 x 4 stamps.
+extern "C" int jd_dec_debug_trace(jd_dec *d, int32_t frame, int64_t *fetch)
+{
+    if (!d) return jd_fail(JD_EINVAL, "jd_dec_debug_trace: null");
+    const size_t n = (size_t)2 * 65536 * 4;
+    if (!d->C.dbg) {
+        long long *p = nullptr;
+        HIPCHK(hipMalloc(&p, n * sizeof(long long)));
+        HIPCHK(hipMemset(p, 0, n * sizeof(long long)));
+        d->allocs.push_back(p);
+        d->C.dbg = p;
+    }
+    d->C.dbg_frame = frame;
+    if (fetch) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(fetch, d->C.dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
+    }
+    return JD_OK;
 }
 
 extern "C" int jd_dec_last_timing(const jd_dec *d, jd_timing *out)

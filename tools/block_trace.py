@@ -1,0 +1,33 @@
+"""Per-block timeline of k_phase_a / k_expand<0> at one lock-step frame (GPU box diagnostic)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from juicer_amd import synth, capi
+U, frame = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 250
+am, net, feats, _ = synth.config_c2(n_utts=U)
+dec = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=150.0, max_streams=U)
+dec.decode_batch(feats)
+dec.debug_trace(frame)
+dec.decode_batch(feats)
+buf = dec.debug_trace(frame, fetch=True)
+for name, b in (("k_phase_a", buf[0]), ("k_expand<0>", buf[1])):
+    rec = b[b[:, 0] != 0]
+    if len(rec) == 0:
+        print(name, "no records"); continue
+    t0 = rec[:, 0].min()
+    work = rec[rec[:, 3] > 0]
+    empty = rec[rec[:, 3] == -1]
+    us = lambda x: x / 100.0
+    print("%s: %d blocks recorded (%d working, %d empty)" % (name, len(rec), len(work), len(empty)))
+    print("   block start (us after first): working p50 %.1f p90 %.1f max %.1f | empty p50 %.1f max %.1f" % (
+        us(np.median(work[:, 0] - t0)), us(np.percentile(work[:, 0] - t0, 90)), us((work[:, 0] - t0).max()),
+        us(np.median(empty[:, 0] - t0)) if len(empty) else -1, us((empty[:, 0] - t0).max()) if len(empty) else -1))
+    print("   setup (ctl loads) us: p50 %.2f p90 %.2f max %.2f" % tuple(us(np.percentile(work[:, 1] - work[:, 0], q)) for q in (50, 90, 100)))
+    print("   work us:              p50 %.2f p90 %.2f max %.2f" % tuple(us(np.percentile(work[:, 2] - work[:, 1], q)) for q in (50, 90, 100)))
+    print("   epilogue us:          p50 %.2f p90 %.2f max %.2f" % tuple(us(np.percentile(work[:, 3] - work[:, 2], q)) for q in (50, 90, 100)))
+    print("   last block end: %.1f us after first start" % us(work[:, 3].max() - t0))
+    # concurrency profile: how many working blocks are alive at 10 sample times
+    end = work[:, 3].max()
+    for frac in (0.1, 0.3, 0.5, 0.7, 0.9):
+        t = t0 + (end - t0) * frac
+        print("      t=%5.1f us: %4d working blocks alive" % (us(t - t0), int(((work[:, 0] <= t) & (work[:, 3] >= t)).sum())))
