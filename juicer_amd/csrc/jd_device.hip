@@ -259,8 +259,7 @@ struct __align__(128) StreamCtl {
     int skipped_prev;   // instances whose creation was skipped last frame (still counted, see k_resolve)
     int lst;            // which active list is current
     int n_act;          // entries in the current active list
-    int hw;             // slot high-water mark
-    int n_free;         // entries on the free-slot stack
+    int pad_a, pad_b;
     int frame;          // next frame to process
     int T;              // frames available
     int error, needs_init, active, started;
@@ -290,8 +289,8 @@ __device__ __forceinline__ int pk_cnt0(unsigned long long v) { return (int)((v >
 __device__ __forceinline__ int pk_ndead(unsigned long long v) { return (int)((v >> PK_SHIFT2) & PK_MASK); }
 
 struct StreamDev {      // per-stream arenas (cold)
-    int *rec;                         // instance records (RecLayout), cap_slots of them
-    int *act[2]; int *free_stk;
+    int *rec[2];                      // the active lists ARE the instance records (RecLayout): list lst is
+                                      // read by phase A, survivors + new instances are written to lst^1
     ArcState *ast;                    // per ARC: {best entry-token candidate of this frame, slot}
     unsigned long long *skey[2];      // per STATE: best frontier item arriving there (round parity)
     unsigned long long *skeyL;        // round 0 only: items whose arc carries a word label (own threshold)
@@ -396,13 +395,13 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
     if (mode == 1) {
         if (!c.needs_init) return;
         // drop whatever the previous utterance left behind
-        const int *actc = S.act[c.lst];
         const int rec_ints = (C.max_n <= 5) ? 32 : 64;
-        for (int q = lane; q < c.n_act; q += 64) S.ast[S.rec[(size_t)actc[q] * rec_ints]].slot = -1;
+        const int *recs = S.rec[c.lst];
+        for (int q = lane; q < c.n_act; q += 64) S.ast[recs[(size_t)q * rec_ints]].slot = -1;
         if (use_hist) for (int b = lane; b < C.hist_nbins; b += 64) S.hist[b] = 0;
         __syncthreads();
         if (lane == 0) {
-            c.n_act = 0; c.hw = 0; c.n_free = 0; c.n_paths = 0; c.frame = 0; c.error = 0;
+            c.n_act = 0; c.n_paths = 0; c.frame = 0; c.error = 0;
             c.best_emit = LZ; c.normalise = 0.0f; c.emitTh = LZ; c.startTh = LZ;
             c.best = f2o(LZ); c.pkA = 1ULL << PK_SHIFT1;                         // cnt0 = 1: the start token
             c.pkE = 0ULL;
@@ -420,7 +419,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
     if (mode == 2) {
         if (c.active != 2) return;
         if (lane == 0) {
-            c.n_act = c.n_alloc; c.hw = c.n_alloc;
+            c.n_act = c.n_alloc;
             c.best_emit = o2f(c.best);
             c.n_paths = c.n_paths + pk_cnt0(c.pkA) + c.n_paths_extra;
             c.n_paths_extra = 0;
@@ -435,7 +434,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
 
     // ---- epilogue of the frame processed in this step's predecessor kernels.  Every counter
     // lives on its own cache line: fetch them all first (independent loads in flight together).
-    const int v_active = c.active, v_nfree = c.n_free, v_hw = c.hw, v_nalloc = c.n_alloc, v_nskip = c.n_skipped;
+    const int v_active = c.active, v_nalloc = c.n_alloc, v_nskip = c.n_skipped;
     const int v_skprev = c.skipped_prev, v_lst = c.lst, v_frame = c.frame;
     const int v_npaths = c.n_paths + pk_cnt0(c.pkA) + c.n_paths_extra;
     const int v_started = c.started, v_needs_init = c.needs_init, v_error = c.error, v_T = c.T;
@@ -446,8 +445,6 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
     float best_emit = c.best_emit;
     int frame_now = v_frame;
     if (v_active == 1) {
-        const int nfree0 = v_nfree + pk_ndead(v_pk);
-        const int from_free = v_nalloc < nfree0 ? v_nalloc : nfree0;
         best_emit = o2f(v_best);
         frame_now = v_frame + 1;
         // per-frame statistics: lane k owns counter k
@@ -458,8 +455,6 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         if (lane == ST_EMIT) v_fr = (int)(v_pe >> 32);
         if (lane < ST_N) { c.st[lane] = v_st + v_fr; c.fr[lane] = 0; }
         if (lane == 0) {
-            c.n_free = nfree0 - from_free;
-            c.hw = v_hw + (v_nalloc - from_free);
             c.n_act = pk_nB(v_pk) + v_nalloc;
             c.best_emit = best_emit;
             if (v_fkey != 0ULL) {
@@ -563,26 +558,28 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
     for (int u = j0; u < units; u += BPS) {
         const int n_act = c.n_act;
         const float normalise = c.normalise, emitTh = c.emitTh, startTh = c.startTh;
-        const int *act_cur = S.act[c.lst];
-        int *act_next = S.act[c.lst ^ 1];
+        const int *rec_cur = S.rec[c.lst];
+        int *rec_next = S.rec[c.lst ^ 1];
         const float *llrow = ll + (size_t)sl * ll_stride + (size_t)(c.frame - f0) * C.G;
         const int q = u * PER + (tid / GS);
         const bool valid = q < n_act;
         bool emit_live = false, has_exit = false, pemit = false;
-        int slot = -1, arc = -1, n = 0;
+        int arc = -1, n = 0;
         Tok nw = null_tok(), ex = null_tok();
         int4 exinfo = make_int4(-1, 0, 0, 0);
-        Tok *tk = nullptr;                                             // the instance's tokens (updated in place)
+        int4 h0 = make_int4(0, 0, 0, 0), h1 = h0, h2 = h0;
+        const Tok *tk = nullptr;                                       // the instance's tokens in the current list
         const float *trP = C.trP;
         const int *se = C.se32;
         if (valid) {
-            slot = act_cur[q];
-            int *rec = S.rec + (size_t)slot * RL::REC_INTS;
-            const int4 h0 = *(const int4 *)rec, h1 = *(const int4 *)(rec + 4);
+            // the active list IS the record array: instance q of this frame sits at record q
+            const int *rec = rec_cur + (size_t)q * RL::REC_INTS;
+            h0 = *(const int4 *)rec; h1 = *(const int4 *)(rec + 4);
+            if (GS == 8) h2 = *(const int4 *)(rec + 8);
             arc = h0.x;
             n = h0.y & 0xff;
             const int tm = h0.y >> 8;
-            tk = (Tok *)(rec + RL::TOK_OFF);
+            tk = (const Tok *)(rec + RL::TOK_OFF);
             // speculative: left-to-right HMMs read states r and r+1; issued together with the header
             const Tok spec0 = tk[r], spec1 = tk[(r + 1 < MN) ? r + 1 : r];
             trP = C.trP + (size_t)tm * MN * MN;
@@ -593,7 +590,6 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
                 int gmj;
                 if (GS == 4) gmj = (r == 0) ? h1.x : (r == 1) ? h1.y : h1.z;
                 else {
-                    const int4 h2 = *(const int4 *)(rec + 8);
                     gmj = (r == 0) ? h1.x : (r == 1) ? h1.y : (r == 2) ? h1.z : (r == 3) ? h2.x : (r == 4) ? h2.y : h2.z;
                 }
                 const float outp = llrow[gmj];                         // :411
@@ -626,6 +622,8 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
                 }
             }
         }
+        long long *dfx = C.dbg ? C.dbg + ((size_t)131072 + blockIdx.x) * 4 : nullptr;
+        if (dbg && u == j0) dfx[0] = wall_clock64();                   // after loads + per-state compute
         // exit state (:443-483): lane GS-1 of the group reads the NEW tokens of its neighbours
         {
             int st = 0, en = 0;
@@ -655,12 +653,6 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
         }
         const unsigned long long bemit = __ballot(emit_live);
         const bool slot_live = ((bemit >> gb) & ((1ull << GS) - 1ull)) != 0ull;
-        // in-place update: every load of the group's old tokens precedes these stores in the
-        // wave's instruction stream (the shuffles above consumed them)
-        if (valid && slot_live) {
-            if (r + 1 < n - 1) tk[r + 1] = nw;
-            if (r == GS - 1) { tk[0] = null_tok(); tk[n - 1] = null_tok(); }       // :428-436, :964
-        }
         const bool live = valid && r == 0 && slot_live;
         const bool dead = valid && r == 0 && !slot_live;
         // block-level compaction: ONE packed returning atomic per unit
@@ -678,13 +670,34 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
                 if (mo) atomicMax(&sh_bb, mo);
             }
         }
+        if (dbg && u == j0) dfx[1] = wall_clock64();                   // before the barrier
         __syncthreads();
         unsigned long long pre = 0, tot = 0;
         for (int w = 0; w < (KTB >> 6); ++w) { const unsigned long long sv = sh_w3[w]; if (w < wid) pre += sv; tot += sv; }
         if (tid == 0) sh_pk = tot ? atomicAdd(&c.pkA, tot) : 0ULL;
         __syncthreads();
+        if (dbg && u == j0) dfx[2] = wall_clock64();                   // after barrier + packed atomic
         const unsigned long long bs = sh_pk;
-        if (live) act_next[pk_nB(bs) + pk_nB(pre) + rank_in(bl)] = slot;
+        // survivors are copied to compacted positions of the next list (header + new tokens, one
+        // 128-byte line written by the group); the arc's hook follows the instance
+        {
+            int pos = live ? pk_nB(bs) + pk_nB(pre) + rank_in(bl) : -1;
+            pos = __shfl(pos, gb);                                     // group leader -> whole group
+            if (valid && pos >= 0) {
+                if (pos >= C.cap_slots) c.error = -41;
+                else {
+                    int *dst = rec_next + (size_t)pos * RL::REC_INTS;
+                    Tok *tn = (Tok *)(dst + RL::TOK_OFF);
+                    if (r + 1 < n - 1) tn[r + 1] = nw;
+                    if (r == GS - 1) {                                 // :428-436, :964 + header
+                        *(int4 *)dst = h0; *(int4 *)(dst + 4) = h1;
+                        if (GS == 8) *(int4 *)(dst + 8) = h2;
+                        tn[0] = null_tok(); tn[n - 1] = null_tok();
+                        S.ast[arc].slot = pos;
+                    }
+                }
+            }
+        }
         if (has_exit) {
             const int k = pk_cnt0(bs) + pk_cnt0(pre) + rank_in(be);
             if (k < C.cap_items) {
@@ -695,10 +708,7 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
                           ((unsigned long long)f2o(ex.score) << 32) | (unsigned)k);
             } else c.error = -42;
         }
-        if (dead) {                                                    // returnNetInst :777-797
-            S.free_stk[c.n_free + pk_ndead(bs) + pk_ndead(pre) + rank_in(bd)] = slot;
-            S.ast[arc].slot = -1;
-        }
+        if (dead) S.ast[arc].slot = -1;                                // returnNetInst :777-797
     }
     __syncthreads();
     if (tid == 0) {
@@ -1026,9 +1036,8 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
     __syncthreads();
     for (int u = j0; u < units; u += BPS) {
         const int q = u * KTB + tid;
-        int *act_next = S.act[c.lst ^ 1];
-        const unsigned long long pk = c.pkA;
-        const int nfree0 = c.n_free + pk_ndead(pk), hw0 = c.hw, nB = pk_nB(pk);
+        int *rec_next = S.rec[c.lst ^ 1];
+        const int nB = pk_nB(c.pkA);
         // An instance whose entry token provably fails next frame's emit threshold is not
         // materialised: next frame normalises by bestEmitScore >= bestA (the phase-A best, final
         // now) and emitTh >= -mainBeam, and float add/sub are monotone, so
@@ -1071,13 +1080,12 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
         __syncthreads();
         unsigned mo = win ? f2o(sc) : 0u;                              // :572-573 (skipped ones can never raise it)
         if (need) {
-            const int k = sh_base + myk;
-            const int ns_ = (k < nfree0) ? S.free_stk[nfree0 - 1 - k] : hw0 + (k - nfree0);
+            const int ns_ = nB + sh_base + myk;                        // appended to the next list
             if (ns_ >= C.cap_slots) { c.error = -41; slot = -1; }
             else {                                                     // attachNetInst :751-774
                 slot = ns_;
                 const int n = ax0.y & 0xff;
-                int *rec = S.rec + (size_t)slot * rec_ints;
+                int *rec = rec_next + (size_t)slot * rec_ints;
                 *(int4 *)rec = make_int4(b, ax0.y, Bk.out, Bk.to);
                 if (rec_ints == 32) *(int4 *)(rec + 4) = make_int4(ax0.w, ax1.x, ax1.y, ax0.z);
                 else {
@@ -1087,14 +1095,13 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
                 Tok *tp = (Tok *)(rec + tok_off);
                 for (int qq = 1; qq < n; ++qq) tp[qq] = null_tok();
                 S.ast[b].slot = slot;
-                act_next[nB + k] = slot;
             }
         }
         if (win && slot >= 0) {
             const Tok it = S.item_tok[ii];
             Tok e;
             e.score = sc; e.ac = it.ac; e.lm = it.lm + Bk.w; e.path = it.path;
-            *(Tok *)(S.rec + (size_t)slot * rec_ints + tok_off) = e;
+            *(Tok *)(rec_next + (size_t)slot * rec_ints + tok_off) = e;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_xor(mo, o); mo = y > mo ? y : mo; }
@@ -1441,9 +1448,8 @@ static int ensure_arenas(jd_dec *d)
         StreamDev &S = d->h_streams[(size_t)s];
         memset(&S, 0, sizeof S);
 #define A(p, n) do { rc = dmalloc(d, &(p), (size_t)(n)); if (rc) return rc; } while (0)
-        A(S.rec, d->cap_slots * ((MN <= 5) ? 32 : 64));
-        A(S.act[0], d->cap_slots); A(S.act[1], d->cap_slots);
-        A(S.free_stk, d->cap_slots);
+        A(S.rec[0], d->cap_slots * ((MN <= 5) ? 32 : 64));
+        A(S.rec[1], d->cap_slots * ((MN <= 5) ? 32 : 64));
         A(S.ast, d->net->n_arcs);
         A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states);
         A(S.touched, d->cap_items);
@@ -1562,7 +1568,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
 
 #define KSAMPLE_EVERY 16
 #define KSAMPLE_MAX 96
-#define BPS_A 128      // blocks per stream: phase A (64 instances per unit; blocks loop beyond 8k instances)
+#define BPS_A 224      // blocks per stream: phase A (64 instances per unit; blocks loop beyond 14k instances)
 #define BPS_X 64       // frontier rounds (16 items per unit)
 #define BPS_R 64       // resolve (256 touched arcs per unit)
 
@@ -1839,7 +1845,7 @@ extern "C" int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out)
 extern "C" int jd_dec_debug_trace(jd_dec *d, int32_t frame, int64_t *fetch)
 {
     if (!d) return jd_fail(JD_EINVAL, "jd_dec_debug_trace: null");
-    const size_t n = (size_t)2 * 65536 * 4;
+    const size_t n = (size_t)3 * 65536 * 4;
     if (!d->C.dbg) {
         long long *p = nullptr;
         HIPCHK(hipMalloc(&p, n * sizeof(long long)));

@@ -31,3 +31,13 @@ for name, b in (("k_phase_a", buf[0]), ("k_expand<0>", buf[1])):
     for frac in (0.1, 0.3, 0.5, 0.7, 0.9):
         t = t0 + (end - t0) * frac
         print("      t=%5.1f us: %4d working blocks alive" % (us(t - t0), int(((work[:, 0] <= t) & (work[:, 3] >= t)).sum())))
+
+# finer phase-A stamps (first unit of each block): loads+compute | to barrier | barrier+atomic | stores
+a, f = buf[0], buf[2]
+m = (a[:, 3] > 0) & (f[:, 0] != 0)
+if m.any():
+    us = lambda x: x / 100.0
+    t_setup = a[m, 1]; t_c = f[m, 0]; t_b = f[m, 1]; t_a = f[m, 2]; t_end = a[m, 2]
+    for name, d in (("record/token/ll loads + state update", t_c - t_setup), ("exit shuffles, ballots", t_b - t_c),
+                    ("barrier + packed atomic + barrier", t_a - t_b), ("stores + (further units) ", t_end - t_a)):
+        print("   phase A %-38s p50 %.2f p90 %.2f us" % (name, us(np.median(d)), us(np.percentile(d, 90))))
