@@ -229,6 +229,7 @@ struct DecConst {
     int max_hyps, hist_min, hist_max, hist_nbins;
     // arena capacities (per stream)
     int cap_slots, cap_items, cap_paths;
+    int gc_threshold;   // collect Path records when more than this many are in use
     // diagnostics (jd_dec_debug_trace): per-block wall_clock64 stamps of one chosen frame
     long long *dbg; int dbg_frame;
 };
@@ -297,6 +298,7 @@ struct StreamDev {      // per-stream arenas (cold)
     int *touched;                     // arcs whose ekey became non-zero this frame
     Tok *item_tok; int4 *item_info;   // frontier items: token + {arc, outLabel, toState, -}
     PathRec *paths; int *hist;
+    PathRec *paths2; int *gc_idx;     // Path garbage collection: compaction target + mark / new-index array
     // result of jd_finish_kernel
     int res_n; int *res_label; int *res_time; float *res_score, *res_ac, *res_lm; int res_cap;
 };
@@ -470,6 +472,10 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
             c.frame = frame_now;
             c.n_paths = v_npaths < C.cap_paths ? v_npaths : C.cap_paths;
         }
+    }
+    if (mode == 3) {                                   // epilogue only (before Path garbage collection)
+        if (lane == 0 && v_active != 0) c.active = 0;
+        return;
     }
     // ---- start of the next frame (:311-339)
     const bool go = v_started && !v_needs_init && v_error == 0 && frame_now < v_T;
@@ -1115,6 +1121,81 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
     }
 }
 
+// Path garbage collection = collectPaths (WFSTDecoderLite.cpp:699-747) as a mark-compact: records
+// reachable from a live token (or bestFinalToken) are kept, everything else - including the
+// indices reserved for exit tokens that were never expanded - is dropped.  No effect on results.
+// One 1024-thread block per stream, run between frames; a no-op below the threshold.
+__global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0)
+{
+    StreamCtl &c = ctl[s0 + blockIdx.x];
+    StreamDev &S = streams[s0 + blockIdx.x];
+    const int np = c.n_paths;
+    if (!c.started || c.needs_init || np <= C.gc_threshold) return;
+    __shared__ int sh_w[16];
+    __shared__ int sh_carry;
+    const int tid = threadIdx.x, NTH = blockDim.x;
+    const int MN = C.max_n, rec_ints = (MN <= 5) ? 32 : 64, tok_off = (MN <= 5) ? 8 : 12;
+    int *idx = S.gc_idx;
+    for (int p = tid; p < np; p += NTH) idx[p] = 0;
+    __syncthreads();
+    // mark: walk the chain of every stored token until an already marked record is met
+    const int *recs = S.rec[c.lst];
+    const int n_tok = c.n_act * MN;
+    for (int k = tid; k < n_tok + 1; k += NTH) {
+        int p;
+        if (k == n_tok) p = c.best_final.path;
+        else {
+            const int q = k / MN, i = k - q * MN;
+            const int n = recs[(size_t)q * rec_ints + 1] & 0xff;
+            p = (i < n) ? ((const Tok *)(recs + (size_t)q * rec_ints + tok_off))[i].path : -1;
+            if (i < n && !(((const Tok *)(recs + (size_t)q * rec_ints + tok_off))[i].score > LZ)) p = -1;
+        }
+        while (p >= 0 && atomicExch(&idx[p], 1) == 0) p = S.paths[p].prev;
+    }
+    __syncthreads();
+    // exclusive scan of the marks -> new indices (idx[p] = new index, -1 if dropped)
+    if (tid == 0) sh_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < np; b0 += NTH) {
+        const int p = b0 + tid;
+        const int m = (p < np) ? idx[p] : 0;
+        int tot;
+        const int ex = block_excl_scan(m, sh_w, tot);
+        const int base = sh_carry;
+        if (p < np) idx[p] = m ? base + ex : -1;
+        __syncthreads();
+        if (tid == 0) sh_carry = base + tot;
+        __syncthreads();
+    }
+    const int kept = sh_carry;
+    // compact into the second arena, remapping prev (prev < p, so its new index is final)
+    for (int p = tid; p < np; p += NTH) {
+        const int ni = idx[p];
+        if (ni >= 0) {
+            PathRec pr = S.paths[p];
+            pr.prev = (pr.prev >= 0) ? idx[pr.prev] : -1;
+            S.paths2[ni] = pr;
+        }
+    }
+    // remap the tokens
+    int *recw = S.rec[c.lst];
+    for (int k = tid; k < n_tok; k += NTH) {
+        const int q = k / MN, i = k - q * MN;
+        const int n = recw[(size_t)q * rec_ints + 1] & 0xff;
+        if (i < n) {
+            Tok *t = (Tok *)(recw + (size_t)q * rec_ints + tok_off) + i;
+            const int p = t->path;
+            if (p >= 0) t->path = (t->score > LZ) ? idx[p] : -1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (c.best_final.path >= 0) c.best_final.path = idx[c.best_final.path];
+        PathRec *tmp = S.paths; S.paths = S.paths2; S.paths2 = tmp;
+        c.n_paths = kept;
+    }
+}
+
 // recognitionFinish (:230-309): walk the Path chain of bestFinalToken.
 __global__ void jd_finish_kernel(StreamCtl *ctl, StreamDev *streams, int s0, int n)
 {
@@ -1406,7 +1487,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     // default arena sizes: sized for 288 GB of HBM, not for frugality
     d->cap_slots = std::min<int64_t>(net->n_arcs + 1024, 1 << 18);
     d->cap_items = 1 << 18;
-    d->cap_paths = 1 << 22;
+    d->cap_paths = 1 << 21;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&d->s_gmm, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&d->s_search, hipStreamNonBlocking)) != hipSuccess) {
@@ -1442,6 +1523,7 @@ static int ensure_arenas(jd_dec *d)
     if (rc) return rc;
     const int B = d->max_streams, MN = d->am->max_n;
     d->C.cap_slots = (int)d->cap_slots; d->C.cap_items = (int)d->cap_items; d->C.cap_paths = (int)d->cap_paths;
+    d->C.gc_threshold = (int)(d->cap_paths / 2);
     d->h_streams.assign((size_t)B, StreamDev());
     std::vector<ArcState> ast0((size_t)d->net->n_arcs, ArcState{0ULL, -1, 0});
     for (int s = 0; s < B; ++s) {
@@ -1454,7 +1536,7 @@ static int ensure_arenas(jd_dec *d)
         A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states);
         A(S.touched, d->cap_items);
         A(S.item_tok, d->cap_items); A(S.item_info, d->cap_items);
-        A(S.paths, d->cap_paths);
+        A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths);
         A(S.hist, HIST_MAX_BINS);
         A(S.res_label, d->res_cap); A(S.res_time, d->res_cap);
         A(S.res_score, d->res_cap); A(S.res_ac, d->res_cap); A(S.res_lm, d->res_cap);
@@ -1609,6 +1691,13 @@ static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll
 #undef EV
 }
 
+// Path garbage collection between two frames: close the frame in flight, then collect
+static void launch_gc(jd_dec *d, int nb, int s0, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 3);
+    hipLaunchKernelGGL(k_gc, dim3(nb), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, s0);
+}
+
 // closes the last frame of a run of steps (epilogue only: no stream has frames left)
 static void launch_close(jd_dec *d, int nb, int s0, hipStream_t st)
 {
@@ -1674,6 +1763,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
         {
             const int nsteps = std::min(Fc, maxT - c * Fc);
             for (int k = 0; k < nsteps; ++k) {
+                if ((c > 0 || k > 0) && (k % 32) == 0) launch_gc(d, nb, 0, d->s_search);   // no-op below the threshold
                 hipEvent_t *ev = nullptr;
                 if (((c * Fc + k) % KSAMPLE_EVERY) == KSAMPLE_EVERY / 2 && d->kev_used < KSAMPLE_MAX) {
                     if (d->kev.empty()) {
@@ -1814,7 +1904,10 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
         rc = launch_gmm(d->am, d->amb, d->d_push, d->d_row_src, n, d->d_ll[0], st);
         if (rc) return rc;
         launch_init(d, 1, s, st);                      // no-op unless the stream is flagged needs_init
-        for (int k = 0; k < n; ++k) launch_step(d, 1, s, d->d_ll[0], (long long)Fc * G, f0, st);
+        for (int k = 0; k < n; ++k) {
+            if ((k % 32) == 0) launch_gc(d, 1, s, st);
+            launch_step(d, 1, s, d->d_ll[0], (long long)Fc * G, f0, st);
+        }
         launch_close(d, 1, s, st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));

@@ -238,3 +238,28 @@ def test_batch_test_cli(small, tmp_path):
             assert int(times[-1]) == feats[u].shape[0]
             assert lines[i + 3].startswith("CPU time ") and "RT factor" in lines[i + 3]
         assert lines[-1].startswith("Total CPU time ")
+
+
+def test_path_garbage_collection(small):
+    """A Path arena far smaller than the number of records an utterance writes: decoding only
+    succeeds because unreachable records are collected between frames (collectPaths,
+    WFSTDecoderLite.cpp:699-747), and the results do not change."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0, max_hyps=200)
+    od = OracleDecoder(onet, oam, **kw)
+    big = capi.Decoder(gnet, gam, max_streams=len(feats), **kw).decode_batch(feats)
+    need = max(h.stats["tot_paths"] for h in big)
+    cap = 1 << 14
+    assert need > 2 * cap, "test is vacuous: %d records fit" % need
+    gd = capi.Decoder(gnet, gam, max_streams=len(feats), max_paths=cap, **kw)
+    gs = gd.decode_batch(feats)
+    for u, x in enumerate(feats):
+        assert_hyp_matches(gs[u], od.decode(x), "gc utt %d" % u)
+        assert np.array_equal(gs[u].score.view(np.uint32), big[u].score.view(np.uint32))
+    # streaming API takes the same path
+    gd.stream_init(0)
+    for pos in range(0, feats[0].shape[0], 50):
+        gd.stream_push(0, feats[0][pos:pos + 50])
+    assert_hyp_matches(gd.stream_finish(0), od.decode(feats[0]), "gc streaming")
