@@ -2,7 +2,7 @@
 //
 //   DecoderBatchTest::configureTests  list file, one path per line, '#'/blank skipped  (DecoderBatchTest.cpp:822-844)
 //   DecoderBatchTest::run             decode, output, "CPU time .. speech time .. RT factor" (:738-777)
-//   DecoderBatchTest::outputResult    DBT_OUTPUT_REF: words separated by ' '           (:339-344)
+//   DecoderBatchTest::outputResult    ref / trans / mlf / xmlf / verbose formats           (:339-430)
 //   DecoderSingleTest::extractResultsFromHypWordMode  label-1, start/end frames       (DecoderSingleTest.cpp:403-468)
 //
 // Tracter (feature files) and Torch3 (CmdLine, vocabulary files) are not in the tree, so this
@@ -53,6 +53,7 @@ int main(int argc, char **argv)
     const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *mmf = 0, *list = 0;
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
     int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0;
+    std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -65,6 +66,7 @@ int main(int argc, char **argv)
         else if (a == "-lmScaleFactor") lmScale = (float)atof(nxt()); else if (a == "-insPenalty") insPen = (float)atof(nxt());
         else if (a == "-framesPerSec") framesPerSec = atoi(nxt()); else if (a == "-device") device = atoi(nxt());
         else if (a == "-batch") batch = atoi(nxt()); else if (a == "-perFrameAdapter") useAdapter = 1;
+        else if (a == "-outputFormat") outputFormat = nxt();
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (!fsm || (!amf && !mmf) || !list) {
@@ -104,17 +106,70 @@ int main(int argc, char **argv)
         fclose(f);
     }
 
+    // word strings: vocab->words[label-1] in the reference (DecoderSingleTest.cpp:443); here the output
+    // symbol table of the transducer (symbol id == output label), integers when it is not given
+    std::vector<std::string> syms;
+    if (outsyms) {
+        FILE *f = fopen(outsyms, "rb");
+        char line[10000], sym[10000]; int id;
+        while (f && fgets(line, sizeof line, f))
+            if (sscanf(line, "%s %d", sym, &id) == 2 && id >= 0) { if ((size_t)id >= syms.size()) syms.resize(id + 1); syms[id] = sym; }
+        if (f) fclose(f);
+    }
+    auto word = [&](int label) -> std::string {
+        if (label >= 0 && (size_t)label < syms.size() && !syms[label].empty()) return syms[label];
+        return std::to_string(label - 1);
+    };
+    if (outputFormat == "mlf" || outputFormat == "xmlf") printf("#!MLF!#\n");     // DecoderBatchTest::openOutputFile
     double decodeTime = 0.0, speechTime = 0.0;
-    auto print_utt = [&](size_t u, int n, const int32_t *label, const int32_t *time, double decTime) {
-        printf("File: %s\n", files[u].c_str());
-        // extractResultsFromHypWordMode: chain is newest first; word index = state - 1
-        for (int k = n - 1; k >= 0; --k) printf("%d ", label[k] - 1);
-        printf("\n");
-        printf("  [ ");
-        for (int k = n - 1; k >= 0; --k) printf("%d ", time[k] + 1);
-        printf("(%d) ]\n", nfr[u]);
+    // DecoderBatchTest::outputResult (DecoderBatchTest.cpp:339-430) on the word list that
+    // DecoderSingleTest::extractResultsFromHypWordMode (DecoderSingleTest.cpp:403-468) derives from the
+    // DecHyp chain: chain is newest first; start time = previous end time; per-word score deltas.
+    auto print_utt = [&](size_t u, int n, const int32_t *label, const int32_t *time, const float *ac, const float *lm,
+                         double decTime) {
+        fprintf(stderr, "File: %s\n", files[u].c_str());
+        std::vector<int> lab(n), st(n), et(n);
+        std::vector<float> wac(n), wlm(n);
+        for (int w = 0; w < n; ++w) {
+            const int k = n - 1 - w;                   // chain index of word w
+            lab[w] = label[k]; et[w] = time[k];
+            st[w] = (w == 0) ? 0 : et[w - 1];
+            wac[w] = ac ? ac[k] - ((w > 0) ? ac[k + 1] : 0.0f) : 0.0f;
+            wlm[w] = lm ? lm[k] - ((w > 0) ? lm[k + 1] : 0.0f) : 0.0f;
+        }
+        if (outputFormat == "ref") {
+            for (int w = 0; w < n; ++w) printf("%s ", word(lab[w]).c_str());
+            printf("\n");
+        } else if (outputFormat == "trans") {
+            for (int w = 0; w < n; ++w) printf("%s ", word(lab[w]).c_str());
+            printf("(trans-%d)\n", n);
+        } else if (outputFormat == "mlf" || outputFormat == "xmlf") {
+            std::string base = files[u];
+            size_t sl = base.rfind('/'); if (sl != std::string::npos) base = base.substr(sl + 1);
+            size_t dot = base.rfind('.'); if (dot != std::string::npos) base = base.substr(0, dot);
+            printf("\"*/%s.rec\"\n", base.c_str());
+            for (int w = 0; w < n; ++w) {
+                if (outputFormat == "mlf") printf("%s\n", word(lab[w]).c_str());
+                else {                                 // HTK 100 ns units (:381-403)
+                    double s0 = (float)1.0e7 / (float)framesPerSec * (float)st[w];
+                    if (s0 > 0) s0 += (float)1.0e7 / (float)framesPerSec;
+                    double e0 = (float)1.0e7 / (float)framesPerSec * (float)et[w];
+                    if (e0 > 0) e0 += (float)1.0e7 / (float)framesPerSec;
+                    printf("%.0f %.0f %s %f\n", s0, e0, word(lab[w]).c_str(), wac[w] + wlm[w]);
+                }
+            }
+            printf(".\n");
+        } else {                                       // verbose
+            printf("%s\n", files[u].c_str());
+            printf("\tActual :    ");
+            for (int w = 0; w < n; ++w) printf("%s ", word(lab[w]).c_str());
+            printf("  [ ");
+            for (int w = 0; w < n; ++w) printf("%d ", et[w] + 1);
+            printf("(%d) ]\n", nfr[u]);
+        }
         const double uttTime = (double)nfr[u] / framesPerSec;
-        printf("CPU time %.3f  speech time %.3f  RT factor %.3f\n", decTime, uttTime, uttTime > 0 ? decTime / uttTime : 0.0);
+        fprintf(stderr, "CPU time %.3f  speech time %.3f  RT factor %.3f\n", decTime, uttTime,
+                uttTime > 0 ? decTime / uttTime : 0.0);
         decodeTime += decTime; speechTime += uttTime;
     };
 
@@ -134,9 +189,12 @@ int main(int argc, char **argv)
             }
             JuicerAmd::DecHyp *hyp = dec.finish();
             std::vector<int32_t> lab, tim;
-            for (JuicerAmd::DecHypHist *h = hyp ? hyp->hist : 0; h; h = h->prev) { lab.push_back(h->state); tim.push_back(h->time); }
+            std::vector<float> hac, hlm;
+            for (JuicerAmd::DecHypHist *h = hyp ? hyp->hist : 0; h; h = h->prev) {
+                lab.push_back(h->state); tim.push_back(h->time); hac.push_back(h->acousticScore); hlm.push_back(h->lmScore);
+            }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            print_utt(u, (int)lab.size(), lab.data(), tim.data(), dt);
+            print_utt(u, (int)lab.size(), lab.data(), tim.data(), hac.data(), hlm.data(), dt);
         }
     } else {
         jd_dec *dec = 0;
@@ -151,12 +209,13 @@ int main(int argc, char **argv)
         for (size_t u = 0; u < files.size(); ++u) tot += nfr[u];
         for (size_t u = 0; u < files.size(); ++u) {
             if (hyps[u].n < 0) fprintf(stderr, "WARNING: no token survived at the end of decoding\n");
-            print_utt(u, hyps[u].n > 0 ? hyps[u].n : 0, hyps[u].label, hyps[u].time, tot ? dt * nfr[u] / tot : 0.0);
+            print_utt(u, hyps[u].n > 0 ? hyps[u].n : 0, hyps[u].label, hyps[u].time, hyps[u].ac, hyps[u].lm,
+                      tot ? dt * nfr[u] / tot : 0.0);
         }
         jd_dec_destroy(dec);
     }
-    printf("\n\nTotal CPU time %.3f  Total speech time %.3f  Avg. RT factor %.3f\n", decodeTime, speechTime,
-           speechTime > 0 ? decodeTime / speechTime : 0.0);
+    fprintf(stderr, "\n\nTotal CPU time %.3f  Total speech time %.3f  Avg. RT factor %.3f\n", decodeTime, speechTime,
+            speechTime > 0 ? decodeTime / speechTime : 0.0);
     jd_am_destroy(am);
     jd_net_destroy(net);
     return 0;

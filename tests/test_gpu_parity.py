@@ -203,8 +203,9 @@ def test_histogram_ceiling_is_an_error(built):
 
 
 def test_batch_test_cli(small, tmp_path):
-    """DecoderBatchTest counterpart (C++ host over the C ABI): list file in, ref-format lines +
-    RT factor out; both the batched path and the frame-by-frame IDecoder adapter."""
+    """DecoderBatchTest counterpart (C++ host over the C ABI): list file in, the reference's output
+    formats out (DecoderBatchTest.cpp:339-430) + RT-factor log lines; batched path, MMF models and
+    the frame-by-frame IDecoder adapter."""
     import subprocess
     from juicer_amd import build as jbuild, io as jio, synth
     from oracle.oracle import OracleDecoder
@@ -213,6 +214,7 @@ def test_batch_test_cli(small, tmp_path):
     jio.write_fsm(tmp_path / "g.fsm", net)
     jio.write_jdam(tmp_path / "m.jdam", am)
     jio.write_mmf(tmp_path / "m.mmf", am)
+    (tmp_path / "out.syms").write_text("<eps> 0\n" + "".join("W%d %d\n" % (i, i) for i in range(1, net.n_words + 1)))
     lst = tmp_path / "list.txt"
     with open(lst, "w") as f:
         f.write("# comment line\n\n")
@@ -221,23 +223,49 @@ def test_batch_test_cli(small, tmp_path):
             f.write("%s\n" % (tmp_path / ("u%d.jdf" % u)))
     od = OracleDecoder(onet, oam, main_beam=150.0, max_hyps=200)
     want = [od.decode(x) for x in feats]
-    for extra in (["-modelsFName", str(tmp_path / "m.jdam")], ["-htkModelsFName", str(tmp_path / "m.mmf")],
-                  ["-htkModelsFName", str(tmp_path / "m.mmf"), "-perFrameAdapter"]):
+
+    def run(*extra):
         out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-inputFName", str(lst),
-                              "-mainBeam", "150", "-maxHyps", "200"] + extra, capture_output=True, text=True,
+                              "-mainBeam", "150", "-maxHyps", "200"] + list(extra), capture_output=True, text=True,
                              timeout=240)
         assert out.returncode == 0, out.stderr
-        lines = out.stdout.splitlines()
-        files = [i for i, l in enumerate(lines) if l.startswith("File: ")]
-        assert len(files) == len(feats)
-        for u, i in enumerate(files):
-            words = [int(w) for w in lines[i + 1].split()]
-            assert words == (want[u].label[::-1] - 1).tolist()
-            times = lines[i + 2].replace("[", "").replace("]", "").replace("(", "").replace(")", "").split()
-            assert [int(t) for t in times[:-1]] == (want[u].time[::-1] + 1).tolist()
-            assert int(times[-1]) == feats[u].shape[0]
-            assert lines[i + 3].startswith("CPU time ") and "RT factor" in lines[i + 3]
-        assert lines[-1].startswith("Total CPU time ")
+        assert out.stderr.count("RT factor") == len(feats) + 1 and out.stderr.count("File: ") == len(feats)
+        return out.stdout.splitlines()
+
+    # verbose: words (integers without a symbol table) + word-end frames, three front-ends
+    for extra in (["-modelsFName", str(tmp_path / "m.jdam")], ["-htkModelsFName", str(tmp_path / "m.mmf")],
+                  ["-htkModelsFName", str(tmp_path / "m.mmf"), "-perFrameAdapter"]):
+        lines = run("-outputFormat", "verbose", *extra)
+        assert len(lines) == 2 * len(feats)
+        for u in range(len(feats)):
+            assert lines[2 * u].endswith("u%d.jdf" % u)
+            body, times = lines[2 * u + 1].split("[")
+            assert [int(w) for w in body.replace("Actual :", "").split()] == (want[u].label[::-1] - 1).tolist()
+            t = times.replace("]", "").replace("(", "").replace(")", "").split()
+            assert [int(v) for v in t[:-1]] == (want[u].time[::-1] + 1).tolist() and int(t[-1]) == feats[u].shape[0]
+    mm = ["-htkModelsFName", str(tmp_path / "m.mmf"), "-outSymsFName", str(tmp_path / "out.syms")]
+    # ref / trans with word strings from the output symbol table
+    lines = run("-outputFormat", "ref", *mm)
+    for u in range(len(feats)):
+        assert lines[u].split() == ["W%d" % l for l in want[u].label[::-1]]
+    lines = run("-outputFormat", "trans", *mm)
+    assert all(lines[u].endswith("(trans-%d)" % want[u].n) for u in range(len(feats)))
+    # mlf / xmlf
+    lines = run("-outputFormat", "mlf", *mm)
+    assert lines[0] == "#!MLF!#" and lines[1] == '"*/u0.rec"' and lines.count(".") == len(feats)
+    lines = run("-outputFormat", "xmlf", *mm)
+    k = lines.index('"*/u1.rec"') + 1
+    w = want[1]
+    ends = w.time[::-1]
+    for j in range(w.n):
+        st, et, name, sc = lines[k + j].split()
+        s0 = 0 if j == 0 else int(ends[j - 1])
+        e0 = int(ends[j])                   # HTK units; the reference adds one frame only to non-zero times
+        assert int(st) == (0 if s0 == 0 else (s0 + 1) * 100000) and int(et) == (0 if e0 == 0 else (e0 + 1) * 100000)
+        assert name == "W%d" % w.label[::-1][j]
+        dac = w.ac[::-1][j] - (w.ac[::-1][j - 1] if j else 0.0)
+        dlm = w.lm[::-1][j] - (w.lm[::-1][j - 1] if j else 0.0)
+        assert abs(float(sc) - (dac + dlm)) <= 1e-3 * max(1.0, abs(dac + dlm))
 
 
 def test_path_garbage_collection(small):
