@@ -110,6 +110,7 @@ def main():
 
     if rank != 0:
         if world > 1:
+            dist.barrier(device_ids=[local_rank])      # rank 0 finishes its CPU baseline first
             dist.destroy_process_group()
         return
 
@@ -194,8 +195,9 @@ def main():
                                   % (net.n_arcs, G, M, D, U, args.beam, args.max_hyps),
                       "frames_per_step": int(frames_total), "utts_per_gpu": U, "parallelism": "utterance-sharded x%d" % world},
            "roofline": roofline, "cpu_baseline": cpu}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

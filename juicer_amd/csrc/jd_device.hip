@@ -1485,8 +1485,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     }
     C.trP = d->d_trP; C.se32 = d->d_se32;
     // default arena sizes: sized for 288 GB of HBM, not for frugality
-    d->cap_slots = std::min<int64_t>(net->n_arcs + 1024, 1 << 18);
-    d->cap_items = 1 << 18;
+    d->cap_slots = std::min<int64_t>(net->n_arcs + 1024, 1 << 19);   // 128-byte records, two lists
+    d->cap_items = std::min<int64_t>(std::max<int64_t>(net->n_arcs + 1024, 1 << 16), 1 << 21);   // frontier items / touched arcs
     d->cap_paths = 1 << 21;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&d->s_gmm, hipStreamNonBlocking)) != hipSuccess ||
@@ -1763,7 +1763,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
         {
             const int nsteps = std::min(Fc, maxT - c * Fc);
             for (int k = 0; k < nsteps; ++k) {
-                if ((c > 0 || k > 0) && (k % 32) == 0) launch_gc(d, nb, 0, d->s_search);   // no-op below the threshold
+                if ((c > 0 || k > 0) && (k % 8) == 0) launch_gc(d, nb, 0, d->s_search);    // no-op below the threshold
                 hipEvent_t *ev = nullptr;
                 if (((c * Fc + k) % KSAMPLE_EVERY) == KSAMPLE_EVERY / 2 && d->kev_used < KSAMPLE_MAX) {
                     if (d->kev.empty()) {
@@ -1905,7 +1905,7 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
         if (rc) return rc;
         launch_init(d, 1, s, st);                      // no-op unless the stream is flagged needs_init
         for (int k = 0; k < n; ++k) {
-            if ((k % 32) == 0) launch_gc(d, 1, s, st);
+            if ((k % 8) == 0) launch_gc(d, 1, s, st);
             launch_step(d, 1, s, d->d_ll[0], (long long)Fc * G, f0, st);
         }
         launch_close(d, 1, s, st);

@@ -100,3 +100,20 @@ def test_fullsize_gmm_tile_parity(c2):
     print("gmm mismatches %d of %d" % (diff.sum(), diff.size))
     assert diff.mean() <= 1e-5
     assert np.abs(g.view(np.int32).astype(np.int64) - o.view(np.int32).astype(np.int64)).max() <= 1
+
+
+def test_fullsize_wide_beam(c2):
+    """mainBeam 300 on the 1M-arc graph: ~180k live hypotheses per frame and stream (the default
+    arenas must hold them) - parity with the oracle on a short utterance."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    kw = dict(main_beam=300.0)
+    x = [f[:160] for f in c2["feats"][:3]]
+    gd = capi.Decoder(c2["gnet"], c2["gam"], max_streams=3, **kw)
+    gs = gd.decode_batch(x)
+    od = OracleDecoder(OracleNet(c2["net"]), OracleAM(c2["am"]), **kw)
+    o = od.decode(x[0])
+    print("beam 300: %.0f active emit hyps/frame, ties %d" % (o.stats["tot_active_emit_hyps"] / o.stats["n_frames"], o.stats["ties"]))
+    assert_hyp_matches(gs[0], o, "beam300", check_stats=(o.stats["ties"] == 0))
+    for k in ("n_frames", "tot_active_emit_hyps", "tot_proc_emit_hyps"):
+        assert gs[0].stats[k] == o.stats[k]
