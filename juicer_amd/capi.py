@@ -345,7 +345,7 @@ class Decoder:
         return out
 
     def debug_trace(self, frame: int, fetch: bool = False):
-        buf = np.zeros((3, 65536, 4), np.int64) if fetch else None
+        buf = np.zeros((4, 65536, 4), np.int64) if fetch else None
         _check(lib().jd_dec_debug_trace(self.h, C.c_int32(frame), None if buf is None else _p(buf, C.c_int64)))
         return buf
 

@@ -734,42 +734,42 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
 // monotonicity of float addition no other item can win anything downstream.
 // Block-level aggregation: Path records are allocated with one atomic per unit, first-touched
 // arcs are staged in LDS and appended to the stream's list with one atomic per unit.
-#define TBS_CAP 1536
-struct BlockStage { int n; int fb; int np; int pb; int buf[TBS_CAP]; };
+#define TBS_CAP 512                  // per-wave stage of first-touched arcs
+struct WaveStage { int n; int buf[TBS_CAP]; };
+struct BlockStage { int np; int pb; WaveStage w[KTB / 64]; };
+
+// wave-private: append the staged arcs to the stream's touched list (one atomic), no barriers
+__device__ __forceinline__ void stage_flush_wave(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &w)
+{
+    const int lane = lane_id();
+    const int n = w.n;
+    if (n == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&c.n_touched, n);
+    base = __shfl(base, 0);
+    for (int k = lane; k < n; k += 64) {
+        if (base + k < C.cap_items) S.touched[base + k] = w.buf[k]; else c.error = -42;
+    }
+    if (lane == 0) w.n = 0;
+}
 
 __device__ __forceinline__ void stage_touch(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st,
                                             bool touch, int tb)
 {
     const unsigned long long bt = __ballot(touch);
     if (!bt) return;
-    const int first = __ffsll((long long)bt) - 1;
-    int base = 0;
-    if (lane_id() == first) base = atomicAdd(&st.n, __popcll(bt));
-    base = __shfl(base, first);
-    if (touch) {
-        const int pos = base + rank_in(bt);
-        if (pos < TBS_CAP) st.buf[pos] = tb;
-        else {                                                         // stage full: straight to the list
-            const int gi = atomicAdd(&c.n_touched, 1);
-            if (gi < C.cap_items) S.touched[gi] = tb; else c.error = -42;
-        }
-    }
+    WaveStage &w = st.w[threadIdx.x >> 6];
+    const int base = w.n;                                              // wave-private: uniform read
+    if (touch) w.buf[base + rank_in(bt)] = tb;
+    const int nn = base + __popcll(bt);
+    if (lane_id() == 0) w.n = nn;
+    if (nn > TBS_CAP - 64) stage_flush_wave(C, c, S, w);               // keep room for the next 64
 }
 
-// all threads of the block; leaves the stage empty and synchronised
+// end of a unit: every wave flushes its own stage (no block barrier: waves never wait for each other)
 __device__ __forceinline__ void stage_flush_block(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st)
 {
-    __syncthreads();
-    const int n = st.n < TBS_CAP ? st.n : TBS_CAP;
-    if (threadIdx.x == 0) st.fb = n ? atomicAdd(&c.n_touched, n) : 0;
-    __syncthreads();
-    const int fb = st.fb;
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        if (fb + k < C.cap_items) S.touched[fb + k] = st.buf[k]; else c.error = -42;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { st.n = 0; st.np = 0; }
-    __syncthreads();
+    stage_flush_wave(C, c, S, st.w[threadIdx.x >> 6]);
 }
 
 // arc walk of one wave (GPW items, EG lanes each)
@@ -838,7 +838,7 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
                                             bool have, int ii, unsigned long long *sk_in_u,
                                             unsigned long long *sk_in_l, unsigned long long *sk_out,
                                             int *items_counter, int items_base, int &n_arcs, int &n_paths_made,
-                                            int &n_pend)
+                                            int &n_pend, long long *dbx = nullptr)
 {
     const int lane = lane_id();
     const int er = lane & (EG - 1), eb = lane & ~(EG - 1);
@@ -871,7 +871,10 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
         __syncthreads();
         p = labelled ? c.n_paths + path_base_extra + stage.pb + wb + rank_in(bl) : -1;
         p = __shfl(p, eb);
+        __syncthreads();
+        if (threadIdx.x == 0) stage.np = 0;
     }
+    if (dbx && t.score != 12345.0f) dbx[0] = wall_clock64();          // item loaded
     if (have) {
         const int state = (info.x >= 0) ? info.z : C.init_state;
         rs = C.row_ptr[state];                                         // issued before the winner is known
@@ -888,6 +891,7 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
             have = have && winner;
         }
     }
+    if (dbx && rs1 != -12345) dbx[1] = wall_clock64();                 // winner known, row bounds loaded
     int deg = 0;
     if (have) {
         if (info.x >= 0) {
@@ -916,7 +920,9 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
         }
         deg = rs1 - rs;
     }
+    if (dbx) dbx[2] = wall_clock64();                                  // path / final done
     expand_arcs(C, c, S, stage, t, ii, rs, deg, endTh, wordTh, sk_out, items_counter, items_base, n_arcs);
+    if (dbx) dbx[3] = wall_clock64();                                  // arcs walked
 }
 
 // frontier rounds 0 and 1, flattened over all streams.  ROUND 0 reads the live exit tokens
@@ -941,7 +947,8 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
     long long *dbp = C.dbg + ((size_t)65536 + blockIdx.x) * 4;
     if (dbg) { dbp[0] = t_start; dbp[1] = wall_clock64(); dbp[2] = 0; dbp[3] = (j0 >= units) ? -1 : 0; }
     if (j0 >= units) return;
-    if (tid == 0) { stage.n = 0; stage.np = 0; sh_acc[0] = sh_acc[1] = sh_acc[2] = 0; }
+    if (tid == 0) { stage.np = 0; sh_acc[0] = sh_acc[1] = sh_acc[2] = 0; }
+    if (lane == 0) stage.w[tid >> 6].n = 0;
     __syncthreads();
     for (int u = j0; u < units; u += BPS) {
         const float bestA = o2f(c.best);
@@ -957,7 +964,8 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
         expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, ROUND == 0 && !init, cnt0, endTh, wordTh,
                     ROUND == 0 && !init, k < nin, in_base + k,
                     S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], S.skey[(ROUND & 1) ^ 1],
-                    (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base, n_arcs, n_paths_made, n_pend);
+                    (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base, n_arcs, n_paths_made, n_pend,
+                    (dbg && u == j0) ? C.dbg + ((size_t)196608 + blockIdx.x) * 4 : nullptr);
         if (dbg) dbp[2] = wall_clock64();
         n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
         if (lane == 0) {
@@ -985,7 +993,8 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
     const StreamDev &S = streams[s0 + blockIdx.x];
     constexpr int PER = KT / EG;
     const int tid = threadIdx.x, lane = lane_id();
-    if (tid == 0) { stage.n = 0; stage.np = 0; }
+    if (tid == 0) stage.np = 0;
+    if (lane == 0) stage.w[tid >> 6].n = 0;
     __syncthreads();
     const float bestA = o2f(c.best);
     const bool init = c.active == 2;
@@ -1938,7 +1947,7 @@ extern "C" int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out)
 extern "C" int jd_dec_debug_trace(jd_dec *d, int32_t frame, int64_t *fetch)
 {
     if (!d) return jd_fail(JD_EINVAL, "jd_dec_debug_trace: null");
-    const size_t n = (size_t)3 * 65536 * 4;
+    const size_t n = (size_t)4 * 65536 * 4;
     if (!d->C.dbg) {
         long long *p = nullptr;
         HIPCHK(hipMalloc(&p, n * sizeof(long long)));

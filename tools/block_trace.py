@@ -41,3 +41,13 @@ if m.any():
     for name, d in (("record/token/ll loads + state update", t_c - t_setup), ("exit shuffles, ballots", t_b - t_c),
                     ("barrier + packed atomic + barrier", t_a - t_b), ("stores + (further units) ", t_end - t_a)):
         print("   phase A %-38s p50 %.2f p90 %.2f us" % (name, us(np.median(d)), us(np.percentile(d, 90))))
+
+# finer expansion stamps (thread 0's group, first unit of each block)
+a, f = buf[1], buf[3]
+m = (a[:, 3] > 0) & (f[:, 3] != 0)
+if m.any():
+    us = lambda x: x / 100.0
+    for name, d in (("item info/token load", f[m, 0] - a[m, 1]), ("winner check + row bounds", f[m, 1] - f[m, 0]),
+                    ("path record / final state", f[m, 2] - f[m, 1]), ("arc walk (thread 0's wave)", f[m, 3] - f[m, 2]),
+                    ("stage flush + stats", a[m, 3] - f[m, 3])):
+        print("   expand<0> %-30s p50 %.2f p90 %.2f max %.2f us" % (name, us(np.median(d)), us(np.percentile(d, 90)), us(d.max())))
