@@ -179,7 +179,11 @@ int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am,
                   int32_t max_hyps, int32_t block_size, int32_t device, int32_t max_streams);
 void jd_dec_destroy(jd_dec *d);
 
-/* Capacity knobs (call before first init; defaults sized from the network). */
+/* Per-stream arena capacities, in records (call before the first init; 0 keeps the default).
+ * Defaults are taken from the free HBM when the arenas are first allocated: half of it is split
+ * over max_streams, each stream's share going 50/20/30 to instance records (128 B, two lists),
+ * frontier items and Path records, never below 2^19 / 2^21 / 2^21 and never above what the
+ * graph can need (one instance per arc).  An overflow is reported as JD_ENOMEM naming the arena. */
 int jd_dec_set_capacity(jd_dec *d, int64_t max_slots, int64_t max_paths, int64_t max_items);
 
 /* IDecoder::init() (Decoder.h:26) for stream s. */

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 // whose work items are flattened over every stream (so the whole chip works on
 // every phase, and kernel boundaries are the phase barriers):
 //
-//   k_boundary   per stream: epilogue of frame f-1 (free list, bestFinal, stats)
+//   k_boundary   per stream: epilogue of frame f-1 (list swap, bestFinal, stats)
 //                + thresholds / histogram threshold of frame f         (:311-339)
 //   k_phase_a    HMM-internal propagation over all active arc instances
 //                (GS lanes per instance), ballot+scan compaction         (:376-484, :899-935)
@@ -214,7 +214,6 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 #define KT 256                       // threads per block of the small search kernels (tail)
 #define KTB 256                      // threads per block of the flattened kernels (phase A, expand, resolve)
 #define EG 16                        // lanes cooperating on one frontier item
-#define MAX_B 1024                   // max concurrent streams
 
 struct DecConst {
     // network (CSR in HBM)
@@ -252,9 +251,8 @@ struct __align__(16) ArcState { unsigned long long key; int slot; int pad; };
 // hot per-stream scalars.  Line 0 is read-mostly while the frame kernels run (written by
 // k_boundary); every atomically updated counter sits on its own 128-byte line so that the
 // L2 never serialises unrelated atomics (or readers of line 0) behind each other.
-#define PK_SHIFT1 21
-#define PK_SHIFT2 42
-#define PK_MASK 0x1fffffULL
+#define PK_SHIFT1 32
+#define PK_MASK 0xffffffffULL
 struct __align__(128) StreamCtl {
     // ---- line 0: persistent / per-frame constants
     int skipped_prev;   // instances whose creation was skipped last frame (still counted, see k_resolve)
@@ -268,7 +266,7 @@ struct __align__(128) StreamCtl {
     float normalise, emitTh, startTh;
     int pad0[17];
     // ---- one line per atomic counter
-    __align__(128) unsigned long long pkA;   // phase A: nB | cnt0 << 21 | ndead << 42
+    __align__(128) unsigned long long pkA;   // phase A: survivors (nB) | exit tokens (cnt0) << 32
     __align__(128) unsigned best;            // ordered-uint bestEmitScore of this frame
     __align__(128) int cnt1;                 // items produced by frontier round 0
     __align__(128) int cnt2;                 // items produced by frontier round 1
@@ -287,7 +285,6 @@ struct __align__(128) StreamCtl {
 };
 __device__ __forceinline__ int pk_nB(unsigned long long v) { return (int)(v & PK_MASK); }
 __device__ __forceinline__ int pk_cnt0(unsigned long long v) { return (int)((v >> PK_SHIFT1) & PK_MASK); }
-__device__ __forceinline__ int pk_ndead(unsigned long long v) { return (int)((v >> PK_SHIFT2) & PK_MASK); }
 
 struct StreamDev {      // per-stream arenas (cold)
     int *rec[2];                      // the active lists ARE the instance records (RecLayout): list lst is
@@ -328,59 +325,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh_w, int &total)
     return base + x - v;
 }
 
-// wave-aggregated append: returns this lane's index (or -1 when !want)
-__device__ __forceinline__ int wave_append(bool want, int *counter)
-{
-    const unsigned long long bal = __ballot(want);
-    if (!bal) return -1;
-    const int first = __ffsll((long long)bal) - 1;
-    int base = 0;
-    if (lane_id() == first) base = atomicAdd(counter, __popcll(bal));
-    base = __shfl(base, first);
-    return want ? base + rank_in(bal) : -1;
-}
-
 __device__ __forceinline__ int wave_sum(int v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
-}
-
-// Work-unit map: every kernel flattens "units" (fixed-size groups of work items)
-// over the streams.  sh_pre[s] = units of streams < s.  Returns total units.
-template <typename F>
-__device__ int build_unit_map(int B, int *sh_pre, int *sh_w, F units_of)
-{
-    const int E = (B + KT - 1) / KT;
-    int loc[(MAX_B + KT - 1) / KT];
-    int sum = 0;
-#pragma unroll
-    for (int e = 0; e < (MAX_B + KT - 1) / KT; ++e) {
-        const int s = threadIdx.x * E + e;
-        loc[e] = (e < E && s < B) ? units_of(s) : 0;
-        sum += loc[e];
-    }
-    int total;
-    int pre = block_excl_scan(sum, sh_w, total);
-#pragma unroll
-    for (int e = 0; e < (MAX_B + KT - 1) / KT; ++e) {
-        const int s = threadIdx.x * E + e;
-        if (e < E && s < B) { sh_pre[s] = pre; pre += loc[e]; }
-    }
-    if (threadIdx.x == 0) sh_pre[B] = total;
-    __syncthreads();
-    return total;
-}
-
-__device__ __forceinline__ int find_stream(const int *sh_pre, int B, int u)
-{
-    int lo = 0, hi = B;                 // sh_pre[lo] <= u < sh_pre[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (sh_pre[mid] <= u) lo = mid; else hi = mid;
-    }
-    return lo;
 }
 
 // ---- per-stream frame boundary: epilogue of the frame just processed + start of the next
@@ -437,7 +386,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
     // ---- epilogue of the frame processed in this step's predecessor kernels.  Every counter
     // lives on its own cache line: fetch them all first (independent loads in flight together).
     const int v_active = c.active, v_nalloc = c.n_alloc, v_nskip = c.n_skipped;
-    const int v_skprev = c.skipped_prev, v_lst = c.lst, v_frame = c.frame;
+    const int v_skprev = c.skipped_prev, v_lst = c.lst, v_frame = c.frame, v_nact = c.n_act;
     const int v_npaths = c.n_paths + pk_cnt0(c.pkA) + c.n_paths_extra;
     const int v_started = c.started, v_needs_init = c.needs_init, v_error = c.error, v_T = c.T;
     const unsigned long long v_pk = c.pkA, v_pe = c.pkE, v_fkey = c.final_key;
@@ -451,7 +400,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         frame_now = v_frame + 1;
         // per-frame statistics: lane k owns counter k
         if (lane == ST_MODELS) v_fr = pk_nB(v_pk) + v_nalloc + v_nskip;                     // :981
-        if (lane == ST_INSTS) v_fr = pk_nB(v_pk) + pk_ndead(v_pk) + v_skprev;               // skipped ones die "now"
+        if (lane == ST_INSTS) v_fr = v_nact + v_skprev;                                     // skipped ones die "now"
         if (lane == ST_END) v_fr = pk_cnt0(v_pk);
         if (lane == ST_PEMIT) v_fr = (int)(v_pe & 0xffffffffULL);
         if (lane == ST_EMIT) v_fr = (int)(v_pe >> 32);
@@ -530,8 +479,9 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
 
 // ---- phase A: doHMMInternalPropagation (:899-935) + HMMInternalPropagation (:376-484)
 // GS consecutive lanes own one arc instance; lane r updates emitting state r+1, lane GS-1
-// builds the exit token from its neighbours' results (intra-group shuffles).  Each block
-// walks a CONTIGUOUS range of units, so its work counters are flushed once per stream run.
+// builds the exit token from its neighbours' results (intra-group shuffles).  Blocks
+// [sl*BPS, (sl+1)*BPS) serve stream sl; each strides over that stream's active list, so its
+// work counters are flushed once per block.
 template <int GS>
 __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS,
                                                 const float *__restrict__ ll, long long ll_stride, int f0)
@@ -662,15 +612,14 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
         const bool live = valid && r == 0 && slot_live;
         const bool dead = valid && r == 0 && !slot_live;
         // block-level compaction: ONE packed returning atomic per unit
-        const unsigned long long bl = __ballot(live), be = __ballot(has_exit), bd = __ballot(dead);
+        const unsigned long long bl = __ballot(live), be = __ballot(has_exit);
         {
             unsigned mo = emit_live ? f2o(nw.score) : 0u;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_xor(mo, o); mo = y > mo ? y : mo; }
             const int c_pemit = __popcll(__ballot(pemit));
             if (lane == 0) {
-                sh_w3[wid] = (unsigned long long)__popcll(bl) | ((unsigned long long)__popcll(be) << PK_SHIFT1) |
-                             ((unsigned long long)__popcll(bd) << PK_SHIFT2);
+                sh_w3[wid] = (unsigned long long)__popcll(bl) | ((unsigned long long)__popcll(be) << PK_SHIFT1);
                 const unsigned long long pe = (unsigned long long)c_pemit | ((unsigned long long)__popcll(bemit) << 32);
                 if (pe) atomicAdd(&sh_pe, pe);
                 if (mo) atomicMax(&sh_bb, mo);
@@ -734,74 +683,160 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
 // monotonicity of float addition no other item can win anything downstream.
 // Block-level aggregation: Path records are allocated with one atomic per unit, first-touched
 // arcs are staged in LDS and appended to the stream's list with one atomic per unit.
-#define TBS_CAP 512                  // per-wave stage of first-touched arcs
-struct WaveStage { int n; int buf[TBS_CAP]; };
+#define TBS_CAP 256                  // per-wave stage of first-touched arcs
+#define ITS_CAP 64                   // per-wave stage of produced frontier items
+struct WaveStage { int buf[TBS_CAP]; Tok itok[ITS_CAP]; int4 iinfo[ITS_CAP]; };
 struct BlockStage { int np; int pb; WaveStage w[KTB / 64]; };
+// Fill levels of the calling wave's stage.  They live in REGISTERS, computed identically by
+// all 64 lanes from wave-uniform ballots: an LDS counter written by lane 0 and re-read by the
+// others is a data race in the per-thread memory model (the compiler may forward a lane's own
+// earlier load past another lane's store), and it measurably was one.
+struct WaveFill { int n; int ni; };
+// LDS traffic between lanes of ONE wave needs no hardware fence (a wave's LDS operations execute
+// in order); the compiler just must not move or forward memory accesses across this point.
+#define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
+// where the items produced by an expansion go: the next round's key array + the item counter
+struct ItemSink { unsigned long long *sk_out; int *counter; int base; };
 
-// wave-private: append the staged arcs to the stream's touched list (one atomic), no barriers
-__device__ __forceinline__ void stage_flush_wave(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &w)
+// The stages are wave-private (no barriers: waves never wait for each other) and are emptied
+// when full and at the end of the kernel, NOT per unit: with 10^5..10^6 frontier items per
+// stream-frame (wide beams) one same-address atomic per wave and unit would serialise the
+// whole kernel behind the stream's two counters (~20 ns each).
+__device__ __forceinline__ void stage_flush_touched(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &w,
+                                                    WaveFill &f)
 {
     const int lane = lane_id();
-    const int n = w.n;
+    const int n = f.n;
     if (n == 0) return;
+    WAVE_LDS_ORDER();
     int base = 0;
     if (lane == 0) base = atomicAdd(&c.n_touched, n);
     base = __shfl(base, 0);
     for (int k = lane; k < n; k += 64) {
         if (base + k < C.cap_items) S.touched[base + k] = w.buf[k]; else c.error = -42;
     }
-    if (lane == 0) w.n = 0;
+    WAVE_LDS_ORDER();
+    f.n = 0;
+}
+
+__device__ __forceinline__ void stage_flush_items(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &w,
+                                                  WaveFill &f, const ItemSink &sink)
+{
+    const int lane = lane_id();
+    const int n = f.ni;
+    if (n == 0) return;
+    WAVE_LDS_ORDER();
+    int base = 0;
+    if (lane == 0) base = atomicAdd(sink.counter, n);
+    base = __shfl(base, 0);
+    for (int k = lane; k < n; k += 64) {
+        const int pos = sink.base + base + k;
+        if (pos < C.cap_items) {
+            const Tok u = w.itok[k];
+            const int4 ui = w.iinfo[k];
+            S.item_tok[pos] = u; S.item_info[pos] = ui;
+            // bid for the destination state (state-level recombination of the next round)
+            atomicMax(sink.sk_out + ui.z, ((unsigned long long)f2o(u.score) << 32) | (unsigned)pos);
+        } else c.error = -42;
+    }
+    WAVE_LDS_ORDER();
+    f.ni = 0;
 }
 
 __device__ __forceinline__ void stage_touch(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st,
-                                            bool touch, int tb)
+                                            WaveFill &f, bool touch, int tb)
 {
     const unsigned long long bt = __ballot(touch);
     if (!bt) return;
     WaveStage &w = st.w[threadIdx.x >> 6];
-    const int base = w.n;                                              // wave-private: uniform read
-    if (touch) w.buf[base + rank_in(bt)] = tb;
-    const int nn = base + __popcll(bt);
-    if (lane_id() == 0) w.n = nn;
-    if (nn > TBS_CAP - 64) stage_flush_wave(C, c, S, w);               // keep room for the next 64
+    const int cnt = __popcll(bt);
+    if (f.n + cnt > TBS_CAP) stage_flush_touched(C, c, S, w, f);
+    if (touch) w.buf[f.n + rank_in(bt)] = tb;
+    f.n += cnt;
 }
 
-// end of a unit: every wave flushes its own stage (no block barrier: waves never wait for each other)
-__device__ __forceinline__ void stage_flush_block(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st)
+__device__ __forceinline__ void stage_item(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st,
+                                           WaveFill &f, const ItemSink &sink, bool mk, const Tok &u, const int4 &uinfo)
 {
-    stage_flush_wave(C, c, S, st.w[threadIdx.x >> 6]);
+    const unsigned long long bm = __ballot(mk);
+    if (!bm) return;
+    WaveStage &w = st.w[threadIdx.x >> 6];
+    const int cnt = __popcll(bm);
+    if (f.ni + cnt > ITS_CAP) stage_flush_items(C, c, S, w, f, sink);
+    if (mk) { const int k = f.ni + rank_in(bm); w.itok[k] = u; w.iinfo[k] = uinfo; }
+    f.ni += cnt;
 }
 
-// arc walk of one wave (GPW items, EG lanes each)
+// every wave empties its own stages
+__device__ __forceinline__ void stage_flush_block(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st,
+                                                  WaveFill &f, const ItemSink &sink)
+{
+    WaveStage &w = st.w[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const int n = f.n, ni = f.ni;
+    if ((n | ni) == 0) return;
+    WAVE_LDS_ORDER();
+    // both reservations in flight together: lane 0 the touched list, lane 1 the item list
+    int base = 0;
+    if (lane == 0 && n) base = atomicAdd(&c.n_touched, n);
+    if (lane == 1 && ni) base = atomicAdd(sink.counter, ni);
+    const int bt = __shfl(base, 0), bi = __shfl(base, 1);
+    for (int k = lane; k < n; k += 64) {
+        if (bt + k < C.cap_items) S.touched[bt + k] = w.buf[k]; else c.error = -42;
+    }
+    for (int k = lane; k < ni; k += 64) {
+        const int pos = sink.base + bi + k;
+        if (pos < C.cap_items) {
+            const Tok u = w.itok[k];
+            const int4 ui = w.iinfo[k];
+            S.item_tok[pos] = u; S.item_info[pos] = ui;
+            atomicMax(sink.sk_out + ui.z, ((unsigned long long)f2o(u.score) << 32) | (unsigned)pos);
+        } else c.error = -42;
+    }
+    WAVE_LDS_ORDER();
+    f.n = 0; f.ni = 0;
+}
+
+// arc walk of one wave.  The wave's 64/EG items pool their out-arcs: lane l takes arcs
+// l, l+64, ... of the concatenated arc ranges and fetches the owning item's token from that
+// item's lanes, so a state with thousands of out-arcs (trigram back-off / history states)
+// occupies the whole wave instead of one EG-lane group, and items with few arcs share a pass.
+// t / ii / rs / deg are uniform within an EG-lane group.
 __device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
-                                            const Tok &t, int ii, int rs, int deg, float endTh, float wordTh,
-                                            unsigned long long *sk_out, int *items_counter, int items_base,
-                                            int &n_arcs)
+                                            WaveFill &fill, const Tok &t, int ii, int rs, int deg, float endTh, float wordTh,
+                                            const ItemSink &sink, int &n_arcs)
 {
-    const int er = lane_id() & (EG - 1);
-    int maxdeg = deg;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(maxdeg, o); maxdeg = y > maxdeg ? y : maxdeg; }
-    for (int k0 = 0; k0 < maxdeg; k0 += EG) {
-        const int k = k0 + er;
+    static_assert(EG == 16, "expand_arcs pools the arcs of 4 items per wave");
+    const int lane = lane_id();
+    const int p1 = __shfl(deg, 0), p2 = p1 + __shfl(deg, EG), p3 = p2 + __shfl(deg, 2 * EG);
+    const int tot = p3 + __shfl(deg, 3 * EG);
+    for (int a0 = 0; a0 < tot; a0 += 64) {
+        const int a = a0 + lane;
+        const int g = (a >= p3) ? 3 : (a >= p2) ? 2 : (a >= p1) ? 1 : 0;
+        const int off = a - ((g == 3) ? p3 : (g == 2) ? p2 : (g == 1) ? p1 : 0);
+        const int srcl = g * EG;
+        Tok tg;
+        tg.score = __shfl(t.score, srcl); tg.ac = __shfl(t.ac, srcl);
+        tg.lm = __shfl(t.lm, srcl); tg.path = __shfl(t.path, srcl);
+        const int iig = __shfl(ii, srcl), rsg = __shfl(rs, srcl);
         bool mk = false, touch = false;
         Tok u = null_tok();
         int4 uinfo = make_int4(-1, 0, 0, 0);
         int tb = -1;
-        if (k < deg) {
-            const int b = rs + k;
+        if (a < tot) {
+            const int b = rsg + off;
             const JdArc Bk = C.arcs[b];
             ++n_arcs;
             const int inl = Bk.in & ~TEE_FLAG;
             if (inl == 0) {                                            // :533-540 epsilon input
-                u = t;
-                u.score = t.score + Bk.w;
-                u.lm = t.lm + Bk.w;
+                u = tg;
+                u.score = tg.score + Bk.w;
+                u.lm = tg.lm + Bk.w;
                 mk = u.score > endTh;
                 uinfo = make_int4(b, Bk.out, Bk.to, 0);
             } else {                                                   // :560-582 entry-token recombination
-                const float ns = t.score + Bk.w;
-                const unsigned long long key = ((unsigned long long)f2o(ns) << 32) | (unsigned)ii;
+                const float ns = tg.score + Bk.w;
+                const unsigned long long key = ((unsigned long long)f2o(ns) << 32) | (unsigned)iig;
                 const unsigned long long old = atomicMax(&S.ast[b].key, key);
                 touch = (old == 0ULL);
                 tb = b;
@@ -809,23 +844,16 @@ __device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, con
                     const float tee = C.hmm_tee[inl - 1];
                     const float ns2 = ns + tee;
                     u.score = ns2;
-                    u.ac = t.ac + tee;
-                    u.lm = t.lm + Bk.w;
-                    u.path = t.path;
+                    u.ac = tg.ac + tee;
+                    u.lm = tg.lm + Bk.w;
+                    u.path = tg.path;
                     mk = ns2 > ((Bk.out != 0) ? wordTh : endTh);
                     uinfo = make_int4(b, Bk.out, Bk.to, 0);
                 }
             }
         }
-        stage_touch(C, c, S, stage, touch, tb);
-        const int idx = wave_append(mk, items_counter);
-        if (mk) {
-            const int pos = items_base + idx;
-            if (pos < C.cap_items) {
-                S.item_tok[pos] = u; S.item_info[pos] = uinfo;
-                atomicMax(sk_out + uinfo.z, ((unsigned long long)f2o(u.score) << 32) | (unsigned)pos);
-            } else c.error = -42;
-        }
+        stage_touch(C, c, S, stage, fill, touch, tb);
+        stage_item(C, c, S, stage, fill, sink, mk, u, uinfo);
     }
 }
 
@@ -833,11 +861,11 @@ __device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, con
 //   sk_in_u / sk_in_l : per-state key arrays of this round (unlabelled / word-labelled class)
 //   check_th          : apply the end/word threshold of doHMMExternalPropagation (:952-962) (round 0)
 __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
-                                            int frame, bool last_frame, bool path_direct, int path_base_extra,
+                                            WaveFill &fill, int frame, bool last_frame, bool path_direct, int path_base_extra,
                                             float endTh, float wordTh, bool check_th,
                                             bool have, int ii, unsigned long long *sk_in_u,
-                                            unsigned long long *sk_in_l, unsigned long long *sk_out,
-                                            int *items_counter, int items_base, int &n_arcs, int &n_paths_made,
+                                            unsigned long long *sk_in_l, const ItemSink &sink,
+                                            int &n_arcs, int &n_paths_made,
                                             int &n_pend, long long *dbx = nullptr)
 {
     const int lane = lane_id();
@@ -921,7 +949,7 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
         deg = rs1 - rs;
     }
     if (dbx) dbx[2] = wall_clock64();                                  // path / final done
-    expand_arcs(C, c, S, stage, t, ii, rs, deg, endTh, wordTh, sk_out, items_counter, items_base, n_arcs);
+    expand_arcs(C, c, S, stage, fill, t, ii, rs, deg, endTh, wordTh, sink, n_arcs);
     if (dbx) dbx[3] = wall_clock64();                                  // arcs walked
 }
 
@@ -948,23 +976,30 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
     if (dbg) { dbp[0] = t_start; dbp[1] = wall_clock64(); dbp[2] = 0; dbp[3] = (j0 >= units) ? -1 : 0; }
     if (j0 >= units) return;
     if (tid == 0) { stage.np = 0; sh_acc[0] = sh_acc[1] = sh_acc[2] = 0; }
-    if (lane == 0) stage.w[tid >> 6].n = 0;
     __syncthreads();
+    WaveFill fill; fill.n = 0; fill.ni = 0;
+    // per-frame constants of the stream (nothing this kernel reads is written while it runs,
+    // except by the atomics it issues itself)
+    const float bestA = o2f(c.best);
+    const bool init = c.active == 2;
+    const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;      // :349
+    const float wordTh = (!init && C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;   // :350
+    const int cnt0 = pk_cnt0(c.pkA);
+    const int nin = (ROUND == 0) ? cnt0 : c.cnt1;
+    const int in_base = (ROUND == 0) ? 0 : cnt0;
+    const int frame = c.frame;
+    const bool last_frame = init || frame >= c.T - 1;
+    ItemSink sink;
+    sink.sk_out = S.skey[(ROUND & 1) ^ 1];
+    sink.counter = (ROUND == 0) ? &c.cnt1 : &c.cnt2;
+    sink.base = (ROUND == 0) ? cnt0 : cnt0 + c.cnt1;
     for (int u = j0; u < units; u += BPS) {
-        const float bestA = o2f(c.best);
-        const bool init = c.active == 2;
-        const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;      // :349
-        const float wordTh = (!init && C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;   // :350
-        const int cnt0 = pk_cnt0(c.pkA);
-        const int nin = (ROUND == 0) ? cnt0 : c.cnt1;
-        const int in_base = (ROUND == 0) ? 0 : cnt0;
-        const int out_base = (ROUND == 0) ? cnt0 : cnt0 + c.cnt1;
         const int k = u * PER + (tid / EG);
         int n_arcs = 0, n_paths_made = 0, n_pend = 0;
-        expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, ROUND == 0 && !init, cnt0, endTh, wordTh,
+        expand_unit(C, c, S, stage, fill, frame, last_frame, ROUND == 0 && !init, cnt0, endTh, wordTh,
                     ROUND == 0 && !init, k < nin, in_base + k,
-                    S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], S.skey[(ROUND & 1) ^ 1],
-                    (ROUND == 0) ? &c.cnt1 : &c.cnt2, out_base, n_arcs, n_paths_made, n_pend,
+                    S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], sink,
+                    n_arcs, n_paths_made, n_pend,
                     (dbg && u == j0) ? C.dbg + ((size_t)196608 + blockIdx.x) * 4 : nullptr);
         if (dbg) dbp[2] = wall_clock64();
         n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
@@ -973,8 +1008,8 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
             if (n_paths_made) atomicAdd(&sh_acc[1], n_paths_made);
             if (n_pend) atomicAdd(&sh_acc[2], n_pend);
         }
-        stage_flush_block(C, c, S, stage);
     }
+    stage_flush_block(C, c, S, stage, fill, sink);
     __syncthreads();
     if (tid == 0) {
         if (sh_acc[0]) atomicAdd(&c.fr[ST_ARCS], sh_acc[0]);
@@ -994,8 +1029,8 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
     constexpr int PER = KT / EG;
     const int tid = threadIdx.x, lane = lane_id();
     if (tid == 0) stage.np = 0;
-    if (lane == 0) stage.w[tid >> 6].n = 0;
     __syncthreads();
+    WaveFill fill; fill.n = 0; fill.ni = 0;
     const float bestA = o2f(c.best);
     const bool init = c.active == 2;
     const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;
@@ -1007,10 +1042,11 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
     while (r1 > r0) {
         for (int k0 = r0; k0 < r1; k0 += PER) {
             const int k = k0 + (tid / EG);
-            expand_unit(C, c, S, stage, c.frame, init || c.frame >= c.T - 1, false, pk_cnt0(c.pkA), endTh, wordTh, false,
-                        k < r1, base + k, S.skey[parity],
-                        S.skey[parity], S.skey[parity ^ 1], &c.cnt_tail, tail_base, n_arcs, n_paths_made, n_pend);
-            stage_flush_block(C, c, S, stage);
+            ItemSink sink;
+            sink.sk_out = S.skey[parity ^ 1]; sink.counter = &c.cnt_tail; sink.base = tail_base;
+            expand_unit(C, c, S, stage, fill, c.frame, init || c.frame >= c.T - 1, false, pk_cnt0(c.pkA), endTh, wordTh,
+                        false, k < r1, base + k, S.skey[parity], S.skey[parity], sink, n_arcs, n_paths_made, n_pend);
+            stage_flush_block(C, c, S, stage, fill, sink);
         }
         parity ^= 1;
         __syncthreads();
@@ -1493,10 +1529,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         C.aux = d->d_aux;
     }
     C.trP = d->d_trP; C.se32 = d->d_se32;
-    // default arena sizes: sized for 288 GB of HBM, not for frugality
-    d->cap_slots = std::min<int64_t>(net->n_arcs + 1024, 1 << 19);   // 128-byte records, two lists
-    d->cap_items = std::min<int64_t>(std::max<int64_t>(net->n_arcs + 1024, 1 << 16), 1 << 21);   // frontier items / touched arcs
-    d->cap_paths = 1 << 21;
+    // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
+    d->cap_slots = d->cap_items = d->cap_paths = 0;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&d->s_gmm, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&d->s_search, hipStreamNonBlocking)) != hipSuccess) {
@@ -1525,16 +1559,47 @@ extern "C" int jd_dec_set_capacity(jd_dec *d, int64_t max_slots, int64_t max_pat
     return JD_OK;
 }
 
+// reset a stream's per-arc search state: no candidate, no instance
+__global__ void jd_reset_ast_kernel(ArcState *ast, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ast[i] = ArcState{0ULL, -1, 0};
+}
+static void reset_ast(ArcState *ast, int64_t n_arcs)
+{
+    hipLaunchKernelGGL(jd_reset_ast_kernel, dim3((unsigned)((n_arcs + 255) / 256)), dim3(256), 0, 0, ast, (long long)n_arcs);
+}
+
 static int ensure_arenas(jd_dec *d)
 {
     if (d->arenas_ready) return JD_OK;
     int rc = check_device(d->device);
     if (rc) return rc;
     const int B = d->max_streams, MN = d->am->max_n;
+    {   // Capacities the caller did not set: sized for 288 GB of HBM, not for frugality.  Half of the
+        // free memory is split over the streams; of a stream's share (after its per-arc / per-state
+        // tables) 50% goes to instance records, 20% to frontier items, 30% to Path records - each
+        // between a floor that suits narrow beams and the most the graph can ever need.
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const double n_arcs = (double)d->net->n_arcs, n_states = (double)d->net->n_states;
+        const double fixed = n_arcs * sizeof(ArcState) + n_states * 24.0 + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
+        const double budget = std::max(0.0, 0.5 * (double)free_b / B - fixed);
+        const double rec_b = 2.0 * ((MN <= 5) ? 128 : 256), item_b = 4.0 + sizeof(Tok) + sizeof(int4);
+        const double path_b = 2.0 * sizeof(PathRec) + 4.0;
+        auto pick = [](double share, int64_t lo, int64_t hi) {
+            return std::max<int64_t>(std::min<int64_t>(hi, (int64_t)share), std::min(lo, hi));
+        };
+        if (d->cap_slots <= 0) d->cap_slots = pick(0.5 * budget / rec_b, 1 << 19, d->net->n_arcs + 1024);
+        if (d->cap_items <= 0) d->cap_items = pick(0.2 * budget / item_b, 1 << 21, std::max<int64_t>(2 * d->net->n_arcs + 1024, 1 << 16));
+        if (d->cap_paths <= 0) d->cap_paths = pick(0.3 * budget / path_b, 1 << 21, 1 << 26);
+        const int64_t lim = 0x7fffff00;
+        if (d->cap_slots > lim || d->cap_items > lim || d->cap_paths > lim)
+            return jd_fail(JD_EINVAL, "arena capacity above 2^31 records");
+    }
     d->C.cap_slots = (int)d->cap_slots; d->C.cap_items = (int)d->cap_items; d->C.cap_paths = (int)d->cap_paths;
     d->C.gc_threshold = (int)(d->cap_paths / 2);
     d->h_streams.assign((size_t)B, StreamDev());
-    std::vector<ArcState> ast0((size_t)d->net->n_arcs, ArcState{0ULL, -1, 0});
     for (int s = 0; s < B; ++s) {
         StreamDev &S = d->h_streams[(size_t)s];
         memset(&S, 0, sizeof S);
@@ -1551,7 +1616,8 @@ static int ensure_arenas(jd_dec *d)
         A(S.res_score, d->res_cap); A(S.res_ac, d->res_cap); A(S.res_lm, d->res_cap);
 #undef A
         S.res_cap = d->res_cap;
-        HIPCHK(hipMemcpy(S.ast, ast0.data(), (size_t)d->net->n_arcs * sizeof(ArcState), hipMemcpyHostToDevice));
+        reset_ast(S.ast, d->net->n_arcs);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.skeyL, 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
@@ -1613,10 +1679,8 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
             }
         }
         if (K.error) {      // arenas may be inconsistent after an abort: wipe them for the next init
-            {
-                std::vector<ArcState> ast0((size_t)d->net->n_arcs, ArcState{0ULL, -1, 0});
-                HIPCHK(hipMemcpy(S.ast, ast0.data(), ast0.size() * sizeof(ArcState), hipMemcpyHostToDevice));
-            }
+            reset_ast(S.ast, d->net->n_arcs);
+            HIPCHK(hipDeviceSynchronize());
             HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
             HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
             HIPCHK(hipMemset(S.skeyL, 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
@@ -1659,18 +1723,23 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
 
 #define KSAMPLE_EVERY 16
 #define KSAMPLE_MAX 96
-#define BPS_A 224      // blocks per stream: phase A (64 instances per unit; blocks loop beyond 14k instances)
+// blocks per stream of the flattened kernels.  The base values suit a full batch (64 streams);
+// with few streams each one gets more blocks so that a launch still covers the chip
+// (256 CUs x 8 resident blocks).  Blocks beyond a stream's work return at once.
+#define BPS_A 224      // phase A (64 instances per unit; blocks loop beyond 14k instances)
 #define BPS_X 64       // frontier rounds (16 items per unit)
 #define BPS_R 64       // resolve (256 touched arcs per unit)
+static inline int bps_for(int base, int nb) { return std::max(base, (2048 + nb - 1) / nb); }
 
 // recognitionStart for every stream of [s0, s0+nb) that is flagged needs_init
 static void launch_init(jd_dec *d, int nb, int s0, hipStream_t st)
 {
+    const int bx = bps_for(BPS_X, nb), br = bps_for(BPS_R, nb);
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 1);
-    hipLaunchKernelGGL(k_expand<0>, dim3(nb * BPS_X), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_X);
-    hipLaunchKernelGGL(k_expand<1>, dim3(nb * BPS_X), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_X);
+    hipLaunchKernelGGL(k_expand<0>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
+    hipLaunchKernelGGL(k_expand<1>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
     hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
-    hipLaunchKernelGGL(k_resolve, dim3(nb * BPS_R), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_R);
+    hipLaunchKernelGGL(k_resolve, dim3(nb * br), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, br);
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 2);
 }
 
@@ -1679,23 +1748,24 @@ static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll
                         hipEvent_t *ev = nullptr)
 {
 #define EV(i) do { if (ev) (void)hipEventRecord(ev[i], st); } while (0)
+    const int ba = bps_for(BPS_A, nb), bx = bps_for(BPS_X, nb), br = bps_for(BPS_R, nb);
     EV(0);
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 0);
     EV(1);
     if (d->am->max_n <= 5)
-        hipLaunchKernelGGL(k_phase_a<4>, dim3(nb * BPS_A), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_A, ll,
+        hipLaunchKernelGGL(k_phase_a<4>, dim3(nb * ba), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, ba, ll,
                            ll_stride, f0);
     else
-        hipLaunchKernelGGL(k_phase_a<8>, dim3(nb * BPS_A), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_A, ll,
+        hipLaunchKernelGGL(k_phase_a<8>, dim3(nb * ba), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, ba, ll,
                            ll_stride, f0);
     EV(2);
-    hipLaunchKernelGGL(k_expand<0>, dim3(nb * BPS_X), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_X);
+    hipLaunchKernelGGL(k_expand<0>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
     EV(3);
-    hipLaunchKernelGGL(k_expand<1>, dim3(nb * BPS_X), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_X);
+    hipLaunchKernelGGL(k_expand<1>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
     EV(4);
     hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
     EV(5);
-    hipLaunchKernelGGL(k_resolve, dim3(nb * BPS_R), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, BPS_R);
+    hipLaunchKernelGGL(k_resolve, dim3(nb * br), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, br);
     EV(6);
 #undef EV
 }

@@ -59,6 +59,12 @@ class SynthNet:
     prons: List[np.ndarray] = field(default_factory=list)   # per word: 0-based hmm ids
     succ: Optional[np.ndarray] = None                       # int32 [n_words+1, K] bigram successors
     sp_hmm: int = -1
+    # trigram-shaped graphs (make_wfst_trigram): per history state the successor words and the
+    # history state each one leads to, CSR by history state; back-off target of each history state
+    walk_off: Optional[np.ndarray] = None                   # int64 [n_hist+1]
+    walk_word: Optional[np.ndarray] = None                  # int32
+    walk_dst: Optional[np.ndarray] = None                   # int32
+    walk_backoff: Optional[np.ndarray] = None               # int32 [n_hist] (-1: the unigram hub)
 
     @property
     def n_arcs(self) -> int:
@@ -304,6 +310,181 @@ def sample_utterance(seed: int, net: SynthNet, am: SynthAM, n_words: int,
     return x, np.asarray(words, dtype=np.int32) + 1
 
 
+def _hub_tree(rng, hub, nxt, prons, uni, eps_word_frac):
+    """Lexicon prefix tree below state `hub` with tropical weight pushing (the back-off /
+    unigram state of det(L.G)).  Returns (src, dst, il, ol, w, next free state)."""
+    V = len(prons)
+    src, dst, il, ol, wf = [], [], [], [], []
+    children, node_words, node_min, kids = {}, {hub: []}, {}, {}
+    for w in range(V):
+        nd = hub
+        for hm in prons[w][:-1]:
+            key = (nd, int(hm))
+            if key not in children:
+                children[key] = nxt; node_words[nxt] = []; nxt += 1
+            nd = children[key]
+        node_words[nd].append(w)
+    for (nd, hm), ch in children.items():
+        kids.setdefault(nd, []).append((hm, ch))
+    order = [hub]                      # parents before children; costs bottom-up without recursion
+    for nd in order:
+        order.extend(ch for _, ch in sorted(kids.get(nd, [])))
+    for nd in reversed(order):
+        node_min[nd] = min([float(uni[w]) for w in node_words[nd]] + [node_min[ch] for _, ch in kids.get(nd, [])])
+    eps_w = rng.random(size=V) < eps_word_frac
+    for nd in order:
+        base = node_min[nd]
+        for hm, ch in sorted(kids.get(nd, [])):
+            src.append(nd); dst.append(ch); il.append(hm + 1); ol.append(0); wf.append(node_min[ch] - base)
+        for w in node_words[nd]:
+            cur, cost = nd, float(uni[w]) - base
+            if eps_w[w]:
+                src.append(cur); dst.append(nxt); il.append(0); ol.append(w + 1); wf.append(cost)
+                cur = nxt; nxt += 1; cost = 0.0
+            src.append(cur); dst.append(1 + w); il.append(int(prons[w][-1]) + 1)
+            ol.append(0 if eps_w[w] else w + 1); wf.append(cost)
+    return (np.asarray(src, dtype=np.int32), np.asarray(dst, dtype=np.int32), np.asarray(il, dtype=np.int32),
+            np.asarray(ol, dtype=np.int32), np.asarray(wf, dtype=np.float32), nxt)
+
+
+def make_wfst_trigram(seed: int, am: SynthAM, n_words: int, n_tri_hist: int, k2_mean: float,
+                      k3_mean: float, big_frac: float = 0.01, big_range=(1000, 10000),
+                      pron_len=(2, 5), n_phones: int = 40, eps_word_frac: float = 0.02) -> SynthNet:
+    """Trigram-shaped C.L.G (BASELINE.json configs[3]), generated with numpy only so that
+    tens of millions of arcs take seconds.
+
+    States: 0 = <s> history (initial); 1..V = one-word histories; V+1 = unigram hub (lexicon
+    prefix tree); V+2 .. V+1+H = two-word histories (u,v).  All history states are final.
+    Every (history, successor word) pair owns an un-shared chain of phone arcs that ends in
+    the two-word history (v,w) if the graph has it, else in the one-word history (w).
+    Two-word histories back off (epsilon) to their one-word history, one-word histories to the
+    hub.  A fraction big_frac of the one-word histories has 10^3..10^4 successors (the
+    heavy-tailed out-degree the config asks for); the others are geometric around the mean.
+    """
+    rng = np.random.default_rng(seed)
+    V = n_words
+    n_real_hmm = am.n_hmm - (1 if am.sp_hmm >= 0 else 0)
+    P = min(n_phones, max(2, n_real_hmm // 2))
+    plen = rng.integers(pron_len[0], pron_len[1] + 1, size=V).astype(np.int64)
+    poff = np.zeros(V + 1, dtype=np.int64); poff[1:] = np.cumsum(plen)
+    ph = rng.integers(0, P, size=int(poff[-1]))
+    kk = np.arange(int(poff[-1]), dtype=np.int64) - np.repeat(poff[:-1], plen)      # position in word
+    prev = np.concatenate([[0], ph[:-1]])
+    pflat = np.where(kk == 0, ph, P + (prev * 7919 + ph * 104729 + kk * 31) % (n_real_hmm - P)).astype(np.int32)
+    prons = [pflat[poff[w]:poff[w + 1]] for w in range(V)]
+    hub = V + 1
+
+    # ---- one-word histories (and <s>): successor sets
+    k2 = 1 + rng.geometric(1.0 / max(1.0, k2_mean - 1.0), size=V + 1)
+    big = rng.random(size=V + 1) < big_frac
+    k2[big] = rng.integers(big_range[0], big_range[1] + 1, size=int(big.sum()))
+    k2 = np.minimum(k2, V)
+    h2 = np.repeat(np.arange(V + 1, dtype=np.int64), k2)
+    key2 = np.unique(h2 * V + rng.integers(0, V, size=h2.shape[0]))                 # (history, word), deduplicated
+    h2, w2 = key2 // V, key2 % V
+    # ---- two-word histories: a random subset of the (v, w) pairs seen above (v a real word)
+    cand = key2[h2 > 0]
+    H = min(n_tri_hist, cand.shape[0])
+    tri_key = np.sort(rng.choice(cand, size=H, replace=False))                      # (1+v)*V + w
+    tri_v, tri_w = tri_key // V - 1, tri_key % V
+    tri_state = (V + 2 + np.arange(H)).astype(np.int64)
+    k3 = np.minimum(1 + rng.geometric(1.0 / max(1.0, k3_mean - 1.0), size=H), V)
+    i3 = np.repeat(np.arange(H, dtype=np.int64), k3)
+    key3 = np.unique(i3 * V + rng.integers(0, V, size=i3.shape[0]))
+    i3, w3 = key3 // V, key3 % V
+
+    # ---- all (history state, last word of the history, successor word) triples
+    t_h = np.concatenate([h2, tri_state[i3]])
+    t_last = np.concatenate([h2 - 1, tri_w[i3]])                                    # -1 for <s>
+    t_w = np.concatenate([w2, w3])
+    q = (t_last + 1) * V + t_w
+    pos_c = np.minimum(np.searchsorted(tri_key, q), H - 1)
+    hit = (t_last >= 0) & (tri_key[pos_c] == q)
+    t_dst = np.where(hit, tri_state[pos_c], 1 + t_w)
+    nT = t_h.shape[0]
+    t_cost = rng.uniform(0.5, 8.0, size=nT).astype(np.float32)
+    t_first = rng.random(size=nT) < 0.5                                             # word label on first / last arc
+    # ---- expand the triples into phone-arc chains
+    L = plen[t_w]
+    aoff = np.zeros(nT + 1, dtype=np.int64); aoff[1:] = np.cumsum(L)
+    nA = int(aoff[-1])
+    n_hist = V + 2 + H
+    ibase = n_hist + (aoff[:-1] - np.arange(nT))                                    # first interior state of a chain
+    trip = np.repeat(np.arange(nT, dtype=np.int64), L)
+    k = np.arange(nA, dtype=np.int64) - aoff[trip]
+    last = k == (L[trip] - 1)
+    c_src = np.where(k == 0, t_h[trip], ibase[trip] + k - 1).astype(np.int32)
+    c_dst = np.where(last, t_dst[trip], ibase[trip] + k).astype(np.int32)
+    c_il = (pflat[poff[t_w[trip]] + k] + 1).astype(np.int32)
+    c_ol = np.where((t_first[trip] & (k == 0)) | (~t_first[trip] & last), t_w[trip] + 1, 0).astype(np.int32)
+    c_w = np.where(k == 0, t_cost[trip], np.float32(0.0)).astype(np.float32)
+    del trip, k, last
+    nxt = n_hist + (nA - nT)
+    # ---- back-off arcs (stable sort below puts them after the history state's word chains)
+    b_src = np.concatenate([np.arange(0, V + 1), tri_state]).astype(np.int32)
+    b_dst = np.concatenate([np.full(V + 1, hub), 1 + tri_v]).astype(np.int32)
+    b_w = rng.uniform(1.0, 4.0, size=b_src.shape[0]).astype(np.float32)
+    uni = rng.uniform(4.0, 12.0, size=V)
+    u_src, u_dst, u_il, u_ol, u_w, nxt = _hub_tree(rng, hub, nxt, prons, uni, eps_word_frac)
+
+    src = np.concatenate([c_src, b_src, u_src]); dst = np.concatenate([c_dst, b_dst, u_dst])
+    il = np.concatenate([c_il, np.zeros_like(b_src), u_il]); ol = np.concatenate([c_ol, np.zeros_like(b_src), u_ol])
+    wf = np.concatenate([c_w, b_w, u_w])
+    del c_src, c_dst, c_il, c_ol, c_w
+    order = np.argsort(src, kind="stable")
+    fstate = np.concatenate([np.arange(1, V + 1), tri_state]).astype(np.int32)
+    fweight = rng.uniform(0.0, 2.0, size=fstate.shape[0]).astype(np.float32)
+    # walk tables for sample_utterance_walk (the triples are sorted by history state id)
+    walk_off = np.zeros(n_hist + 1, dtype=np.int64)
+    np.add.at(walk_off, t_h + 1, 1)
+    walk_off = np.cumsum(walk_off)
+    walk_backoff = np.full(n_hist, -1, dtype=np.int32)
+    walk_backoff[tri_state] = 1 + tri_v
+    return SynthNet(n_states=int(nxt), src=src[order], dst=dst[order], ilab=il[order], olab=ol[order],
+                    w_file=wf[order], fstate=fstate, fweight_file=fweight, n_words=V, prons=prons,
+                    succ=None, sp_hmm=-1, walk_off=walk_off, walk_word=t_w.astype(np.int32),
+                    walk_dst=t_dst.astype(np.int32), walk_backoff=walk_backoff)
+
+
+def sample_utterance_walk(seed: int, net: SynthNet, am: SynthAM, n_words: int,
+                          p_backoff: float = 0.2, noise: float = 1.0):
+    """sample_utterance for make_wfst_trigram graphs: a random accepted word sequence that
+    follows explicit n-gram arcs, backing off one level with probability p_backoff."""
+    rng = np.random.default_rng(seed)
+    words, gmm_seq = [], []
+    h = 0
+    for _ in range(n_words):
+        while True:
+            lo, hi = int(net.walk_off[h]), int(net.walk_off[h + 1])
+            if hi > lo and rng.random() >= p_backoff:
+                j = int(rng.integers(lo, hi))
+                w, h = int(net.walk_word[j]), int(net.walk_dst[j])
+                break
+            b = int(net.walk_backoff[h])
+            if b < 0:                                   # the unigram hub: any word
+                w = int(rng.integers(0, net.n_words)); h = 1 + w
+                break
+            h = b
+        words.append(w)
+        for hm in net.prons[w]:
+            n = int(am.hmm_nstates[hm]); tm = am.transp[am.hmm_tm[hm]]
+            s = 0
+            while True:
+                p = tm[s, :n].astype(np.float64)
+                s2 = int(rng.choice(n, p=p / p.sum()))
+                if s2 == n - 1:
+                    break
+                gmm_seq.append(int(am.hmm_gmm[hm, s2]))
+                s = s2
+    g = np.asarray(gmm_seq, dtype=np.int64)
+    cw = np.cumsum(am.weight[g].astype(np.float64), axis=1)
+    u = rng.random(size=(g.shape[0], 1)) * cw[:, -1:]
+    m = np.minimum((u > cw).sum(axis=1), am.max_mix - 1)
+    mu = am.mean[g, m]
+    x = (mu + noise * np.sqrt(am.var[g, m]) * rng.normal(size=mu.shape)).astype(np.float32)
+    return x, np.asarray(words, dtype=np.int32) + 1
+
+
 # ------------------------------------------------------------------ named configs
 
 def config_toy(seed: int = 1):
@@ -345,5 +526,20 @@ def config_c2(seed: int = 0, n_utts: int = 64, target_arcs: int = 1_000_000, n_g
     for u in range(utt_offset, utt_offset + n_utts):
         rng = np.random.default_rng(seed + 300 + u)
         x, w = sample_utterance(seed + 1000 + u, net, am, int(rng.integers(utt_words[0], utt_words[1] + 1)))
+        feats.append(x); words.append(w)
+    return am, net, feats, words
+
+
+def config_c4(seed: int = 0, n_utts: int = 8, n_words: int = 20000, n_tri_hist: int = 400_000,
+              k2_mean: float = 110.0, k3_mean: float = 26.0, n_gmm: int = 5000, n_hmm: int = 12000,
+              n_mix: int = 16, sep: float = 1.0, utt_words=(9, 28), utt_offset: int = 0):
+    """BASELINE.json configs[3]: ~50M-arc trigram-shaped graph, 5k tied states x 16 mix.
+    Smaller n_words / n_tri_hist / k*_mean give the same shape at test sizes."""
+    am = make_models(seed, n_gmm=n_gmm, n_hmm=n_hmm, n_mix=n_mix, n_tm=48, sep=sep)
+    net = make_wfst_trigram(seed + 100, am, n_words, n_tri_hist, k2_mean, k3_mean)
+    feats, words = [], []
+    for u in range(utt_offset, utt_offset + n_utts):
+        rng = np.random.default_rng(seed + 300 + u)
+        x, w = sample_utterance_walk(seed + 1000 + u, net, am, int(rng.integers(utt_words[0], utt_words[1] + 1)))
         feats.append(x); words.append(w)
     return am, net, feats, words
