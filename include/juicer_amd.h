@@ -79,6 +79,17 @@ int jd_net_create_csr(jd_net **out, int32_t n_states, int32_t init_state,
 int jd_net_load_fsm(jd_net **out, const char *fsm_path, const char *insyms_path,
                     const char *outsyms_path, float lm_scale, float ins_penalty);
 
+/* Juicer's binary network cache "<fsm>.bin" (JWNT), which juicer.cpp:854-866 prefers over the
+ * text FSM when it exists: WFSTNetwork(lmScale, insPenalty) + readBinary (WFSTNetwork.cpp:333-359,
+ * 1228-1365).  Arc weights are stored without scale and penalty and get `w *= lm_scale`, then
+ * `+= ins_penalty` on arcs with an output label; final-state weights are used as stored.
+ * Embedded alphabets are skipped (auxiliary '#' symbols are an error, as for the text loader). */
+int jd_net_load_jwnt(jd_net **out, const char *path, float lm_scale, float ins_penalty);
+/* WFSTNetwork::writeBinary (WFSTNetwork.cpp:1106-1225, juicer.cpp:879-882 -writeBinaryFiles):
+ * takes the penalty and the scale the network was built with off the arc weights again;
+ * no alphabets are written. */
+int jd_net_save_jwnt(const jd_net *n, const char *path);
+
 /* Read back the prepared CSR (host copies; any pointer may be NULL) - used by parity tests.
  * fin_w has n_states entries, +inf for non-final states. */
 int jd_net_get_csr(const jd_net *n, int32_t *row_ptr, int32_t *to, float *w, int32_t *in, int32_t *outl,
@@ -117,6 +128,13 @@ int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t max_mix,
  * ~o, ~v (ignored), ~s, ~t, ~h with shared or inline states / <TRANSP>, <NUMMIXES>/<MIXTURE>
  * or the implicit single mixture, optional <GCONST>.  HMM index = order of the ~h macros. */
 int jd_am_load_mmf(jd_am **out, const char *mmf_path);
+
+/* Juicer's binary model cache "<mmf>.bin" (JMBI), preferred by juicer.cpp:778-784:
+ * HTKModels::readBinary (HTKModels.cpp:1110-1233) + HTKFlatModels::init.  The derived values in
+ * the file (sumLogVarPlusNObsLog2Pi, logCompWeights, transition logProbs) are used as stored. */
+int jd_am_load_jmbi(jd_am **out, const char *path);
+/* HTKModels::output(fName, true) (HTKModels.cpp:1044-1105, juicer.cpp:791-795). */
+int jd_am_save_jmbi(const jd_am *a, const char *path);
 
 int32_t jd_am_num_hmms(const jd_am *a);       /* IModels::getNumHMMs       (Models.h:57) */
 int32_t jd_am_num_gmms(const jd_am *a);

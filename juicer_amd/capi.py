@@ -69,7 +69,8 @@ class Hyp:
 # every symbol include/juicer_amd.h declares
 EXPORTS = [
     "jd_net_create_arcs", "jd_net_create_csr", "jd_net_load_fsm", "jd_net_num_arcs", "jd_net_num_states",
-    "jd_net_init_state", "jd_net_destroy", "jd_net_get_csr", "jd_am_create_htk", "jd_am_num_hmms", "jd_am_num_gmms",
+    "jd_net_init_state", "jd_net_destroy", "jd_net_get_csr", "jd_net_load_jwnt", "jd_net_save_jwnt",
+    "jd_am_load_jmbi", "jd_am_save_jmbi", "jd_am_create_htk", "jd_am_num_hmms", "jd_am_num_gmms",
     "jd_am_vec_size", "jd_am_max_states", "jd_am_max_mix", "jd_am_num_transmats", "jd_am_get_topology", "jd_am_load_mmf", "jd_am_get_flat", "jd_am_get_trans", "jd_am_destroy",
     "jd_dec_create", "jd_dec_destroy", "jd_dec_set_capacity", "jd_stream_init", "jd_stream_push",
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
@@ -171,6 +172,17 @@ class Network:
                                  C.c_float(lm_scale), C.c_float(ins_penalty)))
         return cls(h)
 
+    @classmethod
+    def from_jwnt_file(cls, path, lm_scale=1.0, ins_penalty=0.0):
+        """Juicer's binary network cache (<fsm>.bin, WFSTNetwork::readBinary)."""
+        h = C.c_void_p()
+        _check(lib().jd_net_load_jwnt(C.byref(h), os.fsencode(path), C.c_float(lm_scale), C.c_float(ins_penalty)))
+        return cls(h)
+
+    def save_jwnt(self, path):
+        """WFSTNetwork::writeBinary counterpart (-writeBinaryFiles)."""
+        _check(lib().jd_net_save_jwnt(self.h, os.fsencode(path)))
+
     def csr(self):
         ns, na = self.n_states, self.n_arcs
         rp = np.zeros(ns + 1, np.int32); to = np.zeros(na, np.int32); w = np.zeros(na, np.float32)
@@ -222,6 +234,17 @@ class Models:
         h = C.c_void_p()
         _check(L.jd_am_load_mmf(C.byref(h), os.fsencode(path)))
         return cls(h)
+
+    @classmethod
+    def from_jmbi_file(cls, path):
+        """Juicer's binary model cache (<mmf>.bin, HTKModels::readBinary)."""
+        h = C.c_void_p()
+        _check(lib().jd_am_load_jmbi(C.byref(h), os.fsencode(path)))
+        return cls(h)
+
+    def save_jmbi(self, path):
+        """HTKModels::output(path, true) counterpart (-writeBinaryFiles)."""
+        _check(lib().jd_am_save_jmbi(self.h, os.fsencode(path)))
 
     @property
     def n_hmms(self):

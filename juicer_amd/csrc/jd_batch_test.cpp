@@ -5,11 +5,15 @@
 //   DecoderBatchTest::outputResult    ref / trans / mlf / xmlf / verbose formats           (:339-430)
 //   DecoderSingleTest::extractResultsFromHypWordMode  label-1, start/end frames       (DecoderSingleTest.cpp:403-468)
 //
-// Tracter (feature files) and Torch3 (CmdLine, vocabulary files) are not in the tree, so this
-// harness reads the build's own containers:
-//   .jdam  int32 magic 'JDAM', D,n_gmm,max_mix,n_hmm,max_n,n_tm, then the jd_am_create_htk arrays
-//   .jdf   int32 T, int32 D, then T*D float32 (one utterance)
-// and prints integer word ids (outLabel-1), which is what vocab->words[] is indexed by.
+// Networks / models: the text FSM and HTK MMF, or - preferred when present, like
+// juicer.cpp:854-866 / :778-784 - Juicer's binary caches "<fsm>.bin" (JWNT) / "<mmf>.bin" (JMBI);
+// -writeBinaryFiles writes them after a text load (juicer.cpp:879-882, :791-795).
+// Feature files: uncompressed HTK parameter files (12-byte big-endian header + big-endian
+// float32 vectors; Tracter's HTKSource is not in the tree, the format is HTK's published one) or
+// the build's own .jdf container (int32 T, int32 D, then T*D float32).  Models can also come
+// from a .jdam dump (int32 magic 'JDAM', D,n_gmm,max_mix,n_hmm,max_n,n_tm + the jd_am_create_htk
+// arrays).  Words are printed through the output symbol table when given, else as integer ids
+// (outLabel-1, what vocab->words[] is indexed by).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -48,11 +52,53 @@ static jd_am *load_jdam(const char *path)
     return am;
 }
 
+static bool file_exists(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != 0; }
+
+// One utterance: .jdf, or an HTK parameter file (big-endian: int32 nSamples, int32 sampPeriod,
+// int16 sampSize, int16 parmKind; _C compressed files are not supported, a _K checksum is ignored).
+static bool load_features(const char *path, int D, std::vector<float> &x, int32_t &T)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "jd_batch_test: cannot open %s\n", path); return false; }
+    unsigned char h[12];
+    if (fread(h, 1, 12, f) != 12) { fprintf(stderr, "jd_batch_test: %s: short header\n", path); fclose(f); return false; }
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    auto be32 = [&](int o) { return (int32_t)((uint32_t)h[o] << 24 | (uint32_t)h[o + 1] << 16 | (uint32_t)h[o + 2] << 8 | h[o + 3]); };
+    auto be16 = [&](int o) { return (int)(h[o] << 8 | h[o + 1]); };
+    int32_t le[2];
+    memcpy(le, h, 8);
+    const int32_t nS = be32(0);
+    const int sampSize = be16(8), parmKind = be16(10);
+    if (nS >= 0 && sampSize == D * 4 && size >= 12 + (long)nS * sampSize && !(parmKind & 0x400)) {       // HTK
+        T = nS;
+        x.resize((size_t)T * D);
+        fseek(f, 12, SEEK_SET);
+        std::vector<unsigned char> raw((size_t)T * D * 4);
+        if (!raw.empty() && fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); return false; }
+        for (size_t i = 0; i < x.size(); ++i) {
+            const uint32_t v = (uint32_t)raw[4 * i] << 24 | (uint32_t)raw[4 * i + 1] << 16 | (uint32_t)raw[4 * i + 2] << 8 | raw[4 * i + 3];
+            memcpy(&x[i], &v, 4);
+        }
+    } else if (le[0] >= 0 && le[1] == D && size == 8 + (long)le[0] * D * 4) {                             // .jdf
+        T = le[0];
+        x.resize((size_t)T * D);
+        fseek(f, 8, SEEK_SET);
+        if (!x.empty() && fread(x.data(), 4, x.size(), f) != x.size()) { fclose(f); return false; }
+    } else {
+        fprintf(stderr, "jd_batch_test: %s is neither an uncompressed HTK parameter file nor a .jdf file of vecSize %d\n", path, D);
+        fclose(f);
+        return false;
+    }
+    fclose(f);
+    return true;
+}
+
 int main(int argc, char **argv)
 {
     const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *mmf = 0, *list = 0;
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
-    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0;
+    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0;
     std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -67,18 +113,35 @@ int main(int argc, char **argv)
         else if (a == "-framesPerSec") framesPerSec = atoi(nxt()); else if (a == "-device") device = atoi(nxt());
         else if (a == "-batch") batch = atoi(nxt()); else if (a == "-perFrameAdapter") useAdapter = 1;
         else if (a == "-outputFormat") outputFormat = nxt();
+        else if (a == "-writeBinaryFiles") writeBinaryFiles = 1;
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (!fsm || (!amf && !mmf) || !list) {
         fprintf(stderr, "usage: jd_batch_test -fsmFName F (-htkModelsFName M.mmf | -modelsFName M.jdam) -inputFName LIST [-mainBeam b] [-phoneStartBeam b]\n"
-                        "       [-phoneEndBeam b] [-wordEmitBeam b] [-maxHyps n] [-lmScaleFactor s] [-insPenalty p] [-batch n] [-perFrameAdapter]\n");
+                        "       [-phoneEndBeam b] [-wordEmitBeam b] [-maxHyps n] [-lmScaleFactor s] [-insPenalty p] [-batch n] [-perFrameAdapter]\n"
+                        "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles]\n");
         return 2;
     }
     jd_net *net = 0;
-    if (jd_net_load_fsm(&net, fsm, insyms, outsyms, lmScale, insPen)) die("jd_net_load_fsm");
+    const std::string netBin = std::string(fsm) + ".bin";                    // juicer.cpp:854-882
+    if (file_exists(netBin)) {
+        fprintf(stderr, "network from pre-existing binary file %s\n", netBin.c_str());
+        if (jd_net_load_jwnt(&net, netBin.c_str(), lmScale, insPen)) die("jd_net_load_jwnt");
+    } else {
+        if (jd_net_load_fsm(&net, fsm, insyms, outsyms, lmScale, insPen)) die("jd_net_load_fsm");
+        if (writeBinaryFiles && jd_net_save_jwnt(net, netBin.c_str())) die("jd_net_save_jwnt");
+    }
     jd_am *am = 0;
-    if (mmf) { if (jd_am_load_mmf(&am, mmf)) die("jd_am_load_mmf"); }      // -htkModelsFName, juicer.cpp:196
-    else am = load_jdam(amf);
+    if (mmf) {                                                               // -htkModelsFName, juicer.cpp:762-797
+        const std::string amBin = std::string(mmf) + ".bin";
+        if (file_exists(amBin)) {
+            fprintf(stderr, "models from pre-existing binary file %s\n", amBin.c_str());
+            if (jd_am_load_jmbi(&am, amBin.c_str())) die("jd_am_load_jmbi");
+        } else {
+            if (jd_am_load_mmf(&am, mmf)) die("jd_am_load_mmf");
+            if (writeBinaryFiles && jd_am_save_jmbi(am, amBin.c_str())) die("jd_am_save_jmbi");
+        }
+    } else am = load_jdam(amf);
     const int D = jd_am_vec_size(am);
 
     // configureTests: list of input files
@@ -97,13 +160,7 @@ int main(int argc, char **argv)
     std::vector<std::vector<float>> feats(files.size());
     std::vector<int32_t> nfr(files.size());
     for (size_t u = 0; u < files.size(); ++u) {
-        FILE *f = fopen(files[u].c_str(), "rb");
-        if (!f) { fprintf(stderr, "jd_batch_test: cannot open %s\n", files[u].c_str()); return 1; }
-        std::vector<int32_t> h = rd<int32_t>(f, 2);
-        if (h[1] != D) { fprintf(stderr, "jd_batch_test: %s has vecSize %d, models want %d\n", files[u].c_str(), h[1], D); return 1; }
-        nfr[u] = h[0];
-        feats[u] = rd<float>(f, (size_t)h[0] * D);
-        fclose(f);
+        if (!load_features(files[u].c_str(), D, feats[u], nfr[u])) return 1;
     }
 
     // word strings: vocab->words[label-1] in the reference (DecoderSingleTest.cpp:443); here the output

@@ -99,6 +99,7 @@ extern "C" int jd_net_create_arcs(jd_net **out, int64_t n_arcs, const int32_t *f
     }
     int rc = finish_net(n, n_final, fstate, fweight_file, true, lm_scale);
     if (rc) { delete n; return rc; }
+    n->lm_scale = lm_scale; n->ins_penalty = ins_penalty;
     *out = n;
     return JD_OK;
 }
@@ -240,6 +241,11 @@ extern "C" int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t m
     a->det.assign(gm, LZ);
     a->mean.assign(gm * D, 0.0f);
     a->ivar.assign(gm * D, 0.0f);
+    a->var.assign(var, var + gm * D);
+    a->weight.assign(weight, weight + gm);
+    a->sum_log_var.assign(gm, 0.0f);
+    a->log_weight.assign(gm, LZ);
+    a->transp.assign(transp, transp + (size_t)n_tm * max_n * max_n);
     for (int32_t g = 0; g < n_gmm; ++g) {
         int32_t nm = n_mix[g];
         if (nm < 1 || nm > max_mix) { delete a; return jd_fail(JD_EINVAL, "n_mix[%d] out of range", g); }
@@ -255,6 +261,7 @@ extern "C" int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t m
             acc *= -0.5;                                              // HTKModels.cpp:866
             float wgt = weight[gi];
             float lw = (wgt > 0.0) ? std::log(wgt) : LZ;              // :657-663
+            a->sum_log_var[gi] = acc; a->log_weight[gi] = lw;
             a->det[gi] = acc + lw;                                    // HTKFlatModels.cpp:174
         }
         if (nm == 1 && weight[(size_t)g * max_mix] != 1.0f) {         // HTKModels.cpp:665
@@ -589,4 +596,415 @@ extern "C" int jd_am_load_mmf(jd_am **out, const char *mmf_path)
     }
     return jd_am_create_htk(out, D, G, max_mix, n_mix.data(), wt.data(), mu.data(), var.data(), H, max_n, hn.data(),
                             hg.data(), ht.data(), NT, tn.data(), tp.data());
+}
+
+// ------------------------------------------------- Juicer binary caches: JWNT / JMBI
+//
+// "<file>.bin" caches that juicer.cpp:854-866 / :778-784 prefer over the text files when they
+// exist.  Layouts restated from WFSTNetwork::writeBinary/readBinary (WFSTNetwork.cpp:1106-1365),
+// WFSTAlphabet::writeBinary/readBinary (:213-297) and HTKModels::output(.., true) / readBinary
+// and the per-record readers (HTKModels.cpp:1044-1105, 1110-1233, 1309-1372, 1440-1492,
+// 1580-1631, 1697-1740, 1803-1851, 1947-2040).  Native byte order, sizeof(int) == sizeof(real)
+// == 4, sizeof(bool) == 1, as the reference writes them.
+namespace {
+struct BinReader {
+    FILE *f = nullptr; const char *what = "";
+    bool ok = true;
+    template <typename T> T get() { T v{}; if (ok && fread(&v, sizeof(T), 1, f) != 1) ok = false; return v; }
+    template <typename T> bool get_n(T *dst, size_t n) { if (ok && n && fread(dst, sizeof(T), n, f) != n) ok = false; return ok; }
+    bool id(const char *tag) { char b[4] = {0, 0, 0, 0}; get_n(b, 4); return ok && memcmp(b, tag, 4) == 0; }
+    bool skip_name()                              // int len (incl. NUL) + len bytes
+    {
+        int len = get<int>();
+        if (!ok || len < 0 || len > (1 << 20)) return ok = false;
+        if (len > 0) { std::vector<char> nm((size_t)len); get_n(nm.data(), (size_t)len); }
+        return ok;
+    }
+};
+struct BinWriter {
+    FILE *f = nullptr;
+    template <typename T> void put(T v) { fwrite(&v, sizeof(T), 1, f); }
+    template <typename T> void put_n(const T *p, size_t n) { if (n) fwrite(p, sizeof(T), n, f); }
+    void id(const char *tag) { fwrite(tag, 1, 4, f); }
+};
+// WFSTAlphabet::readBinary (WFSTNetwork.cpp:250-297): contents are not needed by this path
+bool skip_alphabet(BinReader &r, bool *has_aux)
+{
+    if (!r.id("JWAL")) return false;
+    int max_label = r.get<int>();
+    (void)r.get<int>();                           // nLabels
+    if (!r.ok) return false;
+    if (max_label >= 0) {
+        for (int i = 0; i <= max_label && r.ok; ++i) r.skip_name();
+        int n_aux = r.get<int>();
+        std::vector<char> is_aux((size_t)max_label + 1);
+        r.get_n(is_aux.data(), is_aux.size());
+        if (r.ok && n_aux > 0) *has_aux = true;
+    }
+    return r.ok;
+}
+}  // namespace
+
+extern "C" int jd_net_load_jwnt(jd_net **out, const char *path, float lm_scale, float ins_penalty)
+{
+    if (!out || !path) return jd_fail(JD_EINVAL, "jd_net_load_jwnt: null argument");
+    BinReader r;
+    r.f = fopen(path, "rb");
+    if (!r.f) return jd_fail(JD_EFORMAT, "WFSTNetwork::readBinary - error opening input file %s", path);
+#define JW_FAIL(...) do { fclose(r.f); return jd_fail(JD_EFORMAT, __VA_ARGS__); } while (0)
+    if (!r.id("JWNT")) JW_FAIL("WFSTNetwork::readBinary - invalid ID");
+    const int init = r.get<int>(), max_state = r.get<int>();
+    (void)r.get<int>();                           // nStates (labelled states)
+    (void)r.get<int>();                           // maxOutTransitions
+    (void)r.get<int>(); (void)r.get<int>(); (void)r.get<int>();   // wordEndMarker, silMarker, spMarker
+    if (!r.ok || max_state < 0 || init < 0 || init > max_state) JW_FAIL("WFSTNetwork::readBinary - bad header");
+    const int S = max_state + 1;
+    std::vector<int> first((size_t)S, 0), cnt((size_t)S, 0), final_ind((size_t)S, -1);
+    std::vector<int> tl;
+    for (int i = 0; i < S; ++i) {
+        (void)r.get<int>();                       // label
+        final_ind[(size_t)i] = r.get<int>();
+        const int nt = r.get<int>();
+        if (!r.ok || nt < 0) JW_FAIL("WFSTNetwork::readBinary - error reading states[%d]", i);
+        cnt[(size_t)i] = nt;
+        if (nt > 0) {
+            tl.resize((size_t)nt);
+            if (!r.get_n(tl.data(), (size_t)nt)) JW_FAIL("WFSTNetwork::readBinary - error reading states[%d].trans array", i);
+            first[(size_t)i] = tl[0];
+            // the Lite core takes "first transition + count" (getTransitions, WFSTNetwork.cpp:709-721):
+            // a state whose list is not a contiguous run would silently decode other arcs there
+            for (int k = 1; k < nt; ++k)
+                if (tl[(size_t)k] != tl[0] + k) JW_FAIL("transitions of state %d are not contiguous", i);
+        }
+    }
+    const int n_final = r.get<int>();
+    if (!r.ok || n_final < 0) JW_FAIL("WFSTNetwork::readBinary - error reading nFinalStates");
+    std::vector<float> fweight((size_t)n_final);
+    for (int i = 0; i < n_final; ++i) { (void)r.get<int>(); fweight[(size_t)i] = r.get<float>(); }
+    const int n_trans = r.get<int>();
+    if (!r.ok || n_trans <= 0) JW_FAIL("WFSTNetwork::readBinary - error reading nTransitions");
+    struct T5 { int id, to; float w; int in, out; };
+    std::vector<T5> tr((size_t)n_trans);
+    if (!r.get_n(tr.data(), (size_t)n_trans)) JW_FAIL("WFSTNetwork::readBinary - error reading transitions");
+    bool aux = false;
+    if (r.get<char>() && !skip_alphabet(r, &aux)) JW_FAIL("WFSTAlphabet::readBinary - bad input alphabet");
+    if (r.get<char>() && !skip_alphabet(r, &aux)) JW_FAIL("WFSTAlphabet::readBinary - bad output alphabet");
+    if (!r.id("JWNT")) JW_FAIL("WFSTNetwork::readBinary - invalid ID (2)");
+    fclose(r.f);
+#undef JW_FAIL
+    if (aux) return jd_fail(JD_EFORMAT, "%s holds auxiliary (#) symbols: remove them first "
+                            "(the Lite core does not understand aux symbols)", path);
+    jd_net *n = new jd_net();
+    n->n_states = S; n->init = init; n->n_arcs = n_trans;
+    n->row_ptr.assign((size_t)S + 1, 0);
+    for (int s = 0; s < S; ++s) n->row_ptr[(size_t)s + 1] = n->row_ptr[(size_t)s] + cnt[(size_t)s];
+    if (n->row_ptr[(size_t)S] != n_trans) { delete n; return jd_fail(JD_EFORMAT, "%s: state lists cover %d of %d transitions", path, n->row_ptr[(size_t)S], n_trans); }
+    n->arcs.resize((size_t)n_trans);
+    for (int s = 0; s < S; ++s)
+        for (int k = 0; k < cnt[(size_t)s]; ++k) {
+            const int64_t i = (int64_t)first[(size_t)s] + k;
+            if (i < 0 || i >= n_trans) { delete n; return jd_fail(JD_EFORMAT, "%s: state %d lists transition %lld", path, s, (long long)i); }
+            const T5 &t = tr[(size_t)i];
+            if (t.to < 0 || t.to >= S || t.in < 0 || t.out < 0) { delete n; return jd_fail(JD_EFORMAT, "%s: transition %lld out of range", path, (long long)i); }
+            float w = t.w;                                            // stored without scale and penalty
+            if (lm_scale != 1.0f) w *= lm_scale;                      // WFSTNetwork.cpp:1343-1349
+            if (ins_penalty != 0.0f && t.out > 0) w += ins_penalty;   // :1351-1357
+            n->arcs[(size_t)n->row_ptr[(size_t)s] + k] = JdArc{t.to, w, t.in, t.out};
+        }
+    // final weights are stored as the writer scaled them and are not rescaled (:1290-1304)
+    n->fin_w.assign((size_t)S, std::numeric_limits<float>::infinity());
+    n->n_final = n_final;
+    for (int s = 0; s < S; ++s) {
+        const int fi = final_ind[(size_t)s];
+        if (fi < 0) continue;
+        if (fi >= n_final) { delete n; return jd_fail(JD_EFORMAT, "%s: states[%d].finalInd out of range", path, s); }
+        n->fin_w[(size_t)s] = fweight[(size_t)fi];
+    }
+    n->max_in = 0;
+    for (const JdArc &a : n->arcs) n->max_in = std::max(n->max_in, a.in);
+    n->lm_scale = lm_scale; n->ins_penalty = ins_penalty;
+    *out = n;
+    return JD_OK;
+}
+
+// WFSTNetwork::writeBinary (WFSTNetwork.cpp:1106-1225): the penalty, then the scale, are taken
+// off the arc weights (float arithmetic, in that order); final weights are written as held.
+extern "C" int jd_net_save_jwnt(const jd_net *n, const char *path)
+{
+    if (!n || !path) return jd_fail(JD_EINVAL, "jd_net_save_jwnt: null argument");
+    BinWriter w;
+    w.f = fopen(path, "wb");
+    if (!w.f) return jd_fail(JD_EFORMAT, "WFSTNetwork::writeBinary - error opening output file %s", path);
+    const int S = n->n_states;
+    std::vector<char> used((size_t)S, 0);
+    int max_out_tr = 0, max_lab = 0, n_used = 0;
+    for (int s = 0; s < S; ++s) {
+        const int c = n->row_ptr[(size_t)s + 1] - n->row_ptr[(size_t)s];
+        if (c > 0) used[(size_t)s] = 1;
+        max_out_tr = std::max(max_out_tr, c);
+        if (n->fin_w[(size_t)s] < std::numeric_limits<float>::infinity()) used[(size_t)s] = 1;
+    }
+    for (const JdArc &a : n->arcs) { used[(size_t)a.to] = 1; max_lab = std::max(max_lab, std::max(a.in, a.out)); }
+    for (int s = 0; s < S; ++s) n_used += used[(size_t)s];
+    w.id("JWNT");
+    w.put<int>(n->init); w.put<int>(S - 1); w.put<int>(n_used); w.put<int>(max_out_tr);
+    w.put<int>(max_lab + 1); w.put<int>(-1); w.put<int>(-1);          // wordEndMarker, silMarker, spMarker
+    int fi = 0;
+    std::vector<int> idx;
+    for (int s = 0; s < S; ++s) {
+        const bool fin = n->fin_w[(size_t)s] < std::numeric_limits<float>::infinity();
+        const int b = n->row_ptr[(size_t)s], c = n->row_ptr[(size_t)s + 1] - b;
+        w.put<int>(used[(size_t)s] ? s : -1);
+        w.put<int>(fin ? fi++ : -1);
+        w.put<int>(c);
+        idx.resize((size_t)c);
+        for (int k = 0; k < c; ++k) idx[(size_t)k] = b + k;
+        w.put_n(idx.data(), (size_t)c);
+    }
+    w.put<int>(fi);
+    for (int s = 0; s < S; ++s)
+        if (n->fin_w[(size_t)s] < std::numeric_limits<float>::infinity()) { w.put<int>(s); w.put<float>(n->fin_w[(size_t)s]); }
+    w.put<int>((int)n->n_arcs);
+    for (int64_t i = 0; i < n->n_arcs; ++i) {
+        const JdArc &a = n->arcs[(size_t)i];
+        float x = a.w;
+        if (n->ins_penalty != 0.0f && a.out > 0) x -= n->ins_penalty;  // :1108-1115
+        if (n->lm_scale != 1.0f) x /= n->lm_scale;                     // :1120-1126
+        w.put<int>((int)i); w.put<int>(a.to); w.put<float>(x); w.put<int>(a.in); w.put<int>(a.out);
+    }
+    w.put<char>(0); w.put<char>(0);                                    // no alphabets held
+    w.id("JWNT");
+    const bool bad = ferror(w.f) != 0;
+    if (fclose(w.f) != 0 || bad) return jd_fail(JD_EFORMAT, "%s: write error", path);
+    return JD_OK;
+}
+
+static void build_se_index(const float *trP, int n, int max_n, int16_t *se)     // HTKModels.cpp:2376-2386
+{
+    for (int j = 1; j < n; ++j) {
+        int mn, mx;
+        for (mn = (j == n - 1 ? 1 : 0); mn < n - 1; ++mn)
+            if (trP[mn * max_n + j] > LZ) break;
+        for (mx = n - 1; mx >= 1; --mx)
+            if (trP[mx * max_n + j] > LZ) break;
+        se[j * 2] = (int16_t)mn;
+        se[j * 2 + 1] = (int16_t)(mx + 1);
+    }
+}
+
+// HTKModels::readBinary (HTKModels.cpp:1110-1233) followed by HTKFlatModels::init
+// (HTKFlatModels.cpp:148-176).  The derived values held by the file (sumLogVarPlusNObsLog2Pi,
+// logCompWeights, transition logProbs) are used as stored, exactly like the reference; only
+// 1.0/var is recomputed.
+extern "C" int jd_am_load_jmbi(jd_am **out, const char *path)
+{
+    if (!out || !path) return jd_fail(JD_EINVAL, "jd_am_load_jmbi: null argument");
+    BinReader r;
+    r.f = fopen(path, "rb");
+    if (!r.f) return jd_fail(JD_EFORMAT, "HTKModels::readBinary - error opening file %s", path);
+#define JM_FAIL(...) do { fclose(r.f); return jd_fail(JD_EFORMAT, __VA_ARGS__); } while (0)
+    if (!r.id("JMBI")) JM_FAIL("HTKModels::readBinary - invalid ID");
+    const int D = r.get<int>(), n_mean = r.get<int>(), n_var = r.get<int>(), n_mixt = r.get<int>();
+    const int n_gmm = r.get<int>(), n_tm = r.get<int>(), n_hmm = r.get<int>();
+    const int LIM = 1 << 26;
+    if (!r.ok || D <= 0 || D > 4096 || n_mean <= 0 || n_var <= 0 || n_mixt <= 0 || n_gmm <= 0 || n_tm <= 0 || n_hmm <= 0 ||
+        n_mean > LIM || n_var > LIM || n_mixt > LIM || n_gmm > LIM || n_tm > LIM || n_hmm > LIM)
+        JM_FAIL("HTKModels::readBinary - bad header");
+    std::vector<float> means((size_t)n_mean * D), vars((size_t)n_var * D), slv((size_t)n_var);
+    std::vector<float> tmpv((size_t)D);
+    for (int i = 0; i < n_mean; ++i) {
+        if (!r.id("JMMN") || !r.skip_name() || !r.get_n(&means[(size_t)i * D], (size_t)D)) JM_FAIL("HTKModels::readBinaryMeanVec - error (vector %d)", i);
+    }
+    for (int i = 0; i < n_var; ++i) {
+        if (!r.id("JMVR") || !r.skip_name() || !r.get_n(&vars[(size_t)i * D], (size_t)D) || !r.get_n(tmpv.data(), (size_t)D))
+            JM_FAIL("HTKModels::readBinaryVarVec - error (vector %d)", i);
+        slv[(size_t)i] = r.get<float>();
+    }
+    std::vector<std::vector<int>> mix_mean((size_t)n_mixt), mix_var((size_t)n_mixt);
+    int max_mix = 0;
+    for (int i = 0; i < n_mixt; ++i) {
+        if (!r.id("JMMX") || !r.skip_name()) JM_FAIL("HTKModels::readBinaryMixture - error (mixture %d)", i);
+        const int nc = r.get<int>();
+        if (!r.ok || nc <= 0 || nc > 65536) JM_FAIL("HTKModels::readBinaryMixture - error reading nComps");
+        mix_mean[(size_t)i].resize((size_t)nc); mix_var[(size_t)i].resize((size_t)nc);
+        r.get_n(mix_mean[(size_t)i].data(), (size_t)nc); r.get_n(mix_var[(size_t)i].data(), (size_t)nc);
+        for (int j = 0; j < nc && r.ok; ++j)
+            if (mix_mean[(size_t)i][(size_t)j] < 0 || mix_mean[(size_t)i][(size_t)j] >= n_mean ||
+                mix_var[(size_t)i][(size_t)j] < 0 || mix_var[(size_t)i][(size_t)j] >= n_var) r.ok = false;
+        if (!r.ok) JM_FAIL("HTKModels::readBinaryMixture - error reading meanVecInds+varVecInds");
+        max_mix = std::max(max_mix, nc);
+    }
+    // HTKFlatModels indexes its flat parameters by GMM but fills them per mixture
+    // (HTKFlatModels.h:61-63, .cpp:148-176): only valid when mixtureInd == gmmInd
+    if (n_mixt != n_gmm) JM_FAIL("HTKFlatModels: %d mixtures for %d GMMs (shared mixture pools are not supported)", n_mixt, n_gmm);
+    std::vector<std::vector<float>> gw((size_t)n_gmm), glw((size_t)n_gmm);
+    for (int g = 0; g < n_gmm; ++g) {
+        if (!r.id("JMGM") || !r.skip_name()) JM_FAIL("HTKModels::readBinaryGMM - error (GMM %d)", g);
+        const int mi = r.get<int>(), nc = r.get<int>();
+        if (!r.ok || mi != g) JM_FAIL("HTKFlatModels: GMM %d uses mixture %d (mixtureInd != gmmInd is not supported)", g, mi);
+        if (nc != (int)mix_mean[(size_t)g].size()) JM_FAIL("HTKModels::readBinaryGMM - component count mismatch (GMM %d)", g);
+        gw[(size_t)g].resize((size_t)nc); glw[(size_t)g].resize((size_t)nc);
+        r.get_n(gw[(size_t)g].data(), (size_t)nc); r.get_n(glw[(size_t)g].data(), (size_t)nc);
+        if (!r.ok) JM_FAIL("HTKModels::readBinaryGMM - error reading compWeights+nCompWeights");
+    }
+    struct Tm { int n; std::vector<int> nsuc; std::vector<std::vector<int>> suc; std::vector<std::vector<float>> p, lp; };
+    std::vector<Tm> tms((size_t)n_tm);
+    int max_n = 0;
+    for (int t = 0; t < n_tm; ++t) {
+        Tm &m = tms[(size_t)t];
+        if (!r.id("JMTM") || !r.skip_name()) JM_FAIL("HTKModels::readBinaryTransMat - error (matrix %d)", t);
+        m.n = r.get<int>();
+        if (!r.ok || m.n < 3 || m.n > JD_MAXN) JM_FAIL("transition matrix %d: %d states (3..%d supported)", t, m.n, JD_MAXN);
+        m.nsuc.resize((size_t)m.n); r.get_n(m.nsuc.data(), (size_t)m.n);
+        m.suc.resize((size_t)m.n); m.p.resize((size_t)m.n); m.lp.resize((size_t)m.n);
+        for (int i = 0; i < m.n && r.ok; ++i) if (m.nsuc[(size_t)i] < 0 || m.nsuc[(size_t)i] > m.n) r.ok = false;
+        for (int i = 0; i < m.n && r.ok; ++i) { m.suc[(size_t)i].resize((size_t)m.nsuc[(size_t)i]); r.get_n(m.suc[(size_t)i].data(), m.suc[(size_t)i].size()); }
+        for (int i = 0; i < m.n && r.ok; ++i) { m.p[(size_t)i].resize((size_t)m.nsuc[(size_t)i]); r.get_n(m.p[(size_t)i].data(), m.p[(size_t)i].size()); }
+        for (int i = 0; i < m.n && r.ok; ++i) { m.lp[(size_t)i].resize((size_t)m.nsuc[(size_t)i]); r.get_n(m.lp[(size_t)i].data(), m.lp[(size_t)i].size()); }
+        for (int i = 0; i < m.n && r.ok; ++i) for (int sj : m.suc[(size_t)i]) if (sj < 0 || sj >= m.n) r.ok = false;
+        if (!r.ok) JM_FAIL("HTKModels::readBinaryTransMat - error reading matrix %d", t);
+        max_n = std::max(max_n, m.n);
+    }
+    struct Hm { int n; std::vector<int> g; int tm; };
+    std::vector<Hm> hmms((size_t)n_hmm);
+    for (int h = 0; h < n_hmm; ++h) {
+        Hm &m = hmms[(size_t)h];
+        if (!r.id("JMHM") || !r.skip_name()) JM_FAIL("HTKModels::readBinaryHMM - error (HMM %d)", h);
+        m.n = r.get<int>();
+        if (!r.ok || m.n < 3 || m.n > JD_MAXN) JM_FAIL("HMM %d: %d states (3..%d supported)", h, m.n, JD_MAXN);
+        m.g.resize((size_t)m.n); r.get_n(m.g.data(), (size_t)m.n);
+        m.tm = r.get<int>();
+        if (!r.ok || m.tm < 0 || m.tm >= n_tm || tms[(size_t)m.tm].n != m.n) JM_FAIL("HTKModels::readBinaryHMM - error reading HMM %d", h);
+    }
+    const bool hybrid = r.get<char>() != 0;
+    if (!r.ok) JM_FAIL("HTKModels::readBinary - error reading hybridMode");
+    fclose(r.f);
+#undef JM_FAIL
+    if (hybrid) return jd_fail(JD_EFORMAT, "%s: hybrid (ANN posterior) models are outside this path", path);
+
+    jd_am *a = new jd_am();
+    a->D = D; a->n_gmm = n_gmm; a->max_mix = max_mix; a->n_hmm = n_hmm; a->max_n = max_n; a->n_tm = n_tm;
+    const size_t gm = (size_t)n_gmm * max_mix;
+    a->n_mix.resize((size_t)n_gmm);
+    a->det.assign(gm, LZ); a->mean.assign(gm * D, 0.0f); a->ivar.assign(gm * D, 0.0f);
+    a->var.assign(gm * D, 1.0f); a->weight.assign(gm, 0.0f); a->sum_log_var.assign(gm, 0.0f); a->log_weight.assign(gm, LZ);
+    for (int g = 0; g < n_gmm; ++g) {
+        const int nc = (int)mix_mean[(size_t)g].size();
+        a->n_mix[(size_t)g] = nc;
+        for (int j = 0; j < nc; ++j) {
+            const size_t gi = (size_t)g * max_mix + j;
+            const float *mu = &means[(size_t)mix_mean[(size_t)g][(size_t)j] * D];
+            const float *vv = &vars[(size_t)mix_var[(size_t)g][(size_t)j] * D];
+            for (int k = 0; k < D; ++k) {
+                a->mean[gi * D + k] = mu[k];                          // HTKFlatModels.cpp:159
+                a->ivar[gi * D + k] = (float)(1.0 / vv[k]);           // :160
+                a->var[gi * D + k] = vv[k];
+            }
+            float det = slv[(size_t)mix_var[(size_t)g][(size_t)j]];   // :163
+            det += glw[(size_t)g][(size_t)j];                         // :174
+            a->det[gi] = det;
+            a->sum_log_var[gi] = slv[(size_t)mix_var[(size_t)g][(size_t)j]];
+            a->log_weight[gi] = glw[(size_t)g][(size_t)j];
+            a->weight[gi] = gw[(size_t)g][(size_t)j];
+        }
+    }
+    a->tm_n.resize((size_t)n_tm);
+    a->trP.assign((size_t)n_tm * max_n * max_n, LZ);
+    a->transp.assign((size_t)n_tm * max_n * max_n, 0.0f);
+    a->se.assign((size_t)n_tm * max_n * 2, 0);
+    std::vector<float> tm_tee((size_t)n_tm, LZ);
+    for (int t = 0; t < n_tm; ++t) {
+        const Tm &m = tms[(size_t)t];
+        a->tm_n[(size_t)t] = m.n;
+        float *trP = a->trP.data() + (size_t)t * max_n * max_n;
+        float *tp = a->transp.data() + (size_t)t * max_n * max_n;
+        for (int i = 0; i < m.n; ++i)                                 // HTKModels.cpp:2357-2361
+            for (size_t k = 0; k < m.suc[(size_t)i].size(); ++k) {
+                trP[i * max_n + m.suc[(size_t)i][k]] = m.lp[(size_t)i][k];
+                tp[i * max_n + m.suc[(size_t)i][k]] = m.p[(size_t)i][k];
+            }
+        build_se_index(trP, m.n, max_n, a->se.data() + (size_t)t * max_n * 2);
+        for (size_t k = 1; k < m.suc[0].size(); ++k)                  // :1359-1369 tee weight
+            if (m.suc[0][k] == m.n - 1) {
+                if (tm_tee[(size_t)t] != LZ) { delete a; return jd_fail(JD_EFORMAT, "HTKModels::addHMM more then one tee transition found (matrix %d)", t); }
+                tm_tee[(size_t)t] = m.lp[0][k];
+            }
+    }
+    a->hmm_n.resize((size_t)n_hmm); a->hmm_tm.resize((size_t)n_hmm);
+    a->hmm_tee.assign((size_t)n_hmm, LZ);
+    a->hmm_gmm.assign((size_t)n_hmm * max_n, -1);
+    for (int h = 0; h < n_hmm; ++h) {
+        const Hm &m = hmms[(size_t)h];
+        a->hmm_n[(size_t)h] = m.n; a->hmm_tm[(size_t)h] = m.tm; a->hmm_tee[(size_t)h] = tm_tee[(size_t)m.tm];
+        for (int j = 1; j < m.n - 1; ++j) {
+            if (m.g[(size_t)j] < 0 || m.g[(size_t)j] >= n_gmm) { delete a; return jd_fail(JD_EFORMAT, "HMM %d state %d: bad gmm index", h, j); }
+            a->hmm_gmm[(size_t)h * max_n + j] = m.g[(size_t)j];
+        }
+    }
+    *out = a;
+    return JD_OK;
+}
+
+// HTKModels::output(fName, true) (HTKModels.cpp:1044-1105): one unnamed mean / variance vector
+// per Gaussian, mixture i belongs to GMM i.
+extern "C" int jd_am_save_jmbi(const jd_am *a, const char *path)
+{
+    if (!a || !path) return jd_fail(JD_EINVAL, "jd_am_save_jmbi: null argument");
+    if (a->var.empty() || a->transp.empty()) return jd_fail(JD_ESTATE, "jd_am_save_jmbi: models hold no HTK-level parameters");
+    BinWriter w;
+    w.f = fopen(path, "wb");
+    if (!w.f) return jd_fail(JD_EFORMAT, "HTKModels::output - error opening file %s", path);
+    const int D = a->D, G = a->n_gmm, MM = a->max_mix, MN = a->max_n;
+    int n_gauss = 0;
+    for (int g = 0; g < G; ++g) n_gauss += a->n_mix[(size_t)g];
+    w.id("JMBI");
+    w.put<int>(D); w.put<int>(n_gauss); w.put<int>(n_gauss); w.put<int>(G); w.put<int>(G); w.put<int>(a->n_tm); w.put<int>(a->n_hmm);
+    for (int g = 0; g < G; ++g)
+        for (int m = 0; m < a->n_mix[(size_t)g]; ++m) { w.id("JMMN"); w.put<int>(0); w.put_n(&a->mean[((size_t)g * MM + m) * D], (size_t)D); }
+    std::vector<float> mh((size_t)D);
+    for (int g = 0; g < G; ++g)
+        for (int m = 0; m < a->n_mix[(size_t)g]; ++m) {
+            const size_t gi = (size_t)g * MM + m;
+            w.id("JMVR"); w.put<int>(0);
+            w.put_n(&a->var[gi * D], (size_t)D);
+            for (int k = 0; k < D; ++k) mh[(size_t)k] = (float)-0.5 / a->var[gi * D + k];     // HTKModels.cpp:863
+            w.put_n(mh.data(), (size_t)D);
+            w.put<float>(a->sum_log_var[gi]);
+        }
+    int gi0 = 0;
+    std::vector<int> idx;
+    for (int g = 0; g < G; ++g) {
+        const int nc = a->n_mix[(size_t)g];
+        w.id("JMMX"); w.put<int>(0); w.put<int>(nc);
+        idx.resize((size_t)nc);
+        for (int m = 0; m < nc; ++m) idx[(size_t)m] = gi0 + m;
+        w.put_n(idx.data(), (size_t)nc); w.put_n(idx.data(), (size_t)nc);
+        gi0 += nc;
+    }
+    for (int g = 0; g < G; ++g) {
+        const int nc = a->n_mix[(size_t)g];
+        w.id("JMGM"); w.put<int>(0); w.put<int>(g); w.put<int>(nc);
+        w.put_n(&a->weight[(size_t)g * MM], (size_t)nc); w.put_n(&a->log_weight[(size_t)g * MM], (size_t)nc);
+    }
+    for (int t = 0; t < a->n_tm; ++t) {
+        const int n = a->tm_n[(size_t)t];
+        const float *tp = &a->transp[(size_t)t * MN * MN], *lp = &a->trP[(size_t)t * MN * MN];
+        w.id("JMTM"); w.put<int>(0); w.put<int>(n);
+        std::vector<int> nsuc((size_t)n, 0);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (tp[i * MN + j] > 0.0f) ++nsuc[(size_t)i];
+        w.put_n(nsuc.data(), (size_t)n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (tp[i * MN + j] > 0.0f) w.put<int>(j);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (tp[i * MN + j] > 0.0f) w.put<float>(tp[i * MN + j]);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (tp[i * MN + j] > 0.0f) w.put<float>(lp[i * MN + j]);
+    }
+    for (int h = 0; h < a->n_hmm; ++h) {
+        const int n = a->hmm_n[(size_t)h];
+        w.id("JMHM"); w.put<int>(0); w.put<int>(n);
+        w.put_n(&a->hmm_gmm[(size_t)h * MN], (size_t)n);
+        w.put<int>(a->hmm_tm[(size_t)h]);
+    }
+    w.put<char>(0);                                                    // hybridMode
+    const bool bad = ferror(w.f) != 0;
+    if (fclose(w.f) != 0 || bad) return jd_fail(JD_EFORMAT, "%s: write error", path);
+    return JD_OK;
 }

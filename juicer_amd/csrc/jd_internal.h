@@ -22,6 +22,9 @@ struct jd_net {
     std::vector<JdArc> arcs;           // sorted by source state, file order within a state
     std::vector<float> fin_w;          // per state; +inf when not final
     int32_t max_in = 0;
+    // the scaling the arc weights carry (transWeightScalingFactor / insPenalty of
+    // WFSTNetwork.h); jd_net_save_jwnt removes it again the way writeBinary does
+    float lm_scale = 1.0f, ins_penalty = 0.0f;
 };
 
 struct jd_am {
@@ -33,6 +36,10 @@ struct jd_am {
     std::vector<int32_t> tm_n;
     std::vector<float> trP;                       // [tm][max_n][max_n]
     std::vector<int16_t> se;                      // [tm][max_n][2]
+    // HTK-level values behind det / trP, kept for jd_am_save_jmbi (HTKModels::output(.., true)):
+    std::vector<float> var, weight;               // [g][m][D], [g][m]
+    std::vector<float> sum_log_var, log_weight;   // [g][m]  VarVec::sumLogVarPlusNObsLog2Pi, GMM::logCompWeights
+    std::vector<float> transp;                    // [tm][max_n][max_n]  a_ij
 };
 
 int jd_fail(int code, const char *fmt, ...);      // sets jd_last_error(), returns code

@@ -291,3 +291,57 @@ def test_path_garbage_collection(small):
     for pos in range(0, feats[0].shape[0], 50):
         gd.stream_push(0, feats[0][pos:pos + 50])
     assert_hyp_matches(gd.stream_finish(0), od.decode(feats[0]), "gc streaming")
+
+
+def test_binary_caches_and_htk_feature_files(small, tmp_path):
+    """The reference's other on-disk formats drive the same decode: "<fsm>.bin" (JWNT) and
+    "<mmf>.bin" (JMBI) caches are preferred when present (juicer.cpp:854-866, :778-784),
+    -writeBinaryFiles creates them, utterances come from HTK parameter files; the result lines
+    equal the text-FSM / MMF / .jdf run's and the oracle's."""
+    import subprocess
+    from juicer_amd import build as jbuild, capi, io as jio, synth
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    am, net, _, _ = synth.config_small()
+    d_txt, d_bin = tmp_path / "txt", tmp_path / "bin"
+    d_txt.mkdir(); d_bin.mkdir()
+    for d in (d_txt, d_bin):
+        jio.write_fsm(d / "g.fsm", net)
+        jio.write_mmf(d / "m.mmf", am)
+    lists = {}
+    for kind, d, writer in (("jdf", d_txt, jio.write_jdf), ("htk", d_bin, jio.write_htk)):
+        lists[kind] = d / "list.txt"
+        with open(lists[kind], "w") as f:
+            for u, x in enumerate(feats):
+                writer(d / ("u%d.%s" % (u, kind)), x)
+                f.write("%s\n" % (d / ("u%d.%s" % (u, kind))))
+
+    def run(d, lst, *extra):
+        out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(d / "g.fsm"), "-htkModelsFName", str(d / "m.mmf"),
+                              "-inputFName", str(lst), "-mainBeam", "150", "-outputFormat", "verbose"] + list(extra),
+                             capture_output=True, text=True, timeout=240)
+        assert out.returncode == 0, out.stderr
+        return [l for l in out.stdout.splitlines() if "Actual" in l], out.stderr
+
+    base, err = run(d_txt, lists["jdf"])
+    assert "pre-existing" not in err
+    first, err = run(d_bin, lists["htk"], "-writeBinaryFiles")          # text load, caches written
+    assert "pre-existing" not in err and (d_bin / "g.fsm.bin").exists() and (d_bin / "m.mmf.bin").exists()
+    again, err = run(d_bin, lists["htk"])                               # now served from the caches
+    assert err.count("pre-existing binary file") == 2
+    assert base == first == again and len(base) == len(feats)
+    od = OracleDecoder(onet, oam, main_beam=150.0)
+    for u, x in enumerate(feats):
+        o = od.decode(x)
+        body = base[u].split("[")[0].replace("Actual :", "").split()
+        assert [int(w) for w in body] == (o.label[::-1] - 1).tolist()
+    # library level: binary-loaded handles decode bit-identically to the originals
+    capi.Network.from_synth(net).save_jwnt(str(tmp_path / "n.bin"))
+    capi.Models.from_htk(am).save_jmbi(str(tmp_path / "a.bin"))
+    kw = dict(main_beam=150.0, max_streams=len(feats))
+    a = capi.Decoder(gnet, gam, **kw).decode_batch(feats)
+    b = capi.Decoder(capi.Network.from_jwnt_file(str(tmp_path / "n.bin")),
+                     capi.Models.from_jmbi_file(str(tmp_path / "a.bin")), **kw).decode_batch(feats)
+    for x, y in zip(a, b):
+        assert x.n == y.n and np.array_equal(x.label, y.label) and np.array_equal(x.time, y.time)
+        assert np.array_equal(x.score.view(np.uint32), y.score.view(np.uint32))
