@@ -3,6 +3,8 @@
 //   DecoderBatchTest::configureTests  list file, one path per line, '#'/blank skipped  (DecoderBatchTest.cpp:822-844)
 //   DecoderBatchTest::run             decode, output, "CPU time .. speech time .. RT factor" (:738-777)
 //   DecoderBatchTest::outputResult    ref / trans / mlf / xmlf / verbose formats           (:339-430)
+//   -refFName expected results (MLF or one line per file), "Expected :" lines, insertion /
+//   deletion / substitution totals at HTK costs 7/7/10                                      (:145-201, :804-939)
 //   DecoderSingleTest::extractResultsFromHypWordMode  label-1, start/end frames       (DecoderSingleTest.cpp:403-468)
 //
 // Networks / models: the text FSM and HTK MMF, or - preferred when present, like
@@ -100,6 +102,9 @@ int main(int argc, char **argv)
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
     int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0;
     std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
+    const char *refFName = 0;                  // -refFName: expected results, MLF or one line per file (juicer.cpp:267)
+    int removeSentMarks = 0;                   // -removeSentMarks (juicer.cpp:273)
+    std::string sentStartWord, sentEndWord;    // -sentStartWord / -sentEndWord (DecVocabulary)
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -114,12 +119,15 @@ int main(int argc, char **argv)
         else if (a == "-batch") batch = atoi(nxt()); else if (a == "-perFrameAdapter") useAdapter = 1;
         else if (a == "-outputFormat") outputFormat = nxt();
         else if (a == "-writeBinaryFiles") writeBinaryFiles = 1;
+        else if (a == "-refFName") refFName = nxt(); else if (a == "-removeSentMarks") removeSentMarks = 1;
+        else if (a == "-sentStartWord") sentStartWord = nxt(); else if (a == "-sentEndWord") sentEndWord = nxt();
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (!fsm || (!amf && !mmf) || !list) {
         fprintf(stderr, "usage: jd_batch_test -fsmFName F (-htkModelsFName M.mmf | -modelsFName M.jdam) -inputFName LIST [-mainBeam b] [-phoneStartBeam b]\n"
                         "       [-phoneEndBeam b] [-wordEmitBeam b] [-maxHyps n] [-lmScaleFactor s] [-insPenalty p] [-batch n] [-perFrameAdapter]\n"
-                        "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles]\n");
+                        "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles] [-refFName REF] [-removeSentMarks]\n"
+                        "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS]\n");
         return 2;
     }
     jd_net *net = 0;
@@ -177,6 +185,63 @@ int main(int argc, char **argv)
         if (label >= 0 && (size_t)label < syms.size() && !syms[label].empty()) return syms[label];
         return std::to_string(label - 1);
     };
+    // vocab->getIndex(word): word id (= output label - 1) or -1
+    auto word_index = [&](const char *w) -> int {
+        if (syms.empty()) {
+            char *e = 0;
+            const long v = strtol(w, &e, 10);
+            return (e && *e == 0 && e != w && v >= 0) ? (int)v : -1;
+        }
+        for (size_t id = 1; id < syms.size(); ++id) if (syms[id] == w) return (int)id - 1;
+        return -1;
+    };
+    // expected results (DecoderBatchTest::configureTests, DecoderBatchTest.cpp:804-939): an HTK MLF
+    // (first line holds "MLF"; entries are matched to input files by base name) or one line of
+    // words per input file, in order.
+    const bool haveExpResults = refFName && refFName[0];
+    std::vector<std::vector<int>> expected(files.size());
+    if (haveExpResults) {
+        FILE *f = fopen(refFName, "rb");
+        if (!f) { fprintf(stderr, "DecoderBatchTest::configureTests - error opening results file\n"); return 1; }
+        std::vector<char> buf(100000), nm(100000), rw(1000);
+        char *line = buf.data(), *fname = nm.data();
+        std::vector<char> have(files.size(), 0);
+        bool haveMLF = false;
+        if (fgets(line, 1000, f) && strstr(line, "MLF")) haveMLF = true; else fseek(f, 0, SEEK_SET);
+        size_t testIndex = 0;
+        while (fgets(line, 100000, f)) {
+            if (haveMLF) {
+                if (sscanf(line, "\"%[^\"]", fname) != 1) continue;
+                char *ptr;
+                if ((ptr = strrchr(fname, '/')) != 0) memmove(fname, ptr + 1, strlen(ptr) + 1);
+                if ((ptr = strrchr(fname, '.')) != 0) *(ptr + 1) = 0;       // keep the '.' (:861)
+                for (size_t i = 0; i < files.size(); ++i) {
+                    if (!strstr(files[i].c_str(), fname)) continue;
+                    if (have[i]) { fprintf(stderr, "DecoderBatchTest::configureTests - duplicate reference transcript %s\n", fname); return 1; }
+                    while (fgets(line, 100000, f) && line[0] != '.') {
+                        if (sscanf(line, "%999s", rw.data()) != 1) continue;
+                        const int id = word_index(rw.data());
+                        if (id >= 0) expected[i].push_back(id);
+                        else fprintf(stderr, "WARNING: Unknown word in ground truth for %s\n", files[i].c_str());
+                    }
+                    have[i] = 1;
+                    break;
+                }
+            } else {
+                if (testIndex >= files.size()) { fprintf(stderr, "DBT::configureTests - testIndex out of range\n"); return 1; }
+                for (char *ptr = strtok(line, " \r\n\t"); ptr; ptr = strtok(0, " \r\n\t")) {
+                    const int id = word_index(ptr);
+                    if (id < 0) printf("DBT::cfgTests - result word %s not in vocab for test %d\n", ptr, (int)testIndex + 1);
+                    expected[testIndex].push_back(id);
+                }
+                have[testIndex++] = 1;
+            }
+        }
+        fclose(f);
+        for (size_t i = 0; i < files.size(); ++i)
+            if (!have[i]) { fprintf(stderr, "DBT::configureTests - ref transcription not found for file %s\n", files[i].c_str()); return 1; }
+    }
+    std::vector<std::vector<int>> actual(files.size());                            // word ids, for the statistics
     if (outputFormat == "mlf" || outputFormat == "xmlf") printf("#!MLF!#\n");     // DecoderBatchTest::openOutputFile
     double decodeTime = 0.0, speechTime = 0.0;
     // DecoderBatchTest::outputResult (DecoderBatchTest.cpp:339-430) on the word list that
@@ -185,14 +250,25 @@ int main(int argc, char **argv)
     auto print_utt = [&](size_t u, int n, const int32_t *label, const int32_t *time, const float *ac, const float *lm,
                          double decTime) {
         fprintf(stderr, "File: %s\n", files[u].c_str());
+        // chain entries kept: all, or all but <s> / </s> with -removeSentMarks (DecoderSingleTest.cpp:412-416)
+        std::vector<int> keep;
+        for (int k = n - 1; k >= 0; --k) {
+            if (removeSentMarks) {
+                const std::string ws = word(label[k]);
+                if ((!sentStartWord.empty() && ws == sentStartWord) || (!sentEndWord.empty() && ws == sentEndWord)) continue;
+            }
+            keep.push_back(k);
+        }
+        n = (int)keep.size();
         std::vector<int> lab(n), st(n), et(n);
         std::vector<float> wac(n), wlm(n);
         for (int w = 0; w < n; ++w) {
-            const int k = n - 1 - w;                   // chain index of word w
+            const int k = keep[w];                     // chain index of word w
             lab[w] = label[k]; et[w] = time[k];
             st[w] = (w == 0) ? 0 : et[w - 1];
-            wac[w] = ac ? ac[k] - ((w > 0) ? ac[k + 1] : 0.0f) : 0.0f;
-            wlm[w] = lm ? lm[k] - ((w > 0) ? lm[k + 1] : 0.0f) : 0.0f;
+            wac[w] = ac ? ac[k] - ((w > 0) ? ac[keep[w - 1]] : 0.0f) : 0.0f;
+            wlm[w] = lm ? lm[k] - ((w > 0) ? lm[keep[w - 1]] : 0.0f) : 0.0f;
+            actual[u].push_back(lab[w] - 1);
         }
         if (outputFormat == "ref") {
             for (int w = 0; w < n; ++w) printf("%s ", word(lab[w]).c_str());
@@ -218,6 +294,11 @@ int main(int argc, char **argv)
             printf(".\n");
         } else {                                       // verbose
             printf("%s\n", files[u].c_str());
+            if (haveExpResults) {                      // :311-322
+                printf("\tExpected :  ");
+                for (int id : expected[u]) { if (id < 0) printf("<OOV> "); else printf("%s ", word(id + 1).c_str()); }
+                printf("\n");
+            }
             printf("\tActual :    ");
             for (int w = 0; w < n; ++w) printf("%s ", word(lab[w]).c_str());
             printf("  [ ");
@@ -273,6 +354,42 @@ int main(int argc, char **argv)
     }
     fprintf(stderr, "\n\nTotal CPU time %.3f  Total speech time %.3f  Avg. RT factor %.3f\n", decodeTime, speechTime,
             speechTime > 0 ? decodeTime / speechTime : 0.0);
+    // DecoderBatchTest::closeOutputFile -> printStatistics(7, 7, 10) (DecoderBatchTest.cpp:243-253, 145-201):
+    // verbose output with expected results ends with the decode-time lines and the edit-distance
+    // totals at HTK's insertion / deletion / substitution costs.  The alignment itself is Torch3's
+    // EditDistance (not in the tree): restated here as the usual minimum-cost alignment; the layout of
+    // the two totals lines is this build's own (parity unpinned).
+    if (outputFormat == "verbose" && haveExpResults) {
+        const int ci = 7, cd = 7, cs = 10;
+        long nIns = 0, nDel = 0, nSub = 0, nRef = 0, nSeq = 0, nSeqOk = 0;
+        for (size_t u = 0; u < files.size(); ++u) {
+            const std::vector<int> &a = actual[u], &e = expected[u];
+            const size_t A = a.size(), E = e.size();
+            std::vector<int> cost((A + 1) * (E + 1)), op((A + 1) * (E + 1));     // op: 0 ok, 1 sub, 2 ins, 3 del
+            for (size_t i = 0; i <= A; ++i)
+                for (size_t j = 0; j <= E; ++j) {
+                    int &c = cost[i * (E + 1) + j], &o = op[i * (E + 1) + j];
+                    if (!i && !j) { c = 0; o = 0; continue; }
+                    c = 0x7fffffff;
+                    if (i && j) { const bool eq = a[i - 1] == e[j - 1]; c = cost[(i - 1) * (E + 1) + j - 1] + (eq ? 0 : cs); o = eq ? 0 : 1; }
+                    if (i && cost[(i - 1) * (E + 1) + j] + ci < c) { c = cost[(i - 1) * (E + 1) + j] + ci; o = 2; }
+                    if (j && cost[i * (E + 1) + j - 1] + cd < c) { c = cost[i * (E + 1) + j - 1] + cd; o = 3; }
+                }
+            long ui = 0, ud = 0, us = 0;
+            for (size_t i = A, j = E; i || j;) {
+                const int o = op[i * (E + 1) + j];
+                if (o == 2) { ++ui; --i; } else if (o == 3) { ++ud; --j; } else { us += o; --i; --j; }
+            }
+            nIns += ui; nDel += ud; nSub += us; nRef += (long)E; ++nSeq; nSeqOk += (ui + ud + us) == 0;
+        }
+        printf("\nTotal time spent decoding = %.2f secs\n", decodeTime);
+        printf("Total amount of speech    = %.2f secs\n", speechTime);
+        printf("Real-time (RT) factor     = %.2f\n", speechTime > 0 ? decodeTime / speechTime : 0.0);
+        printf("total %ld: insert %ld / delete %ld / subst %ld / n_seq %ld / n_seq_correct %ld\n", nRef, nIns, nDel, nSub, nSeq, nSeqOk);
+        printf("accuracy %.2f  (insert %.2f%% / delete %.2f%% / subst %.2f%%)\n\n",
+               nRef ? 100.0 * (nRef - nIns - nDel - nSub) / nRef : 0.0, nRef ? 100.0 * nIns / nRef : 0.0,
+               nRef ? 100.0 * nDel / nRef : 0.0, nRef ? 100.0 * nSub / nRef : 0.0);
+    }
     jd_am_destroy(am);
     jd_net_destroy(net);
     return 0;

@@ -345,3 +345,101 @@ def test_binary_caches_and_htk_feature_files(small, tmp_path):
     for x, y in zip(a, b):
         assert x.n == y.n and np.array_equal(x.label, y.label) and np.array_equal(x.time, y.time)
         assert np.array_equal(x.score.view(np.uint32), y.score.view(np.uint32))
+
+
+def _align_counts(actual, expected, ci=7, cd=7, cs=10):
+    """Independent minimum-cost alignment (same tie order as the harness: match/sub, then ins, then del)."""
+    A, E = len(actual), len(expected)
+    cost = [[0] * (E + 1) for _ in range(A + 1)]
+    op = [[0] * (E + 1) for _ in range(A + 1)]
+    for i in range(A + 1):
+        for j in range(E + 1):
+            if i == 0 and j == 0:
+                continue
+            best, o = None, 0
+            if i and j:
+                eq = actual[i - 1] == expected[j - 1]
+                best, o = cost[i - 1][j - 1] + (0 if eq else cs), (0 if eq else 1)
+            if i and (best is None or cost[i - 1][j] + ci < best):
+                best, o = cost[i - 1][j] + ci, 2
+            if j and (best is None or cost[i][j - 1] + cd < best):
+                best, o = cost[i][j - 1] + cd, 3
+            cost[i][j], op[i][j] = best, o
+    i, j, ins, dele, sub = A, E, 0, 0, 0
+    while i or j:
+        o = op[i][j]
+        if o == 2:
+            ins += 1; i -= 1
+        elif o == 3:
+            dele += 1; j -= 1
+        else:
+            sub += o; i -= 1; j -= 1
+    return ins, dele, sub
+
+
+def test_batch_test_expected_results_and_error_totals(small, tmp_path):
+    """-refFName (DecoderBatchTest.cpp:804-939): reference transcripts as an MLF or one line per
+    file, 'Expected :' lines in verbose output, and the closing insertion/deletion/substitution
+    totals at HTK costs 7/7/10 (:145-201, :251)."""
+    import subprocess
+    from juicer_amd import build as jbuild, io as jio, synth
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    am, net, _, words = synth.config_small()
+    jio.write_fsm(tmp_path / "g.fsm", net)
+    jio.write_mmf(tmp_path / "m.mmf", am)
+    (tmp_path / "out.syms").write_text("<eps> 0\n" + "".join("W%d %d\n" % (i, i) for i in range(1, net.n_words + 1)))
+    lst = tmp_path / "list.txt"
+    with open(lst, "w") as f:
+        for u, x in enumerate(feats):
+            jio.write_htk(tmp_path / ("utt%02d.htk" % u), x)
+            f.write("%s\n" % (tmp_path / ("utt%02d.htk" % u)))
+    # the truth: generating words, with one word changed, one dropped and an out-of-vocabulary one
+    truth = [["W%d" % w for w in ws] for ws in words]
+    truth[0][1] = "W1" if truth[0][1] != "W1" else "W2"
+    truth[1] = truth[1][:-1]
+    truth[2] = truth[2] + ["NOTAWORD"]
+    (tmp_path / "ref.txt").write_text("".join(" ".join(t) + "\n" for t in truth))
+    with open(tmp_path / "ref.mlf", "w") as f:
+        f.write("#!MLF!#\n")
+        for u in reversed(range(len(feats))):                      # MLF entries are matched by name, any order
+            f.write('"*/utt%02d.lab"\n' % u + "".join(w + "\n" for w in truth[u]) + ".\n")
+    od = OracleDecoder(onet, oam, main_beam=150.0)
+    hyp = [(od.decode(x).label[::-1] - 1).tolist() for x in feats]
+    ids = lambda t, keep_oov: [int(w[1:]) - 1 if w[1:].isdigit() else -1 for w in t if keep_oov or w[1:].isdigit()]
+
+    def run(ref):
+        out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-htkModelsFName", str(tmp_path / "m.mmf"),
+                              "-outSymsFName", str(tmp_path / "out.syms"), "-inputFName", str(lst), "-mainBeam", "150",
+                              "-outputFormat", "verbose", "-refFName", str(ref)], capture_output=True, text=True, timeout=240)
+        assert out.returncode == 0, out.stderr
+        return out.stdout.splitlines(), out.stderr
+
+    for ref, keep_oov in ((tmp_path / "ref.txt", True), (tmp_path / "ref.mlf", False)):
+        lines, err = run(ref)
+        exp_lines = [l for l in lines if "Expected :" in l]
+        assert len(exp_lines) == len(feats)
+        for u, l in enumerate(exp_lines):
+            want = [w if w[1:].isdigit() else "<OOV>" for w in truth[u] if keep_oov or w[1:].isdigit()]
+            assert l.split(":", 1)[1].split() == want
+        if not keep_oov:
+            assert "Unknown word in ground truth" in err            # MLF: dropped with a warning (:876-880)
+        else:
+            assert any("result word NOTAWORD not in vocab" in l for l in lines)   # ref format: kept as <OOV> (:905-906)
+        tot = [0, 0, 0]
+        n_ref = 0
+        for u in range(len(feats)):
+            e = ids(truth[u], keep_oov)
+            c = _align_counts(hyp[u], e)
+            tot = [a + b for a, b in zip(tot, c)]
+            n_ref += len(e)
+        assert sum(tot) >= 2
+        line = [l for l in lines if l.startswith("total ")][0]
+        assert line.startswith("total %d: insert %d / delete %d / subst %d / n_seq %d" % (n_ref, tot[0], tot[1], tot[2], len(feats)))
+        assert any(l.startswith("Real-time (RT) factor") for l in lines)
+    # a transcript missing for one input file is an error before any decoding (:925-931)
+    (tmp_path / "short.mlf").write_text('#!MLF!#\n"*/utt00.lab"\nW1\n.\n')
+    out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-htkModelsFName", str(tmp_path / "m.mmf"),
+                          "-outSymsFName", str(tmp_path / "out.syms"), "-inputFName", str(lst), "-refFName", str(tmp_path / "short.mlf")],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "ref transcription not found" in out.stderr
