@@ -50,15 +50,24 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: juicer_amd has no CPU fallback")
+    # JD_BENCH_SHARE_GPU=1 (development only): all ranks use GPU 0 over gloo, to exercise the
+    # multi-rank code path on a one-GPU box; the reported numbers are meaningless then.
+    share_gpu = os.environ.get("JD_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if rank == 0:
         jbuild.build()
+    bar_kw = {} if share_gpu else {"device_ids": [local_rank]}
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(**bar_kw)
 
     U = args.utts_per_gpu
     am, net, feats, _ = synth.config_c2(seed=args.seed, n_utts=U, target_arcs=args.arcs,
@@ -81,7 +90,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(**bar_kw)
 
     for _ in range(args.warmup):
         step()
@@ -110,7 +119,7 @@ def main():
 
     if rank != 0:
         if world > 1:
-            dist.barrier(device_ids=[local_rank])      # rank 0 finishes its CPU baseline first
+            dist.barrier(**bar_kw)                      # rank 0 finishes its CPU baseline first
             dist.destroy_process_group()
         return
 
@@ -197,7 +206,7 @@ def main():
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(**bar_kw)
         dist.destroy_process_group()
 
 
