@@ -1388,6 +1388,7 @@ struct jd_dec {
     bool arenas_ready = false;
     int64_t cap_slots = 0, cap_paths = 0, cap_items = 0;
     int res_cap = 8192;
+    int *d_res = nullptr;                 // result arena, see ensure_arenas
     // chunked pipeline
     int Fc = 128;
     float *d_ll[2] = {nullptr, nullptr};
@@ -1600,6 +1601,8 @@ static int ensure_arenas(jd_dec *d)
     d->C.cap_slots = (int)d->cap_slots; d->C.cap_items = (int)d->cap_items; d->C.cap_paths = (int)d->cap_paths;
     d->C.gc_threshold = (int)(d->cap_paths / 2);
     d->h_streams.assign((size_t)B, StreamDev());
+    rc = dmalloc(d, &d->d_res, (size_t)B * 5 * d->res_cap);
+    if (rc) return rc;
     for (int s = 0; s < B; ++s) {
         StreamDev &S = d->h_streams[(size_t)s];
         memset(&S, 0, sizeof S);
@@ -1612,8 +1615,13 @@ static int ensure_arenas(jd_dec *d)
         A(S.item_tok, d->cap_items); A(S.item_info, d->cap_items);
         A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths);
         A(S.hist, HIST_MAX_BINS);
-        A(S.res_label, d->res_cap); A(S.res_time, d->res_cap);
-        A(S.res_score, d->res_cap); A(S.res_ac, d->res_cap); A(S.res_lm, d->res_cap);
+        {   // the five result arrays of all streams live in one arena [stream][array][res_cap]:
+            // fetch_results brings a whole wave back with a single strided copy
+            int *base = d->d_res + (size_t)s * 5 * d->res_cap;
+            S.res_label = base; S.res_time = base + d->res_cap;
+            S.res_score = (float *)(base + 2 * (size_t)d->res_cap); S.res_ac = (float *)(base + 3 * (size_t)d->res_cap);
+            S.res_lm = (float *)(base + 4 * (size_t)d->res_cap);
+        }
 #undef A
         S.res_cap = d->res_cap;
         reset_ast(S.ast, d->net->n_arcs);
@@ -1661,6 +1669,12 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
     HIPCHK(hipMemcpy(hs.data(), d->d_streams + s0, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hc.data(), d->d_ctl + s0, (size_t)n * sizeof(StreamCtl), hipMemcpyDeviceToHost));
     int first_err = JD_OK;
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) kmax = std::max(kmax, std::min(hs[(size_t)i].res_n, d->res_cap));
+    std::vector<int> hres((size_t)n * 5 * std::max(kmax, 0));
+    if (kmax > 0)                                                      // rows = (stream, array), first kmax words of each
+        HIPCHK(hipMemcpy2D(hres.data(), (size_t)kmax * 4, d->d_res + (size_t)s0 * 5 * d->res_cap, (size_t)d->res_cap * 4,
+                           (size_t)kmax * 4, (size_t)n * 5, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
         const StreamDev &S = hs[(size_t)i];
         const StreamCtl &K = hc[(size_t)i];
@@ -1707,11 +1721,10 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
         const size_t kk = (size_t)std::max(k, 0);
         R.label.resize(kk); R.time.resize(kk); R.score.resize(kk); R.ac.resize(kk); R.lm.resize(kk);
         if (kk) {
-            HIPCHK(hipMemcpy(R.label.data(), S.res_label, kk * sizeof(int), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(R.time.data(), S.res_time, kk * sizeof(int), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(R.score.data(), S.res_score, kk * sizeof(float), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(R.ac.data(), S.res_ac, kk * sizeof(float), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(R.lm.data(), S.res_lm, kk * sizeof(float), hipMemcpyDeviceToHost));
+            const int *row = hres.data() + (size_t)i * 5 * kmax;
+            memcpy(R.label.data(), row, kk * 4); memcpy(R.time.data(), row + kmax, kk * 4);
+            memcpy(R.score.data(), row + 2 * (size_t)kmax, kk * 4); memcpy(R.ac.data(), row + 3 * (size_t)kmax, kk * 4);
+            memcpy(R.lm.data(), row + 4 * (size_t)kmax, kk * 4);
         }
         H.label = R.label.data(); H.time = R.time.data();
         H.score = R.score.data(); H.ac = R.ac.data(); H.lm = R.lm.data();
