@@ -132,6 +132,68 @@ def make_models(seed: int, n_gmm: int, n_hmm: int, n_mix: int, D: int = 39,
                    n_tm=n_tm_tot, tm_nstates=tm_nstates, transp=transp, sp_hmm=sp)
 
 
+def make_models_mixed(seed: int, n_gmm: int, n_hmm: int, n_mix: int, D: int = 39,
+                      sizes=(3, 4, 5, 6, 7, 8), with_tee: bool = True, sep: float = 1.0) -> SynthAM:
+    """HMMs of mixed topology: `sizes` = total state counts (entry + emitting + exit), i.e. 1 to 6
+    emitting states, left-to-right with occasional skips; one transition matrix per HMM size and
+    variant.  Exercises the 8-lane instance layout (more than 3 emitting states) and HMMs of
+    different lengths side by side.  With with_tee the last HMM is a 3-state tee model."""
+    rng = np.random.default_rng(seed)
+    max_n = max(sizes)
+    centre = rng.normal(0.0, sep, size=(n_gmm, 1, D))
+    mean = (centre + rng.normal(0.0, 0.5 * sep, size=(n_gmm, n_mix, D))).astype(np.float32)
+    var = rng.uniform(0.3, 3.0, size=(n_gmm, n_mix, D)).astype(np.float32)
+    wraw = rng.gamma(2.0, 1.0, size=(n_gmm, n_mix))
+    wraw = np.maximum(wraw / wraw.sum(axis=1, keepdims=True), 1e-3)
+    weight = (wraw / wraw.sum(axis=1, keepdims=True)).astype(np.float32)
+    if n_mix == 1:
+        weight[:] = 1.0
+    variants = 3
+    tms, tm_n = [], []
+    for n in sizes:
+        for v in range(variants):
+            a = np.zeros((max_n, max_n), np.float32)
+            a[0, 1] = 1.0
+            for j in range(1, n - 1):
+                stay = rng.uniform(0.5, 0.8)
+                a[j, j] = stay
+                if v == 2 and j + 2 <= n - 1 and n > 3:            # a skip: two successors besides the loop
+                    sk = np.float32(0.3 * (1.0 - stay))
+                    a[j, j + 2] = sk
+                    a[j, j + 1] = np.float32(1.0 - stay - sk)
+                else:
+                    a[j, j + 1] = np.float32(1.0 - stay)
+            if v == 1 and n > 4:                                   # entry may also start in the second emitting state
+                a[0, 1], a[0, 2] = 0.7, 0.3
+            tms.append(a); tm_n.append(n)
+    tee_tm = -1
+    if with_tee:
+        a = np.zeros((max_n, max_n), np.float32)
+        a[0, 1], a[0, 2], a[1, 1], a[1, 2] = 0.6, 0.4, 0.7, 0.3
+        tms.append(a); tm_n.append(3); tee_tm = len(tms) - 1
+    hmm_nstates = np.zeros(n_hmm, np.int32)
+    hmm_tm = np.zeros(n_hmm, np.int32)
+    hmm_gmm = np.full((n_hmm, max_n), -1, np.int32)
+    # tied states are handed out without replacement while they last: two adjacent phones sharing
+    # a tied state AND a transition matrix tie exactly (stay-then-move == move-then-stay)
+    pool = list(rng.permutation(n_gmm))
+    for h in range(n_hmm):
+        k = int(rng.integers(0, len(sizes) * variants))
+        hmm_tm[h] = k; hmm_nstates[h] = tm_n[k]
+        for j in range(1, tm_n[k] - 1):
+            hmm_gmm[h, j] = pool.pop() if pool else int(rng.integers(0, n_gmm))
+    sp = -1
+    if with_tee:
+        sp = n_hmm - 1
+        hmm_tm[sp] = tee_tm; hmm_nstates[sp] = 3
+        hmm_gmm[sp, :] = -1
+        hmm_gmm[sp, 1] = int(rng.integers(0, n_gmm))
+    return SynthAM(D=D, n_gmm=n_gmm, max_mix=n_mix, n_mix=np.full(n_gmm, n_mix, dtype=np.int32), weight=weight,
+                   mean=mean, var=var, n_hmm=n_hmm, max_n=max_n, hmm_nstates=hmm_nstates, hmm_gmm=hmm_gmm,
+                   hmm_tm=hmm_tm, n_tm=len(tms), tm_nstates=np.asarray(tm_n, np.int32),
+                   transp=np.stack(tms).astype(np.float32), sp_hmm=sp)
+
+
 def make_wfst(seed: int, am: SynthAM, n_words: int, n_succ: int,
               pron_len=(2, 5), with_sp: bool = False, hub: str = "flat",
               n_phones: int = 40, eps_word_frac: float = 0.02) -> SynthNet:
@@ -510,6 +572,19 @@ def config_small(seed: int = 7, n_utts: int = 4, with_sp: bool = True, sep: floa
     feats, words = [], []
     for u in range(n_utts):
         x, w = sample_utterance(seed + 1000 + u, net, am, int(rng.integers(utt_words[0], utt_words[1] + 1)))
+        feats.append(x); words.append(w)
+    return am, net, feats, words
+
+
+def config_mixed(seed: int = 11, n_utts: int = 4, sizes=(3, 4, 5, 6, 7, 8), with_sp: bool = True,
+                 n_words: int = 40, n_succ: int = 5):
+    """~10k-arc regression case with HMMs of 1..6 emitting states (8-lane instance records)."""
+    am = make_models_mixed(seed, n_gmm=220, n_hmm=36, n_mix=3, sizes=sizes, with_tee=with_sp, sep=0.7)
+    net = make_wfst(seed + 100, am, n_words=n_words, n_succ=n_succ, with_sp=with_sp)
+    rng = np.random.default_rng(seed + 300)
+    feats, words = [], []
+    for u in range(n_utts):
+        x, w = sample_utterance(seed + 1000 + u, net, am, int(rng.integers(5, 11)))
         feats.append(x); words.append(w)
     return am, net, feats, words
 

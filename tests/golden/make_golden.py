@@ -27,6 +27,10 @@ CASES = {
     "small": (lambda: synth.config_small(), [
         dict(main_beam=150.0), dict(main_beam=150.0, max_hyps=200),
         dict(main_beam=120.0, end_beam=90.0, word_beam=70.0, start_beam=100.0, max_hyps=150)]),
+    # HMMs with 1..6 emitting states, skips, double entries, tee model (the 8-lane instance layout)
+    "mixed": (lambda: synth.config_mixed(), [
+        dict(main_beam=150.0), dict(main_beam=150.0, end_beam=100.0, word_beam=80.0, start_beam=120.0),
+        dict(main_beam=120.0, end_beam=90.0, word_beam=70.0, start_beam=100.0, max_hyps=150)]),
 }
 
 

@@ -97,6 +97,36 @@ def test_small_decode_batch(small, bi):
     print("bit-exact utterances: %d / %d" % (nexact, len(feats)))
 
 
+@pytest.fixture(scope="module")
+def mixed(built):
+    from juicer_amd import synth
+    return _setup(synth.config_mixed())
+
+
+@pytest.mark.parametrize("bi", range(len(BEAMS)))
+def test_mixed_topology_decode(mixed, bi):
+    """HMMs with 1 to 6 emitting states side by side (3..8 states incl. entry/exit), skip and
+    double-entry transitions, the tee model between words: the 8-lane instance layout
+    (k_phase_a<8>, 256-byte records) against the oracle."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, words = mixed
+    assert gam.max_states == 8
+    kw = BEAMS[bi]
+    big = (1 << 25) if kw.get("main_beam", 0.0) in (0.0, 200.0) and not kw.get("max_hyps") else 0
+    gd = capi.Decoder(gnet, gam, max_streams=len(feats), max_paths=big, **kw)
+    od = OracleDecoder(onet, oam, **kw)
+    gs = gd.decode_batch(feats)
+    checked = 0
+    for u, x in enumerate(feats):
+        o = od.decode(x)
+        # equal-score recombinations (homophones in the tiny lexicon) never sat on the best path
+        # here: labels, times and scores must agree; the work counters only when tie-free
+        assert_hyp_matches(gs[u], o, "mixed utt %d %s" % (u, kw), check_stats=(o.stats["ties"] == 0))
+        checked += o.stats["ties"] == 0
+    assert checked >= 1 or not kw
+
+
 def test_more_utts_than_streams(small):
     """decode_batch with n_utts > max_streams runs in waves and re-inits streams."""
     from juicer_amd import capi
@@ -443,3 +473,41 @@ def test_batch_test_expected_results_and_error_totals(small, tmp_path):
                           "-outSymsFName", str(tmp_path / "out.syms"), "-inputFName", str(lst), "-refFName", str(tmp_path / "short.mlf")],
                          capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "ref transcription not found" in out.stderr
+
+
+@pytest.mark.parametrize("case", ["toy", "small", "mixed"])
+def test_hip_path_matches_committed_golden_vectors(built, case):
+    """The HIP path against tests/golden/oracle_golden.json directly (no oracle at run time):
+    labels and word-end frames identical, scores within 1e-4 relative (bit-exact counted),
+    the reference's statistics identical on tie-free utterances."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    from helpers import STAT_KEYS, rel_close
+    from juicer_amd import capi
+    g = json.load(open(os.path.join(here, "golden", "oracle_golden.json")))[case]
+    am, net, feats, _ = make_golden.CASES[case][0]()
+    assert make_golden.input_digest(am, net, feats) == g["input_sha256"], "synthetic generator changed"
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    unhex = lambda hs: np.frombuffer(bytes.fromhex("".join(hs)), np.float32) if hs else np.zeros(0, np.float32)
+    exact = total = 0
+    for run in g["runs"]:
+        hyps = capi.Decoder(gnet, gam, max_streams=len(feats), **run["beams"]).decode_batch(feats)
+        for u, (h, want) in enumerate(zip(hyps, run["utts"])):
+            what = "%s %s utt %d" % (case, run["beams"], u)
+            assert h.n == want["n"], what
+            assert h.label.tolist() == want["label"] and h.time.tolist() == want["time"], what
+            for f in ("score", "ac", "lm"):
+                w = unhex(want[f + "_hex"])
+                assert rel_close(getattr(h, f), w), what + " " + f
+                exact += int(np.array_equal(getattr(h, f).view(np.uint32), w.view(np.uint32))); total += 1
+            tot = unhex(want["tot"])
+            assert rel_close([h.tot_score, h.tot_ac, h.tot_lm], tot), what
+            if want["stats"]["ties"] == 0:
+                for k in STAT_KEYS:
+                    assert h.stats[k] == want["stats"][k], "%s stat %s" % (what, k)
+    print("bit-exact score arrays: %d / %d" % (exact, total))
+    assert exact >= total * 0.9

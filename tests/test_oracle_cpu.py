@@ -21,7 +21,7 @@ def _hex32(a):
     return [np.float32(v).tobytes().hex() for v in a]
 
 
-@pytest.mark.parametrize("case", ["toy", "small"])
+@pytest.mark.parametrize("case", ["toy", "small", "mixed"])
 def test_oracle_matches_golden(built, golden, case):
     import make_golden
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
