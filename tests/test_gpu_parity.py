@@ -511,3 +511,39 @@ def test_hip_path_matches_committed_golden_vectors(built, case):
                     assert h.stats[k] == want["stats"][k], "%s stat %s" % (what, k)
     print("bit-exact score arrays: %d / %d" % (exact, total))
     assert exact >= total * 0.9
+
+
+def test_ragged_mixture_counts(built):
+    """GMMs with different numbers of mixture components (the flat arrays are padded to the
+    largest, HTKFlatModels.cpp:113,145): scores bit-exact, decode identical to the oracle."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small()
+    rng = np.random.default_rng(5)
+    am.n_mix = rng.integers(1, am.max_mix + 1, size=am.n_gmm).astype(np.int32)
+    for g in range(am.n_gmm):                                   # weights of the kept components sum to one
+        k = int(am.n_mix[g])
+        am.weight[g, k:] = 0.0
+        am.weight[g, :k] = am.weight[g, :k] / am.weight[g, :k].sum() if k > 1 else 1.0
+    gam, oam = capi.Models.from_htk(am), OracleAM(am)
+    for a, b in zip(gam.flat(), oam.flat()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    x = np.concatenate(feats)[:300]
+    assert np.array_equal(gam.score_frames(x).view(np.uint32), oam.score_frames(x).view(np.uint32))
+    kw = dict(main_beam=150.0)
+    gs = capi.Decoder(capi.Network.from_synth(net), gam, max_streams=len(feats), **kw).decode_batch(feats)
+    od = OracleDecoder(OracleNet(net), oam, **kw)
+    for u, f in enumerate(feats):
+        o = od.decode(f)
+        assert_hyp_matches(gs[u], o, "ragged utt %d" % u, check_stats=(o.stats["ties"] == 0))
+
+
+def test_histogram_too_wide_is_refused(small):
+    """The histogram spans [-(beam+800)-1, 201] in unit bins (WFSTDecoderLite.cpp:76-82); the
+    kernel keeps it in LDS, so a beam that needs more bins than fit is an error at creation."""
+    from juicer_amd import capi
+    gnet, gam = small[0], small[1]
+    capi.Decoder(gnet, gam, main_beam=1000.0, max_hyps=100, max_streams=1)
+    with pytest.raises(capi.JuicerAmdError) as e:
+        capi.Decoder(gnet, gam, main_beam=1200.0, max_hyps=100, max_streams=1)
+    assert "histogram" in str(e.value).lower()
