@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 #define TEE_FLAG 0x40000000          // bit 30 of the device arc's in-label: the arc's HMM is a tee model
 #define KT 256                       // threads per block of the small search kernels (tail)
 #define KTB 256                      // threads per block of the flattened kernels (phase A, expand, resolve)
-#define EG 16                        // lanes cooperating on one frontier item
+#ifndef JD_EG
+#define JD_EG 16
+#endif
+#define EG JD_EG                     // lanes owning one frontier item (its arcs are pooled per wave)
 
 struct DecConst {
     // network (CSR in HBM)
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
 // arcs are staged in LDS and appended to the stream's list with one atomic per unit.
 #define TBS_CAP 256                  // per-wave stage of first-touched arcs
 #define ITS_CAP 64                   // per-wave stage of produced frontier items
-struct WaveStage { int buf[TBS_CAP]; Tok itok[ITS_CAP]; int4 iinfo[ITS_CAP]; };
+struct WaveStage { int buf[TBS_CAP]; int pfx[64 / EG + 1]; Tok itok[ITS_CAP]; int4 iinfo[ITS_CAP]; };
 struct BlockStage { int np; int pb; WaveStage w[KTB / 64]; };
 // Fill levels of the calling wave's stage.  They live in REGISTERS, computed identically by
 // all 64 lanes from wave-uniform ballots: an LDS counter written by lane 0 and re-read by the
@@ -806,14 +809,24 @@ __device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, con
                                             WaveFill &fill, const Tok &t, int ii, int rs, int deg, float endTh, float wordTh,
                                             const ItemSink &sink, int &n_arcs)
 {
-    static_assert(EG == 16, "expand_arcs pools the arcs of 4 items per wave");
+    constexpr int NGRP = 64 / EG;                                      // items per wave
     const int lane = lane_id();
-    const int p1 = __shfl(deg, 0), p2 = p1 + __shfl(deg, EG), p3 = p2 + __shfl(deg, 2 * EG);
-    const int tot = p3 + __shfl(deg, 3 * EG);
+    // exclusive prefix of the groups' degrees (group leaders carry deg, other lanes 0)
+    int incl = ((lane & (EG - 1)) == 0) ? deg : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+    const int tot = __shfl(incl, 63);
+    int *pfx = stage.w[threadIdx.x >> 6].pfx;                          // wave-private, NGRP + 1 entries
+    WAVE_LDS_ORDER();
+    if ((lane & (EG - 1)) == 0) pfx[lane / EG] = incl - deg;
+    if (lane == 0) pfx[NGRP] = tot;
+    WAVE_LDS_ORDER();
     for (int a0 = 0; a0 < tot; a0 += 64) {
         const int a = a0 + lane;
-        const int g = (a >= p3) ? 3 : (a >= p2) ? 2 : (a >= p1) ? 1 : 0;
-        const int off = a - ((g == 3) ? p3 : (g == 2) ? p2 : (g == 1) ? p1 : 0);
+        int g = 0;                                                     // largest g with pfx[g] <= a
+#pragma unroll
+        for (int st = NGRP / 2; st > 0; st >>= 1) if (pfx[g + st] <= a) g += st;
+        const int off = a - pfx[g];
         const int srcl = g * EG;
         Tok tg;
         tg.score = __shfl(t.score, srcl); tg.ac = __shfl(t.ac, srcl);
