@@ -97,6 +97,7 @@ def main():
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     gmm_ms = search_ms = 0.0
+    tm = {}
     gmm_launches = search_steps = ksamples = 0
     kernel_us = [0.0] * 6
     hyps = None
@@ -133,18 +134,19 @@ def main():
     st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals
     lock_steps = max(1, search_steps // steps)                            # launches of each search kernel per step
     gmm_l = max(1, gmm_launches // steps)
+    names = [n for n in capi.kernel_names(tm) if n]
+    expand_name = "k_expand_closure" if tm.get("closure_inline") else "k_expand<0>"
     per_launch_bytes = {
         # token read + write (16-B tokens), arc->hmm lookup, likelihood gather
         "k_phase_a": ((32.0 * MN + 4.0) * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]) / lock_steps,
         # exit token + CSR bounds, arc records + slot map, Path records
-        "k_expand<0>": (24.0 * st["tot_proc_end_hyps"] + 20.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"]) / lock_steps,
+        expand_name: (24.0 * st["tot_proc_end_hyps"] + 20.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"]) / lock_steps,
         # destination entry-token read-modify-write
         "k_resolve": 32.0 * st["tot_arcs_visited"] / lock_steps,
         # parameters once per launch + features
         "jd_gmm_kernel": G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / gmm_l,
     }
-    names = list(capi.KERNEL_NAMES)
-    avg_us = {n: (kernel_us[i] / ksamples if ksamples else 0.0) for i, n in enumerate(names)}
+    avg_us = {n: (kernel_us[i] / ksamples if ksamples else 0.0) for i, n in enumerate(capi.kernel_names(tm)) if n}
     avg_us["jd_gmm_kernel"] = 1e3 * gmm_ms / max(1, gmm_launches)
     # share of a step's GPU time: sampled average x launches per step
     tot_ms = {n: avg_us[n] * lock_steps / 1e3 for n in names}

@@ -158,6 +158,8 @@ typedef struct jd_stats {          /* WFSTDecoderLite.cpp:231-241 + build counte
     int64_t tot_active_models;     /* totalActiveModels   */
     int64_t tot_proc_emit_hyps;    /* totalProcEmitHyps   */
     int64_t tot_proc_end_hyps;     /* totalProcEndHyps    */
+    /* work the GPU path actually did: at most the reference's figures (only the best tokens
+     * per destination state are expanded) and, with the inline closure, slightly run-dependent */
     int64_t tot_arcs_visited;      /* out-arcs visited by propagateToken (A)      */
     int64_t tot_paths;             /* Path records created (Wd)                    */
     int64_t tot_insts_in;          /* instances processed by internal propagation (Mdl) */
@@ -240,11 +242,14 @@ typedef struct jd_timing {
     int32_t gmm_launches, search_launches;   /* chunk-level launches (search: runs of steps)    */
     int64_t gmm_frames;       /* stream-frames scored                           */
     int64_t gmm_states;       /* tied states scored per frame                    */
-    int64_t search_steps;     /* lock-step frames executed                        */
+    int64_t search_steps;     /* lock-step frames executed (= launches of each search kernel) */
     /* summed duration (us) of each search kernel over the sampled steps, in launch order:
-     * k_boundary, k_phase_a, k_expand<0>, k_expand<1>, k_expand_tail, k_resolve */
+     * k_boundary, k_phase_a, k_expand<0>, k_expand<1>, k_expand_tail, k_resolve; with
+     * closure_inline, slot 2 is k_expand_closure and slots 3 and 4 are not launched (0) */
     double kernel_us[6];
     int32_t kernel_samples;   /* number of sampled steps                          */
+    int32_t closure_inline;   /* 1: the network's epsilon/tee closures are small enough (static
+                               * bound) to run inside the expansion kernel: 4 launches per frame */
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 

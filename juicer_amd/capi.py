@@ -46,9 +46,15 @@ class Timing(C.Structure):
     _fields_ = [("gmm_ms", C.c_double), ("search_ms", C.c_double), ("total_ms", C.c_double),
                 ("gmm_launches", C.c_int32), ("search_launches", C.c_int32),
                 ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64), ("search_steps", C.c_int64),
-                ("kernel_us", C.c_double * 6), ("kernel_samples", C.c_int32)]
+                ("kernel_us", C.c_double * 6), ("kernel_samples", C.c_int32), ("closure_inline", C.c_int32)]
 
 KERNEL_NAMES = ["k_boundary", "k_phase_a", "k_expand<0>", "k_expand<1>", "k_expand_tail", "k_resolve"]
+# launch slots when the network's closures run inline (jd_timing.closure_inline): slots 3, 4 unused
+KERNEL_NAMES_INLINE = ["k_boundary", "k_phase_a", "k_expand_closure", None, None, "k_resolve"]
+
+
+def kernel_names(timing: dict):
+    return KERNEL_NAMES_INLINE if timing.get("closure_inline") else KERNEL_NAMES
 
 
 @dataclass

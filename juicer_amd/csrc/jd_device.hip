@@ -232,6 +232,7 @@ struct DecConst {
     // arena capacities (per stream)
     int cap_slots, cap_items, cap_paths;
     int gc_threshold;   // collect Path records when more than this many are in use
+    int inline_closure; // epsilon/tee closures are small (static bound): done inside k_expand_closure
     // diagnostics (jd_dec_debug_trace): per-block wall_clock64 stamps of one chosen frame
     long long *dbg; int dbg_frame;
 };
@@ -275,6 +276,7 @@ struct __align__(128) StreamCtl {
     __align__(128) int cnt2;                 // items produced by frontier round 1
     __align__(128) int cnt_tail;             // items produced by the tail rounds
     __align__(128) int n_touched;
+    __align__(128) int n_dirty;              // states whose closure key (skey[1]) is non-zero this frame (inline closure)
     __align__(128) int n_alloc;              // instances attached this frame (= new active entries)
     __align__(128) int n_skipped;            // hopeless instances not materialised this frame
     __align__(128) int n_paths;              // Path records in use at frame start (updated by k_boundary)
@@ -296,6 +298,7 @@ struct StreamDev {      // per-stream arenas (cold)
     unsigned long long *skey[2];      // per STATE: best frontier item arriving there (round parity)
     unsigned long long *skeyL;        // round 0 only: items whose arc carries a word label (own threshold)
     int *touched;                     // arcs whose ekey became non-zero this frame
+    int *dirty;                       // inline closure: states whose skey[1] entry became non-zero this frame
     Tok *item_tok; int4 *item_info;   // frontier items: token + {arc, outLabel, toState, -}
     PathRec *paths; int *hist;
     PathRec *paths2; int *gc_idx;     // Path garbage collection: compaction target + mark / new-index array
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
             c.best = f2o(LZ); c.pkA = 1ULL << PK_SHIFT1;                         // cnt0 = 1: the start token
             c.pkE = 0ULL;
             c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
-            c.n_alloc = 0; c.n_touched = 0; c.final_key = 0ULL; c.n_skipped = 0; c.skipped_prev = 0;
+            c.n_alloc = 0; c.n_touched = 0; c.n_dirty = 0; c.final_key = 0ULL; c.n_skipped = 0; c.skipped_prev = 0;
             c.n_paths_extra = 0;
             for (int k = 0; k < ST_N; ++k) { c.fr[k] = 0; c.st[k] = 0; }
             c.best_final = null_tok();
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         c.startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;       // :337
         c.best = f2o(LZ); c.pkA = 0ULL; c.pkE = 0ULL;                            // :905
         c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
-        c.n_alloc = 0; c.n_touched = 0; c.n_skipped = 0; c.n_paths_extra = 0;
+        c.n_alloc = 0; c.n_touched = 0; c.n_dirty = 0; c.n_skipped = 0; c.n_paths_extra = 0;
         c.final_key = 0ULL;                                                      // :316 bestFinalToken = nullToken
         if (v_active != 1) c.active = 1;
     }
@@ -687,14 +690,22 @@ __global__ __launch_bounds__(KTB) void k_phase_a(DecConst C, StreamCtl *ctl, Str
 // Block-level aggregation: Path records are allocated with one atomic per unit, first-touched
 // arcs are staged in LDS and appended to the stream's list with one atomic per unit.
 #define TBS_CAP 256                  // per-wave stage of first-touched arcs
-#define ITS_CAP 64                   // per-wave stage of produced frontier items
-struct WaveStage { int buf[TBS_CAP]; int pfx[64 / EG + 1]; Tok itok[ITS_CAP]; int4 iinfo[ITS_CAP]; };
+#define ITS_CAP 64                   // per-wave stage of produced frontier items / inline-closure queue
+#define DS_CAP 128                   // per-wave stage of dirty states (inline closure)
+#define INLINE_CLOSURE_MAX (ITS_CAP / (64 / EG))   // largest closure per item the inline queue can hold
+struct WaveStage { int buf[TBS_CAP]; int pfx[64 / EG + 1]; int qpos[ITS_CAP]; int dbuf[DS_CAP];
+                   Tok itok[ITS_CAP]; int4 iinfo[ITS_CAP]; };
 struct BlockStage { int np; int pb; WaveStage w[KTB / 64]; };
 // Fill levels of the calling wave's stage.  They live in REGISTERS, computed identically by
 // all 64 lanes from wave-uniform ballots: an LDS counter written by lane 0 and re-read by the
 // others is a data race in the per-thread memory model (the compiler may forward a lane's own
 // earlier load past another lane's store), and it measurably was one.
-struct WaveFill { int n; int ni; };
+struct WaveFill {
+    int n; int ni;                  // touched arcs / produced items staged
+    int nd;                         // dirty states staged                       (inline closure)
+    int qh, qt;                     // closure queue window in itok/iinfo/qpos   (inline closure)
+    int cb, cl;                     // next free global item index of the wave's reserved chunk, indices left
+};
 // LDS traffic between lanes of ONE wave needs no hardware fence (a wave's LDS operations execute
 // in order); the compiler just must not move or forward memory accesses across this point.
 #define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
@@ -800,11 +811,86 @@ __device__ __forceinline__ void stage_flush_block(const DecConst &C, StreamCtl &
     f.n = 0; f.ni = 0;
 }
 
+// ---- inline closure (DecConst::inline_closure).  When the graph's epsilon / tee closures are
+// provably small (jd_dec_create bounds them), the wave that produces a closure item expands it
+// itself, right after the unit that produced it, instead of handing it to another kernel:
+// one launch replaces k_expand<0>, k_expand<1> and k_expand_tail.  State-level recombination
+// becomes a RUNNING maximum on skey[1]: an item is expanded iff it is the best arrival at its
+// state so far (checked when produced and again when taken from the queue), so the best one is
+// always expanded and a state is expanded O(log arrivals) times instead of once - same results.
+// Touched skey[1] entries are listed ("dirty") and zeroed by k_resolve.
+__device__ __forceinline__ void stage_dirty(const DecConst &C, StreamCtl &c, const StreamDev &S, WaveStage &w,
+                                            WaveFill &f, bool first, int state)
+{
+    const unsigned long long bf = __ballot(first);
+    if (!bf) return;
+    const int cnt = __popcll(bf);
+    if (f.nd + cnt > DS_CAP) {
+        WAVE_LDS_ORDER();
+        int base = 0;
+        if (lane_id() == 0) base = atomicAdd(&c.n_dirty, f.nd);
+        base = __shfl(base, 0);
+        for (int k = lane_id(); k < f.nd; k += 64) {
+            if (base + k < C.cap_items) S.dirty[base + k] = w.dbuf[k]; else c.error = -42;
+        }
+        WAVE_LDS_ORDER();
+        f.nd = 0;
+    }
+    if (first) w.dbuf[f.nd + rank_in(bf)] = state;
+    f.nd += cnt;
+}
+
+__device__ __forceinline__ void closure_push(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &st,
+                                             WaveFill &f, const ItemSink &sink, bool mk, const Tok &u, const int4 &uinfo)
+{
+    WaveStage &w = st.w[threadIdx.x >> 6];
+    // cheap pre-filter: not better than the best arrival so far -> nothing downstream can win
+    bool pass = false;
+    unsigned so = 0;
+    if (mk) {
+        so = f2o(u.score);
+        const unsigned long long cur = __hip_atomic_load(sink.sk_out + uinfo.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pass = so > (unsigned)(cur >> 32);
+    }
+    const unsigned long long bp = __ballot(pass);
+    if (!bp) return;
+    const int cnt = __popcll(bp);
+    // global item indices (k_resolve / bestFinal find the token through them) from the wave's
+    // reserved chunk: one atomic per 64 indices; unused indices are harmless holes
+    if (f.cl < cnt) {
+        int b = 0;
+        if (lane_id() == 0) b = atomicAdd(sink.counter, 64);
+        f.cb = sink.base + __shfl(b, 0); f.cl = 64;
+    }
+    const int pos = f.cb + rank_in(bp);
+    f.cb += cnt; f.cl -= cnt;
+    bool keep = false, first = false;
+    if (pass) {
+        if (pos < C.cap_items) {
+            const unsigned long long key = ((unsigned long long)so << 32) | (unsigned)pos;
+            const unsigned long long old = atomicMax(sink.sk_out + uinfo.z, key);
+            keep = key > old; first = old == 0ULL;
+        } else c.error = -42;
+    }
+    stage_dirty(C, c, S, w, f, first, uinfo.z);
+    const unsigned long long bk = __ballot(keep);
+    if (!bk) return;
+    const int nk = __popcll(bk);
+    if (f.qt + nk > ITS_CAP) { c.error = -42; return; }                // excluded by the static closure bound
+    if (keep) {
+        S.item_tok[pos] = u; S.item_info[pos] = uinfo;
+        const int k = f.qt + rank_in(bk);
+        w.itok[k] = u; w.iinfo[k] = uinfo; w.qpos[k] = pos;
+    }
+    f.qt += nk;
+}
+
 // arc walk of one wave.  The wave's 64/EG items pool their out-arcs: lane l takes arcs
 // l, l+64, ... of the concatenated arc ranges and fetches the owning item's token from that
 // item's lanes, so a state with thousands of out-arcs (trigram back-off / history states)
 // occupies the whole wave instead of one EG-lane group, and items with few arcs share a pass.
 // t / ii / rs / deg are uniform within an EG-lane group.
+template <bool INLINE>
 __device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
                                             WaveFill &fill, const Tok &t, int ii, int rs, int deg, float endTh, float wordTh,
                                             const ItemSink &sink, int &n_arcs)
@@ -866,13 +952,15 @@ __device__ __forceinline__ void expand_arcs(const DecConst &C, StreamCtl &c, con
             }
         }
         stage_touch(C, c, S, stage, fill, touch, tb);
-        stage_item(C, c, S, stage, fill, sink, mk, u, uinfo);
+        if (INLINE) closure_push(C, c, S, stage, fill, sink, mk, u, uinfo);
+        else stage_item(C, c, S, stage, fill, sink, mk, u, uinfo);
     }
 }
 
 // One unit = KT/EG items of one stream.  All threads of the block call this.
 //   sk_in_u / sk_in_l : per-state key arrays of this round (unlabelled / word-labelled class)
 //   check_th          : apply the end/word threshold of doHMMExternalPropagation (:952-962) (round 0)
+template <bool INLINE>
 __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
                                             WaveFill &fill, int frame, bool last_frame, bool path_direct, int path_base_extra,
                                             float endTh, float wordTh, bool check_th,
@@ -962,14 +1050,80 @@ __device__ __forceinline__ void expand_unit(const DecConst &C, StreamCtl &c, con
         deg = rs1 - rs;
     }
     if (dbx) dbx[2] = wall_clock64();                                  // path / final done
-    expand_arcs(C, c, S, stage, fill, t, ii, rs, deg, endTh, wordTh, sink, n_arcs);
+    expand_arcs<INLINE>(C, c, S, stage, fill, t, ii, rs, deg, endTh, wordTh, sink, n_arcs);
     if (dbx) dbx[3] = wall_clock64();                                  // arcs walked
 }
 
-// frontier rounds 0 and 1, flattened over all streams.  ROUND 0 reads the live exit tokens
-// written (and bid for their destination states) by phase A.
-template <int ROUND>
-__global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS)
+// inline closure: the wave takes up to 64/EG items from its queue and expands them (which may
+// queue more).  No block barriers: every wave of the block runs its own closure.
+__device__ __forceinline__ void closure_step(const DecConst &C, StreamCtl &c, const StreamDev &S, BlockStage &stage,
+                                             WaveFill &fill, int frame, bool last_frame, int path_base_extra,
+                                             float endTh, float wordTh, const ItemSink &sink,
+                                             int &n_arcs, int &n_paths_made)
+{
+    constexpr int NGRP = 64 / EG;
+    const int lane = lane_id();
+    const int er = lane & (EG - 1), eb = lane & ~(EG - 1);
+    const float INF = __builtin_inff();
+    WaveStage &w = stage.w[threadIdx.x >> 6];
+    const int k = fill.qh + lane / EG;
+    bool have = k < fill.qt;
+    fill.qh = (fill.qh + NGRP < fill.qt) ? fill.qh + NGRP : fill.qt;
+    Tok t = null_tok();
+    int4 info = make_int4(-1, 0, 0, 0);
+    int ii = 0, rs = 0, rs1 = 0;
+    WAVE_LDS_ORDER();
+    if (have) {
+        t = w.itok[k]; info = w.iinfo[k]; ii = w.qpos[k];
+        rs = C.row_ptr[info.z];
+        rs1 = C.row_ptr[info.z + 1];
+        const unsigned long long kv = __hip_atomic_load(sink.sk_out + info.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        have = (unsigned)(kv & 0xffffffffULL) == (unsigned)ii;         // still the best arrival at this state
+    }
+    // Path records of word labels on the arc just traversed (:497-509): wave-level reservation
+    const bool labelled = have && info.y != 0 && er == 0;
+    const unsigned long long bl = __ballot(labelled);
+    int p = -1;
+    if (bl) {
+        const int first = __ffsll((long long)bl) - 1;
+        int wb = 0;
+        if (lane == first) wb = atomicAdd(&c.n_paths_extra, __popcll(bl));
+        wb = __shfl(wb, first);
+        p = labelled ? c.n_paths + path_base_extra + wb + rank_in(bl) : -1;
+        p = __shfl(p, eb);
+    }
+    int deg = 0;
+    if (have) {
+        if (info.y != 0) {
+            if (p < C.cap_paths) {
+                if (er == 0) {
+                    PathRec pr;
+                    pr.prev = t.path; pr.frame = frame; pr.label = info.y; pr.pad0 = 0;
+                    pr.score = t.score; pr.ac = t.ac; pr.lm = t.lm; pr.pad1 = 0.0f;
+                    S.paths[p] = pr;
+                    S.item_tok[ii].path = p;
+                    ++n_paths_made;
+                }
+                t.path = p;
+            } else c.error = -43;
+        }
+        if (er == 0 && last_frame) {                                   // :513-520
+            const float fw = C.fin_w[info.z];
+            if (fw < INF) {
+                const float cs = t.score + fw;
+                if (cs > LZ) atomicMax(&c.final_key, ((unsigned long long)f2o(cs) << 32) | (unsigned)ii);
+            }
+        }
+        deg = rs1 - rs;
+    }
+    expand_arcs<true>(C, c, S, stage, fill, t, ii, rs, deg, endTh, wordTh, sink, n_arcs);
+}
+
+// frontier rounds, flattened over all streams.  ROUND 0 reads the live exit tokens written (and
+// bid for their destination states) by phase A.  INLINE (round 0 only): every wave also runs the
+// epsilon / tee closure of what it produced, so no further round is needed (k_expand_closure).
+template <int ROUND, bool INLINE>
+__device__ __forceinline__ void expand_body(const DecConst &C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS)
 {
     __shared__ BlockStage stage;
     __shared__ int sh_acc[3];                                          // ARCS, PATHS, PEND of this block
@@ -990,7 +1144,7 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
     if (j0 >= units) return;
     if (tid == 0) { stage.np = 0; sh_acc[0] = sh_acc[1] = sh_acc[2] = 0; }
     __syncthreads();
-    WaveFill fill; fill.n = 0; fill.ni = 0;
+    WaveFill fill = {0, 0, 0, 0, 0, 0, 0};
     // per-frame constants of the stream (nothing this kernel reads is written while it runs,
     // except by the atomics it issues itself)
     const float bestA = o2f(c.best);
@@ -1009,11 +1163,16 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
     for (int u = j0; u < units; u += BPS) {
         const int k = u * PER + (tid / EG);
         int n_arcs = 0, n_paths_made = 0, n_pend = 0;
-        expand_unit(C, c, S, stage, fill, frame, last_frame, ROUND == 0 && !init, cnt0, endTh, wordTh,
-                    ROUND == 0 && !init, k < nin, in_base + k,
-                    S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], sink,
-                    n_arcs, n_paths_made, n_pend,
-                    (dbg && u == j0) ? C.dbg + ((size_t)196608 + blockIdx.x) * 4 : nullptr);
+        expand_unit<INLINE>(C, c, S, stage, fill, frame, last_frame, ROUND == 0 && !init, cnt0, endTh, wordTh,
+                            ROUND == 0 && !init, k < nin, in_base + k,
+                            S.skey[ROUND & 1], (ROUND == 0) ? S.skeyL : S.skey[ROUND & 1], sink,
+                            n_arcs, n_paths_made, n_pend,
+                            (dbg && u == j0) ? C.dbg + ((size_t)196608 + blockIdx.x) * 4 : nullptr);
+        if (INLINE) {                                                  // closure of what this wave just produced
+            while (fill.qh < fill.qt)
+                closure_step(C, c, S, stage, fill, frame, last_frame, cnt0, endTh, wordTh, sink, n_arcs, n_paths_made);
+            fill.qh = 0; fill.qt = 0;
+        }
         if (dbg) dbp[2] = wall_clock64();
         n_arcs = wave_sum(n_arcs); n_paths_made = wave_sum(n_paths_made); n_pend = wave_sum(n_pend);
         if (lane == 0) {
@@ -1022,7 +1181,23 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
             if (n_pend) atomicAdd(&sh_acc[2], n_pend);
         }
     }
-    stage_flush_block(C, c, S, stage, fill, sink);
+    if (INLINE) {                                                      // touched arcs + dirty states, reservations together
+        WaveStage &w = stage.w[tid >> 6];
+        const int n = fill.n, nd = fill.nd;
+        if (n | nd) {
+            WAVE_LDS_ORDER();
+            int base = 0;
+            if (lane == 0 && n) base = atomicAdd(&c.n_touched, n);
+            if (lane == 1 && nd) base = atomicAdd(&c.n_dirty, nd);
+            const int bt = __shfl(base, 0), bd = __shfl(base, 1);
+            for (int k = lane; k < n; k += 64) {
+                if (bt + k < C.cap_items) S.touched[bt + k] = w.buf[k]; else c.error = -42;
+            }
+            for (int k = lane; k < nd; k += 64) {
+                if (bd + k < C.cap_items) S.dirty[bd + k] = w.dbuf[k]; else c.error = -42;
+            }
+        }
+    } else stage_flush_block(C, c, S, stage, fill, sink);
     __syncthreads();
     if (tid == 0) {
         if (sh_acc[0]) atomicAdd(&c.fr[ST_ARCS], sh_acc[0]);
@@ -1030,6 +1205,17 @@ __global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, Stre
         if (sh_acc[2]) atomicAdd(&c.fr[ST_PEND], sh_acc[2]);
         if (dbg) dbp[3] = wall_clock64();
     }
+}
+
+template <int ROUND>
+__global__ __launch_bounds__(KTB) void k_expand(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS)
+{
+    expand_body<ROUND, false>(C, ctl, streams, s0, BPS);
+}
+
+__global__ __launch_bounds__(KTB) void k_expand_closure(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS)
+{
+    expand_body<0, true>(C, ctl, streams, s0, BPS);
 }
 
 // remaining closure rounds (items produced by round 1 and later): rare, one block per stream
@@ -1043,7 +1229,7 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
     const int tid = threadIdx.x, lane = lane_id();
     if (tid == 0) stage.np = 0;
     __syncthreads();
-    WaveFill fill; fill.n = 0; fill.ni = 0;
+    WaveFill fill = {0, 0, 0, 0, 0, 0, 0};
     const float bestA = o2f(c.best);
     const bool init = c.active == 2;
     const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;
@@ -1057,7 +1243,7 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
             const int k = k0 + (tid / EG);
             ItemSink sink;
             sink.sk_out = S.skey[parity ^ 1]; sink.counter = &c.cnt_tail; sink.base = tail_base;
-            expand_unit(C, c, S, stage, fill, c.frame, init || c.frame >= c.T - 1, false, pk_cnt0(c.pkA), endTh, wordTh,
+            expand_unit<false>(C, c, S, stage, fill, c.frame, init || c.frame >= c.T - 1, false, pk_cnt0(c.pkA), endTh, wordTh,
                         false, k < r1, base + k, S.skey[parity], S.skey[parity], sink, n_arcs, n_paths_made, n_pend);
             stage_flush_block(C, c, S, stage, fill, sink);
         }
@@ -1095,6 +1281,9 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
     const StreamDev &S = streams[s];
     const int nt = c.n_touched < C.cap_items ? c.n_touched : C.cap_items;
     const int units = (nt + KTB - 1) / KTB;
+    // inline closure: zero the per-state closure keys that were used this frame
+    const int nd = C.inline_closure ? (c.n_dirty < C.cap_items ? c.n_dirty : C.cap_items) : 0;
+    for (int i = j0 * KTB + tid; i < nd; i += BPS * KTB) S.skey[1][S.dirty[i]] = 0ULL;
     if (j0 >= units) return;
     if (tid == 0) { sh_best = 0u; sh_skip = 0; }
     __syncthreads();
@@ -1402,6 +1591,7 @@ struct jd_dec {
     int64_t cap_slots = 0, cap_paths = 0, cap_items = 0;
     int res_cap = 8192;
     int *d_res = nullptr;                 // result arena, see ensure_arenas
+    long long max_closure = 0;            // static closure bound of the network (see jd_dec_create)
     // chunked pipeline
     int Fc = 128;
     float *d_ll[2] = {nullptr, nullptr};
@@ -1543,6 +1733,49 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         C.aux = d->d_aux;
     }
     C.trP = d->d_trP; C.se32 = d->d_se32;
+    {   // Static bound on the epsilon / tee closure one frontier item can cause: the number of
+        // epsilon-input or tee-model arcs on all paths of such arcs below a state (a tee arc
+        // forwards the token to its end state in the same frame, WFSTDecoderLite.cpp:584-600).
+        // Small and acyclic -> the closure runs inline in k_expand_closure (4 launches per
+        // frame); otherwise the rounds are separate kernels (6 launches per frame).
+        const int S_ = net->n_states;
+        const long long LIMIT = INLINE_CLOSURE_MAX;
+        std::vector<long long> sz((size_t)S_, -1);                     // -1 unknown, -2 on the DFS stack
+        long long worst = 0;
+        auto passes = [&](const JdArc &a) { return a.in == 0 || (a.in - 1 < am->n_hmm && am->hmm_tee[(size_t)a.in - 1] > LZ); };
+        std::vector<std::pair<int, int>> stk;                          // (state, next arc)
+        for (int s0_ = 0; s0_ < S_ && worst <= LIMIT; ++s0_) {
+            if (sz[(size_t)s0_] >= 0) continue;
+            stk.push_back({s0_, net->row_ptr[(size_t)s0_]});
+            sz[(size_t)s0_] = -2;
+            std::vector<long long> acc(1, 0);
+            while (!stk.empty() && worst <= LIMIT) {
+                auto &top = stk.back();
+                const int st_ = top.first;
+                if (top.second == net->row_ptr[(size_t)st_ + 1]) {
+                    sz[(size_t)st_] = acc.back();
+                    worst = std::max(worst, acc.back());
+                    const long long done = acc.back();
+                    acc.pop_back(); stk.pop_back();
+                    if (!acc.empty()) acc.back() += 1 + done;           // the arc that led here + its closure
+                    continue;
+                }
+                const JdArc &a = net->arcs[(size_t)top.second++];
+                if (!passes(a)) continue;
+                if (sz[(size_t)a.to] == -2) { worst = LIMIT + 1; break; }   // epsilon cycle
+                if (sz[(size_t)a.to] >= 0) { acc.back() += 1 + sz[(size_t)a.to]; continue; }
+                sz[(size_t)a.to] = -2;
+                stk.push_back({a.to, net->row_ptr[(size_t)a.to]});
+                acc.push_back(0);
+            }
+            stk.clear();
+        }
+        d->max_closure = worst;
+        C.inline_closure = worst <= LIMIT ? 1 : 0;
+        if (const char *e = getenv("JD_INLINE_CLOSURE")) {              // development: 0 forces the staged kernels
+            if (atoi(e) == 0) C.inline_closure = 0;
+        }
+    }
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = 0;
     hipError_t e;
@@ -1625,6 +1858,7 @@ static int ensure_arenas(jd_dec *d)
         A(S.ast, d->net->n_arcs);
         A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states);
         A(S.touched, d->cap_items);
+        A(S.dirty, d->cap_items);
         A(S.item_tok, d->cap_items); A(S.item_info, d->cap_items);
         A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths);
         A(S.hist, HIST_MAX_BINS);
@@ -1770,9 +2004,13 @@ static void launch_init(jd_dec *d, int nb, int s0, hipStream_t st)
 {
     const int bx = bps_for(BPS_X, nb), br = bps_for(BPS_R, nb);
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 1);
-    hipLaunchKernelGGL(k_expand<0>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
-    hipLaunchKernelGGL(k_expand<1>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
-    hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
+    if (d->C.inline_closure)
+        hipLaunchKernelGGL(k_expand_closure, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
+    else {
+        hipLaunchKernelGGL(k_expand<0>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
+        hipLaunchKernelGGL(k_expand<1>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
+        hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
+    }
     hipLaunchKernelGGL(k_resolve, dim3(nb * br), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, br);
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 2);
 }
@@ -1793,11 +2031,16 @@ static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll
         hipLaunchKernelGGL(k_phase_a<8>, dim3(nb * ba), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, ba, ll,
                            ll_stride, f0);
     EV(2);
-    hipLaunchKernelGGL(k_expand<0>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
-    EV(3);
-    hipLaunchKernelGGL(k_expand<1>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
-    EV(4);
-    hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
+    if (d->C.inline_closure) {
+        hipLaunchKernelGGL(k_expand_closure, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
+        EV(3); EV(4);                                                  // no further rounds: zero-length slots
+    } else {
+        hipLaunchKernelGGL(k_expand<0>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
+        EV(3);
+        hipLaunchKernelGGL(k_expand<1>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
+        EV(4);
+        hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
+    }
     EV(5);
     hipLaunchKernelGGL(k_resolve, dim3(nb * br), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, br);
     EV(6);
@@ -1919,6 +2162,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
     d->timing.search_launches += n_chunks;
     for (int u = 0; u < nb; ++u) d->timing.gmm_frames += T[(size_t)u];
     d->timing.gmm_states = G;
+    d->timing.closure_inline = d->C.inline_closure;
     return JD_OK;
 }
 

@@ -564,10 +564,13 @@ def config_toy(seed: int = 1):
 
 def config_small(seed: int = 7, n_utts: int = 4, with_sp: bool = True, sep: float = 0.6,
                  n_words: int = 60, n_succ: int = 6, n_gmm: int = 90, n_hmm: int = 41,
-                 n_mix: int = 4, utt_words=(6, 14)):
-    """~10k-arc regression case with the tee model between words."""
+                 n_mix: int = 4, utt_words=(6, 14), hub: str = "flat"):
+    """~10k-arc regression case with the tee model between words.  hub="flat": every back-off
+    fans out into one eps:word arc per word (large epsilon closures); hub="tree": lexicon prefix
+    tree below the back-off state (small closures, the shape of a determinised C.L.G)."""
     am = make_models(seed, n_gmm=n_gmm, n_hmm=n_hmm, n_mix=n_mix, n_tm=8, sep=sep, with_tee=with_sp)
-    net = make_wfst(seed + 100, am, n_words=n_words, n_succ=n_succ, with_sp=with_sp)
+    net = make_wfst(seed + 100, am, n_words=n_words, n_succ=n_succ, with_sp=with_sp, hub=hub,
+                    eps_word_frac=0.02 if hub == "flat" else 0.2)
     rng = np.random.default_rng(seed + 300)
     feats, words = [], []
     for u in range(n_utts):
