@@ -2033,8 +2033,7 @@ static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll
     EV(2);
     if (d->C.inline_closure) {
         hipLaunchKernelGGL(k_expand_closure, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
-        EV(3); EV(4);                                                  // no further rounds: zero-length slots
-    } else {
+    } else {                                                           // (events 3 and 4 stay unused inline)
         hipLaunchKernelGGL(k_expand<0>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
         EV(3);
         hipLaunchKernelGGL(k_expand<1>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
@@ -2152,7 +2151,12 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
     for (int i = 0; i < d->kev_used; ++i)
         for (int k = 0; k < 6; ++k) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, d->kev[(size_t)i * 8 + k], d->kev[(size_t)i * 8 + k + 1]) == hipSuccess)
+            int k1 = k + 1;
+            if (d->C.inline_closure) {                                 // slot 2 spans events 2 -> 5, slots 3 and 4 are empty
+                if (k == 3 || k == 4) continue;
+                if (k == 2) k1 = 5;
+            }
+            if (hipEventElapsedTime(&ms, d->kev[(size_t)i * 8 + k], d->kev[(size_t)i * 8 + k1]) == hipSuccess)
                 d->timing.kernel_us[k] += 1e3 * ms;
         }
     d->timing.kernel_samples += d->kev_used;
