@@ -277,6 +277,7 @@ struct __align__(128) StreamCtl {
     __align__(128) int cnt_tail;             // items produced by the tail rounds
     __align__(128) int n_touched;
     __align__(128) int n_dirty;              // states whose closure key (skey[1]) is non-zero this frame (inline closure)
+    __align__(128) int done_r;               // k_resolve blocks of this stream that have finished (fused frame boundary)
     __align__(128) int n_alloc;              // instances attached this frame (= new active entries)
     __align__(128) int n_skipped;            // hopeless instances not materialised this frame
     __align__(128) int n_paths;              // Path records in use at frame start (updated by k_boundary)
@@ -338,66 +339,25 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
-// ---- per-stream frame boundary: epilogue of the frame just processed + start of the next
-// mode 0: normal step.  mode 1: recognitionStart (:139-228) part 1 (before the start-token
-// expansion).  mode 2: recognitionStart part 2 (after it).
-__global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int mode)
+// ---- frame boundary of one stream, executed by ONE wave: epilogue of the frame just processed
+// (list swap, bestFinalToken, statistics) + start of the next (:311-339).  mode 0: both;
+// mode 3: epilogue only.  Runs either as k_boundary or, fused, in the last k_resolve block of
+// the stream - there the counters other workgroups have just updated (device-scope atomics) are
+// read with agent-scope atomic loads; everything it writes is consumed by later kernels only.
+#define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
+template <typename T> __device__ __forceinline__ T CL(T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void boundary_frame(const DecConst &C, StreamCtl &c, StreamDev &S, int lane, int *sh_hist, int mode)
 {
-    const int s = s0 + blockIdx.x, lane = threadIdx.x;
-    StreamCtl &c = ctl[s];
-    StreamDev &S = streams[s];
-    __shared__ int sh_hist[HIST_MAX_BINS];
     const bool use_hist = C.max_hyps > 0;
-
-    if (mode == 1) {
-        if (!c.needs_init) return;
-        // drop whatever the previous utterance left behind
-        const int rec_ints = (C.max_n <= 5) ? 32 : 64;
-        const int *recs = S.rec[c.lst];
-        for (int q = lane; q < c.n_act; q += 64) S.ast[recs[(size_t)q * rec_ints]].slot = -1;
-        if (use_hist) for (int b = lane; b < C.hist_nbins; b += 64) S.hist[b] = 0;
-        __syncthreads();
-        if (lane == 0) {
-            c.n_act = 0; c.n_paths = 0; c.frame = 0; c.error = 0;
-            c.best_emit = LZ; c.normalise = 0.0f; c.emitTh = LZ; c.startTh = LZ;
-            c.best = f2o(LZ); c.pkA = 1ULL << PK_SHIFT1;                         // cnt0 = 1: the start token
-            c.pkE = 0ULL;
-            c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
-            c.n_alloc = 0; c.n_touched = 0; c.n_dirty = 0; c.final_key = 0ULL; c.n_skipped = 0; c.skipped_prev = 0;
-            c.n_paths_extra = 0;
-            for (int k = 0; k < ST_N; ++k) { c.fr[k] = 0; c.st[k] = 0; }
-            c.best_final = null_tok();
-            Tok z; z.score = 0.0f; z.ac = 0.0f; z.lm = 0.0f; z.path = -1;       // :221-226
-            S.item_tok[0] = z; S.item_info[0] = make_int4(-1, 0, 0, 0);
-            c.active = 2;                                                        // 2 = initialising
-        }
-        return;
-    }
-    if (mode == 2) {
-        if (c.active != 2) return;
-        if (lane == 0) {
-            c.n_act = c.n_alloc;
-            c.best_emit = o2f(c.best);
-            c.n_paths = c.n_paths + pk_cnt0(c.pkA) + c.n_paths_extra;
-            c.n_paths_extra = 0;
-            c.lst ^= 1;
-            for (int k = 0; k < ST_N; ++k) { c.st[k] += c.fr[k]; c.fr[k] = 0; }
-            c.st[ST_MODELS] = 0;
-            c.needs_init = 0; c.active = 0;
-            c.best_final = null_tok();
-        }
-        return;
-    }
-
     // ---- epilogue of the frame processed in this step's predecessor kernels.  Every counter
     // lives on its own cache line: fetch them all first (independent loads in flight together).
-    const int v_active = c.active, v_nalloc = c.n_alloc, v_nskip = c.n_skipped;
+    const int v_active = c.active, v_nalloc = CL(&c.n_alloc), v_nskip = CL(&c.n_skipped);
     const int v_skprev = c.skipped_prev, v_lst = c.lst, v_frame = c.frame, v_nact = c.n_act;
-    const int v_npaths = c.n_paths + pk_cnt0(c.pkA) + c.n_paths_extra;
+    const int v_npaths = c.n_paths + pk_cnt0(CL(&c.pkA)) + CL(&c.n_paths_extra);
     const int v_started = c.started, v_needs_init = c.needs_init, v_error = c.error, v_T = c.T;
-    const unsigned long long v_pk = c.pkA, v_pe = c.pkE, v_fkey = c.final_key;
-    const unsigned v_best = c.best;
-    int v_fr = (lane < ST_N) ? c.fr[lane] : 0;
+    const unsigned long long v_pk = CL(&c.pkA), v_pe = CL(&c.pkE), v_fkey = CL(&c.final_key);
+    const unsigned v_best = CL(&c.best);
+    int v_fr = (lane < ST_N) ? CL(&c.fr[lane]) : 0;
     long long v_st = (lane < ST_N) ? c.st[lane] : 0;
     float best_emit = c.best_emit;
     int frame_now = v_frame;
@@ -440,7 +400,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
     if (use_hist) {                                                              // Histogram::calcThresh, Histogram.cpp:134-158
         const int nb = C.hist_nbins;
         for (int b = lane; b < nb; b += 64) { sh_hist[b] = S.hist[b]; S.hist[b] = 0; }   // :329 reset
-        __syncthreads();
+        WAVE_LDS_ORDER();                                                      // one wave: its LDS operations are ordered
         const int K = (nb + 63) >> 6;
         const int hi = nb - 1 - lane * K;
         int sum = 0;
@@ -479,8 +439,64 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
         c.n_alloc = 0; c.n_touched = 0; c.n_dirty = 0; c.n_skipped = 0; c.n_paths_extra = 0;
         c.final_key = 0ULL;                                                      // :316 bestFinalToken = nullToken
+        c.done_r = 0;
         if (v_active != 1) c.active = 1;
     }
+}
+
+// ---- per-stream frame boundary: epilogue of the frame just processed + start of the next
+// mode 0: normal step.  mode 1: recognitionStart (:139-228) part 1 (before the start-token
+// expansion).  mode 2: recognitionStart part 2 (after it).
+__global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int mode)
+{
+    const int s = s0 + blockIdx.x, lane = threadIdx.x;
+    StreamCtl &c = ctl[s];
+    StreamDev &S = streams[s];
+    __shared__ int sh_hist[HIST_MAX_BINS];
+    const bool use_hist = C.max_hyps > 0;
+
+    if (mode == 1) {
+        if (!c.needs_init) return;
+        // drop whatever the previous utterance left behind
+        const int rec_ints = (C.max_n <= 5) ? 32 : 64;
+        const int *recs = S.rec[c.lst];
+        for (int q = lane; q < c.n_act; q += 64) S.ast[recs[(size_t)q * rec_ints]].slot = -1;
+        if (use_hist) for (int b = lane; b < C.hist_nbins; b += 64) S.hist[b] = 0;
+        __syncthreads();
+        if (lane == 0) {
+            c.n_act = 0; c.n_paths = 0; c.frame = 0; c.error = 0;
+            c.best_emit = LZ; c.normalise = 0.0f; c.emitTh = LZ; c.startTh = LZ;
+            c.best = f2o(LZ); c.pkA = 1ULL << PK_SHIFT1;                         // cnt0 = 1: the start token
+            c.pkE = 0ULL;
+            c.cnt1 = 0; c.cnt2 = 0; c.cnt_tail = 0;
+            c.n_alloc = 0; c.n_touched = 0; c.n_dirty = 0; c.final_key = 0ULL; c.n_skipped = 0; c.skipped_prev = 0;
+            c.done_r = 0;
+            c.n_paths_extra = 0;
+            for (int k = 0; k < ST_N; ++k) { c.fr[k] = 0; c.st[k] = 0; }
+            c.best_final = null_tok();
+            Tok z; z.score = 0.0f; z.ac = 0.0f; z.lm = 0.0f; z.path = -1;       // :221-226
+            S.item_tok[0] = z; S.item_info[0] = make_int4(-1, 0, 0, 0);
+            c.active = 2;                                                        // 2 = initialising
+        }
+        return;
+    }
+    if (mode == 2) {
+        if (c.active != 2) return;
+        if (lane == 0) {
+            c.n_act = c.n_alloc;
+            c.best_emit = o2f(c.best);
+            c.n_paths = c.n_paths + pk_cnt0(c.pkA) + c.n_paths_extra;
+            c.n_paths_extra = 0;
+            c.lst ^= 1;
+            for (int k = 0; k < ST_N; ++k) { c.st[k] += c.fr[k]; c.fr[k] = 0; }
+            c.st[ST_MODELS] = 0;
+            c.needs_init = 0; c.active = 0;
+            c.best_final = null_tok();
+        }
+        return;
+    }
+
+    boundary_frame(C, c, S, lane, sh_hist, mode);
 }
 
 // ---- phase A: doHMMInternalPropagation (:899-935) + HMMInternalPropagation (:376-484)
@@ -706,9 +722,8 @@ struct WaveFill {
     int qh, qt;                     // closure queue window in itok/iinfo/qpos   (inline closure)
     int cb, cl;                     // next free global item index of the wave's reserved chunk, indices left
 };
-// LDS traffic between lanes of ONE wave needs no hardware fence (a wave's LDS operations execute
-// in order); the compiler just must not move or forward memory accesses across this point.
-#define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
+// (WAVE_LDS_ORDER: LDS traffic between lanes of ONE wave needs no hardware fence - a wave's LDS
+// operations execute in order - the compiler just must not move or forward accesses across it.)
 // where the items produced by an expansion go: the next round's key array + the item counter
 struct ItemSink { unsigned long long *sk_out; int *counter; int base; };
 
@@ -1263,12 +1278,18 @@ __global__ __launch_bounds__(KT) void k_expand_tail(DecConst C, StreamCtl *ctl, 
 
 // ---- resolve: the winning candidate of every touched arc becomes the entry token of its
 // instance; missing instances are attached here (attachNetInst :751-774), one lane per arc.
-__global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS)
+// fuse != 0: every block of an active stream reports when it is done and the last one runs the
+// frame boundary (epilogue of this frame + start of the next) itself, so that a lock-step frame is
+// k_phase_a, k_expand*, k_resolve and nothing else.
+__global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, StreamDev *streams, int s0, int BPS, int fuse)
 {
     __shared__ int sh_w[KTB / 64];
     __shared__ int sh_base;
     __shared__ unsigned sh_best;
     __shared__ int sh_skip;
+    __shared__ int sh_last;
+    __shared__ volatile unsigned sh_sink;
+    __shared__ int sh_hist[HIST_MAX_BINS];
     const int tid = threadIdx.x, lane = lane_id();
     const int MN = C.max_n;
     const int rec_ints = (MN <= 5) ? 32 : 64, tok_off = (MN <= 5) ? 8 : 12, aux_ints = (MN <= 5) ? 8 : 12;
@@ -1284,8 +1305,10 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
     // inline closure: zero the per-state closure keys that were used this frame
     const int nd = C.inline_closure ? (c.n_dirty < C.cap_items ? c.n_dirty : C.cap_items) : 0;
     for (int i = j0 * KTB + tid; i < nd; i += BPS * KTB) S.skey[1][S.dirty[i]] = 0ULL;
-    if (j0 >= units) return;
-    if (tid == 0) { sh_best = 0u; sh_skip = 0; }
+    // blocks that report for the fused boundary: those with work, at least block 0
+    const int nrep = units < 1 ? 1 : (units < BPS ? units : BPS);
+    if (j0 >= (fuse ? nrep : units)) return;
+    if (tid == 0) { sh_best = 0u; sh_skip = 0; sh_last = 0; }
     __syncthreads();
     for (int u = j0; u < units; u += BPS) {
         const int q = u * KTB + tid;
@@ -1363,9 +1386,19 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
     }
     __syncthreads();
     if (tid == 0) {
-        if (sh_best) atomicMax(&c.best, sh_best);
-        if (sh_skip) atomicAdd(&c.n_skipped, sh_skip);
+        unsigned r = 0;
+        if (sh_best) r += atomicMax(&c.best, sh_best);
+        if (sh_skip) r += (unsigned)atomicAdd(&c.n_skipped, sh_skip);
+        if (fuse) {
+            // the atomics above and this block's n_alloc reservations have RETURNED, i.e. were
+            // performed, before the block reports itself done (the volatile store consumes r)
+            sh_sink = r;
+            sh_last = atomicAdd(&c.done_r, 1) == nrep - 1;
+        }
     }
+    if (!fuse) return;
+    __syncthreads();
+    if (sh_last && tid < 64) boundary_frame(C, c, streams[s], tid, sh_hist, 0);
 }
 
 // Path garbage collection = collectPaths (WFSTDecoderLite.cpp:699-747) as a mark-compact: records
@@ -2011,18 +2044,20 @@ static void launch_init(jd_dec *d, int nb, int s0, hipStream_t st)
         hipLaunchKernelGGL(k_expand<1>, dim3(nb * bx), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, bx);
         hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
     }
-    hipLaunchKernelGGL(k_resolve, dim3(nb * br), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, br);
+    hipLaunchKernelGGL(k_resolve, dim3(nb * br), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, br, 0);
     hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 2);
 }
 
-// one lock-step frame for streams [s0, s0+nb); ev != nullptr: 7 events bracketing the 6 launches
+// one lock-step frame for streams [s0, s0+nb); ev != nullptr: 7 events bracketing the launches.
+// lead: the frame boundary has not been run yet (first frame of a run of steps) -> k_boundary
+// first; otherwise the previous step's k_resolve has already done it (fused, see k_resolve).
 static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll_stride, int f0, hipStream_t st,
-                        hipEvent_t *ev = nullptr)
+                        bool lead, hipEvent_t *ev = nullptr)
 {
 #define EV(i) do { if (ev) (void)hipEventRecord(ev[i], st); } while (0)
     const int ba = bps_for(BPS_A, nb), bx = bps_for(BPS_X, nb), br = bps_for(BPS_R, nb);
     EV(0);
-    hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 0);
+    if (lead) hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 0);
     EV(1);
     if (d->am->max_n <= 5)
         hipLaunchKernelGGL(k_phase_a<4>, dim3(nb * ba), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, ba, ll,
@@ -2041,15 +2076,15 @@ static void launch_step(jd_dec *d, int nb, int s0, const float *ll, long long ll
         hipLaunchKernelGGL(k_expand_tail, dim3(nb), dim3(KT), 0, st, d->C, d->d_ctl, d->d_streams, s0);
     }
     EV(5);
-    hipLaunchKernelGGL(k_resolve, dim3(nb * br), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, br);
+    hipLaunchKernelGGL(k_resolve, dim3(nb * br), dim3(KTB), 0, st, d->C, d->d_ctl, d->d_streams, s0, br, 1);
     EV(6);
 #undef EV
 }
 
-// Path garbage collection between two frames: close the frame in flight, then collect
+// Path garbage collection between two frames (the last frame has been closed by the fused
+// boundary of its k_resolve, or by launch_close)
 static void launch_gc(jd_dec *d, int nb, int s0, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_boundary, dim3(nb), dim3(64), 0, st, d->C, d->d_ctl, d->d_streams, s0, 3);
     hipLaunchKernelGGL(k_gc, dim3(nb), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, s0);
 }
 
@@ -2127,7 +2162,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
                     }
                     ev = d->kev.data() + (size_t)d->kev_used++ * 8;
                 }
-                launch_step(d, nb, 0, d->d_ll[buf], (long long)Fc * G, c * Fc, d->s_search, ev);
+                launch_step(d, nb, 0, d->d_ll[buf], (long long)Fc * G, c * Fc, d->s_search, c == 0 && k == 0, ev);
             }
             if (c == n_chunks - 1) launch_close(d, nb, 0, d->s_search);
         }
@@ -2267,7 +2302,7 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
         launch_init(d, 1, s, st);                      // no-op unless the stream is flagged needs_init
         for (int k = 0; k < n; ++k) {
             if ((k % 8) == 0) launch_gc(d, 1, s, st);
-            launch_step(d, 1, s, d->d_ll[0], (long long)Fc * G, f0, st);
+            launch_step(d, 1, s, d->d_ll[0], (long long)Fc * G, f0, st, k == 0);
         }
         launch_close(d, 1, s, st);
         HIPCHK(hipGetLastError());
