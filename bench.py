@@ -134,7 +134,7 @@ def main():
     st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals
     lock_steps = max(1, search_steps // steps)                            # launches of each search kernel per step
     gmm_l = max(1, gmm_launches // steps)
-    names = [n for n in capi.kernel_names(tm) if n]
+    names = [n for n in capi.kernel_names(tm) if n and n != "k_boundary"]   # the frame boundary runs inside k_resolve
     expand_name = "k_expand_closure" if tm.get("closure_inline") else "k_expand<0>"
     per_launch_bytes = {
         # token read + write (16-B tokens), arc->hmm lookup, likelihood gather
@@ -146,7 +146,7 @@ def main():
         # parameters once per launch + features
         "jd_gmm_kernel": G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / gmm_l,
     }
-    avg_us = {n: (kernel_us[i] / ksamples if ksamples else 0.0) for i, n in enumerate(capi.kernel_names(tm)) if n}
+    avg_us = {n: (kernel_us[i] / ksamples if ksamples else 0.0) for i, n in enumerate(capi.kernel_names(tm)) if n in names}
     avg_us["jd_gmm_kernel"] = 1e3 * gmm_ms / max(1, gmm_launches)
     # share of a step's GPU time: sampled average x launches per step
     tot_ms = {n: avg_us[n] * lock_steps / 1e3 for n in names}

@@ -245,7 +245,8 @@ typedef struct jd_timing {
     int64_t search_steps;     /* lock-step frames executed (= launches of each search kernel) */
     /* summed duration (us) of each search kernel over the sampled steps, in launch order:
      * k_boundary, k_phase_a, k_expand<0>, k_expand<1>, k_expand_tail, k_resolve; with
-     * closure_inline, slot 2 is k_expand_closure and slots 3 and 4 are not launched (0) */
+     * closure_inline, slot 2 is k_expand_closure and slots 3 and 4 are not launched (0); slot 0
+     * stays 0 because the sampled steps' frame boundary runs inside k_resolve */
     double kernel_us[6];
     int32_t kernel_samples;   /* number of sampled steps                          */
     int32_t closure_inline;   /* 1: the network's epsilon/tee closures are small enough (static

@@ -2187,6 +2187,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
         for (int k = 0; k < 6; ++k) {
             float ms = 0.0f;
             int k1 = k + 1;
+            if (k == 0) continue;                                      // sampled steps never lead: no k_boundary launch in slot 0
             if (d->C.inline_closure) {                                 // slot 2 spans events 2 -> 5, slots 3 and 4 are empty
                 if (k == 3 || k == 4) continue;
                 if (k == 2) k1 = 5;
