@@ -340,13 +340,13 @@ __device__ __forceinline__ int wave_sum(int v)
 }
 
 // ---- frame boundary of one stream, executed by ONE wave: epilogue of the frame just processed
-// (list swap, bestFinalToken, statistics) + start of the next (:311-339).  mode 0: both;
-// mode 3: epilogue only.  Runs either as k_boundary or, fused, in the last k_resolve block of
+// (list swap, bestFinalToken, statistics) + start of the next (:311-339).
+// Runs either as k_boundary or, fused, in the last k_resolve block of
 // the stream - there the counters other workgroups have just updated (device-scope atomics) are
 // read with agent-scope atomic loads; everything it writes is consumed by later kernels only.
 #define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
 template <typename T> __device__ __forceinline__ T CL(T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void boundary_frame(const DecConst &C, StreamCtl &c, StreamDev &S, int lane, int *sh_hist, int mode)
+__device__ __forceinline__ void boundary_frame(const DecConst &C, StreamCtl &c, StreamDev &S, int lane, int *sh_hist)
 {
     const bool use_hist = C.max_hyps > 0;
     // ---- epilogue of the frame processed in this step's predecessor kernels.  Every counter
@@ -387,10 +387,6 @@ __device__ __forceinline__ void boundary_frame(const DecConst &C, StreamCtl &c, 
             c.frame = frame_now;
             c.n_paths = v_npaths < C.cap_paths ? v_npaths : C.cap_paths;
         }
-    }
-    if (mode == 3) {                                   // epilogue only (before Path garbage collection)
-        if (lane == 0 && v_active != 0) c.active = 0;
-        return;
     }
     // ---- start of the next frame (:311-339)
     const bool go = v_started && !v_needs_init && v_error == 0 && frame_now < v_T;
@@ -496,7 +492,7 @@ __global__ __launch_bounds__(64) void k_boundary(DecConst C, StreamCtl *ctl, Str
         return;
     }
 
-    boundary_frame(C, c, S, lane, sh_hist, mode);
+    boundary_frame(C, c, S, lane, sh_hist);
 }
 
 // ---- phase A: doHMMInternalPropagation (:899-935) + HMMInternalPropagation (:376-484)
@@ -1398,7 +1394,7 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
     }
     if (!fuse) return;
     __syncthreads();
-    if (sh_last && tid < 64) boundary_frame(C, c, streams[s], tid, sh_hist, 0);
+    if (sh_last && tid < 64) boundary_frame(C, c, streams[s], tid, sh_hist);
 }
 
 // Path garbage collection = collectPaths (WFSTDecoderLite.cpp:699-747) as a mark-compact: records
