@@ -152,3 +152,18 @@ def test_trigram_shaped_wide_beam_parity(built):
     assert ok >= 1
     for u in range(4):
         assert gs[u].n > 0
+
+
+def test_fullsize_more_utterances_than_streams(c2):
+    """configs[2] shape on one GPU: more utterances than streams are decoded as successive
+    lock-step waves; every utterance gets the result it gets in a single wave."""
+    from juicer_amd import capi, synth
+    _, _, more, _ = synth.config_c2(n_utts=40, utt_offset=100)       # same graph / models (seed 0), other utterances
+    kw = dict(main_beam=150.0)
+    one = capi.Decoder(c2["gnet"], c2["gam"], max_streams=40, **kw).decode_batch(more)
+    waves = capi.Decoder(c2["gnet"], c2["gam"], max_streams=16, **kw).decode_batch(more)   # 16 + 16 + 8
+    for a, b in zip(one, waves):
+        assert a.n == b.n and a.n > 0 and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
+        assert np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
+        for k in STAT_KEYS:
+            assert a.stats[k] == b.stats[k]
