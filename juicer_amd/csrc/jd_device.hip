@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <numeric>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -1938,7 +1939,8 @@ static int mark_init(jd_dec *d, int s0, int n, hipStream_t st)
     return JD_OK;
 }
 
-static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
+// results of streams [s0, s0+n) -> out[out_idx[i]] (out_idx == nullptr: out[out0 + i])
+static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const int *out_idx = nullptr)
 {
     std::vector<StreamDev> hs((size_t)n);
     std::vector<StreamCtl> hc((size_t)n);
@@ -1954,8 +1956,9 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0)
     for (int i = 0; i < n; ++i) {
         const StreamDev &S = hs[(size_t)i];
         const StreamCtl &K = hc[(size_t)i];
-        HostResult &R = d->results[(size_t)(out0 + i)];
-        jd_hyp &H = out[out0 + i];
+        const int oi = out_idx ? out_idx[i] : out0 + i;
+        HostResult &R = d->results[(size_t)oi];
+        jd_hyp &H = out[oi];
         memset(&H, 0, sizeof H);
         if (K.error && first_err == JD_OK) {
             if (K.error == JD_EHIST)
@@ -2091,13 +2094,15 @@ static void launch_close(jd_dec *d, int nb, int s0, hipStream_t st)
 }
 
 // Decode one wave of nb <= max_streams utterances held in device memory.
-static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *offs, hipStream_t user_stream)
+// Stream u decodes frames [ustart[u], ustart[u] + ulen[u]) of d_feats.
+static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *ustart, const int64_t *ulen,
+                       hipStream_t user_stream)
 {
     const int Fc = d->Fc, G = d->am->n_gmm;
     std::vector<int> T((size_t)nb);
     int maxT = 0;
     for (int u = 0; u < nb; ++u) {
-        const int64_t t = offs[u + 1] - offs[u];
+        const int64_t t = ulen[u];
         if (t < 0 || t > 0x3fffffff) return jd_fail(JD_EINVAL, "utterance %d: bad frame count", u);
         T[(size_t)u] = (int)t;
         maxT = std::max(maxT, (int)t);
@@ -2115,7 +2120,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *o
         for (int u = 0; u < nb; ++u)
             for (int dt = 0; dt < Fc; ++dt) {
                 const int f = c * Fc + dt;
-                const int64_t src = offs[u] + f;
+                const int64_t src = ustart[u] + f;
                 if (src > 0x7fffffff) return jd_fail(JD_EINVAL, "more than 2^31 frames in one batch");
                 row_src[((size_t)c * nb + u) * Fc + dt] = (f < T[(size_t)u]) ? (int)src : -1;
             }
@@ -2213,11 +2218,23 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
     if ((size_t)n_utts > d->results.size()) d->results.resize((size_t)n_utts);
     d->timing = jd_timing();
     int first_err = JD_OK;
+    // More utterances than streams: successive lock-step waves.  A wave lasts as long as its
+    // longest utterance, so the waves are formed from the utterances sorted by length (results do
+    // not depend on which utterances share a wave).
+    std::vector<int> order((size_t)n_utts);
+    std::iota(order.begin(), order.end(), 0);
+    if (n_utts > d->max_streams)
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offs[a + 1] - offs[a] > offs[b + 1] - offs[b]; });
+    std::vector<int64_t> ustart((size_t)d->max_streams), ulen((size_t)d->max_streams);
     for (int u0 = 0; u0 < n_utts; u0 += d->max_streams) {
         const int nb = std::min(d->max_streams, n_utts - u0);
-        rc = decode_wave(d, nb, d_feats, offs + u0, (hipStream_t)hip_stream);
+        for (int i = 0; i < nb; ++i) {
+            const int u = order[(size_t)(u0 + i)];
+            ustart[(size_t)i] = offs[u]; ulen[(size_t)i] = offs[u + 1] - offs[u];
+        }
+        rc = decode_wave(d, nb, d_feats, ustart.data(), ulen.data(), (hipStream_t)hip_stream);
         if (rc) return rc;
-        rc = fetch_results(d, 0, nb, out, u0);
+        rc = fetch_results(d, 0, nb, out, 0, order.data() + u0);
         if (rc && first_err == JD_OK) first_err = rc;
     }
     for (int s = 0; s < d->max_streams; ++s) { d->stream_started[(size_t)s] = 0; d->stream_T[(size_t)s] = 0; }
