@@ -139,9 +139,14 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
     float *so = sx + GMM_ROWS * dp;                   // [64][GMM_GT+1]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r0 = blockIdx.x * GMM_ROWS;
-    const int g0 = blockIdx.y * GMM_GT;
     const int Dn = (DT > 0) ? DT : D;
+    // tiles = (64-row tile, GMM_GT-state group); the grid may be smaller than the number of
+    // tiles (launch_gmm bounds how many wave slots the scoring may hold next to the search)
+    const int n_rt = (n_rows + GMM_ROWS - 1) / GMM_ROWS, n_gt = (G + GMM_GT - 1) / GMM_GT;
+    for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
+    const int r0 = (tile % n_rt) * GMM_ROWS;
+    const int g0 = (tile / n_rt) * GMM_GT;
+    __syncthreads();                                  // previous tile's LDS reads are done
 
     // stage the 64 x D feature tile (coalesced along D)
     for (int e = tid; e < GMM_ROWS * Dn; e += 256) {
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
     for (int e = tid; e < GMM_ROWS * GMM_GT; e += 256) {
         int r = e / GMM_GT, c = e - r * GMM_GT;
         if (r0 + r < n_rows && g0 + c < G) ll[(size_t)(r0 + r) * G + g0 + c] = so[r * (GMM_GT + 1) + c];
+    }
     }
 }
 
@@ -1540,11 +1546,16 @@ static void free_am_gmm(AmDevBuf &b)
     b = AmDevBuf();
 }
 
+// max_blocks > 0 bounds the grid (the kernel strides over the tiles): next to the search, a
+// chip-filling scoring launch holds every wave slot for milliseconds and the latency-bound search
+// kernels, which need slots for microseconds at a time, all but stop (measured: 25 ms of
+// scoring cost the search 20 ms).  A bounded grid scores in the background instead.
 static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, const int *d_row_src, int n_rows,
-                      float *d_ll, hipStream_t st)
+                      float *d_ll, hipStream_t st, int max_blocks = 0)
 {
     if (n_rows <= 0) return JD_OK;
-    dim3 grid((n_rows + GMM_ROWS - 1) / GMM_ROWS, (a->n_gmm + GMM_GT - 1) / GMM_GT);
+    const long long tiles = (long long)((n_rows + GMM_ROWS - 1) / GMM_ROWS) * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
+    dim3 grid((unsigned)((max_blocks > 0 && tiles > max_blocks) ? max_blocks : tiles));
     const int dp = a->D | 1;
     const size_t sm = (size_t)(GMM_ROWS * dp + GMM_ROWS * (GMM_GT + 1)) * sizeof(float);
     if (a->D == 39)
@@ -1622,6 +1633,9 @@ struct jd_dec {
     int res_cap = 8192;
     int *d_res = nullptr;                 // result arena, see ensure_arenas
     long long max_closure = 0;            // static closure bound of the network (see jd_dec_create)
+    int gmm_bg_blocks = 384;              // grid bound of a scoring launch that overlaps the search (see launch_gmm);
+                                          // 1.5 per CU, doubled whenever the scoring turns out to be the bottleneck
+    int n_cus = 256;
     // chunked pipeline
     int Fc = 128;
     float *d_ll[2] = {nullptr, nullptr};
@@ -1697,6 +1711,13 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (rc) return rc;
     jd_dec *d = new jd_dec();
     d->net = net; d->am = am; d->device = device; d->max_streams = max_streams; d->block_size = block_size;
+    if (const char *e = getenv("JD_FC")) { const int v = atoi(e); if (v >= 16 && v <= 4096) d->Fc = v; }   // development: frames per scoring chunk
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->n_cus = prop.multiProcessorCount;
+        d->gmm_bg_blocks = d->n_cus + d->n_cus / 2;
+    }
+    if (const char *e = getenv("JD_GMM_BLOCKS")) d->gmm_bg_blocks = atoi(e);                                  // development: 0 = unbounded
     DecConst &C = d->C;
     C.start_win = start_beam; C.emit_win = main_beam; C.end_win = end_beam; C.word_win = word_beam;
     C.max_hyps = max_hyps;
@@ -2145,7 +2166,9 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         const int buf = c & 1;
         if (c >= 2) HIPCHK(hipStreamWaitEvent(d->s_gmm, d->ev_search[buf], 0));   // ll buffer free again
         HIPCHK(hipEventRecord(gs[(size_t)c], d->s_gmm));
-        rc = launch_gmm(d->am, d->amb, d_feats, d->d_row_src + (size_t)c * nb * Fc, nb * Fc, d->d_ll[buf], d->s_gmm);
+        // chunk 0 is on the critical path (whole chip); later chunks score in the background
+        rc = launch_gmm(d->am, d->amb, d_feats, d->d_row_src + (size_t)c * nb * Fc, nb * Fc, d->d_ll[buf], d->s_gmm,
+                        c == 0 ? 0 : d->gmm_bg_blocks);
         if (rc) return rc;
         HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm));
         HIPCHK(hipEventRecord(d->ev_gmm[buf], d->s_gmm));
@@ -2177,12 +2200,22 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     HIPCHK(hipStreamSynchronize(d->s_search));
     auto w1 = std::chrono::steady_clock::now();
     d->timing.total_ms += std::chrono::duration<double, std::milli>(w1 - w0).count();
+    double waited_ms = 0.0, searched_ms = 0.0;
     for (int c = 0; c < n_chunks; ++c) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, gs[(size_t)c], ge[(size_t)c]) == hipSuccess) d->timing.gmm_ms += ms;
-        if (hipEventElapsedTime(&ms, ss[(size_t)c], se[(size_t)c]) == hipSuccess) d->timing.search_ms += ms;
+        float gms = 0.0f, sms = 0.0f, gap = 0.0f;
+        if (hipEventElapsedTime(&gms, gs[(size_t)c], ge[(size_t)c]) == hipSuccess) d->timing.gmm_ms += gms;
+        if (hipEventElapsedTime(&sms, ss[(size_t)c], se[(size_t)c]) == hipSuccess) { d->timing.search_ms += sms; searched_ms += sms; }
+        // chunk c >= 1 is scored while chunk c-1 is searched; the search of chunk c starts when both
+        // are done: time between the end of search c-1 and the start of search c = waiting for scores
+        if (c >= 1 && hipEventElapsedTime(&gap, se[(size_t)c - 1], ss[(size_t)c]) == hipSuccess) waited_ms += gap;
+    }
+    for (int c = 0; c < n_chunks; ++c) {
         (void)hipEventDestroy(gs[(size_t)c]); (void)hipEventDestroy(ge[(size_t)c]);
         (void)hipEventDestroy(ss[(size_t)c]); (void)hipEventDestroy(se[(size_t)c]);
+    }
+    if (waited_ms > 0.05 * searched_ms && d->gmm_bg_blocks > 0) {       // give the scoring more of the chip next time
+        d->gmm_bg_blocks *= 2;
+        if (d->gmm_bg_blocks > 4 * d->n_cus) d->gmm_bg_blocks = 0;     // unbounded
     }
     for (int i = 0; i < d->kev_used; ++i)
         for (int k = 0; k < 6; ++k) {
