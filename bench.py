@@ -151,7 +151,10 @@ def main():
     # share of a step's GPU time: sampled average x launches per step
     tot_ms = {n: avg_us[n] * lock_steps / 1e3 for n in names}
     tot_ms["jd_gmm_kernel"] = gmm_ms / steps
-    dom = max(per_launch_bytes, key=lambda k: tot_ms[k])
+    # dominant kernel of the critical path: the search kernels of the lock-step frames.  The GMM
+    # kernel scores one chunk ahead on its own stream with a deliberately bounded grid (it is
+    # throttled so that it never holds the search's wave slots) - its duration is not step time.
+    dom = max((k for k in per_launch_bytes if k != "jd_gmm_kernel"), key=lambda k: tot_ms[k])
     achieved = per_launch_bytes[dom] / (avg_us[dom] * 1e-6) / 1e9 if avg_us[dom] > 0 else 0.0
     search_bytes = (32.0 * MN * st["tot_insts_in"] + 4.0 * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]
                     + 24.0 * st["tot_proc_end_hyps"] + 52.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"])
@@ -178,7 +181,9 @@ def main():
                 "search_all_kernels": {"algorithmic_GB_per_step": round(search_bytes / 1e9, 3),
                                        "ms_per_step": round(search_ms / steps, 3),
                                        "GBps": round(search_bytes / max(search_ms / steps, 1e-9) / 1e6, 1)},
-                "gmm_valu_tflops": round(gmm_flops / max(tot_ms["jd_gmm_kernel"], 1e-9) / 1e9, 3)}
+                "gmm_background": {"valu_tflops": round(gmm_flops / max(tot_ms["jd_gmm_kernel"], 1e-9) / 1e9, 3),
+                                   "ms_per_step": round(tot_ms["jd_gmm_kernel"], 3),
+                                   "note": "scores one chunk ahead on its own stream, bounded grid; overlapped with the search"}}
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample
     cpu = None
