@@ -128,7 +128,7 @@ def main():
     fps = frames_total * steps / elapsed
     # ---- roofline of the dominant kernel.  Algorithmic bytes per stream-frame (SURVEY.md 8d,
     # DESIGN.md 5) from the decoder's own work counters; durations from HIP events recorded on
-    # the decoder's streams inside the timed region (every 16th lock-step frame is bracketed
+    # the decoder's streams inside the timed region (every 32nd lock-step frame is bracketed
     # kernel by kernel; the GMM kernel is bracketed on every launch).
     D, G, M, MN = am.D, am.n_gmm, am.max_mix, am.max_n
     st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals

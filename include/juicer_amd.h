@@ -236,7 +236,7 @@ int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
 
 /* Durations (HIP events on the decoder's own streams) of the kernels of the most recent
  * jd_decode_batch*(): total GMM-kernel time, total search time (all kernels of all steps),
- * wall time of the call, and per-kernel durations on every 16th step. */
+ * wall time of the call, and per-kernel durations on every 32nd step. */
 typedef struct jd_timing {
     double gmm_ms, search_ms, total_ms;
     int32_t gmm_launches, search_launches;   /* chunk-level launches (search: runs of steps)    */

@@ -2034,7 +2034,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
     return first_err;
 }
 
-#define KSAMPLE_EVERY 16
+#define KSAMPLE_EVERY 32
 #define KSAMPLE_MAX 96
 // blocks per stream of the flattened kernels.  The base values suit a full batch (64 streams);
 // with few streams each one gets more blocks so that a launch still covers the chip
