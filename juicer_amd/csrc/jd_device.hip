@@ -1305,12 +1305,14 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
     const StreamDev &S = streams[s];
     const int nt = c.n_touched < C.cap_items ? c.n_touched : C.cap_items;
     const int units = (nt + KTB - 1) / KTB;
+    // blocks that take part: those with touched arcs to resolve, at least block 0.  Only they may
+    // read the stream's counters: a surplus block can start after the stream's last participating
+    // block has already run the fused boundary, which resets them.
+    const int nrep = units < 1 ? 1 : (units < BPS ? units : BPS);
+    if (j0 >= nrep) return;
     // inline closure: zero the per-state closure keys that were used this frame
     const int nd = C.inline_closure ? (c.n_dirty < C.cap_items ? c.n_dirty : C.cap_items) : 0;
-    for (int i = j0 * KTB + tid; i < nd; i += BPS * KTB) S.skey[1][S.dirty[i]] = 0ULL;
-    // blocks that report for the fused boundary: those with work, at least block 0
-    const int nrep = units < 1 ? 1 : (units < BPS ? units : BPS);
-    if (j0 >= (fuse ? nrep : units)) return;
+    for (int i = j0 * KTB + tid; i < nd; i += nrep * KTB) S.skey[1][S.dirty[i]] = 0ULL;
     if (tid == 0) { sh_best = 0u; sh_skip = 0; sh_last = 0; }
     __syncthreads();
     for (int u = j0; u < units; u += BPS) {
