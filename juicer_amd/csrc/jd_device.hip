@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
                                                      const float *__restrict__ par,
                                                      const float *__restrict__ det,
                                                      const int *__restrict__ n_mix, int G, int M, int D,
-                                                     float *__restrict__ ll)
+                                                     float *__restrict__ ll, int skip_unused)
 {
     constexpr int DP = (DT > 0) ? (DT | 1) : 0;      // odd row stride: conflict-free per-lane rows
     extern __shared__ __align__(16) char smem[];
@@ -144,8 +144,15 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
     // tiles (launch_gmm bounds how many wave slots the scoring may hold next to the search)
     const int n_rt = (n_rows + GMM_ROWS - 1) / GMM_ROWS, n_gt = (G + GMM_GT - 1) / GMM_GT;
     for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
-    const int r0 = (tile % n_rt) * GMM_ROWS;
-    const int g0 = (tile / n_rt) * GMM_GT;
+    // row tile skewed by the state group: a bounded grid whose size is a multiple of n_rt would
+    // otherwise hand each workgroup the same row tile every time (and the skipped ones no work)
+    const int gt = tile / n_rt;
+    const int r0 = ((tile + gt) % n_rt) * GMM_ROWS;
+    const int g0 = gt * GMM_GT;
+    // a tile whose rows are all unused (stream finished / chunk shorter than its slot) is skipped:
+    // the valid rows of a stream's slot are a prefix of it and slots are multiples of the tile
+    // (rows_per_slot % GMM_ROWS == 0), so the tile's first row decides
+    if (skip_unused && row_src[r0] < 0) continue;
     __syncthreads();                                  // previous tile's LDS reads are done
 
     // stage the 64 x D feature tile (coalesced along D)
@@ -1552,8 +1559,9 @@ static void free_am_gmm(AmDevBuf &b)
 // chip-filling scoring launch holds every wave slot for milliseconds and the latency-bound search
 // kernels, which need slots for microseconds at a time, all but stop (measured: 25 ms of
 // scoring cost the search 20 ms).  A bounded grid scores in the background instead.
+// skip_unused: row_src marks unused rows with -1 in whole-tile runs (decode_wave's stream slots).
 static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, const int *d_row_src, int n_rows,
-                      float *d_ll, hipStream_t st, int max_blocks = 0)
+                      float *d_ll, hipStream_t st, int max_blocks = 0, int skip_unused = 0)
 {
     if (n_rows <= 0) return JD_OK;
     const long long tiles = (long long)((n_rows + GMM_ROWS - 1) / GMM_ROWS) * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
@@ -1562,10 +1570,10 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
     const size_t sm = (size_t)(GMM_ROWS * dp + GMM_ROWS * (GMM_GT + 1)) * sizeof(float);
     if (a->D == 39)
         hipLaunchKernelGGL(jd_gmm_kernel<39>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
-                           b.n_mix, a->n_gmm, a->max_mix, a->D, d_ll);
+                           b.n_mix, a->n_gmm, a->max_mix, a->D, d_ll, skip_unused);
     else
         hipLaunchKernelGGL(jd_gmm_kernel<0>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
-                           b.n_mix, a->n_gmm, a->max_mix, a->D, d_ll);
+                           b.n_mix, a->n_gmm, a->max_mix, a->D, d_ll, skip_unused);
     HIPCHK(hipGetLastError());
     return JD_OK;
 }
@@ -2170,7 +2178,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         HIPCHK(hipEventRecord(gs[(size_t)c], d->s_gmm));
         // chunk 0 is on the critical path (whole chip); later chunks score in the background
         rc = launch_gmm(d->am, d->amb, d_feats, d->d_row_src + (size_t)c * nb * Fc, nb * Fc, d->d_ll[buf], d->s_gmm,
-                        c == 0 ? 0 : d->gmm_bg_blocks);
+                        c == 0 ? 0 : d->gmm_bg_blocks, (Fc % GMM_ROWS) == 0);
         if (rc) return rc;
         HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm));
         HIPCHK(hipEventRecord(d->ev_gmm[buf], d->s_gmm));
