@@ -1,6 +1,6 @@
 """GPU-box diagnosis: print GPU vs oracle results side by side (not a test)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from juicer_amd import synth, capi
 from oracle.oracle import OracleNet, OracleAM, OracleDecoder

@@ -3,7 +3,7 @@
 the tee model, 5-state and mixed-topology HMMs, random pruning settings - each decoded in one
 lock-step batch and compared with the CPU oracle.  Not part of the test suite; prints a summary.
 
-    python tools/fuzz_parity.py [n_cases] [first_seed]
+    python tests/manual/fuzz_parity.py [n_cases] [first_seed]
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import assert_hyp_matches, bit_exact                      # noqa: E402

@@ -3,7 +3,7 @@
 mixtures, mainBeam 300 (wide-beam stress).  Decodes --utts utterances in lock-step on the GPU,
 checks the first --oracle-utts of them against the CPU oracle, prints one JSON line.
 
-    python tools/run_c4.py [--scale 1.0] [--utts 8] [--oracle-utts 2] [--beam 300]
+    python tests/manual/run_c4.py [--scale 1.0] [--utts 8] [--oracle-utts 2] [--beam 300]
 """
 import argparse
 import json
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

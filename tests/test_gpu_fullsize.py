@@ -129,7 +129,7 @@ def test_trigram_shaped_wide_beam_parity(built):
     """BASELINE.json configs[3] in shape (trigram-level + bigram-level histories, back-off
     epsilon arcs, history states with up to thousands of out-arcs, 5000 tied states, beam 300)
     at about a tenth of its size so that the oracle finishes in seconds; the full ~50M-arc
-    case is tools/run_c4.py (result recorded in profiles/)."""
+    case is tests/manual/run_c4.py (result recorded in profiles/)."""
     from juicer_amd import capi, synth
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
     am, net, feats, words = synth.config_c4(n_utts=4, n_words=6000, n_tri_hist=40_000, utt_words=(3, 6))
