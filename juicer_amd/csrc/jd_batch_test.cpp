@@ -16,6 +16,7 @@
 // from a .jdam dump (int32 magic 'JDAM', D,n_gmm,max_mix,n_hmm,max_n,n_tm + the jd_am_create_htk
 // arrays).  Words are printed through the output symbol table when given, else as integer ids
 // (outLabel-1, what vocab->words[] is indexed by).
+#include <unistd.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -103,6 +104,7 @@ int main(int argc, char **argv)
     int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0;
     std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
     const char *refFName = 0;                  // -refFName: expected results, MLF or one line per file (juicer.cpp:267)
+    const char *outputFName = 0;               // -outputFName: "", "stdout", "stderr" or a file (DecoderBatchTest.cpp:216-230)
     int removeSentMarks = 0;                   // -removeSentMarks (juicer.cpp:273)
     std::string sentStartWord, sentEndWord;    // -sentStartWord / -sentEndWord (DecVocabulary)
     for (int i = 1; i < argc; ++i) {
@@ -120,6 +122,7 @@ int main(int argc, char **argv)
         else if (a == "-outputFormat") outputFormat = nxt();
         else if (a == "-writeBinaryFiles") writeBinaryFiles = 1;
         else if (a == "-refFName") refFName = nxt(); else if (a == "-removeSentMarks") removeSentMarks = 1;
+        else if (a == "-outputFName") outputFName = nxt();
         else if (a == "-sentStartWord") sentStartWord = nxt(); else if (a == "-sentEndWord") sentEndWord = nxt();
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -127,8 +130,12 @@ int main(int argc, char **argv)
         fprintf(stderr, "usage: jd_batch_test -fsmFName F (-htkModelsFName M.mmf | -modelsFName M.jdam) -inputFName LIST [-mainBeam b] [-phoneStartBeam b]\n"
                         "       [-phoneEndBeam b] [-wordEmitBeam b] [-maxHyps n] [-lmScaleFactor s] [-insPenalty p] [-batch n] [-perFrameAdapter]\n"
                         "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles] [-refFName REF] [-removeSentMarks]\n"
-                        "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS]\n");
+                        "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n");
         return 2;
+    }
+    if (outputFName && outputFName[0] && strcmp(outputFName, "stdout") != 0) {     // DecoderBatchTest::openOutputFile
+        if (strcmp(outputFName, "stderr") == 0) { if (dup2(2, 1) < 0) { perror("dup2"); return 1; } }
+        else if (!freopen(outputFName, "wb", stdout)) { fprintf(stderr, "DecoderBatchTest::setupOutputFile - error opening output file\n"); return 1; }
     }
     jd_net *net = 0;
     const std::string netBin = std::string(fsm) + ".bin";                    // juicer.cpp:854-882

@@ -1405,6 +1405,7 @@ __global__ __launch_bounds__(KTB) void k_resolve(DecConst C, StreamCtl *ctl, Str
             // the atomics above and this block's n_alloc reservations have RETURNED, i.e. were
             // performed, before the block reports itself done (the volatile store consumes r)
             sh_sink = r;
+            (void)sh_sink;
             sh_last = atomicAdd(&c.done_r, 1) == nrep - 1;
         }
     }

@@ -296,6 +296,13 @@ def test_batch_test_cli(small, tmp_path):
         dac = w.ac[::-1][j] - (w.ac[::-1][j - 1] if j else 0.0)
         dlm = w.lm[::-1][j] - (w.lm[::-1][j - 1] if j else 0.0)
         assert abs(float(sc) - (dac + dlm)) <= 1e-3 * max(1.0, abs(dac + dlm))
+    # -outputFName: results go to the named file (stdout stays empty), "stderr" to the log stream
+    ref_lines = run("-outputFormat", "ref", *mm)
+    out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-inputFName", str(lst), "-mainBeam", "150",
+                          "-maxHyps", "200", "-outputFormat", "ref", "-outputFName", str(tmp_path / "res.txt")] + mm,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and out.stdout == ""
+    assert (tmp_path / "res.txt").read_text().splitlines() == ref_lines
 
 
 def test_path_garbage_collection(small):
