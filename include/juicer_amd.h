@@ -267,6 +267,11 @@ int jd_dec_debug_trace(jd_dec *d, int32_t frame, int64_t *fetch);
 int jd_am_score_frames(const jd_am *a, int32_t device, const float *frames,
                        int32_t n_frames, float *out);
 
+/* Test hook behind the bit-exactness of logAdd (HTKFlatModels.cpp:266-293 calls expf on a float):
+ * the kernels' own expf for x[0..n), evaluated on HIP device `device`, or by its host twin
+ * (same source) when device == -1.  tests/test_expf.py compares both with the host libm. */
+int jd_debug_expf(int32_t device, const float *x, int64_t n, float *out);
+
 const char *jd_last_error(void);
 const char *jd_version(void);
 

@@ -22,12 +22,12 @@ namespace JuicerAmd {
 using Juicer::DecHyp;
 using Juicer::DecHypHist;
 using Juicer::IDecoder;
-typedef WFSTLattice LatticeT;
+typedef Juicer::WFSTLattice LatticeT;     // src/WFSTLattice.h:52 (namespace Juicer, :20)
 }
 #else
 namespace JuicerAmd {
 #ifndef DHHTYPE
-#define DHHTYPE 0
+#define DHHTYPE 1                     // DecHypHistPool.h:106
 #endif
 struct DecHypHist {                  // DecHypHistPool.h:38-49
     unsigned char type;

@@ -80,7 +80,7 @@ EXPORTS = [
     "jd_am_vec_size", "jd_am_max_states", "jd_am_max_mix", "jd_am_num_transmats", "jd_am_get_topology", "jd_am_load_mmf", "jd_am_get_flat", "jd_am_get_trans", "jd_am_destroy",
     "jd_dec_create", "jd_dec_destroy", "jd_dec_set_capacity", "jd_stream_init", "jd_stream_push",
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
-    "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace",
+    "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
 ]
 
 _lib = None

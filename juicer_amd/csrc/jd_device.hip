@@ -77,18 +77,21 @@ __device__ __forceinline__ int rank_in(unsigned long long bal)
 // glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c, ARM optimized-routines
 // algorithm): N=32 table + cubic in double, rounded once to float.  Replicated
 // so that device logAdd equals the host libm result bit for bit (verified on
-// the host for all 1.2e8 floats in [-18.5, -1e-3]; see tests/test_expf.py).
-__device__ __constant__ unsigned long long jd_exp2f_tab[32] = {
-    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
-    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
-    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
-    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
-    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
-    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
-    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
-    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+// the host for all 1.2e8 floats in [-18.5, -1e-3]: tests/test_expf.py, through jd_debug_expf).
+#define JD_EXP2F_TAB                                                                              \
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,   \
+    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,   \
+    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,   \
+    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,   \
+    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,   \
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,   \
+    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,   \
+    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL
+__device__ __constant__ unsigned long long jd_exp2f_tab[32] = {JD_EXP2F_TAB};
+static const unsigned long long jd_exp2f_tab_host[32] = {JD_EXP2F_TAB};     // jd_debug_expf(device = -1)
 
-__device__ __forceinline__ float jd_expf(float x)
+// one source for the device function and its host twin (jd_debug_expf checks both against libm)
+__host__ __device__ __forceinline__ float jd_expf_impl(float x, const unsigned long long *tab)
 {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32.0;
     const double SHIFT = 0x1.8p+52;
@@ -97,12 +100,14 @@ __device__ __forceinline__ float jd_expf(float x)
     const double C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
     double z = InvLn2N * (double)x;
     double kd = z + SHIFT;
-    unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    unsigned long long ki;
+    memcpy(&ki, &kd, sizeof ki);
     kd -= SHIFT;
     double r = z - kd;
-    unsigned long long t = jd_exp2f_tab[ki & 31];
+    unsigned long long t = tab[ki & 31];
     t += ki << 47;
-    double s = __longlong_as_double((long long)t);
+    double s;
+    memcpy(&s, &t, sizeof s);
     double p = C0 * r + C1;
     double r2 = r * r;
     double y = C2 * r + 1.0;
@@ -110,6 +115,7 @@ __device__ __forceinline__ float jd_expf(float x)
     y = y * s;
     return (float)y;
 }
+__device__ __forceinline__ float jd_expf(float x) { return jd_expf_impl(x, jd_exp2f_tab); }
 
 // HTKFlatModels::logAdd, HTKFlatModels.cpp:266-293
 __device__ __forceinline__ float jd_log_add(float x, float y)
@@ -2405,6 +2411,33 @@ extern "C" int jd_dec_debug_trace(jd_dec *d, int32_t frame, int64_t *fetch)
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(fetch, d->C.dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
     }
+    return JD_OK;
+}
+
+// Test hook for the bit-exactness claim of jd_expf: evaluates it for x[0..n) on HIP device
+// `device`, or - device == -1 - its host twin compiled from the same source.
+__global__ void jd_debug_expf_kernel(const float *x, long long n, float *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = jd_expf(x[i]);
+}
+extern "C" int jd_debug_expf(int32_t device, const float *x, int64_t n, float *out)
+{
+    if (!x || !out || n < 0) return jd_fail(JD_EINVAL, "jd_debug_expf: bad argument");
+    if (device == -1) {
+        for (int64_t i = 0; i < n; ++i) out[i] = jd_expf_impl(x[i], jd_exp2f_tab_host);
+        return JD_OK;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    float *dx = nullptr, *dy = nullptr;
+    HIPCHK(hipMalloc(&dx, std::max<size_t>((size_t)n, 1) * sizeof(float)));
+    HIPCHK(hipMalloc(&dy, std::max<size_t>((size_t)n, 1) * sizeof(float)));
+    HIPCHK(hipMemcpy(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (n) hipLaunchKernelGGL(jd_debug_expf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, (long long)n, dy);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dy, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy);
     return JD_OK;
 }
 

@@ -108,8 +108,13 @@ extern "C" int jd_net_create_csr(jd_net **out, int32_t n_states, int32_t init_st
                                  const int32_t *to, const float *w, const int32_t *in, const int32_t *outl,
                                  int32_t n_final, const int32_t *fstate, const float *fweight)
 {
-    if (!out || n_states <= 0 || init_state < 0 || init_state >= n_states || !row_ptr)
+    if (!out || n_states <= 0 || init_state < 0 || init_state >= n_states || !row_ptr || !to || !w || !in || !outl)
         return jd_fail(JD_EINVAL, "jd_net_create_csr: bad arguments");
+    if (row_ptr[0] != 0) return jd_fail(JD_EINVAL, "jd_net_create_csr: row_ptr[0] must be 0");
+    for (int32_t s = 0; s < n_states; ++s)
+        if (row_ptr[s + 1] < row_ptr[s])
+            return jd_fail(JD_EINVAL, "jd_net_create_csr: row_ptr decreases at state %d", s);
+    if (row_ptr[n_states] <= 0) return jd_fail(JD_EINVAL, "jd_net_create_csr: no arcs");
     jd_net *n = new jd_net();
     n->n_states = n_states;
     n->init = init_state;

@@ -410,6 +410,8 @@ struct jo_dec {
     float startTh, endTh, wordTh, emitTh;
     int32_t currFrame, nActiveInsts, nActiveEmitHyps, nActiveEndHyps, nEmitProc, nEndProc;
     jo_stats st;
+    int tie_mode;                         /* 0 = reference (first visited wins), 1 = last visited wins (test aid) */
+    int64_t tie_kind[4];                  /* bestFinal, entry token, HMM-internal, entry ties whose tokens differ */
     /* HTKFlatModels cache state */
     int32_t *cacheT; float *cache; const float *const *currInput; int32_t currInputLen, amFrame;
     int err, started;
@@ -559,11 +561,13 @@ static void propagate(jo_dec *d, Tok *tok, int32_t arc)
         int32_t fi = net->final_ind[net->to[arc]];                  /* :513-520 */
         if (fi >= 0) {
             float weight = net->final_w[fi];
-            if (tok->score + weight > d->bestFinal.score) {
+            const int ftie = tok->score + weight == d->bestFinal.score && d->bestFinal.score > LZ;
+            if (ftie) { ++d->st.ties; ++d->tie_kind[0]; }
+            if (tok->score + weight > d->bestFinal.score || (ftie && d->tie_mode)) {
                 d->bestFinal = *tok;
                 d->bestFinal.score += weight;
                 d->bestFinal.lm += weight;
-            } else if (tok->score + weight == d->bestFinal.score) ++d->st.ties;
+            }
         }
         state = net->to[arc];
     } else state = net->init;
@@ -587,13 +591,21 @@ static void propagate(jo_dec *d, Tok *tok, int32_t arc)
             }
             Tok *res = &d->toks[(size_t)inst * d->maxN];            /* :560-582 */
             float newScore = tok->score + net->w[b];
-            if (newScore > res->score) {
+            int etie = 0;
+            if (newScore == res->score && newScore > LZ) {
+                ++d->tie_kind[1];
+                /* order dependent only if the two tokens differ in what they carry */
+                if (tok->path != res->path || tok->ac != res->ac || tok->lm + net->w[b] != res->lm) {
+                    ++d->tie_kind[3]; ++d->st.ties; etie = 1;
+                }
+            }
+            if (newScore > res->score || (etie && d->tie_mode)) {
                 if (res->score <= LZ) ++d->insts[inst].nact;
                 *res = *tok;
                 res->score = newScore;
                 res->lm += net->w[b];
                 if (newScore > d->bestEmitScore) d->bestEmitScore = newScore;
-            } else if (newScore == res->score && newScore > LZ) ++d->st.ties;
+            }
             float tee = d->insts[inst].tee;                         /* :584-600 */
             if (tee > LZ) {
                 newScore += tee;
@@ -624,6 +636,7 @@ int jo_init(jo_dec *d)
     d->normaliseScore = 0.0f; d->bestEmitScore = LZ;                /* :189-191 */
     d->startTh = d->endTh = d->wordTh = d->emitTh = LZ;             /* :197-200 */
     memset(&d->st, 0, sizeof d->st);
+    memset(d->tie_kind, 0, sizeof d->tie_kind);
     d->nActiveInsts = d->nActiveEmitHyps = d->nActiveEndHyps = d->nEmitProc = d->nEndProc = 0;
     d->err = 0; d->started = 1; d->amFrame = -1;
     Tok tmp = {0.0f, 0.0f, 0.0f, -1};                               /* :221-227 */
@@ -655,7 +668,7 @@ static void hmm_internal(jo_dec *d, int32_t ii)
                 *res = *cur;
                 res->score = tmpScore;
                 res->ac += trP[i * maxN + j];
-            } else if (tmpScore == res->score && tmpScore > LZ) ++d->st.ties;
+            } else if (tmpScore == res->score && tmpScore > LZ) ++d->tie_kind[2];
         }
         res->score -= d->normaliseScore;
         if (res->score > d->emitTh) {
@@ -686,7 +699,7 @@ static void hmm_internal(jo_dec *d, int32_t ii)
                 *r = *cur;
                 r->score = tmpScore;
                 r->ac += trP[i * maxN + N_1];
-            } else if (tmpScore == r->score && tmpScore > LZ) ++d->st.ties;
+            } else if (tmpScore == r->score && tmpScore > LZ) ++d->tie_kind[2];
         }
         if (r->score <= LZ) *r = NULLTOK;
         else { ++inst->nact; ++d->nActiveEndHyps; }
@@ -825,4 +838,32 @@ int jo_decode_utt(jo_dec *d, const float *feats, int32_t T, jo_hyp *out, double 
     if (cpu_seconds) *cpu_seconds = (double)(t1 - t0) / CLOCKS_PER_SEC;
     free(rows);
     return rc;
+}
+
+/* equal-score recombinations by kind (see jo_stats.ties): bestFinalToken (:513-520), entry
+ * token (:560-582), HMM-internal max over predecessors (:393-406, :459: lowest index wins, an
+ * order every implementation shares), and the entry-token ties whose two tokens actually differ */
+int jo_tie_breakdown(const jo_dec *d, int64_t out[4])
+{
+    if (!d || !out) return -1;
+    for (int i = 0; i < 4; ++i) out[i] = d->tie_kind[i];
+    return 0;
+}
+
+/* Test aid: mode 1 lets the LAST visited token win equal-score recombinations of entry tokens and
+ * bestFinalToken (the reference keeps the first, strict > at :516, :563).  A result that is the
+ * same under both rules does not depend on visiting order at all. */
+int jo_dec_set_tie_mode(jo_dec *d, int mode)
+{
+    if (!d) return -1;
+    d->tie_mode = mode ? 1 : 0;
+    return 0;
+}
+
+/* the host libm's expf, elementwise (what HTKFlatModels::logAdd calls on a float, :266-293) */
+int jo_expf_array(const float *x, int64_t n, float *out)
+{
+    if (!x || !out || n < 0) return -1;
+    for (int64_t i = 0; i < n; ++i) out[i] = expf(x[i]);
+    return 0;
 }

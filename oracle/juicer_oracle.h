@@ -29,7 +29,8 @@ typedef struct jo_stats {
     int32_t n_frames;
     int64_t tot_active_emit_hyps, tot_active_end_hyps, tot_active_models;
     int64_t tot_proc_emit_hyps, tot_proc_end_hyps;
-    int64_t tot_arcs_visited, tot_paths, tot_insts_in, ties;
+    int64_t tot_arcs_visited, tot_paths, tot_insts_in;
+    int64_t ties;              /* equal-score recombinations whose winner depends on visiting order */
 } jo_stats;
 
 typedef struct jo_hyp {
@@ -80,6 +81,17 @@ int jo_finish(jo_dec *d, jo_hyp *out);
 int jo_decode_utt(jo_dec *d, const float *feats, int32_t n_frames, jo_hyp *out, double *cpu_seconds);
 /* per-frame trace for debugging parity: bestEmitScore after each frame */
 int jo_set_trace(jo_dec *d, float *best_emit_per_frame, int32_t cap);
+
+/* equal-score recombinations of the last utterance by kind: [0] bestFinalToken, [1] entry token,
+ * [2] HMM-internal (lowest predecessor wins: not order dependent), [3] entry-token ties whose
+ * two tokens differ in acoustic / LM score or history (the only ones whose winner matters) */
+int jo_tie_breakdown(const jo_dec *d, int64_t out[4]);
+/* test aid: 0 = reference rule (first visited token keeps an equal-score recombination),
+ * 1 = last visited wins.  jo_stats.ties counts the order-dependent ties only ([0] + [3]). */
+int jo_dec_set_tie_mode(jo_dec *d, int mode);
+
+/* host libm expf, elementwise */
+int jo_expf_array(const float *x, int64_t n, float *out);
 
 const char *jo_last_error(void);
 

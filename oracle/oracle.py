@@ -54,6 +54,7 @@ class OracleHyp:
     tot_lm: float
     stats: dict
     cpu_seconds: float = 0.0
+    tie_kinds: tuple = (0, 0, 0, 0)   # bestFinal, entry, HMM-internal, order-dependent entry ties
 
 
 _lib = None
@@ -172,9 +173,10 @@ class OracleDecoder:
                                C.c_float(end_beam), C.c_float(word_beam), C.c_int32(max_hyps),
                                C.c_int32(block_size)))
 
-    def decode(self, feats, trace: Optional[np.ndarray] = None) -> OracleHyp:
+    def decode(self, feats, trace: Optional[np.ndarray] = None, tie_mode: int = 0) -> OracleHyp:
         L = lib()
         x = _f32(feats)
+        L.jo_dec_set_tie_mode(self.h, C.c_int(tie_mode))
         if trace is not None:
             L.jo_set_trace(self.h, _p(trace, C.c_float), C.c_int32(trace.shape[0]))
         else:
@@ -188,11 +190,32 @@ class OracleDecoder:
         def arr(ptr, dt):
             return np.array([ptr[i] for i in range(k)], dtype=dt)
         st = {f: getattr(hyp.stats, f) for f, _ in _Stats._fields_}
+        kinds = (C.c_int64 * 4)()
+        L.jo_tie_breakdown(self.h, kinds)
         return OracleHyp(n=n, label=arr(hyp.label, np.int32), time=arr(hyp.time, np.int32),
                          score=arr(hyp.score, np.float32), ac=arr(hyp.ac, np.float32),
                          lm=arr(hyp.lm, np.float32), tot_score=float(hyp.tot_score),
                          tot_ac=float(hyp.tot_ac), tot_lm=float(hyp.tot_lm), stats=st,
-                         cpu_seconds=float(secs.value))
+                         cpu_seconds=float(secs.value), tie_kinds=tuple(int(k) for k in kinds))
+
+    def decode_certified(self, feats) -> OracleHyp:
+        """Reference-rule decode whose result is certified not to depend on visiting order: when
+        order-dependent equal-score recombinations occurred (stats['ties'] > 0: float32 collisions
+        between different tokens), the utterance is decoded again with the opposite rule (last
+        visited wins) and both results must coincide.  Raises AssertionError otherwise - pick
+        another fixture, there is nothing a different implementation could be held to."""
+        o = self.decode(feats)
+        if o.stats["ties"]:
+            f = self.decode(feats, tie_mode=1)
+            same = (f.n == o.n and np.array_equal(f.label, o.label) and np.array_equal(f.time, o.time)
+                    and np.array_equal(f.score.view(np.uint32), o.score.view(np.uint32))
+                    and np.array_equal(f.ac.view(np.uint32), o.ac.view(np.uint32))
+                    and np.array_equal(f.lm.view(np.uint32), o.lm.view(np.uint32)))
+            assert same, "fixture is tie-order sensitive (%d order-dependent ties)" % o.stats["ties"]
+            for k in o.stats:
+                if k not in ("ties", "tot_arcs_visited", "tot_paths"):
+                    assert f.stats[k] == o.stats[k], k
+        return o
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:

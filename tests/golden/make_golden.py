@@ -60,7 +60,7 @@ def main():
             od = OracleDecoder(onet, oam, **kw)
             utts = []
             for f in feats:
-                h = od.decode(f)
+                h = od.decode_certified(f)          # result independent of the visiting order of equal-score tokens
                 utts.append({"n": h.n, "label": h.label.tolist(), "time": h.time.tolist(),
                              "score_hex": [np.float32(v).tobytes().hex() for v in h.score],
                              "ac_hex": [np.float32(v).tobytes().hex() for v in h.ac],

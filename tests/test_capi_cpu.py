@@ -176,3 +176,24 @@ def test_mmf_text_loader_errors(built, tmp_path):
         capi.Models.from_mmf_file(str(p))
     with pytest.raises(capi.JuicerAmdError):
         capi.Models.from_mmf_file(str(tmp_path / "missing.mmf"))
+
+
+def test_adapter_compiles_inside_the_juicer_tree():
+    """include/juicer_amd_decoder.hpp has two branches; the one a Juicer maintainer would use
+    (#ifdef DECODER_H: derive from Juicer::IDecoder, return Juicer::DecHyp, Juicer::WFSTLattice)
+    is compiled here against an own-written mock of Decoder.h's declarations
+    (tests/mock_juicer/Decoder.h; the real header needs the absent Torch3), the stand-alone
+    branch against nothing.  Compile-only: no GPU, no link."""
+    import subprocess
+    import tempfile
+    inc = os.path.join(ROOT, "include")
+    mock = os.path.join(ROOT, "tests", "mock_juicer")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", mock, "-I", inc,
+                           os.path.join(mock, "adapter_in_tree.cpp")])
+    subprocess.check_call(["g++", "-std=c++98", "-Wall", "-fsyntax-only", "-I", mock, "-I", inc, "-x", "c++",
+                           "-include", "Decoder.h", os.path.join(inc, "juicer_amd_decoder.hpp")])   # Juicer is C++98-era
+    with tempfile.NamedTemporaryFile("w", suffix=".cpp") as f:
+        f.write('#include "juicer_amd_decoder.hpp"\nJuicerAmd::IDecoder *p = 0;\n'
+                'int main() { return DHHTYPE == 1 ? 0 : 1; }\n')          # DecHypHistPool.h:106
+        f.flush()
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, f.name])

@@ -28,17 +28,14 @@ def test_fullsize_oracle_parity(c2):
     od = OracleDecoder(OracleNet(c2["net"]), OracleAM(c2["am"]), **kw)
     checked = exact = 0
     for u in range(6):
-        o = od.decode(c2["feats"][u])
-        if o.stats["ties"]:
-            # equal-score recombinations: the winner is order dependent in the reference too;
-            # labels/times must still agree unless the tie sat on the best path
-            if not (gs[u].n == o.n and np.array_equal(gs[u].label, o.label)):
-                continue
-        assert_hyp_matches(gs[u], o, "c2 utt %d" % u, check_stats=(o.stats["ties"] == 0))
+        # decode_certified: the oracle's result is verified not to depend on the visiting order
+        # of equal-score tokens (it fails, never skips, if a fixture were order sensitive)
+        o = od.decode_certified(c2["feats"][u])
+        assert_hyp_matches(gs[u], o, "c2 utt %d" % u)
         checked += 1
         exact += bit_exact(gs[u], o)
     print("checked %d utterances, %d bit-exact incl. scores" % (checked, exact))
-    assert checked >= 4
+    assert checked == 6 and exact == 6
 
 
 def test_fullsize_histogram_pruning_parity(c2):
@@ -48,13 +45,10 @@ def test_fullsize_histogram_pruning_parity(c2):
     gd = capi.Decoder(c2["gnet"], c2["gam"], max_streams=4, **kw)
     gs = gd.decode_batch(c2["feats"][:4])
     od = OracleDecoder(OracleNet(c2["net"]), OracleAM(c2["am"]), **kw)
-    ok = 0
     for u in range(4):
-        o = od.decode(c2["feats"][u])
-        if o.stats["ties"] == 0:
-            assert_hyp_matches(gs[u], o, "c2 hist utt %d" % u)
-            ok += 1
-    assert ok >= 2
+        o = od.decode_certified(c2["feats"][u])
+        assert_hyp_matches(gs[u], o, "c2 hist utt %d" % u)
+        assert bit_exact(gs[u], o)
 
 
 def test_fullsize_properties(c2):
@@ -118,9 +112,9 @@ def test_fullsize_wide_beam(c2):
     gd = capi.Decoder(c2["gnet"], c2["gam"], max_streams=3, **kw)
     gs = gd.decode_batch(x)
     od = OracleDecoder(OracleNet(c2["net"]), OracleAM(c2["am"]), **kw)
-    o = od.decode(x[0])
-    print("beam 300: %.0f active emit hyps/frame, ties %d" % (o.stats["tot_active_emit_hyps"] / o.stats["n_frames"], o.stats["ties"]))
-    assert_hyp_matches(gs[0], o, "beam300", check_stats=(o.stats["ties"] == 0))
+    o = od.decode_certified(x[0])
+    print("beam 300: %.0f active emit hyps/frame, order-dependent ties %d" % (o.stats["tot_active_emit_hyps"] / o.stats["n_frames"], o.stats["ties"]))
+    assert_hyp_matches(gs[0], o, "beam300")
     for k in ("n_frames", "tot_active_emit_hyps", "tot_proc_emit_hyps"):
         assert gs[0].stats[k] == o.stats[k]
 
@@ -140,16 +134,12 @@ def test_trigram_shaped_wide_beam_parity(built):
     gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=4, **kw)
     gs = gd.decode_batch(feats)
     od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
-    ok = 0
     for u in range(2):
-        o = od.decode(feats[u])
-        # with the whole graph inside the beam, equal-score recombinations are common; their
-        # winner is order dependent in the reference too (first one met keeps the entry token)
-        if o.stats["ties"] and not (gs[u].n == o.n and np.array_equal(gs[u].label, o.label)):
-            continue
-        assert_hyp_matches(gs[u], o, "c4-shaped utt %d" % u, check_stats=(o.stats["ties"] == 0))
-        ok += 1
-    assert ok >= 1
+        # with the whole graph inside the beam, float32 collisions between different tokens do
+        # occur (utterance 1: 66 of ~2e8 recombinations); decode_certified proves the result does
+        # not depend on which of the two the reference would have met first
+        o = od.decode_certified(feats[u])
+        assert_hyp_matches(gs[u], o, "c4-shaped utt %d" % u)
     for u in range(4):
         assert gs[u].n > 0
 
