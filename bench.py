@@ -5,14 +5,25 @@ One "step" = one pass of the hot path (dense GMM scoring + token-passing search)
 over one batch of synthetic utterances per GPU: BASELINE.json configs[1]
 (~1M-arc composed WFST, 3000 tied states x 16 mixtures, 64 utterances per GPU,
 mainBeam 150).  Features are resident in HBM before the timed region.
-N>1: one rank per GPU (torchrun), utterances sharded across ranks, no data-path
-collective; ONE RCCL all_gather of the padded 1-best records per step.
+
+N>1: one rank per GPU, utterances sharded across ranks, no data-path collective;
+ONE RCCL all_gather of the padded 1-best records per step.  `python bench.py
+--gpus N` spawns its own ranks (torch.distributed.run) when it was not started
+by torchrun; under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+After the timed region rank 0 of a 1-GPU run also times (1 warm-up + 1 step
+each) the other single-GPU workloads of BASELINE.json and reports them under
+"legs": the north_star target (10M-arc class graph, beam 200), configs[3]
+(~48M-arc trigram-shaped graph, beam 300) and the maxHyps 6000 variant of
+configs[1] - each with its own roofline.  --no-extra-legs skips them.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,6 +33,90 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def search_bytes(st, max_n):
+    """Algorithmic bytes of the search for the work in `st` (batch totals of jd_stats): SURVEY.md
+    8(d) / DESIGN.md 5.  Token read + write (16-B tokens) and arc->hmm lookup per instance,
+    likelihood gather per emitting hypothesis, exit token + CSR bounds per end hypothesis,
+    arc record + hook + entry-token read-modify-write per visited arc, one Path record per word end."""
+    return ((32.0 * max_n + 4.0) * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]
+            + 24.0 * st["tot_proc_end_hyps"] + 52.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"])
+
+
+def roofline_of(st, max_n, tm, traffic=None):
+    """Roofline of k_search, the persistent kernel every search launch is: achieved = algorithmic
+    bytes per launch / average launch duration (HIP events around each launch on the decoder's
+    search stream, jd_dec_last_timing)."""
+    launches = max(1, tm["search_launches"])
+    per_launch = search_bytes(st, max_n) / launches
+    avg_us = 1e3 * tm["search_ms"] / launches
+    achieved = per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(per_launch, 1), "avg_launch_us": round(avg_us, 3),
+            "launches_per_step": launches, "workgroups_per_stream": tm["cluster_wgs"]}
+
+
+def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=2):
+    """One extra workload: warm-up pass + timed pass(es) on one GPU, its own roofline."""
+    import torch
+    from juicer_amd import capi
+    U = len(feats)
+    t0 = time.perf_counter()
+    dec = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam, max_hyps=max_hyps,
+                       device=dev.index, max_streams=U)
+    offs = np.zeros(U + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in feats])
+    d_feats = torch.from_numpy(np.concatenate(feats)).to(dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    best, hyps, tm = None, None, None
+    for i in range(passes):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        if i > 0 or passes == 1:
+            if best is None or dt < best:
+                best, tm = dt, dec.last_timing()
+    frames = int(offs[-1])
+    st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}
+    out = {"workload": "%s: %d-arc composed C.L.G, %d tied states x %d mix, %d utterances, mainBeam %g, maxHyps %d"
+                       % (name, net.n_arcs, am.n_gmm, am.max_mix, U, beam, max_hyps),
+           "value": round(frames / best, 1), "unit": "frames/s", "xRT": round(frames / best / 100.0, 2),
+           "frames_per_step": frames, "ms_per_step": round(best * 1e3, 3),
+           "search_ms": round(tm["search_ms"], 3), "gmm_ms": round(tm["gmm_ms"], 3),
+           "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
+                                                                              "tot_proc_end_hyps", "tot_arcs_visited")},
+           "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
+           "roofline": roofline_of(st, am.max_n, tm), "setup_s": round(time.perf_counter() - t0 - best * passes, 1)}
+    if oracle_utts > 0:
+        from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+        od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=beam, max_hyps=max_hyps)
+        secs, fr, same = 0.0, 0, 0
+        for u in range(min(oracle_utts, U)):
+            o = od.decode(feats[u])
+            secs += o.cpu_seconds; fr += feats[u].shape[0]
+            same += int(hyps[u].n == o.n and np.array_equal(hyps[u].label, o.label) and np.array_equal(hyps[u].time, o.time))
+        out["cpu_oracle"] = {"frames_per_s": round(fr / secs, 1), "utts": min(oracle_utts, U), "identical_1best": same}
+    dec.close()
+    del d_feats
+    torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -35,8 +130,17 @@ def main():
     ap.add_argument("--max-hyps", type=int, default=0)
     ap.add_argument("--cpu-sample-utts", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
+
+    share_gpu = os.environ.get("JD_BENCH_SHARE_GPU") == "1"      # development: all ranks on GPU 0, gloo
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus and not share_gpu:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -46,13 +150,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and world > 1:
+    if world != max(1, args.gpus):
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: juicer_amd has no CPU fallback")
-    # JD_BENCH_SHARE_GPU=1 (development only): all ranks use GPU 0 over gloo, to exercise the
-    # multi-rank code path on a one-GPU box; the reported numbers are meaningless then.
-    share_gpu = os.environ.get("JD_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -96,18 +197,14 @@ def main():
         step()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    gmm_ms = search_ms = 0.0
+    acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0}
     tm = {}
-    gmm_launches = search_steps = ksamples = 0
-    kernel_us = [0.0] * 6
     hyps = None
     for _ in range(args.steps):
         hyps, allh = step()
         tm = dec.last_timing()
-        gmm_ms += tm["gmm_ms"]; search_ms += tm["search_ms"]
-        gmm_launches += tm["gmm_launches"]; search_steps += tm["search_steps"]
-        ksamples += tm["kernel_samples"]
-        kernel_us = [a + b for a, b in zip(kernel_us, tm["kernel_us"])]
+        for k in acc:
+            acc[k] += tm[k]
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -115,8 +212,10 @@ def main():
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0]); frames_total = float(tsum[1])
+        n_gathered = len(allh)
     else:
         frames_total = float(frames_local)
+        n_gathered = len(hyps)
 
     if rank != 0:
         if world > 1:
@@ -126,64 +225,32 @@ def main():
 
     steps = args.steps
     fps = frames_total * steps / elapsed
-    # ---- roofline of the dominant kernel.  Algorithmic bytes per stream-frame (SURVEY.md 8d,
-    # DESIGN.md 5) from the decoder's own work counters; durations from HIP events recorded on
-    # the decoder's streams inside the timed region (every 32nd lock-step frame is bracketed
-    # kernel by kernel; the GMM kernel is bracketed on every launch).
     D, G, M, MN = am.D, am.n_gmm, am.max_mix, am.max_n
-    st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals
-    lock_steps = max(1, search_steps // steps)                            # launches of each search kernel per step
-    gmm_l = max(1, gmm_launches // steps)
-    names = [n for n in capi.kernel_names(tm) if n and n != "k_boundary"]   # the frame boundary runs inside k_resolve
-    expand_name = "k_expand_closure" if tm.get("closure_inline") else "k_expand<0>"
-    per_launch_bytes = {
-        # token read + write (16-B tokens), arc->hmm lookup, likelihood gather
-        "k_phase_a": ((32.0 * MN + 4.0) * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]) / lock_steps,
-        # exit token + CSR bounds, arc records + slot map, Path records
-        expand_name: (24.0 * st["tot_proc_end_hyps"] + 20.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"]) / lock_steps,
-        # destination entry-token read-modify-write
-        "k_resolve": 32.0 * st["tot_arcs_visited"] / lock_steps,
-        # parameters once per launch + features
-        "jd_gmm_kernel": G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / gmm_l,
-    }
-    avg_us = {n: (kernel_us[i] / ksamples if ksamples else 0.0) for i, n in enumerate(capi.kernel_names(tm)) if n in names}
-    avg_us["jd_gmm_kernel"] = 1e3 * gmm_ms / max(1, gmm_launches)
-    # share of a step's GPU time: sampled average x launches per step
-    tot_ms = {n: avg_us[n] * lock_steps / 1e3 for n in names}
-    tot_ms["jd_gmm_kernel"] = gmm_ms / steps
-    # dominant kernel of the critical path: the search kernels of the lock-step frames.  The GMM
-    # kernel scores one chunk ahead on its own stream with a deliberately bounded grid (it is
-    # throttled so that it never holds the search's wave slots) - its duration is not step time.
-    dom = max((k for k in per_launch_bytes if k != "jd_gmm_kernel"), key=lambda k: tot_ms[k])
-    achieved = per_launch_bytes[dom] / (avg_us[dom] * 1e-6) / 1e9 if avg_us[dom] > 0 else 0.0
-    search_bytes = (32.0 * MN * st["tot_insts_in"] + 4.0 * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]
-                    + 24.0 * st["tot_proc_end_hyps"] + 52.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"])
-    gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
-    # HBM traffic per launch of that kernel from the committed PMC passes (profiles/, same
-    # workload; separate --pmc runs).  (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 FETCH_SIZE reports
-    # half of a wide read (MI355X_MICROARCH.md, HBM); only valid for the default workload.
+    st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals (rank 0)
+    default_cfg = (args.arcs == 1_000_000 and args.beam == 150.0 and args.max_hyps == 0 and U == 64 and args.seed == 0)
+    # HBM traffic per launch of k_search from the committed PMC passes (profiles/, same command,
+    # separate --pmc runs): (2*FETCH_SIZE + WRITE_SIZE) KiB - gfx950's FETCH_SIZE reports half of a
+    # wide read (MI355X_MICROARCH.md, HBM).  Only meaningful for the default workload.
     traffic = None
     try:
-        default_cfg = (args.arcs == 1_000_000 and args.beam == 150.0 and args.max_hyps == 0 and U == 64 and args.seed == 0)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_pmc_summary.json")))
-        key = {"k_phase_a": "k_phase_a<4>", "jd_gmm_kernel": "jd_gmm_kernel<39>"}.get(dom, dom)
-        if default_cfg and key in pmc:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_c2_pmc_summary.json")))
+        key = next(k for k in pmc if k.startswith("k_search"))
+        if default_cfg:
             traffic = round((2.0 * pmc[key]["FETCH_SIZE"]["mean"] + pmc[key]["WRITE_SIZE"]["mean"]) * 1024.0, 1)
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(per_launch_bytes[dom], 1),
-                "avg_launch_us": round(avg_us[dom], 3), "launches_per_step": lock_steps if dom != "jd_gmm_kernel" else gmm_l,
-                "sampled_launches": ksamples if dom != "jd_gmm_kernel" else gmm_launches,
-                "kernels_ms_per_step": {k: round(v, 3) for k, v in tot_ms.items()},
-                "kernels_avg_us": {k: round(v, 2) for k, v in avg_us.items()},
-                "search_all_kernels": {"algorithmic_GB_per_step": round(search_bytes / 1e9, 3),
-                                       "ms_per_step": round(search_ms / steps, 3),
-                                       "GBps": round(search_bytes / max(search_ms / steps, 1e-9) / 1e6, 1)},
-                "gmm_background": {"valu_tflops": round(gmm_flops / max(tot_ms["jd_gmm_kernel"], 1e-9) / 1e9, 3),
-                                   "ms_per_step": round(tot_ms["jd_gmm_kernel"], 3),
-                                   "note": "scores one chunk ahead on its own stream, bounded grid; overlapped with the search"}}
+    step_tm = dict(tm)
+    step_tm["search_ms"] = acc["search_ms"] / steps
+    step_tm["search_launches"] = max(1, acc["search_launches"] // steps)
+    roofline = roofline_of(st, MN, step_tm, traffic)
+    gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
+    gmm_bytes = G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / max(1, tm["gmm_launches"])
+    roofline["search_ms_per_step"] = round(acc["search_ms"] / steps, 3)
+    roofline["gmm"] = {"kernel": "jd_gmm_kernel", "ms_per_step": round(acc["gmm_ms"] / steps, 3),
+                       "valu_tflops": round(gmm_flops / max(acc["gmm_ms"] / steps, 1e-9) / 1e9, 3),
+                       "algorithmic_bytes_per_launch": round(gmm_bytes, 1),
+                       "search_waited_ms_per_step": round(acc["gmm_wait_ms"] / steps, 3),
+                       "note": "scores one chunk ahead of the search on its own stream (bounded grid beside it)"}
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample
     cpu = None
@@ -202,15 +269,35 @@ def main():
                          "init..finish as DecoderSingleTest.cpp:259-300; GPU 1-best identical on %d/%d"
                          % (ns, fr, same, ns)}
 
+    name = "configs[1]" if default_cfg else "configs[1]-shaped (non-default size / pruning)"
     out = {"metric": "frames/sec decoded", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
            "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic", "xRT": round(fps / 100.0, 1),
-           "config": {"workload": "configs[1]: %d-arc composed C.L.G, %d tied states x %d mix, D=%d, "
+           "config": {"workload": "%s: %d-arc composed C.L.G, %d tied states x %d mix, D=%d, "
                                   "%d utterances per GPU, mainBeam %g, maxHyps %d"
-                                  % (net.n_arcs, G, M, D, U, args.beam, args.max_hyps),
-                      "frames_per_step": int(frames_total), "utts_per_gpu": U, "parallelism": "utterance-sharded x%d" % world},
+                                  % (name, net.n_arcs, G, M, D, U, args.beam, args.max_hyps),
+                      "frames_per_step": int(frames_total), "utts_per_gpu": U, "gathered_hyps": n_gathered,
+                      "parallelism": "utterance-sharded x%d" % world},
            "roofline": roofline, "cpu_baseline": cpu}
+
+    # ---- the other single-GPU workloads of BASELINE.json (not part of `value`)
+    if world == 1 and not args.no_extra_legs:
+        dec.close()
+        del d_feats
+        torch.cuda.empty_cache()
+        legs = {}
+        try:
+            legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev)
+            a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=64, n_words=10000, n_tri_hist=100_000)
+            legs["north_star_10M_beam200"] = run_leg("north_star target (trigram-shaped)", a4, n4, f4, 200.0, 0, dev,
+                                                     oracle_utts=0 if args.no_cpu_baseline else 1)
+            del a4, n4, f4
+            a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=8)
+            legs["configs3_50M_beam300"] = run_leg("configs[3]", a4, n4, f4, 300.0, 0, dev)
+        except Exception as e:                                    # a leg must never take the headline down
+            legs["error"] = repr(e)
+        out["legs"] = legs
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(**bar_kw)

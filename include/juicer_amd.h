@@ -234,30 +234,27 @@ int jd_decode_batch(jd_dec *d, int32_t n_utts, const float *const *feats,
 int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
                            const int64_t *offs, void *hip_stream, jd_hyp *out);
 
-/* Durations (HIP events on the decoder's own streams) of the kernels of the most recent
- * jd_decode_batch*(): total GMM-kernel time, total search time (all kernels of all steps),
- * wall time of the call, and per-kernel durations on every 32nd step. */
+/* Timing of the most recent jd_decode_batch*() (HIP events on the decoder's own streams): total
+ * duration of the GMM-kernel launches, of the k_search launches (the persistent search kernel:
+ * one launch per chunk of frames, repeated when a stream had to stop for Path garbage
+ * collection), wall time of the call. */
 typedef struct jd_timing {
     double gmm_ms, search_ms, total_ms;
-    int32_t gmm_launches, search_launches;   /* chunk-level launches (search: runs of steps)    */
+    double gmm_wait_ms;       /* host time spent waiting for scores the search needed next      */
+    int32_t gmm_launches, search_launches;
+    int32_t relaunches;       /* k_search launches repeated after an in-chunk garbage collection */
+    int32_t cluster_wgs;      /* workgroups (1024 threads) per stream cluster in the last launch */
     int64_t gmm_frames;       /* stream-frames scored                           */
     int64_t gmm_states;       /* tied states scored per frame                    */
-    int64_t search_steps;     /* lock-step frames executed (= launches of each search kernel) */
-    /* summed duration (us) of each search kernel over the sampled steps, in launch order:
-     * k_boundary, k_phase_a, k_expand<0>, k_expand<1>, k_expand_tail, k_resolve; with
-     * closure_inline, slot 2 is k_expand_closure and slots 3 and 4 are not launched (0); slot 0
-     * stays 0 because the sampled steps' frame boundary runs inside k_resolve */
-    double kernel_us[6];
-    int32_t kernel_samples;   /* number of sampled steps                          */
-    int32_t closure_inline;   /* 1: the network's epsilon/tee closures are small enough (static
-                               * bound) to run inside the expansion kernel: 4 launches per frame */
+    int64_t search_frames;    /* stream-frames decoded                          */
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 
-/* Diagnostics: per-block wall-clock stamps (100 MHz: start, after setup, after work, end) of
- * k_phase_a (blocks [0,65536)) and k_expand<0> (blocks [65536,131072)) at lock-step frame `frame`
- * of the following decodes; `fetch` (2*65536*4 int64, may be NULL) receives the last recording. */
-int jd_dec_debug_trace(jd_dec *d, int32_t frame, int64_t *fetch);
+/* Diagnostics: per-workgroup cycle accounting of k_search (100 MHz wall clock).  enable >= 0 with
+ * fetch == NULL switches it on and clears it, enable < 0 switches it off; with fetch != NULL
+ * (1024 x 8 int64) the sums so far are copied out: per workgroup of the grid
+ * {phase A, barrier wait, phase X, barrier wait, frames, -, -, -}. */
+int jd_dec_debug_trace(jd_dec *d, int32_t enable, int64_t *fetch);
 
 /*
  * Companion kernel on its own: HTKFlatModels::calcGMMOutput

@@ -19,6 +19,7 @@ LIB = os.path.join(HERE, "libjuicer_amd.so")
 BATCH_TEST = os.path.join(HERE, "jd_batch_test")
 BATCH_SRC = os.path.join(CSRC, "jd_batch_test.cpp")
 SOURCES = [os.path.join(CSRC, "jd_host.cpp"), os.path.join(CSRC, "jd_device.hip")]
+HEADERS_EXTRA = [os.path.join(CSRC, "jd_search.h")]
 HEADERS = [os.path.join(CSRC, "jd_internal.h"), os.path.join(ROOT, "include", "juicer_amd.h"),
            os.path.join(ROOT, "include", "juicer_amd_decoder.hpp"), BATCH_SRC]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -36,7 +37,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB) or not os.path.exists(BATCH_TEST):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + [__file__])
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + HEADERS_EXTRA + [__file__])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -44,17 +44,10 @@ class CHyp(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("gmm_ms", C.c_double), ("search_ms", C.c_double), ("total_ms", C.c_double),
+                ("gmm_wait_ms", C.c_double),
                 ("gmm_launches", C.c_int32), ("search_launches", C.c_int32),
-                ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64), ("search_steps", C.c_int64),
-                ("kernel_us", C.c_double * 6), ("kernel_samples", C.c_int32), ("closure_inline", C.c_int32)]
-
-KERNEL_NAMES = ["k_boundary", "k_phase_a", "k_expand<0>", "k_expand<1>", "k_expand_tail", "k_resolve"]
-# launch slots when the network's closures run inline (jd_timing.closure_inline): slots 3, 4 unused
-KERNEL_NAMES_INLINE = ["k_boundary", "k_phase_a", "k_expand_closure", None, None, "k_resolve"]
-
-
-def kernel_names(timing: dict):
-    return KERNEL_NAMES_INLINE if timing.get("closure_inline") else KERNEL_NAMES
+                ("relaunches", C.c_int32), ("cluster_wgs", C.c_int32),
+                ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64), ("search_frames", C.c_int64)]
 
 
 @dataclass
@@ -369,13 +362,13 @@ class Decoder:
     def last_timing(self) -> dict:
         t = Timing()
         _check(lib().jd_dec_last_timing(self.h, C.byref(t)))
-        out = {f: getattr(t, f) for f, _ in Timing._fields_}
-        out["kernel_us"] = [float(v) for v in t.kernel_us]
-        return out
+        return {f: getattr(t, f) for f, _ in Timing._fields_}
 
-    def debug_trace(self, frame: int, fetch: bool = False):
-        buf = np.zeros((4, 65536, 4), np.int64) if fetch else None
-        _check(lib().jd_dec_debug_trace(self.h, C.c_int32(frame), None if buf is None else _p(buf, C.c_int64)))
+    def debug_trace(self, enable: int = 0, fetch: bool = False):
+        """In-kernel cycle accounting of k_search: enable, or fetch [1024, 8] int64 sums per
+        workgroup {phase A, barrier, phase X, barrier, frames} in 100 MHz ticks."""
+        buf = np.zeros((1024, 8), np.int64) if fetch else None
+        _check(lib().jd_dec_debug_trace(self.h, C.c_int32(enable), None if buf is None else _p(buf, C.c_int64)))
         return buf
 
     def close(self):

@@ -559,11 +559,11 @@ def small_tree(built):
 
 
 @pytest.mark.parametrize("bi", range(len(BEAMS)))
-def test_inline_closure_tree_hub(small_tree, bi):
+def test_tree_hub_closure_rounds(small_tree, bi):
     """A determinised-C.L.G-shaped graph (prefix-tree back-off state, tee model between words,
-    eps:word arcs inside the tree): its epsilon / tee closures are statically small, so the
-    closure runs inside the expansion kernel (k_expand_closure, 4 launches per frame).
-    Same results as the oracle, and as the staged kernels on the same graph."""
+    eps:word arcs inside the tree): every frame runs epsilon / tee closure rounds behind the exit
+    tokens (one cluster barrier per non-empty round).  Same results as the oracle, and the same
+    whatever the cluster size (1 workgroup: no inter-workgroup traffic at all; 7: ragged)."""
     import os
     from juicer_amd import capi
     from oracle.oracle import OracleDecoder
@@ -572,30 +572,20 @@ def test_inline_closure_tree_hub(small_tree, bi):
     big = (1 << 25) if kw.get("main_beam", 0.0) in (0.0, 200.0) and not kw.get("max_hyps") else 0
     gd = capi.Decoder(gnet, gam, max_streams=len(feats), max_paths=big, **kw)
     gs = gd.decode_batch(feats)
-    assert gd.last_timing()["closure_inline"] == 1
     od = OracleDecoder(onet, oam, **kw)
     for u, x in enumerate(feats):
         o = od.decode_certified(x)
         assert_hyp_matches(gs[u], o, "tree utt %d %s" % (u, kw))
-    os.environ["JD_INLINE_CLOSURE"] = "0"                     # development knob: force the staged kernels
-    try:
-        gd2 = capi.Decoder(gnet, gam, max_streams=len(feats), max_paths=big, **kw)
-        g2 = gd2.decode_batch(feats)
-        assert gd2.last_timing()["closure_inline"] == 0
-    finally:
-        del os.environ["JD_INLINE_CLOSURE"]
-    for a, b in zip(gs, g2):
-        assert a.n == b.n and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
-        assert np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
-        for k in ("tot_active_models", "tot_proc_emit_hyps", "tot_proc_end_hyps", "tot_insts_in"):
-            assert a.stats[k] == b.stats[k]
-
-
-def test_closure_mode_follows_the_graph(toy, small, small_tree):
-    """Flat hub (one eps:word arc per word below every back-off): closure too large for the
-    inline queue -> staged rounds; toy / tree-hub graphs -> inline."""
-    from juicer_amd import capi
-    for cfg, want in ((toy, 1), (small, 0), (small_tree, 1)):
-        gd = capi.Decoder(cfg[0], cfg[1], main_beam=150.0, max_streams=1)
-        gd.decode_batch(cfg[4][:1])
-        assert gd.last_timing()["closure_inline"] == want
+    for cw in ("1", "7"):
+        os.environ["JD_CW"] = cw                                  # development knob: workgroups per stream cluster
+        try:
+            gd2 = capi.Decoder(gnet, gam, max_streams=len(feats), max_paths=big, **kw)
+            g2 = gd2.decode_batch(feats)
+            assert gd2.last_timing()["cluster_wgs"] == int(cw)
+        finally:
+            del os.environ["JD_CW"]
+        for a, b in zip(gs, g2):
+            assert a.n == b.n and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
+            assert np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
+            for k in ("tot_active_models", "tot_proc_emit_hyps", "tot_proc_end_hyps", "tot_insts_in"):
+                assert a.stats[k] == b.stats[k]
