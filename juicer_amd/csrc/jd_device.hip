@@ -222,10 +222,10 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 // entry-token candidates point at those) or from bestFinalToken are kept, everything else is
 // dropped.  No effect on results.  One 1024-thread block per stream, run between launches; a no-op
 // below the threshold.
-template <int GS>
+template <int NE>
 __global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamDev *streams, const int2 *work, int s_single)
 {
-    typedef RecLayout<GS> RL;
+    typedef RecLayout<NE> RL;
     const int s = work ? work[blockIdx.x].x : s_single;
     StreamCtl &c = ctl[s];
     StreamDev &S = streams[s];
@@ -234,7 +234,6 @@ __global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamD
     __shared__ int sh_w[16];
     __shared__ int sh_carry;
     const int tid = threadIdx.x, NTH = blockDim.x, lane = tid & 63, wid = tid >> 6;
-    const int MN = C.max_n;
     const int nw = c.lst_nw;
     const Geo g = make_geo(C, nw);
     const int p = c.frame & 1;                       // list the next frame reads; items of the last frame: parity p^1
@@ -242,21 +241,25 @@ __global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamD
     for (int q = tid; q < np; q += NTH) idx[q] = 0;
     __syncthreads();
     auto mark = [&](int q) { while (q >= 0 && atomicExch(&idx[q], 1) == 0) q = S.paths[q].prev; };
+    // token of emitting state j (1..NE) of record q of wave segment w (structure-of-arrays chunks of 64)
+    auto tok_ptr = [&](int w, int q, int fld) -> int4 * {
+        return (int4 *)((char *)S.rec + (size_t)p * C.cap_slots * RL::REC_BYTES
+                        + ((size_t)w * (g.seg_rec >> 6) + (size_t)(q >> 6)) * RL::CHUNK_BYTES + (size_t)fld * 1024 + (size_t)(q & 63) * 16);
+    };
     // mark: tokens of the instance records ...
     for (int w = wid; w < nw; w += 16) {
         const int n_rec = min(S.tot[(size_t)(TOT_REC0 + p) * MAXW + w], (int)g.seg_rec);
-        for (int k = lane; k < n_rec * MN; k += 64) {
-            const int q = k / MN, i = k - q * MN;
-            const int *rec = S.rec[p] + ((size_t)w * g.seg_rec + q) * RL::REC_INTS;
-            const int n = rec[1] & 0xff;
-            if (i >= 1 && i < n - 1) {
-                const Tok t = ((const Tok *)(rec + RL::TOK_OFF))[i];
-                if (t.score > LZ) mark(t.path);
+        for (int k = lane; k < n_rec * NE; k += 64) {
+            const int q = k / NE, j = k - q * NE + 1;
+            const int n = tok_ptr(w, q, 0)->y & 0xff;
+            if (j < n - 1) {
+                const int4 t = *tok_ptr(w, q, RL::HF + j - 1);
+                if (__int_as_float(t.x) > LZ) mark(t.w);
             }
         }
         // ... and of the last frame's frontier items
         const int n_it = min(S.item_end[w], (int)g.seg_item);
-        for (int k = lane; k < n_it; k += 64) mark(S.item_tok[p ^ 1][(size_t)w * g.seg_item + k].path);
+        for (int k = lane; k < n_it; k += 64) mark(S.items[2 * ((size_t)(p ^ 1) * C.cap_items + (size_t)w * g.seg_item + k)].w);
     }
     if (tid == 0) mark(c.best_final.path);
     __syncthreads();
@@ -291,19 +294,18 @@ __global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamD
     // remap the tokens
     for (int w = wid; w < nw; w += 16) {
         const int n_rec = min(S.tot[(size_t)(TOT_REC0 + p) * MAXW + w], (int)g.seg_rec);
-        for (int k = lane; k < n_rec * MN; k += 64) {
-            const int q = k / MN, i = k - q * MN;
-            int *rec = S.rec[p] + ((size_t)w * g.seg_rec + q) * RL::REC_INTS;
-            const int n = rec[1] & 0xff;
-            if (i >= 1 && i < n - 1) {
-                Tok *t = (Tok *)(rec + RL::TOK_OFF) + i;
-                if (t->path >= 0) t->path = (t->score > LZ) ? idx[t->path] : -1;
+        for (int k = lane; k < n_rec * NE; k += 64) {
+            const int q = k / NE, j = k - q * NE + 1;
+            const int n = tok_ptr(w, q, 0)->y & 0xff;
+            if (j < n - 1) {
+                int4 *t = tok_ptr(w, q, RL::HF + j - 1);
+                if (t->w >= 0) t->w = (__int_as_float(t->x) > LZ) ? idx[t->w] : -1;
             }
         }
         const int n_it = min(S.item_end[w], (int)g.seg_item);
         for (int k = lane; k < n_it; k += 64) {
-            Tok *t = S.item_tok[p ^ 1] + (size_t)w * g.seg_item + k;
-            if (t->path >= 0) t->path = idx[t->path];
+            int4 *t = S.items + 2 * ((size_t)(p ^ 1) * C.cap_items + (size_t)w * g.seg_item + k);   // token half of the item
+            if (t->w >= 0) t->w = idx[t->w];
         }
     }
     __syncthreads();
@@ -466,7 +468,7 @@ struct jd_dec {
     // device copies of static data
     int *d_row_ptr = nullptr; JdArc *d_arcs = nullptr; float *d_fin_w = nullptr; int *d_aux = nullptr;
     int *d_se32 = nullptr;
-    float *d_hmm_tee = nullptr, *d_trP = nullptr;
+    float *d_hmm_tee = nullptr, *d_trP = nullptr, *d_hmm_tmax0 = nullptr;
     // per-stream state
     StreamDev *d_streams = nullptr;
     StreamCtl *d_ctl = nullptr;
@@ -586,6 +588,14 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     }
     TRY(dupload(d, &d->d_fin_w, net->fin_w.data(), net->fin_w.size()));
     TRY(dupload(d, &d->d_hmm_tee, am->hmm_tee.data(), am->hmm_tee.size()));
+    {   // largest log transition probability out of the entry state of every HMM (phase X, hopeless candidates)
+        std::vector<float> tmax((size_t)am->n_hmm, LZ);
+        for (int h = 0; h < am->n_hmm; ++h) {
+            const float *t0 = am->trP.data() + (size_t)am->hmm_tm[(size_t)h] * am->max_n * am->max_n;
+            for (int j = 0; j < am->hmm_n[(size_t)h]; ++j) tmax[(size_t)h] = std::max(tmax[(size_t)h], t0[j]);
+        }
+        TRY(dupload(d, &d->d_hmm_tmax0, tmax.data(), tmax.size()));
+    }
     TRY(dupload(d, &d->d_trP, am->trP.data(), am->trP.size()));
     std::vector<int> se32((size_t)am->n_tm * am->max_n);
     for (size_t i = 0; i < se32.size(); ++i)
@@ -594,7 +604,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     TRY(upload_am_gmm(am, d->amb));
     C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init;
     C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
-    C.hmm_tee = d->d_hmm_tee;
+    C.hmm_tee = d->d_hmm_tee; C.hmm_tmax0 = d->d_hmm_tmax0;
     {   // per-arc instance template: what phase A needs to attach an instance (attachNetInst :751-774),
         // one hop from the arc id: {nStates | transMat << 8, g0, g1, g2} (+ {g3, g4, g5, 0})
         const int AI = (am->max_n <= 5) ? 4 : 8;
@@ -657,7 +667,7 @@ static int ensure_arenas(jd_dec *d)
     int rc = check_device(d->device);
     if (rc) return rc;
     const int B = d->max_streams, MN = d->am->max_n;
-    const int64_t rec_bytes = (MN <= 5) ? 128 : 256;
+    const int64_t rec_bytes = (MN <= 5) ? RecLayout<3>::REC_BYTES : RecLayout<6>::REC_BYTES;
     {   // Capacities the caller did not set: sized for 288 GB of HBM, not for frugality.  Half of the
         // free memory is split over the streams; of a stream's share (after its per-arc / per-state
         // tables) 50% goes to instance records, 20% to frontier items, 30% to Path records - each
@@ -668,12 +678,12 @@ static int ensure_arenas(jd_dec *d)
         const double n_arcs = (double)d->net->n_arcs, n_states = (double)d->net->n_states;
         const double fixed = n_arcs * sizeof(ArcState) + n_states * 24.0 + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
         const double budget = std::max(0.0, 0.5 * (double)free_b / B - fixed);
-        const double rec_b = 2.0 * rec_bytes, item_b = 2.0 * (sizeof(Tok) + sizeof(int4)) + 16.0;
+        const double rec_b = 2.0 * rec_bytes, item_b = 2.0 * (sizeof(Tok) + sizeof(int4)) + 32.0;
         const double path_b = 2.0 * sizeof(PathRec) + 4.0;
         auto pick = [](double share, int64_t lo, int64_t hi) {
             return std::max<int64_t>(std::min<int64_t>(hi, (int64_t)share), std::min(lo, hi));
         };
-        const int64_t lim_rec = 0xffffff00LL / rec_bytes, lim_item = 0xffffff00LL / 16;
+        const int64_t lim_rec = (0xe0000000LL / (2 * rec_bytes)) & ~63LL, lim_item = 0xe0000000LL / 64;
         if (d->cap_slots <= 0) d->cap_slots = pick(0.5 * budget / rec_b, 1 << 19, std::min<int64_t>(d->net->n_arcs + 65536, lim_rec));
         if (d->cap_items <= 0) d->cap_items = pick(0.2 * budget / item_b, 1 << 21, std::min<int64_t>(std::max<int64_t>(2 * d->net->n_arcs + 65536, 1 << 21), lim_item));
         if (d->cap_paths <= 0) d->cap_paths = pick(0.3 * budget / path_b, 1 << 21, 1 << 26);
@@ -681,7 +691,7 @@ static int ensure_arenas(jd_dec *d)
             return jd_fail(JD_EINVAL, "arena capacity too large (instance records and frontier items are addressed "
                            "with 32-bit byte offsets: at most %lld / %lld records)", (long long)lim_rec, (long long)lim_item);
         // every wave of a stream's cluster owns 1/NW of each arena (NW <= MAXW): keep a useful segment
-        d->cap_slots = std::max<int64_t>(d->cap_slots, 4 * MAXW);
+        d->cap_slots = std::max<int64_t>(d->cap_slots, 64 * MAXW) & ~63LL;   // >= one 64-record chunk per wave segment
         d->cap_items = std::max<int64_t>(d->cap_items, 16 * MAXW);
         d->cap_new = std::min<int64_t>(4 * d->cap_items, 0x7fffff00LL);
     }
@@ -695,13 +705,11 @@ static int ensure_arenas(jd_dec *d)
         StreamDev &S = d->h_streams[(size_t)s];
         memset(&S, 0, sizeof S);
 #define A(p, n) do { rc = dmalloc(d, &(p), (size_t)(n)); if (rc) return rc; } while (0)
-        A(S.rec[0], d->cap_slots * (rec_bytes / 4));
-        A(S.rec[1], d->cap_slots * (rec_bytes / 4));
+        A(S.rec, 2 * d->cap_slots * (rec_bytes / 4));
         A(S.ast, d->net->n_arcs);
         A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states);
-        A(S.item_tok[0], d->cap_items); A(S.item_tok[1], d->cap_items);
-        A(S.item_info[0], d->cap_items); A(S.item_info[1], d->cap_items);
-        A(S.newl, d->cap_new);
+        A(S.items, 4 * d->cap_items);
+        A(S.newl, d->cap_new); A(S.cleanl, d->cap_new);
         A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW);
         A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths);
         A(S.hist, 2 * HIST_MAX_BINS);
@@ -860,18 +868,18 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work, const float *
     A.pack = d->pack && (A.n_slots % 8 == 0);
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
     A.status = d->d_status; A.dbg = d->d_dbg;
-    const bool gs4 = d->am->max_n <= 5;
+    const bool ne3 = d->am->max_n <= 5;
     const int max_rounds = (f_end - f0) + 64;                          // every launch makes at least one frame of progress
     for (int it = 0;; ++it) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
         HIPCHK(hipEventRecord(e0, st));
-        if (gs4) hipLaunchKernelGGL(k_search<4>, dim3(A.n_slots * A.Cw), dim3(SNT), 0, st, A);
-        else hipLaunchKernelGGL(k_search<8>, dim3(A.n_slots * A.Cw), dim3(SNT), 0, st, A);
+        if (ne3) hipLaunchKernelGGL(k_search<3>, dim3(A.n_slots * A.Cw), dim3(SNT), 0, st, A);
+        else hipLaunchKernelGGL(k_search<6>, dim3(A.n_slots * A.Cw), dim3(SNT), 0, st, A);
         HIPCHK(hipEventRecord(e1, st));
-        if (gs4) hipLaunchKernelGGL(k_gc<4>, dim3(n_work), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, d->d_work, 0);
-        else hipLaunchKernelGGL(k_gc<8>, dim3(n_work), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, d->d_work, 0);
+        if (ne3) hipLaunchKernelGGL(k_gc<3>, dim3(n_work), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, d->d_work, 0);
+        else hipLaunchKernelGGL(k_gc<6>, dim3(n_work), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, d->d_work, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""In-kernel cycle accounting of k_search on the bench workload (or --arcs/--beam/--utts):
+per workgroup {phase A, barrier wait, phase X, barrier wait} in 100 MHz ticks, averaged."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from juicer_amd import capi, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--utts", type=int, default=64)
+ap.add_argument("--arcs", type=int, default=1_000_000)
+ap.add_argument("--beam", type=float, default=150.0)
+ap.add_argument("--max-hyps", type=int, default=0)
+ap.add_argument("--trim", type=int, default=0, help="cut every utterance to this many frames (0 = keep)")
+args = ap.parse_args()
+am, net, feats, _ = synth.config_c2(n_utts=args.utts, target_arcs=args.arcs)
+if args.trim:
+    feats = [f[:args.trim] for f in feats]
+dec = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=args.beam, max_hyps=args.max_hyps,
+                   max_streams=args.utts)
+dec.decode_batch(feats)
+dec.debug_trace(0)
+h = dec.decode_batch(feats)
+tm = dec.last_timing()
+buf = dec.debug_trace(0, fetch=True)
+used = buf[buf[:, 4] > 0]
+fr = used[:, 4].astype(np.float64)
+names = ["phase A", "barrier 1", "phase X", "barrier 2+"]
+print("workgroups that ran frames: %d, stream-frames per workgroup: mean %.0f" % (len(used), fr.mean()))
+tot = 0.0
+for k, n in enumerate(names):
+    us = used[:, k] / 100.0 / fr
+    tot += us.mean()
+    print("%-11s mean %7.2f us/frame   min %7.2f   max %7.2f" % (n, us.mean(), us.min(), us.max()))
+print("sum %.2f us/frame;  search_ms %.2f for %d frames, %d launches, last cluster size %d"
+      % (tot, tm["search_ms"], tm["search_frames"], tm["search_launches"], tm["cluster_wgs"]))
+st = {k: sum(x.stats[k] for x in h) for k in h[0].stats}
+print({k: round(v / tm["search_frames"], 1) for k, v in st.items() if k.startswith("tot")})
