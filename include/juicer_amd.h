@@ -252,8 +252,9 @@ int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 
 /* Diagnostics: per-workgroup cycle accounting of k_search (100 MHz wall clock).  enable >= 0 with
  * fetch == NULL switches it on and clears it, enable < 0 switches it off; with fetch != NULL
- * (1024 x 8 int64) the sums so far are copied out: per workgroup of the grid
- * {phase A, barrier wait, phase X, barrier wait, frames, -, -, -}. */
+ * (1024 x 16 int64) the sums so far are copied out: per workgroup of the grid (thread 0's timeline)
+ * {work lists A, phase A, workgroup wait, cluster barrier 1, work lists X, phase X, workgroup wait,
+ *  cluster barriers of X, frames, ...}. */
 int jd_dec_debug_trace(jd_dec *d, int32_t enable, int64_t *fetch);
 
 /*

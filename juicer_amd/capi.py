@@ -365,9 +365,9 @@ class Decoder:
         return {f: getattr(t, f) for f, _ in Timing._fields_}
 
     def debug_trace(self, enable: int = 0, fetch: bool = False):
-        """In-kernel cycle accounting of k_search: enable, or fetch [1024, 8] int64 sums per
-        workgroup {phase A, barrier, phase X, barrier, frames} in 100 MHz ticks."""
-        buf = np.zeros((1024, 8), np.int64) if fetch else None
+        """In-kernel cycle accounting of k_search: enable, or fetch [1024, 16] int64 sums per workgroup
+        {lists A, phase A, wg wait, barrier 1, lists X, phase X, wg wait, barriers X, frames} in 100 MHz ticks."""
+        buf = np.zeros((1024, 16), np.int64) if fetch else None
         _check(lib().jd_dec_debug_trace(self.h, C.c_int32(enable), None if buf is None else _p(buf, C.c_int64)))
         return buf
 

@@ -709,7 +709,7 @@ static int ensure_arenas(jd_dec *d)
         A(S.ast, d->net->n_arcs);
         A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states);
         A(S.items, 4 * d->cap_items);
-        A(S.newl, d->cap_new); A(S.cleanl, d->cap_new);
+        A(S.newl, d->cap_new); A(S.cleanl, d->cap_new); A(S.dirtyl, d->cap_new);
         A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW);
         A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths);
         A(S.hist, 2 * HIST_MAX_BINS);
@@ -1123,13 +1123,14 @@ extern "C" int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out)
 }
 
 // Diagnostics: per-workgroup cycle accounting of k_search (100 MHz wall clock): for every
-// workgroup of the grid {phase A, barrier wait, phase X, barrier wait, frames}, summed over the
-// launches since it was enabled.  enable >= 0 switches it on (and clears it), < 0 off;
-// fetch (1024 x 8 int64, may be NULL) receives the current sums.
+// workgroup of the grid {work lists A, phase A, workgroup wait, cluster barrier, work lists X, phase X,
+// workgroup wait, cluster barriers, frames} (thread 0's timeline), summed over the launches since it
+// was enabled.  enable >= 0 switches it on (and clears it), < 0 off;
+// fetch (1024 x 16 int64, may be NULL) receives the current sums.
 extern "C" int jd_dec_debug_trace(jd_dec *d, int32_t enable, int64_t *fetch)
 {
     if (!d) return jd_fail(JD_EINVAL, "jd_dec_debug_trace: null");
-    const size_t n = (size_t)1024 * 8;
+    const size_t n = (size_t)1024 * 16;
     static_assert(sizeof(long long) == sizeof(int64_t), "");
     if (fetch && d->d_dbg) {
         HIPCHK(hipDeviceSynchronize());

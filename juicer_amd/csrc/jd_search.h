@@ -16,8 +16,10 @@
 //            previous frame's expansion left the best candidate of each arc in a 64-bit key
 //            (ordered score << 32 | frontier item) - so there is no separate "resolve" pass, and a
 //            new instance is only ever written if something in it survives its first frame.
-//   phase X  frontier expansion (propagateToken): exit tokens, then epsilon / tee closure rounds
-//            (one barrier per non-empty round), atomic-max recombination into the per-arc keys.
+//   phase X  frontier expansion (propagateToken): exit tokens; the epsilon / tee closure of what a
+//            wave produces is expanded by that wave right away (a per-wave queue in LDS; what does
+//            not fit goes to a further round behind a barrier), atomic-max recombination into the
+//            per-arc keys.
 //
 // No list is shared for appending: every wave owns a segment of each output list (instance
 // records, frontier items, newly entered arcs) and publishes its fill count at the end of the
@@ -107,20 +109,26 @@ struct __align__(128) StreamCtl {
 struct StreamDev {      // per-stream arenas
     int *rec;                         // instance records, [2][cap_slots] by frame parity: list f&1 is read by frame f
     ArcState *ast;                    // per ARC
-    unsigned long long *skey[2];      // per STATE: best frontier item arriving there (round parity)
-    unsigned long long *skeyL;        // round 0 only: items whose arc carries a word label (own threshold)
+    unsigned long long *skey[2];      // per STATE: [0] best exit token arriving there (reset by its winner),
+                                      // [1] best closure item so far (running maximum, zeroed through the dirty list)
+    unsigned long long *skeyL;        // exit tokens whose arc carries a word label (own threshold)
     int4 *items;                      // frontier items of a frame, [2][cap_items] by frame parity: 32 bytes each,
-                                      // token + {arc, out, to, -}
+                                      // token + {arc, out, to, flag}; flag 1 = a closure item that needs no
+                                      // expansion in a later round (done by its producer, or superseded)
     int *newl;                        // arcs entered this frame that have no instance and may survive the next frame
     int *cleanl;                      // arcs entered this frame whose first candidate was hopeless (key clean-up, see phase X)
-    int *tot;                         // published per-wave fill counts: [rec0 | rec1 | new | exit | closure0 | closure1 | clean][MAXW]
+    int *dirtyl;                      // states whose closure key (skey[1]) became non-zero this frame
+    int *tot;                         // published per-wave fill counts, TOT_N arrays of MAXW
     int *item_end;                    // per wave: items written in the last processed frame (k_gc)
     PathRec *paths; int *hist;        // hist: [2][HIST_MAX_BINS] by frame parity
     PathRec *paths2; int *gc_idx;     // Path garbage collection: compaction target + mark / new-index array
     // result of jd_finish_kernel
     int res_n; int *res_label; int *res_time; float *res_score, *res_ac, *res_lm; int res_cap;
 };
-enum { TOT_REC0 = 0, TOT_REC1 = 1, TOT_NEW = 2, TOT_EXIT = 3, TOT_CL0 = 4, TOT_CL1 = 5, TOT_CLEAN = 6, TOT_N = 7 };
+enum { TOT_REC0 = 0, TOT_REC1 = 1, TOT_NEW = 2, TOT_CLEAN = 3, TOT_DIRTY = 4, TOT_EXIT = 5,
+       TOT_CL0 = 6, TOT_CL1 = 7,        // closure items left for the next round: size of the range that holds them (0: none)
+       TOT_CLS0 = 8, TOT_CLS1 = 9,      // ... and where that range starts in the wave's item segment
+       TOT_N = 10 };
 
 struct SearchArgs {
     DecConst C;
@@ -133,13 +141,14 @@ struct SearchArgs {
     const float *ll; long long ll_stride; int f0;   // likelihoods: ll[slot * ll_stride + (f - f0) * G + g]
     int f_end;               // process frames < min(T, f_end)
     int *status;             // += 1 for every stream that stopped early (Path garbage collection needed)
-    long long *dbg;          // optional: per-workgroup cycle accounting [phase A, barrier, phase X, barrier, frames]
+    long long *dbg;          // optional: per-workgroup cycle accounting (jd_dec_debug_trace)
 };
 
 // ------------------------------------------------------------------ device helpers
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define AUX_SC1 16
+#define QCAP 64                      // closure items a wave keeps for itself (inline closure queue)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigned long long bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(unsigned)(bytes > 0xffffffffULL ? 0xffffffffULL : bytes), 0x00020000);
@@ -165,45 +174,87 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v)
     for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_xor(v, o); v = y > v ? y : v; }
     return v;
 }
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
 
+#define NLISTS 4
 struct SearchShared {
-    int pfx_a[MAXW + 1]; int cnt_a[MAXW];      // chunk prefix / fill counts of list a (records; items)
-    int pfx_b[MAXW + 1]; int cnt_b[MAXW];      // ... of list b (newly entered arcs)
-    int pfx_c[MAXW + 1]; int cnt_c[MAXW];      // ... of list c (key clean-up)
+    int pfx[NLISTS][MAXW + 1]; int cnt[NLISTS][MAXW];   // chunk prefix / fill counts of the lists a phase reads
     int start[MAXW];                           // per writer wave: where its items of the current round begin
     int hist[HIST_MAX_BINS];                   // this workgroup's share of the frame's histogram
     int hprev[HIST_MAX_BINS];                  // the stream's bins of the previous frame
     float trP[TRP_LDS_MAX]; int se[TRP_LDS_MAX / 4];   // transition tables (when they fit)
     int wpfx[SW][64];                          // phase X: per wave, prefix of the out-degrees of its 64 items
-    int wsum[SW];
+    v4i qtok[SW][QCAP], qinfo[SW][QCAP];       // phase X: per wave, closure items it will expand itself
+    int wsum[NLISTS][SW], wsum2[NLISTS][SW];
+    int next;                                  // next chunk (of this workgroup's share) to hand to a wave
     unsigned best;
     int abort;
     int new_all;                               // arcs entered without an instance (this workgroup, this frame)
     int stat[ST_N];                            // this workgroup's counters of the current frame
     long long acc[ST_N];                       // ... summed over the frames of the launch
-    long long clk[4];
+    long long clk[8];
 };
 
-// exclusive prefix over the per-wave chunk counts of a published list.  All SNT threads call it.
-// K = records per chunk; segcap = capacity of one wave segment (counts are clamped to it).
-__device__ __forceinline__ int build_prefix(SearchShared &sh, int *pfx, int *cnt, const int *tot, int nw, int K, unsigned segcap)
+// Turn the published per-wave fill counts of up to NLISTS lists into chunk prefixes (LDS).  The
+// loads of all lists are in flight together and the scans share two barriers.  All SNT threads
+// call it.  K = records per chunk; segcap = capacity of a wave segment (counts are clamped to it).
+struct ListSrc { const int *tot; int K; unsigned segcap; };
+template <int N>
+__device__ __forceinline__ void build_lists(SearchShared &sh, const ListSrc (&src)[N], int nw, int (&Q)[N], int (&items)[N])
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int c = 0;
-    if (tid < nw) { c = CL(tot + tid); if (c < 0) c = 0; if ((unsigned)c > segcap) c = (int)segcap; }
+    int c[N], n[N], x[N], y[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[k] = (tid < nw) ? CL(src[k].tot + tid) : 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (c[k] < 0) c[k] = 0;
+        if ((unsigned)c[k] > src[k].segcap) c[k] = (int)src[k].segcap;
+        n[k] = (c[k] + src[k].K - 1) / src[k].K;
+        x[k] = n[k]; y[k] = c[k];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int u = __shfl_up(x[k], o), v = __shfl_up(y[k], o);
+            if (lane >= o) { x[k] += u; y[k] += v; }
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { sh.wsum[k][wid] = x[k]; sh.wsum2[k][wid] = y[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int base = 0, total = 0, it = 0;
+#pragma unroll
+        for (int w = 0; w < SW; ++w) { const int s = sh.wsum[k][w]; if (w < wid) base += s; total += s; it += sh.wsum2[k][w]; }
+        if (tid < nw) { sh.pfx[k][tid] = base + x[k] - n[k]; sh.cnt[k][tid] = c[k]; }
+        if (tid == 0) sh.pfx[k][nw] = total;
+        Q[k] = RFL(total); items[k] = RFL(it);
+    }
+    __syncthreads();
+}
+// the same list again with another chunk size (counts are already in LDS)
+__device__ __forceinline__ int rebuild_list(SearchShared &sh, int k, int nw, int K)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = (tid < nw) ? sh.cnt[k][tid] : 0;
     const int n = (c + K - 1) / K;
     int x = n;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) sh.wsum[wid] = x;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(x, o); if (lane >= o) x += u; }
+    if (lane == 63) sh.wsum[k][wid] = x;
     __syncthreads();
     int base = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < SW; ++w) { const int s = sh.wsum[w]; if (w < wid) base += s; total += s; }
-    if (tid < nw) { pfx[tid] = base + x - n; cnt[tid] = c; }
-    if (tid == 0) pfx[nw] = total;
+    for (int w = 0; w < SW; ++w) { const int s = sh.wsum[k][w]; if (w < wid) base += s; total += s; }
+    if (tid < nw) sh.pfx[k][tid] = base + x - n;
+    if (tid == 0) sh.pfx[k][nw] = total;
     __syncthreads();
-    return __builtin_amdgcn_readfirstlane(total);
+    return RFL(total);
 }
 
 // largest w in [0, nw) with pfx[w] <= r (r < pfx[nw], wave-uniform): two ballot steps.  Empty
@@ -217,7 +268,17 @@ __device__ __forceinline__ int find_seg(const int *pfx, int nw, int r)
     const int base = (__popcll(m1) - 1) * stride;
     int i2 = base + lane; if (i2 > nw) i2 = nw;
     const unsigned long long m2 = __ballot(lane < stride && pfx[i2] <= r);
-    return __builtin_amdgcn_readfirstlane(base + __popcll(m2) - 1);
+    return RFL(base + __popcll(m2) - 1);
+}
+
+// Chunks of a phase are dealt to workgroups round-robin (chunk u belongs to workgroup u % Cw) and,
+// inside a workgroup, handed to whichever wave is free next - the waves of a workgroup wait for each
+// other at the end of the phase anyway.  sh.next is reset (and a barrier passed) before the phase.
+__device__ __forceinline__ int grab_chunk(SearchShared &sh, int jw, int Cw)
+{
+    int k = 0;
+    if ((threadIdx.x & 63) == 0) k = atomicAdd(&sh.next, 1);
+    return jw + RFL(k) * Cw;
 }
 
 // ---- cluster barrier: all Cw workgroups of one stream.  target = Cw * (number of this barrier).
@@ -227,13 +288,16 @@ __device__ __forceinline__ void cluster_barrier(SearchShared &sh, StreamCtl &c, 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     ++nbar;
-    if (Cw > 1 && threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = nbar * (unsigned)Cw;
-        unsigned spins = 0;
-        while (CL(&c.bar) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0 && wall_clock64() > t_limit) { sh.abort = 1; break; }
+    if (threadIdx.x == 0) {
+        sh.next = 0;
+        if (Cw > 1) {
+            __hip_atomic_fetch_add(&c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = nbar * (unsigned)Cw;
+            unsigned spins = 0;
+            while (CL(&c.bar) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0 && wall_clock64() > t_limit) { sh.abort = 1; break; }
+            }
         }
     }
     __syncthreads();
@@ -283,9 +347,8 @@ __device__ __host__ __forceinline__ Geo make_geo(const DecConst &C, int nw)
 struct StreamView {     // wave-uniform descriptors of one stream's arenas
     __amdgpu_buffer_rsrc_t rec, items;          // both frame parities in one descriptor each
     unsigned rec_par, item_par;                 // byte offset of parity 1 in them
-    ArcState *ast; unsigned long long *skey0, *skey1, *skeyL; int *newl, *cleanl; int *tot; PathRec *paths; int *hist;
+    ArcState *ast; unsigned long long *skey0, *skeyC, *skeyL; int *newl, *cleanl, *dirtyl; int *tot; PathRec *paths; int *hist;
 };
-
 
 // byte offset of chunk ci of wave segment w in a record list (parity offset added by the caller)
 template <int NE>
@@ -299,13 +362,13 @@ __device__ __forceinline__ unsigned rec_chunk_off(unsigned seg_rec, int w, int c
 // doHMMInternalPropagation (:899-935) + HMMInternalPropagation (:376-484).  One lane owns one
 // instance and updates its emitting states in turn, so a wave has 64 instances in flight and all
 // loads of a pass are issued back to back (no divergent load branches: lanes without work read
-// out of range and get zeros).  A wave takes chunks of 64 (of ONE writer segment) round-robin;
-// survivors and exit tokens go to the wave's own output segments - no atomics, no barriers.
-// Work items: [0, Qr) chunks of instance records, [Qr, Qr+Qn) chunks of newly entered arcs,
-// [Qr+Qn, Qr+Qn+Qc) chunks of arcs whose keys only need cleaning.
+// out of range and get zeros).  Waves take chunks of 64 (of ONE writer segment); survivors and exit
+// tokens go to the wave's own output segments - no atomics, no barriers.  Work items, in this
+// order: chunks of instance records (list 0), of newly entered arcs (1), of arcs whose keys only
+// need cleaning (2), of states whose closure keys need zeroing (3).
 template <int NE, bool TRPL>
 __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
-                                        const Geo &gin, const Geo &gout, int Qr, int Qn, int Qc, int gw, int NW, int p,
+                                        const Geo &gin, const Geo &gout, const int (&Q)[4], int jw, int Cw, int gw, int p,
                                         float normalise, float emitTh, float startTh, const float *llrow,
                                         int &out_cnt, int &exit_cnt)
 {
@@ -319,29 +382,35 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     const unsigned rcur = p ? V.rec_par : 0u, rnext = p ? 0u : V.rec_par;           // byte offsets of the two lists
     const unsigned iprev = p ? 0u : V.item_par, icur = p ? V.item_par : 0u;
     const unsigned item_base = (unsigned)gw * gout.seg_item;
+    const int Q01 = Q[0] + Q[1], Q012 = Q01 + Q[2], Qall = Q012 + Q[3];
     int c_insts = 0, c_pemit = 0, c_emit = 0, c_end = 0, c_surv = 0;
     unsigned mo = 0u;
 #pragma nounroll
-    for (int u = gw; u < Qr + Qn + Qc; u += NW) {
-        if (u >= Qr + Qn) {
-            // key clean-up: arcs whose first candidate of the previous frame was hopeless and that
-            // did not make it onto the new list afterwards keep a stale key - nobody else consumes it
-            const int ru = u - Qr - Qn;
-            const int w = find_seg(sh.pfx_c, gin.nw, ru);
-            const int ci = ru - __builtin_amdgcn_readfirstlane(sh.pfx_c[w]);
-            if (ci * 64 + lane < __builtin_amdgcn_readfirstlane(sh.cnt_c[w])) {
-                const int b = CL(V.cleanl + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
-                if (CL(&V.ast[b].live) != 2) CS(&V.ast[b].key, 0ULL);
+    for (;;) {
+        const int u = grab_chunk(sh, jw, Cw);
+        if (u >= Qall) break;
+        if (u >= Q01) {
+            // key clean-up.  (2) arcs whose first candidate of the previous frame was hopeless and that
+            // did not make it onto the new list afterwards keep a stale key - nobody else consumes it;
+            // (3) closure keys are running maxima that nobody resets during their frame
+            const int k = (u >= Q012) ? 3 : 2;
+            const int ru = u - (k == 3 ? Q012 : Q01);
+            const int w = find_seg(sh.pfx[k], gin.nw, ru);
+            const int ci = ru - RFL(sh.pfx[k][w]);
+            if (ci * 64 + lane < RFL(sh.cnt[k][w])) {
+                const int b = CL((k == 3 ? V.dirtyl : V.cleanl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
+                if (k == 3) CS(V.skeyC + b, 0ULL);
+                else if (CL(&V.ast[b].live) != 2) CS(&V.ast[b].key, 0ULL);
             }
             continue;
         }
-        const bool is_new = u >= Qr;
-        const int ru = is_new ? u - Qr : u;
-        const int *pfx = is_new ? sh.pfx_b : sh.pfx_a;
-        const int *cnt = is_new ? sh.cnt_b : sh.cnt_a;
+        const bool is_new = u >= Q[0];
+        const int ru = is_new ? u - Q[0] : u;
+        const int *pfx = sh.pfx[is_new ? 1 : 0];
+        const int *cnt = sh.cnt[is_new ? 1 : 0];
         const int w = find_seg(pfx, gin.nw, ru);
-        const int ci = ru - __builtin_amdgcn_readfirstlane(pfx[w]);
-        const bool valid = ci * 64 + lane < __builtin_amdgcn_readfirstlane(cnt[w]);
+        const int ci = ru - RFL(pfx[w]);
+        const bool valid = ci * 64 + lane < RFL(cnt[w]);
         v4i h0, h1, h2 = {0, 0, 0, 0};
         Tok tk[NE + 1];
         if (!is_new) {
@@ -498,13 +567,20 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
 
 // ------------------------------------------------------------------ phase X
 //
-// propagateToken (:491-605) for one round of frontier items.  One lane owns one item (threshold,
-// winner check, Path record, final state); the out-arcs of the wave's 64 items are then pooled:
-// lane l takes arcs l, l+64, ... of the concatenated ranges, so a history state with thousands of
-// out-arcs occupies the whole wave and items with few arcs share a pass.  State-level
-// recombination: of all items that reached a state in one round only the best (per threshold
-// class) is expanded - every item would add the same arc weights, and float addition is monotone,
-// so no other item can win anything downstream.
+// propagateToken (:491-605).  One lane owns one frontier item (threshold, winner check, Path
+// record, final state); the out-arcs of the wave's items are then pooled: lane l takes arcs
+// l, l+64, ... of the concatenated ranges, so a history state with thousands of out-arcs occupies
+// the whole wave and items with few arcs share a pass.
+//
+// State-level recombination.  All items at one state add the same arc weights and float addition
+// is monotone, so only the best item at a state can win anything downstream.  Exit tokens (round
+// 0) bid for their state in phase A; after the barrier exactly the best one finds its own index in
+// the state's key and is expanded.  Closure items (a token that has just traversed an epsilon arc
+// or a tee model, :533-540 / :584-600) are produced while the expansion runs, so their keys are
+// RUNNING maxima: an item is expanded iff it is the best arrival at its state so far (checked when
+// it is produced and again when it is taken up) - the best one is always expanded, a state at most
+// O(log arrivals) times, results are the same.  A wave expands the closure items it produces
+// itself, right away (QCAP of them wait in LDS); the rest is left for a further round.
 //
 // Hopeless candidates.  An entry token with (score + max_j trP[0][j]) - bestA <= -mainBeam
 // (bestA = this frame's best emitting score) fails :409 next frame whatever happens: that frame
@@ -513,43 +589,60 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
 // is counted (new_all) but only put on the new list - i.e. tried in the next phase A - once a
 // candidate arrives that is not hopeless; an arc whose first candidate was hopeless goes to the
 // clean-up list so that its key does not outlive the frame.
-struct XOut { int item_cnt; int new_cnt; int clean_cnt; };
+struct XOut { int item_cnt; int new_cnt; int clean_cnt; int dirty_cnt; };
 __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
-                                        const Geo &gin, const Geo &gout, int Q, int round, int gw, int NW,
+                                        const Geo &gin, const Geo &gout, int Q, int KX, int round, int jw, int Cw, int gw,
                                         int p, int pframe, bool init, bool last_frame, float endTh, float wordTh,
-                                        float bestA, XOut &out, int &round_items)
+                                        float bestA, XOut &out, int &deferred)
 {
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = RFL(threadIdx.x >> 6);
     const float INF = __builtin_inff();
     const unsigned icur = p ? V.item_par : 0u;
-    unsigned long long *sk_in_u = (round & 1) ? V.skey1 : V.skey0;
-    unsigned long long *sk_in_l = (round == 0) ? V.skeyL : sk_in_u;
-    unsigned long long *sk_out = (round & 1) ? V.skey0 : V.skey1;
-    const bool check_th = round == 0 && !init;                         // :952-962
     const bool can_filter = !init && C.emit_win > 0.0f && bestA > LZ;
     const unsigned item_base = (unsigned)gw * gout.seg_item, new_base = (unsigned)gw * gout.seg_new;
     int *wpfx = sh.wpfx[wid];
+    v4i *qtok = sh.qtok[wid], *qinfo = sh.qinfo[wid];
+    int q_n = 0;                                                       // closure items waiting in this wave's queue
     int c_arcs = 0, c_paths = 0, c_pend = 0, c_new = 0;
     unsigned mo = 0u;
 #pragma nounroll
-    for (int u = gw; u < Q; u += NW) {
-        const int w = find_seg(sh.pfx_a, gin.nw, u);
-        const int ci = u - __builtin_amdgcn_readfirstlane(sh.pfx_a[w]);
-        const bool valid = ci * 64 + lane < __builtin_amdgcn_readfirstlane(sh.cnt_a[w]);
-        const unsigned ii = (unsigned)w * gin.seg_item + (unsigned)(__builtin_amdgcn_readfirstlane(sh.start[w]) + ci * 64 + lane);
+    for (;;) {
+        // ---- a batch of up to 64 items: the wave's own closure queue first, else the next chunk
+        bool valid, exit_kind;
+        unsigned ii;
+        Tok t;
+        v4i info;
+        if (q_n > 0) {
+            valid = lane < q_n;
+            exit_kind = false;
+            t = as_tok(qtok[lane & (QCAP - 1)]);
+            info = qinfo[lane & (QCAP - 1)];
+            ii = (unsigned)info.w;                                     // (the queue keeps the item's index here)
+            q_n = 0;
+        } else {
+            const int u = grab_chunk(sh, jw, Cw);
+            if (u >= Q) break;
+            const int w = find_seg(sh.pfx[0], gin.nw, u);
+            const int ci = u - RFL(sh.pfx[0][w]);
+            valid = lane < KX && ci * KX + lane < RFL(sh.cnt[0][w]);
+            ii = (unsigned)w * gin.seg_item + (unsigned)(RFL(sh.start[w]) + ci * KX + lane);
+            const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
+            t = as_tok(ld16(V.items, ioff));
+            info = ld16(V.items, ioff + 16u);                          // {arc, out, to, flag}; arc -1 = the start token
+            exit_kind = round == 0;
+            if (!exit_kind && info.w != 0) valid = false;              // expanded by its producer / superseded
+        }
         const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
-        Tok t = as_tok(ld16(V.items, ioff));
-        const v4i info = ld16(V.items, ioff + 16u);                    // {arc, out, to, -}; arc -1 = the start token
         const bool real = valid && info.x >= 0;                        // an item that traversed an arc
         const int state = !valid ? 0 : (info.x >= 0) ? info.z : C.init_state;
         // second level, in flight together: CSR row bounds, the state's key, the Path reservation
         const int rs = C.row_ptr[state], rs1 = C.row_ptr[state + 1];
-        unsigned long long *sk = ((info.y != 0) ? sk_in_l : sk_in_u) + state;
+        unsigned long long *sk = (!exit_kind ? V.skeyC : (info.y != 0) ? V.skeyL : V.skey0) + state;
         unsigned long long kv = 0ULL;
         if (real) kv = CL(sk);
         bool have = valid;
-        if (real && check_th) {
+        if (real && exit_kind && !init) {                              // :952-962
             have = t.score > ((info.y != 0) ? wordTh : endTh);
             if (have) ++c_pend;
         }
@@ -564,10 +657,10 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             pbase = __shfl(pbase, first);
         }
         if (real) {
-            // every state that received a bid is cleaned up by its winner, expanded or not (an item
-            // below its threshold still holds the key of its state if it was the best one there)
             const bool winner = (unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL;
-            if (winner) CS(sk, 0ULL);
+            // every state that received exit-token bids is cleaned up by its winner, expanded or not (an
+            // item below its threshold still holds the key of its state if it was the best one there)
+            if (winner && exit_kind) CS(sk, 0ULL);
             have = have && winner;
         }
         if (have && real) {
@@ -600,25 +693,33 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
         const int tot = __shfl(incl, 63);
         wpfx[lane] = incl - deg;                                       // wave-private: a wave's LDS operations are ordered
+        // owner of pooled arc a = largest g with wpfx[g] <= a; its arc record is fetched one pass ahead
+        auto owner_of = [&](int a) { int g = 0;
+#pragma unroll
+            for (int stp = 32; stp > 0; stp >>= 1) if (wpfx[g + stp] <= a) g += stp;
+            return g; };
+        int g_nx = owner_of(lane);
+        int b_nx = __shfl(rs, g_nx) + (lane - wpfx[g_nx]);
+        JdArc Bk_nx = {0, 0.0f, 0, 0};
+        if (lane < tot) Bk_nx = C.arcs[b_nx];
 #pragma nounroll
         for (int a0 = 0; a0 < tot; a0 += 64) {
             const int a = a0 + lane;
-            int g = 0;                                                 // largest g with wpfx[g] <= a (the item that owns arc a)
-#pragma unroll
-            for (int stp = 32; stp > 0; stp >>= 1) if (wpfx[g + stp] <= a) g += stp;
-            const int off = a - wpfx[g];
+            const int g = g_nx, b = b_nx;
+            const JdArc Bk = Bk_nx;
+            if (a0 + 64 < tot) {                                       // next pass's arc records: in flight during this one
+                g_nx = owner_of(a + 64);
+                b_nx = __shfl(rs, g_nx) + (a + 64 - wpfx[g_nx]);
+                if (a + 64 < tot) Bk_nx = C.arcs[b_nx];
+            }
             Tok tg;
             tg.score = __shfl(t.score, g); tg.ac = __shfl(t.ac, g);
             tg.lm = __shfl(t.lm, g); tg.path = __shfl(t.path, g);
             const unsigned iig = (unsigned)__shfl((int)ii, g);
-            const int rsg = __shfl(rs, g);
             bool mk = false, touch = false, clean = false;
             Tok un = null_tok();
-            v4i uinfo = {-1, 0, 0, 0};
             int tb = -1;
             if (a < tot) {
-                const int b = rsg + off;
-                const JdArc Bk = C.arcs[b];
                 ++c_arcs;
                 const int inl = Bk.in & ~TEE_FLAG;
                 if (inl == 0) {                                        // :533-540 epsilon input
@@ -626,7 +727,6 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                     un.score = tg.score + Bk.w;
                     un.lm = tg.lm + Bk.w;
                     mk = un.score > endTh;
-                    uinfo = (v4i){b, Bk.out, Bk.to, 0};
                 } else {                                               // :560-582 entry-token recombination
                     const float ns = tg.score + Bk.w;
                     const unsigned so = f2o(ns);
@@ -654,7 +754,6 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                         un.lm = tg.lm + Bk.w;
                         un.path = tg.path;
                         mk = ns2 > ((Bk.out != 0) ? wordTh : endTh);
-                        uinfo = (v4i){b, Bk.out, Bk.to, 0};
                     }
                 }
             }
@@ -670,19 +769,46 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                     out.new_cnt += nt; out.clean_cnt += nc;
                 }
             }
-            // closure items -> this wave's item segment (next round), bidding for their state
-            const unsigned long long bm = __ballot(mk);
-            if (bm) {
-                const int nm = __popcll(bm);
-                if (out.item_cnt + nm > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); }
-                else {
-                    if (mk) {
-                        const unsigned k = item_base + (unsigned)(out.item_cnt + rank_in(bm));
-                        st16(V.items, icur + k * 32u, as_v4(un));
-                        st16(V.items, icur + k * 32u + 16u, uinfo);
-                        atomicMax(sk_out + uinfo.z, ((unsigned long long)f2o(un.score) << 32) | k);
+            // closure items: the best arrival at its state so far is kept (running maximum), written to
+            // this wave's item segment and - if the wave's queue has room - expanded by this wave itself
+            if (__ballot(mk)) {
+                const unsigned so = f2o(un.score);
+                bool pass = false;                                     // cheap pre-filter before an index is spent
+                if (mk) pass = so > (unsigned)(CL(V.skeyC + Bk.to) >> 32);
+                const unsigned long long bp = __ballot(pass);
+                const int np = __popcll(bp);
+                if (out.item_cnt + np > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); }
+                else if (np) {
+                    const unsigned k = item_base + (unsigned)(out.item_cnt + rank_in(bp));
+                    bool keep = false, first = false;
+                    if (pass) {
+                        const unsigned long long key = ((unsigned long long)so << 32) | k;
+                        const unsigned long long old = atomicMax(V.skeyC + Bk.to, key);
+                        keep = key > old; first = old == 0ULL;
                     }
-                    out.item_cnt += nm; round_items += nm;
+                    const unsigned long long bk = __ballot(keep), bf = __ballot(first);
+                    const int room = QCAP - q_n;
+                    const bool inl = keep && rank_in(bk) < room;       // expanded by this wave, right after this batch
+                    if (pass) {
+                        st16(V.items, icur + k * 32u, as_v4(un));
+                        st16(V.items, icur + k * 32u + 16u, (v4i){b, Bk.out, Bk.to, (keep && !inl) ? 0 : 1});
+                    }
+                    if (inl) {
+                        const int qi = q_n + rank_in(bk);
+                        qtok[qi] = as_v4(un); qinfo[qi] = (v4i){b, Bk.out, Bk.to, (int)k};
+                    }
+                    const int nk = __popcll(bk);
+                    const int n_inl = nk < room ? nk : room;
+                    q_n += n_inl; deferred += nk - n_inl;
+                    out.item_cnt += np;
+                    if (bf) {                                          // closure keys used this frame: zeroed by the next phase A
+                        const int nf = __popcll(bf);
+                        if (out.dirty_cnt + nf > (int)gout.seg_new) { if (lane == 0) CS(&c.err[p], (int)JDE_NEW); }
+                        else {
+                            if (first) CS(V.dirtyl + (size_t)new_base + (unsigned)(out.dirty_cnt + rank_in(bf)), Bk.to);
+                            out.dirty_cnt += nf;
+                        }
+                    }
                 }
             }
         }
@@ -707,25 +833,26 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
     const DecConst &C = A.C;
     StreamCtl &c = A.ctl[s];
     const StreamDev &S = A.streams[s];
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform values live in SGPRs
+    const int tid = threadIdx.x, lane = tid & 63, wid = RFL(tid >> 6);     // wave-uniform values live in SGPRs
     const int Cw = A.Cw, NW = Cw * SW, gw = jw * SW + wid;
     const int MN = C.max_n;
     // ---- launch-constant state (line 0 of the control block is not written while the launch runs)
-    int f = __builtin_amdgcn_readfirstlane(c.frame);
-    const int T = __builtin_amdgcn_readfirstlane(c.T);
-    const bool needs_init = __builtin_amdgcn_readfirstlane(c.needs_init) != 0;
+    int f = RFL(c.frame);
+    const int T = RFL(c.T);
+    const bool needs_init = RFL(c.needs_init) != 0;
     if (!c.started || c.error != 0) return;
     const int f_stop = T < A.f_end ? T : A.f_end;
     if (!needs_init && f >= f_stop) return;
-    float best_emit = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.best_emit)));
-    const int old_nw = __builtin_amdgcn_readfirstlane(c.lst_nw);
+    float best_emit = __int_as_float(RFL(__float_as_int(c.best_emit)));
+    const int old_nw = RFL(c.lst_nw);
     Geo gin = make_geo(C, old_nw > 0 ? old_nw : NW);
     const Geo gout = make_geo(C, NW);
     StreamView V;
     V.rec = mk_rsrc(S.rec, 2ULL * C.cap_slots * RL::REC_BYTES);
     V.items = mk_rsrc(S.items, 2ULL * C.cap_items * 32u);
     V.rec_par = C.cap_slots * (unsigned)RL::REC_BYTES; V.item_par = C.cap_items * 32u;
-    V.ast = S.ast; V.skey0 = S.skey[0]; V.skey1 = S.skey[1]; V.skeyL = S.skeyL; V.newl = S.newl; V.cleanl = S.cleanl;
+    V.ast = S.ast; V.skey0 = S.skey[0]; V.skeyC = S.skey[1]; V.skeyL = S.skeyL;
+    V.newl = S.newl; V.cleanl = S.cleanl; V.dirtyl = S.dirtyl;
     V.tot = S.tot; V.paths = S.paths; V.hist = S.hist;
     const bool use_hist = C.max_hyps > 0;
     const bool trp_lds = (size_t)C.n_tm * MN * MN <= TRP_LDS_MAX && (size_t)C.n_tm * MN <= TRP_LDS_MAX / 4;
@@ -735,9 +862,9 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
         for (int i = tid; i < C.n_tm * MN; i += SNT) sh.se[i] = C.se32[i];
     }
     if (tid == 0) {
-        sh.abort = 0; sh.best = 0u; sh.new_all = 0;
+        sh.abort = 0; sh.best = 0u; sh.new_all = 0; sh.next = 0;
         for (int k = 0; k < ST_N; ++k) { sh.stat[k] = 0; sh.acc[k] = 0; }
-        for (int k = 0; k < 4; ++k) sh.clk[k] = 0;
+        for (int k = 0; k < 8; ++k) sh.clk[k] = 0;
     }
     if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) sh.hist[b] = 0;
     __syncthreads();
@@ -747,26 +874,28 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
     int my_item_end = 0;                                               // items this wave wrote in the last processed frame
     bool aborted = false, failed = false;
     bool init_pending = needs_init;
+    auto tot_of = [&](int k) { return V.tot + (size_t)k * MAXW; };
 
     // =============================================================== recognitionStart (:139-228), part 1
     if (needs_init) {
-        // drop whatever the previous utterance left behind: instance flags and pending candidates
+        // drop whatever the previous utterance left behind: instance flags, pending candidates, closure keys
         const int p0 = f & 1;
-        const int Qr = build_prefix(sh, sh.pfx_a, sh.cnt_a, V.tot + (size_t)(TOT_REC0 + p0) * MAXW, gin.nw, 64, gin.seg_rec);
-        const int Qn = build_prefix(sh, sh.pfx_b, sh.cnt_b, V.tot + (size_t)TOT_NEW * MAXW, gin.nw, 64, gin.seg_new);
-        const int Qc = build_prefix(sh, sh.pfx_c, sh.cnt_c, V.tot + (size_t)TOT_CLEAN * MAXW, gin.nw, 64, gin.seg_new);
-        for (int u = gw; u < Qr + Qn + Qc; u += NW) {
-            const int kind = (u >= Qr + Qn) ? 2 : (u >= Qr) ? 1 : 0;
-            const int ru = kind == 2 ? u - Qr - Qn : kind == 1 ? u - Qr : u;
-            const int *pfx = kind == 2 ? sh.pfx_c : kind == 1 ? sh.pfx_b : sh.pfx_a;
-            const int *cnt = kind == 2 ? sh.cnt_c : kind == 1 ? sh.cnt_b : sh.cnt_a;
-            const int w = find_seg(pfx, gin.nw, ru);
-            const int ci = ru - __builtin_amdgcn_readfirstlane(pfx[w]);
-            if (ci * 64 + lane < __builtin_amdgcn_readfirstlane(cnt[w])) {
+        const ListSrc src[4] = {{tot_of(TOT_REC0 + p0), 64, gin.seg_rec}, {tot_of(TOT_NEW), 64, gin.seg_new},
+                                {tot_of(TOT_CLEAN), 64, gin.seg_new}, {tot_of(TOT_DIRTY), 64, gin.seg_new}};
+        int Q[4], items[4];
+        build_lists<4>(sh, src, gin.nw, Q, items);
+        const int Qall = Q[0] + Q[1] + Q[2] + Q[3];
+        for (int u = gw; u < Qall; u += NW) {
+            const int kind = (u >= Q[0] + Q[1] + Q[2]) ? 3 : (u >= Q[0] + Q[1]) ? 2 : (u >= Q[0]) ? 1 : 0;
+            const int ru = u - (kind == 3 ? Q[0] + Q[1] + Q[2] : kind == 2 ? Q[0] + Q[1] : kind == 1 ? Q[0] : 0);
+            const int w = find_seg(sh.pfx[kind], gin.nw, ru);
+            const int ci = ru - RFL(sh.pfx[kind][w]);
+            if (ci * 64 + lane < RFL(sh.cnt[kind][w])) {
                 int b;
                 if (kind == 0) b = ld16(V.rec, (p0 ? V.rec_par : 0u) + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u).x;
-                else b = CL((kind == 1 ? V.newl : V.cleanl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
-                CS(&V.ast[b].key, 0ULL); CS(&V.ast[b].live, 0);
+                else b = CL((kind == 1 ? V.newl : kind == 2 ? V.cleanl : V.dirtyl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
+                if (kind == 3) CS(V.skeyC + b, 0ULL);
+                else { CS(&V.ast[b].key, 0ULL); CS(&V.ast[b].live, 0); }
             }
         }
         if (use_hist) for (int b = jw * SNT + tid; b < 2 * HIST_MAX_BINS; b += Cw * SNT) CS(V.hist + b, 0);
@@ -787,8 +916,8 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
         // "exit" segment, which holds the start token.  (Visible to the others after the next barrier.)
         gin = gout;
         if (lane == 0) {
-            CS(V.tot + (size_t)TOT_REC0 * MAXW + gw, 0); CS(V.tot + (size_t)TOT_REC1 * MAXW + gw, 0);
-            CS(V.tot + (size_t)TOT_EXIT * MAXW + gw, gw == 0 ? 1 : 0);
+            CS(tot_of(TOT_REC0) + gw, 0); CS(tot_of(TOT_REC1) + gw, 0);
+            CS(tot_of(TOT_EXIT) + gw, gw == 0 ? 1 : 0);
         }
         cluster_barrier(sh, c, Cw, nbar, t_limit);
         aborted = aborted || sh.abort != 0;
@@ -804,37 +933,41 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
         const int p = init ? 1 : (f & 1);
         // stop early when the Path arena needs collecting (k_gc runs between launches); n_paths only
         // changes in phase X, so every workgroup of the cluster reads the same value here
-        if (!init && frames_done > 0 && __builtin_amdgcn_readfirstlane(CL(&c.n_paths)) > C.gc_threshold) break;
-        long long t0 = 0, t1 = 0, t2 = 0;
-        if (A.dbg && tid == 0) t0 = t2 = wall_clock64();
+        if (!init && frames_done > 0 && RFL(CL(&c.n_paths)) > C.gc_threshold) break;
+        long long t0 = 0;
+        const bool clk_on = A.dbg != nullptr && tid == 0;
+#define CLK(slot) do { if (clk_on) { const long long tn_ = wall_clock64(); sh.clk[slot] += tn_ - t0; t0 = tn_; } } while (0)
+        if (clk_on) t0 = wall_clock64();
         int exit_cnt = (init && gw == 0) ? 1 : 0;
         unsigned ba = 0u;
         if (!init) {
             // ---- frame start (:311-339): thresholds + the work lists of phase A
             const float normalise = (best_emit > LZ) ? best_emit : 0.0f;             // :321
             float emitTh = (C.emit_win > 0.0f ? -C.emit_win : LZ);                   // :331
-            if (use_hist) {
-                // bins of the previous frame (parity p^1); every workgroup evaluates the same threshold
+            if (use_hist)                                              // bins of the previous frame (parity p^1)
                 for (int b = tid; b < C.hist_nbins; b += SNT) sh.hprev[b] = CL(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b);
-                __syncthreads();
+            const ListSrc src[4] = {{tot_of(TOT_REC0 + p), 64, gin.seg_rec}, {tot_of(TOT_NEW), 64, gin.seg_new},
+                                    {tot_of(TOT_CLEAN), 64, gin.seg_new}, {tot_of(TOT_DIRTY), 64, gin.seg_new}};
+            int Q[4], items[4];
+            build_lists<4>(sh, src, gin.nw, Q, items);
+            if (use_hist) {                                            // every workgroup evaluates the same threshold
                 float th = hist_threshold(C, sh.hprev, lane);
                 th -= normalise;                                                     // :325
                 if (C.emit_win > 0.0f && th < -C.emit_win) th = -C.emit_win;         // :326-327
                 emitTh = th;
             }
             const float startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;   // :337
-            const int Qr = build_prefix(sh, sh.pfx_a, sh.cnt_a, V.tot + (size_t)(TOT_REC0 + p) * MAXW, gin.nw, 64, gin.seg_rec);
-            const int Qn = build_prefix(sh, sh.pfx_b, sh.cnt_b, V.tot + (size_t)TOT_NEW * MAXW, gin.nw, 64, gin.seg_new);
-            const int Qc = build_prefix(sh, sh.pfx_c, sh.cnt_c, V.tot + (size_t)TOT_CLEAN * MAXW, gin.nw, 64, gin.seg_new);
             // arcs entered in the previous frame are instances of this one, tried or not (:899-935)
             if (jw == 0 && tid == 0) atomicAdd(&sh.stat[ST_INSTS], CL(&c.new_all[p ^ 1]));
             const float *llrow = A.ll + (size_t)ll_slot * A.ll_stride + (size_t)(f - A.f0) * C.G;
             int out_cnt = 0;
-            if (trp_lds) phase_a<NE, true>(C, sh, c, V, gin, gout, Qr, Qn, Qc, gw, NW, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else phase_a<NE, false>(C, sh, c, V, gin, gout, Qr, Qn, Qc, gw, NW, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            CLK(0);                                                    // thresholds + work lists
+            if (trp_lds) phase_a<NE, true>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else phase_a<NE, false>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            CLK(1);                                                    // phase A (wave 0's share)
             if (lane == 0) {
-                CS(V.tot + (size_t)(TOT_REC0 + (p ^ 1)) * MAXW + gw, out_cnt);
-                CS(V.tot + (size_t)TOT_EXIT * MAXW + gw, exit_cnt);
+                CS(tot_of(TOT_REC0 + (p ^ 1)) + gw, out_cnt);
+                CS(tot_of(TOT_EXIT) + gw, exit_cnt);
             }
             __syncthreads();
             if (use_hist)                                              // Histogram of this frame: workgroup bins -> stream bins
@@ -843,12 +976,12 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
                     if (v) { atomicAdd(V.hist + (size_t)p * HIST_MAX_BINS + b, v); sh.hist[b] = 0; }
                 }
             if (tid == 0 && sh.best) { atomicMax(&c.bestA[p], sh.best); sh.best = 0u; }
-            if (A.dbg && tid == 0) { t1 = wall_clock64(); sh.clk[0] += t1 - t0; }
+            CLK(2);                                                    // waiting for the workgroup's other waves + publishing
             cluster_barrier(sh, c, Cw, nbar, t_limit);
             if (sh.abort) { aborted = true; break; }
             gin = gout;                                                // every list read from here on was written by this launch
-            if (A.dbg && tid == 0) { t2 = wall_clock64(); sh.clk[1] += t2 - t1; }
-            ba = (unsigned)__builtin_amdgcn_readfirstlane((int)CL(&c.bestA[p]));
+            CLK(3);                                                    // cluster barrier 1
+            ba = (unsigned)RFL((int)CL(&c.bestA[p]));
         }
         // ---- phase X
         const float bestA = ba ? o2f(ba) : LZ;
@@ -859,41 +992,55 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
             if (tid == 0) { CS(&c.bestA[p ^ 1], 0u); CS(&c.bestX[p ^ 1], 0u); CS(&c.new_all[p ^ 1], 0); }
             if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) CS(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b, 0);
         }
-        XOut xo = {exit_cnt, 0, 0};
+        XOut xo = {exit_cnt, 0, 0, 0};
         for (int round = 0;; ++round) {
-            int Q;
+            // Items are taken in chunks of KX per wave pass.  The arcs of a chunk are walked by ONE wave,
+            // so when there are fewer than 64 items per wave the chunks shrink to spread the arc walk
+            // over the cluster (the item stage just leaves lanes idle).
+            int KX = 64;
+            int Q1[1], n1[1];
             if (round == 0) {
                 if (tid < gin.nw) sh.start[tid] = 0;
-                Q = build_prefix(sh, sh.pfx_a, sh.cnt_a, V.tot + (size_t)TOT_EXIT * MAXW, gin.nw, 64, gin.seg_item);
+                const ListSrc src[1] = {{tot_of(TOT_EXIT), KX, gin.seg_item}};
+                build_lists<1>(sh, src, gin.nw, Q1, n1);
             } else {
-                if (tid < gin.nw) sh.start[tid] += sh.cnt_a[tid];      // items of round r begin where those of round r-1 ended
-                __syncthreads();
-                Q = build_prefix(sh, sh.pfx_a, sh.cnt_a, V.tot + (size_t)(TOT_CL0 + (round & 1)) * MAXW, gin.nw, 64, gin.seg_item);
-                if (Q == 0) break;
+                if (tid < gin.nw) sh.start[tid] = CL(tot_of(TOT_CLS0 + (round & 1)) + tid);
+                const ListSrc src[1] = {{tot_of(TOT_CL0 + (round & 1)), KX, gin.seg_item}};
+                build_lists<1>(sh, src, gin.nw, Q1, n1);
+                if (Q1[0] == 0) break;
             }
-            int round_items = 0;
-            phase_x(C, sh, c, V, gin, gout, Q, round, gw, NW, p, init ? 0 : f, init, last_frame, endTh, wordTh, bestA, xo, round_items);
+            int Q = Q1[0];
+            if (Q < NW) {
+                while (KX > 4 && n1[0] < KX * NW) KX >>= 1;            // about one chunk per wave
+                if (KX < 64) Q = rebuild_list(sh, 0, gin.nw, KX);
+            }
+            CLK(4);                                                    // phase X work lists
+            const int round_start = xo.item_cnt;
+            int deferred = 0;
+            phase_x(C, sh, c, V, gin, gout, Q, KX, round, jw, Cw, gw, p, init ? 0 : f, init, last_frame, endTh, wordTh, bestA, xo, deferred);
+            CLK(5);                                                    // phase X (wave 0's share)
             if (lane == 0) {
-                CS(V.tot + (size_t)(TOT_CL0 + ((round + 1) & 1)) * MAXW + gw, round_items);
-                CS(V.tot + (size_t)TOT_NEW * MAXW + gw, xo.new_cnt);
-                CS(V.tot + (size_t)TOT_CLEAN * MAXW + gw, xo.clean_cnt);
+                CS(tot_of(TOT_CL0 + ((round + 1) & 1)) + gw, deferred > 0 ? xo.item_cnt - round_start : 0);
+                CS(tot_of(TOT_CLS0 + ((round + 1) & 1)) + gw, round_start);
+                CS(tot_of(TOT_NEW) + gw, xo.new_cnt);
+                CS(tot_of(TOT_CLEAN) + gw, xo.clean_cnt);
+                CS(tot_of(TOT_DIRTY) + gw, xo.dirty_cnt);
             }
             __syncthreads();
             if (tid == 0) {
                 if (sh.best) { atomicMax(&c.bestX[p], sh.best); sh.best = 0u; }
                 if (sh.new_all) { atomicAdd(&c.new_all[p], sh.new_all); sh.new_all = 0; }
             }
-            long long t3 = 0;
-            if (A.dbg && tid == 0) { t3 = wall_clock64(); sh.clk[2] += t3 - t2; }
+            CLK(6);                                                    // waiting for the workgroup's other waves + publishing
             cluster_barrier(sh, c, Cw, nbar, t_limit);
             if (sh.abort) { aborted = true; break; }
-            if (A.dbg && tid == 0) { t2 = wall_clock64(); sh.clk[3] += t2 - t3; }
+            CLK(7);                                                    // cluster barriers of phase X
         }
         if (aborted) break;
         my_item_end = xo.item_cnt;
         // ---- frame end
         {
-            const unsigned bx = (unsigned)__builtin_amdgcn_readfirstlane((int)CL(&c.bestX[p]));
+            const unsigned bx = (unsigned)RFL((int)CL(&c.bestX[p]));
             const unsigned bb = ba > bx ? ba : bx;
             best_emit = bb ? o2f(bb) : LZ;                             // :417-418, :572-573
         }
@@ -912,7 +1059,7 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
             }
             c.best_final = bf;
         }
-        if (__builtin_amdgcn_readfirstlane(CL(&c.err[p])) != 0) failed = true;       // raised before this frame's last barrier: seen by all
+        if (RFL(CL(&c.err[p])) != 0) failed = true;                    // raised before this frame's last barrier: seen by all
         if (init) init_pending = false;
         else { ++f; ++frames_done; }
     }
@@ -926,8 +1073,9 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
     if (tid == 0) {
         for (int k = 0; k < ST_N; ++k) if (sh.acc[k]) atomicAdd((unsigned long long *)&c.st[k], (unsigned long long)sh.acc[k]);
         if (A.dbg) {
-            long long *d = A.dbg + (size_t)blockIdx.x * 8;
-            d[0] += sh.clk[0]; d[1] += sh.clk[1]; d[2] += sh.clk[2]; d[3] += sh.clk[3]; d[4] += frames_done;
+            long long *d = A.dbg + (size_t)blockIdx.x * 16;
+            for (int k = 0; k < 8; ++k) d[k] += sh.clk[k];
+            d[8] += frames_done;
         }
         if (jw == 0) {
             const int e0 = CL(&c.err[0]), e1 = CL(&c.err[1]);
@@ -949,5 +1097,5 @@ __global__ __launch_bounds__(SNT) void k_search(SearchArgs A)
     const int q = A.pack ? (int)(blockIdx.x % (unsigned)A.n_slots) : (int)(blockIdx.x / (unsigned)A.Cw);
     const int jw = A.pack ? (int)(blockIdx.x / (unsigned)A.n_slots) : (int)(blockIdx.x % (unsigned)A.Cw);
     for (int k = q; k < A.n_work; k += A.n_slots)
-        run_stream<NE>(A, sh, __builtin_amdgcn_readfirstlane(A.work[k].x), __builtin_amdgcn_readfirstlane(A.work[k].y), jw);
+        run_stream<NE>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw);
 }

@@ -28,9 +28,9 @@ dec.debug_trace(0)
 h = dec.decode_batch(feats)
 tm = dec.last_timing()
 buf = dec.debug_trace(0, fetch=True)
-used = buf[buf[:, 4] > 0]
-fr = used[:, 4].astype(np.float64)
-names = ["phase A", "barrier 1", "phase X", "barrier 2+"]
+used = buf[buf[:, 8] > 0]
+fr = used[:, 8].astype(np.float64)
+names = ["lists A", "phase A", "wg wait A", "barrier 1", "lists X", "phase X", "wg wait X", "barriers X"]
 print("workgroups that ran frames: %d, stream-frames per workgroup: mean %.0f" % (len(used), fr.mean()))
 tot = 0.0
 for k, n in enumerate(names):
