@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 // dropped.  No effect on results.  One 1024-thread block per stream, run between launches; a no-op
 // below the threshold.
 template <int NE>
-__global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamDev *streams, const int2 *work, int s_single)
+__global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single)
 {
     typedef RecLayout<NE> RL;
     const int s = work ? work[blockIdx.x].x : s_single;
@@ -351,7 +351,7 @@ __global__ void jd_set_T_kernel(StreamCtl *ctl, int s0, int n, const int *T)
 }
 
 // before every k_search launch: the cluster barriers of the streams it advances start at zero
-__global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int2 *work, int n, int *status)
+__global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int *status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) ctl[work[i].x].bar = 0u;
@@ -468,7 +468,7 @@ struct jd_dec {
     // device copies of static data
     int *d_row_ptr = nullptr; JdArc *d_arcs = nullptr; float *d_fin_w = nullptr; int *d_aux = nullptr;
     int *d_se32 = nullptr;
-    float *d_hmm_tee = nullptr, *d_trP = nullptr, *d_hmm_tmax0 = nullptr;
+    float *d_hmm_tee = nullptr, *d_trP = nullptr, *d_hmm_tmax0 = nullptr, *d_lrt = nullptr;
     // per-stream state
     StreamDev *d_streams = nullptr;
     StreamCtl *d_ctl = nullptr;
@@ -483,8 +483,9 @@ struct jd_dec {
     int n_cus = 256;
     // search launches: one 1024-thread workgroup per CU, Cw of them per stream
     int max_cw = MAXCW;                   // upper bound of workgroups per stream cluster (JD_CW overrides)
-    int pack = 0;                         // workgroup -> cluster mapping of k_search (JD_PACK)
-    int2 *d_work = nullptr; int work_cap = 0;
+    int weighted = 1;                     // size the clusters by the streams' recent load (JD_WEIGHTED=0: uniform)
+    int4 *d_work = nullptr; int work_cap = 0;
+    std::vector<long long> load_prev;         // per stream: work counters at the end of the previous chunk (cluster sizing)
     int *d_status = nullptr; int *h_status = nullptr;
     long long *d_dbg = nullptr;           // in-kernel cycle accounting (jd_dec_debug_trace)
     // chunked pipeline
@@ -622,8 +623,37 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         C.aux = d->d_aux;
     }
     C.trP = d->d_trP; C.se32 = d->d_se32;
+    {   // Plain left-to-right topologies (every emitting state entered from its predecessor and itself,
+        // the exit state from the last emitting state - createTrPandSEIndex, HTKModels.cpp:2330-2390,
+        // gives SEIndex[j] = {j-1, j+1}): phase A then needs a_k = log P(k-1 -> k), s_k = log P(k -> k) only
+        const int MNn = am->max_n, NEn = (MNn <= 5) ? 3 : 6, LRW = (NEn == 3) ? 8 : 16;
+        bool all_lr = (size_t)am->n_tm * LRW <= TRP_LDS_MAX;
+        for (int t = 0; t < am->n_tm && all_lr; ++t) {
+            const int n = am->tm_n[(size_t)t];
+            if (n < 3) all_lr = false;
+            for (int j = 1; j < n && all_lr; ++j) {
+                const int st = am->se[((size_t)t * MNn + j) * 2], en = am->se[((size_t)t * MNn + j) * 2 + 1];
+                if (j < n - 1 ? (st != j - 1 || en != j + 1) : (st != n - 2 || en != n - 1)) all_lr = false;
+            }
+        }
+        for (int h = 0; h < am->n_hmm && all_lr; ++h)
+            if (am->hmm_n[(size_t)h] != am->tm_n[(size_t)am->hmm_tm[(size_t)h]]) all_lr = false;
+        if (getenv("JD_NO_LR")) all_lr = false;                                  // development: force the general path
+        C.lrt = nullptr;
+        if (all_lr) {
+            std::vector<float> lrt((size_t)am->n_tm * LRW, LZ);
+            for (int t = 0; t < am->n_tm; ++t) {
+                const float *tp = am->trP.data() + (size_t)t * MNn * MNn;
+                const int n = am->tm_n[(size_t)t];
+                for (int k = 1; k <= n - 1; ++k) lrt[(size_t)t * LRW + k - 1] = tp[(k - 1) * MNn + k];          // a_k
+                for (int k = 1; k <= n - 2; ++k) lrt[(size_t)t * LRW + NEn + k] = tp[k * MNn + k];              // s_k
+            }
+            TRY(dupload(d, &d->d_lrt, lrt.data(), lrt.size()));
+            C.lrt = d->d_lrt;
+        }
+    }
     if (const char *e = getenv("JD_CW")) { const int v = atoi(e); if (v >= 1 && v <= MAXCW) d->max_cw = v; }   // development
-    if (const char *e = getenv("JD_PACK")) d->pack = atoi(e) != 0;
+    if (const char *e = getenv("JD_WEIGHTED")) d->weighted = atoi(e) != 0;
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
     hipError_t e;
@@ -849,23 +879,49 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
 // workgroup per CU in total, all resident at once (the clusters synchronise with barriers of their
 // own).  A launch stops a stream early when its Path arena needs collecting; k_gc runs after every
 // launch (a no-op below the threshold) and the launch is repeated until every stream is through.
-static int launch_search(jd_dec *d, const std::vector<int2> &work, const float *ll, long long ll_stride, int f0, int f_end,
-                         hipStream_t st)
+static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const float *ll, long long ll_stride, int f0, int f_end,
+                         hipStream_t st, const std::vector<double> *weight = nullptr)
 {
-    const int n_work = (int)work.size();
+    const int n_work = (int)work_in.size();
     if (n_work == 0) return JD_OK;
     if (n_work > d->work_cap) {
         if (d->d_work) (void)hipFree(d->d_work);
-        HIPCHK(hipMalloc(&d->d_work, (size_t)n_work * sizeof(int2)));
+        HIPCHK(hipMalloc(&d->d_work, (size_t)n_work * sizeof(int4)));
         d->work_cap = n_work;
     }
-    HIPCHK(hipMemcpyAsync(d->d_work, work.data(), (size_t)n_work * sizeof(int2), hipMemcpyHostToDevice, st));
     SearchArgs A;
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work;
     const int nwg = std::max(1, d->n_cus);
     A.Cw = std::max(1, std::min(d->max_cw, nwg / n_work));
     A.n_slots = std::min(n_work, std::max(1, nwg / A.Cw));
-    A.pack = d->pack && (A.n_slots % 8 == 0);
+    std::vector<int4> work((size_t)n_work);
+    for (int k = 0; k < n_work; ++k) work[(size_t)k] = make_int4(work_in[(size_t)k].x, work_in[(size_t)k].y, k * A.Cw, A.Cw);
+    int grid = A.n_slots * A.Cw;
+    if (weight && d->weighted && n_work > 1 && n_work <= nwg && A.Cw < d->max_cw + 1 && nwg >= 2 * n_work) {
+        // weighted mode: one workgroup each, the rest in proportion to the streams' recent load
+        double tot = 0.0;
+        for (double w : *weight) tot += std::max(w, 0.0);
+        if (tot > 0.0) {
+            const int spare = nwg - n_work;
+            std::vector<int> cw((size_t)n_work, 1);
+            std::vector<std::pair<double, int>> frac;
+            int used = 0;
+            for (int k = 0; k < n_work; ++k) {
+                const double want = spare * std::max((*weight)[(size_t)k], 0.0) / tot;
+                int extra = std::min((int)want, d->max_cw - 1);
+                cw[(size_t)k] += extra; used += extra;
+                frac.push_back({want - (int)want, k});
+            }
+            std::sort(frac.begin(), frac.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first > b.first; });
+            for (size_t i = 0; i < frac.size() && used < spare; ++i)
+                if (cw[(size_t)frac[i].second] < d->max_cw) { ++cw[(size_t)frac[i].second]; ++used; }
+            int first = 0;
+            for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw[(size_t)k]; first += cw[(size_t)k]; }
+            grid = first;
+            A.n_slots = 0;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(d->d_work, work.data(), (size_t)n_work * sizeof(int4), hipMemcpyHostToDevice, st));
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
     A.status = d->d_status; A.dbg = d->d_dbg;
     const bool ne3 = d->am->max_n <= 5;
@@ -875,8 +931,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work, const float *
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
         HIPCHK(hipEventRecord(e0, st));
-        if (ne3) hipLaunchKernelGGL(k_search<3>, dim3(A.n_slots * A.Cw), dim3(SNT), 0, st, A);
-        else hipLaunchKernelGGL(k_search<6>, dim3(A.n_slots * A.Cw), dim3(SNT), 0, st, A);
+        if (ne3) hipLaunchKernelGGL(k_search<3>, dim3(grid), dim3(SNT), 0, st, A);
+        else hipLaunchKernelGGL(k_search<6>, dim3(grid), dim3(SNT), 0, st, A);
         HIPCHK(hipEventRecord(e1, st));
         if (ne3) hipLaunchKernelGGL(k_gc<3>, dim3(n_work), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, d->d_work, 0);
         else hipLaunchKernelGGL(k_gc<6>, dim3(n_work), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, d->d_work, 0);
@@ -955,16 +1011,30 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     if (rc) return rc;
     double waited_ms = 0.0;
     std::vector<int2> work;
+    std::vector<double> weight;
+    std::vector<long long> st_now((size_t)nb * ST_N), st_prev((size_t)nb * ST_N, 0);
+    std::vector<double> load((size_t)nb, 0.0);                         // work per frame of every stream in the last chunk
     for (int c = 0; c < n_chunks; ++c) {
         const auto tw0 = std::chrono::steady_clock::now();
         HIPCHK(hipEventSynchronize(ge[(size_t)c]));                    // scores of this chunk are there
         waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
         if (c + 1 < n_chunks) { rc = score_chunk(c + 1); if (rc) return rc; }
-        work.clear();
+        work.clear(); weight.clear();
         for (int u = 0; u < nb; ++u)
-            if (c == 0 || T[(size_t)u] > c * Fc) work.push_back(make_int2(u, u));
-        rc = launch_search(d, work, d->d_ll[c & 1], (long long)Fc * G, c * Fc, (c + 1) * Fc, d->s_search);
+            if (c == 0 || T[(size_t)u] > c * Fc) { work.push_back(make_int2(u, u)); weight.push_back(load[(size_t)u]); }
+        rc = launch_search(d, work, d->d_ll[c & 1], (long long)Fc * G, c * Fc, (c + 1) * Fc, d->s_search, c > 0 ? &weight : nullptr);
         if (rc) return rc;
+        if (c + 1 < n_chunks && d->weighted) {
+            // the streams' work counters (instances processed + arcs visited) size the next chunk's clusters
+            HIPCHK(hipMemcpy2D(st_now.data(), ST_N * sizeof(long long), (const char *)d->d_ctl + offsetof(StreamCtl, st),
+                               sizeof(StreamCtl), ST_N * sizeof(long long), (size_t)nb, hipMemcpyDeviceToHost));
+            for (int u = 0; u < nb; ++u) {
+                const long long *a = st_now.data() + (size_t)u * ST_N, *b = st_prev.data() + (size_t)u * ST_N;
+                const int fr = std::min((c + 1) * Fc, T[(size_t)u]) - std::min(c * Fc, T[(size_t)u]);
+                load[(size_t)u] = fr > 0 ? (double)((a[ST_INSTS] - b[ST_INSTS]) + (a[ST_ARCS] - b[ST_ARCS])) / fr : 0.0;
+            }
+            st_prev = st_now;
+        }
     }
     hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, 0, nb);
     HIPCHK(hipGetLastError());

@@ -52,6 +52,7 @@ struct DecConst {
     const float *hmm_tee;
     const float *hmm_tmax0;   // per HMM: largest log transition probability out of the entry state
     const float *trP; const int *se32;
+    const float *lrt;   // left-to-right topologies only (else null): per transMat a_1.., s_1.. (see phase A)
     // pruning (WFSTDecoderLite ctor, WFSTDecoderLite.cpp:38-82)
     float start_win, emit_win, end_win, word_win;
     int max_hyps, hist_min, hist_max, hist_nbins;
@@ -133,11 +134,11 @@ enum { TOT_REC0 = 0, TOT_REC1 = 1, TOT_NEW = 2, TOT_CLEAN = 3, TOT_DIRTY = 4, TO
 struct SearchArgs {
     DecConst C;
     StreamCtl *ctl; StreamDev *streams;
-    const int2 *work;        // {stream, likelihood slot} of every stream this launch advances
+    const int4 *work;        // {stream, likelihood slot, first workgroup, workgroups} of every stream this launch advances
     int n_work;
-    int Cw;                  // workgroups per cluster
-    int n_slots;             // clusters in the grid (slot q serves work items q, q + n_slots, ...)
-    int pack;                // 1: a cluster's workgroups are n_slots blocks apart (same XCD when n_slots % 8 == 0)
+    int Cw;                  // uniform mode: workgroups per cluster
+    int n_slots;             // uniform mode: clusters in the grid (slot q serves work items q, q + n_slots, ...);
+                             // 0 = weighted mode: work item k owns workgroups [work[k].z, work[k].z + work[k].w)
     const float *ll; long long ll_stride; int f0;   // likelihoods: ll[slot * ll_stride + (f - f0) * G + g]
     int f_end;               // process frames < min(T, f_end)
     int *status;             // += 1 for every stream that stopped early (Path garbage collection needed)
@@ -149,9 +150,15 @@ struct SearchArgs {
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define AUX_SC1 16
 #define QCAP 64                      // closure items a wave keeps for itself (inline closure queue)
+// The descriptor inputs go through readfirstlane so that the compiler can PROVE them wave-uniform;
+// otherwise it wraps every buffer access in a "waterfall" loop (cdna_hip_programming.md, T20).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigned long long bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(unsigned)(bytes > 0xffffffffULL ? 0xffffffffULL : bytes), 0x00020000);
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bytes > 0xffffffffULL ? 0xffffffffULL : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)n, 0x00020000);
 }
 // 16-byte agent-scope (sc1) accesses through a wave-uniform buffer descriptor (out-of-range
 // offsets read 0 / are dropped by the hardware bounds check)
@@ -366,7 +373,11 @@ __device__ __forceinline__ unsigned rec_chunk_off(unsigned seg_rec, int w, int c
 // tokens go to the wave's own output segments - no atomics, no barriers.  Work items, in this
 // order: chunks of instance records (list 0), of newly entered arcs (1), of arcs whose keys only
 // need cleaning (2), of states whose closure keys need zeroing (3).
-template <int NE, bool TRPL>
+//
+// LR: every transition matrix of the model set is plain left-to-right (state j is entered from j-1 and
+// itself, the exit state from the last emitting state; no skips): the predecessor loops become one
+// comparison per state, on a compact table a_k = log P(k-1 -> k), s_k = log P(k -> k) in LDS.
+template <int NE, bool TRPL, bool LR>
 __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
                                         const Geo &gin, const Geo &gout, const int (&Q)[4], int jw, int Cw, int gw, int p,
                                         float normalise, float emitTh, float startTh, const float *llrow,
@@ -451,68 +462,94 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             tk[0].ac = it.ac; tk[0].lm = it.lm + __int_as_float(h1.w); tk[0].path = it.path;
             if (tk[0].score < startTh) tk[0] = null_tok();            // :915-918 (a candidate is never LOG_ZERO)
         }
-        const float *trP = trP_all + (size_t)tm * MN * MN;
-        const int *se = se_all + (size_t)tm * MN;
         Tok nw[NE + 1];
         int live_mask = 0;
+        Tok ex = null_tok();
+        auto emit = [&](int j, float best, float btp, const Tok &src) {   // :408-424
+            const float sc = best - normalise;                         // :408
+            if (sc > emitTh) {                                         // :409
+                ++c_pemit;
+                nw[j].score = sc + outp[j - 1];
+                nw[j].ac = (src.ac + btp) + outp[j - 1];
+                nw[j].lm = src.lm;
+                nw[j].path = src.path;
+                live_mask |= 1 << j;
+                if (use_hist) {                                        // Histogram::addScore, Histogram.cpp:64-100
+                    const double ds = (double)nw[j].score;
+                    const int sci = (nw[j].score < 0.0f) ? (int)(ds - 0.5) : (int)(ds + 0.5);
+                    if (sci > C.hist_max) CS(&c.err[p], (int)JD_EHIST);
+                    else if (sci >= C.hist_min) atomicAdd(&sh.hist[sci - C.hist_min], 1);
+                }
+                const unsigned so = f2o(nw[j].score);
+                mo = so > mo ? so : mo;
+            }
+        };
+        if (LR) {
+            constexpr int LRW = (NE == 3) ? 8 : 16;                    // a_1 .. a_{NE+1}, s_1 .. s_NE
+            const float4 *lt = (const float4 *)(sh.trP + tm * LRW);
+            float tw[LRW];
 #pragma unroll
-        for (int j = 1; j <= NE; ++j) {                                // :387-424 emitting state j
-            nw[j] = null_tok();
-            if (j < n - 1) {
-                const int sev = se[j];
+            for (int q = 0; q < LRW / 4; ++q) { const float4 v = lt[q]; tw[4 * q] = v.x; tw[4 * q + 1] = v.y; tw[4 * q + 2] = v.z; tw[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int j = 1; j <= NE; ++j) {                            // :387-424 emitting state j: predecessors j-1 and j
+                nw[j] = null_tok();
+                const float a = tw[j - 1], sf = tw[NE + j];
+                const float c0 = tk[j - 1].score + a, c1 = tk[j].score + sf;
+                const bool self = c1 > c0;                             // the lower predecessor wins ties (:401)
+                Tok src;
+                src.score = 0.0f; src.ac = self ? tk[j].ac : tk[j - 1].ac; src.lm = self ? tk[j].lm : tk[j - 1].lm;
+                src.path = self ? tk[j].path : tk[j - 1].path;
+                if (j < n - 1) emit(j, self ? c1 : c0, self ? sf : a, src);
+            }
+            // exit state (:443-483): entered from the last emitting state only
+            Tok le = null_tok();
+            float ax = 0.0f;
+#pragma unroll
+            for (int i = 1; i <= NE; ++i) if (i == n - 2) { le = nw[i]; ax = tw[i]; }
+            if (le.score > LZ) { ex = le; ex.score = le.score + ax; ex.ac = le.ac + ax; if (!(ex.score > LZ)) ex = null_tok(); }
+        } else {
+            // general topologies, branch-free: every (predecessor, state) pair is evaluated and selected
+            const float *trP = trP_all + (size_t)tm * MN * MN;
+            const int *se = se_all + (size_t)tm * MN;
+#pragma unroll
+            for (int j = 1; j <= NE; ++j) {                            // :387-424 emitting state j
+                nw[j] = null_tok();
+                const int sev = se[j < MN ? j : 0];
                 const int st = sev & 0xffff, en = sev >> 16;
                 float best = 0.0f, btp = 0.0f;
                 Tok src = null_tok();
-                bool first = true;
+                bool have = false;
 #pragma unroll
                 for (int i = 0; i <= NE; ++i) {                        // predecessors in ascending order, the first wins ties
-                    if (i == st || (i > st && i < en)) {
-                        const float tp = trP[i * MN + j];
-                        const float tmp = tk[i].score + tp;
-                        if (first || tmp > best) { best = tmp; btp = tp; src = tk[i]; first = false; }
-                    }
+                    const bool v = (i == st) | ((i > st) & (i < en));
+                    const float tp = trP[(i < MN ? i : 0) * MN + (j < MN ? j : 0)];
+                    const float tmp = tk[i].score + tp;
+                    const bool take = v & (!have | (tmp > best));
+                    best = take ? tmp : best; btp = take ? tp : btp;
+                    src.ac = take ? tk[i].ac : src.ac; src.lm = take ? tk[i].lm : src.lm; src.path = take ? tk[i].path : src.path;
+                    have |= v;
                 }
-                const float sc = best - normalise;                     // :408
-                if (!first && sc > emitTh) {                           // :409
-                    ++c_pemit;
-                    nw[j].score = sc + outp[j - 1];
-                    nw[j].ac = (src.ac + btp) + outp[j - 1];
-                    nw[j].lm = src.lm;
-                    nw[j].path = src.path;
-                    live_mask |= 1 << j;
-                    if (use_hist) {                                    // Histogram::addScore, Histogram.cpp:64-100
-                        const double ds = (double)nw[j].score;
-                        const int sci = (nw[j].score < 0.0f) ? (int)(ds - 0.5) : (int)(ds + 0.5);
-                        if (sci > C.hist_max) CS(&c.err[p], (int)JD_EHIST);
-                        else if (sci >= C.hist_min) atomicAdd(&sh.hist[sci - C.hist_min], 1);
-                    }
-                    const unsigned so = f2o(nw[j].score);
-                    mo = so > mo ? so : mo;
+                if (have & (j < n - 1)) emit(j, best, btp, src);
+            }
+            // exit state (:443-483) from the NEW tokens
+            {
+                const int sev = se[n >= 2 ? n - 1 : 0];
+                const int st = sev & 0xffff, en = sev >> 16;
+                bool have = false;
+#pragma unroll
+                for (int i = 1; i <= NE; ++i) {
+                    const bool v = (i == st) | ((i > st) & (i < en));
+                    const float tp = trP[(i < MN ? i : 0) * MN + (n >= 2 ? n - 1 : 0)];
+                    const float tmp = nw[i].score + tp;
+                    const bool take = v & (!have | (tmp > ex.score));
+                    ex.score = take ? tmp : ex.score; ex.ac = take ? nw[i].ac + tp : ex.ac;
+                    ex.lm = take ? nw[i].lm : ex.lm; ex.path = take ? nw[i].path : ex.path;
+                    have |= v;
                 }
+                if (!(have & (n >= 2)) || !(ex.score > LZ)) ex = null_tok();
             }
         }
         c_emit += __popc(live_mask);
-        // exit state (:443-483) from the NEW tokens
-        Tok ex = null_tok();
-        if (n >= 2) {
-            const int sev = se[n - 1];
-            const int st = sev & 0xffff, en = sev >> 16;
-            bool first = true;
-#pragma unroll
-            for (int i = 1; i <= NE; ++i) {
-                if (i == st || (i > st && i < en)) {
-                    const float tp = trP[i * MN + (n - 1)];
-                    const float tmp = nw[i].score + tp;
-                    if (first || tmp > ex.score) {
-                        ex = nw[i];
-                        ex.score = tmp;
-                        ex.ac = nw[i].ac + tp;
-                        first = false;
-                    }
-                }
-            }
-            if (first || !(ex.score > LZ)) ex = null_tok();
-        }
         const bool has_exit = ex.score > LZ;
         const bool slot_live = live_mask != 0;
         const unsigned long long bl = __ballot(slot_live), be = __ballot(has_exit);
@@ -827,14 +864,14 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
 // ------------------------------------------------------------------ one stream, one launch
 
 template <int NE>
-__device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw)
+__device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw)
 {
     typedef RecLayout<NE> RL;
     const DecConst &C = A.C;
     StreamCtl &c = A.ctl[s];
     const StreamDev &S = A.streams[s];
     const int tid = threadIdx.x, lane = tid & 63, wid = RFL(tid >> 6);     // wave-uniform values live in SGPRs
-    const int Cw = A.Cw, NW = Cw * SW, gw = jw * SW + wid;
+    const int NW = Cw * SW, gw = jw * SW + wid;
     const int MN = C.max_n;
     // ---- launch-constant state (line 0 of the control block is not written while the launch runs)
     int f = RFL(c.frame);
@@ -855,8 +892,10 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
     V.newl = S.newl; V.cleanl = S.cleanl; V.dirtyl = S.dirtyl;
     V.tot = S.tot; V.paths = S.paths; V.hist = S.hist;
     const bool use_hist = C.max_hyps > 0;
-    const bool trp_lds = (size_t)C.n_tm * MN * MN <= TRP_LDS_MAX && (size_t)C.n_tm * MN <= TRP_LDS_MAX / 4;
+    const bool lr = C.lrt != nullptr;                                  // plain left-to-right topologies (compact table in LDS)
+    const bool trp_lds = !lr && (size_t)C.n_tm * MN * MN <= TRP_LDS_MAX && (size_t)C.n_tm * MN <= TRP_LDS_MAX / 4;
     __syncthreads();                                                   // the previous stream of this slot is done with LDS
+    if (lr) for (int i = tid; i < C.n_tm * ((NE == 3) ? 8 : 16); i += SNT) sh.trP[i] = C.lrt[i];
     if (trp_lds) {
         for (int i = tid; i < C.n_tm * MN * MN; i += SNT) sh.trP[i] = C.trP[i];
         for (int i = tid; i < C.n_tm * MN; i += SNT) sh.se[i] = C.se32[i];
@@ -962,8 +1001,9 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
             const float *llrow = A.ll + (size_t)ll_slot * A.ll_stride + (size_t)(f - A.f0) * C.G;
             int out_cnt = 0;
             CLK(0);                                                    // thresholds + work lists
-            if (trp_lds) phase_a<NE, true>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else phase_a<NE, false>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            if (lr) phase_a<NE, true, true>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else if (trp_lds) phase_a<NE, true, false>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else phase_a<NE, false, false>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
             CLK(1);                                                    // phase A (wave 0's share)
             if (lane == 0) {
                 CS(tot_of(TOT_REC0 + (p ^ 1)) + gw, out_cnt);
@@ -1086,16 +1126,24 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
     }
 }
 
-// Workgroup b belongs to cluster slot q = b / Cw (spread: consecutive blocks, i.e. consecutive
-// XCDs, serve one stream) or q = b % n_slots (pack: a stream's workgroups are n_slots apart and
-// share an XCD when n_slots is a multiple of 8).  All workgroups of the grid must be resident at
-// once - the host sizes the grid to the device (one 1024-thread workgroup per CU).
+// Uniform mode: workgroup b belongs to cluster slot q = b / Cw (consecutive blocks, i.e. consecutive
+// XCDs, serve one stream); a slot serves its streams one after the other.  Weighted mode (at most
+// one stream per workgroup): stream k owns the workgroups [first_k, first_k + n_k) - the host sizes
+// the clusters by the streams' recent load.  All workgroups of the grid must be resident at once:
+// the host sizes the grid to the device (one 1024-thread workgroup per CU).
 template <int NE>
 __global__ __launch_bounds__(SNT) void k_search(SearchArgs A)
 {
     __shared__ SearchShared sh;
-    const int q = A.pack ? (int)(blockIdx.x % (unsigned)A.n_slots) : (int)(blockIdx.x / (unsigned)A.Cw);
-    const int jw = A.pack ? (int)(blockIdx.x / (unsigned)A.n_slots) : (int)(blockIdx.x % (unsigned)A.Cw);
-    for (int k = q; k < A.n_work; k += A.n_slots)
-        run_stream<NE>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw);
+    if (A.n_slots > 0) {
+        const int q = (int)(blockIdx.x / (unsigned)A.Cw), jw = (int)(blockIdx.x % (unsigned)A.Cw);
+        for (int k = q; k < A.n_work; k += A.n_slots)
+            run_stream<NE>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, A.Cw);
+    } else {
+        int lo = 0, hi = A.n_work - 1;                                 // last k with first_k <= blockIdx.x
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (RFL(A.work[mid].z) <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+        const int4 wk = A.work[lo];
+        const int first = RFL(wk.z), n = RFL(wk.w);
+        if ((int)blockIdx.x < first + n) run_stream<NE>(A, sh, RFL(wk.x), RFL(wk.y), (int)blockIdx.x - first, n);
+    }
 }
