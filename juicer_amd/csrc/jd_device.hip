@@ -214,6 +214,106 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 }
 
 
+// ---- the D = 39 kernel: TWO frames per lane, packed fp32 arithmetic.
+//
+// A lane owns rows r and r + 64 of a 128-row tile; their vectors sit side by side in register
+// pairs, so every VALU instruction of the distance loop is a packed one (v_pk_add_f32 /
+// v_pk_mul_f32: two IEEE fp32 operations, no contraction - the same roundings as the reference's
+// scalar code, HTKFlatModels.cpp:249-250) with the tied state's (mean, ivar) pairs arriving
+// through the scalar cache.  logAdd (HTKFlatModels.cpp:266-293) evaluates log(1.0 + e), e in
+// (0, 1], in double with a 128-interval table (c = 1 + k/128; log y = -log(invc) + log1p(y invc - 1),
+// degree-7 polynomial: < 1 ulp in double, like the libm the reference links).
+#define GMM_ROWS2 128
+typedef float jd_f2 __attribute__((ext_vector_type(2)));
+struct JdLogTab { double invc, logc; };
+
+__device__ __forceinline__ float jd_log_add2(float x, float y, const JdLogTab *tab)
+{
+    if (x < y) { const float t = x; x = y; y = t; }
+    const float diff = y - x;
+    if (diff < -18.42) return x;
+    const double e = (double)jd_expf(diff);
+    const double yy = 1.0 + e;
+    const int k = (int)(e * 128.0 + 0.5);
+    const JdLogTab t = tab[k];
+    const double r = __builtin_fma(yy, t.invc, -1.0);
+    double q = 1.0 / 7.0;
+    q = __builtin_fma(q, r, -1.0 / 6.0);
+    q = __builtin_fma(q, r, 1.0 / 5.0);
+    q = __builtin_fma(q, r, -1.0 / 4.0);
+    q = __builtin_fma(q, r, 1.0 / 3.0);
+    q = __builtin_fma(q, r, -1.0 / 2.0);
+    q = __builtin_fma(q, r, 1.0);
+    return (float)((double)x + (t.logc + q * r));
+}
+
+__global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restrict__ feats,
+                                                       const int *__restrict__ row_src, int n_rows,
+                                                       const float *__restrict__ par,
+                                                       const float *__restrict__ det,
+                                                       const int *__restrict__ n_mix, int G, int M,
+                                                       float *__restrict__ ll, int skip_unused,
+                                                       const JdLogTab *__restrict__ logtab)
+{
+    constexpr int DT = 39, DP = 39;                   // odd row stride: conflict-free per-lane rows
+    extern __shared__ __align__(16) char smem[];
+    JdLogTab *stab = (JdLogTab *)smem;                // [129] (+ pad)
+    float *sx = (float *)(smem + 130 * sizeof(JdLogTab));   // [128][DP]
+    float *so = sx + GMM_ROWS2 * DP;                  // [128][GMM_GT+1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 129; i += 256) stab[i] = logtab[i];
+    const int n_rt = (n_rows + GMM_ROWS2 - 1) / GMM_ROWS2, n_gt = (G + GMM_GT - 1) / GMM_GT;
+    for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
+        // row tile skewed by the state group (see jd_gmm_kernel)
+        const int gt = tile / n_rt;
+        const int r0 = ((tile + gt) % n_rt) * GMM_ROWS2;
+        const int g0 = gt * GMM_GT;
+        if (skip_unused && row_src[r0] < 0) continue;
+        __syncthreads();                              // previous tile's LDS reads are done
+        for (int e = tid; e < GMM_ROWS2 * DT; e += 256) {
+            const int r = e / DT, j = e - r * DT;
+            const int src = (r0 + r < n_rows) ? row_src[r0 + r] : -1;
+            sx[r * DP + j] = (src >= 0) ? feats[(size_t)src * DT + j] : 0.0f;
+        }
+        __syncthreads();
+        jd_f2 x[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) { x[j].x = sx[lane * DP + j]; x[j].y = sx[(lane + 64) * DP + j]; }
+        constexpr int GPW = GMM_GT / 4;               // tied states per wave
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int gl = wid * GPW + gi;            // wave-uniform
+            const int g = g0 + gl;
+            float acc0 = LZ, acc1 = LZ;
+            if (g < G) {
+                const int nm = n_mix[g];
+                const float *pg = par + (size_t)g * M * DT * 2;
+                const float *dg = det + (size_t)g * M;
+                for (int m = 0; m < nm; ++m) {
+                    const float *pm = pg + (size_t)m * DT * 2;
+                    jd_f2 sum = {0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) {
+                        const jd_f2 mu = {pm[2 * j], pm[2 * j]}, iv = {pm[2 * j + 1], pm[2 * j + 1]};
+                        const jd_f2 xmu = x[j] - mu;              // HTKFlatModels.cpp:249
+                        sum += xmu * xmu * iv;                    // :250  (no contraction)
+                    }
+                    const double dm = (double)dg[m];
+                    acc0 = jd_log_add2(acc0, (float)(-0.5 * (double)sum.x + dm), stab);   // :254
+                    acc1 = jd_log_add2(acc1, (float)(-0.5 * (double)sum.y + dm), stab);
+                }
+            }
+            so[lane * (GMM_GT + 1) + gl] = acc0;
+            so[(lane + 64) * (GMM_GT + 1) + gl] = acc1;
+        }
+        __syncthreads();
+        for (int e = tid; e < GMM_ROWS2 * GMM_GT; e += 256) {
+            const int r = e / GMM_GT, c = e - r * GMM_GT;
+            if (r0 + r < n_rows && g0 + c < G) ll[(size_t)(r0 + r) * G + g0 + c] = so[r * (GMM_GT + 1) + c];
+        }
+    }
+}
+
 // --------------------------------------------------------------- search kernels
 #include "jd_search.h"
 
@@ -362,6 +462,7 @@ __global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int 
 
 struct AmDevBuf {
     float *par = nullptr, *det = nullptr; int *n_mix = nullptr;
+    JdLogTab *logtab = nullptr;
     int device = -1;
 };
 
@@ -380,6 +481,17 @@ static int upload_am_gmm(const jd_am *a, AmDevBuf &b)
     HIPCHK(hipMemcpy(b.par, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b.det, a->det.data(), gm * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b.n_mix, a->n_mix.data(), (size_t)a->n_gmm * sizeof(int), hipMemcpyHostToDevice));
+    {   // table of jd_log_add2: c_k = 1 + k/128, invc = fl(1/c_k), logc = -log(invc) (so that the identity
+        // log y = logc + log1p(y invc - 1) holds for the ROUNDED invc)
+        std::vector<JdLogTab> t(129);
+        for (int k = 0; k <= 128; ++k) {
+            const double c = 1.0 + k / 128.0;
+            t[(size_t)k].invc = (k == 0) ? 1.0 : 1.0 / c;
+            t[(size_t)k].logc = (k == 0) ? 0.0 : (double)(-logl((long double)t[(size_t)k].invc));
+        }
+        HIPCHK(hipMalloc(&b.logtab, t.size() * sizeof(JdLogTab)));
+        HIPCHK(hipMemcpy(b.logtab, t.data(), t.size() * sizeof(JdLogTab), hipMemcpyHostToDevice));
+    }
     return JD_OK;
 }
 
@@ -388,6 +500,7 @@ static void free_am_gmm(AmDevBuf &b)
     if (b.par) (void)hipFree(b.par);
     if (b.det) (void)hipFree(b.det);
     if (b.n_mix) (void)hipFree(b.n_mix);
+    if (b.logtab) (void)hipFree(b.logtab);
     b = AmDevBuf();
 }
 
@@ -400,16 +513,19 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
                       float *d_ll, hipStream_t st, int max_blocks = 0, int skip_unused = 0)
 {
     if (n_rows <= 0) return JD_OK;
-    const long long tiles = (long long)((n_rows + GMM_ROWS - 1) / GMM_ROWS) * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
+    const int rows_per_tile = (a->D == 39) ? GMM_ROWS2 : GMM_ROWS;
+    const long long tiles = (long long)((n_rows + rows_per_tile - 1) / rows_per_tile) * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
     dim3 grid((unsigned)((max_blocks > 0 && tiles > max_blocks) ? max_blocks : tiles));
-    const int dp = a->D | 1;
-    const size_t sm = (size_t)(GMM_ROWS * dp + GMM_ROWS * (GMM_GT + 1)) * sizeof(float);
-    if (a->D == 39)
-        hipLaunchKernelGGL(jd_gmm_kernel<39>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
-                           b.n_mix, a->n_gmm, a->max_mix, a->D, d_ll, skip_unused);
-    else
+    if (a->D == 39) {
+        const size_t sm = 130 * sizeof(JdLogTab) + (size_t)(GMM_ROWS2 * 39 + GMM_ROWS2 * (GMM_GT + 1)) * sizeof(float);
+        hipLaunchKernelGGL(jd_gmm_kernel39, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
+                           b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab);
+    } else {
+        const int dp = a->D | 1;
+        const size_t sm = (size_t)(GMM_ROWS * dp + GMM_ROWS * (GMM_GT + 1)) * sizeof(float);
         hipLaunchKernelGGL(jd_gmm_kernel<0>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
                            b.n_mix, a->n_gmm, a->max_mix, a->D, d_ll, skip_unused);
+    }
     HIPCHK(hipGetLastError());
     return JD_OK;
 }
@@ -1002,7 +1118,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         HIPCHK(hipEventRecord(gs[(size_t)c], d->s_gmm));
         // chunk 0 is on the critical path (whole chip); later chunks score in the background
         int r = launch_gmm(d->am, d->amb, d_feats, d->d_row_src + (size_t)c * nb * Fc, nb * Fc, d->d_ll[c & 1], d->s_gmm,
-                           c == 0 ? 0 : d->gmm_bg_blocks, (Fc % GMM_ROWS) == 0);
+                           c == 0 ? 0 : d->gmm_bg_blocks, (Fc % GMM_ROWS2) == 0);
         if (r) return r;
         HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm));
         return JD_OK;

@@ -33,9 +33,9 @@
 // arrives at a barrier.  Static data (graph, models, likelihoods) uses plain cached loads.
 #pragma once
 
-#define SW 16                        // waves per search workgroup
+#define SW 8                         // waves per search workgroup
 #define SNT (SW * 64)                // threads per search workgroup
-#define MAXW 1024                    // most waves one cluster may have (64 workgroups per stream)
+#define MAXW SNT                      // most waves one cluster may have (one thread per wave when the lists are set up)
 #define MAXCW (MAXW / SW)
 #define TEE_FLAG 0x40000000          // bit 30 of the device arc's in-label: the arc's HMM is a tee model
 #define TRP_LDS_MAX 4096             // floats of transition tables cached in LDS (else read from HBM)
@@ -465,7 +465,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         Tok nw[NE + 1];
         int live_mask = 0;
         Tok ex = null_tok();
-        auto emit = [&](int j, float best, float btp, const Tok &src) {   // :408-424
+        auto emit = [&](int j, float best, float btp, const Tok &src) __attribute__((always_inline)) {   // :408-424
             const float sc = best - normalise;                         // :408
             if (sc > emitTh) {                                         // :409
                 ++c_pemit;
@@ -731,7 +731,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         const int tot = __shfl(incl, 63);
         wpfx[lane] = incl - deg;                                       // wave-private: a wave's LDS operations are ordered
         // owner of pooled arc a = largest g with wpfx[g] <= a; its arc record is fetched one pass ahead
-        auto owner_of = [&](int a) { int g = 0;
+        auto owner_of = [&](int a) __attribute__((always_inline)) { int g = 0;
 #pragma unroll
             for (int stp = 32; stp > 0; stp >>= 1) if (wpfx[g + stp] <= a) g += stp;
             return g; };
@@ -864,7 +864,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
 // ------------------------------------------------------------------ one stream, one launch
 
 template <int NE>
-__device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw)
+__device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw)
 {
     typedef RecLayout<NE> RL;
     const DecConst &C = A.C;
@@ -913,7 +913,7 @@ __device__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_
     int my_item_end = 0;                                               // items this wave wrote in the last processed frame
     bool aborted = false, failed = false;
     bool init_pending = needs_init;
-    auto tot_of = [&](int k) { return V.tot + (size_t)k * MAXW; };
+    auto tot_of = [&](int k) __attribute__((always_inline)) { return V.tot + (size_t)k * MAXW; };
 
     // =============================================================== recognitionStart (:139-228), part 1
     if (needs_init) {
@@ -1135,15 +1135,15 @@ template <int NE>
 __global__ __launch_bounds__(SNT) void k_search(SearchArgs A)
 {
     __shared__ SearchShared sh;
+    int k, kstep, jw, Cw;
     if (A.n_slots > 0) {
-        const int q = (int)(blockIdx.x / (unsigned)A.Cw), jw = (int)(blockIdx.x % (unsigned)A.Cw);
-        for (int k = q; k < A.n_work; k += A.n_slots)
-            run_stream<NE>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, A.Cw);
+        k = (int)(blockIdx.x / (unsigned)A.Cw); jw = (int)(blockIdx.x % (unsigned)A.Cw); Cw = A.Cw; kstep = A.n_slots;
     } else {
         int lo = 0, hi = A.n_work - 1;                                 // last k with first_k <= blockIdx.x
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (RFL(A.work[mid].z) <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
-        const int4 wk = A.work[lo];
-        const int first = RFL(wk.z), n = RFL(wk.w);
-        if ((int)blockIdx.x < first + n) run_stream<NE>(A, sh, RFL(wk.x), RFL(wk.y), (int)blockIdx.x - first, n);
+        const int first = RFL(A.work[lo].z);
+        Cw = RFL(A.work[lo].w); jw = (int)blockIdx.x - first;
+        k = (jw < Cw) ? lo : A.n_work; kstep = A.n_work;
     }
+    for (; k < A.n_work; k += kstep) run_stream<NE>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw);
 }
