@@ -836,9 +836,10 @@ static int ensure_arenas(jd_dec *d)
         if (d->cap_slots > lim_rec || d->cap_items > lim_item || d->cap_paths > 0x7fffff00LL)
             return jd_fail(JD_EINVAL, "arena capacity too large (instance records and frontier items are addressed "
                            "with 32-bit byte offsets: at most %lld / %lld records)", (long long)lim_rec, (long long)lim_item);
-        // every wave of a stream's cluster owns 1/NW of each arena (NW <= MAXW): keep a useful segment
-        d->cap_slots = std::max<int64_t>(d->cap_slots, 64 * MAXW) & ~63LL;   // >= one 64-record chunk per wave segment
-        d->cap_items = std::max<int64_t>(d->cap_items, 16 * MAXW);
+        // every wave of a stream's cluster owns 1/NW of each arena; small arenas limit the cluster
+        // size instead (launch_search), down to one workgroup per stream
+        d->cap_slots = std::max<int64_t>(d->cap_slots, 64 * SW) & ~63LL;
+        d->cap_items = std::max<int64_t>(d->cap_items, 64 * SW);
         d->cap_new = std::min<int64_t>(4 * d->cap_items, 0x7fffff00LL);
     }
     d->C.cap_slots = (unsigned)d->cap_slots; d->C.cap_items = (unsigned)d->cap_items; d->C.cap_new = (unsigned)d->cap_new;
@@ -1008,12 +1009,16 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const floa
     SearchArgs A;
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work;
     const int nwg = std::max(1, d->n_cus);
-    A.Cw = std::max(1, std::min(d->max_cw, nwg / n_work));
+    // a wave segment holds at least one 64-record chunk of instances and 512 frontier items (one wave
+    // writes the whole epsilon closure of the items it expands)
+    const int cw_cap = (int)std::max<int64_t>(1, std::min<int64_t>(d->cap_slots / (64 * SW), d->cap_items / (512 * SW)));
+    const int max_cw = std::min(d->max_cw, cw_cap);
+    A.Cw = std::max(1, std::min(max_cw, nwg / n_work));
     A.n_slots = std::min(n_work, std::max(1, nwg / A.Cw));
     std::vector<int4> work((size_t)n_work);
     for (int k = 0; k < n_work; ++k) work[(size_t)k] = make_int4(work_in[(size_t)k].x, work_in[(size_t)k].y, k * A.Cw, A.Cw);
     int grid = A.n_slots * A.Cw;
-    if (weight && d->weighted && n_work > 1 && n_work <= nwg && A.Cw < d->max_cw + 1 && nwg >= 2 * n_work) {
+    if (weight && d->weighted && n_work > 1 && max_cw > 1 && nwg >= 2 * n_work) {
         // weighted mode: one workgroup each, the rest in proportion to the streams' recent load
         double tot = 0.0;
         for (double w : *weight) tot += std::max(w, 0.0);
@@ -1024,13 +1029,13 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const floa
             int used = 0;
             for (int k = 0; k < n_work; ++k) {
                 const double want = spare * std::max((*weight)[(size_t)k], 0.0) / tot;
-                int extra = std::min((int)want, d->max_cw - 1);
+                int extra = std::min((int)want, max_cw - 1);
                 cw[(size_t)k] += extra; used += extra;
                 frac.push_back({want - (int)want, k});
             }
             std::sort(frac.begin(), frac.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first > b.first; });
             for (size_t i = 0; i < frac.size() && used < spare; ++i)
-                if (cw[(size_t)frac[i].second] < d->max_cw) { ++cw[(size_t)frac[i].second]; ++used; }
+                if (cw[(size_t)frac[i].second] < max_cw) { ++cw[(size_t)frac[i].second]; ++used; }
             int first = 0;
             for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw[(size_t)k]; first += cw[(size_t)k]; }
             grid = first;

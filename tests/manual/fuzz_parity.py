@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity sweep (GPU box): many small seeded problems - both hub shapes, with / without
 the tee model, 5-state and mixed-topology HMMs, random pruning settings - each decoded in one
-lock-step batch and compared with the CPU oracle.  Not part of the test suite; prints a summary.
+batch and compared with the CPU oracle.  Not part of the test suite; prints a summary.
 
     python tests/manual/fuzz_parity.py [n_cases] [first_seed]
 """
@@ -28,7 +28,7 @@ def main():
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     rng = np.random.default_rng(s0)
     t0 = time.time()
-    checked = exact = ties = inline = 0
+    checked = exact = ties = 0
     for case in range(n):
         seed = s0 + case
         hub = "tree" if rng.random() < 0.6 else "flat"
@@ -47,20 +47,16 @@ def main():
         gnet = capi.Network.from_synth(net, lm, pen)
         gd = capi.Decoder(gnet, capi.Models.from_htk(am), max_streams=len(feats), **kw)
         gs = gd.decode_batch(feats)
-        inline += gd.last_timing()["closure_inline"]
         od = OracleDecoder(OracleNet(net, lm, pen), OracleAM(am), **kw)
         for u, x in enumerate(feats):
-            o = od.decode(x)
+            o = od.decode_certified(x)            # fails (never skips) if a case depended on tie order
             what = "case %d (%s hub=%s sp=%s %s lm=%g pen=%g) utt %d" % (seed, kind, hub, with_sp, kw, lm, pen, u)
-            if o.stats["ties"]:
-                ties += 1
-                if not (gs[u].n == o.n and np.array_equal(gs[u].label, o.label)):
-                    continue                      # a tie on the best path: order dependent in the reference too
-            assert_hyp_matches(gs[u], o, what, check_stats=(o.stats["ties"] == 0))
+            ties += int(o.stats["ties"] > 0)
+            assert_hyp_matches(gs[u], o, what)
             checked += 1
             exact += bit_exact(gs[u], o)
-    print("fuzz: %d cases (%d with inline closure), %d utterances checked, %d bit-exact incl. scores, %d with ties, %.1f s"
-          % (n, inline, checked, exact, ties, time.time() - t0))
+    print("fuzz: %d cases, %d utterances checked, %d bit-exact incl. scores, %d with order-dependent ties (certified), %.1f s"
+          % (n, checked, exact, ties, time.time() - t0))
 
 
 if __name__ == "__main__":

@@ -197,3 +197,16 @@ def test_adapter_compiles_inside_the_juicer_tree():
                 'int main() { return DHHTYPE == 1 ? 0 : 1; }\n')          # DecHypHistPool.h:106
         f.flush()
         subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, f.name])
+
+
+def test_csr_input_is_validated(built):
+    """jd_net_create_csr refuses malformed CSR input instead of walking out of bounds later."""
+    from juicer_amd import capi
+    ok = dict(n_states=3, init_state=0, row_ptr=[0, 2, 3, 3], to=[1, 2, 2], w=[0.5, 1.0, 0.25], ilab=[1, 2, 1],
+              olab=[0, 1, 0], fstate=[2], fweight=[0.0])
+    assert capi.Network.from_csr(**ok).n_arcs == 3
+    for bad in (dict(row_ptr=[1, 2, 3, 3]), dict(row_ptr=[0, 2, 1, 3]), dict(row_ptr=[0, 0, 0, 0]),
+                dict(to=[1, 2, 7]), dict(init_state=5)):
+        with pytest.raises(capi.JuicerAmdError) as e:
+            capi.Network.from_csr(**{**ok, **bad})
+        assert e.value.code == capi.JD_EINVAL

@@ -157,3 +157,29 @@ def test_fullsize_more_utterances_than_streams(c2):
         assert np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
         for k in STAT_KEYS:
             assert a.stats[k] == b.stats[k]
+
+
+def test_configs3_full_size(built):
+    """BASELINE.json configs[3] at FULL size: ~48M-arc trigram-shaped graph (history states with up
+    to 10^4 out-arcs, back-off epsilon arcs), 5000 tied states x 16 mixtures, mainBeam 300, 8
+    utterances in one batch (~2 million live instances per stream-frame).  The oracle needs
+    ~0.15 s per frame here, so one short utterance is checked against it - certified not to depend
+    on the visiting order of equal-score tokens - plus the batch properties."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, words = synth.config_c4(n_utts=8, utt_words=(3, 6))
+    assert net.n_arcs > 45_000_000 and am.n_gmm == 5000
+    kw = dict(main_beam=300.0)
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=8, **kw)
+    gs = gd.decode_batch(feats)
+    u = int(np.argmin([f.shape[0] for f in feats]))
+    o = OracleDecoder(OracleNet(net), OracleAM(am), **kw).decode_certified(feats[u])
+    print("configs[3]: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties, oracle %.1f frames/s"
+          % (u, feats[u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"],
+             feats[u].shape[0] / o.cpu_seconds))
+    assert_hyp_matches(gs[u], o, "configs[3] utt %d" % u)
+    assert o.stats["tot_insts_in"] / o.stats["n_frames"] > 500_000
+    for v in range(8):
+        assert gs[v].n > 0
+        t = gs[v].time[::-1]
+        assert np.all(np.diff(t) >= 0) and t[-1] <= feats[v].shape[0] - 1

@@ -1,0 +1,42 @@
+"""N>1 path on real hardware: two ranks (one process each, torch.distributed) drive the HIP decoder
+on the one GPU of the box; their gathered 1-best records equal a single-rank decode.  Also the
+bench's own rank spawning (`python bench.py --gpus 2` without torchrun)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_gather_hip_hypotheses(built):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "tests", "mr_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "identical to the single-rank decode: True" in out.stdout
+
+
+def test_bench_spawns_its_own_ranks(built):
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself (here both on GPU 0 over
+    gloo, JD_BENCH_SHARE_GPU=1 - the numbers are meaningless, the path is what is tested)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--utts-per-gpu", "6",
+           "--arcs", "60000", "--no-cpu-baseline", "--no-extra-legs"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["gathered_hyps"] == 12 and d["value"] > 0

@@ -203,16 +203,80 @@ def test_lm_scale_and_insertion_penalty(small):
         assert_hyp_matches(gs[u], od.decode_certified(feats[u]), "lmscale utt %d" % u)
 
 
-def test_arena_overflow_is_reported(small):
+@pytest.mark.parametrize("arena", ["instance slots", "frontier items", "Path records"])
+def test_arena_overflow_is_reported(small, arena):
+    """Every device arena overflows into a recoverable JD_ENOMEM that names it (never a fault, never
+    a silent truncation); small arenas also shrink the stream's workgroup cluster."""
     from juicer_amd import capi
     gnet, gam, onet, oam, feats, _ = small
-    gd = capi.Decoder(gnet, gam, max_streams=1, max_slots=64, max_paths=1 << 16, max_items=1 << 12)
+    kw = {"instance slots": dict(max_slots=512), "frontier items": dict(max_items=512),
+          "Path records": dict(max_paths=256)}[arena]
+    gd = capi.Decoder(gnet, gam, max_streams=1, **kw)               # no beam: thousands of instances per frame
     with pytest.raises(capi.JuicerAmdError) as ei:
         gd.decode_batch(feats[:1])
-    assert ei.value.code == capi.JD_ENOMEM
-    # the decoder stays usable once capacity is sufficient for the input
+    assert ei.value.code == capi.JD_ENOMEM and arena in str(ei.value), str(ei.value)
+    # the same decoder object is usable again (its arenas are wiped) - still too small for this input
+    with pytest.raises(capi.JuicerAmdError):
+        gd.decode_batch(feats[1:2])
+    # and a decoder with sufficient capacity is unaffected
     gd2 = capi.Decoder(gnet, gam, max_streams=1, main_beam=150.0)
     assert gd2.decode_batch(feats[:1])[0].n > 0
+
+
+def test_small_arenas_still_decode(small):
+    """Capacities just large enough: tiny wave segments, one workgroup per stream - same results."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0, max_hyps=200)
+    gd = capi.Decoder(gnet, gam, max_streams=2, max_slots=4096, max_items=4096, max_paths=1 << 15, **kw)
+    gs = gd.decode_batch(feats[:2])
+    assert gd.last_timing()["cluster_wgs"] <= 8
+    od = OracleDecoder(onet, oam, **kw)
+    for u in range(2):
+        assert_hyp_matches(gs[u], od.decode_certified(feats[u]), "small arenas utt %d" % u)
+
+
+def test_randomised_sweep_slice(built):
+    """A seeded slice of tests/manual/fuzz_parity.py: small random problems - both hub shapes (flat:
+    thousands of epsilon closure items per word end), with / without the tee model, 5-state and
+    mixed-topology HMMs, LM scale / insertion penalty, every pruning combination, 1-6 utterances
+    per batch - each against the certified oracle, statistics included."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    beams = [dict(main_beam=150.0), dict(main_beam=200.0), dict(main_beam=100.0, end_beam=70.0, word_beam=50.0),
+             dict(main_beam=150.0, max_hyps=200), dict(max_hyps=400), dict(main_beam=120.0, start_beam=100.0, max_hyps=150),
+             dict(main_beam=250.0, end_beam=200.0)]
+    s0 = 5000
+    rng = np.random.default_rng(s0)
+    checked = exact = 0
+    for case in range(64):
+        seed = s0 + case
+        hub = "tree" if rng.random() < 0.6 else "flat"
+        with_sp = bool(rng.random() < 0.7)
+        if rng.random() < 0.35:
+            am = synth.make_models_mixed(seed, n_gmm=260, n_hmm=40, n_mix=int(rng.integers(1, 5)), with_tee=with_sp, sep=0.7)
+            kind = "mixed"
+        else:
+            am = synth.make_models(seed, n_gmm=100, n_hmm=45, n_mix=int(rng.integers(1, 6)), n_tm=8, sep=0.6, with_tee=with_sp,
+                                   with_skip=bool(rng.random() < 0.5))
+            kind = "5state"
+        net = synth.make_wfst(seed + 100, am, n_words=int(rng.integers(20, 90)), n_succ=int(rng.integers(2, 9)),
+                              with_sp=with_sp, hub=hub, eps_word_frac=float(rng.choice([0.0, 0.05, 0.3])))
+        feats = [synth.sample_utterance(seed + 1000 + u, net, am, int(rng.integers(3, 12)))[0] for u in range(int(rng.integers(1, 7)))]
+        kw = dict(beams[int(rng.integers(0, len(beams)))])
+        lm = float(rng.choice([1.0, 7.5])); pen = float(rng.choice([0.0, -2.0]))
+        gd = capi.Decoder(capi.Network.from_synth(net, lm, pen), capi.Models.from_htk(am), max_streams=len(feats), **kw)
+        gs = gd.decode_batch(feats)
+        od = OracleDecoder(OracleNet(net, lm, pen), OracleAM(am), **kw)
+        for u, x in enumerate(feats):
+            o = od.decode_certified(x)
+            what = "case %d (%s hub=%s sp=%s %s lm=%g pen=%g) utt %d" % (seed, kind, hub, with_sp, kw, lm, pen, u)
+            assert_hyp_matches(gs[u], o, what)
+            checked += 1
+            exact += bit_exact(gs[u], o)
+    print("sweep: %d utterances, %d bit-exact incl. scores" % (checked, exact))
+    assert checked >= 150 and exact >= checked - 2
 
 
 def test_histogram_ceiling_is_an_error(built):
