@@ -594,8 +594,6 @@ struct jd_dec {
     int64_t cap_slots = 0, cap_paths = 0, cap_items = 0, cap_new = 0;
     int res_cap = 8192;
     int *d_res = nullptr;                 // result arena, see ensure_arenas
-    int gmm_bg_blocks = 384;              // grid bound of a scoring launch that overlaps the search (see launch_gmm);
-                                          // 1.5 per CU, doubled whenever the scoring turns out to be the bottleneck
     int n_cus = 256;
     // search launches: one 1024-thread workgroup per CU, Cw of them per stream
     int max_cw = MAXCW;                   // upper bound of workgroups per stream cluster (JD_CW overrides)
@@ -605,8 +603,10 @@ struct jd_dec {
     int *d_status = nullptr; int *h_status = nullptr;
     long long *d_dbg = nullptr;           // in-kernel cycle accounting (jd_dec_debug_trace)
     // chunked pipeline
-    int Fc = 128;
+    int Fc = 128;                         // frames per scoring chunk of the streaming API (jd_stream_push)
+    int Fw_env = 0;                       // JD_FC: frames per chunk of the batch path (0 = as long as the longest utterance)
     float *d_ll[2] = {nullptr, nullptr};
+    size_t ll_cap[2] = {0, 0};            // floats
     int *d_row_src = nullptr; size_t row_src_cap = 0;
     int *d_T = nullptr;
     hipStream_t s_gmm = nullptr, s_search = nullptr;
@@ -673,16 +673,16 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (rc) return rc;
     jd_dec *d = new jd_dec();
     d->net = net; d->am = am; d->device = device; d->max_streams = max_streams; d->block_size = block_size;
-    if (const char *e = getenv("JD_FC")) { const int v = atoi(e); if (v >= 16 && v <= 4096) d->Fc = v; }   // development: frames per scoring chunk
+    if (const char *e = getenv("JD_FC")) { const int v = atoi(e); if (v >= 16 && v <= 65536) d->Fw_env = v; }   // development: frames per chunk of a batch
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->n_cus = prop.multiProcessorCount;
-        d->gmm_bg_blocks = d->n_cus + d->n_cus / 2;
     }
-    if (const char *e = getenv("JD_GMM_BLOCKS")) d->gmm_bg_blocks = atoi(e);                                  // development: 0 = unbounded
     DecConst &C = d->C;
     C.start_win = start_beam; C.emit_win = main_beam; C.end_win = end_beam; C.word_win = word_beam;
     C.max_hyps = max_hyps;
+    C.x_chunks = 2;
+    if (const char *e = getenv("JD_XCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) C.x_chunks = v; }   // development
     C.hist_min = 0; C.hist_max = 0; C.hist_nbins = 0;
     if (max_hyps > 0) {                          // WFSTDecoderLite.cpp:76-82, Histogram.cpp:29-37
         float mn = (main_beam > 0.0) ? (float)(-main_beam - 800.0) : -1000.0f;
@@ -897,8 +897,8 @@ static int ensure_arenas(jd_dec *d)
         }
         HIPCHK(hipMemcpy(d->d_ctl, hc.data(), hc.size() * sizeof(StreamCtl), hipMemcpyHostToDevice));
     }
-    for (int i = 0; i < 2; ++i)
-        HIPCHK(hipMalloc(&d->d_ll[i], (size_t)B * d->Fc * d->am->n_gmm * sizeof(float)));
+    HIPCHK(hipMalloc(&d->d_ll[0], (size_t)d->Fc * d->am->n_gmm * sizeof(float)));   // streaming API: one stream, one chunk
+    d->ll_cap[0] = (size_t)d->Fc * d->am->n_gmm;
     HIPCHK(hipDeviceSynchronize());
     d->arenas_ready = true;
     return JD_OK;
@@ -1077,7 +1077,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const floa
 static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *ustart, const int64_t *ulen,
                        hipStream_t user_stream)
 {
-    const int Fc = d->Fc, G = d->am->n_gmm;
+    const int G = d->am->n_gmm;
     std::vector<int> T((size_t)nb);
     int maxT = 0;
     for (int u = 0; u < nb; ++u) {
@@ -1086,7 +1086,28 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         T[(size_t)u] = (int)t;
         maxT = std::max(maxT, (int)t);
     }
+    // Frames per chunk.  A search launch lasts as long as its slowest stream and streams do not wait
+    // for each other inside a launch, so the fewer launches the better: one chunk covers the longest
+    // utterance when the likelihood table (nb x frames x tied states floats, 288 GB of HBM to draw on)
+    // fits a quarter of the free memory; otherwise the batch is decoded in several chunks, scored
+    // alternately into two tables.
+    int Fc = std::max(128, (maxT + 127) / 128 * 128);
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const double have = 0.25 * (double)free_b + (double)(d->ll_cap[0] + d->ll_cap[1]) * sizeof(float);
+        const double per_frame = (double)nb * G * sizeof(float);
+        if ((double)Fc * per_frame > have) Fc = std::max(128, (int)(0.5 * have / per_frame) / 128 * 128);
+        if (d->Fw_env > 0) Fc = d->Fw_env;
+    }
     const int n_chunks = std::max(1, (maxT + Fc - 1) / Fc);            // chunk 0 also carries recognitionStart
+    for (int i = 0; i < std::min(2, n_chunks); ++i)
+        if ((size_t)nb * Fc * G > d->ll_cap[i]) {
+            if (d->d_ll[i]) (void)hipFree(d->d_ll[i]);
+            d->d_ll[i] = nullptr; d->ll_cap[i] = 0;
+            HIPCHK(hipMalloc(&d->d_ll[i], (size_t)nb * Fc * G * sizeof(float)));
+            d->ll_cap[i] = (size_t)nb * Fc * G;
+        }
     // row -> source frame table for all chunks: row = (c*nb + u)*Fc + dt
     const size_t n_rows_all = (size_t)n_chunks * nb * Fc;
     if (n_rows_all > d->row_src_cap) {
@@ -1121,9 +1142,10 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     // so by the time chunk c+1 is scored into buffer (c+1)&1 the search of chunk c-1 has left it.
     auto score_chunk = [&](int c) -> int {
         HIPCHK(hipEventRecord(gs[(size_t)c], d->s_gmm));
-        // chunk 0 is on the critical path (whole chip); later chunks score in the background
+        // (a later chunk is launched while the previous one is searched: k_search holds every CU's
+        // registers, so its workgroups start as the search's clusters finish - they fill the tail)
         int r = launch_gmm(d->am, d->amb, d_feats, d->d_row_src + (size_t)c * nb * Fc, nb * Fc, d->d_ll[c & 1], d->s_gmm,
-                           c == 0 ? 0 : d->gmm_bg_blocks, (Fc % GMM_ROWS2) == 0);
+                           0, (Fc % GMM_ROWS2) == 0);
         if (r) return r;
         HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm));
         return JD_OK;
@@ -1142,8 +1164,14 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         if (c + 1 < n_chunks) { rc = score_chunk(c + 1); if (rc) return rc; }
         work.clear(); weight.clear();
         for (int u = 0; u < nb; ++u)
-            if (c == 0 || T[(size_t)u] > c * Fc) { work.push_back(make_int2(u, u)); weight.push_back(load[(size_t)u]); }
-        rc = launch_search(d, work, d->d_ll[c & 1], (long long)Fc * G, c * Fc, (c + 1) * Fc, d->s_search, c > 0 ? &weight : nullptr);
+            if (c == 0 || T[(size_t)u] > c * Fc) {
+                // a launch lasts as long as its slowest stream: size the clusters by the work ahead of
+                // each stream - the frames it has in this launch times its recent work per frame
+                const double frames = (double)(std::min(T[(size_t)u], (c + 1) * Fc) - c * Fc);
+                work.push_back(make_int2(u, u));
+                weight.push_back(std::max(frames, 1.0) * (load[(size_t)u] > 0.0 ? load[(size_t)u] : 1.0));
+            }
+        rc = launch_search(d, work, d->d_ll[c & 1], (long long)Fc * G, c * Fc, (c + 1) * Fc, d->s_search, &weight);
         if (rc) return rc;
         if (c + 1 < n_chunks && d->weighted) {
             // the streams' work counters (instances processed + arcs visited) size the next chunk's clusters
@@ -1169,10 +1197,6 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         (void)hipEventDestroy(gs[(size_t)c]); (void)hipEventDestroy(ge[(size_t)c]);
     }
     d->timing.gmm_wait_ms += waited_ms;
-    if (n_chunks > 1 && waited_ms > 0.05 * d->timing.search_ms && d->gmm_bg_blocks > 0) {   // give the scoring more of the chip next time
-        d->gmm_bg_blocks *= 2;
-        if (d->gmm_bg_blocks > 4 * d->n_cus) d->gmm_bg_blocks = 0;    // unbounded
-    }
     d->timing.gmm_launches += n_chunks;
     for (int u = 0; u < nb; ++u) d->timing.search_frames += T[(size_t)u];
     d->timing.gmm_frames = d->timing.search_frames;

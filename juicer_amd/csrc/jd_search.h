@@ -59,6 +59,7 @@ struct DecConst {
     // arena capacities (per stream, in records)
     unsigned cap_slots, cap_items, cap_new; int cap_paths;
     int gc_threshold;   // a launch stops early (for k_gc) when more Path records than this are in use
+    int x_chunks;       // phase X: chunks per wave the item lists are cut into (dynamic hand-out balances the arc walks)
 };
 
 // An active arc instance (NetInst, WFSTDecoderLite.h:66-75) is a record of 16-byte fields: header
@@ -1050,8 +1051,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 if (Q1[0] == 0) break;
             }
             int Q = Q1[0];
-            if (Q < NW) {
-                while (KX > 4 && n1[0] < KX * NW) KX >>= 1;            // about one chunk per wave
+            if (Q < NW * C.x_chunks) {
+                while (KX > 4 && n1[0] < KX * NW * C.x_chunks) KX >>= 1;   // a few chunks per wave
                 if (KX < 64) Q = rebuild_list(sh, 0, gin.nw, KX);
             }
             CLK(4);                                                    // phase X work lists
