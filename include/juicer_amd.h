@@ -234,6 +234,22 @@ int jd_decode_batch(jd_dec *d, int32_t n_utts, const float *const *feats,
 int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
                            const int64_t *offs, void *hip_stream, jd_hyp *out);
 
+/*
+ * The same loop sharded over the GPUs of ONE node from C++ (no Python, no torchrun): one decoder
+ * and one host thread per device, utterances in contiguous shards, no data-path collective, and
+ * ONE RCCL all-gather (over xGMI) of fixed-size padded 1-best records at the end; results come back
+ * in utterance order.  devices == NULL means devices 0 .. n_devices-1.  RCCL is loaded with
+ * dlopen on first use.  jd_hyp storage is owned by the jd_multi and valid until its next decode.
+ */
+typedef struct jd_multi jd_multi;
+int jd_multi_create(jd_multi **out, const jd_net *net, const jd_am *am,
+                    float start_beam, float main_beam, float end_beam, float word_beam,
+                    int32_t max_hyps, int32_t block_size, int32_t n_devices, const int32_t *devices,
+                    int32_t max_streams_per_device);
+int jd_multi_decode_batch(jd_multi *m, int32_t n_utts, const float *const *feats,
+                          const int32_t *n_frames, jd_hyp *out);
+void jd_multi_destroy(jd_multi *m);
+
 /* Timing of the most recent jd_decode_batch*() (HIP events on the decoder's own streams): total
  * duration of the GMM-kernel launches, of the k_search launches (the persistent search kernel:
  * one launch per chunk of frames, repeated when a stream had to stop for Path garbage

@@ -101,7 +101,7 @@ int main(int argc, char **argv)
 {
     const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *mmf = 0, *list = 0;
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
-    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0;
+    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0, nDevices = 0;
     std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
     const char *refFName = 0;                  // -refFName: expected results, MLF or one line per file (juicer.cpp:267)
     const char *outputFName = 0;               // -outputFName: "", "stdout", "stderr" or a file (DecoderBatchTest.cpp:216-230)
@@ -119,6 +119,7 @@ int main(int argc, char **argv)
         else if (a == "-lmScaleFactor") lmScale = (float)atof(nxt()); else if (a == "-insPenalty") insPen = (float)atof(nxt());
         else if (a == "-framesPerSec") framesPerSec = atoi(nxt()); else if (a == "-device") device = atoi(nxt());
         else if (a == "-batch") batch = atoi(nxt()); else if (a == "-perFrameAdapter") useAdapter = 1;
+        else if (a == "-devices") nDevices = atoi(nxt());
         else if (a == "-outputFormat") outputFormat = nxt();
         else if (a == "-writeBinaryFiles") writeBinaryFiles = 1;
         else if (a == "-refFName") refFName = nxt(); else if (a == "-removeSentMarks") removeSentMarks = 1;
@@ -130,7 +131,8 @@ int main(int argc, char **argv)
         fprintf(stderr, "usage: jd_batch_test -fsmFName F (-htkModelsFName M.mmf | -modelsFName M.jdam) -inputFName LIST [-mainBeam b] [-phoneStartBeam b]\n"
                         "       [-phoneEndBeam b] [-wordEmitBeam b] [-maxHyps n] [-lmScaleFactor s] [-insPenalty p] [-batch n] [-perFrameAdapter]\n"
                         "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles] [-refFName REF] [-removeSentMarks]\n"
-                        "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n");
+                        "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n"
+                        "       [-device d | -devices N   (N GPUs of this node: utterances sharded, one RCCL gather of the 1-best)]\n");
         return 2;
     }
     if (outputFName && outputFName[0] && strcmp(outputFName, "stdout") != 0) {     // DecoderBatchTest::openOutputFile
@@ -341,6 +343,24 @@ int main(int argc, char **argv)
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             print_utt(u, (int)lab.size(), lab.data(), tim.data(), hac.data(), hlm.data(), dt);
         }
+    } else if (nDevices > 0) {
+        // -devices N: the utterance loop sharded over N GPUs of this node, one RCCL gather of the 1-best
+        jd_multi *mg = 0;
+        if (jd_multi_create(&mg, net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, 5, nDevices, 0, batch)) die("jd_multi_create");
+        std::vector<const float *> ptr(files.size());
+        for (size_t u = 0; u < files.size(); ++u) ptr[u] = feats[u].data();
+        std::vector<jd_hyp> hyps(files.size());
+        auto t0 = std::chrono::steady_clock::now();
+        if (jd_multi_decode_batch(mg, (int)files.size(), ptr.data(), nfr.data(), hyps.data())) die("jd_multi_decode_batch");
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        long tot = 0;
+        for (size_t u = 0; u < files.size(); ++u) tot += nfr[u];
+        for (size_t u = 0; u < files.size(); ++u) {
+            if (hyps[u].n < 0) fprintf(stderr, "WARNING: no token survived at the end of decoding\n");
+            print_utt(u, hyps[u].n > 0 ? hyps[u].n : 0, hyps[u].label, hyps[u].time, hyps[u].ac, hyps[u].lm,
+                      tot ? dt * nfr[u] / tot : 0.0);
+        }
+        jd_multi_destroy(mg);
     } else {
         jd_dec *dec = 0;
         if (jd_dec_create(&dec, net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, 5, device, batch)) die("jd_dec_create");

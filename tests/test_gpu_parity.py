@@ -338,6 +338,10 @@ def test_batch_test_cli(small, tmp_path):
     lines = run("-outputFormat", "ref", *mm)
     for u in range(len(feats)):
         assert lines[u].split() == ["W%d" % l for l in want[u].label[::-1]]
+    # -devices N: the C++ multi-GPU path (jd_multi_*: one decoder + thread per device, one RCCL
+    # all-gather of the 1-best records).  This box has one GPU, so N = 1 - the communicator, the
+    # packing, the collective and the unpacking all run; the xmlf lines carry times and scores.
+    assert run("-outputFormat", "xmlf", "-devices", "1", *mm) == run("-outputFormat", "xmlf", *mm)
     lines = run("-outputFormat", "trans", *mm)
     assert all(lines[u].endswith("(trans-%d)" % want[u].n) for u in range(len(feats)))
     # mlf / xmlf
