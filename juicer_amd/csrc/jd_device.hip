@@ -597,9 +597,9 @@ struct jd_dec {
     int n_cus = 256;
     // search launches: one 1024-thread workgroup per CU, Cw of them per stream
     int max_cw = MAXCW;                   // upper bound of workgroups per stream cluster (JD_CW overrides)
-    int weighted = 1;                     // size the clusters by the streams' recent load (JD_WEIGHTED=0: uniform)
+    int weighted = 1;                     // size the clusters by the work ahead of each stream (JD_WEIGHTED=0: uniform)
+    double model_a_us = 10.0, model_b_us = 288.0;   // cost model of a stream-frame: a + b / workgroups (launch_search)
     int4 *d_work = nullptr; int work_cap = 0;
-    std::vector<long long> load_prev;         // per stream: work counters at the end of the previous chunk (cluster sizing)
     int *d_status = nullptr; int *h_status = nullptr;
     long long *d_dbg = nullptr;           // in-kernel cycle accounting (jd_dec_debug_trace)
     // chunked pipeline
@@ -770,6 +770,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     }
     if (const char *e = getenv("JD_CW")) { const int v = atoi(e); if (v >= 1 && v <= MAXCW) d->max_cw = v; }   // development
     if (const char *e = getenv("JD_WEIGHTED")) d->weighted = atoi(e) != 0;
+    if (const char *e = getenv("JD_MODEL_A")) d->model_a_us = atof(e);
+    if (const char *e = getenv("JD_MODEL_B")) d->model_b_us = atof(e);
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
     hipError_t e;
@@ -1019,28 +1021,54 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const floa
     for (int k = 0; k < n_work; ++k) work[(size_t)k] = make_int4(work_in[(size_t)k].x, work_in[(size_t)k].y, k * A.Cw, A.Cw);
     int grid = A.n_slots * A.Cw;
     if (weight && d->weighted && n_work > 1 && max_cw > 1 && nwg >= 2 * n_work) {
-        // weighted mode: one workgroup each, the rest in proportion to the streams' recent load
-        double tot = 0.0;
-        for (double w : *weight) tot += std::max(w, 0.0);
-        if (tot > 0.0) {
-            const int spare = nwg - n_work;
-            std::vector<int> cw((size_t)n_work, 1);
-            std::vector<std::pair<double, int>> frac;
-            int used = 0;
+        // Weighted mode.  weight[k] = frames stream k has in this launch.  A stream's frame costs about
+        // a + b / workgroups  (a: the barriers and list set-up of a frame; b: the part that divides over
+        // the cluster), so stream k finishes after  frames_k * (a + b / C_k).  The launch ends with its
+        // last stream: the C_k that make all streams finish together solve  C_k = b / (tau / frames_k - a)
+        // for the smallest common tau the device's workgroups allow (bisection).  a and b were fitted on
+        // configs[1] (DESIGN.md "cluster sizes"); sizing by a stream's measured work per frame (a pilot
+        // launch, or the previous chunk's counters) was tried and is slower - the work of the frames
+        // ahead is not the work of the frames behind.
+        const double a_us = d->model_a_us, b_us = d->model_b_us;
+        auto need = [&](double tau, std::vector<double> *out) {
+            double tot = 0.0;
             for (int k = 0; k < n_work; ++k) {
-                const double want = spare * std::max((*weight)[(size_t)k], 0.0) / tot;
-                int extra = std::min((int)want, max_cw - 1);
-                cw[(size_t)k] += extra; used += extra;
-                frac.push_back({want - (int)want, k});
+                const double fr = std::max((*weight)[(size_t)k], 1.0);
+                const double slack = tau / fr - a_us;
+                double c = slack > 1e-9 ? b_us / slack : 1e9;
+                c = std::min(std::max(c, 1.0), (double)max_cw);
+                if (out) (*out)[(size_t)k] = c;
+                tot += c;
             }
-            std::sort(frac.begin(), frac.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first > b.first; });
-            for (size_t i = 0; i < frac.size() && used < spare; ++i)
-                if (cw[(size_t)frac[i].second] < max_cw) { ++cw[(size_t)frac[i].second]; ++used; }
-            int first = 0;
-            for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw[(size_t)k]; first += cw[(size_t)k]; }
-            grid = first;
-            A.n_slots = 0;
+            return tot;
+        };
+        double lo_t = 0.0, hi_t = 1.0;
+        while (need(hi_t, nullptr) > nwg && hi_t < 1e15) hi_t *= 2.0;
+        for (int it = 0; it < 60; ++it) { const double mid = 0.5 * (lo_t + hi_t); if (need(mid, nullptr) > nwg) lo_t = mid; else hi_t = mid; }
+        std::vector<double> want((size_t)n_work);
+        need(hi_t, &want);
+        std::vector<int> cw((size_t)n_work, 1);
+        std::vector<std::pair<double, int>> frac;
+        int used = 0;
+        for (int k = 0; k < n_work; ++k) {
+            cw[(size_t)k] = std::max(1, std::min(max_cw, (int)want[(size_t)k]));
+            used += cw[(size_t)k];
+            frac.push_back({want[(size_t)k] - (int)want[(size_t)k], k});
         }
+        std::sort(frac.begin(), frac.end(), [](const std::pair<double, int> &x, const std::pair<double, int> &y) { return x.first > y.first; });
+        for (int pass = 0; pass < 4 && used < nwg; ++pass)                 // left-over workgroups: largest remainders first
+            for (size_t i = 0; i < frac.size() && used < nwg; ++i)
+                if (cw[(size_t)frac[i].second] < max_cw) { ++cw[(size_t)frac[i].second]; ++used; }
+        while (used > nwg) {                                               // (rounding can only overshoot by the floor of ones)
+            int big = 0;
+            for (int k = 1; k < n_work; ++k) if (cw[(size_t)k] > cw[(size_t)big]) big = k;
+            if (cw[(size_t)big] <= 1) break;
+            --cw[(size_t)big]; --used;
+        }
+        int first = 0;
+        for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw[(size_t)k]; first += cw[(size_t)k]; }
+        grid = first;
+        A.n_slots = 0;
     }
     HIPCHK(hipMemcpyAsync(d->d_work, work.data(), (size_t)n_work * sizeof(int4), hipMemcpyHostToDevice, st));
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
@@ -1062,6 +1090,12 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const floa
         HIPCHK(hipStreamSynchronize(st));
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) d->timing.search_ms += ms;
+        if (getenv("JD_VERBOSE")) {                                        // development
+            int cmin = 1 << 30, cmax = 0;
+            for (const int4 &w : work) { cmin = std::min(cmin, w.w); cmax = std::max(cmax, w.w); }
+            fprintf(stderr, "k_search: %d streams, grid %d (clusters %d..%d workgroups, %s), frames [%d, %d): %.3f ms\n", n_work, grid,
+                    cmin, cmax, A.n_slots ? "uniform" : "weighted", f0, f_end, ms);
+        }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         d->timing.search_launches += 1;
         d->timing.cluster_wgs = A.Cw;
@@ -1155,35 +1189,21 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     double waited_ms = 0.0;
     std::vector<int2> work;
     std::vector<double> weight;
-    std::vector<long long> st_now((size_t)nb * ST_N), st_prev((size_t)nb * ST_N, 0);
-    std::vector<double> load((size_t)nb, 0.0);                         // work per frame of every stream in the last chunk
     for (int c = 0; c < n_chunks; ++c) {
         const auto tw0 = std::chrono::steady_clock::now();
         HIPCHK(hipEventSynchronize(ge[(size_t)c]));                    // scores of this chunk are there
         waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
         if (c + 1 < n_chunks) { rc = score_chunk(c + 1); if (rc) return rc; }
+        // a launch lasts as long as its slowest stream: the clusters are sized by the frames ahead of each
+        const int c0 = c * Fc, c1 = (c + 1) * Fc;
         work.clear(); weight.clear();
         for (int u = 0; u < nb; ++u)
-            if (c == 0 || T[(size_t)u] > c * Fc) {
-                // a launch lasts as long as its slowest stream: size the clusters by the work ahead of
-                // each stream - the frames it has in this launch times its recent work per frame
-                const double frames = (double)(std::min(T[(size_t)u], (c + 1) * Fc) - c * Fc);
+            if (c == 0 || T[(size_t)u] > c0) {
                 work.push_back(make_int2(u, u));
-                weight.push_back(std::max(frames, 1.0) * (load[(size_t)u] > 0.0 ? load[(size_t)u] : 1.0));
+                weight.push_back((double)(std::min(T[(size_t)u], c1) - c0));
             }
-        rc = launch_search(d, work, d->d_ll[c & 1], (long long)Fc * G, c * Fc, (c + 1) * Fc, d->s_search, &weight);
+        rc = launch_search(d, work, d->d_ll[c & 1], (long long)Fc * G, c0, c1, d->s_search, &weight);
         if (rc) return rc;
-        if (c + 1 < n_chunks && d->weighted) {
-            // the streams' work counters (instances processed + arcs visited) size the next chunk's clusters
-            HIPCHK(hipMemcpy2D(st_now.data(), ST_N * sizeof(long long), (const char *)d->d_ctl + offsetof(StreamCtl, st),
-                               sizeof(StreamCtl), ST_N * sizeof(long long), (size_t)nb, hipMemcpyDeviceToHost));
-            for (int u = 0; u < nb; ++u) {
-                const long long *a = st_now.data() + (size_t)u * ST_N, *b = st_prev.data() + (size_t)u * ST_N;
-                const int fr = std::min((c + 1) * Fc, T[(size_t)u]) - std::min(c * Fc, T[(size_t)u]);
-                load[(size_t)u] = fr > 0 ? (double)((a[ST_INSTS] - b[ST_INSTS]) + (a[ST_ARCS] - b[ST_ARCS])) / fr : 0.0;
-            }
-            st_prev = st_now;
-        }
     }
     hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, 0, nb);
     HIPCHK(hipGetLastError());
