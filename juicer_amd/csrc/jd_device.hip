@@ -227,24 +227,32 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 typedef float jd_f2 __attribute__((ext_vector_type(2)));
 struct JdLogTab { double invc, logc; };
 
-__device__ __forceinline__ float jd_log_add2(float x, float y, const JdLogTab *tab)
+// One logAdd step for the two frames of a lane, straight-line (no branch: some lane of a wave always
+// takes the long path) and written pairwise so that the two dependent chains interleave.  etab is
+// the LDS copy of jd_exp2f_tab, tab the LDS copy of the log table.
+__device__ __forceinline__ void jd_log_add2x2(float &a0, float &a1, float c0, float c1, const JdLogTab *tab,
+                                              const unsigned long long *etab)
 {
-    if (x < y) { const float t = x; x = y; y = t; }
-    const float diff = y - x;
-    if (diff < -18.42) return x;
-    const double e = (double)jd_expf(diff);
-    const double yy = 1.0 + e;
-    const int k = (int)(e * 128.0 + 0.5);
-    const JdLogTab t = tab[k];
-    const double r = __builtin_fma(yy, t.invc, -1.0);
-    double q = 1.0 / 7.0;
-    q = __builtin_fma(q, r, -1.0 / 6.0);
-    q = __builtin_fma(q, r, 1.0 / 5.0);
-    q = __builtin_fma(q, r, -1.0 / 4.0);
-    q = __builtin_fma(q, r, 1.0 / 3.0);
-    q = __builtin_fma(q, r, -1.0 / 2.0);
-    q = __builtin_fma(q, r, 1.0);
-    return (float)((double)x + (t.logc + q * r));
+    const bool s0 = a0 < c0, s1 = a1 < c1;
+    const float x0 = s0 ? c0 : a0, y0 = s0 ? a0 : c0;
+    const float x1 = s1 ? c1 : a1, y1 = s1 ? a1 : c1;
+    const float d0 = y0 - x0, d1 = y1 - x1;
+    const bool keep0 = d0 < -18.42, keep1 = d1 < -18.42;               // HTKFlatModels.cpp:276 (double compare)
+    // (the clamp keeps the table index in range for the lanes whose result is discarded)
+    const double e0 = (double)jd_expf_impl(fmaxf(d0, -19.0f), etab), e1 = (double)jd_expf_impl(fmaxf(d1, -19.0f), etab);
+    const double yy0 = 1.0 + e0, yy1 = 1.0 + e1;
+    const JdLogTab t0 = tab[(int)(e0 * 128.0 + 0.5)], t1 = tab[(int)(e1 * 128.0 + 0.5)];
+    const double r0 = __builtin_fma(yy0, t0.invc, -1.0), r1 = __builtin_fma(yy1, t1.invc, -1.0);
+    double q0 = 1.0 / 7.0, q1 = 1.0 / 7.0;
+    q0 = __builtin_fma(q0, r0, -1.0 / 6.0); q1 = __builtin_fma(q1, r1, -1.0 / 6.0);
+    q0 = __builtin_fma(q0, r0, 1.0 / 5.0);  q1 = __builtin_fma(q1, r1, 1.0 / 5.0);
+    q0 = __builtin_fma(q0, r0, -1.0 / 4.0); q1 = __builtin_fma(q1, r1, -1.0 / 4.0);
+    q0 = __builtin_fma(q0, r0, 1.0 / 3.0);  q1 = __builtin_fma(q1, r1, 1.0 / 3.0);
+    q0 = __builtin_fma(q0, r0, -1.0 / 2.0); q1 = __builtin_fma(q1, r1, -1.0 / 2.0);
+    q0 = __builtin_fma(q0, r0, 1.0);        q1 = __builtin_fma(q1, r1, 1.0);
+    const float n0 = (float)((double)x0 + (t0.logc + q0 * r0)), n1 = (float)((double)x1 + (t1.logc + q1 * r1));
+    a0 = keep0 ? x0 : n0;
+    a1 = keep1 ? x1 : n1;
 }
 
 __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restrict__ feats,
@@ -258,11 +266,14 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
     constexpr int DT = 39, DP = 39;                   // odd row stride: conflict-free per-lane rows
     extern __shared__ __align__(16) char smem[];
     JdLogTab *stab = (JdLogTab *)smem;                // [129] (+ pad)
-    float *sx = (float *)(smem + 130 * sizeof(JdLogTab));   // [128][DP]
-    float *so = sx + GMM_ROWS2 * DP;                  // [128][GMM_GT+1]
+    unsigned long long *setab = (unsigned long long *)(smem + 130 * sizeof(JdLogTab));   // [32]
+    float *sx = (float *)(smem + 130 * sizeof(JdLogTab) + 32 * sizeof(unsigned long long));   // [128][DP]
+    float *so = sx;                                   // [128][GMM_GT+1]: the feature tile is in registers by then
+                                                      // (36 KB per workgroup: four of them share a CU's LDS)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 129; i += 256) stab[i] = logtab[i];
+    if (tid < 32) setab[tid] = jd_exp2f_tab[tid];
     const int n_rt = (n_rows + GMM_ROWS2 - 1) / GMM_ROWS2, n_gt = (G + GMM_GT - 1) / GMM_GT;
     for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
         // row tile skewed by the state group (see jd_gmm_kernel)
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
         jd_f2 x[DT];
 #pragma unroll
         for (int j = 0; j < DT; ++j) { x[j].x = sx[lane * DP + j]; x[j].y = sx[(lane + 64) * DP + j]; }
+        __syncthreads();                              // sx is re-used as the output tile
         constexpr int GPW = GMM_GT / 4;               // tied states per wave
         for (int gi = 0; gi < GPW; ++gi) {
             const int gl = wid * GPW + gi;            // wave-uniform
@@ -292,15 +304,21 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
                 for (int m = 0; m < nm; ++m) {
                     const float *pm = pg + (size_t)m * DT * 2;
                     jd_f2 sum = {0.0f, 0.0f};
+                    // three dimensions at a time: their squared distances are independent, only the
+                    // running sum is a chain (added in the reference's order)
 #pragma unroll
-                    for (int j = 0; j < DT; ++j) {
-                        const jd_f2 mu = {pm[2 * j], pm[2 * j]}, iv = {pm[2 * j + 1], pm[2 * j + 1]};
-                        const jd_f2 xmu = x[j] - mu;              // HTKFlatModels.cpp:249
-                        sum += xmu * xmu * iv;                    // :250  (no contraction)
+                    for (int j = 0; j < DT; j += 3) {
+                        const jd_f2 mu0 = {pm[2 * j], pm[2 * j]}, iv0 = {pm[2 * j + 1], pm[2 * j + 1]};
+                        const jd_f2 mu1 = {pm[2 * j + 2], pm[2 * j + 2]}, iv1 = {pm[2 * j + 3], pm[2 * j + 3]};
+                        const jd_f2 mu2 = {pm[2 * j + 4], pm[2 * j + 4]}, iv2 = {pm[2 * j + 5], pm[2 * j + 5]};
+                        const jd_f2 u0 = x[j] - mu0, u1 = x[j + 1] - mu1, u2 = x[j + 2] - mu2;   // HTKFlatModels.cpp:249
+                        const jd_f2 w0 = u0 * u0, w1 = u1 * u1, w2 = u2 * u2;
+                        const jd_f2 z0 = w0 * iv0, z1 = w1 * iv1, z2 = w2 * iv2;                 // :250  (no contraction)
+                        if (j == 0) sum = z0; else sum += z0;             // (0.0f + z0 == z0: z0 >= +0)
+                        sum += z1; sum += z2;
                     }
                     const double dm = (double)dg[m];
-                    acc0 = jd_log_add2(acc0, (float)(-0.5 * (double)sum.x + dm), stab);   // :254
-                    acc1 = jd_log_add2(acc1, (float)(-0.5 * (double)sum.y + dm), stab);
+                    jd_log_add2x2(acc0, acc1, (float)(-0.5 * (double)sum.x + dm), (float)(-0.5 * (double)sum.y + dm), stab, setab);   // :254
                 }
             }
             so[lane * (GMM_GT + 1) + gl] = acc0;
@@ -517,7 +535,7 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
     const long long tiles = (long long)((n_rows + rows_per_tile - 1) / rows_per_tile) * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
     dim3 grid((unsigned)((max_blocks > 0 && tiles > max_blocks) ? max_blocks : tiles));
     if (a->D == 39) {
-        const size_t sm = 130 * sizeof(JdLogTab) + (size_t)(GMM_ROWS2 * 39 + GMM_ROWS2 * (GMM_GT + 1)) * sizeof(float);
+        const size_t sm = 130 * sizeof(JdLogTab) + 32 * sizeof(unsigned long long) + (size_t)GMM_ROWS2 * std::max(39, GMM_GT + 1) * sizeof(float);
         hipLaunchKernelGGL(jd_gmm_kernel39, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
                            b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab);
     } else {
