@@ -205,6 +205,13 @@ void jd_dec_destroy(jd_dec *d);
  * frontier items and Path records, never below 2^19 / 2^21 / 2^21 and never above what the
  * graph can need (one instance per arc).  An overflow is reported as JD_ENOMEM naming the arena. */
 int jd_dec_set_capacity(jd_dec *d, int64_t max_slots, int64_t max_paths, int64_t max_items);
+/* WFSTDecoderLite::setMaxAllocModels (WFSTDecoderLite.cpp:807-820; environment variable
+ * MaxAllocModels, default 10, :73-74), same argument convention: < 100 a percentage of the network's
+ * transitions, 100..7999 a memory limit in MB (of 40 + 24 * maxNStates bytes per instance), otherwise
+ * a number of instances.  The reference drops its cached NetInst objects between utterances when
+ * more than this many are allocated (:164-169); here it sizes the per-stream arena of instance
+ * records (equivalent to jd_dec_set_capacity's max_slots).  Before the first decode. */
+int jd_dec_set_max_alloc_models(jd_dec *d, int32_t max_alloc_models);
 
 /* IDecoder::init() (Decoder.h:26) for stream s. */
 int jd_stream_init(jd_dec *d, int32_t s);
@@ -215,6 +222,30 @@ int jd_stream_init(jd_dec *d, int32_t s);
 int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t n_frames);
 /* IDecoder::finish() (Decoder.h:28). */
 int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out);
+
+/*
+ * PARTIAL_DECODING (WFSTDecoderLite.cpp:822-896, compiled in by src/CMakeLists.txt:5): the Path
+ * records every open hypothesis of a stream has converged into - the part of the result that can
+ * no longer change - collected in the decoder's partialPaths list (WFSTDecoderLite.h:199-205).
+ *
+ * jd_dec_set_partial_interval = setPartialDecodeOptions (:892-896; the reference takes the value
+ * from the environment variable PartialTraceInterval, :116-119; 0 = off, the default).  With an
+ * interval > 0 jd_stream_push traces on the reference's schedule - together with the path
+ * collection of the first frame f with f - lastPathCollectFrame > 100, if
+ * f - lastPartialTraceFrame > interval (:362-368) - and jd_stream_finish completes the list from
+ * the best token (:245-251).  Of the two collection triggers only this frame rule exists here;
+ * the other one (nPath / nPathNew > 12 with nPath > 10000) counts the reference allocator's live
+ * Path objects.  It decides when a trace is taken, never what a trace at a given frame finds.
+ *
+ * jd_stream_partial returns the stream's partialPaths - (output label, frame) of each record,
+ * oldest first; *n is the full length, at most cap entries are written - after, if trace_now != 0,
+ * running tracePartialPath (:824-868) on the frame the stream has reached (*found = its return
+ * value).  Streaming API only: a batch returns whole results, and the list recognitionFinish
+ * ends up with is the hypothesis itself (jd_hyp.label / .time, newest first).
+ */
+int jd_dec_set_partial_interval(jd_dec *d, int32_t interval);
+int jd_stream_partial(jd_dec *d, int32_t s, int32_t trace_now, int32_t cap, int32_t *n,
+                      int32_t *labels, int32_t *times, int32_t *found);
 
 /*
  * DecoderBatchTest::run() inner loop (DecoderBatchTest.cpp:738-771) for a

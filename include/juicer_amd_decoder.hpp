@@ -70,6 +70,8 @@ public:
     {
         check(jd_dec_create(&dec_, network, models, phoneStartPruneWin, emitPruneWin, phoneEndPruneWin,
                             wordPruneWin, maxEmitHyps, blockSize, device, 1));
+        if (const char *e = getenv("PartialTraceInterval"))            // WFSTDecoderLite.cpp:116-119 (GetEnv, default 0)
+            setPartialDecodeOptions(atoi(e));
     }
     virtual ~GpuWFSTDecoder() { jd_dec_destroy(dec_); }
 
@@ -123,6 +125,23 @@ public:
     }
 
     const jd_stats &statistics() const { return stats_; }   // WFSTDecoderLite.cpp:231-241
+
+    // WFSTDecoderLite::setMaxAllocModels (WFSTDecoderLite.h:101, .cpp:807-820): before the first init()
+    void setMaxAllocModels(int maxAllocModels) { check(jd_dec_set_max_alloc_models(dec_, maxAllocModels)); }
+    // PARTIAL_DECODING: setPartialDecodeOptions (.cpp:892-896) and the partialPaths list (.h:199-205)
+    // as (output label, frame) pairs, oldest first; traceNow runs tracePartialPath (.cpp:824-868) on
+    // the frames processed so far (buffered frames are flushed first)
+    void setPartialDecodeOptions(int traceInterval) { check(jd_dec_set_partial_interval(dec_, traceInterval)); }
+    bool partialPaths(std::vector<int> &labels, std::vector<int> &frames, bool traceNow = false)
+    {
+        if (traceNow) flush();
+        int n = 0, found = 0;
+        check(jd_stream_partial(dec_, 0, traceNow ? 1 : 0, 0, &n, 0, 0, &found));
+        labels.assign((size_t)n, 0); frames.assign((size_t)n, 0);
+        int f2 = 0;
+        if (n > 0) check(jd_stream_partial(dec_, 0, 0, n, &n, &labels[0], &frames[0], &f2));
+        return found != 0;
+    }
 
 private:
     void flush()

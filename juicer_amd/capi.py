@@ -75,6 +75,7 @@ EXPORTS = [
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_decode_batch", "jd_multi_destroy",
+    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models",
 ]
 
 _lib = None
@@ -336,6 +337,29 @@ class Decoder:
         h = CHyp()
         _check(lib().jd_stream_finish(self.h, C.c_int32(s), C.byref(h)))
         return _hyp_from_c(h)
+
+    def set_max_alloc_models(self, v: int):
+        """WFSTDecoderLite::setMaxAllocModels (:807-820): percentage / MB / count, see juicer_amd.h."""
+        _check(lib().jd_dec_set_max_alloc_models(self.h, C.c_int32(v)))
+
+    # -- PARTIAL_DECODING (WFSTDecoderLite.cpp:822-896)
+    def set_partial_interval(self, interval: int):
+        _check(lib().jd_dec_set_partial_interval(self.h, C.c_int32(interval)))
+
+    def stream_partial(self, s: int = 0, trace_now: bool = False):
+        """(found, partialPaths as [(label, frame)], oldest first); trace_now runs tracePartialPath first."""
+        n, found = C.c_int32(0), C.c_int32(0)
+        cap, was_found = 256, False
+        while True:
+            lab, tim = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+            _check(lib().jd_stream_partial(self.h, C.c_int32(s), C.c_int32(1 if trace_now else 0), C.c_int32(cap), C.byref(n),
+                                           _p(lab, C.c_int32), _p(tim, C.c_int32), C.byref(found)))
+            if trace_now:
+                was_found = bool(found.value)
+            if n.value <= cap:
+                break
+            cap, trace_now = n.value, False
+        return was_found, [(int(lab[i]), int(tim[i])) for i in range(n.value)]
 
     # -- DecoderBatchTest inner loop
     def decode_batch(self, feats: Sequence[np.ndarray]) -> List[Hyp]:

@@ -335,6 +335,13 @@ int main(int argc, char **argv)
                 if (nFrames + nData - 1 >= nfr[u]) --nData;
             }
             JuicerAmd::DecHyp *hyp = dec.finish();
+            if (getenv("PartialTraceInterval") && atoi(getenv("PartialTraceInterval")) > 0) {   // WFSTDecoderLite.cpp:245-258
+                std::vector<int> pl, pf;
+                dec.partialPaths(pl, pf);
+                fprintf(stderr, "Partial paths recovered at frames: ");
+                for (size_t k = 0; k < pf.size(); ++k) fprintf(stderr, "%03d ", pf[k]);
+                fprintf(stderr, "\n");
+            }
             std::vector<int32_t> lab, tim;
             std::vector<float> hac, hlm;
             for (JuicerAmd::DecHypHist *h = hyp ? hyp->hist : 0; h; h = h->prev) {

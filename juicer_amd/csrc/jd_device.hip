@@ -434,6 +434,109 @@ __global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamD
     }
 }
 
+// PARTIAL_DECODING: tracePartialPath (WFSTDecoderLite.cpp:824-868) on the state a launch left behind.
+//
+// The reference walks back from the first token with a Path of every active instance, counts the
+// visits per Path record (records newer than the last traced one only) and stops at the first record
+// that all nActiveInsts walks reach: the deepest record common to all of them.  Here: the instances
+// are the records of the next frame's list plus the arcs entered in the last frame that have no
+// record yet (new list, and the clean-up list of the "hopeless" ones - the reference attached an
+// instance for those too); an instance's first token is its entry token - the candidate that won the
+// arc's key in the last phase X - then its emitting states in order.  Path indices grow along a
+// chain (a record is allocated after its predecessor, and k_gc keeps the order), so the common
+// record lies on the chain of ANY tip: the chain of the highest tip is written out, every other tip
+// walks down until it meets it, and the shallowest meeting point is the answer.
+// out[0] = found, out[1] = records on the chain from the root to the found one (oldest first in
+// res_label / res_time, at most res_cap of them).
+template <int NE, typename F>
+__device__ __forceinline__ void jd_for_each_tip(const DecConst &C, const StreamCtl &c, const StreamDev &S, F &&f)
+{
+    typedef RecLayout<NE> RL;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nw = c.lst_nw;
+    const Geo g = make_geo(C, nw);
+    const int p = c.frame & 1;
+    auto entry_tip = [&](int arc) -> int {
+        const unsigned long long kv = S.ast[arc].key;
+        if (kv == 0ULL) return -1;
+        return S.items[2 * ((size_t)(p ^ 1) * C.cap_items + (size_t)(kv & 0xffffffffULL))].w;
+    };
+    for (int w = wid; w < nw; w += 16) {
+        const char *seg = (const char *)S.rec + (size_t)p * C.cap_slots * RL::REC_BYTES + (size_t)w * (g.seg_rec >> 6) * RL::CHUNK_BYTES;
+        const int n_rec = min(S.tot[(size_t)(TOT_REC0 + p) * MAXW + w], (int)g.seg_rec);
+        for (int q = lane; q < n_rec; q += 64) {
+            const char *r = seg + (size_t)(q >> 6) * RL::CHUNK_BYTES + (size_t)(q & 63) * 16;
+            const int4 h0 = *(const int4 *)r;
+            int tip = entry_tip(h0.x);
+            const int n = h0.y & 0xff;
+            for (int j = 1; j <= NE && tip < 0; ++j)
+                if (j < n - 1) tip = ((const int4 *)(r + (size_t)(RL::HF + j - 1) * 1024))->w;
+            f(tip);
+        }
+        const int n_new = min(S.tot[(size_t)TOT_NEW * MAXW + w], (int)g.seg_new);
+        for (int q = lane; q < n_new; q += 64) f(entry_tip(S.newl[(size_t)w * g.seg_new + q]));
+        const int n_cl = min(S.tot[(size_t)TOT_CLEAN * MAXW + w], (int)g.seg_new);
+        for (int q = lane; q < n_cl; q += 64) {
+            const int b = S.cleanl[(size_t)w * g.seg_new + q];
+            if (S.ast[b].live != 2) f(entry_tip(b));                    // (2: a later candidate put it on the new list)
+        }
+    }
+}
+
+template <int NE>
+__global__ __launch_bounds__(1024) void k_partial(DecConst C, StreamCtl *ctl, StreamDev *streams, int s, int last_frame, int *out)
+{
+    StreamCtl &c = ctl[s];
+    StreamDev &S = streams[s];
+    __shared__ int sh_max, sh_bad, sh_cnt, sh_depth, sh_D;
+    const int tid = threadIdx.x;
+    if (tid == 0) { sh_max = -1; sh_bad = 0; sh_cnt = 0; sh_depth = 0; sh_D = 0; out[0] = 0; out[1] = 0; }
+    __syncthreads();
+    if (!c.started || c.needs_init || c.error != 0 || c.lst_nw <= 0) return;
+    {
+        int mx = -1, bad = 0, cnt = 0;
+        jd_for_each_tip<NE>(C, c, S, [&](int tip) { ++cnt; if (tip < 0) bad = 1; else mx = max(mx, tip); });
+        if (mx >= 0) atomicMax(&sh_max, mx);
+        if (bad) atomicOr(&sh_bad, 1);
+        if (cnt) atomicAdd(&sh_cnt, cnt);
+    }
+    __syncthreads();
+    // an instance none of whose tokens has a Path yet: nothing can be common to all (:850-854)
+    if (sh_cnt == 0 || sh_bad || sh_max < 0) return;
+    int *ch = S.gc_idx;                                                // the chain of the highest tip, newest first
+    if (tid == 0) {
+        int n = 0;
+        for (int q = sh_max; q >= 0; q = S.paths[q].prev) ch[n++] = q;
+        sh_depth = n;
+    }
+    __syncthreads();
+    const int depth = sh_depth;
+    {
+        int dmax = 0;
+        jd_for_each_tip<NE>(C, c, S, [&](int tip) {
+            int i = 0, q = tip;
+            for (;;) {
+                while (i < depth && ch[i] > q) ++i;
+                if (i == depth || ch[i] == q) break;
+                q = S.paths[q].prev;
+                if (q < 0) { i = depth; break; }
+            }
+            dmax = max(dmax, i);
+        });
+        if (dmax) atomicMax(&sh_D, dmax);
+    }
+    __syncthreads();
+    const int D0 = sh_D;
+    if (D0 >= depth) return;                                           // no record is common to all
+    if (S.paths[ch[D0]].frame <= last_frame) return;                   // nothing newer than the last traced record (:858)
+    const int n = depth - D0;
+    for (int k = tid; k < n && k < S.res_cap; k += blockDim.x) {       // traceWinningPaths :874-890, oldest first
+        const PathRec pr = S.paths[ch[depth - 1 - k]];
+        S.res_label[k] = pr.label; S.res_time[k] = pr.frame;
+    }
+    if (tid == 0) { out[0] = 1; out[1] = n; }
+}
+
 // recognitionFinish (:230-309): walk the Path chain of bestFinalToken.
 __global__ void jd_finish_kernel(StreamCtl *ctl, StreamDev *streams, int s0, int n)
 {
@@ -631,6 +734,11 @@ struct jd_dec {
     // streaming API state
     std::vector<int> stream_T;                 // frames pushed so far
     std::vector<int> stream_started;
+    // PARTIAL_DECODING (WFSTDecoderLite.h:199-205), streaming API
+    int partial_interval = 0;                  // partialTraceInterval
+    std::vector<int> last_collect, last_trace; // lastPathCollectFrame, lastPartialTraceFrame
+    std::vector<std::vector<int32_t>> partial_label, partial_time;   // partialPaths, oldest first
+    int *d_partial_out = nullptr;
     float *d_push = nullptr; size_t push_cap = 0;
     // results
     std::vector<HostResult> results;
@@ -800,6 +908,10 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     }
     d->stream_T.assign((size_t)max_streams, 0);
     d->stream_started.assign((size_t)max_streams, 0);
+    d->last_collect.assign((size_t)max_streams, -1);
+    d->last_trace.assign((size_t)max_streams, -1);
+    d->partial_label.resize((size_t)max_streams);
+    d->partial_time.resize((size_t)max_streams);
     d->results.resize((size_t)max_streams);
 #undef TRY
     *out = d;
@@ -813,6 +925,24 @@ extern "C" int jd_dec_set_capacity(jd_dec *d, int64_t max_slots, int64_t max_pat
     if (max_slots > 0) d->cap_slots = max_slots;
     if (max_paths > 0) d->cap_paths = max_paths;
     if (max_items > 0) d->cap_items = max_items;
+    return JD_OK;
+}
+
+// setMaxAllocModels (WFSTDecoderLite.cpp:807-820): same argument convention - below 100 a percentage
+// of the network's transitions, 100..7999 a memory limit in MB, from 8000 a number of instances.  The
+// reference compares it with the NetInst objects its pools have handed out and drops them all between
+// two utterances when there are more (:164-169) - a cap on what stays cached, never an error.  Here
+// instance memory is one arena of records per stream, reused wholesale by every utterance: the limit
+// sizes that arena (a stream that needs more live instances in one frame fails with JD_ENOMEM).
+extern "C" int jd_dec_set_max_alloc_models(jd_dec *d, int32_t max_alloc_models)
+{
+    if (!d || max_alloc_models <= 0) return jd_fail(JD_EINVAL, "setMaxAllocModels: maxAllocModels > 0");
+    if (d->arenas_ready) return jd_fail(JD_ESTATE, "jd_dec_set_max_alloc_models: arenas already allocated");
+    int64_t n;
+    if (max_alloc_models < 100) n = d->net->n_arcs * max_alloc_models / 100;                        // :809-811
+    else if (max_alloc_models < 8000) n = (int64_t)max_alloc_models * 1024 * 1024 / (40 + 24 * (int64_t)d->am->max_n);   // :812-814, sizeof(NetInst) + sizeof(Token) * nStatePools
+    else n = max_alloc_models;                                                                       // :815-817
+    d->cap_slots = std::max<int64_t>(std::min<int64_t>(n, d->net->n_arcs + 65536), 64 * SW);   // (one instance per arc at most)
     return JD_OK;
 }
 
@@ -1313,6 +1443,34 @@ extern "C" int jd_stream_init(jd_dec *d, int32_t s)
     HIPCHK(hipStreamSynchronize(d->s_search));
     d->stream_T[(size_t)s] = 0;
     d->stream_started[(size_t)s] = 1;
+    d->last_collect[(size_t)s] = -1; d->last_trace[(size_t)s] = -1;    // WFSTDecoderLite.cpp:179-181, 202-206
+    d->partial_label[(size_t)s].clear(); d->partial_time[(size_t)s].clear();
+    return JD_OK;
+}
+
+// tracePartialPath (:824-868) on stream s at the frame it has reached; extends the stream's
+// partialPaths when a converged record is found
+static int trace_partial(jd_dec *d, int s, int *found)
+{
+    if (!d->d_partial_out) { int rc = dmalloc(d, &d->d_partial_out, 2); if (rc) return rc; }
+    std::vector<int32_t> &L = d->partial_label[(size_t)s], &Tm = d->partial_time[(size_t)s];
+    const int last_frame = Tm.empty() ? -1 : Tm.back();
+    hipStream_t st = d->s_search;
+    if (d->am->max_n <= 5) hipLaunchKernelGGL(k_partial<3>, dim3(1), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, s, last_frame, d->d_partial_out);
+    else hipLaunchKernelGGL(k_partial<6>, dim3(1), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, s, last_frame, d->d_partial_out);
+    HIPCHK(hipGetLastError());
+    int ho[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(ho, d->d_partial_out, sizeof ho, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    d->last_trace[(size_t)s] = d->stream_T[(size_t)s] - 1;             // :867
+    if (found) *found = ho[0];
+    if (!ho[0]) return JD_OK;
+    if (ho[1] > d->res_cap) return jd_fail(JD_ENOMEM, "stream %d: partial path has %d records (> %d)", s, ho[1], d->res_cap);
+    // the chain from the root to the found record; the records traced before are its prefix
+    L.resize((size_t)ho[1]); Tm.resize((size_t)ho[1]);
+    const int *base = d->d_res + (size_t)s * 5 * d->res_cap;           // res_label, res_time: arrays 0 and 1 of the stream
+    HIPCHK(hipMemcpy(L.data(), base, (size_t)ho[1] * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(Tm.data(), base + d->res_cap, (size_t)ho[1] * 4, hipMemcpyDeviceToHost));
     return JD_OK;
 }
 
@@ -1325,8 +1483,14 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
     if (rc) return rc;
     const int D = d->am->D, G = d->am->n_gmm, Fc = d->Fc;
     hipStream_t st = d->s_search;
-    for (int done = 0; done < n_frames; done += Fc) {
-        const int n = std::min(Fc, n_frames - done);
+    for (int done = 0, n = 0; done < n_frames; done += n) {
+        n = std::min(Fc, n_frames - done);
+        // PARTIAL_DECODING rides on the path collection's frame rule (:362-368): collection happens
+        // after the first frame f with f - lastPathCollectFrame > 100, and the trace with it when the
+        // interval has passed.  (The reference's other collection trigger, nPath / nPathNew > 12 with
+        // nPath > 10000, counts its allocator's live Path objects and has no counterpart here.)
+        const int f_collect = d->last_collect[(size_t)s] + 101;
+        if (d->partial_interval > 0) n = std::min(n, std::max(1, f_collect + 1 - d->stream_T[(size_t)s]));
         if ((size_t)n * D > d->push_cap) {
             if (d->d_push) (void)hipFree(d->d_push);
             HIPCHK(hipMalloc(&d->d_push, (size_t)Fc * D * sizeof(float)));
@@ -1351,7 +1515,45 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
         rc = launch_search(d, std::vector<int2>(1, make_int2(s, 0)), d->d_ll[0], (long long)Fc * G, f0, Tnew, st);
         if (rc) return rc;
         d->stream_T[(size_t)s] = Tnew;
+        if (d->partial_interval > 0 && Tnew - 1 == f_collect) {
+            d->last_collect[(size_t)s] = f_collect;                    // :746
+            if (f_collect - d->last_trace[(size_t)s] > d->partial_interval) {
+                rc = trace_partial(d, s, nullptr);
+                if (rc) return rc;
+            }
+        }
     }
+    return JD_OK;
+}
+
+// setPartialDecodeOptions (WFSTDecoderLite.cpp:892-896; the reference reads PartialTraceInterval
+// from the environment, :116-119)
+extern "C" int jd_dec_set_partial_interval(jd_dec *d, int32_t interval)
+{
+    if (!d || interval < 0) return jd_fail(JD_EINVAL, "jd_dec_set_partial_interval: traceInterval >= 0");
+    d->partial_interval = interval;
+    return JD_OK;
+}
+
+extern "C" int jd_stream_partial(jd_dec *d, int32_t s, int32_t trace_now, int32_t cap, int32_t *n, int32_t *labels,
+                                 int32_t *times, int32_t *found)
+{
+    if (!d || s < 0 || s >= d->max_streams || cap < 0 || !n) return jd_fail(JD_EINVAL, "jd_stream_partial: bad argument");
+    if (!d->stream_started[(size_t)s]) return jd_fail(JD_ESTATE, "jd_stream_partial before jd_stream_init");
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    int fnd = 0;
+    if (trace_now && d->stream_T[(size_t)s] > 0) {
+        rc = trace_partial(d, s, &fnd);
+        if (rc) return rc;
+    }
+    const std::vector<int32_t> &L = d->partial_label[(size_t)s], &Tm = d->partial_time[(size_t)s];
+    *n = (int32_t)L.size();
+    for (int k = 0; k < std::min<int>(cap, *n); ++k) {
+        if (labels) labels[k] = L[(size_t)k];
+        if (times) times[k] = Tm[(size_t)k];
+    }
+    if (found) *found = fnd;
     return JD_OK;
 }
 
@@ -1372,6 +1574,11 @@ extern "C" int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out)
     std::vector<jd_hyp> tmp((size_t)d->max_streams);
     rc = fetch_results(d, s, 1, tmp.data(), s);
     *out = tmp[(size_t)s];
+    if (d->partial_interval > 0 && out->n >= 0) {                      // :245-251 one more trace, from the best token
+        std::vector<int32_t> &L = d->partial_label[(size_t)s], &Tm = d->partial_time[(size_t)s];
+        L.resize((size_t)out->n); Tm.resize((size_t)out->n);
+        for (int k = 0; k < out->n; ++k) { L[(size_t)k] = out->label[out->n - 1 - k]; Tm[(size_t)k] = out->time[out->n - 1 - k]; }
+    }
     return rc;
 }
 

@@ -7,14 +7,14 @@
  *   HTKModels parameter preparation       src/HTKModels.cpp:581-593, 600-676, 835-870, 873-974, 2330-2390
  *   HTKFlatModels flatten + GMM + logAdd  src/HTKFlatModels.cpp:94-177, 226-306
  *   Histogram                             src/Histogram.cpp:23-56, 64-120, 134-158
- *   WFSTDecoderLite                       src/WFSTDecoderLite.cpp:139-228, 230-309, 311-605, 751-805, 899-982
+ *   WFSTDecoderLite                       src/WFSTDecoderLite.cpp:139-228, 230-309, 311-605, 751-805, 822-896, 899-982
  *   DecoderSingleTest frame protocol      src/DecoderSingleTest.cpp:259-298
  * Compile with:  gcc -O2 -ffp-contract=off  (no -march=native, no -ffast-math)
  * so that every float operation rounds exactly once, in the reference's order.
  *
  * Deliberate omissions that do not change results: Path garbage collection
- * (collectPaths, WFSTDecoderLite.cpp:699-747 only frees unreachable records),
- * PARTIAL_DECODING tracing (:824-890, off unless an env var is set), LogFile.
+ * (collectPaths, WFSTDecoderLite.cpp:699-747 only frees unreachable records; its
+ * frame-rule schedule is kept for the PARTIAL_DECODING trace, see jo_process_frame), LogFile.
  */
 #include "juicer_oracle.h"
 
@@ -411,6 +411,11 @@ struct jo_dec {
     int32_t currFrame, nActiveInsts, nActiveEmitHyps, nActiveEndHyps, nEmitProc, nEndProc;
     jo_stats st;
     int tie_mode;                         /* 0 = reference (first visited wins), 1 = last visited wins (test aid) */
+    /* PARTIAL_DECODING (WFSTDecoderLite.h:199-205) */
+    int32_t partialTraceInterval, lastPartialTraceFrame, lastPathCollectFrame;
+    int32_t *partialPaths; int32_t n_partial, cap_partial;   /* vector<Path*> partialPaths, as Path indices */
+    int32_t *jointCount; int64_t cap_joint;                  /* Path::jointCount */
+    int32_t *p_label, *p_time;                               /* jo_partial_get view */
     int64_t tie_kind[4];                  /* bestFinal, entry token, HMM-internal, entry ties whose tokens differ */
     /* HTKFlatModels cache state */
     int32_t *cacheT; float *cache; const float *const *currInput; int32_t currInputLen, amFrame;
@@ -427,6 +432,7 @@ void jo_dec_destroy(jo_dec *d)
     free(d->hook); free(d->insts); free(d->toks); free(d->paths); free(d->tokenBuf);
     free(d->cacheT); free(d->cache);
     free(d->r_label); free(d->r_time); free(d->r_score); free(d->r_ac); free(d->r_lm);
+    free(d->partialPaths); free(d->jointCount); free(d->p_label); free(d->p_time);
     free(d);
 }
 
@@ -639,6 +645,8 @@ int jo_init(jo_dec *d)
     memset(d->tie_kind, 0, sizeof d->tie_kind);
     d->nActiveInsts = d->nActiveEmitHyps = d->nActiveEndHyps = d->nEmitProc = d->nEndProc = 0;
     d->err = 0; d->started = 1; d->amFrame = -1;
+    d->n_partial = 0;                                               /* :179-181 */
+    d->lastPathCollectFrame = -1; d->lastPartialTraceFrame = -1;    /* :202-206 */
     Tok tmp = {0.0f, 0.0f, 0.0f, -1};                               /* :221-227 */
     propagate(d, &tmp, -1);
     join_new(d);
@@ -753,6 +761,84 @@ static void do_external(jo_dec *d)
     d->st.tot_active_models += d->nActiveInsts;
 }
 
+/* traceWinningPaths, WFSTDecoderLite.cpp:874-890: the Path records from the last traced one
+ * (exclusive) down to |path| (inclusive) are appended to partialPaths, oldest first */
+static void trace_winning(jo_dec *d, int32_t path)
+{
+    if (path < 0) return;                                           /* assert(path) :875 */
+    int32_t last = d->n_partial ? d->partialPaths[d->n_partial - 1] : -1;
+    if (path == last) return;                                       /* :880 */
+    int32_t n = 1;
+    for (int32_t q = path; d->paths[q].prev != last && d->paths[q].prev >= 0; q = d->paths[q].prev) ++n;   /* :882-886 */
+    if (d->n_partial + n > d->cap_partial) {
+        d->cap_partial = (d->n_partial + n) * 2 + 64;
+        d->partialPaths = (int32_t *)realloc(d->partialPaths, sizeof(int32_t) * (size_t)d->cap_partial);
+    }
+    int32_t q = path;
+    for (int32_t k = n - 1; k >= 0; --k) { d->partialPaths[d->n_partial + k] = q; q = d->paths[q].prev; }   /* :887-889 */
+    d->n_partial += n;
+}
+
+/* tracePartialPath, WFSTDecoderLite.cpp:824-868.  Returns 1 if a Path record all open
+ * hypotheses converge into was found (and partialPaths extended), else 0. */
+int jo_trace_partial(jo_dec *d)
+{
+    if (!d || !d->started) return fail(-6, "tracePartialPath before init");
+    int found = 0;
+    int32_t lastTraced = d->n_partial ? d->partialPaths[d->n_partial - 1] : -1;
+    int32_t lastTracedFrame = lastTraced >= 0 ? d->paths[lastTraced].frame : -1;
+    /* step 1 (:832-842): reset jointCount of every Path newer than the last traced one */
+    if (d->n_paths > d->cap_joint) {
+        d->cap_joint = d->n_paths * 2 + 64;
+        d->jointCount = (int32_t *)realloc(d->jointCount, sizeof(int32_t) * (size_t)d->cap_joint);
+    }
+    for (int64_t q = 0; q < d->n_paths; ++q)
+        if (d->paths[q].frame > lastTracedFrame) d->jointCount[q] = 0;
+    /* step 2 (:844-865): from every instance's first token that has a path, count the visits */
+    for (int32_t inst = d->active; !found && inst >= 0; inst = d->insts[inst].next) {
+        const Tok *tok = &d->toks[(size_t)inst * d->maxN];
+        int32_t path = -1;
+        /* :850-854 walks tok upwards until a path is found; it is bounded by the instance here
+         * (an instance none of whose tokens has a path yet contributes nothing, so nothing is
+         * found; the reference would read past the instance) */
+        for (int32_t i = 0; i < d->insts[inst].n && path < 0; ++i) path = tok[i].path;
+        while (path >= 0) {                                         /* :857-866 */
+            if (d->paths[path].frame > lastTracedFrame && ++d->jointCount[path] == d->nActiveInsts) {
+                found = 1;
+                trace_winning(d, path);
+                break;
+            }
+            path = d->paths[path].prev;
+        }
+    }
+    d->lastPartialTraceFrame = d->currFrame;                        /* :867 */
+    return found;
+}
+
+/* setPartialDecodeOptions, :892-896 */
+int jo_set_partial_interval(jo_dec *d, int32_t interval)
+{
+    if (!d || interval < 0) return fail(-1, "setPartialDecodeOptions: traceInterval >= 0");
+    d->partialTraceInterval = interval;
+    return 0;
+}
+
+/* partialPaths as (label, frame) of its Path records, oldest first (:252-256 prints the frames) */
+int jo_partial_get(jo_dec *d, int32_t *n, const int32_t **labels, const int32_t **times)
+{
+    if (!d || !n) return fail(-1, "jo_partial_get: null argument");
+    d->p_label = (int32_t *)realloc(d->p_label, sizeof(int32_t) * (size_t)(d->n_partial + 1));
+    d->p_time = (int32_t *)realloc(d->p_time, sizeof(int32_t) * (size_t)(d->n_partial + 1));
+    for (int32_t k = 0; k < d->n_partial; ++k) {
+        d->p_label[k] = d->paths[d->partialPaths[k]].label;
+        d->p_time[k] = d->paths[d->partialPaths[k]].frame;
+    }
+    *n = d->n_partial;
+    if (labels) *labels = d->p_label;
+    if (times) *times = d->p_time;
+    return 0;
+}
+
 /* processFrame, WFSTDecoderLite.cpp:311-372 */
 int jo_process_frame(jo_dec *d, const float *const *rows, int32_t frame, int32_t n_avail)
 {
@@ -773,6 +859,17 @@ int jo_process_frame(jo_dec *d, const float *const *rows, int32_t frame, int32_t
     d->endTh = (d->endWin > 0.0 ? (d->bestEmitScore - d->endWin) : LZ);        /* :349 */
     d->wordTh = (d->wordWin > 0.0 ? (d->bestEmitScore - d->wordWin) : LZ);     /* :350 */
     do_external(d);                                                 /* :353 */
+    /* path collection :355-370.  collectPaths itself is omitted (it only frees unreachable
+     * records); what is kept is WHEN it runs, because the partial trace rides on it.  Of the two
+     * triggers only the frame rule is modelled: the other one (nPath / nPathNew > 12 and
+     * nPath > 10000) depends on the allocator's count of live Path objects, which this
+     * restatement does not keep.  It changes the frames at which a trace is taken, never what a
+     * trace at a given frame finds. */
+    if (d->currFrame - d->lastPathCollectFrame > 100) {
+        d->lastPathCollectFrame = d->currFrame;                     /* :746 */
+        if (d->partialTraceInterval > 0 && (d->currFrame - d->lastPartialTraceFrame > d->partialTraceInterval))
+            jo_trace_partial(d);                                    /* :365-368 */
+    }
     if (d->trace && frame < d->trace_cap) d->trace[frame] = d->bestEmitScore;
     if (d->err == -5) return fail(-5, "Histogram::addScore - score > maxScore");
     return 0;
@@ -785,6 +882,8 @@ int jo_finish(jo_dec *d, jo_hyp *out)
     d->st.n_frames = d->currFrame + 1;
     out->stats = d->st;
     Tok best = d->bestFinal;
+    if (d->partialTraceInterval > 0 && best.score > LZ)             /* :245-251 one more trace from the best token */
+        trace_winning(d, best.path);
     if (best.score == LZ) { out->n = -1; return 0; }                /* :264-267 */
     int32_t n = 0;
     for (int32_t p = best.path; p >= 0; p = d->paths[p].prev) ++n;

@@ -82,6 +82,14 @@ int jo_decode_utt(jo_dec *d, const float *feats, int32_t n_frames, jo_hyp *out, 
 /* per-frame trace for debugging parity: bestEmitScore after each frame */
 int jo_set_trace(jo_dec *d, float *best_emit_per_frame, int32_t cap);
 
+/* PARTIAL_DECODING (WFSTDecoderLite.cpp:822-896): jo_set_partial_interval = setPartialDecodeOptions
+ * (the reference reads it from the environment variable PartialTraceInterval, :116-119);
+ * jo_trace_partial = tracePartialPath on the current state (the frame loop calls it on the
+ * reference's schedule, :362-368); jo_partial_get = the partialPaths list, oldest first. */
+int jo_set_partial_interval(jo_dec *d, int32_t interval);
+int jo_trace_partial(jo_dec *d);
+int jo_partial_get(jo_dec *d, int32_t *n, const int32_t **labels, const int32_t **times);
+
 /* equal-score recombinations of the last utterance by kind: [0] bestFinalToken, [1] entry token,
  * [2] HMM-internal (lowest predecessor wins: not order dependent), [3] entry-token ties whose
  * two tokens differ in acoustic / LM score or history (the only ones whose winner matters) */

@@ -198,6 +198,61 @@ class OracleDecoder:
                          tot_ac=float(hyp.tot_ac), tot_lm=float(hyp.tot_lm), stats=st,
                          cpu_seconds=float(secs.value), tie_kinds=tuple(int(k) for k in kinds))
 
+    def _partial_list(self):
+        L = lib()
+        n = C.c_int32(0)
+        lab = C.POINTER(C.c_int32)()
+        tim = C.POINTER(C.c_int32)()
+        _check(L.jo_partial_get(self.h, C.byref(n), C.byref(lab), C.byref(tim)))
+        return [(int(lab[i]), int(tim[i])) for i in range(n.value)]
+
+    def decode_partial(self, feats, interval: int = 0, trace_at=()):
+        """PARTIAL_DECODING (WFSTDecoderLite.cpp:822-896).  Runs DecoderSingleTest's frame loop with
+        setPartialDecodeOptions(interval) (0: the reference's own schedule is off) and, as a test aid,
+        calls tracePartialPath after every frame listed in trace_at.  Returns (snapshots, final):
+        snapshots[f] = (found, partialPaths as [(label, frame)], oldest first) for every frame f after
+        which a trace ran (explicit ones: found is the return value; scheduled ones: whether the list
+        grew), final = partialPaths after recognitionFinish."""
+        L = lib()
+        x = _f32(feats)
+        T, D = x.shape[0], self.am.D
+        L.jo_dec_set_tie_mode(self.h, C.c_int(0))
+        L.jo_set_trace(self.h, None, C.c_int32(0))
+        _check(L.jo_set_partial_interval(self.h, C.c_int32(interval)))
+        rows = (C.POINTER(C.c_float) * max(T, 1))()
+        base = x.ctypes.data
+        for t in range(T):
+            rows[t] = C.cast(base + t * D * 4, C.POINTER(C.c_float))
+        rows_addr = C.addressof(rows)
+        psz = C.sizeof(C.POINTER(C.c_float))
+        trace_at = set(int(f) for f in trace_at)
+        snaps = {}
+        _check(L.jo_init(self.h))
+        n_frames, n_data = 0, min(20, T)                                # DecoderSingleTest.cpp:267-277
+        last_collect, last_trace, before = -1, -1, 0
+        while n_data > 0:                                               # :280-295
+            _check(L.jo_process_frame(self.h, C.c_void_p(rows_addr + n_frames * psz), C.c_int32(n_frames), C.c_int32(n_data)))
+            f = n_frames
+            if f - last_collect > 100:                                  # the schedule jo_process_frame follows
+                last_collect = f
+                if interval > 0 and f - last_trace > interval:
+                    lst = self._partial_list()
+                    snaps[f] = (len(lst) > before, lst)
+                    before, last_trace = len(lst), f
+            if f in trace_at:
+                found = L.jo_trace_partial(self.h)
+                lst = self._partial_list()
+                snaps[f] = (bool(found), lst)
+                before, last_trace = len(lst), f
+            n_frames += 1
+            if not (n_frames + n_data - 1 < T):
+                n_data -= 1
+        hyp = _Hyp()
+        _check(L.jo_finish(self.h, C.byref(hyp)))
+        final = self._partial_list()
+        _check(L.jo_set_partial_interval(self.h, C.c_int32(0)))
+        return snaps, final
+
     def decode_certified(self, feats) -> OracleHyp:
         """Reference-rule decode whose result is certified not to depend on visiting order: when
         order-dependent equal-score recombinations occurred (stats['ties'] > 0: float32 collisions

@@ -367,6 +367,17 @@ def test_batch_test_cli(small, tmp_path):
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and out.stdout == ""
     assert (tmp_path / "res.txt").read_text().splitlines() == ref_lines
+    # PartialTraceInterval (WFSTDecoderLite.cpp:116-119): the adapter traces on the reference's schedule
+    # and the log gets recognitionFinish's line (:252-256) - the frames of the whole best path
+    import os
+    out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-inputFName", str(lst), "-mainBeam", "150",
+                          "-maxHyps", "200", "-outputFormat", "ref", "-perFrameAdapter"] + mm,
+                         capture_output=True, text=True, timeout=240, env=dict(os.environ, PartialTraceInterval="50"))
+    assert out.returncode == 0 and out.stdout.splitlines() == ref_lines
+    got = [l for l in out.stderr.splitlines() if l.startswith("Partial paths recovered at frames:")]
+    assert len(got) == len(feats)
+    for u in range(len(feats)):
+        assert [int(v) for v in got[u].split(":")[1].split()] == want[u].time[::-1].tolist()
 
 
 def test_path_garbage_collection(small):
@@ -657,3 +668,95 @@ def test_tree_hub_closure_rounds(small_tree, bi):
             assert np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
             for k in ("tot_active_models", "tot_proc_emit_hyps", "tot_proc_end_hyps", "tot_insts_in"):
                 assert a.stats[k] == b.stats[k]
+
+
+@pytest.mark.parametrize("cfg_name", ["small", "small_tree", "mixed"])
+def test_partial_decoding_traces(cfg_name, request):
+    """PARTIAL_DECODING, tracePartialPath / traceWinningPaths (WFSTDecoderLite.cpp:824-890): a trace
+    asked for after the same frames finds the same converged Path record on the GPU as the restated
+    reference, and the accumulated partialPaths lists are identical throughout - also with a Path
+    arena so small that records are collected (and renumbered) between the traces."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = request.getfixturevalue(cfg_name)
+    kw = dict(main_beam=150.0, max_hyps=200) if cfg_name != "mixed" else dict(main_beam=200.0)
+    od = OracleDecoder(onet, oam, **kw)
+    n_found = n_traces = 0
+    for gd in (capi.Decoder(gnet, gam, max_streams=2, **kw), capi.Decoder(gnet, gam, max_streams=2, max_paths=1 << 12, **kw)):
+        for u in range(min(3, len(feats))):
+            x = feats[u]
+            at = list(range(7, x.shape[0], 23))
+            snaps, _ = od.decode_partial(x, interval=0, trace_at=at)
+            gd.stream_init(1)
+            pos = 0
+            for f in at:
+                gd.stream_push(1, x[pos:f + 1])
+                pos = f + 1
+                found, lst = gd.stream_partial(1, trace_now=True)
+                assert (found, lst) == snaps[f], "%s utt %d frame %d: %r vs %r" % (cfg_name, u, f, (found, lst[-3:]), (snaps[f][0], snaps[f][1][-3:]))
+                n_found += found
+                n_traces += 1
+            gd.stream_push(1, x[pos:])
+            g = gd.stream_finish(1)
+            assert_hyp_matches(g, od.decode_certified(x), "partial %s utt %d" % (cfg_name, u))
+            # every traced record is part of the final result (the prefix that could no longer change)
+            final = list(zip(g.label.tolist()[::-1], g.time.tolist()[::-1]))
+            assert final[:len(lst)] == lst
+    assert n_found >= 4 and n_found < n_traces, "vacuous: %d of %d traces found a record" % (n_found, n_traces)
+
+
+def test_partial_decoding_schedule(small):
+    """setPartialDecodeOptions(interval): traces ride on the path collection's frame rule (:362-368)
+    whatever the push sizes are, and finish() completes the list from the best token (:245-251)."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0)
+    od = OracleDecoder(onet, oam, **kw)
+    gd = capi.Decoder(gnet, gam, max_streams=1, **kw)
+    x = np.concatenate([feats[0], feats[1], feats[2], feats[0]])       # long enough for several collections
+    assert x.shape[0] > 450
+    for interval, step in ((1, 37), (150, 64), (150, 1000)):
+        snaps, final = od.decode_partial(x, interval=interval)
+        assert len(snaps) >= 2
+        gd.set_partial_interval(interval)
+        gd.stream_init(0)
+        seen = {}
+        for pos in range(0, x.shape[0], step):
+            gd.stream_push(0, x[pos:pos + step])
+            last = min(x.shape[0], pos + step) - 1
+            # the list as it stands after this push = the reference's after its last trace up to here
+            due = [f for f in sorted(snaps) if f <= last]
+            _, lst = gd.stream_partial(0)
+            assert lst == (snaps[due[-1]][1] if due else []), "interval %d, after frame %d" % (interval, last)
+            seen[last] = lst
+        g = gd.stream_finish(0)
+        _, lst = gd.stream_partial(0)
+        assert lst == final == list(zip(g.label.tolist()[::-1], g.time.tolist()[::-1]))
+    gd.set_partial_interval(0)
+
+
+def test_max_alloc_models(small):
+    """setMaxAllocModels (WFSTDecoderLite.cpp:807-820): percentage / MB / count forms size the
+    instance-record arena; results do not depend on it, and too small a limit is a named JD_ENOMEM."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    n_arcs = synth.config_small()[1].n_arcs
+    kw = dict(main_beam=150.0, max_hyps=200)
+    od = OracleDecoder(onet, oam, **kw)
+    want = od.decode_certified(feats[0])
+    for v in (100, 20000):                                              # 100 MB, 20000 instances
+        gd = capi.Decoder(gnet, gam, max_streams=1, **kw)
+        gd.set_max_alloc_models(v)
+        assert_hyp_matches(gd.decode_batch(feats[:1])[0], want, "MaxAllocModels %d" % v)
+        with pytest.raises(capi.JuicerAmdError):                        # only before the arenas exist
+            gd.set_max_alloc_models(v)
+    gd = capi.Decoder(gnet, gam, max_streams=1)                         # no beam: an instance on most arcs
+    gd.set_max_alloc_models(60)                                         # 60 % of the arcs (:809-811)
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        gd.decode_batch(feats[:1])
+    assert ei.value.code == capi.JD_ENOMEM and "instance slots" in str(ei.value)
+    assert "capacity %d," % ((n_arcs * 60 // 100) & ~63) in str(ei.value), str(ei.value)
+    with pytest.raises(capi.JuicerAmdError):
+        capi.Decoder(gnet, gam, max_streams=1).set_max_alloc_models(0)  # assert(maxAllocModels_ > 0) :808

@@ -99,3 +99,39 @@ def test_oracle_rejects_bad_input(built):
         a = getattr(bad, f); setattr(bad, f, np.concatenate([a[1:], a[:1]]))
     with pytest.raises(RuntimeError):
         OracleNet(bad)
+
+
+def test_oracle_partial_decoding(built):
+    """PARTIAL_DECODING restatement (WFSTDecoderLite.cpp:822-896): every traced list is a prefix of the
+    final result (a converged record can no longer change), the scheduled traces sit on the path
+    collection frames (100, 201, 302, ...: the first frame f with f - lastPathCollectFrame > 100) and
+    respect the interval, and recognitionFinish completes the list to the whole best path."""
+    from juicer_amd import synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small()
+    od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=150.0)
+    x = np.concatenate(feats)
+    o = od.decode(x)
+    best = list(zip(o.label.tolist()[::-1], o.time.tolist()[::-1]))
+    snaps, final = od.decode_partial(x, interval=0, trace_at=range(5, x.shape[0], 17))
+    assert final == (snaps[max(snaps)][1] if snaps else [])            # interval 0: finish adds nothing (:247)
+    grew = 0
+    prev = []
+    for f in sorted(snaps):
+        found, lst = snaps[f]
+        assert best[:len(lst)] == lst and lst[:len(prev)] == prev
+        assert found == (len(lst) > len(prev))
+        assert all(t <= f for _, t in lst)
+        grew += found
+        prev = lst
+    assert grew >= 3
+    for interval in (1, 150, 250):
+        snaps, final = od.decode_partial(x, interval=interval)
+        assert final == best
+        frames = sorted(snaps)
+        assert all((f + 1) % 101 == 0 for f in frames)                  # 100, 201, 302, ...
+        assert all(b - a > interval for a, b in zip(frames, frames[1:]))
+        assert frames and frames[0] == 100 * (1 + interval // 101) + interval // 101
+    # the decoder is reusable afterwards and unaffected
+    o2 = od.decode(x)
+    assert o2.n == o.n and np.array_equal(o2.label, o.label)
