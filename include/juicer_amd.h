@@ -100,6 +100,22 @@ int32_t jd_net_num_states(const jd_net *n);   /* WFSTNetwork::getNumStates      
 int32_t jd_net_init_state(const jd_net *n);   /* WFSTNetwork::getInitState      */
 void    jd_net_destroy(jd_net *n);
 
+/*
+ * Dynamic composition, first step (WFSTOnTheFlyDecoder, juicer.cpp:594-598): C.L and G
+ * are handed over apart - cl loaded like the reference's clNetwork (scale 1.0, juicer.cpp:933-940), g like
+ * its gNetwork (lmScaleFactor; arcs of a state sorted by input label, one per label, the back-off
+ * epsilon first: WFSTSortedInLabelNetwork, WFSTNetwork.cpp:2693-2710) - and composed ON THE DEVICE into
+ * an ordinary network for jd_dec_create: reachable (C.L state, G state) pairs only, G advanced by a
+ * binary search for the C.L arc's output label (WFSTOnTheFlyDecoder.cpp:3106-3159), back-off epsilons
+ * taken right after a word only (WFSTOnTheFlyDecoder.cpp:1590-1622), lexicon branches that hold no word
+ * the G state has an arc for left out (label look-ahead, WFSTNetwork.cpp:1505-2590, on label intervals:
+ * tight when words are numbered in the lexicon tree's depth-first order).  Exact definition and the
+ * state / arc numbering: csrc/jd_compose.hip.  max_states / max_arcs bound the result (0: a default
+ * derived from the inputs); JD_ENOMEM names the one that was too small.  There is no CPU path.
+ */
+int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t device,
+                   int64_t max_states, int64_t max_arcs);
+
 /* ---------------------------------------------------------- acoustic models */
 
 /*

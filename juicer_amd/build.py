@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libjuicer_amd.so")
 BATCH_TEST = os.path.join(HERE, "jd_batch_test")
 BATCH_SRC = os.path.join(CSRC, "jd_batch_test.cpp")
-SOURCES = [os.path.join(CSRC, "jd_host.cpp"), os.path.join(CSRC, "jd_device.hip"), os.path.join(CSRC, "jd_multi.cpp")]
+SOURCES = [os.path.join(CSRC, "jd_host.cpp"), os.path.join(CSRC, "jd_device.hip"), os.path.join(CSRC, "jd_multi.cpp"),
+           os.path.join(CSRC, "jd_compose.hip")]
 HEADERS_EXTRA = [os.path.join(CSRC, "jd_search.h")]
 HEADERS = [os.path.join(CSRC, "jd_internal.h"), os.path.join(ROOT, "include", "juicer_amd.h"),
            os.path.join(ROOT, "include", "juicer_amd_decoder.hpp"), BATCH_SRC]

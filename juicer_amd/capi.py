@@ -75,7 +75,7 @@ EXPORTS = [
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_decode_batch", "jd_multi_destroy",
-    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models",
+    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models", "jd_net_compose",
 ]
 
 _lib = None
@@ -178,6 +178,13 @@ class Network:
         """Juicer's binary network cache (<fsm>.bin, WFSTNetwork::readBinary)."""
         h = C.c_void_p()
         _check(lib().jd_net_load_jwnt(C.byref(h), os.fsencode(path), C.c_float(lm_scale), C.c_float(ins_penalty)))
+        return cls(h)
+
+    @classmethod
+    def compose(cls, cl: "Network", g: "Network", device: int = 0, max_states: int = 0, max_arcs: int = 0):
+        """C.L o G on the device (jd_net_compose): the dynamic-composition row's first step."""
+        h = C.c_void_p()
+        _check(lib().jd_net_compose(C.byref(h), cl.h, g.h, C.c_int32(device), C.c_int64(max_states), C.c_int64(max_arcs)))
         return cls(h)
 
     def save_jwnt(self, path):

@@ -326,6 +326,91 @@ def make_wfst(seed: int, am: SynthAM, n_words: int, n_succ: int,
                     n_words=V, prons=prons, succ=succ, sp_hmm=am.sp_hmm if use_sp else -1)
 
 
+def make_cl_g(seed: int, am: SynthAM, n_words: int, n_succ: int, n_tri: int = 0, n_succ3: int = 3,
+              pron_len=(2, 5), with_sp: bool = False, n_phones: int = 40):
+    """SEPARATE C.L and G (BASELINE.json configs[4], the inputs of jd_net_compose), returned as two
+    SynthNet objects (cl, g) in FSM file form.
+
+    C.L: lexicon prefix-tree transducer.  State 0 = root (initial and final).  The first L-1 models of
+    a pronunciation are shared tree arcs, the last model arc is per word, carries the word label and
+    leads back to the root (through the tee "sp" model if the model set has one).  Words are numbered
+    in the depth-first order of the tree (= pronunciations in lexicographic order), which makes the
+    label sets below a tree node contiguous intervals.  Pronunciation costs on the word arcs.
+    G: back-off n-gram acceptor.  State 0 = <s> (initial), 1..V = one-word histories (final), V+1 =
+    unigram state, then n_tri two-word histories (u,v) (final).  A history has arcs for its successor
+    words and an epsilon arc (the back-off) to the next shorter history; the unigram state has an arc
+    for every word.  Arcs are written in random order (a loader has to sort them)."""
+    rng = np.random.default_rng(seed)
+    V, K = n_words, min(n_succ, n_words)
+    n_real_hmm = am.n_hmm - (1 if am.sp_hmm >= 0 else 0)
+    use_sp = with_sp and am.sp_hmm >= 0
+    P = min(n_phones, max(2, n_real_hmm // 2))
+    prons = []
+    for l in rng.integers(pron_len[0], pron_len[1] + 1, size=V):
+        ph = rng.integers(0, P, size=int(l))
+        hm = [int(ph[0])]
+        for k in range(1, int(l)):
+            hm.append(P + (int(ph[k - 1]) * 7919 + int(ph[k]) * 104729 + k * 31) % (n_real_hmm - P))
+        prons.append(tuple(hm))
+    prons.sort()                                        # depth-first order of the prefix tree
+    # ---- C.L
+    src, dst, il, ol, wf = [], [], [], [], []
+    nxt = 1
+    back = 0
+    if use_sp:
+        back = nxt; nxt += 1                            # word-end node: sp (tee) arc to the root
+        src.append(back); dst.append(0); il.append(am.sp_hmm + 1); ol.append(0); wf.append(0.0)
+    children = {}
+    for w, pr in enumerate(prons):
+        nd = 0
+        for hm in pr[:-1]:
+            key = (nd, hm)
+            if key not in children:
+                children[key] = nxt
+                src.append(nd); dst.append(nxt); il.append(hm + 1); ol.append(0); wf.append(0.0)
+                nxt += 1
+            nd = children[key]
+        src.append(nd); dst.append(back); il.append(pr[-1] + 1); ol.append(w + 1); wf.append(float(rng.uniform(0.0, 1.0)))
+    order = np.argsort(np.asarray(src), kind="stable")
+    A = lambda x, dt: np.asarray(x, dtype=dt)[order]
+    cl = SynthNet(n_states=nxt, src=A(src, np.int32), dst=A(dst, np.int32), ilab=A(il, np.int32), olab=A(ol, np.int32),
+                  w_file=A(wf, np.float32), fstate=np.asarray([0], np.int32), fweight_file=np.asarray([0.0], np.float32),
+                  n_words=V, prons=[np.asarray(p, np.int32) for p in prons], sp_hmm=am.sp_hmm if use_sp else -1)
+    # ---- G
+    succ = np.zeros((V + 1, K), dtype=np.int32)
+    for h in range(V + 1):
+        succ[h] = rng.choice(V, size=K, replace=False)
+    uni = V + 1
+    tri = {}                                            # (u, v) -> state, v a successor of u
+    while len(tri) < min(n_tri, V * K):
+        u = int(rng.integers(0, V)); v = int(succ[1 + u, rng.integers(0, K)])
+        if (u, v) not in tri:
+            tri[(u, v)] = V + 2 + len(tri)
+    src, dst, il, ol, wf = [], [], [], [], []
+    def arc(a, b, lab, cost):
+        src.append(a); dst.append(b); il.append(lab); ol.append(lab); wf.append(cost)
+    for h in range(V + 1):
+        for w in succ[h]:
+            w = int(w)
+            arc(h, tri.get((h - 1, w), 1 + w) if h > 0 else 1 + w, w + 1, float(rng.uniform(0.5, 8.0)))
+        arc(h, uni, 0, float(rng.uniform(1.0, 4.0)))
+    for w in range(V):
+        arc(uni, 1 + w, w + 1, float(rng.uniform(4.0, 12.0)))
+    for (u, v), st in tri.items():
+        for w in rng.choice(V, size=min(n_succ3, V), replace=False):
+            w = int(w)
+            arc(st, tri.get((v, w), 1 + w), w + 1, float(rng.uniform(0.3, 5.0)))
+        arc(st, 1 + v, 0, float(rng.uniform(0.5, 3.0)))
+    perm = rng.permutation(len(src))                    # file order: shuffled, then grouped by state
+    order = perm[np.argsort(np.asarray(src)[perm], kind="stable")]
+    fstate = np.concatenate([np.arange(1, V + 1), np.arange(V + 2, V + 2 + len(tri))]).astype(np.int32)
+    g = SynthNet(n_states=V + 2 + len(tri), src=A(src, np.int32), dst=A(dst, np.int32), ilab=A(il, np.int32),
+                 olab=A(ol, np.int32), w_file=A(wf, np.float32), fstate=fstate,
+                 fweight_file=rng.uniform(0.0, 2.0, size=fstate.shape[0]).astype(np.float32),
+                 n_words=V, prons=cl.prons, succ=succ, sp_hmm=cl.sp_hmm)
+    return cl, g
+
+
 def make_wfst_sized(seed: int, am: SynthAM, target_arcs: int, n_words: int,
                     pron_len=(2, 5), with_sp: bool = False, hub: str = "tree") -> SynthNet:
     """Pick the bigram fan-out so that the graph has about target_arcs arcs."""

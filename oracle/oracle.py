@@ -101,6 +101,21 @@ class OracleNet:
         self.n_arcs = int(L.jo_net_num_arcs(self.h))
         self.n_states = int(L.jo_net_num_states(self.h))
 
+    @classmethod
+    def from_csr(cls, n_states, init_state, row_ptr, to, w, ilab, olab, fstate, fweight):
+        """weights taken as they are (already scaled): jo_net_create_csr"""
+        L = lib()
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        rp, to_, il, ol = _i32(row_ptr), _i32(to), _i32(ilab), _i32(olab)
+        w_, fs, fw = _f32(w), _i32(fstate), _f32(fweight)
+        _check(L.jo_net_create_csr(C.byref(self.h), C.c_int32(n_states), C.c_int32(init_state), _p(rp, C.c_int32),
+                                   _p(to_, C.c_int32), _p(w_, C.c_float), _p(il, C.c_int32), _p(ol, C.c_int32),
+                                   C.c_int32(fs.shape[0]), _p(fs, C.c_int32), _p(fw, C.c_float)))
+        self.n_arcs = int(L.jo_net_num_arcs(self.h))
+        self.n_states = int(L.jo_net_num_states(self.h))
+        return self
+
     def arrays(self):
         L = lib()
         first = np.zeros(self.n_states, np.int32); cnt = np.zeros(self.n_states, np.int32)

@@ -1,0 +1,141 @@
+"""Offline composition of C.L and G in plain Python - TEST INFRASTRUCTURE for jd_net_compose
+(csrc/jd_compose.hip).  There is no oracle for the dynamic-composition row: the reference's
+WFSTOnTheFlyDecoder is not built by either of its build systems and no longer compiles (SURVEY.md
+section 2 row 15), so the device composition is checked against
+
+  compose_filtered  the same definition (filter flag, back-off after a word only, interval
+                    look-ahead, canonical numbering) written a second time with dictionaries - the
+                    arrays must come out identical, bit for bit;
+  compose_naive     textbook epsilon composition with nothing clever: every (C.L state, G state)
+                    pair, G's epsilon taken anywhere, no filter, no look-ahead.  A different (larger,
+                    redundant) graph with the same set of weighted paths: decoding it with the CPU
+                    oracle must give the words, times and (up to float association) scores the GPU
+                    static path gives on the device-composed graph.
+
+Inputs are csr() dictionaries of capi.Network objects, i.e. the weights as the loaders scaled them.
+"""
+import numpy as np
+
+INF = np.float32(np.inf)
+
+
+def _sorted_g(g):
+    """per state: arcs sorted by input label (WFSTSortedInLabelNetwork)"""
+    rows = []
+    for s in range(len(g["row_ptr"]) - 1):
+        a0, a1 = int(g["row_ptr"][s]), int(g["row_ptr"][s + 1])
+        idx = sorted(range(a0, a1), key=lambda a: int(g["ilab"][a]))
+        rows.append([(int(g["ilab"][a]), int(g["olab"][a]), int(g["to"][a]), np.float32(g["w"][a])) for a in idx])
+    return rows
+
+
+def _lookahead(cl):
+    S = len(cl["row_ptr"]) - 1
+    lo = [2 ** 31 - 1] * S
+    hi = [0] * S
+    changed = True
+    on_cycle = set()
+    # label-less cycles: states reachable from themselves through arcs without an output label
+    eps_next = [[int(cl["to"][a]) for a in range(int(cl["row_ptr"][c]), int(cl["row_ptr"][c + 1])) if int(cl["olab"][a]) == 0]
+                for c in range(S)]
+    for c in range(S):
+        seen, stack = set(), list(eps_next[c])
+        while stack:
+            x = stack.pop()
+            if x == c:
+                on_cycle.add(c)
+                break
+            if x not in seen:
+                seen.add(x)
+                stack.extend(eps_next[x])
+    for c in on_cycle:
+        lo[c], hi[c] = 1, 2 ** 31 - 1
+    while changed:
+        changed = False
+        for c in range(S):
+            for a in range(int(cl["row_ptr"][c]), int(cl["row_ptr"][c + 1])):
+                o, t = int(cl["olab"][a]), int(cl["to"][a])
+                l, h = (o, o) if o else (lo[t], hi[t])
+                if l <= h and (l < lo[c] or h > hi[c]):
+                    lo[c], hi[c] = min(lo[c], l), max(hi[c], h)
+                    changed = True
+    return lo, hi
+
+
+def _finish(states, arcs_of, fin_of, init_key, order_key):
+    """canonical numbering + CSR arrays"""
+    keys = sorted(states, key=order_key)
+    idx = {k: i for i, k in enumerate(keys)}
+    row_ptr, to, w, il, ol = [0], [], [], [], []
+    for k in keys:
+        for (dk, ww, i, o) in arcs_of[k]:
+            to.append(idx[dk]); w.append(ww); il.append(i); ol.append(o)
+        row_ptr.append(len(to))
+    fin = np.asarray([fin_of[k] for k in keys], np.float32)
+    return dict(n_states=len(keys), init=idx[init_key], row_ptr=np.asarray(row_ptr, np.int32), to=np.asarray(to, np.int32),
+                w=np.asarray(w, np.float32), ilab=np.asarray(il, np.int32), olab=np.asarray(ol, np.int32), fin_w=fin)
+
+
+def compose_filtered(cl, cl_init, g, g_init):
+    G = _sorted_g(g)
+    lo, hi = _lookahead(cl)
+    glabels = [[a[0] for a in row] for row in G]
+
+    def any_in(gs, l, h):
+        return l <= h and any(l <= x <= h for x in glabels[gs])
+
+    start = (cl_init, g_init, 1)
+    states, arcs_of, fin_of = {start}, {}, {}
+    queue = [start]
+    while queue:
+        c, gs, f = k = queue.pop()
+        out = []
+        if f and G[gs] and G[gs][0][0] == 0:
+            _, o, t, ww = G[gs][0]
+            out.append(((c, t, 1), ww, 0, o))
+        for a in range(int(cl["row_ptr"][c]), int(cl["row_ptr"][c + 1])):
+            x, t, ww, i = int(cl["olab"][a]), int(cl["to"][a]), np.float32(cl["w"][a]), int(cl["ilab"][a])
+            if x == 0:
+                if any_in(gs, lo[t], hi[t]):
+                    out.append(((t, gs, 0), ww, i, 0))
+            else:
+                for (l, o, t2, wg) in G[gs]:
+                    if l == x:
+                        out.append(((t, t2, 1), np.float32(ww + wg), i, o))
+        arcs_of[k] = out
+        fc, fg = np.float32(cl["fin_w"][c]), np.float32(g["fin_w"][gs])
+        fin_of[k] = np.float32(fc + fg) if np.isfinite(fc) and np.isfinite(fg) else INF
+        for (dk, _, _, _) in out:
+            if dk not in states:
+                states.add(dk)
+                queue.append(dk)
+    return _finish(states, arcs_of, fin_of, start, lambda k: (k[0], k[2], k[1]))
+
+
+def compose_naive(cl, cl_init, g, g_init):
+    G = _sorted_g(g)
+    start = (cl_init, g_init)
+    states, arcs_of, fin_of = {start}, {}, {}
+    queue = [start]
+    while queue:
+        c, gs = k = queue.pop()
+        out = []
+        for (l, o, t, ww) in G[gs]:
+            if l == 0:
+                out.append(((c, t), ww, 0, o))
+        for a in range(int(cl["row_ptr"][c]), int(cl["row_ptr"][c + 1])):
+            x, t, ww, i = int(cl["olab"][a]), int(cl["to"][a]), np.float32(cl["w"][a]), int(cl["ilab"][a])
+            if x == 0:
+                out.append(((t, gs), ww, i, 0))
+            else:
+                for (l, o, t2, wg) in G[gs]:
+                    if l == x:
+                        out.append(((t, t2), np.float32(ww + wg), i, o))
+        arcs_of[k] = out
+        fc, fg = np.float32(cl["fin_w"][c]), np.float32(g["fin_w"][gs])
+        fin_of[k] = np.float32(fc + fg) if np.isfinite(fc) and np.isfinite(fg) else INF
+        for (dk, _, _, _) in out:
+            if dk not in states:
+                states.add(dk)
+                queue.append(dk)
+    return _finish(states, arcs_of, fin_of, start, lambda k: k)

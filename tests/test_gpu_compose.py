@@ -1,0 +1,85 @@
+"""Dynamic-composition row (BASELINE.json configs[4]), first step: C.L o G on
+the device (jd_net_compose) feeding the static search.
+
+NO ORACLE IS POSSIBLE for this row: the reference's WFSTOnTheFlyDecoder is not compiled by either of
+its build systems and has bit-rotted.  The device composition is
+validated against offline composition instead (tests/compose_ref.py): the same definition written a
+second time in Python (identical arrays), and textbook epsilon composition decoded by the CPU oracle
+through the static path (same words, times, scores)."""
+import numpy as np
+import pytest
+
+from compose_ref import compose_filtered, compose_naive
+from helpers import rel_close
+
+pytestmark = pytest.mark.gpu
+
+CASES = [dict(seed=5, n_words=40, n_succ=4, n_tri=30, with_sp=True, lm=1.0),
+         dict(seed=6, n_words=60, n_succ=6, n_tri=0, with_sp=False, lm=7.5),
+         dict(seed=8, n_words=25, n_succ=3, n_tri=40, with_sp=True, lm=3.0)]
+
+
+def _case(c):
+    from juicer_amd import capi, synth
+    am = synth.make_models(c["seed"], n_gmm=100, n_hmm=45, n_mix=2, n_tm=8, sep=0.6, with_tee=c["with_sp"])
+    cl, g = synth.make_cl_g(c["seed"], am, n_words=c["n_words"], n_succ=c["n_succ"], n_tri=c["n_tri"], with_sp=c["with_sp"])
+    ncl = capi.Network.from_synth(cl, 1.0, 0.0)          # juicer.cpp:933-940: the C.L network carries scale 1.0
+    ng = capi.Network.from_synth(g, c["lm"], 0.0)        # juicer.cpp:961-970: G carries lmScaleFactor
+    return am, cl, g, ncl, ng
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: "seed%d" % c["seed"])
+def test_device_composition_matches_offline_composition(built, c):
+    from juicer_amd import capi
+    am, cl, g, ncl, ng = _case(c)
+    dev = capi.Network.compose(ncl, ng)
+    want = compose_filtered(ncl.csr(), ncl.init_state, ng.csr(), ng.init_state)
+    got = dev.csr()
+    assert dev.n_states == want["n_states"] and dev.init_state == want["init"]
+    for k in ("row_ptr", "to", "ilab", "olab"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["w"].view(np.uint32), want["w"].view(np.uint32))
+    assert np.array_equal(got["fin_w"].view(np.uint32), want["fin_w"].view(np.uint32))
+    # the look-ahead did something: far fewer states than all (C.L state, G state) pairs reachable without it
+    naive = compose_naive(ncl.csr(), ncl.init_state, ng.csr(), ng.init_state)
+    assert dev.n_states < naive["n_states"]
+    # twice the same answer (the numbering does not depend on discovery order)
+    again = capi.Network.compose(ncl, ng).csr()
+    assert all(np.array_equal(again[k], got[k]) for k in got)
+
+
+@pytest.mark.parametrize("c", CASES[:2], ids=lambda c: "seed%d" % c["seed"])
+def test_decoding_the_device_composed_graph(built, c):
+    """Static path on the device-composed graph == CPU oracle on the textbook composition."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, cl, g, ncl, ng = _case(c)
+    dev = capi.Network.compose(ncl, ng)
+    nv = compose_naive(ncl.csr(), ncl.init_state, ng.csr(), ng.init_state)
+    fs = np.nonzero(np.isfinite(nv["fin_w"]))[0].astype(np.int32)
+    onet = OracleNet.from_csr(nv["n_states"], nv["init"], nv["row_ptr"], nv["to"], nv["w"], nv["ilab"], nv["olab"], fs, nv["fin_w"][fs])
+    feats = [synth.sample_utterance(c["seed"] + 1000 + u, g, am, 6 + u)[0] for u in range(3)]
+    kw = dict(main_beam=200.0)
+    gs = capi.Decoder(dev, capi.Models.from_htk(am), max_streams=len(feats), **kw).decode_batch(feats)
+    od = OracleDecoder(onet, OracleAM(am), **kw)
+    for u, x in enumerate(feats):
+        o = od.decode(x)
+        assert gs[u].n == o.n and o.n > 0
+        assert np.array_equal(gs[u].label, o.label) and np.array_equal(gs[u].time, o.time)
+        assert rel_close(gs[u].score, o.score) and rel_close(gs[u].ac, o.ac) and rel_close(gs[u].lm, o.lm)
+
+
+def test_compose_errors(built):
+    from juicer_amd import capi, synth
+    am, cl, g, ncl, ng = _case(CASES[0])
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        capi.Network.compose(ncl, ng, max_states=64)
+    assert ei.value.code == capi.JD_ENOMEM and "states" in str(ei.value)
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        capi.Network.compose(ncl, ng, max_arcs=64)
+    assert ei.value.code == capi.JD_ENOMEM and "arcs" in str(ei.value)
+    # a G state with two arcs for one word is refused (WFSTSortedInLabelNetwork::binarySearchInLabel)
+    g2 = synth.make_cl_g(5, am, n_words=40, n_succ=4, n_tri=0)[1]
+    g2.ilab = g2.ilab.copy(); g2.ilab[1] = g2.ilab[2]
+    with pytest.raises(capi.JuicerAmdError):
+        capi.Network.compose(ncl, capi.Network.from_synth(g2))
