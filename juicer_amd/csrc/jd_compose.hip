@@ -286,7 +286,7 @@ extern "C" int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, i
     if (rc) return rc;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
-        return jd_fail(JD_EHIP, "jd_net_compose: no HIP device %d (the composition runs on the GPU; there is no CPU path)", device);
+        return jd_fail(JD_ENODEV, "jd_net_compose: no HIP device %d (the composition runs on the GPU; there is no CPU path)", device);
     if (hipSetDevice(device) != hipSuccess) return jd_fail(JD_EHIP, "hipSetDevice(%d) failed", device);
     if (max_states <= 0) max_states = std::min<int64_t>(0x7ffffff0LL, std::max<int64_t>(1 << 20, 4 * ((int64_t)cl->n_states + g->n_states) + (int64_t)g->n_arcs * 8));
     if (max_arcs <= 0) max_arcs = std::min<int64_t>(0x7ffffff0LL, std::max<int64_t>(1 << 22, ((int64_t)cl->n_arcs + g->n_arcs) * 16));

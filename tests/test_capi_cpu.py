@@ -111,6 +111,10 @@ def test_no_cpu_fallback(built):
     with pytest.raises(capi.JuicerAmdError) as ei:
         m.score_frames(feats[0][:4])
     assert ei.value.code == capi.JD_ENODEV
+    cl, gr = synth.make_cl_g(1, am, n_words=5, n_succ=2)
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        capi.Network.compose(capi.Network.from_synth(cl), capi.Network.from_synth(gr))
+    assert ei.value.code == capi.JD_ENODEV
 
 
 def test_product_does_not_reference_oracle():
