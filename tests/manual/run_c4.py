@@ -58,8 +58,7 @@ def main():
            "gen_seconds": round(t_gen, 1), "frames": frames,
            "gpu_seconds_per_pass_host_inclusive": round(best, 3), "frames_per_sec": round(frames / best, 1),
            "search_ms": round(tm["search_ms"], 2), "gmm_ms": round(tm["gmm_ms"], 2),
-           "kernels_avg_us": {n: round(x / max(1, tm["kernel_samples"]), 1)
-                              for n, x in zip(capi.kernel_names(tm), tm["kernel_us"]) if n and n != "k_boundary"},
+           "search_launches": int(tm["search_launches"]), "relaunches": int(tm["relaunches"]),
            "per_frame": {k: round(st[k] / frames, 1) for k in ("tot_insts_in", "tot_proc_emit_hyps", "tot_proc_end_hyps",
                                                                "tot_arcs_visited", "tot_paths")},
            "n_hyp_words": [int(h.n) for h in hyps],
