@@ -847,7 +847,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     TRY(upload_am_gmm(am, d->amb));
     C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init;
     C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
-    C.hmm_tee = d->d_hmm_tee; C.hmm_tmax0 = d->d_hmm_tmax0;
+    C.hmm_tee = d->d_hmm_tee; C.n_hmm = am->n_hmm; C.hmm_tmax0 = d->d_hmm_tmax0;
     {   // per-arc instance template: what phase A needs to attach an instance (attachNetInst :751-774),
         // one hop from the arc id: {nStates | transMat << 8, g0, g1, g2} (+ {g3, g4, g5, 0})
         const int AI = (am->max_n <= 5) ? 4 : 8;

@@ -39,6 +39,7 @@
 #define MAXCW (MAXW / SW)
 #define TEE_FLAG 0x40000000          // bit 30 of the device arc's in-label: the arc's HMM is a tee model
 #define TRP_LDS_MAX 4096             // floats of transition tables cached in LDS (else read from HBM)
+#define TEE_LDS_MAX 2048             // HMMs whose tee log-probability is cached in LDS
 
 enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_INSTS, ST_N };
 enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_BARRIER = -50 };
@@ -49,7 +50,7 @@ struct DecConst {
     const int *aux;     // per arc: {nStates | transMat << 8, g0, g1, g2} (+ {g3, g4, g5, 0} for > 5 states)
     // models
     int G, max_n, n_tm;
-    const float *hmm_tee;
+    const float *hmm_tee; int n_hmm;
     const float *hmm_tmax0;   // per HMM: largest log transition probability out of the entry state
     const float *trP; const int *se32;
     const float *lrt;   // left-to-right topologies only (else null): per transMat a_1.., s_1.. (see phase A)
@@ -191,6 +192,7 @@ struct SearchShared {
     int hist[HIST_MAX_BINS];                   // this workgroup's share of the frame's histogram
     int hprev[HIST_MAX_BINS];                  // the stream's bins of the previous frame
     float trP[TRP_LDS_MAX]; int se[TRP_LDS_MAX / 4];   // transition tables (when they fit)
+    float tee[TEE_LDS_MAX];                    // tee transition log-probability per HMM (when they fit)
     int wpfx[SW][64];                          // phase X: per wave, prefix of the out-degrees of its 64 items
     v4i qtok[SW][QCAP], qinfo[SW][QCAP];       // phase X: per wave, closure items it will expand itself
     int wsum[NLISTS][SW], wsum2[NLISTS][SW];
@@ -201,6 +203,9 @@ struct SearchShared {
     int stat[ST_N];                            // this workgroup's counters of the current frame
     long long acc[ST_N];                       // ... summed over the frames of the launch
     long long clk[8];
+#ifdef JD_FINE
+    long long fclk[7];                         // development build: hop timing inside the phases (FINE)
+#endif
 };
 
 // Turn the published per-wave fill counts of up to NLISTS lists into chunk prefixes (LDS).  The
@@ -378,6 +383,32 @@ __device__ __forceinline__ unsigned rec_chunk_off(unsigned seg_rec, int w, int c
 // LR: every transition matrix of the model set is plain left-to-right (state j is entered from j-1 and
 // itself, the exit state from the last emitting state; no skips): the predecessor loops become one
 // comparison per state, on a compact table a_k = log P(k-1 -> k), s_k = log P(k -> k) in LDS.
+#ifdef JD_FINE
+// development build (-DJD_FINE=1: phase A, =2: phase X): drains the memory counters and charges the time
+// since the last mark to slot k; thread 0 of every workgroup only.  Serialises the hops it measures -
+// not for benchmarks.
+#define FINE_START_() long long ft_ = 0; do { if (threadIdx.x == 0) ft_ = wall_clock64(); } while (0)
+#define FINE_(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                      if (threadIdx.x == 0) { const long long tn_ = wall_clock64(); sh.fclk[k] += tn_ - ft_; ft_ = tn_; } } while (0)
+#define FINE_COUNT_(k) do { if (threadIdx.x == 0) sh.fclk[k] += 1; } while (0)
+#endif
+#if defined(JD_FINE) && JD_FINE == 1
+#define FINE_START() FINE_START_()
+#define FINE(k) FINE_(k)
+#else
+#define FINE_START() do { } while (0)
+#define FINE(k) do { } while (0)
+#endif
+#if defined(JD_FINE) && JD_FINE == 2
+#define XFINE_START() FINE_START_()
+#define XFINE(k) FINE_(k)
+#define XFINE_COUNT(k) FINE_COUNT_(k)
+#else
+#define XFINE_START() do { } while (0)
+#define XFINE(k) do { } while (0)
+#define XFINE_COUNT(k) do { } while (0)
+#endif
+
 template <int NE, bool TRPL, bool LR>
 __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
                                         const Geo &gin, const Geo &gout, const int (&Q)[4], int jw, int Cw, int gw, int p,
@@ -416,6 +447,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             }
             continue;
         }
+        FINE_START();
         const bool is_new = u >= Q[0];
         const int ru = is_new ? u - Q[0] : u;
         const int *pfx = sh.pfx[is_new ? 1 : 0];
@@ -442,6 +474,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
 #pragma unroll
             for (int j = 1; j <= NE; ++j) tk[j] = null_tok();
         }
+        FINE(0);                                                       // hop 1: the record
         const int arc = h0.x;
         const int n = h0.y & 0xff;                                     // 0 for lanes without an instance
         const int tm = h0.y >> 8;
@@ -454,6 +487,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             const int gj = (j == 0) ? h1.x : (j == 1) ? h1.y : (j == 2) ? h1.z : (j == 3) ? h2.x : (j == 4) ? h2.y : h2.z;
             outp[j] = llrow[(j + 1 < n - 1) ? gj : 0];                 // :411
         }
+        FINE(1);                                                       // hop 2: key + likelihoods
         // entry token = the best candidate phase X of the previous frame left in the arc's key (:560-582)
         tk[0] = null_tok();
         if (kv != 0ULL) {
@@ -463,6 +497,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             tk[0].ac = it.ac; tk[0].lm = it.lm + __int_as_float(h1.w); tk[0].path = it.path;
             if (tk[0].score < startTh) tk[0] = null_tok();            // :915-918 (a candidate is never LOG_ZERO)
         }
+        FINE(2);                                                       // hop 3: the winning item
         Tok nw[NE + 1];
         int live_mask = 0;
         Tok ex = null_tok();
@@ -550,6 +585,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 if (!(have & (n >= 2)) || !(ex.score > LZ)) ex = null_tok();
             }
         }
+        FINE(3);                                                       // arithmetic
         c_emit += __popc(live_mask);
         const bool has_exit = ex.score > LZ;
         const bool slot_live = live_mask != 0;
@@ -589,6 +625,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 c_end += nex;
             }
         }
+        FINE(4);                                                       // stores + atomics acknowledged
     }
     // per-wave totals -> workgroup counters (LDS)
     mo = wave_umax(mo);
@@ -638,6 +675,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
     const float INF = __builtin_inff();
     const unsigned icur = p ? V.item_par : 0u;
     const bool can_filter = !init && C.emit_win > 0.0f && bestA > LZ;
+    const bool tee_lds = C.n_hmm <= TEE_LDS_MAX;
     const unsigned item_base = (unsigned)gw * gout.seg_item, new_base = (unsigned)gw * gout.seg_new;
     int *wpfx = sh.wpfx[wid];
     v4i *qtok = sh.qtok[wid], *qinfo = sh.qinfo[wid];
@@ -647,6 +685,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
 #pragma nounroll
     for (;;) {
         // ---- a batch of up to 64 items: the wave's own closure queue first, else the next chunk
+        XFINE_START();
+        XFINE_COUNT(5);
         bool valid, exit_kind;
         unsigned ii;
         Tok t;
@@ -671,6 +711,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             exit_kind = round == 0;
             if (!exit_kind && info.w != 0) valid = false;              // expanded by its producer / superseded
         }
+        XFINE(0);                                                      // hop 1: the items
         const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
         const bool real = valid && info.x >= 0;                        // an item that traversed an arc
         const int state = !valid ? 0 : (info.x >= 0) ? info.z : C.init_state;
@@ -694,6 +735,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             if (lane == first) pbase = atomicAdd(&c.n_paths, __popcll(blab));
             pbase = __shfl(pbase, first);
         }
+        XFINE(1);                                                      // hop 2: row bounds, state key, Path reservation
         if (real) {
             const bool winner = (unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL;
             // every state that received exit-token bids is cleaned up by its winner, expanded or not (an
@@ -724,6 +766,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 }
             }
         }
+        XFINE(2);                                                      // winners: key reset, Path record, final state
         // ---- pooled arc walk: exclusive prefix of the items' out-degrees
         const int deg = have ? rs1 - rs : 0;
         int incl = deg;
@@ -740,8 +783,10 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         int b_nx = __shfl(rs, g_nx) + (lane - wpfx[g_nx]);
         JdArc Bk_nx = {0, 0.0f, 0, 0};
         if (lane < tot) Bk_nx = C.arcs[b_nx];
+        XFINE(3);                                                      // prefix + hop 3: the first 64 arcs
 #pragma nounroll
         for (int a0 = 0; a0 < tot; a0 += 64) {
+            XFINE_COUNT(6);
             const int a = a0 + lane;
             const int g = g_nx, b = b_nx;
             const JdArc Bk = Bk_nx;
@@ -757,42 +802,54 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             bool mk = false, touch = false, clean = false;
             Tok un = null_tok();
             int tb = -1;
-            if (a < tot) {
-                ++c_arcs;
-                const int inl = Bk.in & ~TEE_FLAG;
-                if (inl == 0) {                                        // :533-540 epsilon input
-                    un = tg;
-                    un.score = tg.score + Bk.w;
-                    un.lm = tg.lm + Bk.w;
-                    mk = un.score > endTh;
-                } else {                                               // :560-582 entry-token recombination
-                    const float ns = tg.score + Bk.w;
-                    const unsigned so = f2o(ns);
-                    ArcState *as = V.ast + b;
-                    const int lv = CL(&as->live);                      // in flight together with the atomic
-                    const unsigned long long old = atomicMax(&as->key, ((unsigned long long)so << 32) | iig);
-                    tb = b;
-                    mo = so > mo ? so : mo;                            // :572-573
-                    if (lv != 1) {                                     // no instance: attachNetInst :751-774
-                        if (old == 0ULL) ++c_new;
-                        if (can_filter) {
-                            const float tmax = C.hmm_tmax0[inl - 1];
-                            const bool mine = (ns + tmax) - bestA > -C.emit_win;
-                            const bool before = old != 0ULL && (o2f((unsigned)(old >> 32)) + tmax) - bestA > -C.emit_win;
-                            touch = mine && !before;                   // the first candidate that may survive
-                            clean = old == 0ULL && !mine;
-                        } else touch = old == 0ULL;
-                        if (touch) CS(&as->live, 2);
-                    }
-                    if (Bk.in & TEE_FLAG) {                            // :584-600 tee model
-                        const float tee = C.hmm_tee[inl - 1];
-                        const float ns2 = ns + tee;
-                        un.score = ns2;
-                        un.ac = tg.ac + tee;
-                        un.lm = tg.lm + Bk.w;
-                        un.path = tg.path;
-                        mk = ns2 > ((Bk.out != 0) ? wordTh : endTh);
-                    }
+            // Everything a pass READS is requested before anything is waited for - one memory round trip:
+            // the arc's recombination key (atomic max) with its instance flag and the model's constant, and
+            // the closure key of the destination state of every arc that can produce a closure item (as a
+            // pre-filter: hot history states receive many arrivals, and an atomic on a contended key costs
+            // far more than this load - measured: without it a pass takes 2.4 us instead of 2.1).
+            const bool on = a < tot;
+            const int inl = Bk.in & ~TEE_FLAG;
+            const bool entry = on && inl != 0;
+            const bool is_tee = entry && (Bk.in & TEE_FLAG) != 0;
+            const float ns = tg.score + Bk.w;                          // (:535 / :562: the same sum either way)
+            const unsigned so = f2o(ns);
+            ArcState *as = V.ast + b;
+            int lv = 0;
+            unsigned long long old = 0ULL, skc = 0ULL;
+            float tmax = 0.0f;
+            if (entry) {
+                lv = CL(&as->live);
+                old = atomicMax(&as->key, ((unsigned long long)so << 32) | iig);
+                if (can_filter) tmax = C.hmm_tmax0[inl - 1];
+            }
+            if ((on && inl == 0) || is_tee) skc = CL(V.skeyC + Bk.to);
+            if (on) ++c_arcs;
+            if (on && inl == 0) {                                      // :533-540 epsilon input
+                un = tg;
+                un.score = ns;
+                un.lm = tg.lm + Bk.w;
+                mk = un.score > endTh;
+            } else if (is_tee) {                                       // :584-600 tee model
+                const float tee = tee_lds ? sh.tee[inl - 1] : C.hmm_tee[inl - 1];
+                const float ns2 = ns + tee;
+                un.score = ns2;
+                un.ac = tg.ac + tee;
+                un.lm = tg.lm + Bk.w;
+                un.path = tg.path;
+                mk = ns2 > ((Bk.out != 0) ? wordTh : endTh);
+            }
+            if (entry) {                                               // :560-582 entry-token recombination
+                tb = b;
+                mo = so > mo ? so : mo;                                // :572-573
+                if (lv != 1) {                                         // no instance: attachNetInst :751-774
+                    if (old == 0ULL) ++c_new;
+                    if (can_filter) {
+                        const bool mine = (ns + tmax) - bestA > -C.emit_win;
+                        const bool before = old != 0ULL && (o2f((unsigned)(old >> 32)) + tmax) - bestA > -C.emit_win;
+                        touch = mine && !before;                       // the first candidate that may survive
+                        clean = old == 0ULL && !mine;
+                    } else touch = old == 0ULL;
+                    if (touch) CS(&as->live, 2);
                 }
             }
             // newly entered arcs -> this wave's segments of the new / clean-up lists
@@ -810,9 +867,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             // closure items: the best arrival at its state so far is kept (running maximum), written to
             // this wave's item segment and - if the wave's queue has room - expanded by this wave itself
             if (__ballot(mk)) {
-                const unsigned so = f2o(un.score);
-                bool pass = false;                                     // cheap pre-filter before an index is spent
-                if (mk) pass = so > (unsigned)(CL(V.skeyC + Bk.to) >> 32);
+                const unsigned sou = f2o(un.score);
+                const bool pass = mk && sou > (unsigned)(skc >> 32);   // cheap pre-filter before an index is spent
                 const unsigned long long bp = __ballot(pass);
                 const int np = __popcll(bp);
                 if (out.item_cnt + np > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); }
@@ -820,24 +876,24 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                     const unsigned k = item_base + (unsigned)(out.item_cnt + rank_in(bp));
                     bool keep = false, first = false;
                     if (pass) {
-                        const unsigned long long key = ((unsigned long long)so << 32) | k;
-                        const unsigned long long old = atomicMax(V.skeyC + Bk.to, key);
-                        keep = key > old; first = old == 0ULL;
+                        const unsigned long long key = ((unsigned long long)sou << 32) | k;
+                        const unsigned long long cold = atomicMax(V.skeyC + Bk.to, key);
+                        keep = key > cold; first = cold == 0ULL;
                     }
                     const unsigned long long bk = __ballot(keep), bf = __ballot(first);
                     const int room = QCAP - q_n;
-                    const bool inl = keep && rank_in(bk) < room;       // expanded by this wave, right after this batch
+                    const bool inq = keep && rank_in(bk) < room;       // expanded by this wave, right after this batch
                     if (pass) {
                         st16(V.items, icur + k * 32u, as_v4(un));
-                        st16(V.items, icur + k * 32u + 16u, (v4i){b, Bk.out, Bk.to, (keep && !inl) ? 0 : 1});
+                        st16(V.items, icur + k * 32u + 16u, (v4i){b, Bk.out, Bk.to, (keep && !inq) ? 0 : 1});
                     }
-                    if (inl) {
+                    if (inq) {
                         const int qi = q_n + rank_in(bk);
                         qtok[qi] = as_v4(un); qinfo[qi] = (v4i){b, Bk.out, Bk.to, (int)k};
                     }
                     const int nk = __popcll(bk);
-                    const int n_inl = nk < room ? nk : room;
-                    q_n += n_inl; deferred += nk - n_inl;
+                    const int n_inq = nk < room ? nk : room;
+                    q_n += n_inq; deferred += nk - n_inq;
                     out.item_cnt += np;
                     if (bf) {                                          // closure keys used this frame: zeroed by the next phase A
                         const int nf = __popcll(bf);
@@ -850,6 +906,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 }
             }
         }
+        XFINE(4);                                                      // the arc passes of this batch
     }
     mo = wave_umax(mo);
     c_arcs = wave_sum(c_arcs); c_paths = wave_sum(c_paths); c_pend = wave_sum(c_pend); c_new = wave_sum(c_new);
@@ -897,6 +954,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     const bool trp_lds = !lr && (size_t)C.n_tm * MN * MN <= TRP_LDS_MAX && (size_t)C.n_tm * MN <= TRP_LDS_MAX / 4;
     __syncthreads();                                                   // the previous stream of this slot is done with LDS
     if (lr) for (int i = tid; i < C.n_tm * ((NE == 3) ? 8 : 16); i += SNT) sh.trP[i] = C.lrt[i];
+    if (C.n_hmm <= TEE_LDS_MAX) for (int i = tid; i < C.n_hmm; i += SNT) sh.tee[i] = C.hmm_tee[i];
     if (trp_lds) {
         for (int i = tid; i < C.n_tm * MN * MN; i += SNT) sh.trP[i] = C.trP[i];
         for (int i = tid; i < C.n_tm * MN; i += SNT) sh.se[i] = C.se32[i];
@@ -905,6 +963,9 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         sh.abort = 0; sh.best = 0u; sh.new_all = 0; sh.next = 0;
         for (int k = 0; k < ST_N; ++k) { sh.stat[k] = 0; sh.acc[k] = 0; }
         for (int k = 0; k < 8; ++k) sh.clk[k] = 0;
+#ifdef JD_FINE
+        for (int k = 0; k < 7; ++k) sh.fclk[k] = 0;
+#endif
     }
     if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) sh.hist[b] = 0;
     __syncthreads();
@@ -1117,6 +1178,9 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             long long *d = A.dbg + (size_t)blockIdx.x * 16;
             for (int k = 0; k < 8; ++k) d[k] += sh.clk[k];
             d[8] += frames_done;
+#ifdef JD_FINE
+            for (int k = 0; k < 7; ++k) d[9 + k] += sh.fclk[k];
+#endif
         }
         if (jw == 0) {
             const int e0 = CL(&c.err[0]), e1 = CL(&c.err[1]);

@@ -39,5 +39,14 @@ for k, n in enumerate(names):
     print("%-11s mean %7.2f us/frame   min %7.2f   max %7.2f" % (n, us.mean(), us.min(), us.max()))
 print("sum %.2f us/frame;  search_ms %.2f for %d frames, %d launches, last cluster size %d"
       % (tot, tm["search_ms"], tm["search_frames"], tm["search_launches"], tm["cluster_wgs"]))
+if used[:, 9:16].any():                                               # a -DJD_FINE build: hops inside a phase
+    if used[:, 14].any():                                             # JD_FINE=2: phase X (slots 5, 6 are counts)
+        names = ["X items", "X rows + key + Path", "X winners", "X prefix + first arcs", "X arc passes"]
+        print("  batches per frame %.2f, arc passes per frame %.2f (thread 0's wave)" % ((used[:, 14] / fr).mean(), (used[:, 15] / fr).mean()))
+    else:
+        names = ["A record loads", "A key + likelihoods", "A winning item", "A arithmetic", "A stores acked"]
+    for k, n in enumerate(names):
+        us = used[:, 9 + k] / 100.0 / fr
+        print("  %-22s mean %7.2f us/frame (thread 0's wave, memory counters drained after every hop)" % (n, us.mean()))
 st = {k: sum(x.stats[k] for x in h) for k in h[0].stats}
 print({k: round(v / tm["search_frames"], 1) for k, v in st.items() if k.startswith("tot")})
