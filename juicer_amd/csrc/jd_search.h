@@ -428,76 +428,86 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     const int Q01 = Q[0] + Q[1], Q012 = Q01 + Q[2], Qall = Q012 + Q[3];
     int c_insts = 0, c_pemit = 0, c_emit = 0, c_end = 0, c_surv = 0;
     unsigned mo = 0u;
-#pragma nounroll
-    for (;;) {
-        const int u = grab_chunk(sh, jw, Cw);
-        if (u >= Qall) break;
-        if (u >= Q01) {
-            // key clean-up.  (2) arcs whose first candidate of the previous frame was hopeless and that
-            // did not make it onto the new list afterwards keep a stale key - nobody else consumes it;
-            // (3) closure keys are running maxima that nobody resets during their frame
-            const int k = (u >= Q012) ? 3 : 2;
-            const int ru = u - (k == 3 ? Q012 : Q01);
-            const int w = find_seg(sh.pfx[k], gin.nw, ru);
-            const int ci = ru - RFL(sh.pfx[k][w]);
-            if (ci * 64 + lane < RFL(sh.cnt[k][w])) {
-                const int b = CL((k == 3 ? V.dirtyl : V.cleanl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
-                if (k == 3) CS(V.skeyC + b, 0ULL);
-                else if (CL(&V.ast[b].live) != 2) CS(&V.ast[b].key, 0ULL);
-            }
-            continue;
-        }
-        FINE_START();
-        const bool is_new = u >= Q[0];
+    // The pass loop is software-pipelined two deep.  A pass is a chain of dependent memory round trips
+    // (record -> arc key + likelihoods -> winning item) followed by arithmetic and stores, and with
+    // two waves per SIMD nothing else hides them; the memory counter is in-order, so a wait for a
+    // load also waits for every store issued before it.  Hence: the NEXT chunk's record is requested
+    // while this chunk's item is in flight (stage R), and its key + likelihoods right BEFORE this
+    // chunk's stores (stage K) - by the time they are needed they are there, and no wait has a store
+    // in front of it.  Chunks come in increasing order per workgroup (records, then new arcs, then
+    // the two clean-up lists), so the clean-up chunks form a plain loop of their own at the end.
+    auto stage_r = [&](int u, bool &is_new, bool &valid, int &nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1])
+        __attribute__((always_inline)) {
+        is_new = u >= Q[0];
         const int ru = is_new ? u - Q[0] : u;
         const int *pfx = sh.pfx[is_new ? 1 : 0];
         const int *cnt = sh.cnt[is_new ? 1 : 0];
         const int w = find_seg(pfx, gin.nw, ru);
         const int ci = ru - RFL(pfx[w]);
-        const bool valid = ci * 64 + lane < RFL(cnt[w]);
-        v4i h0, h1, h2 = {0, 0, 0, 0};
-        Tok tk[NE + 1];
+        valid = ci * 64 + lane < RFL(cnt[w]);
+        nb = 0;
         if (!is_new) {
             const unsigned off = valid ? rcur + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u : OOB_OFF;
             h0 = ld16(V.rec, off); h1 = ld16(V.rec, off + 1024u);
             if (NE == 6) h2 = ld16(V.rec, off + 2048u);
 #pragma unroll
             for (int j = 1; j <= NE; ++j) tk[j] = as_tok(ld16(V.rec, off + (unsigned)(HF + j - 1) * 1024u));
-        } else {                                                       // attachNetInst :751-774, from the arc's template
-            int b = 0;
-            if (valid) b = CL(V.newl + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
-            const JdArc Bk = C.arcs[b];
-            const int4 a0 = ((const int4 *)C.aux)[(NE == 3) ? b : 2 * b];
-            h0 = (v4i){b, valid ? a0.x : 0, Bk.out, Bk.to};
+        } else if (valid) nb = CL(V.newl + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
+    };
+    auto stage_k = [&](bool is_new, bool valid, int nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1],
+                       unsigned long long &kv, float (&outp)[NE]) __attribute__((always_inline)) {
+        if (is_new) {                                                  // attachNetInst :751-774, from the arc's template
+            const JdArc Bk = C.arcs[nb];
+            const int4 a0 = ((const int4 *)C.aux)[(NE == 3) ? nb : 2 * nb];
+            h0 = (v4i){nb, valid ? a0.x : 0, Bk.out, Bk.to};
             h1 = (v4i){a0.y, a0.z, a0.w, __float_as_int(Bk.w)};
-            if (NE == 6) { const int4 a1 = ((const int4 *)C.aux)[2 * b + 1]; h2 = (v4i){a1.x, a1.y, a1.z, 0}; }
+            if (NE == 6) { const int4 a1 = ((const int4 *)C.aux)[2 * nb + 1]; h2 = (v4i){a1.x, a1.y, a1.z, 0}; }
 #pragma unroll
             for (int j = 1; j <= NE; ++j) tk[j] = null_tok();
         }
-        FINE(0);                                                       // hop 1: the record
-        const int arc = h0.x;
-        const int n = h0.y & 0xff;                                     // 0 for lanes without an instance
-        const int tm = h0.y >> 8;
-        // second level of loads, all in flight together: the arc's key, the likelihoods
-        unsigned long long kv = 0ULL;
-        if (valid) kv = CL(&V.ast[arc].key);
-        float outp[NE];
+        const int n = h0.y & 0xff;
+        kv = 0ULL;
+        if (valid) kv = CL(&V.ast[h0.x].key);                          // the arc's key and the likelihoods: in flight together
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int gj = (j == 0) ? h1.x : (j == 1) ? h1.y : (j == 2) ? h1.z : (j == 3) ? h2.x : (j == 4) ? h2.y : h2.z;
             outp[j] = llrow[(j + 1 < n - 1) ? gj : 0];                 // :411
         }
-        FINE(1);                                                       // hop 2: key + likelihoods
+    };
+    int u = grab_chunk(sh, jw, Cw);
+    bool is_new = false, valid = false;
+    int nb = 0;
+    v4i h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, h2 = {0, 0, 0, 0};
+    Tok tk[NE + 1];
+    unsigned long long kv = 0ULL;
+    float outp[NE];
+    if (u < Q01) { stage_r(u, is_new, valid, nb, h0, h1, h2, tk); stage_k(is_new, valid, nb, h0, h1, h2, tk, kv, outp); }
+#pragma nounroll
+    while (u < Q01) {
+        FINE_START();
+        const int un = grab_chunk(sh, jw, Cw);
+        FINE(0);                                                       // (development build) the wait for stage K
+        const int arc = h0.x;
+        const int n = h0.y & 0xff;                                     // 0 for lanes without an instance
+        const int tm = h0.y >> 8;
         // entry token = the best candidate phase X of the previous frame left in the arc's key (:560-582)
+        v4i itv = {0, 0, 0, 0};
+        if (kv != 0ULL) itv = ld16(V.items, iprev + (unsigned)(kv & 0xffffffffULL) * 32u);
+        // stage R of the next chunk (issued after the item load: the wait for the item leaves it in flight)
+        bool n_is_new = false, n_valid = false;
+        int n_nb = 0;
+        v4i nh0 = {0, 0, 0, 0}, nh1 = {0, 0, 0, 0}, nh2 = {0, 0, 0, 0};
+        Tok ntk[NE + 1];
+        if (un < Q01) stage_r(un, n_is_new, n_valid, n_nb, nh0, nh1, nh2, ntk);
+        if (kv != 0ULL) CS(&V.ast[arc].key, 0ULL);
+        FINE(1);                                                       // the winning item (+ the next record)
         tk[0] = null_tok();
         if (kv != 0ULL) {
-            CS(&V.ast[arc].key, 0ULL);
-            const Tok it = as_tok(ld16(V.items, iprev + (unsigned)(kv & 0xffffffffULL) * 32u));
+            const Tok it = as_tok(itv);
             tk[0].score = o2f((unsigned)(kv >> 32));
             tk[0].ac = it.ac; tk[0].lm = it.lm + __int_as_float(h1.w); tk[0].path = it.path;
             if (tk[0].score < startTh) tk[0] = null_tok();            // :915-918 (a candidate is never LOG_ZERO)
         }
-        FINE(2);                                                       // hop 3: the winning item
         Tok nw[NE + 1];
         int live_mask = 0;
         Tok ex = null_tok();
@@ -585,7 +595,11 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 if (!(have & (n >= 2)) || !(ex.score > LZ)) ex = null_tok();
             }
         }
-        FINE(3);                                                       // arithmetic
+        FINE(2);                                                       // arithmetic
+        // stage K of the next chunk: its record has arrived during the arithmetic
+        unsigned long long nkv = 0ULL;
+        float noutp[NE];
+        if (un < Q01) stage_k(n_is_new, n_valid, n_nb, nh0, nh1, nh2, ntk, nkv, noutp);
         c_emit += __popc(live_mask);
         const bool has_exit = ex.score > LZ;
         const bool slot_live = live_mask != 0;
@@ -625,7 +639,30 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 c_end += nex;
             }
         }
-        FINE(4);                                                       // stores + atomics acknowledged
+#if defined(JD_FINE) && JD_FINE == 1
+        if (threadIdx.x == 0) { const long long tn_ = wall_clock64(); sh.fclk[3] += tn_ - ft_; sh.fclk[4] += 1; }   // issue of stage K + stores (not drained)
+#endif
+        // the next chunk becomes the current one
+        u = un; is_new = n_is_new; valid = n_valid; nb = n_nb; h0 = nh0; h1 = nh1; h2 = nh2; kv = nkv;
+#pragma unroll
+        for (int j = 1; j <= NE; ++j) tk[j] = ntk[j];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) outp[j] = noutp[j];
+    }
+    // key clean-up.  (2) arcs whose first candidate of the previous frame was hopeless and that did not
+    // make it onto the new list afterwards keep a stale key - nobody else consumes it; (3) closure keys
+    // are running maxima that nobody resets during their frame
+#pragma nounroll
+    for (; u < Qall; u = grab_chunk(sh, jw, Cw)) {
+        const int k = (u >= Q012) ? 3 : 2;
+        const int ru = u - (k == 3 ? Q012 : Q01);
+        const int w = find_seg(sh.pfx[k], gin.nw, ru);
+        const int ci = ru - RFL(sh.pfx[k][w]);
+        if (ci * 64 + lane < RFL(sh.cnt[k][w])) {
+            const int b = CL((k == 3 ? V.dirtyl : V.cleanl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
+            if (k == 3) CS(V.skeyC + b, 0ULL);
+            else if (CL(&V.ast[b].live) != 2) CS(&V.ast[b].key, 0ULL);
+        }
     }
     // per-wave totals -> workgroup counters (LDS)
     mo = wave_umax(mo);

@@ -44,7 +44,8 @@ if used[:, 9:16].any():                                               # a -DJD_F
         names = ["X items", "X rows + key + Path", "X winners", "X prefix + first arcs", "X arc passes"]
         print("  batches per frame %.2f, arc passes per frame %.2f (thread 0's wave)" % ((used[:, 14] / fr).mean(), (used[:, 15] / fr).mean()))
     else:
-        names = ["A record loads", "A key + likelihoods", "A winning item", "A arithmetic", "A stores acked"]
+        names = ["A wait for stage K", "A item + next record", "A arithmetic", "A stage K + stores issue"]
+        print("  passes per frame %.2f (thread 0's wave)" % (used[:, 13] / fr).mean())
     for k, n in enumerate(names):
         us = used[:, 9 + k] / 100.0 / fr
         print("  %-22s mean %7.2f us/frame (thread 0's wave, memory counters drained after every hop)" % (n, us.mean()))
