@@ -964,7 +964,7 @@ static int ensure_arenas(jd_dec *d)
     if (rc) return rc;
     const int B = d->max_streams, MN = d->am->max_n;
     const int64_t rec_bytes = (MN <= 5) ? RecLayout<3>::REC_BYTES : RecLayout<6>::REC_BYTES;
-    {   // Capacities the caller did not set: sized for 288 GB of HBM, not for frugality.  Half of the
+    {   // Capacities the caller did not set: sized for 288 GB of HBM, not for frugality.  70% of the
         // free memory is split over the streams; of a stream's share (after its per-arc / per-state
         // tables) 50% goes to instance records, 20% to frontier items, 30% to Path records - each
         // between a floor that suits narrow beams and the most the graph can ever need.  Record and
@@ -973,7 +973,7 @@ static int ensure_arenas(jd_dec *d)
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const double n_arcs = (double)d->net->n_arcs, n_states = (double)d->net->n_states;
         const double fixed = n_arcs * sizeof(ArcState) + n_states * 24.0 + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
-        const double budget = std::max(0.0, 0.5 * (double)free_b / B - fixed);
+        const double budget = std::max(0.0, 0.7 * (double)free_b / B - fixed);
         const double rec_b = 2.0 * rec_bytes, item_b = 2.0 * (sizeof(Tok) + sizeof(int4)) + 32.0;
         const double path_b = 2.0 * sizeof(PathRec) + 4.0;
         auto pick = [](double share, int64_t lo, int64_t hi) {
@@ -982,7 +982,11 @@ static int ensure_arenas(jd_dec *d)
         const int64_t lim_rec = (0xe0000000LL / (2 * rec_bytes)) & ~63LL, lim_item = 0xe0000000LL / 64;
         if (d->cap_slots <= 0) d->cap_slots = pick(0.5 * budget / rec_b, 1 << 19, std::min<int64_t>(d->net->n_arcs + 65536, lim_rec));
         if (d->cap_items <= 0) d->cap_items = pick(0.2 * budget / item_b, 1 << 21, std::min<int64_t>(std::max<int64_t>(2 * d->net->n_arcs + 65536, 1 << 21), lim_item));
-        if (d->cap_paths <= 0) d->cap_paths = pick(0.3 * budget / path_b, 1 << 21, 1 << 26);
+        // (records and items stop at their addressing limits: what they leave of the budget goes to the Path
+        // records - every collection of those is a stop of the stream's launch)
+        if (d->cap_paths <= 0)
+            d->cap_paths = pick(std::max(0.3 * budget, budget - (double)d->cap_slots * rec_b - (double)d->cap_items * item_b) / path_b,
+                                1 << 21, 0x40000000LL);
         if (d->cap_slots > lim_rec || d->cap_items > lim_item || d->cap_paths > 0x7fffff00LL)
             return jd_fail(JD_EINVAL, "arena capacity too large (instance records and frontier items are addressed "
                            "with 32-bit byte offsets: at most %lld / %lld records)", (long long)lim_rec, (long long)lim_item);
@@ -994,7 +998,10 @@ static int ensure_arenas(jd_dec *d)
     }
     d->C.cap_slots = (unsigned)d->cap_slots; d->C.cap_items = (unsigned)d->cap_items; d->C.cap_new = (unsigned)d->cap_new;
     d->C.cap_paths = (int)d->cap_paths;
-    d->C.gc_threshold = (int)(d->cap_paths / 2);
+    // a stream stops for a collection when its Path records pass this mark (checked between frames): half
+    // of a small arena, all but the larger of an eighth / 4 M records of a large one (a frame writes at
+    // most one record per frontier item; running out anyway is the JD_ENOMEM that names the arena)
+    d->C.gc_threshold = (int)std::max<int64_t>(d->cap_paths / 2, d->cap_paths - std::max<int64_t>(d->cap_paths / 8, 4 << 20));
     d->h_streams.assign((size_t)B, StreamDev());
     rc = dmalloc(d, &d->d_res, (size_t)B * 5 * d->res_cap);
     if (rc) return rc;
@@ -1146,16 +1153,22 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
 // workgroup per CU in total, all resident at once (the clusters synchronise with barriers of their
 // own).  A launch stops a stream early when its Path arena needs collecting; k_gc runs after every
 // launch (a no-op below the threshold) and the launch is repeated until every stream is through.
-static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const float *ll, long long ll_stride, int f0, int f_end,
-                         hipStream_t st, const std::vector<double> *weight = nullptr)
+static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const float *ll, long long ll_stride, int f0, int f_end,
+                         hipStream_t st, const std::vector<double> *weight_first = nullptr)
 {
-    const int n_work = (int)work_in.size();
-    if (n_work == 0) return JD_OK;
-    if (n_work > d->work_cap) {
+    if (work_first.empty()) return JD_OK;
+    if ((int)work_first.size() > d->work_cap) {
         if (d->d_work) (void)hipFree(d->d_work);
-        HIPCHK(hipMalloc(&d->d_work, (size_t)n_work * sizeof(int4)));
-        d->work_cap = n_work;
+        HIPCHK(hipMalloc(&d->d_work, work_first.size() * sizeof(int4)));
+        d->work_cap = (int)work_first.size();
     }
+    std::vector<int2> work_in = work_first;
+    std::vector<double> weight_now;
+    const std::vector<double> *weight = weight_first;
+    const bool ne3 = d->am->max_n <= 5;
+    const int max_rounds = (f_end - f0) + 64;                          // every launch makes at least one frame of progress
+    for (int it = 0;; ++it) {
+    const int n_work = (int)work_in.size();
     SearchArgs A;
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work;
     const int nwg = std::max(1, d->n_cus);
@@ -1221,9 +1234,6 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const floa
     HIPCHK(hipMemcpyAsync(d->d_work, work.data(), (size_t)n_work * sizeof(int4), hipMemcpyHostToDevice, st));
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
     A.status = d->d_status; A.dbg = d->d_dbg;
-    const bool ne3 = d->am->max_n <= 5;
-    const int max_rounds = (f_end - f0) + 64;                          // every launch makes at least one frame of progress
-    for (int it = 0;; ++it) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
@@ -1250,6 +1260,20 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_in, const floa
         if (*d->h_status == 0) break;
         d->timing.relaunches += 1;
         if (it >= max_rounds) return jd_fail(JD_ENOMEM, "Path arena too small: no progress after %d garbage collections", it);
+        // Some streams stopped for a collection of their Path records: the launch is repeated for the
+        // streams that are not through, with clusters sized for what each of them still has ahead.
+        std::vector<int> head((size_t)d->max_streams * 4);
+        HIPCHK(hipMemcpy2D(head.data(), 16, d->d_ctl, sizeof(StreamCtl), 16, (size_t)d->max_streams, hipMemcpyDeviceToHost));
+        std::vector<int2> rest;
+        weight_now.clear();
+        for (const int2 &w : work_in) {
+            const int *h = head.data() + (size_t)w.x * 4;              // {frame, T, error, needs_init}
+            const int left = std::min(h[1], f_end) - h[0];
+            if (left > 0 && h[2] == 0) { rest.push_back(w); weight_now.push_back((double)left); }
+        }
+        if (rest.empty()) break;
+        work_in.swap(rest);
+        weight = weight_first ? &weight_now : nullptr;
     }
     return JD_OK;
 }

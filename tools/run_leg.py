@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""One of bench.py's extra legs on its own (GPU box): python tools/run_leg.py north|c3|hyps [passes]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import bench  # noqa: E402
+from juicer_amd import synth  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "north"
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+dev = torch.device("cuda:0")
+if which == "north":
+    a, n, f, _ = synth.config_c4(seed=0, n_utts=64, n_words=10000, n_tri_hist=100_000)
+    out = bench.run_leg("north_star target (trigram-shaped)", a, n, f, 200.0, 0, dev, passes=passes)
+elif which == "c3":
+    a, n, f, _ = synth.config_c4(seed=0, n_utts=8)
+    out = bench.run_leg("configs[3]", a, n, f, 300.0, 0, dev, passes=passes)
+else:
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
+    out = bench.run_leg("configs[1] + histogram pruning", a, n, f, 150.0, 6000, dev, passes=passes)
+print(json.dumps(out))
