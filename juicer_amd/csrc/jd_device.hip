@@ -338,70 +338,152 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
 // Path garbage collection = collectPaths (WFSTDecoderLite.cpp:699-747) as a mark-compact: records
 // reachable from a live token, from a frontier item of the last processed frame (the pending
 // entry-token candidates point at those) or from bestFinalToken are kept, everything else is
-// dropped.  No effect on results.  One 1024-thread block per stream, run between launches; a no-op
-// below the threshold.
+// dropped.  No effect on results.  Run between launches for the streams that stopped for it, G
+// 1024-thread workgroups per stream; the steps are separate kernels (a kernel boundary is the
+// barrier between them): begin (decide, clear the marks) - mark - sum (marks per workgroup range) -
+// scan (new indices) - compact (into the second arena, predecessors remapped) - remap (tokens, items,
+// bestFinalToken; swap the arenas).
+#define GC_MAXG 32
+struct GcState { int active, kept; int part[GC_MAXG]; };
+
+struct GcCtx {
+    int s, blk, G, np, nw, p;
+    Geo g;
+};
+__device__ __forceinline__ bool gc_ctx(const DecConst &C, const StreamCtl *ctl, const int4 *work, int s_single, int G, GcCtx &x)
+{
+    const int wi = blockIdx.x / G;
+    x.blk = blockIdx.x % G; x.G = G;
+    x.s = work ? work[wi].x : s_single;
+    const StreamCtl &c = ctl[x.s];
+    x.np = c.n_paths; x.nw = c.lst_nw;
+    x.p = c.frame & 1;                                // list the next frame reads; items of the last frame: parity p^1
+    if (x.nw > 0) x.g = make_geo(C, x.nw);
+    return true;
+}
+// the range of Path records workgroup blk of G looks after (multiples of 1024)
+__device__ __forceinline__ void gc_range(const GcCtx &x, int &lo, int &hi)
+{
+    const long long per = ((((long long)x.np + x.G - 1) / x.G) + 1023) & ~1023LL;
+    lo = (int)min((long long)x.np, per * x.blk);
+    hi = (int)min((long long)x.np, per * (x.blk + 1));
+}
+
+__global__ __launch_bounds__(1024) void k_gc_begin(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
+{
+    GcCtx x;
+    gc_ctx(C, ctl, work, s_single, G, x);
+    const StreamCtl &c = ctl[x.s];
+    StreamDev &S = streams[x.s];
+    const bool active = c.started && !c.needs_init && c.error == 0 && x.np > C.gc_threshold && x.nw > 0;
+    GcState *gs = (GcState *)S.gc_state;
+    if (x.blk == 0 && threadIdx.x == 0) { gs->active = active ? 1 : 0; gs->kept = 0; }
+    if (!active) return;
+    int lo, hi;
+    gc_range(x, lo, hi);
+    for (int q = lo + threadIdx.x; q < hi; q += blockDim.x) S.gc_idx[q] = 0;
+}
+
 template <int NE>
-__global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single)
+__global__ __launch_bounds__(1024) void k_gc_mark(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
 {
     typedef RecLayout<NE> RL;
-    const int s = work ? work[blockIdx.x].x : s_single;
-    StreamCtl &c = ctl[s];
-    StreamDev &S = streams[s];
-    const int np = c.n_paths;
-    if (!c.started || c.needs_init || c.error != 0 || np <= C.gc_threshold || c.lst_nw <= 0) return;
-    __shared__ int sh_w[16];
-    __shared__ int sh_carry;
-    const int tid = threadIdx.x, NTH = blockDim.x, lane = tid & 63, wid = tid >> 6;
-    const int nw = c.lst_nw;
-    const Geo g = make_geo(C, nw);
-    const int p = c.frame & 1;                       // list the next frame reads; items of the last frame: parity p^1
+    GcCtx x;
+    gc_ctx(C, ctl, work, s_single, G, x);
+    StreamDev &S = streams[x.s];
+    if (!((const GcState *)S.gc_state)->active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int *idx = S.gc_idx;
-    for (int q = tid; q < np; q += NTH) idx[q] = 0;
-    __syncthreads();
     auto mark = [&](int q) { while (q >= 0 && atomicExch(&idx[q], 1) == 0) q = S.paths[q].prev; };
-    // token of emitting state j (1..NE) of record q of wave segment w (structure-of-arrays chunks of 64)
-    auto tok_ptr = [&](int w, int q, int fld) -> int4 * {
-        return (int4 *)((char *)S.rec + (size_t)p * C.cap_slots * RL::REC_BYTES
-                        + ((size_t)w * (g.seg_rec >> 6) + (size_t)(q >> 6)) * RL::CHUNK_BYTES + (size_t)fld * 1024 + (size_t)(q & 63) * 16);
-    };
-    // mark: tokens of the instance records ...
-    for (int w = wid; w < nw; w += 16) {
-        const int n_rec = min(S.tot[(size_t)(TOT_REC0 + p) * MAXW + w], (int)g.seg_rec);
+    // tokens of the instance records (structure-of-arrays chunks of 64) ...
+    for (int w = x.blk * 16 + wid; w < x.nw; w += G * 16) {
+        const char *seg = (const char *)S.rec + (size_t)x.p * C.cap_slots * RL::REC_BYTES + (size_t)w * (x.g.seg_rec >> 6) * RL::CHUNK_BYTES;
+        const int n_rec = min(S.tot[(size_t)(TOT_REC0 + x.p) * MAXW + w], (int)x.g.seg_rec);
         for (int k = lane; k < n_rec * NE; k += 64) {
             const int q = k / NE, j = k - q * NE + 1;
-            const int n = tok_ptr(w, q, 0)->y & 0xff;
+            const char *r = seg + (size_t)(q >> 6) * RL::CHUNK_BYTES + (size_t)(q & 63) * 16;
+            const int n = ((const int4 *)r)->y & 0xff;
             if (j < n - 1) {
-                const int4 t = *tok_ptr(w, q, RL::HF + j - 1);
+                const int4 t = *(const int4 *)(r + (size_t)(RL::HF + j - 1) * 1024);
                 if (__int_as_float(t.x) > LZ) mark(t.w);
             }
         }
         // ... and of the last frame's frontier items
-        const int n_it = min(S.item_end[w], (int)g.seg_item);
-        for (int k = lane; k < n_it; k += 64) mark(S.items[2 * ((size_t)(p ^ 1) * C.cap_items + (size_t)w * g.seg_item + k)].w);
+        const int n_it = min(S.item_end[w], (int)x.g.seg_item);
+        for (int k = lane; k < n_it; k += 64) mark(S.items[2 * ((size_t)(x.p ^ 1) * C.cap_items + (size_t)w * x.g.seg_item + k)].w);
     }
-    if (tid == 0) mark(c.best_final.path);
+    if (x.blk == 0 && tid == 0) mark(ctl[x.s].best_final.path);
+}
+
+__global__ __launch_bounds__(1024) void k_gc_sum(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
+{
+    GcCtx x;
+    gc_ctx(C, ctl, work, s_single, G, x);
+    StreamDev &S = streams[x.s];
+    GcState *gs = (GcState *)S.gc_state;
+    if (!gs->active) return;
+    __shared__ int sh_sum;
+    if (threadIdx.x == 0) sh_sum = 0;
     __syncthreads();
-    // exclusive scan of the marks -> new indices (idx[q] = new index, -1 if dropped)
-    if (tid == 0) sh_carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < np; b0 += NTH) {
-        const int q = b0 + tid;
-        const int m = (q < np) ? idx[q] : 0;
-        int x = m;
+    int lo, hi, mine = 0;
+    gc_range(x, lo, hi);
+    for (int q = lo + threadIdx.x; q < hi; q += blockDim.x) mine += S.gc_idx[q];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
-        if (lane == 63) sh_w[wid] = x;
+    for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&sh_sum, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) gs->part[x.blk] = sh_sum;
+}
+
+// exclusive scan of the marks -> new indices (idx[q] = new index, -1 if dropped)
+__global__ __launch_bounds__(1024) void k_gc_scan(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
+{
+    GcCtx x;
+    gc_ctx(C, ctl, work, s_single, G, x);
+    StreamDev &S = streams[x.s];
+    GcState *gs = (GcState *)S.gc_state;
+    if (!gs->active) return;
+    __shared__ int sh_w[16];
+    __shared__ int sh_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int *idx = S.gc_idx;
+    if (tid == 0) {
+        int base = 0, all = 0;
+        for (int b = 0; b < G; ++b) { if (b < x.blk) base += gs->part[b]; all += gs->part[b]; }
+        sh_carry = base;
+        if (x.blk == 0) gs->kept = all;
+    }
+    __syncthreads();
+    int lo, hi;
+    gc_range(x, lo, hi);
+    for (int b0 = lo; b0 < hi; b0 += 1024) {
+        const int q = b0 + tid;
+        const int m = (q < hi) ? idx[q] : 0;
+        int v = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if (lane >= o) v += y; }
+        if (lane == 63) sh_w[wid] = v;
         __syncthreads();
         int base = sh_carry, tot = 0;
-        for (int w = 0; w < 16; ++w) { const int v = sh_w[w]; if (w < wid) base += v; tot += v; }
-        if (q < np) idx[q] = m ? base + x - m : -1;
+        for (int w = 0; w < 16; ++w) { const int u = sh_w[w]; if (w < wid) base += u; tot += u; }
+        if (q < hi) idx[q] = m ? base + v - m : -1;
         __syncthreads();
         if (tid == 0) sh_carry += tot;
         __syncthreads();
     }
-    const int kept = sh_carry;
-    // compact into the second arena, remapping prev (prev < q, so its new index is final)
-    for (int q = tid; q < np; q += NTH) {
+}
+
+// compact into the second arena, remapping prev (prev < q: its new index is final after the scan)
+__global__ __launch_bounds__(1024) void k_gc_compact(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
+{
+    GcCtx x;
+    gc_ctx(C, ctl, work, s_single, G, x);
+    StreamDev &S = streams[x.s];
+    if (!((const GcState *)S.gc_state)->active) return;
+    const int *idx = S.gc_idx;
+    int lo, hi;
+    gc_range(x, lo, hi);
+    for (int q = lo + threadIdx.x; q < hi; q += blockDim.x) {
         const int ni = idx[q];
         if (ni >= 0) {
             PathRec pr = S.paths[q];
@@ -409,29 +491,59 @@ __global__ __launch_bounds__(1024) void k_gc(DecConst C, StreamCtl *ctl, StreamD
             S.paths2[ni] = pr;
         }
     }
-    // remap the tokens
-    for (int w = wid; w < nw; w += 16) {
-        const int n_rec = min(S.tot[(size_t)(TOT_REC0 + p) * MAXW + w], (int)g.seg_rec);
+}
+
+template <int NE>
+__global__ __launch_bounds__(1024) void k_gc_remap(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
+{
+    typedef RecLayout<NE> RL;
+    GcCtx x;
+    gc_ctx(C, ctl, work, s_single, G, x);
+    StreamDev &S = streams[x.s];
+    const GcState *gs = (const GcState *)S.gc_state;
+    if (!gs->active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int *idx = S.gc_idx;
+    for (int w = x.blk * 16 + wid; w < x.nw; w += G * 16) {
+        char *seg = (char *)S.rec + (size_t)x.p * C.cap_slots * RL::REC_BYTES + (size_t)w * (x.g.seg_rec >> 6) * RL::CHUNK_BYTES;
+        const int n_rec = min(S.tot[(size_t)(TOT_REC0 + x.p) * MAXW + w], (int)x.g.seg_rec);
         for (int k = lane; k < n_rec * NE; k += 64) {
             const int q = k / NE, j = k - q * NE + 1;
-            const int n = tok_ptr(w, q, 0)->y & 0xff;
+            char *r = seg + (size_t)(q >> 6) * RL::CHUNK_BYTES + (size_t)(q & 63) * 16;
+            const int n = ((const int4 *)r)->y & 0xff;
             if (j < n - 1) {
-                int4 *t = tok_ptr(w, q, RL::HF + j - 1);
+                int4 *t = (int4 *)(r + (size_t)(RL::HF + j - 1) * 1024);
                 if (t->w >= 0) t->w = (__int_as_float(t->x) > LZ) ? idx[t->w] : -1;
             }
         }
-        const int n_it = min(S.item_end[w], (int)g.seg_item);
+        const int n_it = min(S.item_end[w], (int)x.g.seg_item);
         for (int k = lane; k < n_it; k += 64) {
-            int4 *t = S.items + 2 * ((size_t)(p ^ 1) * C.cap_items + (size_t)w * g.seg_item + k);   // token half of the item
+            int4 *t = S.items + 2 * ((size_t)(x.p ^ 1) * C.cap_items + (size_t)w * x.g.seg_item + k);   // token half of the item
             if (t->w >= 0) t->w = idx[t->w];
         }
     }
-    __syncthreads();
-    if (tid == 0) {
+    if (x.blk == 0 && tid == 0) {                     // (no workgroup of this kernel reads the Path arenas)
+        StreamCtl &c = ctl[x.s];
         if (c.best_final.path >= 0) c.best_final.path = idx[c.best_final.path];
         PathRec *tmp = S.paths; S.paths = S.paths2; S.paths2 = tmp;
-        c.n_paths = kept;
+        c.n_paths = gs->kept;
     }
+}
+
+// the six steps for the streams of a work list (or one stream), on stream st
+static void launch_gc(const DecConst &C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int n_work, int s_single, bool ne3,
+                      int n_cus, hipStream_t st)
+{
+    const int G = std::max(1, std::min(GC_MAXG, n_cus / std::max(1, n_work)));
+    const dim3 grid((unsigned)(n_work * G)), blk(1024);
+    hipLaunchKernelGGL(k_gc_begin, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
+    if (ne3) hipLaunchKernelGGL(k_gc_mark<3>, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
+    else hipLaunchKernelGGL(k_gc_mark<6>, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
+    hipLaunchKernelGGL(k_gc_sum, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
+    hipLaunchKernelGGL(k_gc_scan, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
+    hipLaunchKernelGGL(k_gc_compact, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
+    if (ne3) hipLaunchKernelGGL(k_gc_remap<3>, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
+    else hipLaunchKernelGGL(k_gc_remap<6>, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
 }
 
 // PARTIAL_DECODING: tracePartialPath (WFSTDecoderLite.cpp:824-868) on the state a launch left behind.
@@ -1015,7 +1127,7 @@ static int ensure_arenas(jd_dec *d)
         A(S.items, 4 * d->cap_items);
         A(S.newl, d->cap_new); A(S.cleanl, d->cap_new); A(S.dirtyl, d->cap_new);
         A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW);
-        A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths);
+        A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths); A(S.gc_state, sizeof(GcState) / 4);
         A(S.hist, 2 * HIST_MAX_BINS);
         {   // the five result arrays of all streams live in one arena [stream][array][res_cap]:
             // fetch_results brings a whole wave back with a single strided copy
@@ -1149,10 +1261,10 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
 }
 
 // Advance the streams of `work` ({stream, likelihood slot}) through frames [.., f_end) with ONE
-// persistent launch (k_search): every stream gets a cluster of Cw workgroups, one 1024-thread
-// workgroup per CU in total, all resident at once (the clusters synchronise with barriers of their
-// own).  A launch stops a stream early when its Path arena needs collecting; k_gc runs after every
-// launch (a no-op below the threshold) and the launch is repeated until every stream is through.
+// persistent launch (k_search): every stream gets a cluster of workgroups, one 512-thread workgroup
+// per CU in total, all resident at once (the clusters synchronise with barriers of their own).  A
+// launch stops a stream early when its Path arena needs collecting; the collection (k_gc_*) runs
+// after such a launch and the launch is repeated until every stream is through.
 static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const float *ll, long long ll_stride, int f0, int f_end,
                          hipStream_t st, const std::vector<double> *weight_first = nullptr)
 {
@@ -1241,8 +1353,6 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         if (ne3) hipLaunchKernelGGL(k_search<3>, dim3(grid), dim3(SNT), 0, st, A);
         else hipLaunchKernelGGL(k_search<6>, dim3(grid), dim3(SNT), 0, st, A);
         HIPCHK(hipEventRecord(e1, st));
-        if (ne3) hipLaunchKernelGGL(k_gc<3>, dim3(n_work), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, d->d_work, 0);
-        else hipLaunchKernelGGL(k_gc<6>, dim3(n_work), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, d->d_work, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1260,8 +1370,11 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         if (*d->h_status == 0) break;
         d->timing.relaunches += 1;
         if (it >= max_rounds) return jd_fail(JD_ENOMEM, "Path arena too small: no progress after %d garbage collections", it);
-        // Some streams stopped for a collection of their Path records: the launch is repeated for the
-        // streams that are not through, with clusters sized for what each of them still has ahead.
+        // Some streams stopped for a collection of their Path records (k_gc_*: no-ops for the streams below
+        // their mark): the launch is repeated for the streams that are not through, with clusters sized for
+        // what each of them still has ahead.
+        launch_gc(d->C, d->d_ctl, d->d_streams, d->d_work, n_work, 0, ne3, d->n_cus, st);
+        HIPCHK(hipGetLastError());
         std::vector<int> head((size_t)d->max_streams * 4);
         HIPCHK(hipMemcpy2D(head.data(), 16, d->d_ctl, sizeof(StreamCtl), 16, (size_t)d->max_streams, hipMemcpyDeviceToHost));
         std::vector<int2> rest;

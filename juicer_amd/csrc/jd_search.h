@@ -125,6 +125,7 @@ struct StreamDev {      // per-stream arenas
     int *item_end;                    // per wave: items written in the last processed frame (k_gc)
     PathRec *paths; int *hist;        // hist: [2][HIST_MAX_BINS] by frame parity
     PathRec *paths2; int *gc_idx;     // Path garbage collection: compaction target + mark / new-index array
+    int *gc_state;                    // ... and its per-stream bookkeeping (GcState, jd_device.hip)
     // result of jd_finish_kernel
     int res_n; int *res_label; int *res_time; float *res_score, *res_ac, *res_lm; int res_cap;
 };
