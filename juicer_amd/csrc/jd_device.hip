@@ -862,8 +862,10 @@ static int dmalloc(jd_dec *d, T **p, size_t n)
 {
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
-    if (e != hipSuccess)
-        return jd_fail(JD_EHIP, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return jd_fail(e == hipErrorOutOfMemory ? JD_ENOMEM : JD_EHIP, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+    }
     d->allocs.push_back(q);
     *p = (T *)q;
     return JD_OK;
@@ -1069,9 +1071,8 @@ static void reset_ast(ArcState *ast, int64_t n_arcs)
     hipLaunchKernelGGL(jd_reset_ast_kernel, dim3((unsigned)((n_arcs + 255) / 256)), dim3(256), 0, 0, ast, (long long)n_arcs);
 }
 
-static int ensure_arenas(jd_dec *d)
+static int ensure_arenas_try(jd_dec *d, double mem_fraction)
 {
-    if (d->arenas_ready) return JD_OK;
     int rc = check_device(d->device);
     if (rc) return rc;
     const int B = d->max_streams, MN = d->am->max_n;
@@ -1085,7 +1086,7 @@ static int ensure_arenas(jd_dec *d)
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const double n_arcs = (double)d->net->n_arcs, n_states = (double)d->net->n_states;
         const double fixed = n_arcs * sizeof(ArcState) + n_states * 24.0 + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
-        const double budget = std::max(0.0, 0.7 * (double)free_b / B - fixed);
+        const double budget = std::max(0.0, mem_fraction * (double)free_b / B - fixed);
         const double rec_b = 2.0 * rec_bytes, item_b = 2.0 * (sizeof(Tok) + sizeof(int4)) + 32.0;
         const double path_b = 2.0 * sizeof(PathRec) + 4.0;
         auto pick = [](double share, int64_t lo, int64_t hi) {
@@ -1095,10 +1096,11 @@ static int ensure_arenas(jd_dec *d)
         if (d->cap_slots <= 0) d->cap_slots = pick(0.5 * budget / rec_b, 1 << 19, std::min<int64_t>(d->net->n_arcs + 65536, lim_rec));
         if (d->cap_items <= 0) d->cap_items = pick(0.2 * budget / item_b, 1 << 21, std::min<int64_t>(std::max<int64_t>(2 * d->net->n_arcs + 65536, 1 << 21), lim_item));
         // (records and items stop at their addressing limits: what they leave of the budget goes to the Path
-        // records - every collection of those is a stop of the stream's launch)
+        // records - every collection of those is a stop of the stream's launch - up to 16 per arc of the
+        // graph: small graphs do not write more, and tens of GB take seconds to allocate)
         if (d->cap_paths <= 0)
             d->cap_paths = pick(std::max(0.3 * budget, budget - (double)d->cap_slots * rec_b - (double)d->cap_items * item_b) / path_b,
-                                1 << 21, 0x40000000LL);
+                                1 << 21, std::min<int64_t>(0x40000000LL, std::max<int64_t>(1 << 26, 16 * d->net->n_arcs)));
         if (d->cap_slots > lim_rec || d->cap_items > lim_item || d->cap_paths > 0x7fffff00LL)
             return jd_fail(JD_EINVAL, "arena capacity too large (instance records and frontier items are addressed "
                            "with 32-bit byte offsets: at most %lld / %lld records)", (long long)lim_rec, (long long)lim_item);
@@ -1166,11 +1168,40 @@ static int ensure_arenas(jd_dec *d)
         }
         HIPCHK(hipMemcpy(d->d_ctl, hc.data(), hc.size() * sizeof(StreamCtl), hipMemcpyHostToDevice));
     }
-    HIPCHK(hipMalloc(&d->d_ll[0], (size_t)d->Fc * d->am->n_gmm * sizeof(float)));   // streaming API: one stream, one chunk
+    {
+        void *p = nullptr;                                             // streaming API: one stream, one chunk
+        rc = dmalloc(d, (float **)&p, (size_t)d->Fc * d->am->n_gmm);
+        if (rc) return rc;
+        d->allocs.pop_back();                                          // (owned by d_ll: it is re-sized later)
+        d->d_ll[0] = (float *)p;
+    }
     d->ll_cap[0] = (size_t)d->Fc * d->am->n_gmm;
     HIPCHK(hipDeviceSynchronize());
     d->arenas_ready = true;
     return JD_OK;
+}
+
+// The default capacities take 70% of the device's free memory.  When that cannot be had - another
+// process on the same GPU sized itself at the same moment - the defaults are halved, up to three times.
+static int ensure_arenas(jd_dec *d)
+{
+    if (d->arenas_ready) return JD_OK;
+    const int64_t u_slots = d->cap_slots, u_items = d->cap_items, u_paths = d->cap_paths;   // <= 0: not set by the caller
+    double frac = 0.7;
+    for (int attempt = 0;; ++attempt) {
+        const size_t mark = d->allocs.size();
+        const int rc = ensure_arenas_try(d, frac);
+        if (rc == JD_OK) return JD_OK;
+        for (size_t i = mark; i < d->allocs.size(); ++i) (void)hipFree(d->allocs[i]);
+        d->allocs.resize(mark);
+        if (d->h_status) { (void)hipHostFree(d->h_status); d->h_status = nullptr; }
+        if (d->d_ll[0]) { (void)hipFree(d->d_ll[0]); d->d_ll[0] = nullptr; d->ll_cap[0] = 0; }
+        d->d_res = nullptr; d->d_streams = nullptr; d->d_T = nullptr; d->d_ctl = nullptr; d->d_status = nullptr;
+        (void)hipGetLastError();
+        if (rc != JD_ENOMEM || attempt == 3 || (u_slots > 0 && u_items > 0 && u_paths > 0)) return rc;
+        d->cap_slots = u_slots; d->cap_items = u_items; d->cap_paths = u_paths; d->cap_new = 0;
+        frac *= 0.5;
+    }
 }
 
 // mark streams [s0, s0+n) for re-initialisation (IDecoder::init)
