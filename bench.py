@@ -246,11 +246,17 @@ def main():
     gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
     gmm_bytes = G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / max(1, tm["gmm_launches"])
     roofline["search_ms_per_step"] = round(acc["search_ms"] / steps, 3)
-    roofline["gmm"] = {"kernel": "jd_gmm_kernel", "ms_per_step": round(acc["gmm_ms"] / steps, 3),
+    # the companion kernel is VALU-bound: per (frame pair, mixture) 4 packed fp32 instructions per dimension
+    # + ~116 for the two logAdd steps, 4 cycles each on 1024 SIMDs
+    gmm_valu_ms = (frames_local / 128.0) * G * M * (4.0 * D + 116.0) * 4.0 / 1024.0 / 2.4e9 * 1e3
+    roofline["gmm"] = {"kernel": "jd_gmm_kernel39" if D == 39 else "jd_gmm_kernel", "bound": "valu",
+                       "ms_per_step": round(acc["gmm_ms"] / steps, 3),
+                       "valu_bound_ms": round(gmm_valu_ms, 3),
+                       "frac": round(gmm_valu_ms / max(acc["gmm_ms"] / steps, 1e-9), 4),
                        "valu_tflops": round(gmm_flops / max(acc["gmm_ms"] / steps, 1e-9) / 1e9, 3),
                        "algorithmic_bytes_per_launch": round(gmm_bytes, 1),
                        "search_waited_ms_per_step": round(acc["gmm_wait_ms"] / steps, 3),
-                       "note": "scores one chunk ahead of the search on its own stream (bounded grid beside it)"}
+                       "note": "scored before the search starts: serial step time (k_search holds the register file)"}
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample
     cpu = None
