@@ -1307,6 +1307,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     }
     std::vector<int2> work_in = work_first;
     std::vector<double> weight_now;
+    std::vector<int> frame_before;                                     // per stream: where the previous launch found it
     const std::vector<double> *weight = weight_first;
     const bool ne3 = d->am->max_n <= 5;
     const int max_rounds = (f_end - f0) + 64;                          // every launch makes at least one frame of progress
@@ -1406,14 +1407,20 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // what each of them still has ahead.
         launch_gc(d->C, d->d_ctl, d->d_streams, d->d_work, n_work, 0, ne3, d->n_cus, st);
         HIPCHK(hipGetLastError());
+        // A stream that stopped for a collection after n frames will, by and large, stop again after as many
+        // (its records per frame change slowly): what it has ahead IN THE NEXT LAUNCH is the smaller of that
+        // and the frames it has left - sized by that, the streams stop together instead of idling.
         std::vector<int> head((size_t)d->max_streams * 4);
         HIPCHK(hipMemcpy2D(head.data(), 16, d->d_ctl, sizeof(StreamCtl), 16, (size_t)d->max_streams, hipMemcpyDeviceToHost));
         std::vector<int2> rest;
         weight_now.clear();
+        if (frame_before.empty()) frame_before.assign((size_t)d->max_streams, f0);
         for (const int2 &w : work_in) {
             const int *h = head.data() + (size_t)w.x * 4;              // {frame, T, error, needs_init}
-            const int left = std::min(h[1], f_end) - h[0];
-            if (left > 0 && h[2] == 0) { rest.push_back(w); weight_now.push_back((double)left); }
+            const int end = std::min(h[1], f_end), left = end - h[0];
+            const int done = h[0] - frame_before[(size_t)w.x];
+            frame_before[(size_t)w.x] = h[0];
+            if (left > 0 && h[2] == 0) { rest.push_back(w); weight_now.push_back((double)((done > 0) ? std::min(left, done) : left)); }
         }
         if (rest.empty()) break;
         work_in.swap(rest);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One of bench.py's extra legs on its own (GPU box): python tools/run_leg.py north|c3|hyps [passes]"""
+"""One of bench.py's extra legs on its own (GPU box): python tools/run_leg.py north|c3|hyps [passes [utterances of the c3 leg]]"""
 import json
 import os
 import sys
@@ -12,12 +12,13 @@ from juicer_amd import synth  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "north"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+n_utts = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device("cuda:0")
 if which == "north":
     a, n, f, _ = synth.config_c4(seed=0, n_utts=64, n_words=10000, n_tri_hist=100_000)
     out = bench.run_leg("north_star target (trigram-shaped)", a, n, f, 200.0, 0, dev, passes=passes)
 elif which == "c3":
-    a, n, f, _ = synth.config_c4(seed=0, n_utts=8)
+    a, n, f, _ = synth.config_c4(seed=0, n_utts=n_utts or 8)
     out = bench.run_leg("configs[3]", a, n, f, 300.0, 0, dev, passes=passes)
 else:
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
