@@ -760,3 +760,38 @@ def test_max_alloc_models(small):
     assert "capacity %d," % ((n_arcs * 60 // 100) & ~63) in str(ei.value), str(ei.value)
     with pytest.raises(capi.JuicerAmdError):
         capi.Decoder(gnet, gam, max_streams=1).set_max_alloc_models(0)  # assert(maxAllocModels_ > 0) :808
+
+
+def test_stress_many_streams_repeated(built):
+    """Guards the inter-workgroup protocol of the persistent kernel (write-through stores, agent-scope
+    loads, counter barriers across non-coherent XCD L2s): 64 streams of short utterances, decoded over
+    and over with different cluster shapes (1, 2, 3 and 4+ workgroups per stream, uniform and weighted) -
+    every run must reproduce the oracle's result for every utterance, scores bit for bit."""
+    import os
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small(seed=21, n_utts=64, utt_words=(1, 6), hub="tree")
+    kw = dict(main_beam=150.0, max_hyps=300)
+    od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+    want = [od.decode_certified(x) for x in feats]
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    runs = 0
+    for env in ({}, {"JD_CW": "1"}, {"JD_CW": "2"}, {"JD_CW": "3"}, {"JD_WEIGHTED": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            gd = capi.Decoder(gnet, gam, max_streams=64, **kw)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        for rep in range(6):
+            order = np.random.default_rng(rep).permutation(64) if rep else np.arange(64)
+            gs = gd.decode_batch([feats[i] for i in order])
+            for j, i in enumerate(order):
+                assert_hyp_matches(gs[j], want[i], "stress %r rep %d utt %d" % (env, rep, i))
+                assert bit_exact(gs[j], want[i]), "stress %r rep %d utt %d: scores" % (env, rep, i)
+            runs += 1
+    assert runs == 30
