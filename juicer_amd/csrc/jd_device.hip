@@ -1445,42 +1445,64 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     }
     // Frames per chunk.  A search launch lasts as long as its slowest stream and streams do not wait
     // for each other inside a launch, so the fewer launches the better: one chunk covers the longest
-    // utterance when the likelihood table (nb x frames x tied states floats, 288 GB of HBM to draw on)
-    // fits a quarter of the free memory; otherwise the batch is decoded in several chunks, scored
-    // alternately into two tables.
+    // utterance when the likelihood table (frames of the batch x tied states floats, 288 GB of HBM to
+    // draw on) fits a quarter of the free memory; otherwise the batch is decoded in several chunks,
+    // scored alternately into two tables.  A chunk's table holds the frames the streams really have
+    // in it, packed stream after stream (only the last 128-row scoring tile of a chunk is partly empty).
+    long long sumT = 0;
+    for (int u = 0; u < nb; ++u) sumT += T[(size_t)u];
     int Fc = std::max(128, (maxT + 127) / 128 * 128);
     {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const double have = 0.25 * (double)free_b + (double)(d->ll_cap[0] + d->ll_cap[1]) * sizeof(float);
-        const double per_frame = (double)nb * G * sizeof(float);
-        if ((double)Fc * per_frame > have) Fc = std::max(128, (int)(0.5 * have / per_frame) / 128 * 128);
+        const double per_frame = (double)nb * G * sizeof(float);       // (a chunk holds at most nb * Fc rows)
+        if ((double)(sumT + 128) * G * sizeof(float) > have && (double)Fc * per_frame > have)
+            Fc = std::max(128, (int)(0.5 * have / per_frame) / 128 * 128);
         if (d->Fw_env > 0) Fc = d->Fw_env;
     }
     const int n_chunks = std::max(1, (maxT + Fc - 1) / Fc);            // chunk 0 also carries recognitionStart
+    // rows of a chunk: stream u's frames [c0, min(T_u, c1)) start at row_off[c][u]
+    std::vector<size_t> chunk_row0((size_t)n_chunks + 1, 0);            // first entry of chunk c in the row table
+    std::vector<int> row_off((size_t)n_chunks * nb, 0), chunk_rows((size_t)n_chunks, 0);
+    size_t max_rows = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        long long r = 0;
+        for (int u = 0; u < nb; ++u) {
+            row_off[(size_t)c * nb + u] = (int)r;
+            r += std::max(0, std::min(T[(size_t)u], (c + 1) * Fc) - c * Fc);
+        }
+        if (r > 0x7fffff00LL) return jd_fail(JD_EINVAL, "more than 2^31 frames in one chunk");
+        chunk_rows[(size_t)c] = (int)((r + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2);
+        chunk_row0[(size_t)c + 1] = chunk_row0[(size_t)c] + (size_t)chunk_rows[(size_t)c];
+        max_rows = std::max(max_rows, (size_t)chunk_rows[(size_t)c]);
+    }
+    max_rows = std::max<size_t>(max_rows, GMM_ROWS2);
     for (int i = 0; i < std::min(2, n_chunks); ++i)
-        if ((size_t)nb * Fc * G > d->ll_cap[i]) {
+        if (max_rows * G > d->ll_cap[i]) {
             if (d->d_ll[i]) (void)hipFree(d->d_ll[i]);
             d->d_ll[i] = nullptr; d->ll_cap[i] = 0;
-            HIPCHK(hipMalloc(&d->d_ll[i], (size_t)nb * Fc * G * sizeof(float)));
-            d->ll_cap[i] = (size_t)nb * Fc * G;
+            HIPCHK(hipMalloc(&d->d_ll[i], max_rows * G * sizeof(float)));
+            d->ll_cap[i] = max_rows * G;
         }
-    // row -> source frame table for all chunks: row = (c*nb + u)*Fc + dt
-    const size_t n_rows_all = (size_t)n_chunks * nb * Fc;
+    // row -> source frame table for all chunks
+    const size_t n_rows_all = std::max<size_t>(chunk_row0[(size_t)n_chunks], 1);
     if (n_rows_all > d->row_src_cap) {
         if (d->d_row_src) (void)hipFree(d->d_row_src);
-        HIPCHK(hipMalloc(&d->d_row_src, std::max<size_t>(n_rows_all, 1) * sizeof(int)));
+        HIPCHK(hipMalloc(&d->d_row_src, n_rows_all * sizeof(int)));
         d->row_src_cap = n_rows_all;
     }
-    std::vector<int> row_src(n_rows_all);
+    std::vector<int> row_src(n_rows_all, -1);
     for (int c = 0; c < n_chunks; ++c)
-        for (int u = 0; u < nb; ++u)
-            for (int dt = 0; dt < Fc; ++dt) {
-                const int f = c * Fc + dt;
-                const int64_t src = ustart[u] + f;
+        for (int u = 0; u < nb; ++u) {
+            const int n = std::max(0, std::min(T[(size_t)u], (c + 1) * Fc) - c * Fc);
+            int *dst = row_src.data() + chunk_row0[(size_t)c] + (size_t)row_off[(size_t)c * nb + u];
+            for (int dt = 0; dt < n; ++dt) {
+                const int64_t src = ustart[u] + (int64_t)c * Fc + dt;
                 if (src > 0x7fffffff) return jd_fail(JD_EINVAL, "more than 2^31 frames in one batch");
-                row_src[((size_t)c * nb + u) * Fc + dt] = (f < T[(size_t)u]) ? (int)src : -1;
+                dst[dt] = (int)src;
             }
+        }
     // the caller's features may have been produced asynchronously on its stream (NULL = the
     // default stream): the decoder's own streams are non-blocking, so order against it explicitly
     HIPCHK(hipStreamSynchronize(user_stream));
@@ -1501,8 +1523,9 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         HIPCHK(hipEventRecord(gs[(size_t)c], d->s_gmm));
         // (a later chunk is launched while the previous one is searched: k_search holds every CU's
         // registers, so its workgroups start as the search's clusters finish - they fill the tail)
-        int r = launch_gmm(d->am, d->amb, d_feats, d->d_row_src + (size_t)c * nb * Fc, nb * Fc, d->d_ll[c & 1], d->s_gmm,
-                           0, (Fc % GMM_ROWS2) == 0);
+        if (chunk_rows[(size_t)c] == 0) { HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm)); return JD_OK; }
+        int r = launch_gmm(d->am, d->amb, d_feats, d->d_row_src + chunk_row0[(size_t)c], chunk_rows[(size_t)c], d->d_ll[c & 1], d->s_gmm,
+                           0, true);
         if (r) return r;
         HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm));
         return JD_OK;
@@ -1522,10 +1545,10 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         work.clear(); weight.clear();
         for (int u = 0; u < nb; ++u)
             if (c == 0 || T[(size_t)u] > c0) {
-                work.push_back(make_int2(u, u));
+                work.push_back(make_int2(u, row_off[(size_t)c * nb + u]));   // {stream, its first row in the chunk's table}
                 weight.push_back((double)(std::min(T[(size_t)u], c1) - c0));
             }
-        rc = launch_search(d, work, d->d_ll[c & 1], (long long)Fc * G, c0, c1, d->s_search, &weight);
+        rc = launch_search(d, work, d->d_ll[c & 1], (long long)G, c0, c1, d->s_search, &weight);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, 0, nb);

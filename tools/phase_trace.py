@@ -17,8 +17,12 @@ ap.add_argument("--arcs", type=int, default=1_000_000)
 ap.add_argument("--beam", type=float, default=150.0)
 ap.add_argument("--max-hyps", type=int, default=0)
 ap.add_argument("--trim", type=int, default=0, help="cut every utterance to this many frames (0 = keep)")
+ap.add_argument("--c4", type=float, default=0.0, help="trigram-shaped graph of config_c4 at this scale (1.0 = configs[3]) instead of config_c2")
 args = ap.parse_args()
-am, net, feats, _ = synth.config_c2(n_utts=args.utts, target_arcs=args.arcs)
+if args.c4 > 0:
+    am, net, feats, _ = synth.config_c4(n_utts=args.utts, n_words=int(20000 * args.c4 ** 0.5), n_tri_hist=int(400000 * args.c4))
+else:
+    am, net, feats, _ = synth.config_c2(n_utts=args.utts, target_arcs=args.arcs)
 if args.trim:
     feats = [f[:args.trim] for f in feats]
 dec = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=args.beam, max_hyps=args.max_hyps,
