@@ -1066,13 +1066,14 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     // =============================================================== frames (the first pass may be
     // recognitionStart part 2: the expansion of the start token, a frame without phase A that
     // uses item / key parity 1 like a frame "-1")
+    int np_seen = 0;                                                   // Path records in use, as of the last frame end
     while (!aborted && !failed) {
         const bool init = init_pending;
         if (!init && f >= f_stop) break;
         const int p = init ? 1 : (f & 1);
         // stop early when the Path arena needs collecting (k_gc runs between launches); n_paths only
         // changes in phase X, so every workgroup of the cluster reads the same value here
-        if (!init && frames_done > 0 && RFL(CL(&c.n_paths)) > C.gc_threshold) break;
+        if (!init && frames_done > 0 && np_seen > C.gc_threshold) break;
         long long t0 = 0;
         const bool clk_on = A.dbg != nullptr && tid == 0;
 #define CLK(slot) do { if (clk_on) { const long long tn_ = wall_clock64(); sh.clk[slot] += tn_ - t0; t0 = tn_; } } while (0)
@@ -1121,12 +1122,13 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             if (sh.abort) { aborted = true; break; }
             gin = gout;                                                // every list read from here on was written by this launch
             CLK(3);                                                    // cluster barrier 1
-            ba = (unsigned)RFL((int)CL(&c.bestA[p]));
         }
-        // ---- phase X
-        const float bestA = ba ? o2f(ba) : LZ;
-        const float endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;     // :349
-        const float wordTh = (!init && C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;  // :350
+        // ---- phase X.  (Words that every workgroup reads after a barrier - the frame's best scores, the
+        // error flag, the Path count - are requested together with the next work list's counts: one
+        // round trip, not one each.)
+        float bestA = LZ, endTh = LZ, wordTh = LZ;
+        unsigned bx_raw = 0u;
+        int err_raw = 0, np_raw = 0;
         const bool last_frame = !init && f >= T - 1;
         if (jw == 0 && !init) {                                        // housekeeping for the frame after this one
             if (tid == 0) { CS(&c.bestA[p ^ 1], 0u); CS(&c.bestX[p ^ 1], 0u); CS(&c.new_all[p ^ 1], 0); }
@@ -1140,10 +1142,17 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             int KX = 64;
             int Q1[1], n1[1];
             if (round == 0) {
+                unsigned ba_raw = 0u;
+                if (!init) ba_raw = CL(&c.bestA[p]);
                 if (tid < gin.nw) sh.start[tid] = 0;
                 const ListSrc src[1] = {{tot_of(TOT_EXIT), KX, gin.seg_item}};
                 build_lists<1>(sh, src, gin.nw, Q1, n1);
+                ba = (unsigned)RFL((int)ba_raw);
+                bestA = ba ? o2f(ba) : LZ;
+                endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;     // :349
+                wordTh = (!init && C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;  // :350
             } else {
+                bx_raw = CL(&c.bestX[p]); err_raw = CL(&c.err[p]); np_raw = CL(&c.n_paths);   // final if this round has nothing to do
                 if (tid < gin.nw) sh.start[tid] = CL(tot_of(TOT_CLS0 + (round & 1)) + tid);
                 const ListSrc src[1] = {{tot_of(TOT_CL0 + (round & 1)), KX, gin.seg_item}};
                 build_lists<1>(sh, src, gin.nw, Q1, n1);
@@ -1180,9 +1189,10 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         my_item_end = xo.item_cnt;
         // ---- frame end
         {
-            const unsigned bx = (unsigned)RFL((int)CL(&c.bestX[p]));
+            const unsigned bx = (unsigned)RFL((int)bx_raw);
             const unsigned bb = ba > bx ? ba : bx;
             best_emit = bb ? o2f(bb) : LZ;                             // :417-418, :572-573
+            np_seen = RFL(np_raw);                                     // (n_paths only changes in phase X)
         }
         if (tid == 0)                                                  // totalActiveModels starts with frame 0 (:981)
             for (int k = 0; k < ST_N; ++k) { if (!init || k != ST_MODELS) sh.acc[k] += sh.stat[k]; sh.stat[k] = 0; }
@@ -1199,7 +1209,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             }
             c.best_final = bf;
         }
-        if (RFL(CL(&c.err[p])) != 0) failed = true;                    // raised before this frame's last barrier: seen by all
+        if (RFL(err_raw) != 0) failed = true;                          // raised before this frame's last barrier: seen by all
         if (init) init_pending = false;
         else { ++f; ++frames_done; }
     }
