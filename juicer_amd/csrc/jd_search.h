@@ -1089,6 +1089,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const ListSrc src[4] = {{tot_of(TOT_REC0 + p), 64, gin.seg_rec}, {tot_of(TOT_NEW), 64, gin.seg_new},
                                     {tot_of(TOT_CLEAN), 64, gin.seg_new}, {tot_of(TOT_DIRTY), 64, gin.seg_new}};
             int Q[4], items[4];
+            int new_prev = 0;                                          // arcs entered in the previous frame (read with the lists' counts)
+            if (jw == 0 && tid == 0) new_prev = CL(&c.new_all[p ^ 1]);
             build_lists<4>(sh, src, gin.nw, Q, items);
             if (use_hist) {                                            // every workgroup evaluates the same threshold
                 float th = hist_threshold(C, sh.hprev, lane);
@@ -1098,7 +1100,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             }
             const float startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;   // :337
             // arcs entered in the previous frame are instances of this one, tried or not (:899-935)
-            if (jw == 0 && tid == 0) atomicAdd(&sh.stat[ST_INSTS], CL(&c.new_all[p ^ 1]));
+            if (jw == 0 && tid == 0) atomicAdd(&sh.stat[ST_INSTS], new_prev);
             const float *llrow = A.ll + (size_t)ll_slot * A.ll_stride + (size_t)(f - A.f0) * C.G;
             int out_cnt = 0;
             CLK(0);                                                    // thresholds + work lists
@@ -1130,10 +1132,6 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         unsigned bx_raw = 0u;
         int err_raw = 0, np_raw = 0;
         const bool last_frame = !init && f >= T - 1;
-        if (jw == 0 && !init) {                                        // housekeeping for the frame after this one
-            if (tid == 0) { CS(&c.bestA[p ^ 1], 0u); CS(&c.bestX[p ^ 1], 0u); CS(&c.new_all[p ^ 1], 0); }
-            if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) CS(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b, 0);
-        }
         XOut xo = {exit_cnt, 0, 0, 0};
         for (int round = 0;; ++round) {
             // Items are taken in chunks of KX per wave pass.  The arcs of a chunk are walked by ONE wave,
@@ -1147,6 +1145,11 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 if (tid < gin.nw) sh.start[tid] = 0;
                 const ListSrc src[1] = {{tot_of(TOT_EXIT), KX, gin.seg_item}};
                 build_lists<1>(sh, src, gin.nw, Q1, n1);
+                if (jw == 0 && !init) {                                // housekeeping for the frame after this one (stores:
+                    // after the list's loads, so that nothing waits for their acknowledgement)
+                    if (tid == 0) { CS(&c.bestA[p ^ 1], 0u); CS(&c.bestX[p ^ 1], 0u); CS(&c.new_all[p ^ 1], 0); }
+                    if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) CS(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b, 0);
+                }
                 ba = (unsigned)RFL((int)ba_raw);
                 bestA = ba ? o2f(ba) : LZ;
                 endTh = (!init && C.end_win > 0.0f) ? (bestA - C.end_win) : LZ;     // :349
