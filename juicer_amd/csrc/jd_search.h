@@ -152,6 +152,7 @@ struct SearchArgs {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define AUX_SC1 16
+#define X_SLICE 256                  // phase X: arcs of one state a wave walks itself; the rest becomes slices for the next round
 #define QCAP 64                      // closure items a wave keeps for itself (inline closure queue)
 // The descriptor inputs go through readfirstlane so that the compiler can PROVE them wave-uniform;
 // otherwise it wraps every buffer access in a "waterfall" loop (cdna_hip_programming.md, T20).
@@ -729,6 +730,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         unsigned ii;
         Tok t;
         v4i info;
+        int slice_no = 0;                                              // > 0: this item is a slice of a state with many arcs
         if (q_n > 0) {
             valid = lane < q_n;
             exit_kind = false;
@@ -747,11 +749,12 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             t = as_tok(ld16(V.items, ioff));
             info = ld16(V.items, ioff + 16u);                          // {arc, out, to, flag}; arc -1 = the start token
             exit_kind = round == 0;
-            if (!exit_kind && info.w != 0) valid = false;              // expanded by its producer / superseded
+            if (!exit_kind && (info.w & 3) == 1) valid = false;        // expanded by its producer / superseded
+            if (!exit_kind && (info.w & 3) == 2) slice_no = info.w >> 2;
         }
         XFINE(0);                                                      // hop 1: the items
         const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
-        const bool real = valid && info.x >= 0;                        // an item that traversed an arc
+        const bool real = valid && info.x >= 0 && slice_no == 0;       // an item that traversed an arc (a slice has been through all this)
         const int state = !valid ? 0 : (info.x >= 0) ? info.z : C.init_state;
         // second level, in flight together: CSR row bounds, the state's key, the Path reservation
         const int rs = C.row_ptr[state], rs1 = C.row_ptr[state + 1];
@@ -805,8 +808,32 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             }
         }
         XFINE(2);                                                      // winners: key reset, Path record, final state
+        // ---- A state with thousands of out-arcs (a history with 10^4 successors) would keep this wave busy
+        // for hundreds of passes while the cluster waits at the barrier: the wave walks the first X_SLICE
+        // arcs itself and hands the rest on as SLICES - items of the next round (flag 2 + slice number)
+        // that carry the token as it stands now and skip everything above; the cluster shares them out.
+        int alo = rs, ahi = rs1;
+        if (slice_no > 0) { alo = rs + slice_no * X_SLICE; ahi = min(rs1, alo + X_SLICE); }
+        int n_slices = 0;
+        if (have && slice_no == 0 && rs1 - rs > X_SLICE) { n_slices = (rs1 - rs - 1) / X_SLICE; ahi = rs + X_SLICE; }
+        for (unsigned long long bs = __ballot(n_slices > 0); bs; bs &= bs - 1) {
+            const int src = __ffsll((long long)bs) - 1;
+            const int ns = __shfl(n_slices, src);
+            const v4i tv = {__shfl(__float_as_int(t.score), src), __shfl(__float_as_int(t.ac), src), __shfl(__float_as_int(t.lm), src), __shfl(t.path, src)};
+            const int sx = __shfl(info.x, src), sy = __shfl(info.y, src), sz = __shfl(info.z, src);
+            for (int j0 = 0; j0 < ns; j0 += 64) {
+                const int nj = min(64, ns - j0);
+                if (out.item_cnt + nj > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); break; }
+                if (lane < nj) {
+                    const unsigned k = item_base + (unsigned)(out.item_cnt + lane);
+                    st16(V.items, icur + k * 32u, tv);
+                    st16(V.items, icur + k * 32u + 16u, (v4i){sx, sy, sz, 2 | ((j0 + lane + 1) << 2)});
+                }
+                out.item_cnt += nj; deferred += nj;
+            }
+        }
         // ---- pooled arc walk: exclusive prefix of the items' out-degrees
-        const int deg = have ? rs1 - rs : 0;
+        const int deg = have ? ahi - alo : 0;
         int incl = deg;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
@@ -818,7 +845,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             for (int stp = 32; stp > 0; stp >>= 1) if (wpfx[g + stp] <= a) g += stp;
             return g; };
         int g_nx = owner_of(lane);
-        int b_nx = __shfl(rs, g_nx) + (lane - wpfx[g_nx]);
+        int b_nx = __shfl(alo, g_nx) + (lane - wpfx[g_nx]);
         JdArc Bk_nx = {0, 0.0f, 0, 0};
         if (lane < tot) Bk_nx = C.arcs[b_nx];
         XFINE(3);                                                      // prefix + hop 3: the first 64 arcs
@@ -830,7 +857,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const JdArc Bk = Bk_nx;
             if (a0 + 64 < tot) {                                       // next pass's arc records: in flight during this one
                 g_nx = owner_of(a + 64);
-                b_nx = __shfl(rs, g_nx) + (a + 64 - wpfx[g_nx]);
+                b_nx = __shfl(alo, g_nx) + (a + 64 - wpfx[g_nx]);
                 if (a + 64 < tot) Bk_nx = C.arcs[b_nx];
             }
             Tok tg;
