@@ -795,3 +795,18 @@ def test_stress_many_streams_repeated(built):
                 assert bit_exact(gs[j], want[i]), "stress %r rep %d utt %d: scores" % (env, rep, i)
             runs += 1
     assert runs == 30
+
+
+def test_states_with_many_arcs_are_sliced(built):
+    """A back-off state with 700 eps:word arcs and word histories with 300 successors: phase X walks
+    such states in slices of 256 arcs handed to the next round - same results, same statistics."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small(seed=31, n_utts=3, n_words=700, n_succ=300, hub="flat", utt_words=(3, 6))
+    deg = np.bincount(net.src, minlength=net.n_states)
+    assert deg.max() >= 700 and (deg > 256).sum() > 100
+    for kw in (dict(main_beam=150.0), dict(main_beam=200.0, max_hyps=3000)):
+        od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+        gs = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=3, **kw).decode_batch(feats)
+        for u, x in enumerate(feats):
+            assert_hyp_matches(gs[u], od.decode_certified(x), "sliced %r utt %d" % (kw, u))
