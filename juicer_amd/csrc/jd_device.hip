@@ -832,6 +832,9 @@ struct jd_dec {
     int max_cw = MAXCW;                   // upper bound of workgroups per stream cluster (JD_CW overrides)
     int weighted = 1;                     // size the clusters by the work ahead of each stream (JD_WEIGHTED=0: uniform)
     double model_a_us = 10.0, model_b_us = 288.0;   // cost model of a stream-frame: a + b / workgroups (launch_search)
+    // b was fitted at configs[1]'s load (23.7 k instances + arcs per stream-frame); it scales with the load,
+    // which a decoder learns from the batches it has decoded (first batch: as fitted)
+    double load_scale = 1.0, load_sum = 0.0, load_frames = 0.0;
     int4 *d_work = nullptr; int work_cap = 0;
     int *d_status = nullptr; int *h_status = nullptr;
     long long *d_dbg = nullptr;           // in-kernel cycle accounting (jd_dec_debug_trace)
@@ -1268,6 +1271,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
         H.stats.tot_arcs_visited = K.st[ST_ARCS];
         H.stats.tot_paths = K.st[ST_PATHS];
         H.stats.tot_insts_in = K.st[ST_INSTS];
+        d->load_sum += (double)K.st[ST_INSTS] + (double)K.st[ST_ARCS]; d->load_frames += (double)K.frame;
         H.stats.ties = 0;
         int k = S.res_n;
         if (k > d->res_cap) {
@@ -1334,7 +1338,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // configs[1] (DESIGN.md "cluster sizes"); sizing by a stream's measured work per frame (a pilot
         // launch, or the previous chunk's counters) was tried and is slower - the work of the frames
         // ahead is not the work of the frames behind.
-        const double a_us = d->model_a_us, b_us = d->model_b_us;
+        const double a_us = d->model_a_us, b_us = d->model_b_us * d->load_scale;
         auto need = [&](double tau, std::vector<double> *out) {
             double tot = 0.0;
             for (int k = 0; k < n_work; ++k) {
@@ -1414,6 +1418,17 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         HIPCHK(hipMemcpy2D(head.data(), 16, d->d_ctl, sizeof(StreamCtl), 16, (size_t)d->max_streams, hipMemcpyDeviceToHost));
         std::vector<int2> rest;
         weight_now.clear();
+        if (d->load_scale == 1.0) {                                    // first batch of this decoder: learn the load right here
+            std::vector<long long> st((size_t)d->max_streams * ST_N);
+            HIPCHK(hipMemcpy2D(st.data(), ST_N * sizeof(long long), (const char *)d->d_ctl + offsetof(StreamCtl, st), sizeof(StreamCtl),
+                               ST_N * sizeof(long long), (size_t)d->max_streams, hipMemcpyDeviceToHost));
+            double work = 0.0, frames = 0.0;
+            for (const int2 &w : work_in) {
+                work += (double)st[(size_t)w.x * ST_N + ST_INSTS] + (double)st[(size_t)w.x * ST_N + ST_ARCS];
+                frames += (double)head[(size_t)w.x * 4];
+            }
+            if (frames > 0.0) d->load_scale = std::min(1e5, std::max(0.25, work / frames / 23700.0));
+        }
         if (frame_before.empty()) frame_before.assign((size_t)d->max_streams, f0);
         for (const int2 &w : work_in) {
             const int *h = head.data() + (size_t)w.x * 4;              // {frame, T, error, needs_init}
@@ -1599,6 +1614,11 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         if (rc) return rc;
         rc = fetch_results(d, 0, nb, out, 0, order.data() + u0);
         if (rc && first_err == JD_OK) first_err = rc;
+    }
+    if (d->load_frames > 0.0) {                                        // the load this batch had -> the next batch's cluster sizes
+        const double scale = std::min(1e5, std::max(0.25, d->load_sum / d->load_frames / 23700.0));
+        d->load_scale = (d->load_scale == 1.0) ? scale : 0.5 * (d->load_scale + scale);
+        d->load_sum = d->load_frames = 0.0;
     }
     for (int s = 0; s < d->max_streams; ++s) { d->stream_started[(size_t)s] = 0; d->stream_T[(size_t)s] = 0; }
     return first_err;
