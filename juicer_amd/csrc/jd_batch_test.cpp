@@ -100,6 +100,7 @@ static bool load_features(const char *path, int D, std::vector<float> &x, int32_
 int main(int argc, char **argv)
 {
     const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *mmf = 0, *list = 0;
+    const char *gramFsm = 0, *gramInSyms = 0, *gramOutSyms = 0;              // juicer.cpp:128-130: separate C.L and G
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
     int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0, nDevices = 0;
     std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
@@ -111,6 +112,8 @@ int main(int argc, char **argv)
         std::string a = argv[i];
         auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "-fsmFName") fsm = nxt(); else if (a == "-inSymsFName") insyms = nxt();
+        else if (a == "-gramFsmFName") gramFsm = nxt(); else if (a == "-gramInSymsFName") gramInSyms = nxt();
+        else if (a == "-gramOutSymsFName") gramOutSyms = nxt();
         else if (a == "-outSymsFName") outsyms = nxt(); else if (a == "-modelsFName") amf = nxt();
         else if (a == "-htkModelsFName") mmf = nxt();
         else if (a == "-inputFName") list = nxt(); else if (a == "-mainBeam") mainBeam = (float)atof(nxt());
@@ -132,7 +135,8 @@ int main(int argc, char **argv)
                         "       [-phoneEndBeam b] [-wordEmitBeam b] [-maxHyps n] [-lmScaleFactor s] [-insPenalty p] [-batch n] [-perFrameAdapter]\n"
                         "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles] [-refFName REF] [-removeSentMarks]\n"
                         "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n"
-                        "       [-device d | -devices N   (N GPUs of this node: utterances sharded, one RCCL gather of the 1-best)]\n");
+                        "       [-device d | -devices N   (N GPUs of this node: utterances sharded, one RCCL gather of the 1-best)]\n"
+                        "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S]   (-fsmFName is then C.L: composed with G on the device)]\n");
         return 2;
     }
     if (outputFName && outputFName[0] && strcmp(outputFName, "stdout") != 0) {     // DecoderBatchTest::openOutputFile
@@ -141,7 +145,18 @@ int main(int argc, char **argv)
     }
     jd_net *net = 0;
     const std::string netBin = std::string(fsm) + ".bin";                    // juicer.cpp:854-882
-    if (file_exists(netBin)) {
+    if (gramFsm) {
+        // -gramFsmFName switches to on-the-fly composition (juicer.cpp:332-333): -fsmFName is C.L, loaded with
+        // scale 1.0 (:933-940), the grammar with lmScaleFactor (:968-970); here the two are composed on the
+        // device and decoded by the static core (jd_net_compose)
+        jd_net *cl = 0, *g = 0;
+        if (jd_net_load_fsm(&cl, fsm, insyms, outsyms, 1.0f, 0.0f)) die("jd_net_load_fsm (C.L)");
+        if (jd_net_load_fsm(&g, gramFsm, gramInSyms, gramOutSyms, lmScale, 0.0f)) die("jd_net_load_fsm (G)");
+        if (jd_net_compose(&net, cl, g, device, 0, 0)) die("jd_net_compose");
+        fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs) composed on device %d: %d states, %lld arcs\n", (long long)jd_net_num_arcs(cl),
+                (long long)jd_net_num_arcs(g), device, (int)jd_net_num_states(net), (long long)jd_net_num_arcs(net));
+        jd_net_destroy(cl); jd_net_destroy(g);
+    } else if (file_exists(netBin)) {
         fprintf(stderr, "network from pre-existing binary file %s\n", netBin.c_str());
         if (jd_net_load_jwnt(&net, netBin.c_str(), lmScale, insPen)) die("jd_net_load_jwnt");
     } else {

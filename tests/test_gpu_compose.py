@@ -83,3 +83,33 @@ def test_compose_errors(built):
     g2.ilab = g2.ilab.copy(); g2.ilab[1] = g2.ilab[2]
     with pytest.raises(capi.JuicerAmdError):
         capi.Network.compose(ncl, capi.Network.from_synth(g2))
+
+
+def test_batch_test_cli_with_separate_grammar(built, tmp_path):
+    """juicer's -gramFsmFName mode (juicer.cpp:332-333, 594-598) through the C++ host: C.L and G from FSM
+    files, composed on the device, decoded; same words as decoding the Python-side composition."""
+    import subprocess
+    from juicer_amd import build as jbuild, capi, io as jio, synth
+    c = CASES[0]
+    am, cl, g, ncl, ng = _case(c)
+    jio.write_fsm(tmp_path / "cl.fsm", cl)
+    jio.write_fsm(tmp_path / "g.fsm", g)
+    jio.write_jdam(tmp_path / "m.jdam", am)
+    feats = [synth.sample_utterance(c["seed"] + 2000 + u, g, am, 5 + u)[0] for u in range(3)]
+    with open(tmp_path / "list.txt", "w") as f:
+        for u, x in enumerate(feats):
+            jio.write_jdf(tmp_path / ("u%d.jdf" % u), x)
+            f.write("%s\n" % (tmp_path / ("u%d.jdf" % u)))
+    out = subprocess.run([jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "cl.fsm"), "-gramFsmFName", str(tmp_path / "g.fsm"),
+                          "-modelsFName", str(tmp_path / "m.jdam"), "-inputFName", str(tmp_path / "list.txt"),
+                          "-mainBeam", "200", "-lmScaleFactor", str(c["lm"]), "-outputFormat", "ref"],
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr
+    assert "composed on device" in out.stderr
+    dev = capi.Network.compose(ncl, ng)
+    gs = capi.Decoder(dev, capi.Models.from_htk(am), max_streams=3, main_beam=200.0).decode_batch(feats)
+    lines = out.stdout.splitlines()
+    assert len(lines) == 3
+    for u in range(3):
+        assert gs[u].n > 0
+        assert [int(w) for w in lines[u].split()] == (gs[u].label[::-1] - 1).tolist()
