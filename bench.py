@@ -58,14 +58,15 @@ def roofline_of(st, max_n, tm, traffic=None):
             "launches_per_step": launches, "workgroups_per_stream": tm["cluster_wgs"]}
 
 
-def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=2):
-    """One extra workload: warm-up pass + timed pass(es) on one GPU, its own roofline."""
+def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=2, gnet=None):
+    """One extra workload: warm-up pass + timed pass(es) on one GPU, its own roofline.  gnet: a network
+    that exists already (composed on the device); net is then only asked for its size."""
     import torch
     from juicer_amd import capi
     U = len(feats)
     t0 = time.perf_counter()
-    dec = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam, max_hyps=max_hyps,
-                       device=dev.index, max_streams=U)
+    dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam,
+                       max_hyps=max_hyps, device=dev.index, max_streams=U)
     offs = np.zeros(U + 1, dtype=np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in feats])
     d_feats = torch.from_numpy(np.concatenate(feats)).to(dev)
@@ -104,6 +105,33 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=2):
     dec.close()
     del d_feats
     torch.cuda.empty_cache()
+    return out
+
+
+def compose_leg(seed, dev):
+    """BASELINE.json configs[4] (separate C.L and G) as far as it is built: the two transducers are composed
+    ON THE DEVICE (jd_net_compose) and the result is decoded by the static search; no oracle exists for the
+    reference's on-the-fly decoder (it is not built and no longer compiles), so this leg has no cpu line."""
+    from juicer_amd import capi, synth
+    am = synth.make_models(seed, n_gmm=3000, n_hmm=2000, n_mix=16, n_tm=8, sep=0.6, with_tee=True)
+    t0 = time.perf_counter()
+    cl, g = synth.make_cl_g(seed, am, n_words=20000, n_succ=40, n_tri=200000, n_succ3=8, with_sp=True)
+    t_gen = time.perf_counter() - t0
+    ncl, ng = capi.Network.from_synth(cl, 1.0, 0.0), capi.Network.from_synth(g, 10.0, 0.0)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        net = capi.Network.compose(ncl, ng, device=dev.index, max_states=1 << 26, max_arcs=1 << 27)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    feats = [synth.sample_utterance(seed + 100 + u, g, am, 8)[0] for u in range(64)]
+
+    class _Size:                                                   # what run_leg prints about the graph
+        n_arcs = net.n_arcs
+    out = run_leg("configs[4], composed on the device (lexicon tree o back-off trigram)", am, _Size, feats, 200.0, 0, dev, gnet=net)
+    out["composition"] = {"cl_arcs": int(cl.n_arcs), "g_arcs": int(g.n_arcs), "states": net.n_states, "arcs": net.n_arcs,
+                          "seconds_incl_pcie": round(best, 4), "arcs_per_s": round(net.n_arcs / best, 1),
+                          "generator_seconds": round(t_gen, 1)}
     return out
 
 
@@ -301,6 +329,8 @@ def main():
             del a4, n4, f4
             a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=8)
             legs["configs3_50M_beam300"] = run_leg("configs[3]", a4, n4, f4, 300.0, 0, dev)
+            del a4, n4, f4
+            legs["configs4_device_composition"] = compose_leg(args.seed, dev)
         except Exception as e:                                    # a leg must never take the headline down
             legs["error"] = repr(e)
         out["legs"] = legs
