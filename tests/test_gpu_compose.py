@@ -48,6 +48,22 @@ def test_device_composition_matches_offline_composition(built, c):
     assert all(np.array_equal(again[k], got[k]) for k in got)
 
 
+def test_composed_network_round_trips_through_the_binary_cache(built, tmp_path):
+    """The composed graph is an ordinary network: WFSTNetwork::writeBinary / readBinary counterparts keep it."""
+    from juicer_amd import capi
+    am, cl, g, ncl, ng = _case(CASES[2])
+    dev = capi.Network.compose(ncl, ng)
+    dev.save_jwnt(tmp_path / "clg.bin")
+    back = capi.Network.from_jwnt_file(tmp_path / "clg.bin", 1.0, 0.0)
+    a, b = dev.csr(), back.csr()
+    assert back.n_states == dev.n_states and back.init_state == dev.init_state
+    for k in ("row_ptr", "to", "ilab", "olab"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["w"].view(np.uint32), b["w"].view(np.uint32))
+    fa, fb = a["fin_w"], b["fin_w"]
+    assert np.array_equal(np.isfinite(fa), np.isfinite(fb)) and np.array_equal(fa[np.isfinite(fa)], fb[np.isfinite(fb)])
+
+
 @pytest.mark.parametrize("c", CASES[:2], ids=lambda c: "seed%d" % c["seed"])
 def test_decoding_the_device_composed_graph(built, c):
     """Static path on the device-composed graph == CPU oracle on the textbook composition."""
