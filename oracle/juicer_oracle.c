@@ -939,6 +939,220 @@ int jo_decode_utt(jo_dec *d, const float *feats, int32_t T, jo_hyp *out, double 
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * WFSTDecoderLiteThreading + HTKFlatModelsThreading (src/WFSTDecoderLiteThreading.cpp:78-287,
+ * src/HTKFlatModelsThreading.cpp:40-131): the reference's two-thread organisation.  The search
+ * thread's internal propagation runs in two passes: pass 1 (:178-286) does the transitions of every
+ * instance and, for every emitting state above the threshold whose output is not in the block
+ * cache, queues its GMM for the scoring thread; pass 2 (:120-170) adds the outputs in queue order
+ * as they become ready.  The scoring thread (calcStates, :110-129) computes the block of every
+ * queued GMM.  Results equal the single-thread core's (tests assert it); only the wall time differs.
+ * What is NOT taken over is the reference's queue, a list threaded through plain ints that both
+ * threads write without any synchronisation (its own comment calls the consequence "a very rare
+ * sync problem", :66-69): here a single-producer / single-consumer ring with C11 atomics carries
+ * the same GMM ids in the same order.  Like the reference (:57-60) it refuses models with more than
+ * one transition into the exit state.
+ */
+#include <pthread.h>
+#include <stdatomic.h>
+
+typedef struct {
+    jo_dec *d;
+    int32_t *ring;                          /* queued GMM ids (capacity n_gmm: a GMM is queued once per frame) */
+    atomic_long pushed, done;               /* totals since the utterance began */
+    atomic_int running;
+} ThreadQ;
+
+static void *scoring_thread(void *arg)      /* HTKFlatModelsThreading::calcStates, :110-129 */
+{
+    ThreadQ *q = (ThreadQ *)arg;
+    jo_dec *d = q->d;
+    long n = 0;
+    while (atomic_load_explicit(&q->running, memory_order_acquire)) {
+        if (atomic_load_explicit(&q->pushed, memory_order_acquire) > n) {
+            int32_t g = q->ring[n % d->am->n_gmm];
+            int32_t m = d->currInputLen < d->fnBlock ? d->currInputLen : d->fnBlock;   /* calcGMMOutput's block, HTKFlatModels.cpp:232-258 */
+            for (int32_t k = 0; k < m; ++k)
+                d->cache[(size_t)g * d->fnBlock + k] = gmm_one(d->am, g, d->currInput[k]);
+            d->cacheT[g] = d->amFrame;
+            ++n;
+            atomic_store_explicit(&q->done, n, memory_order_release);
+        }
+    }
+    return NULL;
+}
+
+typedef struct { int32_t inst, state, next; } WaitState;      /* WFSTDecoderLiteThreading.h WaitState + list link */
+
+/* WFSTDecoderLiteThreading::doHMMInternalPropagation, :78-176 (with HMMInternalPropagationPass1, :178-286) */
+static int do_internal_threading(jo_dec *d, ThreadQ *q, int32_t *wait_head, int32_t *wait_tail, int32_t *wait_gmms,
+                                 WaitState **pool, int32_t *pool_cap)
+{
+    const jo_am *am = d->am;
+    const int32_t maxN = am->max_n;
+    d->nActiveEmitHyps = d->nActiveEndHyps = d->nEmitProc = d->nEndProc = 0;
+    d->bestEmitScore = LZ;
+    int32_t waiting = -1, n_pool = 0;
+    const long base = atomic_load_explicit(&q->pushed, memory_order_relaxed);
+    int32_t prev = -1, inst = d->active;
+    while (inst >= 0) {
+        Tok *states = &d->toks[(size_t)inst * maxN];
+        Inst *I = &d->insts[inst];
+        if (states[0].score > LZ && states[0].score < d->startTh) {  /* :97-101 language model pruning */
+            states[0] = NULLTOK;
+            --I->nact;
+        }
+        ++d->st.tot_insts_in;
+        if (I->nact > 0) {                                           /* Pass1, :178-286 */
+            const int32_t N_1 = I->n - 1, tm = am->hmm_tm[I->hmm];
+            const float *trP = am->trP + (size_t)tm * maxN * maxN;
+            const int16_t *se = am->se + (size_t)tm * maxN * 2;
+            if (se[N_1 * 2 + 1] - se[N_1 * 2] != 1 || se[N_1 * 2] != N_1 - 1)
+                return fail(-1, "WFSTDecoderLiteThreading can not deal with HMMs with more than one to-exit transition");
+            I->nact = 0;
+            Tok *res = d->tokenBuf + 1;
+            for (int32_t j = 1; j < N_1; ++j, ++res) {
+                int32_t i = se[j * 2], endi = se[j * 2 + 1];
+                const Tok *cur = &states[i];
+                *res = *cur;
+                res->score += trP[i * maxN + j];
+                res->ac += trP[i * maxN + j];
+                for (++i, ++cur; i < endi; ++i, ++cur) {
+                    float tmpScore = cur->score + trP[i * maxN + j];
+                    if (tmpScore > res->score) { *res = *cur; res->score = tmpScore; res->ac += trP[i * maxN + j]; }
+                }
+                res->score -= d->normaliseScore;
+                if (res->score > d->emitTh) {
+                    ++d->nEmitProc;
+                    const int32_t g = am->hmm_gmm[(size_t)I->hmm * maxN + j];
+                    /* (queued already this frame: join the wait list without looking at a cache entry the other
+                     * thread may be writing; the reference reads it regardless, :234) */
+                    if (wait_head[g] < 0 && d->amFrame - d->cacheT[g] < d->fnBlock) {   /* cachedOutput, :52-60 */
+                        const float outp = d->cache[(size_t)g * d->fnBlock + (d->amFrame - d->cacheT[g])];
+                        res->score += outp;
+                        res->ac += outp;
+                        if (d->hist && hist_add(d->hist, res->score) != 0) d->err = -5;
+                        if (res->score > d->bestEmitScore) d->bestEmitScore = res->score;
+                        if (j == N_1 - 1) {                          /* :244-260 pass to exit state */
+                            Tok *ex = &states[N_1];
+                            *ex = *res;
+                            ex->score += trP[j * maxN + N_1];
+                            ex->ac += trP[j * maxN + N_1];
+                            ++I->nact;
+                            ++d->nActiveEndHyps;
+                        }
+                    } else {                                         /* :261-274 not calculated yet: queue */
+                        if (n_pool == *pool_cap) { *pool_cap *= 2; *pool = (WaitState *)realloc(*pool, sizeof(WaitState) * (size_t)*pool_cap); }
+                        if (wait_head[g] < 0) {
+                            ++waiting;
+                            wait_gmms[waiting] = g;
+                            q->ring[(base + waiting) % am->n_gmm] = g;                               /* addQueue, :102-108 */
+                            atomic_store_explicit(&q->pushed, base + waiting + 1, memory_order_release);
+                            wait_head[g] = n_pool;
+                        } else (*pool)[wait_tail[g]].next = n_pool;
+                        wait_tail[g] = n_pool;
+                        (*pool)[n_pool] = (WaitState){inst, j, -1};
+                        ++n_pool;
+                    }
+                } else *res = NULLTOK;
+            }
+            if ((res - 1)->score <= LZ) states[N_1] = NULLTOK;       /* :277-279 */
+            for (int32_t i = 0; i < N_1; ++i) {                      /* :283-291 */
+                if (d->tokenBuf[i].score > LZ) { ++I->nact; ++d->nActiveEmitHyps; }
+                states[i] = d->tokenBuf[i];
+            }
+        }
+        if (I->nact == 0) inst = return_inst(d, inst, prev);
+        else { prev = inst; inst = I->next; }
+    }
+    /* pass 2 (:120-170): the queued states, in queue order, as their GMMs become ready */
+    for (int32_t i = 0; i <= waiting; ++i) {
+        while (atomic_load_explicit(&q->done, memory_order_acquire) < base + i + 1) { /* nReadyStates() spin, :124-126 */ }
+        const int32_t g = wait_gmms[i];
+        const float outp = d->cache[(size_t)g * d->fnBlock + (d->amFrame - d->cacheT[g])];   /* readOutput, :62-73 */
+        for (int32_t k = wait_head[g]; k >= 0; k = (*pool)[k].next) {
+            const WaitState ws = (*pool)[k];
+            Inst *I = &d->insts[ws.inst];
+            Tok *res = &d->toks[(size_t)ws.inst * maxN + ws.state];
+            res->score += outp;
+            res->ac += outp;
+            if (d->hist && hist_add(d->hist, res->score) != 0) d->err = -5;
+            if (res->score > d->bestEmitScore) d->bestEmitScore = res->score;
+            const int32_t N_1 = I->n - 1;
+            if (ws.state == N_1 - 1) {                               /* :143-162 exit state */
+                const float *trP = am->trP + (size_t)am->hmm_tm[I->hmm] * maxN * maxN;
+                Tok *ex = res + 1;
+                *ex = *res;
+                ex->score += trP[ws.state * maxN + N_1];
+                ex->ac += trP[ws.state * maxN + N_1];
+                ++I->nact;
+                ++d->nActiveEndHyps;
+            }
+        }
+        wait_head[g] = wait_tail[g] = -1;
+    }
+    d->st.tot_active_emit_hyps += d->nActiveEmitHyps;
+    d->st.tot_active_end_hyps += d->nActiveEndHyps;
+    d->st.tot_proc_emit_hyps += d->nEmitProc;
+    return 0;
+}
+
+/* DecoderSingleTest's frame loop (as jo_decode_utt) over the two-thread core; wall_seconds is wall-clock
+ * time (two cores are busy: the scoring thread spins like the reference's) */
+int jo_decode_utt_threading(jo_dec *d, const float *feats, int32_t T, jo_hyp *out, double *wall_seconds)
+{
+    const int32_t D = d->am->D, G = d->am->n_gmm;
+    const float **rows = (const float **)malloc(sizeof(float *) * (size_t)(T > 0 ? T : 1));
+    for (int32_t t = 0; t < T; ++t) rows[t] = feats + (size_t)t * D;
+    ThreadQ q;
+    q.d = d; q.ring = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
+    atomic_init(&q.pushed, 0); atomic_init(&q.done, 0); atomic_init(&q.running, 1);
+    int32_t *wait_head = (int32_t *)malloc(sizeof(int32_t) * (size_t)G), *wait_tail = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
+    int32_t *wait_gmms = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
+    for (int32_t g = 0; g < G; ++g) wait_head[g] = wait_tail[g] = -1;
+    int32_t pool_cap = 4096;
+    WaitState *pool = (WaitState *)malloc(sizeof(WaitState) * (size_t)pool_cap);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int rc = jo_init(d);
+    pthread_t th;
+    if (rc == 0 && pthread_create(&th, NULL, scoring_thread, &q) != 0) rc = fail(-7, "pthread_create failed");
+    const int started = rc == 0;
+    int32_t nFrames = 0, nData = T < 20 ? T : 20;                   /* DecoderSingleTest.cpp:267-295 */
+    while (rc == 0 && nData > 0) {
+        /* processFrame (WFSTDecoderLite.cpp:311-372) with the threading core's internal propagation */
+        d->currFrame = nFrames;
+        rc = am_new_frame(d, nFrames, &rows[nFrames], nData);
+        if (rc) break;
+        d->bestFinal = NULLTOK;
+        d->normaliseScore = (d->bestEmitScore > LZ ? d->bestEmitScore : 0.0f);
+        if (d->hist) {
+            d->emitTh = hist_thresh(d->hist, d->maxHyps);
+            d->emitTh -= d->normaliseScore;
+            if (d->emitWin > 0.0 && d->emitTh < -d->emitWin) d->emitTh = -d->emitWin;
+            hist_reset(d->hist);
+        } else d->emitTh = (d->emitWin > 0.0 ? -d->emitWin : LZ);
+        d->startTh = (d->startWin > 0.0 ? (d->bestEmitScore - d->startWin) : LZ);
+        rc = do_internal_threading(d, &q, wait_head, wait_tail, wait_gmms, &pool, &pool_cap);
+        if (rc) break;
+        d->endTh = (d->endWin > 0.0 ? (d->bestEmitScore - d->endWin) : LZ);
+        d->wordTh = (d->wordWin > 0.0 ? (d->bestEmitScore - d->wordWin) : LZ);
+        do_external(d);
+        if (d->err == -5) { rc = fail(-5, "Histogram::addScore - score > maxScore"); break; }
+        ++nFrames;
+        if (!(nFrames + nData - 1 < T)) --nData;
+    }
+    if (started) {
+        atomic_store_explicit(&q.running, 0, memory_order_release);
+        pthread_join(th, NULL);
+    }
+    if (rc == 0) rc = jo_finish(d, out);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (wall_seconds) *wall_seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    free(rows); free(q.ring); free(wait_head); free(wait_tail); free(wait_gmms); free(pool);
+    return rc;
+}
+
 /* equal-score recombinations by kind (see jo_stats.ties): bestFinalToken (:513-520), entry
  * token (:560-582), HMM-internal max over predecessors (:393-406, :459: lowest index wins, an
  * order every implementation shares), and the entry-token ties whose two tokens actually differ */

@@ -82,6 +82,11 @@ int jo_decode_utt(jo_dec *d, const float *feats, int32_t n_frames, jo_hyp *out, 
 /* per-frame trace for debugging parity: bestEmitScore after each frame */
 int jo_set_trace(jo_dec *d, float *best_emit_per_frame, int32_t cap);
 
+/* The reference's two-thread organisation (WFSTDecoderLiteThreading + HTKFlatModelsThreading): the
+ * frame loop of jo_decode_utt over a search thread and a scoring thread.  Same results as
+ * jo_decode_utt; wall_seconds is wall-clock time with two busy cores. */
+int jo_decode_utt_threading(jo_dec *d, const float *feats, int32_t T, jo_hyp *out, double *wall_seconds);
+
 /* PARTIAL_DECODING (WFSTDecoderLite.cpp:822-896): jo_set_partial_interval = setPartialDecodeOptions
  * (the reference reads it from the environment variable PartialTraceInterval, :116-119);
  * jo_trace_partial = tracePartialPath on the current state (the frame loop calls it on the

@@ -188,7 +188,10 @@ class OracleDecoder:
                                C.c_float(end_beam), C.c_float(word_beam), C.c_int32(max_hyps),
                                C.c_int32(block_size)))
 
-    def decode(self, feats, trace: Optional[np.ndarray] = None, tie_mode: int = 0) -> OracleHyp:
+    def decode(self, feats, trace: Optional[np.ndarray] = None, tie_mode: int = 0, threading: bool = False) -> OracleHyp:
+        """threading=True: the reference's two-thread organisation (WFSTDecoderLiteThreading +
+        HTKFlatModelsThreading: search thread + scoring thread); same results, cpu_seconds is then WALL time
+        with two busy cores."""
         L = lib()
         x = _f32(feats)
         L.jo_dec_set_tie_mode(self.h, C.c_int(tie_mode))
@@ -198,7 +201,8 @@ class OracleDecoder:
             L.jo_set_trace(self.h, None, C.c_int32(0))
         hyp = _Hyp()
         secs = C.c_double(0.0)
-        _check(L.jo_decode_utt(self.h, _p(x, C.c_float), C.c_int32(x.shape[0]), C.byref(hyp), C.byref(secs)))
+        fn = L.jo_decode_utt_threading if threading else L.jo_decode_utt
+        _check(fn(self.h, _p(x, C.c_float), C.c_int32(x.shape[0]), C.byref(hyp), C.byref(secs)))
         n = hyp.n
         k = max(n, 0)
 

@@ -135,3 +135,31 @@ def test_oracle_partial_decoding(built):
     # the decoder is reusable afterwards and unaffected
     o2 = od.decode(x)
     assert o2.n == o.n and np.array_equal(o2.label, o.label)
+
+
+def test_oracle_two_thread_core_gives_the_same_results(built):
+    """WFSTDecoderLiteThreading + HTKFlatModelsThreading restated (search thread + scoring thread): results,
+    scores and the reference's statistics equal the single-thread core's; models with a skip into the exit
+    state are refused like the reference does (WFSTDecoderLiteThreading.cpp:45-60)."""
+    from juicer_amd import synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small()
+    for kw in (dict(main_beam=150.0, max_hyps=200), dict(main_beam=200.0, end_beam=120.0, word_beam=100.0, start_beam=150.0), dict()):
+        od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+        for x in feats[:3]:
+            a, b = od.decode(x), od.decode(x, threading=True)
+            assert a.n == b.n and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
+            for f in ("score", "ac", "lm"):
+                assert np.array_equal(getattr(a, f).view(np.uint32), getattr(b, f).view(np.uint32)), f
+            for k in a.stats:
+                if k != "ties":
+                    assert a.stats[k] == b.stats[k], k
+    am2, net2, feats2, _ = synth.config_mixed()
+    od2 = OracleDecoder(OracleNet(net2), OracleAM(am2), main_beam=150.0)
+    try:
+        od2.decode(feats2[0], threading=True)
+        refused = False
+    except RuntimeError as e:
+        refused = "to-exit transition" in str(e)
+    skips = any(int((am2.transp[t, 1:n - 2, n - 1] > 0).any()) for t, n in enumerate(am2.tm_nstates))
+    assert refused == skips
