@@ -687,8 +687,8 @@ __global__ void jd_set_T_kernel(StreamCtl *ctl, int s0, int n, const int *T)
 __global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int *status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ctl[work[i].x].bar = 0u;
-    if (i == 0) *status = 0;
+    if (i < n) { StreamCtl &c = ctl[work[i].x]; c.bar = 0u; c.xbar = 0u; c.xmask = 0u; }
+    if (i == 0) { status[0] = 0; status[1] = 0; }
 }
 
 // --------------------------------------------------------------- host runtime
@@ -837,6 +837,7 @@ struct jd_dec {
     double load_scale = 1.0, load_sum = 0.0, load_frames = 0.0;
     int4 *d_work = nullptr; int work_cap = 0;
     int *d_status = nullptr; int *h_status = nullptr;
+    bool xl_ok = true;                    // XCD-local launches allowed (JD_XCD_LOCAL=0 or one failed placement check switch them off)
     long long *d_dbg = nullptr;           // in-kernel cycle accounting (jd_dec_debug_trace)
     // chunked pipeline
     int Fc = 128;                         // frames per scoring chunk of the streaming API (jd_stream_push)
@@ -1015,6 +1016,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_WEIGHTED")) d->weighted = atoi(e) != 0;
     if (const char *e = getenv("JD_MODEL_A")) d->model_a_us = atof(e);
     if (const char *e = getenv("JD_MODEL_B")) d->model_b_us = atof(e);
+    if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0;                      // development
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
     hipError_t e;
@@ -1159,9 +1161,9 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
     if (rc) return rc;
     rc = dmalloc(d, &d->d_ctl, (size_t)B);
     if (rc) return rc;
-    rc = dmalloc(d, &d->d_status, 1);
+    rc = dmalloc(d, &d->d_status, 2);
     if (rc) return rc;
-    HIPCHK(hipHostMalloc((void **)&d->h_status, sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&d->h_status, 2 * sizeof(int)));
     {
         std::vector<StreamCtl> hc((size_t)B);
         memset(hc.data(), 0, hc.size() * sizeof(StreamCtl));
@@ -1329,6 +1331,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     std::vector<int4> work((size_t)n_work);
     for (int k = 0; k < n_work; ++k) work[(size_t)k] = make_int4(work_in[(size_t)k].x, work_in[(size_t)k].y, k * A.Cw, A.Cw);
     int grid = A.n_slots * A.Cw;
+    bool xl = false;
     if (weight && d->weighted && n_work > 1 && max_cw > 1 && nwg >= 2 * n_work) {
         // Weighted mode.  weight[k] = frames stream k has in this launch.  A stream's frame costs about
         // a + b / workgroups  (a: the barriers and list set-up of a frame; b: the part that divides over
@@ -1374,36 +1377,68 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             if (cw[(size_t)big] <= 1) break;
             --cw[(size_t)big]; --used;
         }
-        int first = 0;
-        for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw[(size_t)k]; first += cw[(size_t)k]; }
-        grid = first;
+        // XCD-local launch (jd_search.h): every cluster inside one eighth of the grid - the clusters go, largest
+        // first, into the eighth with the most room; one that fits nowhere shrinks to the room there is
+        const int bin = nwg / 8;
+        if (d->xl_ok && (nwg & 7) == 0) {
+            std::vector<int> order((size_t)n_work), pos((size_t)n_work, 0), room(8, bin), cwx = cw;
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cwx[(size_t)x] > cwx[(size_t)y]; });
+            bool fits = true;
+            for (int k : order) {
+                int b = 0;
+                for (int q = 1; q < 8; ++q) if (room[(size_t)q] > room[(size_t)b]) b = q;
+                if (room[(size_t)b] <= 0) { fits = false; break; }
+                cwx[(size_t)k] = std::min(cwx[(size_t)k], room[(size_t)b]);
+                pos[(size_t)k] = b * bin + (bin - room[(size_t)b]);
+                room[(size_t)b] -= cwx[(size_t)k];
+            }
+            if (fits) {
+                for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = pos[(size_t)k]; work[(size_t)k].w = cwx[(size_t)k]; }
+                std::sort(work.begin(), work.end(), [](const int4 &x, const int4 &y) { return x.z < y.z; });   // (the kernel searches by first workgroup)
+                grid = nwg;
+                xl = true;
+            }
+        }
+        if (!xl) {
+            int first = 0;
+            for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw[(size_t)k]; first += cw[(size_t)k]; }
+            grid = first;
+        }
         A.n_slots = 0;
-    }
+    } else if (d->xl_ok && A.Cw > 1 && (grid & 7) == 0 && ((grid >> 3) % A.Cw) == 0) xl = true;   // uniform clusters that tile the eighths
     HIPCHK(hipMemcpyAsync(d->d_work, work.data(), (size_t)n_work * sizeof(int4), hipMemcpyHostToDevice, st));
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
     A.status = d->d_status; A.dbg = d->d_dbg;
+    A.xl_selftest = getenv("JD_XL_SELFTEST") ? 1 : 0;                 // (test knob, see SearchArgs)
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
         HIPCHK(hipEventRecord(e0, st));
-        if (ne3) hipLaunchKernelGGL(k_search<3>, dim3(grid), dim3(SNT), 0, st, A);
-        else hipLaunchKernelGGL(k_search<6>, dim3(grid), dim3(SNT), 0, st, A);
+        if (ne3) { if (xl) hipLaunchKernelGGL((k_search<3, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<3, false>), dim3(grid), dim3(SNT), 0, st, A); }
+        else { if (xl) hipLaunchKernelGGL((k_search<6, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false>), dim3(grid), dim3(SNT), 0, st, A); }
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) d->timing.search_ms += ms;
         if (getenv("JD_VERBOSE")) {                                        // development
             int cmin = 1 << 30, cmax = 0;
             for (const int4 &w : work) { cmin = std::min(cmin, w.w); cmax = std::max(cmax, w.w); }
-            fprintf(stderr, "k_search: %d streams, grid %d (clusters %d..%d workgroups, %s), frames [%d, %d): %.3f ms\n", n_work, grid,
-                    cmin, cmax, A.n_slots ? "uniform" : "weighted", f0, f_end, ms);
+            fprintf(stderr, "k_search: %d streams, grid %d (clusters %d..%d workgroups, %s%s), frames [%d, %d): %.3f ms\n", n_work, grid,
+                    cmin, cmax, A.n_slots ? "uniform" : "weighted", xl ? ", XCD-local" : "", f0, f_end, ms);
+        }
+        if (d->h_status[1] != 0) {
+            // a cluster of an XCD-local launch found itself on several XCDs and left its stream untouched: from
+            // now on this decoder launches the agent-scope kernel (the loop below repeats the launch)
+            d->xl_ok = false;
+            if (getenv("JD_VERBOSE")) fprintf(stderr, "k_search: %d cluster(s) not on one XCD - agent-scope launches from here on\n", d->h_status[1]);
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         d->timing.search_launches += 1;
         d->timing.cluster_wgs = A.Cw;
-        if (*d->h_status == 0) break;
+        if (d->h_status[0] == 0 && d->h_status[1] == 0) break;
         d->timing.relaunches += 1;
         if (it >= max_rounds) return jd_fail(JD_ENOMEM, "Path arena too small: no progress after %d garbage collections", it);
         // Some streams stopped for a collection of their Path records (k_gc_*: no-ops for the streams below

@@ -100,6 +100,7 @@ struct __align__(128) StreamCtl {
     int pad0[24];
     __align__(128) int new_all[2];           // arcs entered without an instance in a frame of that parity (listed or not)
     __align__(128) unsigned bar;             // cluster barrier (zeroed by the host before every launch)
+    __align__(128) unsigned xbar, xmask;     // placement handshake of an XCD-local launch (agent scope; zeroed with bar)
     __align__(128) unsigned bestA[2];        // ordered-uint best emitting score of phase A, by frame parity
     __align__(128) unsigned bestX[2];        // ... best entry-token candidate of phase X
     __align__(128) int n_paths;              // Path records in use
@@ -144,7 +145,10 @@ struct SearchArgs {
                              // 0 = weighted mode: work item k owns workgroups [work[k].z, work[k].z + work[k].w)
     const float *ll; long long ll_stride; int f0;   // likelihoods: ll[slot * ll_stride + (f - f0) * G + g]
     int f_end;               // process frames < min(T, f_end)
-    int *status;             // += 1 for every stream that stopped early (Path garbage collection needed)
+    int xl_selftest;         // test knob: an XCD-local launch numbers its workgroups in dispatch order, which puts every
+                             // cluster on several XCDs - the placement check has to catch it
+    int *status;             // [0] += 1 for every stream that stopped early (Path garbage collection needed);
+                             // [1] += 1 for every cluster of an XCD-local launch that found itself on several XCDs
     long long *dbg;          // optional: per-workgroup cycle accounting (jd_dec_debug_trace)
 };
 
@@ -166,10 +170,42 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigne
 }
 // 16-byte agent-scope (sc1) accesses through a wave-uniform buffer descriptor (out-of-range
 // offsets read 0 / are dropped by the hardware bounds check)
+// Two ways of making a stream's mutable words visible to the other workgroups of its cluster.
+//   XL = false  agent scope: `sc1` (write-through) stores, agent-scope atomics; right wherever the
+//               workgroups run.  An `sc1` store (and an agent-scope atomic) drops its line from the XCD's
+//               L2, so even a reader on the same XCD goes to memory for it.
+//   XL = true   the cluster sits on ONE XCD (checked at run time, see run_stream): plain stores keep their
+//               lines in that XCD's L2 and workgroup-scope atomics execute there - every hop between the
+//               cluster's workgroups is an L2 hit.  Loads are `sc1` (L1 bypass, L2-served) either way: a
+//               CU's vector L1 is never refreshed by another CU's stores.
+// The functions below are used through the macros st16 / CS / GMAX / GADD, which pick the flavour of
+// the enclosing function's `XL_`.
 __device__ __forceinline__ v4i ld16(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX_SC1); }
-__device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, unsigned off, v4i v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, AUX_SC1); }
 template <typename T> __device__ __forceinline__ T CL(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ void CS(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool XL> __device__ __forceinline__ void st16x(__amdgpu_buffer_rsrc_t r, unsigned off, v4i v)
+{
+    if (XL) __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, AUX_SC1);
+}
+template <bool XL, typename T> __device__ __forceinline__ void CSx(T *p, T v)
+{
+    if (XL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XL, typename T, typename U> __device__ __forceinline__ T GMAXx(T *p, U v)
+{
+    return XL ? __hip_atomic_fetch_max(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+              : __hip_atomic_fetch_max(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XL, typename T, typename U> __device__ __forceinline__ T GADDx(T *p, U v)
+{
+    return XL ? __hip_atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+              : __hip_atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define st16(r, off, ...) st16x<XL_>(r, off, __VA_ARGS__)
+#define CS(p, ...) CSx<XL_>(p, __VA_ARGS__)
+#define GMAX(p, ...) GMAXx<XL_>(p, __VA_ARGS__)
+#define GADD(p, ...) GADDx<XL_>(p, __VA_ARGS__)
 __device__ __forceinline__ Tok as_tok(v4i v) { Tok t; t.score = __int_as_float(v.x); t.ac = __int_as_float(v.y); t.lm = __int_as_float(v.z); t.path = v.w; return t; }
 __device__ __forceinline__ v4i as_v4(const Tok &t) { v4i v; v.x = __float_as_int(t.score); v.y = __float_as_int(t.ac); v.z = __float_as_int(t.lm); v.w = t.path; return v; }
 __device__ __forceinline__ Tok null_tok() { Tok t; t.score = LZ; t.ac = LZ; t.lm = LZ; t.path = -1; return t; }
@@ -297,8 +333,10 @@ __device__ __forceinline__ int grab_chunk(SearchShared &sh, int jw, int Cw)
 }
 
 // ---- cluster barrier: all Cw workgroups of one stream.  target = Cw * (number of this barrier).
+template <bool XL>
 __device__ __forceinline__ void cluster_barrier(SearchShared &sh, StreamCtl &c, int Cw, unsigned &nbar, long long t_limit)
 {
+    constexpr bool XL_ = XL;
     // every wave: its write-through stores and atomics have been performed before anybody is told
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -306,7 +344,7 @@ __device__ __forceinline__ void cluster_barrier(SearchShared &sh, StreamCtl &c, 
     if (threadIdx.x == 0) {
         sh.next = 0;
         if (Cw > 1) {
-            __hip_atomic_fetch_add(&c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            GADD(&c.bar, 1u);
             const unsigned target = nbar * (unsigned)Cw;
             unsigned spins = 0;
             while (CL(&c.bar) < target) {
@@ -411,12 +449,13 @@ __device__ __forceinline__ unsigned rec_chunk_off(unsigned seg_rec, int w, int c
 #define XFINE_COUNT(k) do { } while (0)
 #endif
 
-template <int NE, bool TRPL, bool LR>
+template <int NE, bool TRPL, bool LR, bool XL>
 __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
                                         const Geo &gin, const Geo &gout, const int (&Q)[4], int jw, int Cw, int gw, int p,
                                         float normalise, float emitTh, float startTh, const float *llrow,
                                         int &out_cnt, int &exit_cnt)
 {
+    constexpr bool XL_ = XL;
     typedef RecLayout<NE> RL;
     constexpr int HF = RL::HF;
     const int lane = threadIdx.x & 63;
@@ -636,7 +675,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 const unsigned ioff = has_exit ? icur + k * 32u : OOB_OFF;
                 st16(V.items, ioff, as_v4(ex));
                 st16(V.items, ioff + 16u, (v4i){arc, h0.z, h0.w, 0});
-                if (has_exit) atomicMax((h0.z != 0 ? V.skeyL : V.skey0) + h0.w, ((unsigned long long)f2o(ex.score) << 32) | k);
+                if (has_exit) GMAX((h0.z != 0 ? V.skeyL : V.skey0) + h0.w, ((unsigned long long)f2o(ex.score) << 32) | k);
                 exit_cnt += nex;
                 c_end += nex;
             }
@@ -704,11 +743,13 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
 // candidate arrives that is not hopeless; an arc whose first candidate was hopeless goes to the
 // clean-up list so that its key does not outlive the frame.
 struct XOut { int item_cnt; int new_cnt; int clean_cnt; int dirty_cnt; };
+template <bool XL>
 __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
                                         const Geo &gin, const Geo &gout, int Q, int KX, int round, int jw, int Cw, int gw,
                                         int p, int pframe, bool init, bool last_frame, float endTh, float wordTh,
                                         float bestA, XOut &out, int &deferred)
 {
+    constexpr bool XL_ = XL;
     const int lane = threadIdx.x & 63;
     const int wid = RFL(threadIdx.x >> 6);
     const float INF = __builtin_inff();
@@ -773,7 +814,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         int pbase = 0;
         if (blab) {
             const int first = __ffsll((long long)blab) - 1;
-            if (lane == first) pbase = atomicAdd(&c.n_paths, __popcll(blab));
+            if (lane == first) pbase = GADD(&c.n_paths, __popcll(blab));
             pbase = __shfl(pbase, first);
         }
         XFINE(1);                                                      // hop 2: row bounds, state key, Path reservation
@@ -803,7 +844,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 const float fw = C.fin_w[info.z];
                 if (fw < INF) {
                     const float cs = t.score + fw;
-                    if (cs > LZ) atomicMax(&c.final_key, ((unsigned long long)f2o(cs) << 32) | ii);
+                    if (cs > LZ) GMAX(&c.final_key, ((unsigned long long)f2o(cs) << 32) | ii);
                 }
             }
         }
@@ -884,7 +925,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             float tmax = 0.0f;
             if (entry) {
                 lv = CL(&as->live);
-                old = atomicMax(&as->key, ((unsigned long long)so << 32) | iig);
+                old = GMAX(&as->key, ((unsigned long long)so << 32) | iig);
                 if (can_filter) tmax = C.hmm_tmax0[inl - 1];
             }
             if ((on && inl == 0) || is_tee) skc = CL(V.skeyC + Bk.to);
@@ -942,7 +983,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                     bool keep = false, first = false;
                     if (pass) {
                         const unsigned long long key = ((unsigned long long)sou << 32) | k;
-                        const unsigned long long cold = atomicMax(V.skeyC + Bk.to, key);
+                        const unsigned long long cold = GMAX(V.skeyC + Bk.to, key);
                         keep = key > cold; first = cold == 0ULL;
                     }
                     const unsigned long long bk = __ballot(keep), bf = __ballot(first);
@@ -986,9 +1027,10 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
 
 // ------------------------------------------------------------------ one stream, one launch
 
-template <int NE>
+template <int NE, bool XL>
 __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw)
 {
+    constexpr bool XL_ = XL;
     typedef RecLayout<NE> RL;
     const DecConst &C = A.C;
     StreamCtl &c = A.ctl[s];
@@ -1036,6 +1078,32 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     __syncthreads();
     unsigned nbar = 0;
     const long long t_limit = wall_clock64() + 3000000000LL;           // 30 s at 100 MHz: a lost workgroup, not a slow one
+    if (XL && Cw > 1) {
+        // XCD-local launch: nothing promises where workgroups run, so the cluster first makes sure it does
+        // sit on one XCD - every workgroup ORs its XCC id into a mask and arrives at a counter (agent-scope
+        // read-modify-writes: performed at the memory side, whatever the placement), then reads the mask
+        // the same way.  A cluster that is spread out leaves the stream untouched; the host repeats the
+        // launch with the agent-scope kernel.
+        if (tid == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;   // HW_REG_XCC_ID[3:0]
+            (void)__hip_atomic_fetch_or(&c.xmask, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            (void)__hip_atomic_fetch_add(&c.xbar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_fetch_add(&c.xbar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)Cw) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0 && wall_clock64() > t_limit) { sh.abort = 1; break; }
+            }
+            const unsigned mask = __hip_atomic_fetch_or(&c.xmask, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__popc(mask) != 1) sh.abort = 2;
+        }
+        __syncthreads();
+        if (sh.abort == 2) {                                           // every workgroup of the cluster sees the same mask
+            if (jw == 0 && tid == 0) atomicAdd(A.status + 1, 1);
+            return;
+        }
+        if (sh.abort) { if (tid == 0 && jw == 0) { c.error = JDE_BARRIER; c.needs_init = 0; } return; }
+    }
     int frames_done = 0;
     int my_item_end = 0;                                               // items this wave wrote in the last processed frame
     bool aborted = false, failed = false;
@@ -1075,7 +1143,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             Tok z; z.score = 0.0f; z.ac = 0.0f; z.lm = 0.0f; z.path = -1;
             st16(V.items, V.item_par, as_v4(z)); st16(V.items, V.item_par + 16u, (v4i){-1, 0, 0, 0});
         }
-        cluster_barrier(sh, c, Cw, nbar, t_limit);
+        cluster_barrier<XL>(sh, c, Cw, nbar, t_limit);
         aborted = sh.abort != 0;
         // every workgroup has read the old lists (possibly written with another geometry): they are
         // gone, this launch's geometry applies and every segment starts empty - except wave 0's
@@ -1085,7 +1153,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             CS(tot_of(TOT_REC0) + gw, 0); CS(tot_of(TOT_REC1) + gw, 0);
             CS(tot_of(TOT_EXIT) + gw, gw == 0 ? 1 : 0);
         }
-        cluster_barrier(sh, c, Cw, nbar, t_limit);
+        cluster_barrier<XL>(sh, c, Cw, nbar, t_limit);
         aborted = aborted || sh.abort != 0;
         f = 0;
     }
@@ -1131,9 +1199,9 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const float *llrow = A.ll + (size_t)ll_slot * A.ll_stride + (size_t)(f - A.f0) * C.G;
             int out_cnt = 0;
             CLK(0);                                                    // thresholds + work lists
-            if (lr) phase_a<NE, true, true>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else if (trp_lds) phase_a<NE, true, false>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else phase_a<NE, false, false>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            if (lr) phase_a<NE, true, true, XL>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else if (trp_lds) phase_a<NE, true, false, XL>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else phase_a<NE, false, false, XL>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
             CLK(1);                                                    // phase A (wave 0's share)
             if (lane == 0) {
                 CS(tot_of(TOT_REC0 + (p ^ 1)) + gw, out_cnt);
@@ -1143,11 +1211,11 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             if (use_hist)                                              // Histogram of this frame: workgroup bins -> stream bins
                 for (int b = tid; b < C.hist_nbins; b += SNT) {
                     const int v = sh.hist[b];
-                    if (v) { atomicAdd(V.hist + (size_t)p * HIST_MAX_BINS + b, v); sh.hist[b] = 0; }
+                    if (v) { GADD(V.hist + (size_t)p * HIST_MAX_BINS + b, v); sh.hist[b] = 0; }
                 }
-            if (tid == 0 && sh.best) { atomicMax(&c.bestA[p], sh.best); sh.best = 0u; }
+            if (tid == 0 && sh.best) { GMAX(&c.bestA[p], sh.best); sh.best = 0u; }
             CLK(2);                                                    // waiting for the workgroup's other waves + publishing
-            cluster_barrier(sh, c, Cw, nbar, t_limit);
+            cluster_barrier<XL>(sh, c, Cw, nbar, t_limit);
             if (sh.abort) { aborted = true; break; }
             gin = gout;                                                // every list read from here on was written by this launch
             CLK(3);                                                    // cluster barrier 1
@@ -1196,7 +1264,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             CLK(4);                                                    // phase X work lists
             const int round_start = xo.item_cnt;
             int deferred = 0;
-            phase_x(C, sh, c, V, gin, gout, Q, KX, round, jw, Cw, gw, p, init ? 0 : f, init, last_frame, endTh, wordTh, bestA, xo, deferred);
+            phase_x<XL>(C, sh, c, V, gin, gout, Q, KX, round, jw, Cw, gw, p, init ? 0 : f, init, last_frame, endTh, wordTh, bestA, xo, deferred);
             CLK(5);                                                    // phase X (wave 0's share)
             if (lane == 0) {
                 CS(tot_of(TOT_CL0 + ((round + 1) & 1)) + gw, deferred > 0 ? xo.item_cnt - round_start : 0);
@@ -1207,11 +1275,11 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             }
             __syncthreads();
             if (tid == 0) {
-                if (sh.best) { atomicMax(&c.bestX[p], sh.best); sh.best = 0u; }
-                if (sh.new_all) { atomicAdd(&c.new_all[p], sh.new_all); sh.new_all = 0; }
+                if (sh.best) { GMAX(&c.bestX[p], sh.best); sh.best = 0u; }
+                if (sh.new_all) { GADD(&c.new_all[p], sh.new_all); sh.new_all = 0; }
             }
             CLK(6);                                                    // waiting for the workgroup's other waves + publishing
-            cluster_barrier(sh, c, Cw, nbar, t_limit);
+            cluster_barrier<XL>(sh, c, Cw, nbar, t_limit);
             if (sh.abort) { aborted = true; break; }
             CLK(7);                                                    // cluster barriers of phase X
         }
@@ -1274,19 +1342,22 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
 // one stream per workgroup): stream k owns the workgroups [first_k, first_k + n_k) - the host sizes
 // the clusters by the streams' recent load.  All workgroups of the grid must be resident at once:
 // the host sizes the grid to the device (one 1024-thread workgroup per CU).
-template <int NE>
+template <int NE, bool XL>
 __global__ __launch_bounds__(SNT) void k_search(SearchArgs A)
 {
     __shared__ SearchShared sh;
     int k, kstep, jw, Cw;
+    // XCD-local launch: workgroup b is expected on XCD b % 8 (observed dispatch order - run_stream checks),
+    // so the workgroups are numbered XCD by XCD and the host keeps every cluster inside one eighth of the grid
+    const unsigned wg = (XL && !A.xl_selftest) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     if (A.n_slots > 0) {
-        k = (int)(blockIdx.x / (unsigned)A.Cw); jw = (int)(blockIdx.x % (unsigned)A.Cw); Cw = A.Cw; kstep = A.n_slots;
+        k = (int)(wg / (unsigned)A.Cw); jw = (int)(wg % (unsigned)A.Cw); Cw = A.Cw; kstep = A.n_slots;
     } else {
-        int lo = 0, hi = A.n_work - 1;                                 // last k with first_k <= blockIdx.x
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (RFL(A.work[mid].z) <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+        int lo = 0, hi = A.n_work - 1;                                 // last k with first_k <= wg
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (RFL(A.work[mid].z) <= (int)wg) lo = mid; else hi = mid - 1; }
         const int first = RFL(A.work[lo].z);
-        Cw = RFL(A.work[lo].w); jw = (int)blockIdx.x - first;
+        Cw = RFL(A.work[lo].w); jw = (int)wg - first;
         k = (jw < Cw) ? lo : A.n_work; kstep = A.n_work;
     }
-    for (; k < A.n_work; k += kstep) run_stream<NE>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw);
+    for (; k < A.n_work; k += kstep) run_stream<NE, XL>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw);
 }

@@ -810,3 +810,40 @@ def test_states_with_many_arcs_are_sliced(built):
         gs = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=3, **kw).decode_batch(feats)
         for u, x in enumerate(feats):
             assert_hyp_matches(gs[u], od.decode_certified(x), "sliced %r utt %d" % (kw, u))
+
+
+def test_xcd_local_launch_and_its_fallback(small, capfd):
+    """Clusters are launched XCD-local (plain stores, workgroup-scope atomics) when they fit an eighth of the
+    grid; a cluster that finds itself on several XCDs must leave its stream untouched and the agent-scope
+    kernel take over.  JD_XL_SELFTEST numbers the workgroups in dispatch order, which spreads every cluster
+    over XCDs: results must be unaffected and the fallback must have happened."""
+    import os
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0, max_hyps=200)
+    od = OracleDecoder(onet, oam, **kw)
+    want = [od.decode_certified(x) for x in feats]
+    batch = [feats[i % len(feats)] for i in range(16)]
+    for selftest in (False, True):
+        env = {"JD_VERBOSE": "1"}
+        if selftest:
+            env["JD_XL_SELFTEST"] = "1"
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            gd = capi.Decoder(gnet, gam, max_streams=16, **kw)
+            for rep in range(3):
+                gs = gd.decode_batch(batch)
+                for i, g in enumerate(gs):
+                    assert_hyp_matches(g, want[i % len(feats)], "xcd-local selftest=%s rep %d utt %d" % (selftest, rep, i))
+                    assert bit_exact(g, want[i % len(feats)])
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        err = capfd.readouterr().err
+        assert "XCD-local" in err, err[-400:]
+        assert ("not on one XCD" in err) == selftest, err[-600:]
