@@ -1385,14 +1385,17 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             std::iota(order.begin(), order.end(), 0);
             std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cwx[(size_t)x] > cwx[(size_t)y]; });
             bool fits = true;
-            for (int k : order) {
+            int shrunk = 0;                                            // workgroups the packing takes away (big clusters are what
+            for (int k : order) {                                      // heavy loads need: then the agent-scope launch is the better one)
                 int b = 0;
                 for (int q = 1; q < 8; ++q) if (room[(size_t)q] > room[(size_t)b]) b = q;
                 if (room[(size_t)b] <= 0) { fits = false; break; }
+                shrunk += std::max(0, cwx[(size_t)k] - room[(size_t)b]);
                 cwx[(size_t)k] = std::min(cwx[(size_t)k], room[(size_t)b]);
                 pos[(size_t)k] = b * bin + (bin - room[(size_t)b]);
                 room[(size_t)b] -= cwx[(size_t)k];
             }
+            if (shrunk > nwg / 32) fits = false;
             if (fits) {
                 for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = pos[(size_t)k]; work[(size_t)k].w = cwx[(size_t)k]; }
                 std::sort(work.begin(), work.end(), [](const int4 &x, const int4 &y) { return x.z < y.z; });   // (the kernel searches by first workgroup)
