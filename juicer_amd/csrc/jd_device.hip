@@ -831,7 +831,7 @@ struct jd_dec {
     // search launches: one 1024-thread workgroup per CU, Cw of them per stream
     int max_cw = MAXCW;                   // upper bound of workgroups per stream cluster (JD_CW overrides)
     int weighted = 1;                     // size the clusters by the work ahead of each stream (JD_WEIGHTED=0: uniform)
-    double model_a_us = 10.0, model_b_us = 288.0;   // cost model of a stream-frame: a + b / workgroups (launch_search)
+    double model_a_us = 10.0, model_b_us = 360.0;   // cost model of a stream-frame: a + b / workgroups (launch_search)
     // b was fitted at configs[1]'s load (23.7 k instances + arcs per stream-frame); it scales with the load,
     // which a decoder learns from the batches it has decoded (first batch: as fitted)
     double load_scale = 1.0, load_sum = 0.0, load_frames = 0.0;
