@@ -555,7 +555,7 @@ static void launch_gc(const DecConst &C, StreamCtl *ctl, StreamDev *streams, con
 // record yet (new list, and the clean-up list of the "hopeless" ones - the reference attached an
 // instance for those too); an instance's first token is its entry token - the candidate that won the
 // arc's key in the last phase X - then its emitting states in order.  Path indices grow along a
-// chain (a record is allocated after its predecessor, and k_gc keeps the order), so the common
+// chain (a record is allocated after its predecessor, and the collection keeps the order), so the common
 // record lies on the chain of ANY tip: the chain of the highest tip is written out, every other tip
 // walks down until it meets it, and the shallowest meeting point is the answer.
 // out[0] = found, out[1] = records on the chain from the root to the found one (oldest first in
@@ -828,7 +828,7 @@ struct jd_dec {
     int res_cap = 8192;
     int *d_res = nullptr;                 // result arena, see ensure_arenas
     int n_cus = 256;
-    // search launches: one 1024-thread workgroup per CU, Cw of them per stream
+    // search launches: one 512-thread workgroup per CU, a cluster of them per stream
     int max_cw = MAXCW;                   // upper bound of workgroups per stream cluster (JD_CW overrides)
     int weighted = 1;                     // size the clusters by the work ahead of each stream (JD_WEIGHTED=0: uniform)
     double model_a_us = 10.0, model_b_us = 360.0;   // cost model of a stream-frame: a + b / workgroups (launch_search)

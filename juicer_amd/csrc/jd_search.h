@@ -59,7 +59,7 @@ struct DecConst {
     int max_hyps, hist_min, hist_max, hist_nbins;
     // arena capacities (per stream, in records)
     unsigned cap_slots, cap_items, cap_new; int cap_paths;
-    int gc_threshold;   // a launch stops early (for k_gc) when more Path records than this are in use
+    int gc_threshold;   // a launch stops early (for the collection, k_gc_*) when more Path records than this are in use
     int x_chunks;       // phase X: chunks per wave the item lists are cut into (dynamic hand-out balances the arc walks)
 };
 
@@ -123,7 +123,7 @@ struct StreamDev {      // per-stream arenas
     int *cleanl;                      // arcs entered this frame whose first candidate was hopeless (key clean-up, see phase X)
     int *dirtyl;                      // states whose closure key (skey[1]) became non-zero this frame
     int *tot;                         // published per-wave fill counts, TOT_N arrays of MAXW
-    int *item_end;                    // per wave: items written in the last processed frame (k_gc)
+    int *item_end;                    // per wave: items written in the last processed frame (k_gc_*)
     PathRec *paths; int *hist;        // hist: [2][HIST_MAX_BINS] by frame parity
     PathRec *paths2; int *gc_idx;     // Path garbage collection: compaction target + mark / new-index array
     int *gc_state;                    // ... and its per-stream bookkeeping (GcState, jd_device.hip)
@@ -1166,7 +1166,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         const bool init = init_pending;
         if (!init && f >= f_stop) break;
         const int p = init ? 1 : (f & 1);
-        // stop early when the Path arena needs collecting (k_gc runs between launches); n_paths only
+        // stop early when the Path arena needs collecting (k_gc_* run between launches); n_paths only
         // changes in phase X, so every workgroup of the cluster reads the same value here
         if (!init && frames_done > 0 && np_seen > C.gc_threshold) break;
         long long t0 = 0;
@@ -1341,7 +1341,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
 // XCDs, serve one stream); a slot serves its streams one after the other.  Weighted mode (at most
 // one stream per workgroup): stream k owns the workgroups [first_k, first_k + n_k) - the host sizes
 // the clusters by the streams' recent load.  All workgroups of the grid must be resident at once:
-// the host sizes the grid to the device (one 1024-thread workgroup per CU).
+// the host sizes the grid to the device (one 512-thread workgroup per CU).
 template <int NE, bool XL>
 __global__ __launch_bounds__(SNT) void k_search(SearchArgs A)
 {
