@@ -1297,6 +1297,24 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
     return first_err;
 }
 
+// The load (instances + arcs per stream-frame) of the streams of a work list so far, from their statistics:
+// scales the cost model's b (jd_dec::load_scale).  Called when the decoder has not seen a batch yet.
+static int learn_load(jd_dec *d, const std::vector<int2> &work_in)
+{
+    std::vector<long long> st((size_t)d->max_streams * ST_N);
+    std::vector<int> head((size_t)d->max_streams * 4);
+    HIPCHK(hipMemcpy2D(st.data(), ST_N * sizeof(long long), (const char *)d->d_ctl + offsetof(StreamCtl, st), sizeof(StreamCtl),
+                       ST_N * sizeof(long long), (size_t)d->max_streams, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(head.data(), 16, d->d_ctl, sizeof(StreamCtl), 16, (size_t)d->max_streams, hipMemcpyDeviceToHost));
+    double work = 0.0, frames = 0.0;
+    for (const int2 &w : work_in) {
+        work += (double)st[(size_t)w.x * ST_N + ST_INSTS] + (double)st[(size_t)w.x * ST_N + ST_ARCS];
+        frames += (double)head[(size_t)w.x * 4];
+    }
+    if (frames > 0.0) d->load_scale = std::min(1e5, std::max(0.25, work / frames / 23700.0));
+    return JD_OK;
+}
+
 // Advance the streams of `work` ({stream, likelihood slot}) through frames [.., f_end) with ONE
 // persistent launch (k_search): every stream gets a cluster of workgroups, one 512-thread workgroup
 // per CU in total, all resident at once (the clusters synchronise with barriers of their own).  A
@@ -1456,17 +1474,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         HIPCHK(hipMemcpy2D(head.data(), 16, d->d_ctl, sizeof(StreamCtl), 16, (size_t)d->max_streams, hipMemcpyDeviceToHost));
         std::vector<int2> rest;
         weight_now.clear();
-        if (d->load_scale == 1.0) {                                    // first batch of this decoder: learn the load right here
-            std::vector<long long> st((size_t)d->max_streams * ST_N);
-            HIPCHK(hipMemcpy2D(st.data(), ST_N * sizeof(long long), (const char *)d->d_ctl + offsetof(StreamCtl, st), sizeof(StreamCtl),
-                               ST_N * sizeof(long long), (size_t)d->max_streams, hipMemcpyDeviceToHost));
-            double work = 0.0, frames = 0.0;
-            for (const int2 &w : work_in) {
-                work += (double)st[(size_t)w.x * ST_N + ST_INSTS] + (double)st[(size_t)w.x * ST_N + ST_ARCS];
-                frames += (double)head[(size_t)w.x * 4];
-            }
-            if (frames > 0.0) d->load_scale = std::min(1e5, std::max(0.25, work / frames / 23700.0));
-        }
+        if (d->load_scale == 1.0) { const int lr = learn_load(d, work_in); if (lr) return lr; }   // first batch of this decoder
         if (frame_before.empty()) frame_before.assign((size_t)d->max_streams, f0);
         for (const int2 &w : work_in) {
             const int *h = head.data() + (size_t)w.x * 4;              // {frame, T, error, needs_init}
@@ -1601,6 +1609,20 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
                 work.push_back(make_int2(u, row_off[(size_t)c * nb + u]));   // {stream, its first row in the chunk's table}
                 weight.push_back((double)(std::min(T[(size_t)u], c1) - c0));
             }
+        if (d->load_scale == 1.0 && d->weighted && c == 0 && nb > 1 && std::min(maxT, c1) - c0 > 128) {
+            // the decoder's very first batch: nothing is known about the load yet, and the cluster sizes depend
+            // on it (a frame of 2 M instances is not a frame of 12 k) - a short launch finds out
+            const int c_mid = c0 + 32;
+            std::vector<double> wp(weight.size());
+            for (size_t i = 0; i < wp.size(); ++i) wp[i] = std::min(weight[i], 32.0);
+            rc = launch_search(d, work, d->d_ll[c & 1], (long long)G, c0, c_mid, d->s_search, &wp);
+            if (rc) return rc;
+            if (d->load_scale == 1.0) { rc = learn_load(d, work); if (rc) return rc; }
+            std::vector<int2> w2; std::vector<double> wt2;
+            for (size_t i = 0; i < work.size(); ++i)
+                if (T[(size_t)work[i].x] > c_mid) { w2.push_back(work[i]); wt2.push_back((double)(std::min(T[(size_t)work[i].x], c1) - c_mid)); }
+            work.swap(w2); weight.swap(wt2);
+        }
         rc = launch_search(d, work, d->d_ll[c & 1], (long long)G, c0, c1, d->s_search, &weight);
         if (rc) return rc;
     }
