@@ -144,6 +144,13 @@ int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t max_mix,
  * ~o, ~v (ignored), ~s, ~t, ~h with shared or inline states / <TRANSP>, <NUMMIXES>/<MIXTURE>
  * or the implicit single mixture, optional <GCONST>.  HMM index = order of the ~h macros. */
 int jd_am_load_mmf(jd_am **out, const char *mmf_path);
+/* HTKModels::Load(phonesListFName, priorsFName, statesPerModel) (HTKModels.cpp:74-218): hybrid ANN / HMM
+ * models - one HMM per phone, states_per_model states each (entry and exit included), one shared
+ * transition matrix (1.0 into the first emitting state, 0.5 / 0.5 self loop / forward); the feature vector
+ * holds one log posterior per phone and an emitting state scores x[phone] - log(prior[phone])
+ * (HTKModels.cpp:481-512, HTKFlatModels.cpp:190-222).  priors: n_phones values as read from the priors
+ * file (the phone list only gives names). */
+int jd_am_create_hybrid(jd_am **out, int32_t n_phones, const float *priors, int32_t states_per_model);
 
 /* Juicer's binary model cache "<mmf>.bin" (JMBI), preferred by juicer.cpp:778-784:
  * HTKModels::readBinary (HTKModels.cpp:1110-1233) + HTKFlatModels::init.  The derived values in

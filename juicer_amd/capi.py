@@ -75,7 +75,7 @@ EXPORTS = [
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_decode_batch", "jd_multi_destroy",
-    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models", "jd_net_compose",
+    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid",
 ]
 
 _lib = None
@@ -301,6 +301,14 @@ class Models:
         tee = np.zeros(self.n_hmms, np.float32)
         _check(lib().jd_am_get_trans(self.h, _p(trP, C.c_float), _p(se, C.c_int16), _p(tee, C.c_float)))
         return trP, se, tee
+
+    @classmethod
+    def from_hybrid(cls, priors, states_per_model: int = 5):
+        """Hybrid ANN / HMM models (HTKModels::Load(phones, priors, statesPerModel)): features are log posteriors."""
+        pr = _f32(priors)
+        h = C.c_void_p()
+        _check(lib().jd_am_create_hybrid(C.byref(h), C.c_int32(pr.shape[0]), _p(pr, C.c_float), C.c_int32(states_per_model)))
+        return cls(h)
 
     def score_frames(self, frames, device: int = 0):
         """Companion GMM kernel on its own: [T, D] -> [T, n_gmm] log-likelihoods."""

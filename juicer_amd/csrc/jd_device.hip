@@ -693,8 +693,20 @@ __global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int 
 
 // --------------------------------------------------------------- host runtime
 
+// hybrid scoring (HTKFlatModels.cpp:190-222): output = x[model] - log prior; rows as in the GMM kernels
+__global__ void jd_hybrid_kernel(const float *__restrict__ feats, const int *__restrict__ row_src, int n_rows,
+                                 const float *__restrict__ log_prior, int G, float *__restrict__ ll)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n_rows * G) return;
+    const int r = (int)(i / G), g = (int)(i - (long long)r * G);
+    const int src = row_src[r];
+    ll[i] = (src >= 0) ? feats[(size_t)src * G + g] - log_prior[g] : 0.0f;
+}
+
 struct AmDevBuf {
     float *par = nullptr, *det = nullptr; int *n_mix = nullptr;
+    float *log_prior = nullptr;
     JdLogTab *logtab = nullptr;
     int device = -1;
 };
@@ -725,6 +737,10 @@ static int upload_am_gmm(const jd_am *a, AmDevBuf &b)
         HIPCHK(hipMalloc(&b.logtab, t.size() * sizeof(JdLogTab)));
         HIPCHK(hipMemcpy(b.logtab, t.data(), t.size() * sizeof(JdLogTab), hipMemcpyHostToDevice));
     }
+    if (a->hybrid) {
+        HIPCHK(hipMalloc(&b.log_prior, a->log_prior.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(b.log_prior, a->log_prior.data(), a->log_prior.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return JD_OK;
 }
 
@@ -734,6 +750,7 @@ static void free_am_gmm(AmDevBuf &b)
     if (b.det) (void)hipFree(b.det);
     if (b.n_mix) (void)hipFree(b.n_mix);
     if (b.logtab) (void)hipFree(b.logtab);
+    if (b.log_prior) (void)hipFree(b.log_prior);
     b = AmDevBuf();
 }
 
@@ -746,6 +763,12 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
                       float *d_ll, hipStream_t st, int max_blocks = 0, int skip_unused = 0)
 {
     if (n_rows <= 0) return JD_OK;
+    if (a->hybrid) {
+        const long long n = (long long)n_rows * a->n_gmm;
+        hipLaunchKernelGGL(jd_hybrid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_feats, d_row_src, n_rows, b.log_prior, a->n_gmm, d_ll);
+        HIPCHK(hipGetLastError());
+        return JD_OK;
+    }
     const int rows_per_tile = (a->D == 39) ? GMM_ROWS2 : GMM_ROWS;
     const long long tiles = (long long)((n_rows + rows_per_tile - 1) / rows_per_tile) * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
     dim3 grid((unsigned)((max_blocks > 0 && tiles > max_blocks) ? max_blocks : tiles));

@@ -324,6 +324,37 @@ extern "C" int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t m
     return JD_OK;
 }
 
+// HTKModels::Load(phonesListFName, priorsFName, statesPerModel), HTKModels.cpp:74-218: hybrid ANN / HMM
+// models.  One HMM per phone with statesPerModel states whose emitting states all score
+// x[phone] - log(prior[phone]) (calcOutput, :481-512 / HTKFlatModels.cpp:190-222); ONE transition matrix:
+// entry -> first emitting state 1.0, every emitting state 0.5 self loop / 0.5 forward (:188-207).
+extern "C" int jd_am_create_hybrid(jd_am **out, int32_t n_phones, const float *priors, int32_t states_per_model)
+{
+    if (!out || !priors || n_phones <= 0) return jd_fail(JD_EINVAL, "jd_am_create_hybrid: bad argument");
+    if (states_per_model <= 2) return jd_fail(JD_EINVAL, "HTKModels::Models(3) - statesPerModel <= 2 (ie. no emitting states)");
+    if (states_per_model > JD_MAXN) return jd_fail(JD_EINVAL, "jd_am_create_hybrid: HMMs with more than %d states are not supported", JD_MAXN);
+    const int32_t P = n_phones, N = states_per_model;
+    std::vector<int32_t> n_mix((size_t)P, 1), hmm_n((size_t)P, N), hmm_gmm((size_t)P * N, -1), hmm_tm((size_t)P, 0), tm_n(1, N);
+    std::vector<float> weight((size_t)P, 1.0f), mean((size_t)P * P, 0.0f), var((size_t)P * P, 1.0f), transp((size_t)N * N, 0.0f);
+    for (int32_t h = 0; h < P; ++h)
+        for (int32_t j = 1; j < N - 1; ++j) hmm_gmm[(size_t)h * N + j] = h;     // :176-179 gmmInds[i] = nHMMs
+    transp[1] = 1.0f;                                                            // :196-199
+    for (int32_t i = 1; i < N - 1; ++i) { transp[(size_t)i * N + i] = 0.5f; transp[(size_t)i * N + i + 1] = 0.5f; }   // :200-204
+    jd_am *a = nullptr;
+    // (the Gaussian tables are placeholders: in hybrid mode nothing reads them)
+    int rc = jd_am_create_htk(&a, P, P, 1, n_mix.data(), weight.data(), mean.data(), var.data(), P, N, hmm_n.data(), hmm_gmm.data(),
+                              hmm_tm.data(), 1, tm_n.data(), transp.data());
+    if (rc) return rc;
+    a->hybrid = true;
+    a->log_prior.resize((size_t)P);
+    for (int32_t h = 0; h < P; ++h) {
+        if (!(priors[h] > 0.0f)) { delete a; return jd_fail(JD_EINVAL, "jd_am_create_hybrid: prior %d is not positive", h); }
+        a->log_prior[(size_t)h] = std::log(priors[h]);                            // :183 log(float)
+    }
+    *out = a;
+    return JD_OK;
+}
+
 extern "C" int32_t jd_am_num_hmms(const jd_am *a) { return a ? a->n_hmm : 0; }
 extern "C" int32_t jd_am_num_gmms(const jd_am *a) { return a ? a->n_gmm : 0; }
 extern "C" int32_t jd_am_vec_size(const jd_am *a) { return a ? a->D : 0; }
@@ -956,6 +987,7 @@ extern "C" int jd_am_save_jmbi(const jd_am *a, const char *path)
 {
     if (!a || !path) return jd_fail(JD_EINVAL, "jd_am_save_jmbi: null argument");
     if (a->var.empty() || a->transp.empty()) return jd_fail(JD_ESTATE, "jd_am_save_jmbi: models hold no HTK-level parameters");
+    if (a->hybrid) return jd_fail(JD_ESTATE, "jd_am_save_jmbi: hybrid models are not written (create them from the priors)");
     BinWriter w;
     w.f = fopen(path, "wb");
     if (!w.f) return jd_fail(JD_EFORMAT, "HTKModels::output - error opening file %s", path);

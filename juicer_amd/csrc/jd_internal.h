@@ -40,6 +40,10 @@ struct jd_am {
     std::vector<float> var, weight;               // [g][m][D], [g][m]
     std::vector<float> sum_log_var, log_weight;   // [g][m]  VarVec::sumLogVarPlusNObsLog2Pi, GMM::logCompWeights
     std::vector<float> transp;                    // [tm][max_n][max_n]  a_ij
+    // hybrid (ANN / LNA) scoring, HTKModels::Load(phones, priors, statesPerModel) HTKModels.cpp:74-218:
+    // the feature vector holds one log posterior per model, output = x[model] - log prior (:481-512)
+    bool hybrid = false;
+    std::vector<float> log_prior;                 // [n_hmm]
 };
 
 int jd_fail(int code, const char *fmt, ...);      // sets jd_last_error(), returns code

@@ -634,6 +634,45 @@ def sample_utterance_walk(seed: int, net: SynthNet, am: SynthAM, n_words: int,
 
 # ------------------------------------------------------------------ named configs
 
+@dataclass
+class HybridAM:
+    """Hybrid ANN / HMM models (input of jd_am_create_hybrid): one HMM per phone, features = log posteriors."""
+    priors: np.ndarray            # float32 [n_phones]
+    states_per_model: int = 5
+    sp_hmm: int = -1
+
+    @property
+    def n_hmm(self) -> int:
+        return int(self.priors.shape[0])
+
+
+def config_hybrid(seed: int = 3, n_phones: int = 30, states_per_model: int = 5, n_words: int = 50, n_succ: int = 5,
+                  n_utts: int = 3, utt_words=(4, 9), hub: str = "tree"):
+    """Hybrid-scoring regression case: bigram-shaped graph over n_phones one-HMM-per-phone models,
+    utterances as log-posterior vectors (softmax of noisy logits that favour the phone being spoken)."""
+    rng = np.random.default_rng(seed)
+    pri = rng.uniform(0.5, 2.0, size=n_phones)
+    am = HybridAM(priors=(pri / pri.sum()).astype(np.float32), states_per_model=states_per_model)
+    net = make_wfst(seed + 100, am, n_words=n_words, n_succ=n_succ, with_sp=False, hub=hub, eps_word_frac=0.1)
+    feats, words = [], []
+    for u in range(n_utts):
+        r = np.random.default_rng(seed + 1000 + u)
+        h, rows, ws = 0, [], []
+        for _ in range(int(r.integers(utt_words[0], utt_words[1] + 1))):
+            w = int(net.succ[h, r.integers(0, net.succ.shape[1])])
+            ws.append(w + 1)
+            for ph in net.prons[w]:
+                for _ in range(states_per_model - 2):               # self loop 0.5 / forward 0.5 per emitting state
+                    for _ in range(int(r.geometric(0.5))):
+                        logit = r.normal(size=n_phones)
+                        logit[int(ph)] += 4.0
+                        rows.append(logit - np.log(np.exp(logit).sum()))
+            h = 1 + w
+        feats.append(np.asarray(rows, dtype=np.float32))
+        words.append(np.asarray(ws, dtype=np.int32))
+    return am, net, feats, words
+
+
 def config_toy(seed: int = 1):
     """BASELINE.json configs[0]: ~16-state 3-word toy, 10 tied states, M=2, one
     100-frame utterance (the look-ahead/plumbing case; includes the tee model)."""

@@ -175,13 +175,14 @@ struct jo_am {
     float *trP;                        /* [tm][max_n][max_n]  trP[i][j]             */
     int16_t *se;                       /* [tm][max_n][2]  start,end for state j     */
     float *tm_tee;
+    int hybrid; float *log_prior;      /* hybridMode, logPriors (HTKModels.cpp:65-66, 163-183) */
 };
 
 void jo_am_destroy(jo_am *a)
 {
     if (!a) return;
     free(a->n_mix); free(a->det); free(a->mean); free(a->ivar); free(a->hmm_n); free(a->hmm_gmm);
-    free(a->hmm_tm); free(a->hmm_tee); free(a->tm_n); free(a->trP); free(a->se); free(a->tm_tee); free(a);
+    free(a->hmm_tm); free(a->hmm_tee); free(a->tm_n); free(a->trP); free(a->se); free(a->tm_tee); free(a->log_prior); free(a);
 }
 
 int jo_am_create_htk(jo_am **out, int32_t D, int32_t n_gmm, int32_t max_mix,
@@ -291,6 +292,33 @@ int jo_am_create_htk(jo_am **out, int32_t D, int32_t n_gmm, int32_t max_mix,
     return 0;
 }
 
+/* HTKModels::Load(phonesListFName, priorsFName, statesPerModel), HTKModels.cpp:74-218 (hybrid ANN / HMM) */
+int jo_am_create_hybrid(jo_am **out, int32_t n_phones, const float *priors, int32_t states_per_model)
+{
+    if (!out || !priors || n_phones <= 0) return fail(-1, "jo_am_create_hybrid: bad argument");
+    if (states_per_model <= 2) return fail(-1, "HTKModels::Models(3) - statesPerModel <= 2 (ie. no emitting states)");
+    const int32_t P = n_phones, N = states_per_model;
+    int32_t *n_mix = (int32_t *)malloc(sizeof(int32_t) * P), *hmm_n = (int32_t *)malloc(sizeof(int32_t) * P);
+    int32_t *hmm_gmm = (int32_t *)malloc(sizeof(int32_t) * (size_t)P * N), *hmm_tm = (int32_t *)calloc(P, sizeof(int32_t));
+    float *weight = (float *)malloc(sizeof(float) * P), *mean = (float *)calloc((size_t)P * P, sizeof(float));
+    float *var = (float *)malloc(sizeof(float) * (size_t)P * P), *transp = (float *)calloc((size_t)N * N, sizeof(float));
+    for (int32_t h = 0; h < P; ++h) {
+        n_mix[h] = 1; hmm_n[h] = N; weight[h] = 1.0f;
+        for (int32_t j = 0; j < N; ++j) hmm_gmm[(size_t)h * N + j] = (j >= 1 && j < N - 1) ? h : -1;   /* :176-181 */
+    }
+    for (size_t i = 0; i < (size_t)P * P; ++i) var[i] = 1.0f;          /* (placeholders: hybrid mode reads no Gaussian) */
+    transp[1] = 1.0f;                                                   /* :196-199 */
+    for (int32_t i = 1; i < N - 1; ++i) { transp[i * N + i] = 0.5f; transp[i * N + i + 1] = 0.5f; }   /* :200-204 */
+    int32_t tm_n = N;
+    int rc = jo_am_create_htk(out, P, P, 1, n_mix, weight, mean, var, P, N, hmm_n, hmm_gmm, hmm_tm, 1, &tm_n, transp);
+    free(n_mix); free(hmm_n); free(hmm_gmm); free(hmm_tm); free(weight); free(mean); free(var); free(transp);
+    if (rc) return rc;
+    (*out)->hybrid = 1;
+    (*out)->log_prior = (float *)malloc(sizeof(float) * P);
+    for (int32_t h = 0; h < P; ++h) (*out)->log_prior[h] = logf(priors[h]);   /* :183 log(float) */
+    return 0;
+}
+
 int jo_am_get_flat(const jo_am *a, float *det, float *mean, float *ivar)
 {
     size_t gm = (size_t)a->n_gmm * a->max_mix;
@@ -323,6 +351,7 @@ static float log_add(float x, float y)
 /* inner loops of HTKFlatModels::calcGMMOutput :239-256 for one (gmm, frame) */
 static float gmm_one(const jo_am *a, int32_t g, const float *x)
 {
+    if (a->hybrid) return x[g] - a->log_prior[g];                   /* calcOutput, HTKFlatModels.cpp:190-197, 216-220 */
     int32_t D = a->D, nMix = a->n_mix[g];
     const float *means = a->mean + (size_t)g * a->max_mix * D;
     const float *vars = a->ivar + (size_t)g * a->max_mix * D;

@@ -66,6 +66,8 @@ int jo_am_get_flat(const jo_am *a, float *det, float *mean, float *ivar);
 int jo_am_get_trans(const jo_am *a, float *trP, int16_t *se, float *tee);
 /* HTKFlatModels::calcGMMOutput for every tied state of every frame, no cache */
 int jo_am_score_frames(const jo_am *a, const float *frames, int32_t n_frames, float *out);
+/* HTKModels::Load(phonesListFName, priorsFName, statesPerModel), HTKModels.cpp:74-218: hybrid ANN / HMM models */
+int jo_am_create_hybrid(jo_am **out, int32_t n_phones, const float *priors, int32_t states_per_model);
 void jo_am_destroy(jo_am *a);
 
 int jo_dec_create(jo_dec **out, const jo_net *net, const jo_am *am,

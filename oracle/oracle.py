@@ -150,6 +150,18 @@ class OracleAM:
                                   _p(hg, C.c_int32), _p(ht, C.c_int32), C.c_int32(am.n_tm),
                                   _p(tn, C.c_int32), _p(tp, C.c_float)))
 
+    @classmethod
+    def from_hybrid(cls, priors, states_per_model: int = 5):
+        """hybrid ANN / HMM models: HTKModels::Load(phones, priors, statesPerModel)"""
+        self = cls.__new__(cls)
+        pr = _f32(priors)
+        self.h = C.c_void_p()
+        P = pr.shape[0]
+        self.D, self.n_gmm, self.max_mix = P, P, 1
+        self.n_hmm, self.max_n, self.n_tm = P, states_per_model, 1
+        _check(lib().jo_am_create_hybrid(C.byref(self.h), C.c_int32(P), _p(pr, C.c_float), C.c_int32(states_per_model)))
+        return self
+
     def flat(self):
         det = np.zeros((self.n_gmm, self.max_mix), np.float32)
         mean = np.zeros((self.n_gmm, self.max_mix, self.D), np.float32)

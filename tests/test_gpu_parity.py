@@ -847,3 +847,32 @@ def test_xcd_local_launch_and_its_fallback(small, capfd):
         err = capfd.readouterr().err
         assert "XCD-local" in err, err[-400:]
         assert ("not on one XCD" in err) == selftest, err[-600:]
+
+
+def test_hybrid_models(built):
+    """Hybrid ANN / HMM scoring (HTKModels::Load(phones, priors, statesPerModel); calcOutput,
+    HTKFlatModels.cpp:190-222): the feature vector is one log posterior per phone and the scoring kernel
+    is a subtraction - scores bit for bit, decoding as with Gaussians (batch, streaming, three- and
+    five-state models)."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    for spm in (5, 3):
+        am, net, feats, words = synth.config_hybrid(seed=3 + spm, states_per_model=spm)
+        gam = capi.Models.from_hybrid(am.priors, am.states_per_model)
+        oam = OracleAM.from_hybrid(am.priors, am.states_per_model)
+        a, b = gam.score_frames(feats[0][:50]), oam.score_frames(feats[0][:50])
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for kw in (dict(main_beam=200.0), dict(main_beam=150.0, max_hyps=100)):
+            od = OracleDecoder(OracleNet(net), oam, **kw)
+            gd = capi.Decoder(capi.Network.from_synth(net), gam, max_streams=len(feats), **kw)
+            gs = gd.decode_batch(feats)
+            for u, x in enumerate(feats):
+                o = od.decode_certified(x)
+                assert_hyp_matches(gs[u], o, "hybrid spm %d %r utt %d" % (spm, kw, u))
+                assert bit_exact(gs[u], o)
+            gd.stream_init(0)
+            for pos in range(0, feats[0].shape[0], 37):
+                gd.stream_push(0, feats[0][pos:pos + 37])
+            assert_hyp_matches(gd.stream_finish(0), od.decode_certified(feats[0]), "hybrid streaming")
+    with pytest.raises(capi.JuicerAmdError):
+        capi.Models.from_hybrid(am.priors, 2)                        # statesPerModel <= 2 (HTKModels.cpp:82-83)

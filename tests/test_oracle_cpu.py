@@ -163,3 +163,26 @@ def test_oracle_two_thread_core_gives_the_same_results(built):
         refused = "to-exit transition" in str(e)
     skips = any(int((am2.transp[t, 1:n - 2, n - 1] > 0).any()) for t, n in enumerate(am2.tm_nstates))
     assert refused == skips
+
+
+def test_oracle_hybrid_scoring(built):
+    """Hybrid ANN / HMM models (HTKModels::Load(phones, priors, statesPerModel), HTKModels.cpp:74-218): an
+    emitting state scores x[phone] - log(prior[phone]); decoding finds the spoken words."""
+    from juicer_amd import synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, words = synth.config_hybrid()
+    oam = OracleAM.from_hybrid(am.priors, am.states_per_model)
+    x = feats[0][:7]
+    got = oam.score_frames(x)
+    want = x.astype(np.float64) - np.log(am.priors.astype(np.float64))[None, :]
+    assert np.allclose(got, want, rtol=0, atol=2e-6)
+    trP, se, tee = oam.trans()
+    n = am.states_per_model
+    assert trP.shape[0] == 1 and np.isclose(trP[0, 0, 1], 0.0) and np.isclose(trP[0, 1, 1], np.log(0.5)) and np.isclose(trP[0, n - 2, n - 1], np.log(0.5))
+    od = OracleDecoder(OracleNet(net), oam, main_beam=200.0)
+    hit = 0
+    for x, w in zip(feats, words):
+        o = od.decode(x)
+        assert o.n > 0
+        hit += int(np.array_equal(o.label[::-1], w))
+    assert hit >= len(feats) - 1
