@@ -108,7 +108,7 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=2, 
     return out
 
 
-def compose_leg(seed, dev):
+def compose_leg(seed, dev, pushing=False):
     """BASELINE.json configs[4] (separate C.L and G) as far as it is built: the two transducers are composed
     ON THE DEVICE (jd_net_compose) and the result is decoded by the static search; no oracle exists for the
     reference's on-the-fly decoder (it is not built and no longer compiles), so this leg has no cpu line."""
@@ -121,15 +121,16 @@ def compose_leg(seed, dev):
     best = None
     for _ in range(2):
         t0 = time.perf_counter()
-        net = capi.Network.compose(ncl, ng, device=dev.index, max_states=1 << 26, max_arcs=1 << 27)
+        net = capi.Network.compose(ncl, ng, device=dev.index, max_states=1 << 26, max_arcs=1 << 27, pushing=pushing)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     feats = [synth.sample_utterance(seed + 100 + u, g, am, 8)[0] for u in range(64)]
 
     class _Size:                                                   # what run_leg prints about the graph
         n_arcs = net.n_arcs
-    out = run_leg("configs[4], composed on the device (lexicon tree o back-off trigram)", am, _Size, feats, 200.0, 0, dev, gnet=net)
-    out["composition"] = {"cl_arcs": int(cl.n_arcs), "g_arcs": int(g.n_arcs), "states": net.n_states, "arcs": net.n_arcs,
+    out = run_leg("configs[4], composed on the device (lexicon tree o back-off trigram%s)" % (", weights pushed" if pushing else ""),
+                  am, _Size, feats, 200.0, 0, dev, gnet=net)
+    out["composition"] = {"pushing": bool(pushing), "cl_arcs": int(cl.n_arcs), "g_arcs": int(g.n_arcs), "states": net.n_states, "arcs": net.n_arcs,
                           "seconds_incl_pcie": round(best, 4), "arcs_per_s": round(net.n_arcs / best, 1),
                           "generator_seconds": round(t_gen, 1)}
     return out

@@ -112,9 +112,12 @@ void    jd_net_destroy(jd_net *n);
  * tight when words are numbered in the lexicon tree's depth-first order).  Exact definition and the
  * state / arc numbering: csrc/jd_compose.hip.  max_states / max_arcs bound the result (0: a default
  * derived from the inputs); JD_ENOMEM names the one that was too small.  There is no CPU path.
+ * pushing != 0: the weight part of the reference's -pushing (doLabelAndWeightPushing, juicer.cpp:240,
+ * 931-935) - the best grammar weight reachable below a lexicon-tree node is paid on the way into it, so the
+ * beam prunes on it; path totals are the same up to float association.
  */
 int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t device,
-                   int64_t max_states, int64_t max_arcs);
+                   int64_t max_states, int64_t max_arcs, int32_t pushing);
 
 /* ---------------------------------------------------------- acoustic models */
 

@@ -181,10 +181,11 @@ class Network:
         return cls(h)
 
     @classmethod
-    def compose(cls, cl: "Network", g: "Network", device: int = 0, max_states: int = 0, max_arcs: int = 0):
+    def compose(cls, cl: "Network", g: "Network", device: int = 0, max_states: int = 0, max_arcs: int = 0, pushing: bool = False):
         """C.L o G on the device (jd_net_compose): the dynamic-composition row's first step."""
         h = C.c_void_p()
-        _check(lib().jd_net_compose(C.byref(h), cl.h, g.h, C.c_int32(device), C.c_int64(max_states), C.c_int64(max_arcs)))
+        _check(lib().jd_net_compose(C.byref(h), cl.h, g.h, C.c_int32(device), C.c_int64(max_states), C.c_int64(max_arcs),
+                                    C.c_int32(1 if pushing else 0)))
         return cls(h)
 
     def save_jwnt(self, path):

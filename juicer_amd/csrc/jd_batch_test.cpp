@@ -102,7 +102,7 @@ int main(int argc, char **argv)
     const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *mmf = 0, *list = 0;
     const char *gramFsm = 0, *gramInSyms = 0, *gramOutSyms = 0;              // juicer.cpp:128-130: separate C.L and G
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
-    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0, nDevices = 0;
+    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0, nDevices = 0, pushing = 0;
     std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
     const char *refFName = 0;                  // -refFName: expected results, MLF or one line per file (juicer.cpp:267)
     const char *outputFName = 0;               // -outputFName: "", "stdout", "stderr" or a file (DecoderBatchTest.cpp:216-230)
@@ -113,7 +113,7 @@ int main(int argc, char **argv)
         auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "-fsmFName") fsm = nxt(); else if (a == "-inSymsFName") insyms = nxt();
         else if (a == "-gramFsmFName") gramFsm = nxt(); else if (a == "-gramInSymsFName") gramInSyms = nxt();
-        else if (a == "-gramOutSymsFName") gramOutSyms = nxt();
+        else if (a == "-gramOutSymsFName") gramOutSyms = nxt(); else if (a == "-pushing") pushing = 1;   // juicer.cpp:240
         else if (a == "-outSymsFName") outsyms = nxt(); else if (a == "-modelsFName") amf = nxt();
         else if (a == "-htkModelsFName") mmf = nxt();
         else if (a == "-inputFName") list = nxt(); else if (a == "-mainBeam") mainBeam = (float)atof(nxt());
@@ -136,7 +136,7 @@ int main(int argc, char **argv)
                         "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles] [-refFName REF] [-removeSentMarks]\n"
                         "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n"
                         "       [-device d | -devices N   (N GPUs of this node: utterances sharded, one RCCL gather of the 1-best)]\n"
-                        "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S]   (-fsmFName is then C.L: composed with G on the device)]\n");
+                        "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S] [-pushing]   (-fsmFName is then C.L: composed with G on the device)]\n");
         return 2;
     }
     if (outputFName && outputFName[0] && strcmp(outputFName, "stdout") != 0) {     // DecoderBatchTest::openOutputFile
@@ -152,7 +152,7 @@ int main(int argc, char **argv)
         jd_net *cl = 0, *g = 0;
         if (jd_net_load_fsm(&cl, fsm, insyms, outsyms, 1.0f, 0.0f)) die("jd_net_load_fsm (C.L)");
         if (jd_net_load_fsm(&g, gramFsm, gramInSyms, gramOutSyms, lmScale, 0.0f)) die("jd_net_load_fsm (G)");
-        if (jd_net_compose(&net, cl, g, device, 0, 0)) die("jd_net_compose");
+        if (jd_net_compose(&net, cl, g, device, 0, 0, pushing)) die("jd_net_compose");
         fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs) composed on device %d: %d states, %lld arcs\n", (long long)jd_net_num_arcs(cl),
                 (long long)jd_net_num_arcs(g), device, (int)jd_net_num_states(net), (long long)jd_net_num_arcs(net));
         jd_net_destroy(cl); jd_net_destroy(g);

@@ -22,6 +22,12 @@
 //                     in that interval (look-ahead: a superset test, it only ever drops dead ends)
 //   C.L arc c -i:x/w->  c', x != eps, and an arc g -x:y/v-> g'   gives (c,g,f) -i:y/(w + v)-> (c',g',1)
 //   (c,g,f) is final iff c and g are: weight fin(c) + fin(g)
+//   pushing (the reference's -pushing, doLabelAndWeightPushing, juicer.cpp:240, 931-935; weights only): let
+//   P(c,g) = the best weight among the arcs of g with a label in [lo(c), hi(c)] - what entering c's part of
+//   the lexicon will cost at least - and P = 0 at the states with f = 1.  Every arc gets + P(destination)
+//   - P(source) (a matched arc: - P(source) only; a final weight likewise), so the grammar's weight is
+//   paid as early as the tree allows and the beam sees it: (w + P(c',g)) - P(c,g), resp. (w + v) - P(c,g).
+//   Path totals are unchanged up to float association.
 //
 // All weights are the ones the two networks carry after loading (each with its own scale, as
 // juicer.cpp:933-970 loads them), i.e. log-domain scores that add, in float32.  States are numbered by
@@ -54,6 +60,7 @@ struct ComposeArgs {
     int *st_c, *st_g; int *n_states; int max_states;                    // states in discovery order (= the BFS queue)
     long long *arc_start; int *arc_cnt; JdArc *arcs; unsigned long long *n_arcs; long long max_arcs;
     float *fin; int *err;
+    int push;                                                            // weight look-ahead pushing (see jd_net_compose)
 };
 
 __device__ __forceinline__ unsigned long long jc_hash(unsigned long long k)
@@ -116,6 +123,26 @@ __device__ __forceinline__ bool jc_any_in(const ComposeArgs &A, int g, int lo_l,
     return lo < end && A.g_arcs[lo].in <= hi_l;
 }
 
+// weight look-ahead: the best weight among the arcs of G state g whose input label lies in [lo, hi] (0 if none)
+__device__ __forceinline__ float jc_potential(const ComposeArgs &A, int g, int lo_l, int hi_l)
+{
+    if (lo_l > hi_l) return 0.0f;
+    int lo = A.g_row[g], hi = A.g_row[g + 1];
+    const int end = hi;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A.g_arcs[mid].in < lo_l) lo = mid + 1; else hi = mid;
+    }
+    float best = 0.0f;
+    bool have = false;
+    for (; lo < end && A.g_arcs[lo].in <= hi_l; ++lo) {
+        const float w = A.g_arcs[lo].w;
+        if (!have || w > best) best = w;
+        have = true;
+    }
+    return best;
+}
+
 // what C.L arc ca contributes at G state g: 0 = nothing, 1 = an arc; *ga = the matched G arc (index, or -1)
 __device__ __forceinline__ int jc_arc_kind(const ComposeArgs &A, const JdArc &ca, int g, int *ga)
 {
@@ -139,6 +166,9 @@ __global__ __launch_bounds__(256) void jc_expand(ComposeArgs A, int begin, int e
     JdArc boa = {0, 0.0f, 0, 0};
     if (flag && A.g_row[g + 1] > A.g_row[g]) { boa = A.g_arcs[A.g_row[g]]; bo = boa.in == 0; }
     const int a0 = A.cl_row[c], a1 = A.cl_row[c + 1];
+    // pushing: what this state's incoming arcs have already paid of the word that is under way
+    float p_src = 0.0f;
+    if (A.push && !flag) { const int2 la = A.cl_la[c]; p_src = jc_potential(A, g, la.x, la.y); }
     // pass 1: how many arcs this state gets
     int mine = 0, ga;
     for (int a = a0 + lane; a < a1; a += 64) mine += jc_arc_kind(A, A.cl_arcs[a], g, &ga);
@@ -153,7 +183,7 @@ __global__ __launch_bounds__(256) void jc_expand(ComposeArgs A, int begin, int e
         A.arc_start[s] = base; A.arc_cnt[s] = total;
         const float fc = A.cl_fin[c], fg = A.g_fin[g];
         const bool fin = fc < std::numeric_limits<float>::infinity() && fg < std::numeric_limits<float>::infinity();
-        A.fin[s] = fin ? fc + fg : std::numeric_limits<float>::infinity();
+        A.fin[s] = fin ? (A.push ? (fc + fg) - p_src : fc + fg) : std::numeric_limits<float>::infinity();
     }
     base = __shfl(base, 0);
     if (base + total > A.max_arcs) return;
@@ -175,10 +205,14 @@ __global__ __launch_bounds__(256) void jc_expand(ComposeArgs A, int begin, int e
         const int chunk_total = __shfl(pre, 63);
         if (cnt) {
             const long long pos = run + pre - 1;
-            if (ca.out == 0) A.arcs[pos] = JdArc{jc_state_id(A, (unsigned)ca.to, g), ca.w, ca.in, 0};
-            else {
+            if (ca.out == 0) {
+                float w = ca.w;
+                if (A.push) { const int2 la = A.cl_la[ca.to]; w = (ca.w + jc_potential(A, g, la.x, la.y)) - p_src; }
+                A.arcs[pos] = JdArc{jc_state_id(A, (unsigned)ca.to, g), w, ca.in, 0};
+            } else {
                 const JdArc m = A.g_arcs[ga];
-                A.arcs[pos] = JdArc{jc_state_id(A, (unsigned)ca.to | JC_FLAG, m.to), ca.w + m.w, ca.in, m.out};
+                const float w = A.push ? (ca.w + m.w) - p_src : ca.w + m.w;
+                A.arcs[pos] = JdArc{jc_state_id(A, (unsigned)ca.to | JC_FLAG, m.to), w, ca.in, m.out};
             }
         }
         run += chunk_total;
@@ -278,7 +312,8 @@ static void cl_lookahead(const jd_net *cl, std::vector<int2> &la)
     }
 }
 
-extern "C" int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t device, int64_t max_states, int64_t max_arcs)
+extern "C" int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t device, int64_t max_states, int64_t max_arcs,
+                              int32_t pushing)
 {
     if (!out || !cl || !g) return jd_fail(JD_EINVAL, "jd_net_compose: null argument");
     std::vector<JdArc> g_sorted;
@@ -327,7 +362,7 @@ extern "C" int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, i
         DAL(A.st_c, int, max_states); DAL(A.st_g, int, max_states); DAL(A.n_states, int, 1);
         DAL(A.arc_start, long long, max_states); DAL(A.arc_cnt, int, max_states); DAL(A.arcs, JdArc, max_arcs);
         DAL(A.n_arcs, unsigned long long, 1); DAL(A.fin, float, max_states); DAL(A.err, int, 1);
-        A.max_states = (int)max_states; A.max_arcs = max_arcs;
+        A.max_states = (int)max_states; A.max_arcs = max_arcs; A.push = pushing ? 1 : 0;
         CHK(hipMemset(A.keys, 0, cap * 8)); CHK(hipMemset(A.vals, 0xff, cap * 4));
         CHK(hipMemset(A.n_arcs, 0, 8)); CHK(hipMemset(A.err, 0, 4));
         // the start pair is state 0 of the discovery order

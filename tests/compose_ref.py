@@ -76,7 +76,7 @@ def _finish(states, arcs_of, fin_of, init_key, order_key):
                 w=np.asarray(w, np.float32), ilab=np.asarray(il, np.int32), olab=np.asarray(ol, np.int32), fin_w=fin)
 
 
-def compose_filtered(cl, cl_init, g, g_init):
+def compose_filtered(cl, cl_init, g, g_init, pushing=False):
     G = _sorted_g(g)
     lo, hi = _lookahead(cl)
     glabels = [[a[0] for a in row] for row in G]
@@ -84,12 +84,20 @@ def compose_filtered(cl, cl_init, g, g_init):
     def any_in(gs, l, h):
         return l <= h and any(l <= x <= h for x in glabels[gs])
 
+    def potential(gs, l, h):
+        """best weight among the arcs of gs with a label in [l, h] (0 if none): the weight look-ahead"""
+        ws = [a[3] for a in G[gs] if l <= a[0] <= h]
+        return max(ws) if (l <= h and ws) else np.float32(0.0)
+
     start = (cl_init, g_init, 1)
     states, arcs_of, fin_of = {start}, {}, {}
     queue = [start]
     while queue:
         c, gs, f = k = queue.pop()
         out = []
+        p_src = np.float32(0.0)
+        if pushing and not f:
+            p_src = np.float32(potential(gs, lo[c], hi[c]))
         if f and G[gs] and G[gs][0][0] == 0:
             _, o, t, ww = G[gs][0]
             out.append(((c, t, 1), ww, 0, o))
@@ -97,14 +105,22 @@ def compose_filtered(cl, cl_init, g, g_init):
             x, t, ww, i = int(cl["olab"][a]), int(cl["to"][a]), np.float32(cl["w"][a]), int(cl["ilab"][a])
             if x == 0:
                 if any_in(gs, lo[t], hi[t]):
+                    if pushing:
+                        ww = np.float32(np.float32(ww + np.float32(potential(gs, lo[t], hi[t]))) - p_src)
                     out.append(((t, gs, 0), ww, i, 0))
             else:
                 for (l, o, t2, wg) in G[gs]:
                     if l == x:
-                        out.append(((t, t2, 1), np.float32(ww + wg), i, o))
+                        w2 = np.float32(ww + wg)
+                        if pushing:
+                            w2 = np.float32(w2 - p_src)
+                        out.append(((t, t2, 1), w2, i, o))
         arcs_of[k] = out
         fc, fg = np.float32(cl["fin_w"][c]), np.float32(g["fin_w"][gs])
-        fin_of[k] = np.float32(fc + fg) if np.isfinite(fc) and np.isfinite(fg) else INF
+        if np.isfinite(fc) and np.isfinite(fg):
+            fin_of[k] = np.float32(np.float32(fc + fg) - p_src) if pushing else np.float32(fc + fg)
+        else:
+            fin_of[k] = INF
         for (dk, _, _, _) in out:
             if dk not in states:
                 states.add(dk)
