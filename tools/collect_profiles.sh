@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs"
-ONE="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs"
+ONE="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs"   # (the warm-up batch takes the decoder's one-off 32-frame probe launch)
 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH < /dev/null > "$OUT/stats.log" 2>&1
 f=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)

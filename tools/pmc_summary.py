@@ -37,7 +37,7 @@ def main():
         out[k] = {}
         for c, per in sorted(cs.items()):
             vals = list(per.values())
-            out[k][c] = {"launches": len(vals), "mean": statistics.fmean(vals), "median": statistics.median(vals)}
+            out[k][c] = {"launches": len(vals), "mean": statistics.fmean(vals), "median": statistics.median(vals), "max": max(vals)}
     json.dump(out, sys.stdout, indent=1)
 
 
