@@ -846,7 +846,9 @@ def test_xcd_local_launch_and_its_fallback(small, capfd):
                     os.environ[k] = v
         err = capfd.readouterr().err
         assert "XCD-local" in err, err[-400:]
-        assert ("not on one XCD" in err) == selftest, err[-600:]
+        if selftest:          # (without the knob the check passes wherever workgroup b runs on XCD b % 8 - observed, not
+            # promised: on a device that places them otherwise the fallback is simply what runs)
+            assert "not on one XCD" in err, err[-600:]
 
 
 def test_hybrid_models(built):
