@@ -291,7 +291,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:                   # (rank 0 at N = 1 only: the other ranks would wait for it)
         from oracle.oracle import OracleAM, OracleDecoder, OracleNet
         ns = min(args.cpu_sample_utts, U)
         od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=args.beam, max_hyps=args.max_hyps)
