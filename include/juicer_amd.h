@@ -119,6 +119,22 @@ void    jd_net_destroy(jd_net *n);
 int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t device,
                    int64_t max_states, int64_t max_arcs, int32_t pushing);
 
+/*
+ * Dynamic composition proper (WFSTOnTheFlyDecoder: C.L o G expanded where the search goes, never as a
+ * whole): the network this returns holds only its start state; decoders created on it expand a composed
+ * state - same expansion step as jd_net_compose, one state at a time - when a token first enters an arc
+ * that leads to it (csrc/jd_lazy.h).  What has been expanded stays, shared by every decoder and stream on
+ * the network, so later utterances find most of what they need.  `am` says which input labels are tee
+ * models; max_states / max_arcs are the room the network may grow into (0: 2^22 states, 2^24 arcs;
+ * decoding fails with JD_ENOMEM when it runs out).  The decoder must be created on the same device; the
+ * network has no arc table to read back (jd_net_get_csr / jd_net_save_jwnt refuse it).  Results are those
+ * of decoding on jd_net_compose's network.  There is no CPU path.
+ */
+int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *g, const jd_am *am, int32_t device,
+                       int64_t max_states, int64_t max_arcs);
+/* composed states and arcs (arena entries, with alignment padding) materialised so far */
+int jd_net_lazy_size(const jd_net *n, int64_t *states, int64_t *arcs);
+
 /* ---------------------------------------------------------- acoustic models */
 
 /*

@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "jd_internal.h"
+#include "jd_lazy.h"        // LazyDev and the expansion step shared with the search kernel
 
 #define CHK(expr)                                                                                  \
     do {                                                                                           \
@@ -438,4 +439,115 @@ done:
     for (void *p : allocs) (void)hipFree(p);
     delete res;
     return rc;
+}
+
+
+// ------------------------------------------------------------------ search-driven composition
+//
+// jd_net_create_lazy: C.L and G stay apart on the device; what jd_dec_create gets is a network whose arc
+// arena is empty but for the start state (and its epsilon closure).  The search kernel expands composed
+// states as its tokens approach them (jd_lazy.h); the arena is shared by every decoder / stream that uses
+// the network and lives as long as it does.
+
+__global__ void jl_init(LazyDev L, const float *hmm_tee, unsigned cf0, int g0, int *ok)
+{
+    __shared__ int q[LZQ + LZD];
+    int qn = 0, dn = 0;
+    int s0 = 0;
+    if (threadIdx.x == 0) s0 = lz_state_id(L, cf0, g0);
+    s0 = __shfl(s0, 0);
+    const bool good = lz_expand(L, hmm_tee, s0, q, &qn, &dn) && lz_drain(L, hmm_tee, q, &qn, &dn, wall_clock64() + 300000000LL);
+    if (threadIdx.x == 0) { ok[0] = (good && !lz_failed(L)) ? 1 : 0; ok[1] = s0; }
+}
+
+static void lazy_free(jd_net *n)
+{
+    if (n->lazy_device >= 0) (void)hipSetDevice(n->lazy_device);
+    for (void *p : n->lazy_allocs) (void)hipFree(p);
+    n->lazy_allocs.clear();
+    n->lazy_dev = nullptr;
+}
+
+extern "C" int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *g, const jd_am *am, int32_t device,
+                                  int64_t max_states, int64_t max_arcs)
+{
+    if (!out || !cl || !g || !am) return jd_fail(JD_EINVAL, "jd_net_create_lazy: null argument");
+    if (cl->lazy_dev || g->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_create_lazy: the inputs must be ordinary networks");
+    std::vector<JdArc> g_sorted;
+    int rc = sorted_g_arcs(g, g_sorted);
+    if (rc) return rc;
+    if (cl->max_in > am->n_hmm) return jd_fail(JD_EINVAL, "network input label %d exceeds the number of HMMs %d", cl->max_in, am->n_hmm);
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return jd_fail(JD_ENODEV, "jd_net_create_lazy: no HIP device %d (there is no CPU path)", device);
+    if (hipSetDevice(device) != hipSuccess) return jd_fail(JD_EHIP, "hipSetDevice(%d) failed", device);
+    if (max_states <= 0) max_states = 1 << 22;
+    if (max_arcs <= 0) max_arcs = 1 << 24;
+    if (max_states > 0x0fffffffLL || max_arcs > 0x0fffffffLL) return jd_fail(JD_EINVAL, "jd_net_create_lazy: capacities are limited to 2^28 states / arcs");
+    jd_net *n = new jd_net();
+    n->lazy_device = device; n->lazy_free = lazy_free;
+    LazyDev L;
+    memset(&L, 0, sizeof L);
+    auto dal = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; n->lazy_allocs.push_back(p); return p; };
+    int *d_ok = nullptr;
+    float *d_tee = nullptr;
+    LazyDev *d_L = nullptr;
+    int h_ok[2] = {0, 0};
+    {
+        size_t cap = 1;
+        while (cap < (size_t)max_states * 2) cap <<= 1;
+        L.mask = cap - 1;
+#define LAL(p, T, cnt) do { p = (T *)dal(sizeof(T) * (size_t)(cnt)); if (!p) { rc = jd_fail(JD_ENOMEM, "jd_net_create_lazy: hipMalloc of %zu bytes failed", sizeof(T) * (size_t)(cnt)); goto done; } } while (0)
+        int *cl_row, *g_row; JdArc *cl_arcs, *g_arcs; float *cl_fin, *g_fin; int2 *cl_la;
+        std::vector<int2> la;
+        cl_lookahead(cl, la);
+        LAL(cl_row, int, cl->row_ptr.size()); LAL(cl_arcs, JdArc, cl->arcs.size()); LAL(cl_fin, float, cl->fin_w.size()); LAL(cl_la, int2, la.size());
+        LAL(g_row, int, g->row_ptr.size()); LAL(g_arcs, JdArc, g_sorted.size()); LAL(g_fin, float, g->fin_w.size());
+        CHK(hipMemcpy(cl_row, cl->row_ptr.data(), cl->row_ptr.size() * 4, hipMemcpyHostToDevice));
+        CHK(hipMemcpy(cl_arcs, cl->arcs.data(), cl->arcs.size() * sizeof(JdArc), hipMemcpyHostToDevice));
+        CHK(hipMemcpy(cl_fin, cl->fin_w.data(), cl->fin_w.size() * 4, hipMemcpyHostToDevice));
+        CHK(hipMemcpy(cl_la, la.data(), la.size() * sizeof(int2), hipMemcpyHostToDevice));
+        CHK(hipMemcpy(g_row, g->row_ptr.data(), g->row_ptr.size() * 4, hipMemcpyHostToDevice));
+        CHK(hipMemcpy(g_arcs, g_sorted.data(), g_sorted.size() * sizeof(JdArc), hipMemcpyHostToDevice));
+        CHK(hipMemcpy(g_fin, g->fin_w.data(), g->fin_w.size() * 4, hipMemcpyHostToDevice));
+        L.cl_row = cl_row; L.cl_arcs = cl_arcs; L.cl_fin = cl_fin; L.cl_la = cl_la; L.g_row = g_row; L.g_arcs = g_arcs; L.g_fin = g_fin;
+        LAL(L.keys, unsigned long long, cap); LAL(L.vals, int, cap);
+        LAL(L.st_c, int, max_states); LAL(L.st_g, int, max_states); LAL(L.rows, int4, max_states);
+        LAL(L.arcs, JdArc, max_arcs); LAL(L.n_states, int, 1); LAL(L.n_arcs, unsigned long long, 1); LAL(L.err, int, 1);
+        LAL(d_ok, int, 2); LAL(d_tee, float, am->hmm_tee.size()); LAL(d_L, LazyDev, 1);
+        L.max_states = (int)max_states; L.max_arcs = max_arcs;
+        CHK(hipMemset(L.keys, 0, cap * 8)); CHK(hipMemset(L.vals, 0xff, cap * 4));
+        CHK(hipMemset(L.n_states, 0, 4)); CHK(hipMemset(L.n_arcs, 0, 8)); CHK(hipMemset(L.err, 0, 4));
+        CHK(hipMemset(L.rows, 0, (size_t)max_states * sizeof(int4)));
+        CHK(hipMemcpy(d_tee, am->hmm_tee.data(), am->hmm_tee.size() * 4, hipMemcpyHostToDevice));
+        CHK(hipMemcpy(d_L, &L, sizeof L, hipMemcpyHostToDevice));
+        // the start state and its closure
+        hipLaunchKernelGGL(jl_init, dim3(1), dim3(64), 0, 0, L, d_tee, (unsigned)cl->init | LZ_FLAG, g->init, d_ok);
+        CHK(hipGetLastError());
+        CHK(hipMemcpy(h_ok, d_ok, sizeof h_ok, hipMemcpyDeviceToHost));
+        if (!h_ok[0]) { rc = jd_fail(JD_ENOMEM, "jd_net_create_lazy: capacities too small for the start state's closure"); goto done; }
+        n->n_states = (int32_t)max_states; n->n_arcs = max_arcs; n->init = h_ok[1];
+        n->n_final = 0; n->max_in = cl->max_in;
+        n->lm_scale = 1.0f; n->ins_penalty = 0.0f;
+        n->lazy_dev = d_L;
+        *out = n;
+        n = nullptr;
+    }
+done:
+    if (n) { lazy_free(n); delete n; }
+    return rc;
+}
+
+// how far a lazily composed network has grown: composed states and arcs materialised so far
+extern "C" int jd_net_lazy_size(const jd_net *n, int64_t *states, int64_t *arcs)
+{
+    if (!n || !n->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_lazy_size: not a lazily composed network");
+    if (hipSetDevice(n->lazy_device) != hipSuccess) return jd_fail(JD_EHIP, "hipSetDevice failed");
+    LazyDev L;
+    int ns = 0; unsigned long long na = 0;
+    if (hipMemcpy(&L, n->lazy_dev, sizeof L, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&ns, L.n_states, 4, hipMemcpyDeviceToHost) != hipSuccess
+        || hipMemcpy(&na, L.n_arcs, 8, hipMemcpyDeviceToHost) != hipSuccess) return jd_fail(JD_EHIP, "jd_net_lazy_size: copy failed");
+    if (states) *states = ns;
+    if (arcs) *arcs = (int64_t)na;
+    return JD_OK;
 }

@@ -963,14 +963,19 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         }
     }
 #define TRY(x) do { rc = (x); if (rc) { jd_dec_destroy(d); return rc; } } while (0)
-    TRY(dupload(d, &d->d_row_ptr, net->row_ptr.data(), net->row_ptr.size()));
-    {   // device arc table: bit 30 of the in-label marks arcs whose HMM is a tee model
+    const bool lazy = net->lazy_dev != nullptr;
+    if (lazy && net->lazy_device != device) {
+        jd_dec_destroy(d);
+        return jd_fail(JD_EINVAL, "jd_dec_create: the lazily composed network lives on device %d, not %d", net->lazy_device, device);
+    }
+    if (!lazy) TRY(dupload(d, &d->d_row_ptr, net->row_ptr.data(), net->row_ptr.size()));
+    if (!lazy) {   // device arc table: bit 30 of the in-label marks arcs whose HMM is a tee model
         std::vector<JdArc> darcs(net->arcs);
         for (JdArc &a : darcs)
             if (a.in > 0 && am->hmm_tee[(size_t)a.in - 1] > LZ) a.in |= TEE_FLAG;
         TRY(dupload(d, &d->d_arcs, darcs.data(), darcs.size()));
     }
-    TRY(dupload(d, &d->d_fin_w, net->fin_w.data(), net->fin_w.size()));
+    if (!lazy) TRY(dupload(d, &d->d_fin_w, net->fin_w.data(), net->fin_w.size()));
     TRY(dupload(d, &d->d_hmm_tee, am->hmm_tee.data(), am->hmm_tee.size()));
     {   // largest log transition probability out of the entry state of every HMM (phase X, hopeless candidates)
         std::vector<float> tmax((size_t)am->n_hmm, LZ);
@@ -989,7 +994,21 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init;
     C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
     C.hmm_tee = d->d_hmm_tee; C.n_hmm = am->n_hmm; C.hmm_tmax0 = d->d_hmm_tmax0;
-    {   // per-arc instance template: what phase A needs to attach an instance (attachNetInst :751-774),
+    C.lazy = (const LazyDev *)net->lazy_dev; C.aux_h = nullptr; C.aux = nullptr;
+    if (lazy) {   // the same template, by HMM: a growing graph has no per-arc table (one more hop through the arc's label)
+        const int AI = (am->max_n <= 5) ? 4 : 8;
+        std::vector<int> aux((size_t)am->n_hmm * AI, 0);
+        for (int hm = 0; hm < am->n_hmm; ++hm) {
+            const int n = am->hmm_n[(size_t)hm];
+            int *a = aux.data() + (size_t)hm * AI;
+            a[0] = n | (am->hmm_tm[(size_t)hm] << 8);
+            for (int j = 1; j < n - 1 && j <= (AI == 4 ? 3 : 6); ++j)
+                a[j] = am->hmm_gmm[(size_t)hm * am->max_n + j];
+        }
+        TRY(dupload(d, &d->d_aux, aux.data(), aux.size()));
+        C.aux_h = d->d_aux;
+        d->xl_ok = false;          // the graph is written by every cluster, on any XCD: agent scope throughout
+    } else {   // per-arc instance template: what phase A needs to attach an instance (attachNetInst :751-774),
         // one hop from the arc id: {nStates | transMat << 8, g0, g1, g2} (+ {g3, g4, g5, 0})
         const int AI = (am->max_n <= 5) ? 4 : 8;
         std::vector<int> aux((size_t)net->n_arcs * AI, 0);
@@ -1039,7 +1058,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_WEIGHTED")) d->weighted = atoi(e) != 0;
     if (const char *e = getenv("JD_MODEL_A")) d->model_a_us = atof(e);
     if (const char *e = getenv("JD_MODEL_B")) d->model_b_us = atof(e);
-    if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0;                      // development
+    if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0 && !lazy;             // development
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
     hipError_t e;
@@ -1267,6 +1286,11 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
             else if (K.error == JDE_BARRIER)
                 first_err = jd_fail(JD_EHIP, "stream %d: a workgroup of the search cluster did not arrive at a barrier "
                                     "(frame %d)", s0 + i, K.frame);
+            else if (K.error == JDE_LAZY_INV)
+                first_err = jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)", s0 + i, K.frame);
+            else if (K.error == JDE_LAZY)
+                first_err = jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of room at frame %d (capacity %d states, "
+                                    "%lld arcs): create it with larger max_states / max_arcs", s0 + i, K.frame, d->net->n_states, (long long)d->net->n_arcs);
             else {
                 const char *what = K.error == JDE_SLOTS ? "instance slots" : K.error == JDE_ITEMS ? "frontier items"
                                  : K.error == JDE_PATHS ? "Path records" : K.error == JDE_NEW ? "newly entered arcs" : "arena";
@@ -1459,8 +1483,9 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
         HIPCHK(hipEventRecord(e0, st));
-        if (ne3) { if (xl) hipLaunchKernelGGL((k_search<3, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<3, false>), dim3(grid), dim3(SNT), 0, st, A); }
-        else { if (xl) hipLaunchKernelGGL((k_search<6, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false>), dim3(grid), dim3(SNT), 0, st, A); }
+        if (d->C.lazy) { if (ne3) hipLaunchKernelGGL((k_search<3, false, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, true>), dim3(grid), dim3(SNT), 0, st, A); }
+        else if (ne3) { if (xl) hipLaunchKernelGGL((k_search<3, true, false>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<3, false, false>), dim3(grid), dim3(SNT), 0, st, A); }
+        else { if (xl) hipLaunchKernelGGL((k_search<6, true, false>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, false>), dim3(grid), dim3(SNT), 0, st, A); }
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));

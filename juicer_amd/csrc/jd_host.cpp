@@ -210,6 +210,7 @@ extern "C" int jd_net_get_csr(const jd_net *n, int32_t *row_ptr, int32_t *to, fl
                               float *fin_w)
 {
     if (!n) return jd_fail(JD_EINVAL, "jd_net_get_csr: null");
+    if (n->lazy_dev) return jd_fail(JD_ESTATE, "jd_net_get_csr: a lazily composed network has no finished arc table");
     if (row_ptr) memcpy(row_ptr, n->row_ptr.data(), n->row_ptr.size() * sizeof(int32_t));
     for (int64_t i = 0; i < n->n_arcs; ++i) {
         const JdArc &a = n->arcs[(size_t)i];
@@ -225,7 +226,7 @@ extern "C" int jd_net_get_csr(const jd_net *n, int32_t *row_ptr, int32_t *to, fl
 extern "C" int64_t jd_net_num_arcs(const jd_net *n) { return n ? n->n_arcs : 0; }
 extern "C" int32_t jd_net_num_states(const jd_net *n) { return n ? n->n_states : 0; }
 extern "C" int32_t jd_net_init_state(const jd_net *n) { return n ? n->init : -1; }
-extern "C" void jd_net_destroy(jd_net *n) { delete n; }
+extern "C" void jd_net_destroy(jd_net *n) { if (n && n->lazy_free) n->lazy_free(n); delete n; }
 
 // ------------------------------------------------------------- acoustic models
 
@@ -768,6 +769,7 @@ extern "C" int jd_net_load_jwnt(jd_net **out, const char *path, float lm_scale, 
 extern "C" int jd_net_save_jwnt(const jd_net *n, const char *path)
 {
     if (!n || !path) return jd_fail(JD_EINVAL, "jd_net_save_jwnt: null argument");
+    if (n->lazy_dev) return jd_fail(JD_ESTATE, "jd_net_save_jwnt: a lazily composed network has no finished arc table");
     BinWriter w;
     w.f = fopen(path, "wb");
     if (!w.f) return jd_fail(JD_EFORMAT, "WFSTNetwork::writeBinary - error opening output file %s", path);

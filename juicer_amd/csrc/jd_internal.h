@@ -25,6 +25,12 @@ struct jd_net {
     // the scaling the arc weights carry (transWeightScalingFactor / insPenalty of
     // WFSTNetwork.h); jd_net_save_jwnt removes it again the way writeBinary does
     float lm_scale = 1.0f, ins_penalty = 0.0f;
+    // search-driven composition (jd_net_create_lazy, jd_compose.hip): the graph lives on one device and grows
+    // while decoders search it; n_states / n_arcs are then its CAPACITIES and row_ptr / arcs / fin_w are empty
+    void *lazy_dev = nullptr;          // LazyDev (device copy)
+    int lazy_device = -1;
+    std::vector<void *> lazy_allocs;   // device allocations behind it
+    void (*lazy_free)(jd_net *) = nullptr;
 };
 
 struct jd_am {

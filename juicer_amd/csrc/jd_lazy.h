@@ -1,0 +1,293 @@
+// jd_lazy.h - search-driven composition of C.L and G: the graph the
+// search runs on grows while it runs.  Included by jd_search.h; the host side is in jd_compose.hip.
+//
+// The expansion step is jd_compose.hip's (binary-search match of the C.L arc's output label among the
+// G state's input-sorted arcs, back-off epsilons after a word only, interval look-ahead) applied to
+// ONE composed state at a time, by the wave of the search that needs it:
+//   invariant   every arc a live instance sits on leads to a CLOSED state: one that has its arcs and whose
+//               epsilon / tee arcs lead to closed states (what a token can reach within a frame) - phase X
+//               therefore never meets a state without arcs;
+//   who         after the last round of phase X every wave walks the arcs IT entered in this frame (its
+//               segment of the new list) and expands the destinations that are not ready, closure included;
+//   sharing     the graph belongs to the decoder, not to a stream: a state is claimed with an agent-scope
+//               compare-and-swap (unknown -> expanding), its arcs are appended to one arena (bump pointer,
+//               128-byte aligned blocks: no line is shared with a block written later) and its row
+//               {first, count, status, final weight} is published after the arcs have drained; a wave that
+//               loses a claim remembers the state and looks again.  Expansions never wait for each other;
+//   closed      "has arcs" (EXPANDED) is not yet "its closure has arcs": the wave that expanded D still has
+//               D's epsilon / tee destinations on its queue.  A state is marked CLOSED by a wave whose queue
+//               ran empty after it expanded D or walked D's arcs - everything below D is then expanded.
+//               The invariant is about CLOSED states; a wave that finds somebody else's EXPANDED state does
+//               not wait for its owner (two owners could wait for each other) but walks its closure itself.
+#ifndef JD_LAZY_H
+#define JD_LAZY_H
+
+#ifndef TEE_FLAG
+#define TEE_FLAG 0x40000000          // (jd_search.h)
+#endif
+#ifndef LZ
+#define LZ (-3.402823466e+38f)       // LOG_ZERO (jd_device.hip)
+#endif
+
+enum { LZ_UNKNOWN = 0, LZ_EXPANDING = 1, LZ_EXPANDED = 2, LZ_CLOSED = 3 };
+#define LZ_FLAG 0x80000000u          // the composition filter's flag, in the top bit of the stored C.L state
+#define LZQ 192                      // closure / pending states a wave can have outstanding
+#define LZD 64                       // states a wave has expanded / walked and not yet marked closed
+
+struct LazyDev {
+    const int *cl_row; const JdArc *cl_arcs; const float *cl_fin; const int2 *cl_la;
+    const int *g_row; const JdArc *g_arcs; const float *g_fin;
+    unsigned long long *keys; int *vals; unsigned long long mask;
+    int *st_c, *st_g;                 // composed state -> (C.L state | flag, G state)
+    int4 *rows;                       // composed state -> {first arc, arcs, status, final weight bits}
+    JdArc *arcs;                      // the arena
+    int *n_states; unsigned long long *n_arcs;
+    int max_states; long long max_arcs;
+    int *err;                         // 1: states exhausted, 2: arcs exhausted, 3: a wave's queue overflowed
+};
+
+// 8-byte write-through (agent-scope) stores: the graph is read by other workgroups, on any XCD, with `sc1` loads
+__device__ __forceinline__ void lz_st8(void *p, int lo, int hi)
+{
+    __hip_atomic_store((unsigned long long *)p, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lz_store_arc(JdArc *p, int to, float w, int in, int out)
+{
+    lz_st8(p, to, __float_as_int(w));
+    lz_st8(&p->in, in, out);
+}
+
+__device__ __forceinline__ unsigned long long lz_hash(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+
+// id of the composed state (cf, g); the lane that creates it writes its row {0, 0, UNKNOWN, final weight}
+// before the id becomes visible.  (Never blocks inside a branch, see jd_compose.hip.)
+__device__ int lz_state_id(const LazyDev &L, unsigned cf, int g)
+{
+    const unsigned long long key = (((unsigned long long)cf << 32) | (unsigned)g) + 1ULL;
+    unsigned long long slot = lz_hash(key) & L.mask;
+    bool mine = false;
+    int id = -1;
+    while (id < 0) {
+        if (!mine) {
+            const unsigned long long old = atomicCAS(&L.keys[slot], 0ULL, key);
+            if (old == 0ULL) {
+                id = atomicAdd(L.n_states, 1);
+                if (id < L.max_states) {
+                    const float fc = L.cl_fin[cf & ~LZ_FLAG], fg = L.g_fin[g];
+                    const bool fin = fc < __builtin_inff() && fg < __builtin_inff();
+                    __hip_atomic_store(&L.st_c[id], (int)cf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&L.st_g[id], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lz_st8(&L.rows[id].x, 0, 0);
+                    lz_st8(&L.rows[id].z, (int)LZ_UNKNOWN, __float_as_int(fin ? fc + fg : __builtin_inff()));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else { atomicMax(L.err, 1); id = L.max_states - 1; }
+                __hip_atomic_store(&L.vals[slot], id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (old == key) mine = true;
+            else slot = (slot + 1) & L.mask;
+        } else {
+            id = __hip_atomic_load(&L.vals[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (id < 0) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return id;
+}
+
+__device__ __forceinline__ int lz_match(const LazyDev &L, int g, int x)   // WFSTOnTheFlyDecoder.cpp:3106-3159
+{
+    int lo = L.g_row[g], hi = L.g_row[g + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int l = L.g_arcs[mid].in;
+        if (l == x) return mid;
+        if (l < x) lo = mid + 1; else hi = mid;
+    }
+    return -1;
+}
+__device__ __forceinline__ bool lz_any_in(const LazyDev &L, int g, int lo_l, int hi_l)
+{
+    if (lo_l > hi_l) return false;
+    int lo = L.g_row[g], hi = L.g_row[g + 1];
+    const int end = hi;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L.g_arcs[mid].in < lo_l) lo = mid + 1; else hi = mid;
+    }
+    return lo < end && L.g_arcs[lo].in <= hi_l;
+}
+__device__ __forceinline__ int lz_arc_kind(const LazyDev &L, const JdArc &ca, int g, int *ga)
+{
+    *ga = -1;
+    if (ca.out == 0) { const int2 la = L.cl_la[ca.to]; return lz_any_in(L, g, la.x, la.y) ? 1 : 0; }
+    *ga = lz_match(L, g, ca.out);
+    return *ga >= 0;
+}
+
+__device__ __forceinline__ int lz_status(const LazyDev &L, int s)
+{
+    return __hip_atomic_load(&L.rows[s].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sticky: once a capacity has run out the network is of no use to anybody (a state may be left half expanded)
+__device__ __forceinline__ bool lz_failed(const LazyDev &L)
+{
+    return __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// the wave-uniform state D has arcs and its closure is on the queue: remember it, to mark it when the queue runs empty
+__device__ __forceinline__ void lz_note(int D, int *q, int *dn)
+{
+    if (*dn < LZD) { if ((threadIdx.x & 63) == 0) q[LZQ + *dn] = D; ++*dn; }   // (full: it stays EXPANDED and is walked again some day)
+}
+
+// One wave makes sure composed state D (wave-uniform) has arcs, expanding it if nobody has.  The destinations
+// of its epsilon / tee arcs go onto the wave's queue q[0 .. *qn) (they must be closed within the same frame); a
+// state another wave is expanding goes onto the queue itself, to be looked at again.  q[LZQ .. LZQ + *dn) lists
+// what to mark closed.  Returns false when a capacity ran out.
+__device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q, int *qn, int *dn)
+{
+    const int lane = threadIdx.x & 63;
+    int st = 0;
+    if (lane == 0) st = atomicCAS(&L.rows[D].z, (int)LZ_UNKNOWN, (int)LZ_EXPANDING);
+    st = __shfl(st, 0);
+    if (st == LZ_CLOSED) return true;
+    if (st == LZ_EXPANDING) {                                          // somebody else's: check again later
+        if (*qn >= LZQ) { if (lane == 0) atomicMax(L.err, 3); return false; }
+        if (lane == 0) q[*qn] = D;
+        ++*qn;
+        return true;
+    }
+    if (st == LZ_EXPANDED) {                                           // somebody else's, closure not known to be complete: walk it
+        const unsigned long long fc = __hip_atomic_load((unsigned long long *)&L.rows[D].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int first = (int)(unsigned)fc, cnt = (int)(fc >> 32);
+        bool ok = true;
+        for (int a = 0; a < cnt && ok; a += 64) {
+            int to = -1;
+            bool closure = false;
+            if (a + lane < cnt) {
+                const JdArc *pa = &L.arcs[first + a + lane];
+                const int in = __hip_atomic_load(&pa->in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                closure = in == 0 || (in & TEE_FLAG) != 0;
+                if (closure) to = __hip_atomic_load(&pa->to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (unsigned long long bc = __ballot(closure); bc; bc &= bc - 1) {
+                const int t = __shfl(to, __ffsll((long long)bc) - 1);
+                if (*qn >= LZQ) { if (lane == 0) atomicMax(L.err, 3); ok = false; break; }
+                if (lane == 0) q[*qn] = t;
+                ++*qn;
+            }
+        }
+        if (ok) lz_note(D, q, dn);
+        return ok;
+    }
+    const unsigned cf = (unsigned)__hip_atomic_load(&L.st_c[D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c = (int)(cf & ~LZ_FLAG), g = __hip_atomic_load(&L.st_g[D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool flag = (cf & LZ_FLAG) != 0;
+    bool bo = false;
+    JdArc boa = {0, 0.0f, 0, 0};
+    if (flag && L.g_row[g + 1] > L.g_row[g]) { boa = L.g_arcs[L.g_row[g]]; bo = boa.in == 0; }
+    const int a0 = L.cl_row[c], a1 = L.cl_row[c + 1];
+    int mine = 0, ga;
+    for (int a = a0 + lane; a < a1; a += 64) mine += lz_arc_kind(L, L.cl_arcs[a], g, &ga);
+    int total = mine;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) total += __shfl_xor(total, o);
+    total += bo ? 1 : 0;
+    int base = 0;
+    if (lane == 0) {
+        const unsigned long long b64 = atomicAdd(L.n_arcs, (unsigned long long)((total + 7) & ~7));   // 128-byte blocks
+        base = (b64 + (unsigned long long)total > (unsigned long long)L.max_arcs) ? -1 : (int)b64;
+    }
+    base = __shfl(base, 0);
+    if (base < 0) { if (lane == 0) atomicMax(L.err, 2); return false; }
+    bool ok = true;
+    int run = base;
+    if (bo) {                                                          // the back-off arc: an epsilon - closure
+        int to = 0;
+        if (lane == 0) {
+            to = lz_state_id(L, cf, boa.to);
+            lz_store_arc(&L.arcs[run], to, boa.w, 0, boa.out);
+        }
+        to = __shfl(to, 0);
+        if (*qn >= LZQ) { if (lane == 0) atomicMax(L.err, 3); ok = false; } else { if (lane == 0) q[*qn] = to; ++*qn; }
+        ++run;
+    }
+    for (int a = a0; a < a1; a += 64) {
+        const bool on = a + lane < a1;
+        JdArc ca = {0, 0.0f, 0, 0};
+        int cnt = 0;
+        ga = -1;
+        if (on) { ca = L.cl_arcs[a + lane]; cnt = lz_arc_kind(L, ca, g, &ga); }
+        int pre = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(pre, o); if (lane >= o) pre += y; }
+        const int chunk_total = __shfl(pre, 63);
+        int to = -1;
+        bool closure = false;
+        if (cnt) {
+            const int pos = run + pre - 1;
+            const bool tee = ca.in > 0 && hmm_tee[ca.in - 1] > LZ;
+            const int in = ca.in | (tee ? TEE_FLAG : 0);
+            if (ca.out == 0) { to = lz_state_id(L, (unsigned)ca.to, g); lz_store_arc(&L.arcs[pos], to, ca.w, in, 0); }
+            else {
+                const JdArc m = L.g_arcs[ga];
+                to = lz_state_id(L, (unsigned)ca.to | LZ_FLAG, m.to);
+                lz_store_arc(&L.arcs[pos], to, ca.w + m.w, in, m.out);
+            }
+            closure = ca.in == 0 || tee;                               // reachable within the frame a token reaches D
+        }
+        for (unsigned long long bc = __ballot(closure); bc; bc &= bc - 1) {
+            const int src = __ffsll((long long)bc) - 1;
+            const int t = __shfl(to, src);
+            if (*qn >= LZQ) { if (lane == 0) atomicMax(L.err, 3); ok = false; break; }
+            if (lane == 0) q[*qn] = t;
+            ++*qn;
+        }
+        run += chunk_total;
+    }
+    // the arcs are in memory (write-through stores, drained) before the row says so; {first, count} before the status
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        lz_st8(&L.rows[D].x, base, total);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&L.rows[D].z, (int)LZ_EXPANDED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (ok) lz_note(D, q, dn);
+    return ok;
+}
+
+// drains a wave's queue: expands what is unknown, walks what others expanded, looks again at what others are
+// expanding; once it is empty everything noted since it was last empty is closed
+__device__ bool lz_drain(const LazyDev &L, const float *hmm_tee, int *q, int *qn, int *dn, long long t_limit)
+{
+    bool ok = true;
+    unsigned spins = 0;
+    while (*qn > 0 && ok) {
+        const int D = q[--*qn];
+        const int st = lz_status(L, D);
+        if (st == LZ_CLOSED) continue;
+        if (st == LZ_EXPANDING) {                                      // another wave's expansion: it does not wait for anybody
+            __builtin_amdgcn_s_sleep(4);
+            // (behind the rest of the queue, so that the wait is spent on other work)
+            for (int k = *qn; k > 0; --k) q[k] = q[k - 1];
+            q[0] = D; ++*qn;
+            ++spins;
+            if ((spins & 63u) == 0 && lz_failed(L)) return false;      // (an expansion that ran out of room never finishes)
+            if ((spins & 4095u) == 0 && wall_clock64() > t_limit) { atomicMax(L.err, 3); return false; }
+            continue;
+        }
+        ok = lz_expand(L, hmm_tee, D, q, qn, dn);
+    }
+    if (ok) {
+        const int lane = threadIdx.x & 63;
+        for (int k = lane; k < *dn; k += 64) __hip_atomic_store(&L.rows[q[LZQ + k]].z, (int)LZ_CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *dn = 0;
+    }
+    return ok;
+}
+
+#endif

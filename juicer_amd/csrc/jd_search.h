@@ -42,7 +42,7 @@
 #define TEE_LDS_MAX 2048             // HMMs whose tee log-probability is cached in LDS
 
 enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_INSTS, ST_N };
-enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_BARRIER = -50 };
+enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_LAZY = -45, JDE_LAZY_INV = -46, JDE_BARRIER = -50 };
 
 struct DecConst {
     // network (CSR in HBM)
@@ -51,6 +51,8 @@ struct DecConst {
     // models
     int G, max_n, n_tm;
     const float *hmm_tee; int n_hmm;
+    const struct LazyDev *lazy;   // search-driven composition (jd_lazy.h): the graph grows while the search runs; else null
+    const int *aux_h;             // the instance template of an arc, by HMM (lazy graphs have no per-arc table)
     const float *hmm_tmax0;   // per HMM: largest log transition probability out of the entry state
     const float *trP; const int *se32;
     const float *lrt;   // left-to-right topologies only (else null): per transMat a_1.., s_1.. (see phase A)
@@ -170,6 +172,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigne
 }
 // 16-byte agent-scope (sc1) accesses through a wave-uniform buffer descriptor (out-of-range
 // offsets read 0 / are dropped by the hardware bounds check)
+#include "jd_lazy.h"
+
 // Two ways of making a stream's mutable words visible to the other workgroups of its cluster.
 //   XL = false  agent scope: `sc1` (write-through) stores, agent-scope atomics; right wherever the
 //               workgroups run.  An `sc1` store (and an agent-scope atomic) drops its line from the XCD's
@@ -231,6 +235,7 @@ struct SearchShared {
     int hprev[HIST_MAX_BINS];                  // the stream's bins of the previous frame
     float trP[TRP_LDS_MAX]; int se[TRP_LDS_MAX / 4];   // transition tables (when they fit)
     float tee[TEE_LDS_MAX];                    // tee transition log-probability per HMM (when they fit)
+    int lzq[SW][LZQ + LZD];                       // lazy graphs: per wave, composed states still to be made ready
     int wpfx[SW][64];                          // phase X: per wave, prefix of the out-degrees of its 64 items
     v4i qtok[SW][QCAP], qinfo[SW][QCAP];       // phase X: per wave, closure items it will expand itself
     int wsum[NLISTS][SW], wsum2[NLISTS][SW];
@@ -400,6 +405,7 @@ __device__ __host__ __forceinline__ Geo make_geo(const DecConst &C, int nw)
 struct StreamView {     // wave-uniform descriptors of one stream's arenas
     __amdgpu_buffer_rsrc_t rec, items;          // both frame parities in one descriptor each
     unsigned rec_par, item_par;                 // byte offset of parity 1 in them
+    __amdgpu_buffer_rsrc_t lrows, larcs;        // lazy graphs: the rows and the arc arena (read with `sc1` loads)
     ArcState *ast; unsigned long long *skey0, *skeyC, *skeyL; int *newl, *cleanl, *dirtyl; int *tot; PathRec *paths; int *hist;
 };
 
@@ -449,7 +455,7 @@ __device__ __forceinline__ unsigned rec_chunk_off(unsigned seg_rec, int w, int c
 #define XFINE_COUNT(k) do { } while (0)
 #endif
 
-template <int NE, bool TRPL, bool LR, bool XL>
+template <int NE, bool TRPL, bool LR, bool XL, bool LZY>
 __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
                                         const Geo &gin, const Geo &gout, const int (&Q)[4], int jw, int Cw, int gw, int p,
                                         float normalise, float emitTh, float startTh, const float *llrow,
@@ -498,11 +504,22 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     auto stage_k = [&](bool is_new, bool valid, int nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1],
                        unsigned long long &kv, float (&outp)[NE]) __attribute__((always_inline)) {
         if (is_new) {                                                  // attachNetInst :751-774, from the arc's template
-            const JdArc Bk = C.arcs[nb];
-            const int4 a0 = ((const int4 *)C.aux)[(NE == 3) ? nb : 2 * nb];
+            JdArc Bk;
+            int4 a0, a1 = make_int4(0, 0, 0, 0);
+            if (LZY) {                                                 // the arena, and the template by HMM
+                const v4i r = ld16(V.larcs, (unsigned)nb * 16u);
+                Bk = JdArc{r.x, __int_as_float(r.y), r.z, r.w};
+                const int hm = (Bk.in & ~TEE_FLAG) - 1;
+                a0 = ((const int4 *)C.aux_h)[(NE == 3) ? hm : 2 * hm];
+                if (NE == 6) a1 = ((const int4 *)C.aux_h)[2 * hm + 1];
+            } else {
+                Bk = C.arcs[nb];
+                a0 = ((const int4 *)C.aux)[(NE == 3) ? nb : 2 * nb];
+                if (NE == 6) a1 = ((const int4 *)C.aux)[2 * nb + 1];
+            }
             h0 = (v4i){nb, valid ? a0.x : 0, Bk.out, Bk.to};
             h1 = (v4i){a0.y, a0.z, a0.w, __float_as_int(Bk.w)};
-            if (NE == 6) { const int4 a1 = ((const int4 *)C.aux)[2 * nb + 1]; h2 = (v4i){a1.x, a1.y, a1.z, 0}; }
+            if (NE == 6) h2 = (v4i){a1.x, a1.y, a1.z, 0};
 #pragma unroll
             for (int j = 1; j <= NE; ++j) tk[j] = null_tok();
         }
@@ -743,7 +760,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
 // candidate arrives that is not hopeless; an arc whose first candidate was hopeless goes to the
 // clean-up list so that its key does not outlive the frame.
 struct XOut { int item_cnt; int new_cnt; int clean_cnt; int dirty_cnt; };
-template <bool XL>
+template <bool XL, bool LZY>
 __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
                                         const Geo &gin, const Geo &gout, int Q, int KX, int round, int jw, int Cw, int gw,
                                         int p, int pframe, bool init, bool last_frame, float endTh, float wordTh,
@@ -798,7 +815,13 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         const bool real = valid && info.x >= 0 && slice_no == 0;       // an item that traversed an arc (a slice has been through all this)
         const int state = !valid ? 0 : (info.x >= 0) ? info.z : C.init_state;
         // second level, in flight together: CSR row bounds, the state's key, the Path reservation
-        const int rs = C.row_ptr[state], rs1 = C.row_ptr[state + 1];
+        int rs, rs1;
+        float fin_lazy = 0.0f;
+        if (LZY) {                                                     // {first arc, arcs, status, final weight}: ready by the invariant
+            const v4i r = ld16(V.lrows, (unsigned)state * 16u);
+            rs = r.x; rs1 = r.x + r.y; fin_lazy = __int_as_float(r.w);
+            if (valid && r.z < LZ_EXPANDED) CS(&c.err[p], (int)JDE_LAZY_INV);   // (cannot happen: the invariant of jd_lazy.h)
+        } else { rs = C.row_ptr[state]; rs1 = C.row_ptr[state + 1]; }
         unsigned long long *sk = (!exit_kind ? V.skeyC : (info.y != 0) ? V.skeyL : V.skey0) + state;
         unsigned long long kv = 0ULL;
         if (real) kv = CL(sk);
@@ -841,7 +864,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             // :513-520 final state.  bestFinalToken is reset every frame (:316) and only read by
             // finish(), so it only has to be evaluated on the last frame that is available.
             if (last_frame) {
-                const float fw = C.fin_w[info.z];
+                const float fw = LZY ? fin_lazy : C.fin_w[info.z];
                 if (fw < INF) {
                     const float cs = t.score + fw;
                     if (cs > LZ) GMAX(&c.final_key, ((unsigned long long)f2o(cs) << 32) | ii);
@@ -888,7 +911,11 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         int g_nx = owner_of(lane);
         int b_nx = __shfl(alo, g_nx) + (lane - wpfx[g_nx]);
         JdArc Bk_nx = {0, 0.0f, 0, 0};
-        if (lane < tot) Bk_nx = C.arcs[b_nx];
+        auto arc_at = [&](int b) __attribute__((always_inline)) -> JdArc {
+            if (LZY) { const v4i r = ld16(V.larcs, (unsigned)b * 16u); return JdArc{r.x, __int_as_float(r.y), r.z, r.w}; }
+            return C.arcs[b];
+        };
+        if (lane < tot) Bk_nx = arc_at(b_nx);
         XFINE(3);                                                      // prefix + hop 3: the first 64 arcs
 #pragma nounroll
         for (int a0 = 0; a0 < tot; a0 += 64) {
@@ -899,7 +926,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             if (a0 + 64 < tot) {                                       // next pass's arc records: in flight during this one
                 g_nx = owner_of(a + 64);
                 b_nx = __shfl(alo, g_nx) + (a + 64 - wpfx[g_nx]);
-                if (a + 64 < tot) Bk_nx = C.arcs[b_nx];
+                if (a + 64 < tot) Bk_nx = arc_at(b_nx);
             }
             Tok tg;
             tg.score = __shfl(t.score, g); tg.ac = __shfl(t.ac, g);
@@ -1027,7 +1054,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
 
 // ------------------------------------------------------------------ one stream, one launch
 
-template <int NE, bool XL>
+template <int NE, bool XL, bool LZY>
 __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw)
 {
     constexpr bool XL_ = XL;
@@ -1056,6 +1083,10 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     V.ast = S.ast; V.skey0 = S.skey[0]; V.skeyC = S.skey[1]; V.skeyL = S.skeyL;
     V.newl = S.newl; V.cleanl = S.cleanl; V.dirtyl = S.dirtyl;
     V.tot = S.tot; V.paths = S.paths; V.hist = S.hist;
+    if (LZY) {
+        V.lrows = mk_rsrc(C.lazy->rows, (unsigned long long)C.lazy->max_states * 16ULL);
+        V.larcs = mk_rsrc(C.lazy->arcs, (unsigned long long)C.lazy->max_arcs * 16ULL);
+    }
     const bool use_hist = C.max_hyps > 0;
     const bool lr = C.lrt != nullptr;                                  // plain left-to-right topologies (compact table in LDS)
     const bool trp_lds = !lr && (size_t)C.n_tm * MN * MN <= TRP_LDS_MAX && (size_t)C.n_tm * MN <= TRP_LDS_MAX / 4;
@@ -1199,9 +1230,9 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const float *llrow = A.ll + (size_t)ll_slot * A.ll_stride + (size_t)(f - A.f0) * C.G;
             int out_cnt = 0;
             CLK(0);                                                    // thresholds + work lists
-            if (lr) phase_a<NE, true, true, XL>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else if (trp_lds) phase_a<NE, true, false, XL>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else phase_a<NE, false, false, XL>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            if (lr) phase_a<NE, true, true, XL, LZY>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else if (trp_lds) phase_a<NE, true, false, XL, LZY>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else phase_a<NE, false, false, XL, LZY>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
             CLK(1);                                                    // phase A (wave 0's share)
             if (lane == 0) {
                 CS(tot_of(TOT_REC0 + (p ^ 1)) + gw, out_cnt);
@@ -1264,7 +1295,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             CLK(4);                                                    // phase X work lists
             const int round_start = xo.item_cnt;
             int deferred = 0;
-            phase_x<XL>(C, sh, c, V, gin, gout, Q, KX, round, jw, Cw, gw, p, init ? 0 : f, init, last_frame, endTh, wordTh, bestA, xo, deferred);
+            phase_x<XL, LZY>(C, sh, c, V, gin, gout, Q, KX, round, jw, Cw, gw, p, init ? 0 : f, init, last_frame, endTh, wordTh, bestA, xo, deferred);
             CLK(5);                                                    // phase X (wave 0's share)
             if (lane == 0) {
                 CS(tot_of(TOT_CL0 + ((round + 1) & 1)) + gw, deferred > 0 ? xo.item_cnt - round_start : 0);
@@ -1284,6 +1315,28 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             CLK(7);                                                    // cluster barriers of phase X
         }
         if (aborted) break;
+        if (LZY) {
+            // search-driven composition: the arcs this wave entered in this frame lead to states that phase X
+            // of a later frame will expand - make them ready now, epsilon / tee closure included (jd_lazy.h)
+            const LazyDev &L = *C.lazy;
+            int *q = sh.lzq[wid];
+            int qn = 0, dn = 0;
+            bool ok = true;
+            const size_t nbase = (size_t)gw * gout.seg_new;
+            for (int i0 = 0; i0 < xo.new_cnt && ok; i0 += 64) {
+                int dest = -1;
+                if (i0 + lane < xo.new_cnt) {
+                    const int b = CL(V.newl + nbase + (unsigned)(i0 + lane));
+                    dest = ld16(V.larcs, (unsigned)b * 16u).x;
+                    if (lz_status(L, dest) == LZ_CLOSED) dest = -1;
+                }
+                for (unsigned long long bm = __ballot(dest >= 0); bm && ok; bm &= bm - 1) {
+                    const int D = __shfl(dest, __ffsll((long long)bm) - 1);
+                    ok = lz_expand(L, C.hmm_tee, D, q, &qn, &dn) && lz_drain(L, C.hmm_tee, q, &qn, &dn, t_limit);
+                }
+            }
+            if ((!ok || lz_failed(L)) && lane == 0) CS(&c.err[p], (int)JDE_LAZY);
+        }
         my_item_end = xo.item_cnt;
         // ---- frame end
         {
@@ -1301,7 +1354,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 const unsigned fi = (unsigned)(fk & 0xffffffffULL);
                 const unsigned ic = p ? V.item_par : 0u;
                 const Tok it = as_tok(ld16(V.items, ic + fi * 32u));
-                const float fw = C.fin_w[ld16(V.items, ic + fi * 32u + 16u).z];
+                const int fst = ld16(V.items, ic + fi * 32u + 16u).z;
+                const float fw = LZY ? __int_as_float(ld16(V.lrows, (unsigned)fst * 16u).w) : C.fin_w[fst];
                 bf.score = o2f((unsigned)(fk >> 32)); bf.ac = it.ac; bf.lm = it.lm + fw; bf.path = it.path;
                 CS(&c.final_key, 0ULL);
             }
@@ -1342,7 +1396,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
 // one stream per workgroup): stream k owns the workgroups [first_k, first_k + n_k) - the host sizes
 // the clusters by the streams' recent load.  All workgroups of the grid must be resident at once:
 // the host sizes the grid to the device (one 512-thread workgroup per CU).
-template <int NE, bool XL>
+template <int NE, bool XL, bool LZY>
 __global__ __launch_bounds__(SNT) void k_search(SearchArgs A)
 {
     __shared__ SearchShared sh;
@@ -1359,5 +1413,5 @@ __global__ __launch_bounds__(SNT) void k_search(SearchArgs A)
         Cw = RFL(A.work[lo].w); jw = (int)wg - first;
         k = (jw < Cw) ? lo : A.n_work; kstep = A.n_work;
     }
-    for (; k < A.n_work; k += kstep) run_stream<NE, XL>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw);
+    for (; k < A.n_work; k += kstep) run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw);
 }

@@ -1,0 +1,103 @@
+"""Dynamic-composition row, second step: C.L o G expanded BY THE SEARCH, where
+its tokens go (jd_net_create_lazy, csrc/jd_lazy.h) - the network is never built as a whole.
+
+The check is the static path on jd_net_compose's graph (itself checked against offline composition and
+the CPU oracle in test_gpu_compose.py): same expansion step, so the same arcs in the same order within a
+state, so bit-identical hypotheses - whatever the order in which states were discovered."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [dict(seed=5, n_words=40, n_succ=4, n_tri=30, with_sp=True, lm=1.0),
+         dict(seed=6, n_words=60, n_succ=6, n_tri=0, with_sp=False, lm=7.5),
+         dict(seed=8, n_words=25, n_succ=3, n_tri=40, with_sp=True, lm=3.0)]
+
+
+def _case(c, n_gmm=100, n_hmm=45):
+    from juicer_amd import capi, synth
+    am = synth.make_models(c["seed"], n_gmm=n_gmm, n_hmm=n_hmm, n_mix=2, n_tm=8, sep=0.6, with_tee=c["with_sp"])
+    cl, g = synth.make_cl_g(c["seed"], am, n_words=c["n_words"], n_succ=c["n_succ"], n_tri=c["n_tri"], with_sp=c["with_sp"])
+    return am, g, capi.Network.from_synth(cl, 1.0, 0.0), capi.Network.from_synth(g, c["lm"], 0.0)
+
+
+def _same(a, b):
+    assert a.n == b.n
+    assert np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
+    for k in ("score", "ac", "lm", "tot_score", "tot_lm"):
+        x, y = np.asarray(getattr(a, k), np.float32), np.asarray(getattr(b, k), np.float32)
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), k
+    for k in ("tot_proc_end_hyps", "tot_paths", "tot_insts_in"):
+        assert a.stats[k] == b.stats[k], k
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: "seed%d" % c["seed"])
+def test_lazy_composition_decodes_like_the_composed_graph(built, c):
+    from juicer_amd import capi, synth
+    am, g, ncl, ng = _case(c)
+    models = capi.Models.from_htk(am)
+    static = capi.Network.compose(ncl, ng)
+    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    s0, a0 = lazy.lazy_size()
+    assert 0 < s0 < static.n_states                    # only the start state's neighbourhood exists
+    feats = [synth.sample_utterance(c["seed"] + 1000 + u, g, am, 6 + u)[0] for u in range(6)]
+    kw = dict(main_beam=300.0, max_streams=3)
+    want = capi.Decoder(static, models, **kw).decode_batch(feats)
+    dec = capi.Decoder(lazy, models, **kw)
+    got = dec.decode_batch(feats[:3])                  # three streams expand the shared graph at once
+    s1, a1 = lazy.lazy_size()
+    got += dec.decode_batch(feats[3:])                 # ... and later utterances reuse it
+    s2, a2 = lazy.lazy_size()
+    assert sum(h.n for h in want) > 0
+    for u in range(len(feats)):
+        _same(got[u], want[u])
+    assert s0 < s1 <= s2 <= static.n_states            # never more than the reachable composition
+    # a second decoder on the grown network, and the same utterances again: nothing new to expand
+    again = capi.Decoder(lazy, models, **kw).decode_batch(feats[:3])
+    for u in range(3):
+        _same(again[u], want[u])
+    assert lazy.lazy_size() == (s2, a2)
+
+
+def test_lazy_composition_streaming_and_wide_beam(built):
+    """An unpruned search expands (nearly) everything reachable, and never more than the full composition; the streaming interface (decoderInit / processFrame / decoderFinish) drives it too."""
+    from juicer_amd import capi, synth
+    c = CASES[2]
+    am, g, ncl, ng = _case(c)
+    models = capi.Models.from_htk(am)
+    static = capi.Network.compose(ncl, ng)
+    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    x = synth.sample_utterance(c["seed"] + 77, g, am, 12)[0]
+    want = capi.Decoder(static, models, main_beam=0.0).decode_batch([x])[0]
+    dec = capi.Decoder(lazy, models, main_beam=0.0)
+    dec.stream_init(0)
+    for i in range(0, x.shape[0], 7):
+        dec.stream_push(0, x[i:i + 7])
+    got = dec.stream_finish(0)
+    _same(got, want)
+    ns = lazy.lazy_size()[0]
+    assert 0.9 * static.n_states <= ns <= static.n_states
+
+
+def test_lazy_network_errors(built):
+    from juicer_amd import capi, synth
+    c = CASES[0]
+    am, g, ncl, ng = _case(c)
+    models = capi.Models.from_htk(am)
+    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    with pytest.raises(capi.JuicerAmdError):
+        lazy.csr()
+    with pytest.raises(capi.JuicerAmdError):
+        capi.Network.lazy(lazy, ng, models)
+    # no room to grow into: creation fails if the start state's closure does not fit, decoding otherwise
+    x = synth.sample_utterance(c["seed"] + 5, g, am, 8)[0]
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        small = capi.Network.lazy(ncl, ng, models, max_states=256, max_arcs=1 << 18)
+        capi.Decoder(small, models, main_beam=300.0).decode_batch([x])
+    assert ei.value.code == capi.JD_ENOMEM
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        small = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=512)
+        capi.Decoder(small, models, main_beam=300.0).decode_batch([x])
+    assert ei.value.code == capi.JD_ENOMEM
+    # the decoder still works on a network with room
+    assert capi.Decoder(lazy, models, main_beam=300.0).decode_batch([x])[0].n >= 0
