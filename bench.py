@@ -130,10 +130,40 @@ def compose_leg(seed, dev, pushing=False):
         n_arcs = net.n_arcs
     out = run_leg("configs[4], composed on the device (lexicon tree o back-off trigram%s)" % (", weights pushed" if pushing else ""),
                   am, _Size, feats, 200.0, 0, dev, gnet=net)
+    if not pushing:
+        out["search_driven"] = lazy_part(ncl, ng, am, feats, dev, net.n_states, net.n_arcs, gnet=net)
     out["composition"] = {"pushing": bool(pushing), "cl_arcs": int(cl.n_arcs), "g_arcs": int(g.n_arcs), "states": net.n_states, "arcs": net.n_arcs,
                           "seconds_incl_pcie": round(best, 4), "arcs_per_s": round(net.n_arcs / best, 1),
                           "generator_seconds": round(t_gen, 1)}
     return out
+
+
+def lazy_part(ncl, ng, am, feats, dev, full_states, full_arcs, gnet):
+    """The same leg with nothing composed beforehand (jd_net_create_lazy): the search expands the composed
+    states it reaches.  Cold = the first pass, while the graph grows; warm = the same utterances again."""
+    from juicer_amd import capi
+    models = capi.Models.from_htk(am)
+    want = capi.Decoder(gnet, models, main_beam=200.0, device=dev.index, max_streams=len(feats)).decode_batch(feats)
+    t0 = time.perf_counter()
+    lz = capi.Network.lazy(ncl, ng, models, device=dev.index, max_states=1 << 23, max_arcs=1 << 25)
+    t_create = time.perf_counter() - t0
+    dec = capi.Decoder(lz, models, main_beam=200.0, device=dev.index, max_streams=len(feats))
+    frames = sum(f.shape[0] for f in feats)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        hyps = dec.decode_batch(feats)
+        times.append(time.perf_counter() - t0)
+    ns, na = lz.lazy_size()
+    same = sum(int(a.n == b.n and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
+                   and np.array_equal(np.asarray(a.score, np.float32).view(np.uint32), np.asarray(b.score, np.float32).view(np.uint32)))
+               for a, b in zip(hyps, want))
+    tm = dec.last_timing()
+    dec.close()
+    return {"create_s": round(t_create, 4), "cold_pass_s_incl_arena_setup": round(times[0], 3), "warm_frames_per_s_incl_pcie": round(frames / min(times[1:]), 1),
+            "warm_search_ms": round(tm["search_ms"], 3), "states_expanded": ns, "arcs_expanded": na,
+            "fraction_of_full_composition": round(ns / max(1, full_states), 4),
+            "identical_to_composed_first": "%d/%d" % (same, len(feats))}
 
 
 def spawn_ranks(n):

@@ -132,7 +132,7 @@ int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t devi
  */
 int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *g, const jd_am *am, int32_t device,
                        int64_t max_states, int64_t max_arcs);
-/* composed states and arcs (arena entries, with alignment padding) materialised so far */
+/* composed states and arcs materialised so far */
 int jd_net_lazy_size(const jd_net *n, int64_t *states, int64_t *arcs);
 
 /* ---------------------------------------------------------- acoustic models */

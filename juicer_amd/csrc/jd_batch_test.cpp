@@ -102,7 +102,7 @@ int main(int argc, char **argv)
     const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *mmf = 0, *list = 0;
     const char *gramFsm = 0, *gramInSyms = 0, *gramOutSyms = 0;              // juicer.cpp:128-130: separate C.L and G
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
-    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0, nDevices = 0, pushing = 0;
+    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0, nDevices = 0, pushing = 0, lazy = 0;
     std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
     const char *refFName = 0;                  // -refFName: expected results, MLF or one line per file (juicer.cpp:267)
     const char *outputFName = 0;               // -outputFName: "", "stdout", "stderr" or a file (DecoderBatchTest.cpp:216-230)
@@ -114,6 +114,7 @@ int main(int argc, char **argv)
         if (a == "-fsmFName") fsm = nxt(); else if (a == "-inSymsFName") insyms = nxt();
         else if (a == "-gramFsmFName") gramFsm = nxt(); else if (a == "-gramInSymsFName") gramInSyms = nxt();
         else if (a == "-gramOutSymsFName") gramOutSyms = nxt(); else if (a == "-pushing") pushing = 1;   // juicer.cpp:240
+        else if (a == "-lazy") lazy = 1;                                         // compose where the search goes (jd_net_create_lazy)
         else if (a == "-outSymsFName") outsyms = nxt(); else if (a == "-modelsFName") amf = nxt();
         else if (a == "-htkModelsFName") mmf = nxt();
         else if (a == "-inputFName") list = nxt(); else if (a == "-mainBeam") mainBeam = (float)atof(nxt());
@@ -136,14 +137,15 @@ int main(int argc, char **argv)
                         "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles] [-refFName REF] [-removeSentMarks]\n"
                         "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n"
                         "       [-device d | -devices N   (N GPUs of this node: utterances sharded, one RCCL gather of the 1-best)]\n"
-                        "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S] [-pushing]   (-fsmFName is then C.L: composed with G on the device)]\n");
+                        "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S] [-pushing] [-lazy]   (-fsmFName is then C.L: composed with G on the\n"
+                        "        device, as a whole before the search or - with -lazy - by the search, where it goes)]\n");
         return 2;
     }
     if (outputFName && outputFName[0] && strcmp(outputFName, "stdout") != 0) {     // DecoderBatchTest::openOutputFile
         if (strcmp(outputFName, "stderr") == 0) { if (dup2(2, 1) < 0) { perror("dup2"); return 1; } }
         else if (!freopen(outputFName, "wb", stdout)) { fprintf(stderr, "DecoderBatchTest::setupOutputFile - error opening output file\n"); return 1; }
     }
-    jd_net *net = 0;
+    jd_net *net = 0, *lazy_cl = 0, *lazy_g = 0;
     const std::string netBin = std::string(fsm) + ".bin";                    // juicer.cpp:854-882
     if (gramFsm) {
         // -gramFsmFName switches to on-the-fly composition (juicer.cpp:332-333): -fsmFName is C.L, loaded with
@@ -152,10 +154,16 @@ int main(int argc, char **argv)
         jd_net *cl = 0, *g = 0;
         if (jd_net_load_fsm(&cl, fsm, insyms, outsyms, 1.0f, 0.0f)) die("jd_net_load_fsm (C.L)");
         if (jd_net_load_fsm(&g, gramFsm, gramInSyms, gramOutSyms, lmScale, 0.0f)) die("jd_net_load_fsm (G)");
-        if (jd_net_compose(&net, cl, g, device, 0, 0, pushing)) die("jd_net_compose");
-        fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs) composed on device %d: %d states, %lld arcs\n", (long long)jd_net_num_arcs(cl),
-                (long long)jd_net_num_arcs(g), device, (int)jd_net_num_states(net), (long long)jd_net_num_arcs(net));
-        jd_net_destroy(cl); jd_net_destroy(g);
+        if (lazy) {
+            // the reference's mode proper: nothing is composed before the search starts (needs the models: tee HMMs)
+            if (pushing || nDevices > 0) { fprintf(stderr, "-lazy: not together with -pushing / -devices\n"); return 2; }
+            lazy_cl = cl; lazy_g = g;
+        } else {
+            if (jd_net_compose(&net, cl, g, device, 0, 0, pushing)) die("jd_net_compose");
+            fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs) composed on device %d: %d states, %lld arcs\n", (long long)jd_net_num_arcs(cl),
+                    (long long)jd_net_num_arcs(g), device, (int)jd_net_num_states(net), (long long)jd_net_num_arcs(net));
+            jd_net_destroy(cl); jd_net_destroy(g);
+        }
     } else if (file_exists(netBin)) {
         fprintf(stderr, "network from pre-existing binary file %s\n", netBin.c_str());
         if (jd_net_load_jwnt(&net, netBin.c_str(), lmScale, insPen)) die("jd_net_load_jwnt");
@@ -175,6 +183,12 @@ int main(int argc, char **argv)
         }
     } else am = load_jdam(amf);
     const int D = jd_am_vec_size(am);
+    if (lazy_cl) {
+        if (jd_net_create_lazy(&net, lazy_cl, lazy_g, am, device, 0, 0)) die("jd_net_create_lazy");
+        fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs): composed by the search on device %d\n", (long long)jd_net_num_arcs(lazy_cl),
+                (long long)jd_net_num_arcs(lazy_g), device);
+        jd_net_destroy(lazy_cl); jd_net_destroy(lazy_g);
+    }
 
     // configureTests: list of input files
     std::vector<std::string> files;

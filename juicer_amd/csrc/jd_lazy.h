@@ -10,8 +10,9 @@
 //   who         after the last round of phase X every wave walks the arcs IT entered in this frame (its
 //               segment of the new list) and expands the destinations that are not ready, closure included;
 //   sharing     the graph belongs to the decoder, not to a stream: a state is claimed with an agent-scope
-//               compare-and-swap (unknown -> expanding), its arcs are appended to one arena (bump pointer,
-//               128-byte aligned blocks: no line is shared with a block written later) and its row
+//               compare-and-swap (unknown -> expanding), its arcs are appended to one arena (bump pointer;
+//               written with write-through stores and read with `sc1` loads like every mutable word of the
+//               search, so blocks need no alignment) and its row
 //               {first, count, status, final weight} is published after the arcs have drained; a wave that
 //               loses a claim remembers the state and looks again.  Expansions never wait for each other;
 //   closed      "has arcs" (EXPANDED) is not yet "its closure has arcs": the wave that expanded D still has
@@ -198,7 +199,7 @@ __device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q,
     total += bo ? 1 : 0;
     int base = 0;
     if (lane == 0) {
-        const unsigned long long b64 = atomicAdd(L.n_arcs, (unsigned long long)((total + 7) & ~7));   // 128-byte blocks
+        const unsigned long long b64 = atomicAdd(L.n_arcs, (unsigned long long)total);
         base = (b64 + (unsigned long long)total > (unsigned long long)L.max_arcs) ? -1 : (int)b64;
     }
     base = __shfl(base, 0);

@@ -235,7 +235,6 @@ struct SearchShared {
     int hprev[HIST_MAX_BINS];                  // the stream's bins of the previous frame
     float trP[TRP_LDS_MAX]; int se[TRP_LDS_MAX / 4];   // transition tables (when they fit)
     float tee[TEE_LDS_MAX];                    // tee transition log-probability per HMM (when they fit)
-    int lzq[SW][LZQ + LZD];                       // lazy graphs: per wave, composed states still to be made ready
     int wpfx[SW][64];                          // phase X: per wave, prefix of the out-degrees of its 64 items
     v4i qtok[SW][QCAP], qinfo[SW][QCAP];       // phase X: per wave, closure items it will expand itself
     int wsum[NLISTS][SW], wsum2[NLISTS][SW];
@@ -1315,11 +1314,12 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             CLK(7);                                                    // cluster barriers of phase X
         }
         if (aborted) break;
-        if (LZY) {
+        if constexpr (LZY) {
+            __shared__ int lzq[SW][LZQ + LZD];                         // per wave: composed states still to be closed (only in the lazy kernels' LDS)
             // search-driven composition: the arcs this wave entered in this frame lead to states that phase X
             // of a later frame will expand - make them ready now, epsilon / tee closure included (jd_lazy.h)
             const LazyDev &L = *C.lazy;
-            int *q = sh.lzq[wid];
+            int *q = lzq[wid];
             int qn = 0, dn = 0;
             bool ok = true;
             const size_t nbase = (size_t)gw * gout.seg_new;

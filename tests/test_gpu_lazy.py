@@ -101,3 +101,29 @@ def test_lazy_network_errors(built):
     assert ei.value.code == capi.JD_ENOMEM
     # the decoder still works on a network with room
     assert capi.Decoder(lazy, models, main_beam=300.0).decode_batch([x])[0].n >= 0
+
+
+def test_batch_test_cli_composes_lazily(built, tmp_path):
+    """juicer's -gramFsmFName mode with the graph composed by the search (-lazy): same output as composing first."""
+    import subprocess
+    from juicer_amd import build as jbuild, capi, io as jio, synth
+    c = CASES[0]
+    am = synth.make_models(c["seed"], n_gmm=100, n_hmm=45, n_mix=2, n_tm=8, sep=0.6, with_tee=True)
+    cl, g = synth.make_cl_g(c["seed"], am, n_words=c["n_words"], n_succ=c["n_succ"], n_tri=c["n_tri"], with_sp=True)
+    jio.write_fsm(tmp_path / "cl.fsm", cl)
+    jio.write_fsm(tmp_path / "g.fsm", g)
+    jio.write_jdam(tmp_path / "m.jdam", am)
+    with open(tmp_path / "list.txt", "w") as f:
+        for u in range(3):
+            jio.write_jdf(tmp_path / ("u%d.jdf" % u), synth.sample_utterance(c["seed"] + 2000 + u, g, am, 5 + u)[0])
+            f.write("%s\n" % (tmp_path / ("u%d.jdf" % u)))
+    base = [jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "cl.fsm"), "-gramFsmFName", str(tmp_path / "g.fsm"),
+            "-modelsFName", str(tmp_path / "m.jdam"), "-inputFName", str(tmp_path / "list.txt"),
+            "-mainBeam", "200", "-lmScaleFactor", str(c["lm"]), "-outputFormat", "ref"]
+    first = subprocess.run(base, capture_output=True, text=True, timeout=240)
+    lazy = subprocess.run(base + ["-lazy"], capture_output=True, text=True, timeout=240)
+    assert first.returncode == 0 and lazy.returncode == 0, lazy.stderr
+    assert "composed by the search" in lazy.stderr
+    assert len(lazy.stdout.splitlines()) == 3 and lazy.stdout == first.stdout
+    bad = subprocess.run(base + ["-lazy", "-pushing"], capture_output=True, text=True, timeout=240)
+    assert bad.returncode == 2
