@@ -128,10 +128,11 @@ int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t devi
  * models; max_states / max_arcs are the room the network may grow into (0: 2^22 states, 2^24 arcs;
  * decoding fails with JD_ENOMEM when it runs out).  The decoder must be created on the same device; the
  * network has no arc table to read back (jd_net_get_csr / jd_net_save_jwnt refuse it).  Results are those
- * of decoding on jd_net_compose's network.  There is no CPU path.
+ * of decoding on jd_net_compose's network (pushing: as there, applied arc by arc as states are expanded).
+ * There is no CPU path.
  */
 int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *g, const jd_am *am, int32_t device,
-                       int64_t max_states, int64_t max_arcs);
+                       int64_t max_states, int64_t max_arcs, int32_t pushing);
 /* composed states and arcs materialised so far */
 int jd_net_lazy_size(const jd_net *n, int64_t *states, int64_t *arcs);
 

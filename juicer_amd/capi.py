@@ -189,10 +189,11 @@ class Network:
         return cls(h)
 
     @classmethod
-    def lazy(cls, cl: "Network", g: "Network", am: "Models", device: int = 0, max_states: int = 0, max_arcs: int = 0):
+    def lazy(cls, cl: "Network", g: "Network", am: "Models", device: int = 0, max_states: int = 0, max_arcs: int = 0, pushing: bool = False):
         """C.L o G expanded by the search, where it goes (jd_net_create_lazy)."""
         h = C.c_void_p()
-        _check(lib().jd_net_create_lazy(C.byref(h), cl.h, g.h, am.h, C.c_int32(device), C.c_int64(max_states), C.c_int64(max_arcs)))
+        _check(lib().jd_net_create_lazy(C.byref(h), cl.h, g.h, am.h, C.c_int32(device), C.c_int64(max_states), C.c_int64(max_arcs),
+                                        C.c_int32(1 if pushing else 0)))
         return cls(h)
 
     def lazy_size(self):

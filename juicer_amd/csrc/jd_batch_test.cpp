@@ -156,7 +156,7 @@ int main(int argc, char **argv)
         if (jd_net_load_fsm(&g, gramFsm, gramInSyms, gramOutSyms, lmScale, 0.0f)) die("jd_net_load_fsm (G)");
         if (lazy) {
             // the reference's mode proper: nothing is composed before the search starts (needs the models: tee HMMs)
-            if (pushing || nDevices > 0) { fprintf(stderr, "-lazy: not together with -pushing / -devices\n"); return 2; }
+            if (nDevices > 0) { fprintf(stderr, "-lazy: not together with -devices (the network lives on one device)\n"); return 2; }
             lazy_cl = cl; lazy_g = g;
         } else {
             if (jd_net_compose(&net, cl, g, device, 0, 0, pushing)) die("jd_net_compose");
@@ -184,7 +184,7 @@ int main(int argc, char **argv)
     } else am = load_jdam(amf);
     const int D = jd_am_vec_size(am);
     if (lazy_cl) {
-        if (jd_net_create_lazy(&net, lazy_cl, lazy_g, am, device, 0, 0)) die("jd_net_create_lazy");
+        if (jd_net_create_lazy(&net, lazy_cl, lazy_g, am, device, 0, 0, pushing)) die("jd_net_create_lazy");
         fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs): composed by the search on device %d\n", (long long)jd_net_num_arcs(lazy_cl),
                 (long long)jd_net_num_arcs(lazy_g), device);
         jd_net_destroy(lazy_cl); jd_net_destroy(lazy_g);

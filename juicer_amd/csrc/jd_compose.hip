@@ -469,7 +469,7 @@ static void lazy_free(jd_net *n)
 }
 
 extern "C" int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *g, const jd_am *am, int32_t device,
-                                  int64_t max_states, int64_t max_arcs)
+                                  int64_t max_states, int64_t max_arcs, int32_t pushing)
 {
     if (!out || !cl || !g || !am) return jd_fail(JD_EINVAL, "jd_net_create_lazy: null argument");
     if (cl->lazy_dev || g->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_create_lazy: the inputs must be ordinary networks");
@@ -515,7 +515,7 @@ extern "C" int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *
         LAL(L.st_c, int, max_states); LAL(L.st_g, int, max_states); LAL(L.rows, int4, max_states);
         LAL(L.arcs, JdArc, max_arcs); LAL(L.n_states, int, 1); LAL(L.n_arcs, unsigned long long, 1); LAL(L.err, int, 1);
         LAL(d_ok, int, 2); LAL(d_tee, float, am->hmm_tee.size()); LAL(d_L, LazyDev, 1);
-        L.max_states = (int)max_states; L.max_arcs = max_arcs;
+        L.max_states = (int)max_states; L.max_arcs = max_arcs; L.push = pushing ? 1 : 0;
         CHK(hipMemset(L.keys, 0, cap * 8)); CHK(hipMemset(L.vals, 0xff, cap * 4));
         CHK(hipMemset(L.n_states, 0, 4)); CHK(hipMemset(L.n_arcs, 0, 8)); CHK(hipMemset(L.err, 0, 4));
         CHK(hipMemset(L.rows, 0, (size_t)max_states * sizeof(int4)));

@@ -44,6 +44,7 @@ struct LazyDev {
     JdArc *arcs;                      // the arena
     int *n_states; unsigned long long *n_arcs;
     int max_states; long long max_arcs;
+    int push;                         // weights pushed along the lexicon tree (jd_compose.hip "pushing")
     int *err;                         // 1: states exhausted, 2: arcs exhausted, 3: a wave's queue overflowed
 };
 
@@ -62,6 +63,33 @@ __device__ __forceinline__ unsigned long long lz_hash(unsigned long long k)
 {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
     return k;
+}
+
+// weight look-ahead (pushing): the best weight among the arcs of G state g with an input label in [lo, hi] (0 if none)
+__device__ __forceinline__ float lz_potential(const LazyDev &L, int g, int lo_l, int hi_l)
+{
+    if (lo_l > hi_l) return 0.0f;
+    int lo = L.g_row[g], hi = L.g_row[g + 1];
+    const int end = hi;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L.g_arcs[mid].in < lo_l) lo = mid + 1; else hi = mid;
+    }
+    float best = 0.0f;
+    bool have = false;
+    for (; lo < end && L.g_arcs[lo].in <= hi_l; ++lo) {
+        const float w = L.g_arcs[lo].w;
+        if (!have || w > best) best = w;
+        have = true;
+    }
+    return best;
+}
+// what the arcs into (c, g, flag) have already paid of the word that is under way
+__device__ __forceinline__ float lz_paid(const LazyDev &L, unsigned cf, int g)
+{
+    if (!L.push || (cf & LZ_FLAG)) return 0.0f;
+    const int2 la = L.cl_la[cf];
+    return lz_potential(L, g, la.x, la.y);
 }
 
 // id of the composed state (cf, g); the lane that creates it writes its row {0, 0, UNKNOWN, final weight}
@@ -83,7 +111,7 @@ __device__ int lz_state_id(const LazyDev &L, unsigned cf, int g)
                     __hip_atomic_store(&L.st_c[id], (int)cf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&L.st_g[id], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     lz_st8(&L.rows[id].x, 0, 0);
-                    lz_st8(&L.rows[id].z, (int)LZ_UNKNOWN, __float_as_int(fin ? fc + fg : __builtin_inff()));
+                    lz_st8(&L.rows[id].z, (int)LZ_UNKNOWN, __float_as_int(fin ? (L.push ? (fc + fg) - lz_paid(L, cf, g) : fc + fg) : __builtin_inff()));
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 } else { atomicMax(L.err, 1); id = L.max_states - 1; }
                 __hip_atomic_store(&L.vals[slot], id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -191,6 +219,7 @@ __device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q,
     JdArc boa = {0, 0.0f, 0, 0};
     if (flag && L.g_row[g + 1] > L.g_row[g]) { boa = L.g_arcs[L.g_row[g]]; bo = boa.in == 0; }
     const int a0 = L.cl_row[c], a1 = L.cl_row[c + 1];
+    const float p_src = lz_paid(L, cf, g);
     int mine = 0, ga;
     for (int a = a0 + lane; a < a1; a += 64) mine += lz_arc_kind(L, L.cl_arcs[a], g, &ga);
     int total = mine;
@@ -232,11 +261,15 @@ __device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q,
             const int pos = run + pre - 1;
             const bool tee = ca.in > 0 && hmm_tee[ca.in - 1] > LZ;
             const int in = ca.in | (tee ? TEE_FLAG : 0);
-            if (ca.out == 0) { to = lz_state_id(L, (unsigned)ca.to, g); lz_store_arc(&L.arcs[pos], to, ca.w, in, 0); }
-            else {
+            if (ca.out == 0) {
+                float w = ca.w;
+                if (L.push) { const int2 la = L.cl_la[ca.to]; w = (ca.w + lz_potential(L, g, la.x, la.y)) - p_src; }
+                to = lz_state_id(L, (unsigned)ca.to, g);
+                lz_store_arc(&L.arcs[pos], to, w, in, 0);
+            } else {
                 const JdArc m = L.g_arcs[ga];
                 to = lz_state_id(L, (unsigned)ca.to | LZ_FLAG, m.to);
-                lz_store_arc(&L.arcs[pos], to, ca.w + m.w, in, m.out);
+                lz_store_arc(&L.arcs[pos], to, L.push ? (ca.w + m.w) - p_src : ca.w + m.w, in, m.out);
             }
             closure = ca.in == 0 || tee;                               // reachable within the frame a token reaches D
         }

@@ -31,13 +31,14 @@ def _same(a, b):
         assert a.stats[k] == b.stats[k], k
 
 
+@pytest.mark.parametrize("pushing", [False, True], ids=["plain", "pushing"])
 @pytest.mark.parametrize("c", CASES, ids=lambda c: "seed%d" % c["seed"])
-def test_lazy_composition_decodes_like_the_composed_graph(built, c):
+def test_lazy_composition_decodes_like_the_composed_graph(built, c, pushing):
     from juicer_amd import capi, synth
     am, g, ncl, ng = _case(c)
     models = capi.Models.from_htk(am)
-    static = capi.Network.compose(ncl, ng)
-    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    static = capi.Network.compose(ncl, ng, pushing=pushing)
+    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18, pushing=pushing)
     s0, a0 = lazy.lazy_size()
     assert 0 < s0 < static.n_states                    # only the start state's neighbourhood exists
     feats = [synth.sample_utterance(c["seed"] + 1000 + u, g, am, 6 + u)[0] for u in range(6)]
@@ -125,5 +126,7 @@ def test_batch_test_cli_composes_lazily(built, tmp_path):
     assert first.returncode == 0 and lazy.returncode == 0, lazy.stderr
     assert "composed by the search" in lazy.stderr
     assert len(lazy.stdout.splitlines()) == 3 and lazy.stdout == first.stdout
-    bad = subprocess.run(base + ["-lazy", "-pushing"], capture_output=True, text=True, timeout=240)
+    pushed = [subprocess.run(base + ["-pushing"] + x, capture_output=True, text=True, timeout=240) for x in ([], ["-lazy"])]
+    assert pushed[1].returncode == 0 and pushed[1].stdout == pushed[0].stdout
+    bad = subprocess.run(base + ["-lazy", "-devices", "1"], capture_output=True, text=True, timeout=240)
     assert bad.returncode == 2

@@ -18,14 +18,24 @@ ap.add_argument("--beam", type=float, default=150.0)
 ap.add_argument("--max-hyps", type=int, default=0)
 ap.add_argument("--trim", type=int, default=0, help="cut every utterance to this many frames (0 = keep)")
 ap.add_argument("--c4", type=float, default=0.0, help="trigram-shaped graph of config_c4 at this scale (1.0 = configs[3]) instead of config_c2")
+ap.add_argument("--clg", action="store_true", help="the configs[4] pair (lexicon tree o back-off trigram) composed on the device; with --lazy: by the search")
+ap.add_argument("--lazy", action="store_true")
 args = ap.parse_args()
-if args.c4 > 0:
+gnet = None
+if args.clg:
+    am = synth.make_models(0, n_gmm=3000, n_hmm=2000, n_mix=16, n_tm=8, sep=0.6, with_tee=True)
+    cl, g = synth.make_cl_g(0, am, n_words=20000, n_succ=40, n_tri=200000, n_succ3=8, with_sp=True)
+    ncl, ng = capi.Network.from_synth(cl, 1.0, 0.0), capi.Network.from_synth(g, 10.0, 0.0)
+    gnet = (capi.Network.lazy(ncl, ng, capi.Models.from_htk(am), max_states=1 << 23, max_arcs=1 << 25) if args.lazy
+            else capi.Network.compose(ncl, ng, max_states=1 << 26, max_arcs=1 << 27))
+    feats = [synth.sample_utterance(100 + u, g, am, 8)[0] for u in range(args.utts)]
+elif args.c4 > 0:
     am, net, feats, _ = synth.config_c4(n_utts=args.utts, n_words=int(20000 * args.c4 ** 0.5), n_tri_hist=int(400000 * args.c4))
 else:
     am, net, feats, _ = synth.config_c2(n_utts=args.utts, target_arcs=args.arcs)
 if args.trim:
     feats = [f[:args.trim] for f in feats]
-dec = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=args.beam, max_hyps=args.max_hyps,
+dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=args.beam, max_hyps=args.max_hyps,
                    max_streams=args.utts)
 dec.decode_batch(feats)
 dec.debug_trace(0)
