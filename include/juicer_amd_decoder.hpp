@@ -162,5 +162,38 @@ private:
     jd_stats stats_;
 };
 
+// Drop-in for `new WFSTOnTheFlyDecoder(clNetwork, gNetwork, models, mainBeam, phoneEndBeam, maxHyps,
+// modelLevelOutput, latticeGeneration, doLabelAndWeightPushing, true)` (juicer.cpp:594-598): C.L and G stay
+// apart and are composed where the search goes (jd_net_create_lazy).  The composed network is owned here and
+// keeps what has been expanded from one utterance to the next.  modelLevelOutput / latticeGeneration are not
+// offered (as in GpuWFSTDecoder); maxStates / maxArcs: the room the network may grow into (0 = defaults).
+struct LazyNetHolder_ {
+    jd_net *lazyNet_;
+    LazyNetHolder_(const jd_net *cl, const jd_net *g, const jd_am *models, int device, long long maxStates, long long maxArcs, bool pushing)
+        : lazyNet_(0)
+    {
+        if (jd_net_create_lazy(&lazyNet_, cl, g, models, device, maxStates, maxArcs, pushing ? 1 : 0) != JD_OK) {
+            fprintf(stderr, "juicer_amd: %s\n", jd_last_error());
+            exit(1);
+        }
+    }
+    ~LazyNetHolder_() { jd_net_destroy(lazyNet_); }
+};
+class GpuWFSTOnTheFlyDecoder : private LazyNetHolder_, public GpuWFSTDecoder {
+public:
+    GpuWFSTOnTheFlyDecoder(const jd_net *clNetwork, const jd_net *gNetwork, const jd_am *models, float emitPruneWin,
+                           float phoneEndPruneWin, int maxEmitHyps, bool doPushing = false, int device = 0,
+                           long long maxStates = 0, long long maxArcs = 0, int blockSize = 5, int flushFrames = 64)
+        : LazyNetHolder_(clNetwork, gNetwork, models, device, maxStates, maxArcs, doPushing),
+          GpuWFSTDecoder(lazyNet_, models, 0.0f, emitPruneWin, phoneEndPruneWin, 0.0f, maxEmitHyps, device, blockSize, flushFrames) {}
+    // composed states / arcs materialised so far
+    void composedSize(long long &states, long long &arcs) const
+    {
+        int64_t s = 0, a = 0;
+        if (jd_net_lazy_size(lazyNet_, &s, &a) != JD_OK) { fprintf(stderr, "juicer_amd: %s\n", jd_last_error()); exit(1); }
+        states = s; arcs = a;
+    }
+};
+
 }  // namespace JuicerAmd
 #endif

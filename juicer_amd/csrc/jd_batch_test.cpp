@@ -183,7 +183,9 @@ int main(int argc, char **argv)
         }
     } else am = load_jdam(amf);
     const int D = jd_am_vec_size(am);
-    if (lazy_cl) {
+    if (lazy_cl && useAdapter) {
+        // the decoder object composes for itself (GpuWFSTOnTheFlyDecoder, the mirror of juicer.cpp:594-598)
+    } else if (lazy_cl) {
         if (jd_net_create_lazy(&net, lazy_cl, lazy_g, am, device, 0, 0, pushing)) die("jd_net_create_lazy");
         fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs): composed by the search on device %d\n", (long long)jd_net_num_arcs(lazy_cl),
                 (long long)jd_net_num_arcs(lazy_g), device);
@@ -351,7 +353,12 @@ int main(int argc, char **argv)
 
     if (useAdapter) {
         // the reference's serial protocol: one IDecoder, frame by frame with 20-row look-ahead
-        JuicerAmd::GpuWFSTDecoder dec(net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, device);
+        JuicerAmd::GpuWFSTDecoder *decp = lazy_cl
+            ? new JuicerAmd::GpuWFSTOnTheFlyDecoder(lazy_cl, lazy_g, am, mainBeam, endBeam, maxHyps, pushing != 0, device)
+            : new JuicerAmd::GpuWFSTDecoder(net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, device);
+        JuicerAmd::GpuWFSTDecoder &dec = *decp;
+        if (lazy_cl) fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs): composed by the search on device %d\n", (long long)jd_net_num_arcs(lazy_cl),
+                             (long long)jd_net_num_arcs(lazy_g), device);
         for (size_t u = 0; u < files.size(); ++u) {
             auto t0 = std::chrono::steady_clock::now();
             dec.init();
@@ -379,6 +386,8 @@ int main(int argc, char **argv)
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             print_utt(u, (int)lab.size(), lab.data(), tim.data(), hac.data(), hlm.data(), dt);
         }
+        delete decp;
+        if (lazy_cl) { jd_net_destroy(lazy_cl); jd_net_destroy(lazy_g); }
     } else if (nDevices > 0) {
         // -devices N: the utterance loop sharded over N GPUs of this node, one RCCL gather of the 1-best
         jd_multi *mg = 0;

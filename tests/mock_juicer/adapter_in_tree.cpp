@@ -8,3 +8,8 @@ Juicer::IDecoder *make(const jd_net *n, const jd_am *a)
 {
     return new JuicerAmd::GpuWFSTDecoder(n, a, 0.0f, 150.0f, 0.0f, 0.0f, 0);
 }
+static_assert(std::is_base_of<Juicer::IDecoder, JuicerAmd::GpuWFSTOnTheFlyDecoder>::value, "the on-the-fly mirror is an IDecoder too");
+Juicer::IDecoder *make_on_the_fly(const jd_net *cl, const jd_net *g, const jd_am *a)
+{
+    return new JuicerAmd::GpuWFSTOnTheFlyDecoder(cl, g, a, 150.0f, 0.0f, 0, true);
+}

@@ -128,5 +128,9 @@ def test_batch_test_cli_composes_lazily(built, tmp_path):
     assert len(lazy.stdout.splitlines()) == 3 and lazy.stdout == first.stdout
     pushed = [subprocess.run(base + ["-pushing"] + x, capture_output=True, text=True, timeout=240) for x in ([], ["-lazy"])]
     assert pushed[1].returncode == 0 and pushed[1].stdout == pushed[0].stdout
+    # the IDecoder mirror of WFSTOnTheFlyDecoder (include/juicer_amd_decoder.hpp), frame by frame
+    adapter = subprocess.run(base + ["-lazy", "-perFrameAdapter"], capture_output=True, text=True, timeout=240)
+    assert adapter.returncode == 0, adapter.stderr
+    assert adapter.stdout == first.stdout
     bad = subprocess.run(base + ["-lazy", "-devices", "1"], capture_output=True, text=True, timeout=240)
     assert bad.returncode == 2
