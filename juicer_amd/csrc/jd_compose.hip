@@ -79,8 +79,10 @@ __device__ int jc_state_id(const ComposeArgs &A, unsigned cf, int g)
     unsigned long long slot = jc_hash(key) & A.mask;
     bool mine = false;                                                 // slot holds this key
     int id = -1;
+    unsigned long long probes = 0;
     while (id < 0) {
         if (!mine) {
+            if (++probes > A.mask) { atomicMax(A.err, (int)JC_ESTATES); return 0; }   // table full (a level far beyond max_states): give up, the host reports it
             const unsigned long long old = atomicCAS(&A.keys[slot], 0ULL, key);
             if (old == 0ULL) {
                 id = atomicAdd(A.n_states, 1);

@@ -100,8 +100,11 @@ __device__ int lz_state_id(const LazyDev &L, unsigned cf, int g)
     unsigned long long slot = lz_hash(key) & L.mask;
     bool mine = false;
     int id = -1;
+    unsigned long long probes = 0;
+    if (__hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0;   // the network has failed: no more insertions
     while (id < 0) {
         if (!mine) {
+            if (++probes > L.mask) { atomicMax(L.err, 1); return 0; }                      // (table full: cannot happen below max_states)
             const unsigned long long old = atomicCAS(&L.keys[slot], 0ULL, key);
             if (old == 0ULL) {
                 id = atomicAdd(L.n_states, 1);

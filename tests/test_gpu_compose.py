@@ -97,6 +97,10 @@ def test_compose_errors(built):
     with pytest.raises(capi.JuicerAmdError) as ei:
         capi.Network.compose(ncl, ng, max_states=64)
     assert ei.value.code == capi.JD_ENOMEM and "states" in str(ei.value)
+    for tiny in (2, 4, 8):                                          # (a breadth-first level far wider than the state table)
+        with pytest.raises(capi.JuicerAmdError) as ei:
+            capi.Network.compose(ncl, ng, max_states=tiny)
+        assert ei.value.code == capi.JD_ENOMEM
     with pytest.raises(capi.JuicerAmdError) as ei:
         capi.Network.compose(ncl, ng, max_arcs=64)
     assert ei.value.code == capi.JD_ENOMEM and "arcs" in str(ei.value)
