@@ -58,9 +58,23 @@ def roofline_of(st, max_n, tm, traffic=None):
             "launches_per_step": launches, "workgroups_per_stream": tm["cluster_wgs"]}
 
 
-def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=2, gnet=None):
+def leg_traffic(leg, launches):
+    """HBM bytes per k_search launch of an extra leg, from the committed PMC passes of that leg on its own
+    (profiles/r02_<leg>_traffic.json, tools/leg_pmc.sh): the largest launch when a step is one launch, else
+    the pass total over the step's launches.  None when there is no such file."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_%s_traffic.json" % leg)))
+        if launches <= 1 or "k_search_hbm_bytes_per_pass" not in t:
+            return round(t["k_search_hbm_bytes_largest_launch"], 1)
+        return round(t["k_search_hbm_bytes_per_pass"] / launches, 1)
+    except Exception:
+        return None
+
+
+def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=2, gnet=None, pmc_leg=None):
     """One extra workload: warm-up pass + timed pass(es) on one GPU, its own roofline.  gnet: a network
-    that exists already (composed on the device); net is then only asked for its size."""
+    that exists already (composed on the device); net is then only asked for its size.  pmc_leg: the name
+    the leg's PMC passes are filed under (leg_traffic)."""
     import torch
     from juicer_amd import capi
     U = len(feats)
@@ -92,7 +106,7 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=2, 
            "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
                                                                               "tot_proc_end_hyps", "tot_arcs_visited")},
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
-           "roofline": roofline_of(st, am.max_n, tm), "setup_s": round(time.perf_counter() - t0 - best * passes, 1)}
+           "roofline": roofline_of(st, am.max_n, tm, leg_traffic(pmc_leg, max(1, tm["search_launches"])) if pmc_leg else None), "setup_s": round(time.perf_counter() - t0 - best * passes, 1)}
     if oracle_utts > 0:
         from oracle.oracle import OracleAM, OracleDecoder, OracleNet
         od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=beam, max_hyps=max_hyps)
@@ -129,7 +143,7 @@ def compose_leg(seed, dev, pushing=False):
     class _Size:                                                   # what run_leg prints about the graph
         n_arcs = net.n_arcs
     out = run_leg("configs[4], composed on the device (lexicon tree o back-off trigram%s)" % (", weights pushed" if pushing else ""),
-                  am, _Size, feats, 200.0, 0, dev, gnet=net)
+                  am, _Size, feats, 200.0, 0, dev, gnet=net, pmc_leg="clg" if (not pushing and seed == 0) else None)
     if not pushing:
         out["search_driven"] = lazy_part(ncl, ng, am, feats, dev, net.n_states, net.n_arcs, gnet=net)
     out["composition"] = {"pushing": bool(pushing), "cl_arcs": int(cl.n_arcs), "g_arcs": int(g.n_arcs), "states": net.n_states, "arcs": net.n_arcs,
@@ -373,10 +387,11 @@ def main():
             legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev)
             a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=64, n_words=10000, n_tri_hist=100_000)
             legs["north_star_10M_beam200"] = run_leg("north_star target (trigram-shaped)", a4, n4, f4, 200.0, 0, dev,
-                                                     oracle_utts=0 if args.no_cpu_baseline else 1)
+                                                     oracle_utts=0 if args.no_cpu_baseline else 1,
+                                                     pmc_leg="north" if args.seed == 0 else None)
             del a4, n4, f4
             a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=8)
-            legs["configs3_50M_beam300"] = run_leg("configs[3]", a4, n4, f4, 300.0, 0, dev)
+            legs["configs3_50M_beam300"] = run_leg("configs[3]", a4, n4, f4, 300.0, 0, dev, pmc_leg="c3" if args.seed == 0 else None)
             del a4, n4, f4
             legs["configs4_device_composition"] = compose_leg(args.seed, dev)
         except Exception as e:                                    # a leg must never take the headline down

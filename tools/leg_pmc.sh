@@ -1,0 +1,32 @@
+#!/bin/bash
+# HBM traffic of k_search in one of bench.py's extra legs: tools/leg_pmc.sh north|c3|clg  (GPU box, through gpurun).
+# Two PMC passes, each with --kernel-trace only; summary -> gpurun_out/prof_<leg>/pmc_summary.json
+set -u
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+LEG=${1:-north}
+OUT=gpurun_out/prof_$LEG
+rm -rf "$OUT"; mkdir -p "$OUT"
+i=0
+for set in "FETCH_SIZE SQ_WAVES" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i + 1))
+    timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -- python tools/run_leg.py $LEG 2 < /dev/null > "$OUT/pmc$i.log" 2>&1
+    grep '^{"workload"' "$OUT/pmc$i.log" | tail -1 > "$OUT/leg_under_pmc$i.json"
+done
+python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
+python - "$OUT" "$LEG" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1] + "/pmc_summary.json"))
+tot_f = tot_w = 0.0
+for k, v in d.items():
+    if "k_search" in k:
+        print(k, {c: (x["launches"], round(x["mean"], 1), round(x["max"], 1)) for c, x in v.items()})
+        tot_f += v["FETCH_SIZE"]["mean"] * v["FETCH_SIZE"]["launches"]
+        tot_w += v["WRITE_SIZE"]["mean"] * v["WRITE_SIZE"]["launches"]
+# tools/run_leg.py <leg> 2 = a warm-up pass and a timed pass of the same batch: HBM bytes of one pass, all k_search launches
+# ((2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE reports half of a wide read, MI355X_MICROARCH.md)
+out = {"leg": sys.argv[2], "passes": 2, "k_search_hbm_bytes_per_pass": (2.0 * tot_f + tot_w) * 1024.0 / 2.0,
+       "source": "tools/leg_pmc.sh: rocprofv3 --kernel-trace --pmc, FETCH_SIZE and WRITE_SIZE in separate runs"}
+json.dump(out, open(sys.argv[1] + "/leg_traffic.json", "w"))
+print(out)
+PY

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One of bench.py's extra legs on its own (GPU box): python tools/run_leg.py north|c3|hyps [passes [utterances of the c3 leg]]"""
+"""One of bench.py's extra legs on its own (GPU box): python tools/run_leg.py north|c3|hyps|clg [passes [utterances of the c3 leg]]"""
 import json
 import os
 import sys
@@ -16,10 +16,12 @@ n_utts = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device("cuda:0")
 if which == "north":
     a, n, f, _ = synth.config_c4(seed=0, n_utts=64, n_words=10000, n_tri_hist=100_000)
-    out = bench.run_leg("north_star target (trigram-shaped)", a, n, f, 200.0, 0, dev, passes=passes)
+    out = bench.run_leg("north_star target (trigram-shaped)", a, n, f, 200.0, 0, dev, passes=passes, pmc_leg="north")
+elif which == "clg":
+    out = bench.compose_leg(0, dev)
 elif which == "c3":
     a, n, f, _ = synth.config_c4(seed=0, n_utts=n_utts or 8)
-    out = bench.run_leg("configs[3]", a, n, f, 300.0, 0, dev, passes=passes)
+    out = bench.run_leg("configs[3]", a, n, f, 300.0, 0, dev, passes=passes, pmc_leg="c3" if not n_utts or n_utts == 8 else None)
 else:
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
     out = bench.run_leg("configs[1] + histogram pruning", a, n, f, 150.0, 6000, dev, passes=passes)
