@@ -320,6 +320,13 @@ int jd_multi_create(jd_multi **out, const jd_net *net, const jd_am *am,
                     float start_beam, float main_beam, float end_beam, float word_beam,
                     int32_t max_hyps, int32_t block_size, int32_t n_devices, const int32_t *devices,
                     int32_t max_streams_per_device);
+/* the same over lazily composed networks (jd_net_create_lazy), one per device, owned by the jd_multi: every
+ * device expands the part of C.L o G its own utterances reach */
+int jd_multi_create_lazy(jd_multi **out, const jd_net *cl, const jd_net *g, const jd_am *am,
+                         int64_t max_states, int64_t max_arcs, int32_t pushing,
+                         float start_beam, float main_beam, float end_beam, float word_beam,
+                         int32_t max_hyps, int32_t block_size, int32_t n_devices, const int32_t *devices,
+                         int32_t max_streams_per_device);
 int jd_multi_decode_batch(jd_multi *m, int32_t n_utts, const float *const *feats,
                           const int32_t *n_frames, jd_hyp *out);
 void jd_multi_destroy(jd_multi *m);

@@ -74,7 +74,7 @@ EXPORTS = [
     "jd_dec_create", "jd_dec_destroy", "jd_dec_set_capacity", "jd_stream_init", "jd_stream_push",
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
-    "jd_multi_create", "jd_multi_decode_batch", "jd_multi_destroy",
+    "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
     "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size",
 ]
 

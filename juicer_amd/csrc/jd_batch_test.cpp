@@ -156,7 +156,6 @@ int main(int argc, char **argv)
         if (jd_net_load_fsm(&g, gramFsm, gramInSyms, gramOutSyms, lmScale, 0.0f)) die("jd_net_load_fsm (G)");
         if (lazy) {
             // the reference's mode proper: nothing is composed before the search starts (needs the models: tee HMMs)
-            if (nDevices > 0) { fprintf(stderr, "-lazy: not together with -devices (the network lives on one device)\n"); return 2; }
             lazy_cl = cl; lazy_g = g;
         } else {
             if (jd_net_compose(&net, cl, g, device, 0, 0, pushing)) die("jd_net_compose");
@@ -183,8 +182,9 @@ int main(int argc, char **argv)
         }
     } else am = load_jdam(amf);
     const int D = jd_am_vec_size(am);
-    if (lazy_cl && useAdapter) {
-        // the decoder object composes for itself (GpuWFSTOnTheFlyDecoder, the mirror of juicer.cpp:594-598)
+    if (lazy_cl && (useAdapter || nDevices > 0)) {
+        // the decoder object composes for itself (GpuWFSTOnTheFlyDecoder, the mirror of juicer.cpp:594-598), resp.
+        // every device gets a lazily composed network of its own (jd_multi_create_lazy)
     } else if (lazy_cl) {
         if (jd_net_create_lazy(&net, lazy_cl, lazy_g, am, device, 0, 0, pushing)) die("jd_net_create_lazy");
         fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs): composed by the search on device %d\n", (long long)jd_net_num_arcs(lazy_cl),
@@ -391,7 +391,13 @@ int main(int argc, char **argv)
     } else if (nDevices > 0) {
         // -devices N: the utterance loop sharded over N GPUs of this node, one RCCL gather of the 1-best
         jd_multi *mg = 0;
-        if (jd_multi_create(&mg, net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, 5, nDevices, 0, batch)) die("jd_multi_create");
+        if (lazy_cl) {
+            if (jd_multi_create_lazy(&mg, lazy_cl, lazy_g, am, 0, 0, pushing, startBeam, mainBeam, endBeam, wordBeam, maxHyps, 5, nDevices, 0, batch))
+                die("jd_multi_create_lazy");
+            fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs): composed by the search on each of %d devices\n", (long long)jd_net_num_arcs(lazy_cl),
+                    (long long)jd_net_num_arcs(lazy_g), nDevices);
+            jd_net_destroy(lazy_cl); jd_net_destroy(lazy_g);
+        } else if (jd_multi_create(&mg, net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, 5, nDevices, 0, batch)) die("jd_multi_create");
         std::vector<const float *> ptr(files.size());
         for (size_t u = 0; u < files.size(); ++u) ptr[u] = feats[u].data();
         std::vector<jd_hyp> hyps(files.size());

@@ -57,6 +57,7 @@ struct jd_multi {
     int n_dev = 0;
     std::vector<int> devices;
     std::vector<jd_dec *> dec;
+    std::vector<jd_net *> own_net;                 // jd_multi_create_lazy: one lazily composed network per device
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> stream;
     std::vector<int32_t *> d_send, d_recv;
@@ -76,15 +77,18 @@ extern "C" void jd_multi_destroy(jd_multi *m)
         if ((size_t)d < m->stream.size() && m->stream[(size_t)d]) (void)hipStreamDestroy(m->stream[(size_t)d]);
         if ((size_t)d < m->comm.size() && m->comm[(size_t)d] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm[(size_t)d]);
         if ((size_t)d < m->dec.size()) jd_dec_destroy(m->dec[(size_t)d]);
+        if ((size_t)d < m->own_net.size()) jd_net_destroy(m->own_net[(size_t)d]);
     }
     delete m;
 }
 
-extern "C" int jd_multi_create(jd_multi **out, const jd_net *net, const jd_am *am, float start_beam, float main_beam,
-                               float end_beam, float word_beam, int32_t max_hyps, int32_t block_size, int32_t n_devices,
-                               const int32_t *devices, int32_t max_streams_per_device)
+// net: one network for every device, or (lazy_cl, lazy_g): a lazily composed network per device
+static int multi_create(jd_multi **out, const jd_net *net, const jd_net *lazy_cl, const jd_net *lazy_g, int64_t lazy_states,
+                        int64_t lazy_arcs, int32_t pushing, const jd_am *am, float start_beam, float main_beam,
+                        float end_beam, float word_beam, int32_t max_hyps, int32_t block_size, int32_t n_devices,
+                        const int32_t *devices, int32_t max_streams_per_device)
 {
-    if (!out || !net || !am || n_devices < 1) return jd_fail(JD_EINVAL, "jd_multi_create: bad argument");
+    if (!out || (!net && !(lazy_cl && lazy_g)) || !am || n_devices < 1) return jd_fail(JD_EINVAL, "jd_multi_create: bad argument");
     int have = 0;
     if (hipGetDeviceCount(&have) != hipSuccess || have <= 0)
         return jd_fail(JD_ENODEV, "no HIP device available; juicer_amd has no CPU fallback");
@@ -105,8 +109,13 @@ extern "C" int jd_multi_create(jd_multi **out, const jd_net *net, const jd_am *a
     m->stream.assign((size_t)n_devices, nullptr);
     m->d_send.assign((size_t)n_devices, nullptr);
     m->d_recv.assign((size_t)n_devices, nullptr);
+    if (!net) m->own_net.assign((size_t)n_devices, nullptr);
     for (int d = 0; d < n_devices; ++d) {
-        rc = jd_dec_create(&m->dec[(size_t)d], net, am, start_beam, main_beam, end_beam, word_beam, max_hyps, block_size,
+        if (!net) {
+            rc = jd_net_create_lazy(&m->own_net[(size_t)d], lazy_cl, lazy_g, am, m->devices[(size_t)d], lazy_states, lazy_arcs, pushing);
+            if (rc) { jd_multi_destroy(m); return rc; }
+        }
+        rc = jd_dec_create(&m->dec[(size_t)d], net ? net : m->own_net[(size_t)d], am, start_beam, main_beam, end_beam, word_beam, max_hyps, block_size,
                            m->devices[(size_t)d], max_streams_per_device);
         if (rc) { jd_multi_destroy(m); return rc; }
         if (hipSetDevice(m->devices[(size_t)d]) != hipSuccess || hipStreamCreate(&m->stream[(size_t)d]) != hipSuccess) {
@@ -130,6 +139,25 @@ extern "C" int jd_multi_create(jd_multi **out, const jd_net *net, const jd_am *a
     }
     *out = m;
     return JD_OK;
+}
+
+extern "C" int jd_multi_create(jd_multi **out, const jd_net *net, const jd_am *am, float start_beam, float main_beam,
+                               float end_beam, float word_beam, int32_t max_hyps, int32_t block_size, int32_t n_devices,
+                               const int32_t *devices, int32_t max_streams_per_device)
+{
+    if (!net) return jd_fail(JD_EINVAL, "jd_multi_create: bad argument");
+    return multi_create(out, net, nullptr, nullptr, 0, 0, 0, am, start_beam, main_beam, end_beam, word_beam, max_hyps, block_size,
+                        n_devices, devices, max_streams_per_device);
+}
+
+extern "C" int jd_multi_create_lazy(jd_multi **out, const jd_net *cl, const jd_net *g, const jd_am *am, int64_t max_states,
+                                    int64_t max_arcs, int32_t pushing, float start_beam, float main_beam, float end_beam,
+                                    float word_beam, int32_t max_hyps, int32_t block_size, int32_t n_devices,
+                                    const int32_t *devices, int32_t max_streams_per_device)
+{
+    if (!cl || !g) return jd_fail(JD_EINVAL, "jd_multi_create_lazy: bad argument");
+    return multi_create(out, nullptr, cl, g, max_states, max_arcs, pushing, am, start_beam, main_beam, end_beam, word_beam, max_hyps,
+                        block_size, n_devices, devices, max_streams_per_device);
 }
 
 static void pack(const jd_hyp &h, int32_t *r)
