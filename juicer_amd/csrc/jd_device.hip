@@ -994,8 +994,11 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init;
     C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
     C.hmm_tee = d->d_hmm_tee; C.n_hmm = am->n_hmm; C.hmm_tmax0 = d->d_hmm_tmax0;
-    C.lazy = (const LazyDev *)net->lazy_dev; C.aux_h = nullptr; C.aux = nullptr;
-    if (lazy) {   // the same template, by HMM: a growing graph has no per-arc table (one more hop through the arc's label)
+    C.lazy = (const LazyDev *)net->lazy_dev; C.aux_h = nullptr;
+    {   // instance template: what phase A needs to attach an instance (attachNetInst :751-774), by HMM -
+        // {nStates | transMat << 8, g0, g1, g2} (+ {g3, g4, g5, 0}): one hop behind the arc record's label, but the
+        // table is a few tens of KB (L2 hits) where a per-arc copy was a second random 64-byte sector per new
+        // instance and 16-32 B per arc of HBM (measured: same speed at configs[1], +0.5 % in the heavy legs)
         const int AI = (am->max_n <= 5) ? 4 : 8;
         std::vector<int> aux((size_t)am->n_hmm * AI, 0);
         for (int hm = 0; hm < am->n_hmm; ++hm) {
@@ -1007,22 +1010,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         }
         TRY(dupload(d, &d->d_aux, aux.data(), aux.size()));
         C.aux_h = d->d_aux;
-        d->xl_ok = false;          // the graph is written by every cluster, on any XCD: agent scope throughout
-    } else {   // per-arc instance template: what phase A needs to attach an instance (attachNetInst :751-774),
-        // one hop from the arc id: {nStates | transMat << 8, g0, g1, g2} (+ {g3, g4, g5, 0})
-        const int AI = (am->max_n <= 5) ? 4 : 8;
-        std::vector<int> aux((size_t)net->n_arcs * AI, 0);
-        for (int64_t b = 0; b < net->n_arcs; ++b) {
-            const int in = net->arcs[(size_t)b].in;
-            if (in <= 0) continue;
-            const int hm = in - 1, n = am->hmm_n[(size_t)hm];
-            int *a = aux.data() + (size_t)b * AI;
-            a[0] = n | (am->hmm_tm[(size_t)hm] << 8);
-            for (int j = 1; j < n - 1 && j <= (AI == 4 ? 3 : 6); ++j)
-                a[j] = am->hmm_gmm[(size_t)hm * am->max_n + j];
-        }
-        TRY(dupload(d, &d->d_aux, aux.data(), aux.size()));
-        C.aux = d->d_aux;
+        if (lazy) d->xl_ok = false;   // a lazy graph is written by every cluster, on any XCD: agent scope throughout
     }
     C.trP = d->d_trP; C.se32 = d->d_se32;
     {   // Plain left-to-right topologies (every emitting state entered from its predecessor and itself,

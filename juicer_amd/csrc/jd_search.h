@@ -47,12 +47,11 @@ enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_LAZ
 struct DecConst {
     // network (CSR in HBM)
     const int *row_ptr; const JdArc *arcs; const float *fin_w; int init_state;
-    const int *aux;     // per arc: {nStates | transMat << 8, g0, g1, g2} (+ {g3, g4, g5, 0} for > 5 states)
     // models
     int G, max_n, n_tm;
     const float *hmm_tee; int n_hmm;
     const struct LazyDev *lazy;   // search-driven composition (jd_lazy.h): the graph grows while the search runs; else null
-    const int *aux_h;             // the instance template of an arc, by HMM (lazy graphs have no per-arc table)
+    const int *aux_h;             // the instance template of an arc, by HMM: {nStates | transMat << 8, g0, g1, g2} (+ {g3, g4, g5, 0} for > 5 states)
     const float *hmm_tmax0;   // per HMM: largest log transition probability out of the entry state
     const float *trP; const int *se32;
     const float *lrt;   // left-to-right topologies only (else null): per transMat a_1.., s_1.. (see phase A)
@@ -508,13 +507,11 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             if (LZY) {                                                 // the arena, and the template by HMM
                 const v4i r = ld16(V.larcs, (unsigned)nb * 16u);
                 Bk = JdArc{r.x, __int_as_float(r.y), r.z, r.w};
-                const int hm = (Bk.in & ~TEE_FLAG) - 1;
+            } else Bk = C.arcs[nb];
+            {   // the template by HMM (a table of a few tens of KB: L2 hits; a per-arc copy would be a second random sector)
+                const int hm = max((Bk.in & ~TEE_FLAG) - 1, 0);        // (arcs on the new list carry a model; idle lanes read arc 0)
                 a0 = ((const int4 *)C.aux_h)[(NE == 3) ? hm : 2 * hm];
                 if (NE == 6) a1 = ((const int4 *)C.aux_h)[2 * hm + 1];
-            } else {
-                Bk = C.arcs[nb];
-                a0 = ((const int4 *)C.aux)[(NE == 3) ? nb : 2 * nb];
-                if (NE == 6) a1 = ((const int4 *)C.aux)[2 * nb + 1];
             }
             h0 = (v4i){nb, valid ? a0.x : 0, Bk.out, Bk.to};
             h1 = (v4i){a0.y, a0.z, a0.w, __float_as_int(Bk.w)};
