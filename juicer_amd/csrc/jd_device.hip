@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "jd_internal.h"
@@ -1157,15 +1158,27 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
     for (int s = 0; s < B; ++s) {
         StreamDev &S = d->h_streams[(size_t)s];
         memset(&S, 0, sizeof S);
-#define A(p, n) do { rc = dmalloc(d, &(p), (size_t)(n)); if (rc) return rc; } while (0)
-        A(S.rec, 2 * d->cap_slots * (rec_bytes / 4));
-        A(S.ast, d->net->n_arcs);
-        A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states);
-        A(S.items, 4 * d->cap_items);
-        A(S.newl, d->cap_new); A(S.cleanl, d->cap_new); A(S.dirtyl, d->cap_new);
-        A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW);
-        A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths); A(S.gc_state, sizeof(GcState) / 4);
-        A(S.hist, 2 * HIST_MAX_BINS);
+        // ONE allocation per stream, carved up into 256-byte aligned pieces (two passes over the same list:
+        // sizes, then pointers).  What a decoder's set-up costs is the BYTES: the driver hands out cleared
+        // memory at 25-60 GB/s (tools/alloc_probe.py), i.e. seconds for the default 70 % of a 288 GB device.
+        char *blk = nullptr;
+        size_t off = 0;
+#define A(p, n) do { const size_t bytes_ = (std::max<size_t>((size_t)(n), 1) * sizeof(*(p)) + 255) & ~(size_t)255; \
+                     if (blk) (p) = (typename std::remove_reference<decltype(p)>::type)(blk + off); off += bytes_; } while (0)
+#define ARENAS() do { \
+        A(S.rec, 2 * d->cap_slots * (rec_bytes / 4)); \
+        A(S.ast, d->net->n_arcs); \
+        A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states); \
+        A(S.items, 4 * d->cap_items); \
+        A(S.newl, d->cap_new); A(S.cleanl, d->cap_new); A(S.dirtyl, d->cap_new); \
+        A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW); \
+        A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths); A(S.gc_state, sizeof(GcState) / 4); \
+        A(S.hist, 2 * HIST_MAX_BINS); } while (0)
+        ARENAS();
+        rc = dmalloc(d, &blk, off);
+        if (rc) return rc;
+        off = 0;
+        ARENAS();
         {   // the five result arrays of all streams live in one arena [stream][array][res_cap]:
             // fetch_results brings a whole wave back with a single strided copy
             int *base = d->d_res + (size_t)s * 5 * d->res_cap;
@@ -1173,6 +1186,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
             S.res_score = (float *)(base + 2 * (size_t)d->res_cap); S.res_ac = (float *)(base + 3 * (size_t)d->res_cap);
             S.res_lm = (float *)(base + 4 * (size_t)d->res_cap);
         }
+#undef ARENAS
 #undef A
         S.res_cap = d->res_cap;
         reset_ast(S.ast, d->net->n_arcs);
