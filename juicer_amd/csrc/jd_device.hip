@@ -1136,7 +1136,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         // graph: small graphs do not write more, and tens of GB take seconds to allocate)
         if (d->cap_paths <= 0)
             d->cap_paths = pick(std::max(0.3 * budget, budget - (double)d->cap_slots * rec_b - (double)d->cap_items * item_b) / path_b,
-                                1 << 21, std::min<int64_t>(0x40000000LL, std::max<int64_t>(1 << 26, 16 * d->net->n_arcs)));
+                                1 << 21, std::min<int64_t>(0x40000000LL, std::max<int64_t>(1 << 24, 16 * d->net->n_arcs)));
         if (d->cap_slots > lim_rec || d->cap_items > lim_item || d->cap_paths > 0x7fffff00LL)
             return jd_fail(JD_EINVAL, "arena capacity too large (instance records and frontier items are addressed "
                            "with 32-bit byte offsets: at most %lld / %lld records)", (long long)lim_rec, (long long)lim_item);
