@@ -159,22 +159,24 @@ def lazy_part(ncl, ng, am, feats, dev, full_states, full_arcs, gnet):
     models = capi.Models.from_htk(am)
     want = capi.Decoder(gnet, models, main_beam=200.0, device=dev.index, max_streams=len(feats)).decode_batch(feats)
     t0 = time.perf_counter()
-    lz = capi.Network.lazy(ncl, ng, models, device=dev.index, max_states=1 << 23, max_arcs=1 << 25)
+    lz = capi.Network.lazy(ncl, ng, models, device=dev.index, max_states=1 << 22, max_arcs=1 << 23)
     t_create = time.perf_counter() - t0
     dec = capi.Decoder(lz, models, main_beam=200.0, device=dev.index, max_streams=len(feats))
     frames = sum(f.shape[0] for f in feats)
-    times = []
+    times, cold_ms = [], None
     for _ in range(3):
         t0 = time.perf_counter()
         hyps = dec.decode_batch(feats)
         times.append(time.perf_counter() - t0)
+        if cold_ms is None:
+            cold_ms = dec.last_timing()["search_ms"]
     ns, na = lz.lazy_size()
     same = sum(int(a.n == b.n and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
                    and np.array_equal(np.asarray(a.score, np.float32).view(np.uint32), np.asarray(b.score, np.float32).view(np.uint32)))
                for a, b in zip(hyps, want))
     tm = dec.last_timing()
     dec.close()
-    return {"create_s": round(t_create, 4), "cold_pass_s_incl_arena_setup": round(times[0], 3), "warm_frames_per_s_incl_pcie": round(frames / min(times[1:]), 1),
+    return {"create_s": round(t_create, 4), "cold_search_ms": round(cold_ms, 3), "cold_pass_wall_s_incl_arena_setup": round(times[0], 3), "warm_frames_per_s_incl_pcie": round(frames / min(times[1:]), 1),
             "warm_search_ms": round(tm["search_ms"], 3), "states_expanded": ns, "arcs_expanded": na,
             "fraction_of_full_composition": round(ns / max(1, full_states), 4),
             "identical_to_composed_first": "%d/%d" % (same, len(feats))}

@@ -1235,6 +1235,11 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
 static int ensure_arenas(jd_dec *d)
 {
     if (d->arenas_ready) return JD_OK;
+    const auto t_start = std::chrono::steady_clock::now();
+    struct Report { jd_dec *d; std::chrono::steady_clock::time_point t0;
+        ~Report() { if (getenv("JD_VERBOSE")) fprintf(stderr, "arenas: slots %lld, items %lld, Path records %lld per stream x %d streams in %.3f s\n",
+                                                      (long long)d->cap_slots, (long long)d->cap_items, (long long)d->cap_paths, d->max_streams,
+                                                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } } report{d, t_start};
     const int64_t u_slots = d->cap_slots, u_items = d->cap_items, u_paths = d->cap_paths;   // <= 0: not set by the caller
     double frac = 0.7;
     for (int attempt = 0;; ++attempt) {

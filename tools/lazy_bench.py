@@ -54,7 +54,7 @@ del dec, static
 
 # search-driven
 t0 = time.perf_counter()
-lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 23, max_arcs=1 << 25)
+lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 22, max_arcs=1 << 23)
 t_create = time.perf_counter() - t0
 dec = capi.Decoder(lazy, models, main_beam=args.beam, max_streams=args.utts)
 lz_t, sizes, same, lz_search = [], [lazy.lazy_size()], 0, []

@@ -26,7 +26,7 @@ if args.clg:
     am = synth.make_models(0, n_gmm=3000, n_hmm=2000, n_mix=16, n_tm=8, sep=0.6, with_tee=True)
     cl, g = synth.make_cl_g(0, am, n_words=20000, n_succ=40, n_tri=200000, n_succ3=8, with_sp=True)
     ncl, ng = capi.Network.from_synth(cl, 1.0, 0.0), capi.Network.from_synth(g, 10.0, 0.0)
-    gnet = (capi.Network.lazy(ncl, ng, capi.Models.from_htk(am), max_states=1 << 23, max_arcs=1 << 25) if args.lazy
+    gnet = (capi.Network.lazy(ncl, ng, capi.Models.from_htk(am), max_states=1 << 22, max_arcs=1 << 23) if args.lazy
             else capi.Network.compose(ncl, ng, max_states=1 << 26, max_arcs=1 << 27))
     feats = [synth.sample_utterance(100 + u, g, am, 8)[0] for u in range(args.utts)]
 elif args.c4 > 0:
