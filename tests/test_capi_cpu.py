@@ -115,6 +115,9 @@ def test_no_cpu_fallback(built):
     with pytest.raises(capi.JuicerAmdError) as ei:
         capi.Network.compose(capi.Network.from_synth(cl), capi.Network.from_synth(gr))
     assert ei.value.code == capi.JD_ENODEV
+    with pytest.raises(capi.JuicerAmdError) as ei:
+        capi.Network.lazy(capi.Network.from_synth(cl), capi.Network.from_synth(gr), m)
+    assert ei.value.code == capi.JD_ENODEV
 
 
 def test_product_does_not_reference_oracle():
