@@ -141,3 +141,32 @@ def test_batch_test_cli_composes_lazily(built, tmp_path):
     multi = subprocess.run(base + ["-lazy", "-devices", "1"], capture_output=True, text=True, timeout=240)
     assert multi.returncode == 0, multi.stderr
     assert "on each of 1 devices" in multi.stderr and multi.stdout == first.stdout
+
+
+def test_lazy_with_the_decoders_other_options(built):
+    """Histogram pruning, PARTIAL_DECODING traces, a small Path arena (records collected and renumbered under
+    way) and setMaxAllocModels behave on a lazily composed network as on the composed graph."""
+    from juicer_amd import capi, synth
+    c = CASES[0]
+    am, g, ncl, ng = _case(c)
+    models = capi.Models.from_htk(am)
+    static = capi.Network.compose(ncl, ng)
+    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    x = np.concatenate([synth.sample_utterance(c["seed"] + 300 + u, g, am, 9)[0] for u in range(3)])
+    kw = dict(main_beam=250.0, max_hyps=400, max_streams=1, max_paths=1 << 12)
+    ds, dl = capi.Decoder(static, models, **kw), capi.Decoder(lazy, models, **kw)
+    dl.set_max_alloc_models(50)                       # (a percentage of the network's - here: the capacity's - transitions)
+    traces = 0
+    for d in (ds, dl):
+        d.set_partial_interval(100)
+        d.stream_init(0)
+    for pos in range(0, x.shape[0], 61):
+        for d in (ds, dl):
+            d.stream_push(0, x[pos:pos + 61])
+        a, b = ds.stream_partial(0, trace_now=True), dl.stream_partial(0, trace_now=True)
+        assert a == b
+        traces += int(a[0])
+    hs, hl = ds.stream_finish(0), dl.stream_finish(0)
+    _same(hl, hs)
+    assert hs.n > 0 and traces > 0
+    assert ds.stream_partial(0) == dl.stream_partial(0)
