@@ -133,6 +133,10 @@ int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t devi
  */
 int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *g, const jd_am *am, int32_t device,
                        int64_t max_states, int64_t max_arcs, int32_t pushing);
+/* Forget everything expanded so far and start again from the start state (where the reference bounds its
+ * memory with an LRU cache, WFSTOnTheFlyDecoder.h:210-371): for a network about to run out of room, or one that
+ * has (which also clears the failure).  No stream of a decoder on the network may be inside an utterance. */
+int jd_net_lazy_reset(jd_net *n);
 /* composed states and arcs materialised so far */
 int jd_net_lazy_size(const jd_net *n, int64_t *states, int64_t *arcs);
 

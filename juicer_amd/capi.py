@@ -75,7 +75,7 @@ EXPORTS = [
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
-    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size",
+    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
 ]
 
 _lib = None
@@ -195,6 +195,9 @@ class Network:
         _check(lib().jd_net_create_lazy(C.byref(h), cl.h, g.h, am.h, C.c_int32(device), C.c_int64(max_states), C.c_int64(max_arcs),
                                         C.c_int32(1 if pushing else 0)))
         return cls(h)
+
+    def lazy_reset(self):
+        _check(lib().jd_net_lazy_reset(self.h))
 
     def lazy_size(self):
         ns, na = C.c_int64(0), C.c_int64(0)

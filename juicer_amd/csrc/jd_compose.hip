@@ -470,6 +470,21 @@ static void lazy_free(jd_net *n)
     n->lazy_dev = nullptr;
 }
 
+// empties the graph (hash table, rows, arena counters, failure flag) and expands the start state with its closure
+static int lazy_start(jd_net *n, const LazyDev &L, int *h_ok)
+{
+    int rc = JD_OK;
+    CHK(hipMemset(L.keys, 0, (size_t)(L.mask + 1) * 8)); CHK(hipMemset(L.vals, 0xff, (size_t)(L.mask + 1) * 4));
+    CHK(hipMemset(L.n_states, 0, 4)); CHK(hipMemset(L.n_arcs, 0, 8)); CHK(hipMemset(L.err, 0, 4));
+    CHK(hipMemset(L.rows, 0, (size_t)L.max_states * sizeof(int4)));
+    hipLaunchKernelGGL(jl_init, dim3(1), dim3(64), 0, 0, L, (const float *)n->lazy_tee, (unsigned)n->lazy_cf0, (int)n->lazy_g0, (int *)n->lazy_ok);
+    CHK(hipGetLastError());
+    CHK(hipMemcpy(h_ok, n->lazy_ok, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    if (!h_ok[0]) rc = jd_fail(JD_ENOMEM, "lazily composed network: capacities too small for the start state's closure");
+done:
+    return rc;
+}
+
 extern "C" int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *g, const jd_am *am, int32_t device,
                                   int64_t max_states, int64_t max_arcs, int32_t pushing)
 {
@@ -518,16 +533,11 @@ extern "C" int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *
         LAL(L.arcs, JdArc, max_arcs); LAL(L.n_states, int, 1); LAL(L.n_arcs, unsigned long long, 1); LAL(L.err, int, 1);
         LAL(d_ok, int, 2); LAL(d_tee, float, am->hmm_tee.size()); LAL(d_L, LazyDev, 1);
         L.max_states = (int)max_states; L.max_arcs = max_arcs; L.push = pushing ? 1 : 0;
-        CHK(hipMemset(L.keys, 0, cap * 8)); CHK(hipMemset(L.vals, 0xff, cap * 4));
-        CHK(hipMemset(L.n_states, 0, 4)); CHK(hipMemset(L.n_arcs, 0, 8)); CHK(hipMemset(L.err, 0, 4));
-        CHK(hipMemset(L.rows, 0, (size_t)max_states * sizeof(int4)));
         CHK(hipMemcpy(d_tee, am->hmm_tee.data(), am->hmm_tee.size() * 4, hipMemcpyHostToDevice));
         CHK(hipMemcpy(d_L, &L, sizeof L, hipMemcpyHostToDevice));
-        // the start state and its closure
-        hipLaunchKernelGGL(jl_init, dim3(1), dim3(64), 0, 0, L, d_tee, (unsigned)cl->init | LZ_FLAG, g->init, d_ok);
-        CHK(hipGetLastError());
-        CHK(hipMemcpy(h_ok, d_ok, sizeof h_ok, hipMemcpyDeviceToHost));
-        if (!h_ok[0]) { rc = jd_fail(JD_ENOMEM, "jd_net_create_lazy: capacities too small for the start state's closure"); goto done; }
+        n->lazy_tee = d_tee; n->lazy_ok = d_ok; n->lazy_cf0 = (uint32_t)cl->init | LZ_FLAG; n->lazy_g0 = g->init;
+        rc = lazy_start(n, L, h_ok);                 // the start state and its closure
+        if (rc) goto done;
         n->n_states = (int32_t)max_states; n->n_arcs = max_arcs; n->init = h_ok[1];
         n->n_final = 0; n->max_in = cl->max_in;
         n->lm_scale = 1.0f; n->ins_penalty = 0.0f;
@@ -538,6 +548,22 @@ extern "C" int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *
 done:
     if (n) { lazy_free(n); delete n; }
     return rc;
+}
+
+// Forget everything that has been expanded (the reference bounds its look-ahead memory with an LRU cache,
+// WFSTOnTheFlyDecoder.h:210-371; here the arena simply starts again): for a long-running service whose network is
+// about to run out of room, or has.  No stream of any decoder on the network may be inside an utterance.
+extern "C" int jd_net_lazy_reset(jd_net *n)
+{
+    if (!n || !n->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_lazy_reset: not a lazily composed network");
+    if (hipSetDevice(n->lazy_device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return jd_fail(JD_EHIP, "jd_net_lazy_reset: device %d", n->lazy_device);
+    LazyDev L;
+    if (hipMemcpy(&L, n->lazy_dev, sizeof L, hipMemcpyDeviceToHost) != hipSuccess) return jd_fail(JD_EHIP, "jd_net_lazy_reset: copy failed");
+    int h_ok[2] = {0, 0};
+    const int rc = lazy_start(n, L, h_ok);
+    if (rc) return rc;
+    if (h_ok[1] != n->init) return jd_fail(JD_ESTATE, "jd_net_lazy_reset: the start state moved");   // (first insertion: always 0)
+    return JD_OK;
 }
 
 // how far a lazily composed network has grown: composed states and arcs materialised so far

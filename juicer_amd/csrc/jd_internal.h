@@ -31,6 +31,8 @@ struct jd_net {
     int lazy_device = -1;
     std::vector<void *> lazy_allocs;   // device allocations behind it
     void (*lazy_free)(jd_net *) = nullptr;
+    void *lazy_tee = nullptr, *lazy_ok = nullptr;      // device: tee log-probabilities by HMM, the init kernel's answer
+    uint32_t lazy_cf0 = 0; int32_t lazy_g0 = 0;        // the start pair
 };
 
 struct jd_am {

@@ -170,3 +170,37 @@ def test_lazy_with_the_decoders_other_options(built):
     _same(hl, hs)
     assert hs.n > 0 and traces > 0
     assert ds.stream_partial(0) == dl.stream_partial(0)
+
+
+def test_lazy_reset(built):
+    """jd_net_lazy_reset: the network forgets what it expanded and grows again to the same results; it also
+    clears a capacity failure."""
+    from juicer_amd import capi, synth
+    c = CASES[1]
+    am, g, ncl, ng = _case(c)
+    models = capi.Models.from_htk(am)
+    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    s0 = lazy.lazy_size()
+    feats = [synth.sample_utterance(c["seed"] + 500 + u, g, am, 7)[0] for u in range(4)]
+    dec = capi.Decoder(lazy, models, main_beam=250.0, max_streams=2)
+    first = dec.decode_batch(feats)
+    s1 = lazy.lazy_size()
+    assert s1[0] > s0[0]
+    lazy.lazy_reset()
+    assert lazy.lazy_size() == s0
+    again = dec.decode_batch(feats)                   # the same decoder, on the emptied network
+    for a, b in zip(again, first):
+        _same(a, b)
+    assert lazy.lazy_size()[0] == s1[0]
+    # a network that ran out of room stays failed until it is reset
+    small = capi.Network.lazy(ncl, ng, models, max_states=300, max_arcs=1 << 18)
+    t0 = small.lazy_size()
+    d2 = capi.Decoder(small, models, main_beam=250.0)
+    for _ in range(2):
+        with pytest.raises(capi.JuicerAmdError) as ei:
+            d2.decode_batch(feats[:1])
+        assert ei.value.code == capi.JD_ENOMEM
+    small.lazy_reset()
+    assert small.lazy_size() == t0
+    with pytest.raises(capi.JuicerAmdError):
+        capi.Network.compose(ncl, ng).lazy_reset()
