@@ -1295,9 +1295,15 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
                                     "(frame %d)", s0 + i, K.frame);
             else if (K.error == JDE_LAZY_INV)
                 first_err = jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)", s0 + i, K.frame);
-            else if (K.error == JDE_LAZY)
-                first_err = jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of room at frame %d (capacity %d states, "
-                                    "%lld arcs): create it with larger max_states / max_arcs", s0 + i, K.frame, d->net->n_states, (long long)d->net->n_arcs);
+            else if (K.error == JDE_LAZY) {
+                LazyDev L;
+                int why = 0;
+                if (hipMemcpy(&L, d->net->lazy_dev, sizeof L, hipMemcpyDeviceToHost) == hipSuccess) (void)hipMemcpy(&why, L.err, sizeof why, hipMemcpyDeviceToHost);
+                first_err = jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of %s at frame %d (capacity %d states, %lld arcs): "
+                                    "create it with larger max_states / max_arcs, or jd_net_lazy_reset it between utterances", s0 + i,
+                                    why == 1 ? "states" : why == 2 ? "arcs" : "room in a wave's closure queue (an epsilon closure of hundreds of states)",
+                                    K.frame, d->net->n_states, (long long)d->net->n_arcs);
+            }
             else {
                 const char *what = K.error == JDE_SLOTS ? "instance slots" : K.error == JDE_ITEMS ? "frontier items"
                                  : K.error == JDE_PATHS ? "Path records" : K.error == JDE_NEW ? "newly entered arcs" : "arena";
