@@ -453,12 +453,11 @@ done:
 
 __global__ void jl_init(LazyDev L, const float *hmm_tee, unsigned cf0, int g0, int *ok)
 {
-    __shared__ int q[LZQ + LZD];
-    int qn = 0, dn = 0;
+    __shared__ int2 stk[LZQ];
     int s0 = 0;
     if (threadIdx.x == 0) s0 = lz_state_id(L, cf0, g0);
     s0 = __shfl(s0, 0);
-    const bool good = lz_expand(L, hmm_tee, s0, q, &qn, &dn) && lz_drain(L, hmm_tee, q, &qn, &dn, wall_clock64() + 300000000LL);
+    const bool good = lz_close(L, hmm_tee, s0, stk, wall_clock64() + 300000000LL);
     if (threadIdx.x == 0) { ok[0] = (good && !lz_failed(L)) ? 1 : 0; ok[1] = s0; }
 }
 

@@ -1301,7 +1301,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
                 if (hipMemcpy(&L, d->net->lazy_dev, sizeof L, hipMemcpyDeviceToHost) == hipSuccess) (void)hipMemcpy(&why, L.err, sizeof why, hipMemcpyDeviceToHost);
                 first_err = jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of %s at frame %d (capacity %d states, %lld arcs): "
                                     "create it with larger max_states / max_arcs, or jd_net_lazy_reset it between utterances", s0 + i,
-                                    why == 1 ? "states" : why == 2 ? "arcs" : "room in a wave's closure queue (an epsilon closure of hundreds of states)",
+                                    why == 1 ? "states" : why == 2 ? "arcs" : "stack closing a state (epsilon / tee arcs more than a hundred deep, or a cycle of them)",
                                     K.frame, d->net->n_states, (long long)d->net->n_arcs);
             }
             else {

@@ -15,11 +15,11 @@
 //               search, so blocks need no alignment) and its row
 //               {first, count, status, final weight} is published after the arcs have drained; a wave that
 //               loses a claim remembers the state and looks again.  Expansions never wait for each other;
-//   closed      "has arcs" (EXPANDED) is not yet "its closure has arcs": the wave that expanded D still has
-//               D's epsilon / tee destinations on its queue.  A state is marked CLOSED by a wave whose queue
-//               ran empty after it expanded D or walked D's arcs - everything below D is then expanded.
-//               The invariant is about CLOSED states; a wave that finds somebody else's EXPANDED state does
-//               not wait for its owner (two owners could wait for each other) but walks its closure itself.
+//   closed      "has arcs" (EXPANDED) is not yet "its closure has arcs".  A wave closes a state depth first
+//               (lz_close: an explicit stack of {state, next arc} in LDS) and marks it CLOSED when every
+//               epsilon / tee arc of it leads to a closed state.  The invariant is about CLOSED states; a wave
+//               that finds somebody else's EXPANDED state does not wait for whoever is closing it (two could
+//               wait for each other) but walks it itself.
 #ifndef JD_LAZY_H
 #define JD_LAZY_H
 
@@ -32,8 +32,7 @@
 
 enum { LZ_UNKNOWN = 0, LZ_EXPANDING = 1, LZ_EXPANDED = 2, LZ_CLOSED = 3 };
 #define LZ_FLAG 0x80000000u          // the composition filter's flag, in the top bit of the stored C.L state
-#define LZQ 192                      // closure / pending states a wave can have outstanding
-#define LZD 64                       // states a wave has expanded / walked and not yet marked closed
+#define LZQ 128                      // depth of a wave's stack when it closes a state (jd_lazy.h: lz_close)
 
 struct LazyDev {
     const int *cl_row; const JdArc *cl_arcs; const float *cl_fin; const int2 *cl_la;
@@ -169,52 +168,12 @@ __device__ __forceinline__ bool lz_failed(const LazyDev &L)
     return __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
-// the wave-uniform state D has arcs and its closure is on the queue: remember it, to mark it when the queue runs empty
-__device__ __forceinline__ void lz_note(int D, int *q, int *dn)
-{
-    if (*dn < LZD) { if ((threadIdx.x & 63) == 0) q[LZQ + *dn] = D; ++*dn; }   // (full: it stays EXPANDED and is walked again some day)
-}
-
-// One wave makes sure composed state D (wave-uniform) has arcs, expanding it if nobody has.  The destinations
-// of its epsilon / tee arcs go onto the wave's queue q[0 .. *qn) (they must be closed within the same frame); a
-// state another wave is expanding goes onto the queue itself, to be looked at again.  q[LZQ .. LZQ + *dn) lists
-// what to mark closed.  Returns false when a capacity ran out.
-__device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q, int *qn, int *dn)
+// One wave gives composed state D (wave-uniform, claimed by the caller: status EXPANDING) its arcs.  Nothing in
+// here waits for anybody.  Returns false when a capacity ran out (the state then stays EXPANDING: the network
+// has failed, see lz_failed).
+__device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D)
 {
     const int lane = threadIdx.x & 63;
-    int st = 0;
-    if (lane == 0) st = atomicCAS(&L.rows[D].z, (int)LZ_UNKNOWN, (int)LZ_EXPANDING);
-    st = __shfl(st, 0);
-    if (st == LZ_CLOSED) return true;
-    if (st == LZ_EXPANDING) {                                          // somebody else's: check again later
-        if (*qn >= LZQ) { if (lane == 0) atomicMax(L.err, 3); return false; }
-        if (lane == 0) q[*qn] = D;
-        ++*qn;
-        return true;
-    }
-    if (st == LZ_EXPANDED) {                                           // somebody else's, closure not known to be complete: walk it
-        const unsigned long long fc = __hip_atomic_load((unsigned long long *)&L.rows[D].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int first = (int)(unsigned)fc, cnt = (int)(fc >> 32);
-        bool ok = true;
-        for (int a = 0; a < cnt && ok; a += 64) {
-            int to = -1;
-            bool closure = false;
-            if (a + lane < cnt) {
-                const JdArc *pa = &L.arcs[first + a + lane];
-                const int in = __hip_atomic_load(&pa->in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                closure = in == 0 || (in & TEE_FLAG) != 0;
-                if (closure) to = __hip_atomic_load(&pa->to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            for (unsigned long long bc = __ballot(closure); bc; bc &= bc - 1) {
-                const int t = __shfl(to, __ffsll((long long)bc) - 1);
-                if (*qn >= LZQ) { if (lane == 0) atomicMax(L.err, 3); ok = false; break; }
-                if (lane == 0) q[*qn] = t;
-                ++*qn;
-            }
-        }
-        if (ok) lz_note(D, q, dn);
-        return ok;
-    }
     const unsigned cf = (unsigned)__hip_atomic_load(&L.st_c[D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int c = (int)(cf & ~LZ_FLAG), g = __hip_atomic_load(&L.st_g[D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool flag = (cf & LZ_FLAG) != 0;
@@ -236,19 +195,12 @@ __device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q,
     }
     base = __shfl(base, 0);
     if (base < 0) { if (lane == 0) atomicMax(L.err, 2); return false; }
-    bool ok = true;
     int run = base;
-    if (bo) {                                                          // the back-off arc: an epsilon - closure
-        int to = 0;
-        if (lane == 0) {
-            to = lz_state_id(L, cf, boa.to);
-            lz_store_arc(&L.arcs[run], to, boa.w, 0, boa.out);
-        }
-        to = __shfl(to, 0);
-        if (*qn >= LZQ) { if (lane == 0) atomicMax(L.err, 3); ok = false; } else { if (lane == 0) q[*qn] = to; ++*qn; }
+    if (bo) {                                                          // the back-off arc first (an epsilon)
+        if (lane == 0) lz_store_arc(&L.arcs[run], lz_state_id(L, cf, boa.to), boa.w, 0, boa.out);
         ++run;
     }
-    for (int a = a0; a < a1; a += 64) {
+    for (int a = a0; a < a1; a += 64) {                                // then the C.L arcs in their order
         const bool on = a + lane < a1;
         JdArc ca = {0, 0.0f, 0, 0};
         int cnt = 0;
@@ -258,8 +210,6 @@ __device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q,
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(pre, o); if (lane >= o) pre += y; }
         const int chunk_total = __shfl(pre, 63);
-        int to = -1;
-        bool closure = false;
         if (cnt) {
             const int pos = run + pre - 1;
             const bool tee = ca.in > 0 && hmm_tee[ca.in - 1] > LZ;
@@ -267,21 +217,11 @@ __device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q,
             if (ca.out == 0) {
                 float w = ca.w;
                 if (L.push) { const int2 la = L.cl_la[ca.to]; w = (ca.w + lz_potential(L, g, la.x, la.y)) - p_src; }
-                to = lz_state_id(L, (unsigned)ca.to, g);
-                lz_store_arc(&L.arcs[pos], to, w, in, 0);
+                lz_store_arc(&L.arcs[pos], lz_state_id(L, (unsigned)ca.to, g), w, in, 0);
             } else {
                 const JdArc m = L.g_arcs[ga];
-                to = lz_state_id(L, (unsigned)ca.to | LZ_FLAG, m.to);
-                lz_store_arc(&L.arcs[pos], to, L.push ? (ca.w + m.w) - p_src : ca.w + m.w, in, m.out);
+                lz_store_arc(&L.arcs[pos], lz_state_id(L, (unsigned)ca.to | LZ_FLAG, m.to), L.push ? (ca.w + m.w) - p_src : ca.w + m.w, in, m.out);
             }
-            closure = ca.in == 0 || tee;                               // reachable within the frame a token reaches D
-        }
-        for (unsigned long long bc = __ballot(closure); bc; bc &= bc - 1) {
-            const int src = __ffsll((long long)bc) - 1;
-            const int t = __shfl(to, src);
-            if (*qn >= LZQ) { if (lane == 0) atomicMax(L.err, 3); ok = false; break; }
-            if (lane == 0) q[*qn] = t;
-            ++*qn;
         }
         run += chunk_total;
     }
@@ -293,38 +233,72 @@ __device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D, int *q,
         __hip_atomic_store(&L.rows[D].z, (int)LZ_EXPANDED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (ok) lz_note(D, q, dn);
-    return ok;
+    return !lz_failed(L);
 }
 
-// drains a wave's queue: expands what is unknown, walks what others expanded, looks again at what others are
-// expanding; once it is empty everything noted since it was last empty is closed
-__device__ bool lz_drain(const LazyDev &L, const float *hmm_tee, int *q, int *qn, int *dn, long long t_limit)
+// One wave closes composed state D0 (wave-uniform): D0 and everything its epsilon / tee arcs lead to gets its
+// arcs.  Depth first with an explicit stack of {state, next arc to look at} in the wave's LDS (stk[0 .. LZQ)): a
+// state is marked CLOSED when its walk is through, so the stack is as deep as the closure is, not as broad (a
+// back-off chain: a handful of entries).  A state another wave is expanding is waited for (expansions wait for
+// nobody); one that somebody else expanded and has not closed yet is walked here too - never waited for, since
+// two walkers could wait for each other.  Returns false when a capacity ran out.
+__device__ bool lz_close(const LazyDev &L, const float *hmm_tee, int D0, int2 *stk, long long t_limit)
 {
-    bool ok = true;
+    const int lane = threadIdx.x & 63;
+    int sp = 0;
+    if (lane == 0) stk[0] = make_int2(D0, 0);
+    sp = 1;
     unsigned spins = 0;
-    while (*qn > 0 && ok) {
-        const int D = q[--*qn];
-        const int st = lz_status(L, D);
-        if (st == LZ_CLOSED) continue;
-        if (st == LZ_EXPANDING) {                                      // another wave's expansion: it does not wait for anybody
+    while (sp > 0) {
+        const int2 top = stk[sp - 1];
+        const int S = top.x;
+        int st = 0;
+        if (lane == 0) st = atomicCAS(&L.rows[S].z, (int)LZ_UNKNOWN, (int)LZ_EXPANDING);
+        st = __shfl(st, 0);
+        if (st == LZ_CLOSED) { --sp; continue; }
+        if (st == LZ_UNKNOWN) {                                        // claimed: give it its arcs, then walk them
+            if (!lz_expand(L, hmm_tee, S)) return false;
+            continue;
+        }
+        if (st == LZ_EXPANDING) {                                      // another wave's expansion: soon over
             __builtin_amdgcn_s_sleep(4);
-            // (behind the rest of the queue, so that the wait is spent on other work)
-            for (int k = *qn; k > 0; --k) q[k] = q[k - 1];
-            q[0] = D; ++*qn;
             ++spins;
             if ((spins & 63u) == 0 && lz_failed(L)) return false;      // (an expansion that ran out of room never finishes)
             if ((spins & 4095u) == 0 && wall_clock64() > t_limit) { atomicMax(L.err, 3); return false; }
             continue;
         }
-        ok = lz_expand(L, hmm_tee, D, q, qn, dn);
+        // EXPANDED: from arc top.y on, the first epsilon / tee arc whose destination is not closed yet
+        const unsigned long long fc = __hip_atomic_load((unsigned long long *)&L.rows[S].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int first = (int)(unsigned)fc, cnt = (int)(fc >> 32);
+        bool descended = false;
+        for (int a = top.y; a < cnt; a += 64) {
+            int to = -1;
+            bool need = false;
+            if (a + lane < cnt) {
+                const JdArc *pa = &L.arcs[first + a + lane];
+                const int in = __hip_atomic_load(&pa->in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (in == 0 || (in & TEE_FLAG) != 0) {
+                    to = __hip_atomic_load(&pa->to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    need = to != S && lz_status(L, to) != LZ_CLOSED;
+                }
+            }
+            const unsigned long long bn = __ballot(need);
+            if (bn) {
+                const int j = __ffsll((long long)bn) - 1;
+                const int T = __shfl(to, j);
+                if (sp >= LZQ) { if (lane == 0) atomicMax(L.err, 3); return false; }   // a closure hundreds of states deep (a cycle of epsilons?)
+                if (lane == 0) { stk[sp - 1] = make_int2(S, a + j + 1); stk[sp] = make_int2(T, 0); }
+                ++sp;
+                descended = true;
+                break;
+            }
+        }
+        if (!descended) {
+            if (lane == 0) __hip_atomic_store(&L.rows[S].z, (int)LZ_CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            --sp;
+        }
     }
-    if (ok) {
-        const int lane = threadIdx.x & 63;
-        for (int k = lane; k < *dn; k += 64) __hip_atomic_store(&L.rows[q[LZQ + k]].z, (int)LZ_CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *dn = 0;
-    }
-    return ok;
+    return true;
 }
 
 #endif

@@ -1312,12 +1312,10 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         }
         if (aborted) break;
         if constexpr (LZY) {
-            __shared__ int lzq[SW][LZQ + LZD];                         // per wave: composed states still to be closed (only in the lazy kernels' LDS)
+            __shared__ int2 lzq[SW][LZQ];                              // per wave: the stack of lz_close (only in the lazy kernels' LDS)
             // search-driven composition: the arcs this wave entered in this frame lead to states that phase X
-            // of a later frame will expand - make them ready now, epsilon / tee closure included (jd_lazy.h)
+            // of a later frame will expand - close them now, epsilon / tee closure included (jd_lazy.h)
             const LazyDev &L = *C.lazy;
-            int *q = lzq[wid];
-            int qn = 0, dn = 0;
             bool ok = true;
             const size_t nbase = (size_t)gw * gout.seg_new;
             for (int i0 = 0; i0 < xo.new_cnt && ok; i0 += 64) {
@@ -1327,10 +1325,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                     dest = ld16(V.larcs, (unsigned)b * 16u).x;
                     if (lz_status(L, dest) == LZ_CLOSED) dest = -1;
                 }
-                for (unsigned long long bm = __ballot(dest >= 0); bm && ok; bm &= bm - 1) {
-                    const int D = __shfl(dest, __ffsll((long long)bm) - 1);
-                    ok = lz_expand(L, C.hmm_tee, D, q, &qn, &dn) && lz_drain(L, C.hmm_tee, q, &qn, &dn, t_limit);
-                }
+                for (unsigned long long bm = __ballot(dest >= 0); bm && ok; bm &= bm - 1)
+                    ok = lz_close(L, C.hmm_tee, __shfl(dest, __ffsll((long long)bm) - 1), lzq[wid], t_limit);
             }
             if ((!ok || lz_failed(L)) && lane == 0) CS(&c.err[p], (int)JDE_LAZY);
         }

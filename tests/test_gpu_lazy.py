@@ -204,3 +204,33 @@ def test_lazy_reset(built):
     assert small.lazy_size() == t0
     with pytest.raises(capi.JuicerAmdError):
         capi.Network.compose(ncl, ng).lazy_reset()
+
+
+def test_lazy_broad_epsilon_closure(built):
+    """A start state with 300 epsilon successors: closing a state is depth first, so the breadth of a closure is
+    no limit (the stack is as deep as the epsilon chains are)."""
+    from juicer_amd import capi, synth
+    am = synth.make_models(3, n_gmm=60, n_hmm=30, n_mix=2, n_tm=8, sep=0.8, with_tee=False)
+    n_br, n_words = 300, 20
+    # C.L: 0 -eps-> i (i = 1..300) -phone:word-> 301 -eps-> 0 ; 301 final
+    row_ptr = [0, n_br] + [n_br + i for i in range(1, n_br + 1)] + [2 * n_br + 1]
+    to = list(range(1, n_br + 1)) + [n_br + 1] * n_br + [0]
+    ilab = [0] * n_br + [1 + (i % am.n_hmm) for i in range(n_br)] + [0]
+    olab = [0] * n_br + [1 + (i % n_words) for i in range(n_br)] + [0]
+    rng = np.random.default_rng(11)
+    w = (-rng.uniform(0.1, 3.0, size=len(to))).astype(np.float32)
+    ncl = capi.Network.from_csr(n_states=n_br + 2, init_state=0, row_ptr=row_ptr, to=to, w=w, ilab=ilab, olab=olab,
+                                fstate=[n_br + 1], fweight=[0.0])
+    # G: one state, a loop per word
+    gw = (-rng.uniform(0.1, 2.0, size=n_words)).astype(np.float32)
+    ng = capi.Network.from_csr(n_states=1, init_state=0, row_ptr=[0, n_words], to=[0] * n_words, w=gw,
+                               ilab=list(range(1, n_words + 1)), olab=list(range(1, n_words + 1)), fstate=[0], fweight=[0.0])
+    models = capi.Models.from_htk(am)
+    static = capi.Network.compose(ncl, ng)
+    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 12, max_arcs=1 << 14)
+    assert lazy.lazy_size()[0] >= n_br + 1           # the start state's closure: every branch, at creation
+    x = np.random.default_rng(5).normal(size=(60, am.D)).astype(np.float32)
+    want = capi.Decoder(static, models, main_beam=200.0).decode_batch([x])[0]
+    got = capi.Decoder(lazy, models, main_beam=200.0).decode_batch([x])[0]
+    assert want.n > 0
+    _same(got, want)
