@@ -32,7 +32,7 @@
 
 enum { LZ_UNKNOWN = 0, LZ_EXPANDING = 1, LZ_EXPANDED = 2, LZ_CLOSED = 3 };
 #define LZ_FLAG 0x80000000u          // the composition filter's flag, in the top bit of the stored C.L state
-#define LZQ 128                      // depth of a wave's stack when it closes a state (jd_lazy.h: lz_close)
+#define LZQ 128                      // depth of a wave's stack when it closes a state (lz_close; at most 128: two ballots look through it)
 
 struct LazyDev {
     const int *cl_row; const JdArc *cl_arcs; const float *cl_fin; const int2 *cl_la;
@@ -248,6 +248,7 @@ __device__ bool lz_close(const LazyDev &L, const float *hmm_tee, int D0, int2 *s
     int sp = 0;
     if (lane == 0) stk[0] = make_int2(D0, 0);
     sp = 1;
+    int cyc = LZQ;                                                     // lowest stack index an epsilon CYCLE came back to (LZQ: none)
     unsigned spins = 0;
     while (sp > 0) {
         const int2 top = stk[sp - 1];
@@ -286,15 +287,30 @@ __device__ bool lz_close(const LazyDev &L, const float *hmm_tee, int D0, int2 *s
             if (bn) {
                 const int j = __ffsll((long long)bn) - 1;
                 const int T = __shfl(to, j);
-                if (sp >= LZQ) { if (lane == 0) atomicMax(L.err, 3); return false; }   // a closure hundreds of states deep (a cycle of epsilons?)
-                if (lane == 0) { stk[sp - 1] = make_int2(S, a + j + 1); stk[sp] = make_int2(T, 0); }
-                ++sp;
+                // a cycle of epsilons comes back to a state this walk is inside of: it is being taken care of - go on
+                // behind the arc, and remember how far down the cycle reaches (see the marking below)
+                const unsigned long long on0 = __ballot(lane < sp && stk[lane].x == T);
+                const unsigned long long on1 = __ballot(lane + 64 < sp && stk[(lane + 64) & (LZQ - 1)].x == T);
+                if (lane == 0) stk[sp - 1] = make_int2(S, a + j + 1);
                 descended = true;
+                if (on0 | on1) {
+                    const int at = on0 ? __ffsll((long long)on0) - 1 : 64 + __ffsll((long long)on1) - 1;
+                    cyc = at < cyc ? at : cyc;
+                    break;
+                }
+                if (sp >= LZQ) { if (lane == 0) atomicMax(L.err, 3); return false; }   // epsilon / tee arcs more than LZQ states deep
+                if (lane == 0) stk[sp] = make_int2(T, 0);
+                ++sp;
                 break;
             }
         }
         if (!descended) {
-            if (lane == 0) __hip_atomic_store(&L.rows[S].z, (int)LZ_CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // every epsilon / tee arc of S leads to a closed state - unless S sits on a cycle whose entry (further down
+            // the stack) is not through yet: then S keeps "expanded" and whoever asks next finds the entry closed
+            if (sp - 1 <= cyc) {
+                if (lane == 0) __hip_atomic_store(&L.rows[S].z, (int)LZ_CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sp - 1 == cyc) cyc = LZQ;
+            }
             --sp;
         }
     }

@@ -234,3 +234,27 @@ def test_lazy_broad_epsilon_closure(built):
     got = capi.Decoder(lazy, models, main_beam=200.0).decode_batch([x])[0]
     assert want.n > 0
     _same(got, want)
+
+
+def test_lazy_epsilon_cycle(built):
+    """A cycle of epsilon arcs in C.L (A -eps-> B -eps-> A): the depth-first closing does not follow it for ever."""
+    from juicer_amd import capi, synth
+    am = synth.make_models(4, n_gmm=40, n_hmm=12, n_mix=2, n_tm=8, sep=0.8, with_tee=False)
+    n_words = 6
+    # states: 0 = A (init), 1 = B, 2 = word end (final, eps back to A).  A and B each have phone:word arcs to 2.
+    arcs = ([(0, 1, -0.5, 0, 0)] + [(0, 2, -0.3 * (k + 1), 1 + k, 1 + k) for k in range(3)]
+            + [(1, 0, -0.7, 0, 0)] + [(1, 2, -0.2 * (k + 1), 4 + k, 4 + k) for k in range(3)] + [(2, 0, -0.1, 0, 0)])
+    row_ptr = [0, 4, 8, 9]
+    ncl = capi.Network.from_csr(n_states=3, init_state=0, row_ptr=row_ptr, to=[a[1] for a in arcs], w=np.float32([a[2] for a in arcs]),
+                                ilab=[a[3] for a in arcs], olab=[a[4] for a in arcs], fstate=[2], fweight=[0.0])
+    ng = capi.Network.from_csr(n_states=1, init_state=0, row_ptr=[0, n_words], to=[0] * n_words, w=np.float32([-0.4] * n_words),
+                               ilab=list(range(1, n_words + 1)), olab=list(range(1, n_words + 1)), fstate=[0], fweight=[0.0])
+    models = capi.Models.from_htk(am)
+    static = capi.Network.compose(ncl, ng)
+    lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 10, max_arcs=1 << 12)
+    x = np.random.default_rng(9).normal(size=(40, am.D)).astype(np.float32)
+    want = capi.Decoder(static, models, main_beam=200.0).decode_batch([x])[0]
+    got = capi.Decoder(lazy, models, main_beam=200.0).decode_batch([x])[0]
+    assert want.n > 0
+    _same(got, want)
+    assert lazy.lazy_size()[0] <= static.n_states
