@@ -1011,7 +1011,6 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         }
         TRY(dupload(d, &d->d_aux, aux.data(), aux.size()));
         C.aux_h = d->d_aux;
-        if (lazy) d->xl_ok = false;   // a lazy graph is written by every cluster, on any XCD: agent scope throughout
     }
     C.trP = d->d_trP; C.se32 = d->d_se32;
     {   // Plain left-to-right topologies (every emitting state entered from its predecessor and itself,
@@ -1047,7 +1046,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_WEIGHTED")) d->weighted = atoi(e) != 0;
     if (const char *e = getenv("JD_MODEL_A")) d->model_a_us = atof(e);
     if (const char *e = getenv("JD_MODEL_B")) d->model_b_us = atof(e);
-    if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0 && !lazy;             // development
+    if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0;                      // development
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
     hipError_t e;
@@ -1456,24 +1455,42 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             --cw[(size_t)big]; --used;
         }
         // XCD-local launch (jd_search.h): every cluster inside one eighth of the grid - the clusters go, largest
-        // first, into the eighth with the most room; one that fits nowhere shrinks to the room there is
+        // first, into the eighth with the most room; one that fits nowhere shrinks to the room there is, and what
+        // an eighth has left over in the end goes to its cluster with the latest predicted finish.  The packed plan
+        // is taken if the model says it ends no more than 4 % after the unpacked one (what plain stores and L2
+        // atomics are measured to be worth): a cluster squeezed into a corner is a long tail.
         const int bin = nwg / 8;
         if (d->xl_ok && (nwg & 7) == 0) {
+            auto t_of = [&](int k, int c) { return std::max((*weight)[(size_t)k], 1.0) * (a_us + b_us / std::max(c, 1)); };
             std::vector<int> order((size_t)n_work), pos((size_t)n_work, 0), room(8, bin), cwx = cw;
+            std::vector<std::vector<int>> member(8);
             std::iota(order.begin(), order.end(), 0);
             std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cwx[(size_t)x] > cwx[(size_t)y]; });
             bool fits = true;
-            int shrunk = 0;                                            // workgroups the packing takes away (big clusters are what
-            for (int k : order) {                                      // heavy loads need: then the agent-scope launch is the better one)
+            for (int k : order) {
                 int b = 0;
                 for (int q = 1; q < 8; ++q) if (room[(size_t)q] > room[(size_t)b]) b = q;
                 if (room[(size_t)b] <= 0) { fits = false; break; }
-                shrunk += std::max(0, cwx[(size_t)k] - room[(size_t)b]);
                 cwx[(size_t)k] = std::min(cwx[(size_t)k], room[(size_t)b]);
-                pos[(size_t)k] = b * bin + (bin - room[(size_t)b]);
+                member[(size_t)b].push_back(k);
                 room[(size_t)b] -= cwx[(size_t)k];
             }
-            if (shrunk > nwg / 32) fits = false;
+            double tau_plain = 0.0, tau_xl = 0.0;
+            if (fits) {
+                for (int b = 0; b < 8; ++b) {
+                    while (room[(size_t)b] > 0 && !member[(size_t)b].empty()) {
+                        int late = -1;
+                        for (int k : member[(size_t)b])
+                            if (cwx[(size_t)k] < max_cw && (late < 0 || t_of(k, cwx[(size_t)k]) > t_of(late, cwx[(size_t)late]))) late = k;
+                        if (late < 0) break;
+                        ++cwx[(size_t)late]; --room[(size_t)b];
+                    }
+                    int at = b * bin;
+                    for (int k : member[(size_t)b]) { pos[(size_t)k] = at; at += cwx[(size_t)k]; }
+                }
+                for (int k = 0; k < n_work; ++k) { tau_plain = std::max(tau_plain, t_of(k, cw[(size_t)k])); tau_xl = std::max(tau_xl, t_of(k, cwx[(size_t)k])); }
+                if (tau_xl > 1.04 * tau_plain) fits = false;
+            }
             if (fits) {
                 for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = pos[(size_t)k]; work[(size_t)k].w = cwx[(size_t)k]; }
                 std::sort(work.begin(), work.end(), [](const int4 &x, const int4 &y) { return x.z < y.z; });   // (the kernel searches by first workgroup)
@@ -1496,7 +1513,10 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
         HIPCHK(hipEventRecord(e0, st));
-        if (d->C.lazy) { if (ne3) hipLaunchKernelGGL((k_search<3, false, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, true>), dim3(grid), dim3(SNT), 0, st, A); }
+        if (d->C.lazy) {   // (the graph's own words are agent scope in either flavour: jd_lazy.h)
+            if (ne3) { if (xl) hipLaunchKernelGGL((k_search<3, true, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<3, false, true>), dim3(grid), dim3(SNT), 0, st, A); }
+            else { if (xl) hipLaunchKernelGGL((k_search<6, true, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, true>), dim3(grid), dim3(SNT), 0, st, A); }
+        }
         else if (ne3) { if (xl) hipLaunchKernelGGL((k_search<3, true, false>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<3, false, false>), dim3(grid), dim3(SNT), 0, st, A); }
         else { if (xl) hipLaunchKernelGGL((k_search<6, true, false>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, false>), dim3(grid), dim3(SNT), 0, st, A); }
         HIPCHK(hipEventRecord(e1, st));
