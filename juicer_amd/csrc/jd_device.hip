@@ -688,8 +688,8 @@ __global__ void jd_set_T_kernel(StreamCtl *ctl, int s0, int n, const int *T)
 __global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int *status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { StreamCtl &c = ctl[work[i].x]; c.bar = 0u; c.xbar = 0u; c.xmask = 0u; }
-    if (i == 0) { status[0] = 0; status[1] = 0; }
+    if (i < n) { StreamCtl &c = ctl[work[i].x]; c.bar = 0u; c.xbar = 0u; c.xmask = 0u; c.stop_req = 0; }
+    if (i == 0) { status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0; }
 }
 
 // --------------------------------------------------------------- host runtime
@@ -855,6 +855,9 @@ struct jd_dec {
     // search launches: one 512-thread workgroup per CU, a cluster of them per stream
     int max_cw = MAXCW;                   // upper bound of workgroups per stream cluster (JD_CW overrides)
     int weighted = 1;                     // size the clusters by the work ahead of each stream (JD_WEIGHTED=0: uniform)
+    int rebalance = 1;                    // cut a launch short and plan the rest anew when part of the grid idles (JD_REBALANCE=0: off)
+    double rebalance_frac = 0.2;          // ... this part (JD_REBALANCE_FRAC)
+    double rebalance_min_us = 4000.0;     // ... and only launches predicted to last this long (JD_REBALANCE_MIN_US; 0 in tests)
     double model_a_us = 10.0, model_b_us = 360.0;   // cost model of a stream-frame: a + b / workgroups (launch_search)
     // b was fitted at configs[1]'s load (23.7 k instances + arcs per stream-frame); it scales with the load,
     // which a decoder learns from the batches it has decoded (first batch: as fitted)
@@ -1044,6 +1047,9 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     }
     if (const char *e = getenv("JD_CW")) { const int v = atoi(e); if (v >= 1 && v <= MAXCW) d->max_cw = v; }   // development
     if (const char *e = getenv("JD_WEIGHTED")) d->weighted = atoi(e) != 0;
+    if (const char *e = getenv("JD_REBALANCE")) d->rebalance = atoi(e) != 0;
+    if (const char *e = getenv("JD_REBALANCE_FRAC")) { const double v = atof(e); if (v > 0.0 && v < 1.0) d->rebalance_frac = v; }
+    if (const char *e = getenv("JD_REBALANCE_MIN_US")) d->rebalance_min_us = atof(e);
     if (const char *e = getenv("JD_MODEL_A")) d->model_a_us = atof(e);
     if (const char *e = getenv("JD_MODEL_B")) d->model_b_us = atof(e);
     if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0;                      // development
@@ -1204,9 +1210,9 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
     if (rc) return rc;
     rc = dmalloc(d, &d->d_ctl, (size_t)B);
     if (rc) return rc;
-    rc = dmalloc(d, &d->d_status, 2);
+    rc = dmalloc(d, &d->d_status, 4);
     if (rc) return rc;
-    HIPCHK(hipHostMalloc((void **)&d->h_status, 2 * sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&d->h_status, 4 * sizeof(int)));
     {
         std::vector<StreamCtl> hc((size_t)B);
         memset(hc.data(), 0, hc.size() * sizeof(StreamCtl));
@@ -1409,6 +1415,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     for (int k = 0; k < n_work; ++k) work[(size_t)k] = make_int4(work_in[(size_t)k].x, work_in[(size_t)k].y, k * A.Cw, A.Cw);
     int grid = A.n_slots * A.Cw;
     bool xl = false;
+    int rebalance_at = 0;
     if (weight && d->weighted && n_work > 1 && max_cw > 1 && nwg >= 2 * n_work) {
         // Weighted mode.  weight[k] = frames stream k has in this launch.  A stream's frame costs about
         // a + b / workgroups  (a: the barriers and list set-up of a frame; b: the part that divides over
@@ -1504,10 +1511,19 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             grid = first;
         }
         A.n_slots = 0;
+        // Re-planning under way (SearchArgs::rebalance_at): the plan above makes the streams finish together only as
+        // far as frames predict work; when a fifth of the grid has run out of work the launch is cut short and the
+        // rest planned anew - worth it while the rest is long against the ~0.2 ms a relaunch costs.
+        rebalance_at = 0;
+        if (d->rebalance && n_work >= 4) {
+            double tau = 0.0;
+            for (int k = 0; k < n_work; ++k) tau = std::max(tau, std::max((*weight)[(size_t)k], 1.0) * (a_us + b_us / std::max(work[(size_t)k].w, 1)));
+            if (tau > d->rebalance_min_us) rebalance_at = std::max(1, (int)(d->rebalance_frac * grid));
+        }
     } else if (d->xl_ok && A.Cw > 1 && (grid & 7) == 0 && ((grid >> 3) % A.Cw) == 0) xl = true;   // uniform clusters that tile the eighths
     HIPCHK(hipMemcpyAsync(d->d_work, work.data(), (size_t)n_work * sizeof(int4), hipMemcpyHostToDevice, st));
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
-    A.status = d->d_status; A.dbg = d->d_dbg;
+    A.status = d->d_status; A.dbg = d->d_dbg; A.rebalance_at = rebalance_at;
     A.xl_selftest = getenv("JD_XL_SELFTEST") ? 1 : 0;                 // (test knob, see SearchArgs)
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1521,7 +1537,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         else { if (xl) hipLaunchKernelGGL((k_search<6, true, false>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, false>), dim3(grid), dim3(SNT), 0, st, A); }
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) d->timing.search_ms += ms;
@@ -1530,6 +1546,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             for (const int4 &w : work) { cmin = std::min(cmin, w.w); cmax = std::max(cmax, w.w); }
             fprintf(stderr, "k_search: %d streams, grid %d (clusters %d..%d workgroups, %s%s), frames [%d, %d): %.3f ms\n", n_work, grid,
                     cmin, cmax, A.n_slots ? "uniform" : "weighted", xl ? ", XCD-local" : "", f0, f_end, ms);
+            if (d->h_status[3]) fprintf(stderr, "          cut short for a re-plan: %d streams go on\n", d->h_status[0]);
         }
         if (d->h_status[1] != 0) {
             // a cluster of an XCD-local launch found itself on several XCDs and left its stream untouched: from
@@ -1546,8 +1563,10 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // Some streams stopped for a collection of their Path records (k_gc_*: no-ops for the streams below
         // their mark): the launch is repeated for the streams that are not through, with clusters sized for
         // what each of them still has ahead.
-        launch_gc(d->C, d->d_ctl, d->d_streams, d->d_work, n_work, 0, ne3, d->n_cus, st);
-        HIPCHK(hipGetLastError());
+        if (d->h_status[0] > d->h_status[3]) {                             // (not when every stop was for a re-plan)
+            launch_gc(d->C, d->d_ctl, d->d_streams, d->d_work, n_work, 0, ne3, d->n_cus, st);
+            HIPCHK(hipGetLastError());
+        }
         // A stream that stopped for a collection after n frames will, by and large, stop again after as many
         // (its records per frame change slowly): what it has ahead IN THE NEXT LAUNCH is the smaller of that
         // and the frames it has left - sized by that, the streams stop together instead of idling.
@@ -1562,7 +1581,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             const int end = std::min(h[1], f_end), left = end - h[0];
             const int done = h[0] - frame_before[(size_t)w.x];
             frame_before[(size_t)w.x] = h[0];
-            if (left > 0 && h[2] == 0) { rest.push_back(w); weight_now.push_back((double)((done > 0) ? std::min(left, done) : left)); }
+            // (a launch cut short for a re-plan says nothing about when a stream's arena fills up: then the frames left count)
+            if (left > 0 && h[2] == 0) { rest.push_back(w); weight_now.push_back((double)((done > 0 && d->h_status[3] == 0) ? std::min(left, done) : left)); }
         }
         if (rest.empty()) break;
         work_in.swap(rest);

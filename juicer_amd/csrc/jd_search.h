@@ -107,6 +107,7 @@ struct __align__(128) StreamCtl {
     __align__(128) int n_paths;              // Path records in use
     __align__(128) unsigned long long final_key;
     __align__(128) int err[2];               // first error raised during a frame of that parity
+    int stop_req;                            // (same line) the cluster is to stop after this frame: the launch is being re-planned
     __align__(128) long long st[ST_N];       // statistics (WFSTDecoderLite.cpp:231-241 + build counters)
     __align__(128) Tok best_final;           // bestFinalToken of the last processed frame
 };
@@ -148,8 +149,11 @@ struct SearchArgs {
     int f_end;               // process frames < min(T, f_end)
     int xl_selftest;         // test knob: an XCD-local launch numbers its workgroups in dispatch order, which puts every
                              // cluster on several XCDs - the placement check has to catch it
-    int *status;             // [0] += 1 for every stream that stopped early (Path garbage collection needed);
-                             // [1] += 1 for every cluster of an XCD-local launch that found itself on several XCDs
+    int rebalance_at;        // weighted mode: when this many workgroups of the grid have nothing left to do (their stream is
+                             // through, or stopped), every cluster stops after its frame and the host plans the rest anew (0: never)
+    int *status;             // [0] += 1 for every stream that stopped early (Path garbage collection, or a re-plan);
+                             // [1] += 1 for every cluster of an XCD-local launch that found itself on several XCDs;
+                             // [2] += the workgroups of every cluster that has left its stream; [3] += 1 per stream stopped for a re-plan
     long long *dbg;          // optional: per-workgroup cycle accounting (jd_dec_debug_trace)
 };
 
@@ -1189,13 +1193,14 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     // recognitionStart part 2: the expansion of the start token, a frame without phase A that
     // uses item / key parity 1 like a frame "-1")
     int np_seen = 0;                                                   // Path records in use, as of the last frame end
+    bool stop_seen = false;                                            // the host wants to re-plan the launch (SearchArgs::rebalance_at)
     while (!aborted && !failed) {
         const bool init = init_pending;
         if (!init && f >= f_stop) break;
         const int p = init ? 1 : (f & 1);
         // stop early when the Path arena needs collecting (k_gc_* run between launches); n_paths only
         // changes in phase X, so every workgroup of the cluster reads the same value here
-        if (!init && frames_done > 0 && np_seen > C.gc_threshold) break;
+        if (!init && frames_done > 0 && (np_seen > C.gc_threshold || stop_seen)) break;
         long long t0 = 0;
         const bool clk_on = A.dbg != nullptr && tid == 0;
 #define CLK(slot) do { if (clk_on) { const long long tn_ = wall_clock64(); sh.clk[slot] += tn_ - t0; t0 = tn_; } } while (0)
@@ -1252,7 +1257,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         // round trip, not one each.)
         float bestA = LZ, endTh = LZ, wordTh = LZ;
         unsigned bx_raw = 0u;
-        int err_raw = 0, np_raw = 0;
+        int err_raw = 0, np_raw = 0, stop_raw = 0;
         const bool last_frame = !init && f >= T - 1;
         XOut xo = {exit_cnt, 0, 0, 0};
         for (int round = 0;; ++round) {
@@ -1269,7 +1274,12 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 build_lists<1>(sh, src, gin.nw, Q1, n1);
                 if (jw == 0 && !init) {                                // housekeeping for the frame after this one (stores:
                     // after the list's loads, so that nothing waits for their acknowledgement)
-                    if (tid == 0) { CS(&c.bestA[p ^ 1], 0u); CS(&c.bestX[p ^ 1], 0u); CS(&c.new_all[p ^ 1], 0); }
+                    if (tid == 0) {
+                        CS(&c.bestA[p ^ 1], 0u); CS(&c.bestX[p ^ 1], 0u); CS(&c.new_all[p ^ 1], 0);
+                        // enough of the grid idles: this cluster stops after this frame (every workgroup of it reads the
+                        // request behind this round's barrier, i.e. in the same frame)
+                        if (A.rebalance_at > 0 && CL(A.status + 2) >= A.rebalance_at) CS(&c.stop_req, 1);
+                    }
                     if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) CS(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b, 0);
                 }
                 ba = (unsigned)RFL((int)ba_raw);
@@ -1278,6 +1288,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 wordTh = (!init && C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;  // :350
             } else {
                 bx_raw = CL(&c.bestX[p]); err_raw = CL(&c.err[p]); np_raw = CL(&c.n_paths);   // final if this round has nothing to do
+                stop_raw = CL(&c.stop_req);
                 if (tid < gin.nw) sh.start[tid] = CL(tot_of(TOT_CLS0 + (round & 1)) + tid);
                 const ListSrc src[1] = {{tot_of(TOT_CL0 + (round & 1)), KX, gin.seg_item}};
                 build_lists<1>(sh, src, gin.nw, Q1, n1);
@@ -1337,6 +1348,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const unsigned bb = ba > bx ? ba : bx;
             best_emit = bb ? o2f(bb) : LZ;                             // :417-418, :572-573
             np_seen = RFL(np_raw);                                     // (n_paths only changes in phase X)
+            stop_seen = RFL(stop_raw) != 0;
         }
         if (tid == 0)                                                  // totalActiveModels starts with frame 0 (:981)
             for (int k = 0; k < ST_N; ++k) { if (!init || k != ST_MODELS) sh.acc[k] += sh.stat[k]; sh.stat[k] = 0; }
@@ -1379,7 +1391,11 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const int e0 = CL(&c.err[0]), e1 = CL(&c.err[1]);
             c.frame = f; c.best_emit = best_emit; c.lst_nw = NW; c.needs_init = 0;
             if (e0 | e1) c.error = e0 ? e0 : e1;
-            else if (f < f_stop) atomicAdd(A.status, 1);               // stopped early: collect Path records, then go on
+            else if (f < f_stop) {                                     // stopped early: collect Path records / re-plan, then go on
+                atomicAdd(A.status, 1);
+                if (stop_seen) atomicAdd(A.status + 3, 1);
+            }
+            if (A.n_slots == 0) atomicAdd(A.status + 2, Cw);           // this cluster's workgroups have nothing left to do in this launch
         }
     }
 }

@@ -851,6 +851,42 @@ def test_xcd_local_launch_and_its_fallback(small, capfd):
             assert "not on one XCD" in err, err[-600:]
 
 
+def test_launch_is_replanned_under_way(small, capfd):
+    """When part of the grid has run out of work a launch is cut short and the rest planned anew (SearchArgs::
+    rebalance_at).  Forced here at toy size - utterances of very different lengths, every launch eligible, a
+    twentieth of the grid as the mark: many short launches, also together with Path collections (small arena) -
+    the results are those of the oracle, bit for bit."""
+    import os
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0)
+    od = OracleDecoder(onet, oam, **kw)
+    batch = []
+    for i in range(12):                                 # lengths from one utterance to four in a row
+        batch.append(np.concatenate([feats[(i + j) % len(feats)] for j in range(1 + i % 4)]))
+    want = [od.decode_certified(x) for x in batch]
+    env = {"JD_VERBOSE": "1", "JD_REBALANCE_MIN_US": "0", "JD_REBALANCE_FRAC": "0.05"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for extra in (dict(), dict(max_paths=1 << 12)):
+            gd = capi.Decoder(gnet, gam, max_streams=12, **kw, **extra)
+            for rep in range(2):
+                gs = gd.decode_batch(batch)
+                for i, g in enumerate(gs):
+                    assert_hyp_matches(g, want[i], "re-plan %r rep %d utt %d" % (extra, rep, i))
+                    assert bit_exact(g, want[i])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    err = capfd.readouterr().err
+    assert err.count("cut short for a re-plan") >= 4, err[-600:]
+
+
 def test_hybrid_models(built):
     """Hybrid ANN / HMM scoring (HTKModels::Load(phones, priors, statesPerModel); calcOutput,
     HTKFlatModels.cpp:190-222): the feature vector is one log posterior per phone and the scoring kernel
