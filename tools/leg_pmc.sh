@@ -4,6 +4,7 @@
 set -u
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
+export JD_BENCH_NO_LAZY=1      # the clg leg: without its search-driven part
 LEG=${1:-north}
 OUT=gpurun_out/prof_$LEG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -26,7 +27,7 @@ for k, v in d.items():
 # tools/run_leg.py <leg> 2 = a warm-up pass and a timed pass of the same batch: HBM bytes of one pass, all k_search launches
 # ((2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE reports half of a wide read, MI355X_MICROARCH.md)
 out = {"leg": sys.argv[2], "passes": 2, "k_search_hbm_bytes_per_pass": (2.0 * tot_f + tot_w) * 1024.0 / 2.0,
-       "source": "tools/leg_pmc.sh: rocprofv3 --kernel-trace --pmc, FETCH_SIZE and WRITE_SIZE in separate runs"}
-json.dump(out, open(sys.argv[1] + "/leg_traffic.json", "w"))
+       "source": "tools/leg_pmc.sh: rocprofv3 --kernel-trace --pmc, FETCH_SIZE and WRITE_SIZE in separate runs of `python tools/run_leg.py %s 2`" % sys.argv[2]}
+json.dump(out, open(sys.argv[1] + "/leg_traffic.json", "w"), indent=1)
 print(out)
 PY
