@@ -17,9 +17,12 @@
 //                     was matched (and at the start): the only place a back-off may be taken, which
 //                     gives every path one canonical form (the epsilon-sequencing composition filter)
 //   back-off        if f = 1 and the first arc of g is an epsilon g -eps/b-> g":  (c,g,1) -eps:eps/b-> (c,g",1)
-//   C.L arc c -i:eps/w-> c'    gives (c,g,f) -i:eps/w-> (c',g,0), provided some word reachable from c'
-//                     before the next word label lies in [lo(c'), hi(c')] AND g has an arc for a label
-//                     in that interval (look-ahead: a superset test, it only ever drops dead ends)
+//   C.L arc c -i:eps/w-> c'    gives (c,g,f) -i:eps/w-> (c',g,0), provided g has an arc for a label in
+//                     [lo(c'), hi(c')], the interval of the first word labels reachable from c' through
+//                     label-less arcs - OR a final C.L state is reachable from c' that way and g is final
+//                     (the tail of the last word; the reference always follows the transitions before the
+//                     C.L final states, WFSTOnTheFlyDecoder.cpp:2665-2697).  A superset test: it only
+//                     ever drops dead ends
 //   C.L arc c -i:x/w->  c', x != eps, and an arc g -x:y/v-> g'   gives (c,g,f) -i:y/(w + v)-> (c',g',1)
 //   (c,g,f) is final iff c and g are: weight fin(c) + fin(g)
 //   pushing (the reference's -pushing, doLabelAndWeightPushing, juicer.cpp:240, 931-935; weights only): let
@@ -150,7 +153,10 @@ __device__ __forceinline__ float jc_potential(const ComposeArgs &A, int g, int l
 __device__ __forceinline__ int jc_arc_kind(const ComposeArgs &A, const JdArc &ca, int g, int *ga)
 {
     *ga = -1;
-    if (ca.out == 0) { const int2 la = A.cl_la[ca.to]; return jc_any_in(A, g, la.x, la.y) ? 1 : 0; }
+    if (ca.out == 0) {                                                 // (see LA_MAYFIN, jd_lazy.h)
+        const int2 la = A.cl_la[ca.to];
+        return (jc_any_in(A, g, la.x, la_hi(la)) || (la_mayfin(la) && A.g_fin[g] < std::numeric_limits<float>::infinity())) ? 1 : 0;
+    }
     *ga = jc_match(A, g, ca.out);
     return *ga >= 0;
 }
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256) void jc_expand(ComposeArgs A, int begin, int e
     const int a0 = A.cl_row[c], a1 = A.cl_row[c + 1];
     // pushing: what this state's incoming arcs have already paid of the word that is under way
     float p_src = 0.0f;
-    if (A.push && !flag) { const int2 la = A.cl_la[c]; p_src = jc_potential(A, g, la.x, la.y); }
+    if (A.push && !flag) { const int2 la = A.cl_la[c]; p_src = jc_potential(A, g, la.x, la_hi(la)); }
     // pass 1: how many arcs this state gets
     int mine = 0, ga;
     for (int a = a0 + lane; a < a1; a += 64) mine += jc_arc_kind(A, A.cl_arcs[a], g, &ga);
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void jc_expand(ComposeArgs A, int begin, int e
             const long long pos = run + pre - 1;
             if (ca.out == 0) {
                 float w = ca.w;
-                if (A.push) { const int2 la = A.cl_la[ca.to]; w = (ca.w + jc_potential(A, g, la.x, la.y)) - p_src; }
+                if (A.push) { const int2 la = A.cl_la[ca.to]; w = (ca.w + jc_potential(A, g, la.x, la_hi(la))) - p_src; }
                 A.arcs[pos] = JdArc{jc_state_id(A, (unsigned)ca.to, g), w, ca.in, 0};
             } else {
                 const JdArc m = A.g_arcs[ga];
@@ -300,19 +306,25 @@ static void cl_lookahead(const jd_net *cl, std::vector<int2> &la)
         }
     }
     // a FULL interval below spreads upwards only through the pass above if it was set before the parent
-    // finished; one more sweep makes every ancestor of a cycle state FULL as well
+    // finished; one more sweep makes every ancestor of a cycle state FULL as well.  The same sweep finds the
+    // states that reach a FINAL C.L state through label-less arcs (LA_MAYFIN, jd_lazy.h).
+    std::vector<char> mf((size_t)S, 0);
+    for (int c = 0; c < S; ++c) mf[(size_t)c] = cl->fin_w[(size_t)c] < std::numeric_limits<float>::infinity();
     bool changed = true;
     while (changed) {
         changed = false;
-        for (int c = 0; c < S; ++c)
+        for (int c = S - 1; c >= 0; --c)
             for (int a = cl->row_ptr[(size_t)c]; a < cl->row_ptr[(size_t)c + 1]; ++a) {
                 const JdArc &arc = cl->arcs[(size_t)a];
                 if (arc.out != 0) continue;
                 const int2 J = la[(size_t)arc.to];
                 int2 &I = la[(size_t)c];
                 if (J.x <= J.y && (J.x < I.x || J.y > I.y)) { I.x = std::min(I.x, J.x); I.y = std::max(I.y, J.y); changed = true; }
+                if (mf[(size_t)arc.to] && !mf[(size_t)c]) { mf[(size_t)c] = 1; changed = true; }
             }
     }
+    for (int c = 0; c < S; ++c)
+        if (mf[(size_t)c]) la[(size_t)c].y = (int)((unsigned)la[(size_t)c].y | LA_MAYFIN);
 }
 
 extern "C" int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t device, int64_t max_states, int64_t max_arcs,

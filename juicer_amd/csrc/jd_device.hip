@@ -940,6 +940,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (net->max_in > am->n_hmm)
         return jd_fail(JD_EINVAL, "network input label %d exceeds the number of HMMs %d", net->max_in, am->n_hmm);
     if (am->max_n > JD_MAXN) return jd_fail(JD_EINVAL, "HMMs with more than %d states unsupported", JD_MAXN);
+    if ((int64_t)net->n_states * (int64_t)sizeof(StateRec) > 0xf0000000LL)   // (32-bit byte offsets of the buffer descriptor)
+        return jd_fail(JD_EINVAL, "networks with more than %lld states unsupported", (long long)(0xf0000000LL / (int64_t)sizeof(StateRec)));
     int rc = check_device(device);
     if (rc) return rc;
     jd_dec *d = new jd_dec();
@@ -995,7 +997,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         se32[i] = ((int)am->se[i * 2] & 0xffff) | ((int)am->se[i * 2 + 1] << 16);
     TRY(dupload(d, &d->d_se32, se32.data(), se32.size()));
     TRY(upload_am_gmm(am, d->amb));
-    C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init;
+    C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init; C.n_states = net->n_states;
     C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
     C.hmm_tee = d->d_hmm_tee; C.n_hmm = am->n_hmm; C.hmm_tmax0 = d->d_hmm_tmax0;
     C.lazy = (const LazyDev *)net->lazy_dev; C.aux_h = nullptr;
@@ -1101,6 +1103,20 @@ extern "C" int jd_dec_set_max_alloc_models(jd_dec *d, int32_t max_alloc_models)
     return JD_OK;
 }
 
+// reset a stream's per-state records: no bids; the CSR row of the state (row_ptr == nullptr: a lazy graph, rows live elsewhere)
+__global__ void jd_reset_srec_kernel(StateRec *srec, const int *row_ptr, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int rs = row_ptr ? row_ptr[i] : 0, cnt = row_ptr ? row_ptr[i + 1] - rs : 0;
+        srec[i] = StateRec{0ULL, 0ULL, 0ULL, rs, cnt};
+    }
+}
+static void reset_srec(StateRec *srec, const int *d_row_ptr, int64_t n_states)
+{
+    hipLaunchKernelGGL(jd_reset_srec_kernel, dim3((unsigned)((n_states + 255) / 256)), dim3(256), 0, 0, srec, d_row_ptr, (long long)n_states);
+}
+
 // reset a stream's per-arc search state: no candidate, no instance
 __global__ void jd_reset_ast_kernel(ArcState *ast, long long n)
 {
@@ -1126,7 +1142,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const double n_arcs = (double)d->net->n_arcs, n_states = (double)d->net->n_states;
-        const double fixed = n_arcs * sizeof(ArcState) + n_states * 24.0 + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
+        const double fixed = n_arcs * sizeof(ArcState) + n_states * (double)sizeof(StateRec) + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
         const double budget = std::max(0.0, mem_fraction * (double)free_b / B - fixed);
         const double rec_b = 2.0 * rec_bytes, item_b = 2.0 * (sizeof(Tok) + sizeof(int4)) + 32.0;
         const double path_b = 2.0 * sizeof(PathRec) + 4.0;
@@ -1173,7 +1189,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
 #define ARENAS() do { \
         A(S.rec, 2 * d->cap_slots * (rec_bytes / 4)); \
         A(S.ast, d->net->n_arcs); \
-        A(S.skey[0], d->net->n_states); A(S.skey[1], d->net->n_states); A(S.skeyL, d->net->n_states); \
+        A(S.srec, d->net->n_states); \
         A(S.items, 4 * d->cap_items); \
         A(S.newl, d->cap_new); A(S.cleanl, d->cap_new); A(S.dirtyl, d->cap_new); \
         A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW); \
@@ -1195,10 +1211,8 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
 #undef A
         S.res_cap = d->res_cap;
         reset_ast(S.ast, d->net->n_arcs);
+        reset_srec(S.srec, d->d_row_ptr, d->net->n_states);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(S.skeyL, 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
         HIPCHK(hipMemset(S.hist, 0, 2 * HIST_MAX_BINS * sizeof(int)));
         HIPCHK(hipMemset(S.tot, 0, TOT_N * MAXW * sizeof(int)));
         HIPCHK(hipMemset(S.item_end, 0, MAXW * sizeof(int)));
@@ -1321,10 +1335,8 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
         }
         if (K.error) {      // arenas may be inconsistent after an abort: wipe them for the next init
             reset_ast(S.ast, d->net->n_arcs);
+            reset_srec(S.srec, d->d_row_ptr, d->net->n_states);
             HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipMemset(S.skey[0], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
-            HIPCHK(hipMemset(S.skey[1], 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
-            HIPCHK(hipMemset(S.skeyL, 0, (size_t)d->net->n_states * sizeof(unsigned long long)));
             HIPCHK(hipMemset(S.tot, 0, TOT_N * MAXW * sizeof(int)));
             HIPCHK(hipMemset(S.item_end, 0, MAXW * sizeof(int)));
             HIPCHK(hipMemset(S.hist, 0, 2 * HIST_MAX_BINS * sizeof(int)));

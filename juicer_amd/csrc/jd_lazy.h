@@ -34,6 +34,15 @@ enum { LZ_UNKNOWN = 0, LZ_EXPANDING = 1, LZ_EXPANDED = 2, LZ_CLOSED = 3 };
 #define LZ_FLAG 0x80000000u          // the composition filter's flag, in the top bit of the stored C.L state
 #define LZQ 128                      // depth of a wave's stack when it closes a state (lz_close; at most 128: two ballots look through it)
 
+// Look-ahead entry of a C.L state (jd_compose.hip, cl_lookahead): {lo, hi | MAYFIN}.  [lo, hi] bounds the first word
+// labels reachable through label-less arcs; MAYFIN (the sign bit of hi) says a FINAL C.L state is reachable that
+// way - the tail of the last word, `... -sil:eps-> final`: such arcs are followed whenever the G state is final,
+// whatever its arcs (the reference always follows the transitions before the C.L final states: they carry
+// NONPUSHING_OUTLABEL, WFSTOnTheFlyDecoder.cpp:2665-2697).
+#define LA_MAYFIN 0x80000000u
+__device__ __host__ __forceinline__ int la_hi(int2 la) { return (int)((unsigned)la.y & ~LA_MAYFIN); }
+__device__ __host__ __forceinline__ bool la_mayfin(int2 la) { return ((unsigned)la.y & LA_MAYFIN) != 0; }
+
 struct LazyDev {
     const int *cl_row; const JdArc *cl_arcs; const float *cl_fin; const int2 *cl_la;
     const int *g_row; const JdArc *g_arcs; const float *g_fin;
@@ -88,7 +97,7 @@ __device__ __forceinline__ float lz_paid(const LazyDev &L, unsigned cf, int g)
 {
     if (!L.push || (cf & LZ_FLAG)) return 0.0f;
     const int2 la = L.cl_la[cf];
-    return lz_potential(L, g, la.x, la.y);
+    return lz_potential(L, g, la.x, la_hi(la));
 }
 
 // id of the composed state (cf, g); the lane that creates it writes its row {0, 0, UNKNOWN, final weight}
@@ -152,7 +161,10 @@ __device__ __forceinline__ bool lz_any_in(const LazyDev &L, int g, int lo_l, int
 __device__ __forceinline__ int lz_arc_kind(const LazyDev &L, const JdArc &ca, int g, int *ga)
 {
     *ga = -1;
-    if (ca.out == 0) { const int2 la = L.cl_la[ca.to]; return lz_any_in(L, g, la.x, la.y) ? 1 : 0; }
+    if (ca.out == 0) {
+        const int2 la = L.cl_la[ca.to];
+        return (lz_any_in(L, g, la.x, la_hi(la)) || (la_mayfin(la) && L.g_fin[g] < __builtin_inff())) ? 1 : 0;
+    }
     *ga = lz_match(L, g, ca.out);
     return *ga >= 0;
 }
@@ -216,7 +228,7 @@ __device__ bool lz_expand(const LazyDev &L, const float *hmm_tee, int D)
             const int in = ca.in | (tee ? TEE_FLAG : 0);
             if (ca.out == 0) {
                 float w = ca.w;
-                if (L.push) { const int2 la = L.cl_la[ca.to]; w = (ca.w + lz_potential(L, g, la.x, la.y)) - p_src; }
+                if (L.push) { const int2 la = L.cl_la[ca.to]; w = (ca.w + lz_potential(L, g, la.x, la_hi(la))) - p_src; }
                 lz_store_arc(&L.arcs[pos], lz_state_id(L, (unsigned)ca.to, g), w, in, 0);
             } else {
                 const JdArc m = L.g_arcs[ga];

@@ -46,7 +46,7 @@ enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_LAZ
 
 struct DecConst {
     // network (CSR in HBM)
-    const int *row_ptr; const JdArc *arcs; const float *fin_w; int init_state;
+    const int *row_ptr; const JdArc *arcs; const float *fin_w; int init_state; int n_states;
     // models
     int G, max_n, n_tm;
     const float *hmm_tee; int n_hmm;
@@ -83,6 +83,15 @@ template <int NE> struct RecLayout {
 };
 #define OOB_OFF 0xf0000000u          // byte offset beyond every arena: buffer loads return 0, stores are dropped
 
+// per-state search state, ONE 32-byte record (half a 64-byte sector) so that everything an exit token or a
+// closure item needs of its state arrives with one memory transaction: the three recombination keys and the
+// state's CSR row.  (Round 2 kept them in four arrays: three sectors fetched, two written back, per token.)
+//   key0  best exit token arriving at the state this frame (bid in phase A, reset by its winner in phase X)
+//   keyL  ... among the tokens whose arc carries a word label (own threshold, :952-962)
+//   keyC  best closure item so far (running maximum, zeroed through the dirty list)
+//   rs, cnt  first out-arc and out-degree (a per-stream copy of row_ptr; unused on lazy graphs, whose rows grow)
+struct __align__(32) StateRec { unsigned long long key0, keyL, keyC; int rs, cnt; };
+
 // per-arc search state: recombination key of this frame + "an instance of this arc is in the list"
 //   live: 0 = no instance, 1 = an instance of this arc is in the list, 2 = no instance yet but the arc
 //         is on the new list of this frame (it will be tried in the next phase A)
@@ -115,15 +124,13 @@ struct __align__(128) StreamCtl {
 struct StreamDev {      // per-stream arenas
     int *rec;                         // instance records, [2][cap_slots] by frame parity: list f&1 is read by frame f
     ArcState *ast;                    // per ARC
-    unsigned long long *skey[2];      // per STATE: [0] best exit token arriving there (reset by its winner),
-                                      // [1] best closure item so far (running maximum, zeroed through the dirty list)
-    unsigned long long *skeyL;        // exit tokens whose arc carries a word label (own threshold)
+    StateRec *srec;                   // per STATE: recombination keys + the CSR row (see StateRec)
     int4 *items;                      // frontier items of a frame, [2][cap_items] by frame parity: 32 bytes each,
                                       // token + {arc, out, to, flag}; flag 1 = a closure item that needs no
                                       // expansion in a later round (done by its producer, or superseded)
     int *newl;                        // arcs entered this frame that have no instance and may survive the next frame
     int *cleanl;                      // arcs entered this frame whose first candidate was hopeless (key clean-up, see phase X)
-    int *dirtyl;                      // states whose closure key (skey[1]) became non-zero this frame
+    int *dirtyl;                      // states whose closure key (StateRec::keyC) became non-zero this frame
     int *tot;                         // published per-wave fill counts, TOT_N arrays of MAXW
     int *item_end;                    // per wave: items written in the last processed frame (k_gc_*)
     PathRec *paths; int *hist;        // hist: [2][HIST_MAX_BINS] by frame parity
@@ -240,6 +247,7 @@ struct SearchShared {
     float tee[TEE_LDS_MAX];                    // tee transition log-probability per HMM (when they fit)
     int wpfx[SW][64];                          // phase X: per wave, prefix of the out-degrees of its 64 items
     v4i qtok[SW][QCAP], qinfo[SW][QCAP];       // phase X: per wave, closure items it will expand itself
+    int2 qrow[SW][QCAP];                       // ... and the CSR rows of their states (they came with the closure key)
     int wsum[NLISTS][SW], wsum2[NLISTS][SW];
     int next;                                  // next chunk (of this workgroup's share) to hand to a wave
     unsigned best;
@@ -408,7 +416,8 @@ struct StreamView {     // wave-uniform descriptors of one stream's arenas
     __amdgpu_buffer_rsrc_t rec, items;          // both frame parities in one descriptor each
     unsigned rec_par, item_par;                 // byte offset of parity 1 in them
     __amdgpu_buffer_rsrc_t lrows, larcs;        // lazy graphs: the rows and the arc arena (read with `sc1` loads)
-    ArcState *ast; unsigned long long *skey0, *skeyC, *skeyL; int *newl, *cleanl, *dirtyl; int *tot; PathRec *paths; int *hist;
+    __amdgpu_buffer_rsrc_t srec_r;              // the per-state records, for 16-byte loads
+    ArcState *ast; StateRec *srec; int *newl, *cleanl, *dirtyl; int *tot; PathRec *paths; int *hist;
 };
 
 // byte offset of chunk ci of wave segment w in a record list (parity offset added by the caller)
@@ -692,7 +701,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 const unsigned ioff = has_exit ? icur + k * 32u : OOB_OFF;
                 st16(V.items, ioff, as_v4(ex));
                 st16(V.items, ioff + 16u, (v4i){arc, h0.z, h0.w, 0});
-                if (has_exit) GMAX((h0.z != 0 ? V.skeyL : V.skey0) + h0.w, ((unsigned long long)f2o(ex.score) << 32) | k);
+                if (has_exit) GMAX((h0.z != 0 ? &V.srec[h0.w].keyL : &V.srec[h0.w].key0), ((unsigned long long)f2o(ex.score) << 32) | k);
                 exit_cnt += nex;
                 c_end += nex;
             }
@@ -718,7 +727,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         const int ci = ru - RFL(sh.pfx[k][w]);
         if (ci * 64 + lane < RFL(sh.cnt[k][w])) {
             const int b = CL((k == 3 ? V.dirtyl : V.cleanl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
-            if (k == 3) CS(V.skeyC + b, 0ULL);
+            if (k == 3) CS(&V.srec[b].keyC, 0ULL);
             else if (CL(&V.ast[b].live) != 2) CS(&V.ast[b].key, 0ULL);
         }
     }
@@ -776,6 +785,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
     const unsigned item_base = (unsigned)gw * gout.seg_item, new_base = (unsigned)gw * gout.seg_new;
     int *wpfx = sh.wpfx[wid];
     v4i *qtok = sh.qtok[wid], *qinfo = sh.qinfo[wid];
+    int2 *qrow = sh.qrow[wid];
     int q_n = 0;                                                       // closure items waiting in this wave's queue
     int c_arcs = 0, c_paths = 0, c_pend = 0, c_new = 0;
     unsigned mo = 0u;
@@ -789,11 +799,14 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         Tok t;
         v4i info;
         int slice_no = 0;                                              // > 0: this item is a slice of a state with many arcs
-        if (q_n > 0) {
+        const bool from_q = q_n > 0;                                   // (wave-uniform)
+        int2 row_q = make_int2(0, 0);
+        if (from_q) {
             valid = lane < q_n;
             exit_kind = false;
             t = as_tok(qtok[lane & (QCAP - 1)]);
             info = qinfo[lane & (QCAP - 1)];
+            row_q = qrow[lane & (QCAP - 1)];
             ii = (unsigned)info.w;                                     // (the queue keeps the item's index here)
             q_n = 0;
         } else {
@@ -814,17 +827,28 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
         const bool real = valid && info.x >= 0 && slice_no == 0;       // an item that traversed an arc (a slice has been through all this)
         const int state = !valid ? 0 : (info.x >= 0) ? info.z : C.init_state;
-        // second level, in flight together: CSR row bounds, the state's key, the Path reservation
+        // second level, in flight together: the state's record (its key and its CSR row: one 64-byte sector), the
+        // Path reservation.  A closure item this wave queued for itself brought its row along - the record was read
+        // when its key was bid for - and has just been found the best arrival at its state: it needs no load at all.
         int rs, rs1;
         float fin_lazy = 0.0f;
-        if (LZY) {                                                     // {first arc, arcs, status, final weight}: ready by the invariant
-            const v4i r = ld16(V.lrows, (unsigned)state * 16u);
-            rs = r.x; rs1 = r.x + r.y; fin_lazy = __int_as_float(r.w);
-            if (valid && r.z < LZ_EXPANDED) CS(&c.err[p], (int)JDE_LAZY_INV);   // (cannot happen: the invariant of jd_lazy.h)
-        } else { rs = C.row_ptr[state]; rs1 = C.row_ptr[state + 1]; }
-        unsigned long long *sk = (!exit_kind ? V.skeyC : (info.y != 0) ? V.skeyL : V.skey0) + state;
+        unsigned long long *sk = (!exit_kind ? &V.srec[state].keyC : (info.y != 0) ? &V.srec[state].keyL : &V.srec[state].key0);
         unsigned long long kv = 0ULL;
-        if (real) kv = CL(sk);
+        const bool carried = !LZY && from_q;                           // (wave-uniform)
+        if (carried) { rs = row_q.x; rs1 = row_q.x + row_q.y; }
+        else {
+            const unsigned soff = real || (valid && !LZY) ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
+            v4i slo = {0, 0, 0, 0};
+            if (exit_kind) slo = ld16(V.srec_r, soff);                 // {key0, keyL}
+            const v4i shi = ld16(V.srec_r, soff + 16u);                // {keyC, first arc, arcs}
+            if (LZY) {                                                 // {first arc, arcs, status, final weight}: ready by the invariant
+                const v4i r = ld16(V.lrows, (unsigned)state * 16u);
+                rs = r.x; rs1 = r.x + r.y; fin_lazy = __int_as_float(r.w);
+                if (valid && r.z < LZ_EXPANDED) CS(&c.err[p], (int)JDE_LAZY_INV);   // (cannot happen: the invariant of jd_lazy.h)
+            } else { rs = shi.z; rs1 = shi.z + shi.w; }
+            const int klo = !exit_kind ? shi.x : (info.y != 0) ? slo.z : slo.x, khi = !exit_kind ? shi.y : (info.y != 0) ? slo.w : slo.y;
+            if (real) kv = ((unsigned long long)(unsigned)khi << 32) | (unsigned)klo;
+        }
         bool have = valid;
         if (real && exit_kind && !init) {                              // :952-962
             have = t.score > ((info.y != 0) ? wordTh : endTh);
@@ -842,7 +866,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         }
         XFINE(1);                                                      // hop 2: row bounds, state key, Path reservation
         if (real) {
-            const bool winner = (unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL;
+            const bool winner = carried || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
             // every state that received exit-token bids is cleaned up by its winner, expanded or not (an
             // item below its threshold still holds the key of its state if it was the best one there)
             if (winner && exit_kind) CS(sk, 0ULL);
@@ -955,7 +979,12 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 old = GMAX(&as->key, ((unsigned long long)so << 32) | iig);
                 if (can_filter) tmax = C.hmm_tmax0[inl - 1];
             }
-            if ((on && inl == 0) || is_tee) skc = CL(V.skeyC + Bk.to);
+            int2 nrow = make_int2(0, 0);                               // the destination's CSR row comes with its closure key
+            {
+                const v4i shi = ld16(V.srec_r, ((on && inl == 0) || is_tee) ? (unsigned)Bk.to * (unsigned)sizeof(StateRec) + 16u : OOB_OFF);
+                skc = ((unsigned long long)(unsigned)shi.y << 32) | (unsigned)shi.x;
+                nrow = make_int2(shi.z, shi.w);
+            }
             if (on) ++c_arcs;
             if (on && inl == 0) {                                      // :533-540 epsilon input
                 un = tg;
@@ -1010,7 +1039,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                     bool keep = false, first = false;
                     if (pass) {
                         const unsigned long long key = ((unsigned long long)sou << 32) | k;
-                        const unsigned long long cold = GMAX(V.skeyC + Bk.to, key);
+                        const unsigned long long cold = GMAX(&V.srec[Bk.to].keyC, key);
                         keep = key > cold; first = cold == 0ULL;
                     }
                     const unsigned long long bk = __ballot(keep), bf = __ballot(first);
@@ -1022,7 +1051,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                     }
                     if (inq) {
                         const int qi = q_n + rank_in(bk);
-                        qtok[qi] = as_v4(un); qinfo[qi] = (v4i){b, Bk.out, Bk.to, (int)k};
+                        qtok[qi] = as_v4(un); qinfo[qi] = (v4i){b, Bk.out, Bk.to, (int)k}; qrow[qi] = nrow;
                     }
                     const int nk = __popcll(bk);
                     const int n_inq = nk < room ? nk : room;
@@ -1080,7 +1109,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     V.rec = mk_rsrc(S.rec, 2ULL * C.cap_slots * RL::REC_BYTES);
     V.items = mk_rsrc(S.items, 2ULL * C.cap_items * 32u);
     V.rec_par = C.cap_slots * (unsigned)RL::REC_BYTES; V.item_par = C.cap_items * 32u;
-    V.ast = S.ast; V.skey0 = S.skey[0]; V.skeyC = S.skey[1]; V.skeyL = S.skeyL;
+    V.ast = S.ast; V.srec = S.srec;
+    V.srec_r = mk_rsrc(S.srec, (unsigned long long)C.n_states * sizeof(StateRec));
     V.newl = S.newl; V.cleanl = S.cleanl; V.dirtyl = S.dirtyl;
     V.tot = S.tot; V.paths = S.paths; V.hist = S.hist;
     if (LZY) {
@@ -1159,7 +1189,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 int b;
                 if (kind == 0) b = ld16(V.rec, (p0 ? V.rec_par : 0u) + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u).x;
                 else b = CL((kind == 1 ? V.newl : kind == 2 ? V.cleanl : V.dirtyl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
-                if (kind == 3) CS(V.skeyC + b, 0ULL);
+                if (kind == 3) CS(&V.srec[b].keyC, 0ULL);
                 else { CS(&V.ast[b].key, 0ULL); CS(&V.ast[b].live, 0); }
             }
         }

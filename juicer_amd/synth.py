@@ -327,7 +327,7 @@ def make_wfst(seed: int, am: SynthAM, n_words: int, n_succ: int,
 
 
 def make_cl_g(seed: int, am: SynthAM, n_words: int, n_succ: int, n_tri: int = 0, n_succ3: int = 3,
-              pron_len=(2, 5), with_sp: bool = False, n_phones: int = 40):
+              pron_len=(2, 5), with_sp: bool = False, n_phones: int = 40, terminal: bool = False):
     """SEPARATE C.L and G (BASELINE.json configs[4], the inputs of jd_net_compose), returned as two
     SynthNet objects (cl, g) in FSM file form.
 
@@ -339,7 +339,12 @@ def make_cl_g(seed: int, am: SynthAM, n_words: int, n_succ: int, n_tri: int = 0,
     G: back-off n-gram acceptor.  State 0 = <s> (initial), 1..V = one-word histories (final), V+1 =
     unigram state, then n_tri two-word histories (u,v) (final).  A history has arcs for its successor
     words and an epsilon arc (the back-off) to the next shorter history; the unigram state has an arc
-    for every word.  Arcs are written in random order (a loader has to sort them)."""
+    for every word.  Arcs are written in random order (a loader has to sort them).
+
+    terminal=True: sentences END.  C.L gets a word `</s>` (label V+1, index V in prons) whose last model
+    is a label-less tail arc into a terminal final state (no arcs out; the root is then not final), and G
+    gets a terminal final state reached by `</s>` from every history and the unigram state (the histories
+    are then not final): the shape `... -sil:eps-> final` / terminal `</s>` of real decoding graphs."""
     rng = np.random.default_rng(seed)
     V, K = n_words, min(n_succ, n_words)
     n_real_hmm = am.n_hmm - (1 if am.sp_hmm >= 0 else 0)
@@ -371,10 +376,18 @@ def make_cl_g(seed: int, am: SynthAM, n_words: int, n_succ: int, n_tri: int = 0,
                 nxt += 1
             nd = children[key]
         src.append(nd); dst.append(back); il.append(pr[-1] + 1); ol.append(w + 1); wf.append(float(rng.uniform(0.0, 1.0)))
+    cl_final = 0
+    if terminal:                                        # root -m0:</s>-> x -m1:eps-> F (terminal, final)
+        m0, m1 = int(rng.integers(0, P)), int(P + rng.integers(0, n_real_hmm - P))
+        src.append(0); dst.append(nxt); il.append(m0 + 1); ol.append(V + 1); wf.append(float(rng.uniform(0.0, 1.0)))
+        src.append(nxt); dst.append(nxt + 1); il.append(m1 + 1); ol.append(0); wf.append(0.0)
+        cl_final = nxt + 1
+        nxt += 2
+        prons = prons + [(m0, m1)]
     order = np.argsort(np.asarray(src), kind="stable")
     A = lambda x, dt: np.asarray(x, dtype=dt)[order]
     cl = SynthNet(n_states=nxt, src=A(src, np.int32), dst=A(dst, np.int32), ilab=A(il, np.int32), olab=A(ol, np.int32),
-                  w_file=A(wf, np.float32), fstate=np.asarray([0], np.int32), fweight_file=np.asarray([0.0], np.float32),
+                  w_file=A(wf, np.float32), fstate=np.asarray([cl_final], np.int32), fweight_file=np.asarray([0.0], np.float32),
                   n_words=V, prons=[np.asarray(p, np.int32) for p in prons], sp_hmm=am.sp_hmm if use_sp else -1)
     # ---- G
     succ = np.zeros((V + 1, K), dtype=np.int32)
@@ -401,10 +414,16 @@ def make_cl_g(seed: int, am: SynthAM, n_words: int, n_succ: int, n_tri: int = 0,
             w = int(w)
             arc(st, tri.get((v, w), 1 + w), w + 1, float(rng.uniform(0.3, 5.0)))
         arc(st, 1 + v, 0, float(rng.uniform(0.5, 3.0)))
+    n_g = V + 2 + len(tri)
+    fstate = np.concatenate([np.arange(1, V + 1), np.arange(V + 2, V + 2 + len(tri))]).astype(np.int32)
+    if terminal:                                        # every history -</s>-> the terminal state, the only final one
+        for h in list(range(1, V + 2)) + sorted(tri.values()):
+            arc(h, n_g, V + 1, float(rng.uniform(0.5, 4.0)))
+        fstate = np.asarray([n_g], np.int32)
+        n_g += 1
     perm = rng.permutation(len(src))                    # file order: shuffled, then grouped by state
     order = perm[np.argsort(np.asarray(src)[perm], kind="stable")]
-    fstate = np.concatenate([np.arange(1, V + 1), np.arange(V + 2, V + 2 + len(tri))]).astype(np.int32)
-    g = SynthNet(n_states=V + 2 + len(tri), src=A(src, np.int32), dst=A(dst, np.int32), ilab=A(il, np.int32),
+    g = SynthNet(n_states=n_g, src=A(src, np.int32), dst=A(dst, np.int32), ilab=A(il, np.int32),
                  olab=A(ol, np.int32), w_file=A(wf, np.float32), fstate=fstate,
                  fweight_file=rng.uniform(0.0, 2.0, size=fstate.shape[0]).astype(np.float32),
                  n_words=V, prons=cl.prons, succ=succ, sp_hmm=cl.sp_hmm)
@@ -421,19 +440,23 @@ def make_wfst_sized(seed: int, am: SynthAM, target_arcs: int, n_words: int,
 
 
 def sample_utterance(seed: int, net: SynthNet, am: SynthAM, n_words: int,
-                     p_backoff: float = 0.2, noise: float = 1.0):
-    """Random accepted word sequence -> (features [T, D] float32, word labels)."""
+                     p_backoff: float = 0.2, noise: float = 1.0, end_word: int = -1):
+    """Random accepted word sequence -> (features [T, D] float32, word labels).  end_word >= 0: that word
+    (make_cl_g's terminal `</s>`, no pause model behind it) closes the sequence."""
     rng = np.random.default_rng(seed)
     words, gmm_seq = [], []
     h = 0
-    for _ in range(n_words):
-        if rng.random() < p_backoff:
+    for k in range(n_words + (1 if end_word >= 0 else 0)):
+        last = end_word >= 0 and k == n_words
+        if last:
+            w = end_word
+        elif rng.random() < p_backoff:
             w = int(rng.integers(0, net.n_words))
         else:
             w = int(net.succ[h, rng.integers(0, net.succ.shape[1])])
         words.append(w)
         models = list(net.prons[w])
-        if net.sp_hmm >= 0:
+        if net.sp_hmm >= 0 and not last:
             models.append(net.sp_hmm)
         for hm in models:
             n = int(am.hmm_nstates[hm]); tm = am.transp[am.hmm_tm[hm]]

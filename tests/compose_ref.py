@@ -4,7 +4,8 @@ WFSTOnTheFlyDecoder is not built by either of its build systems and no longer co
 section 2 row 15), so the device composition is checked against
 
   compose_filtered  the same definition (filter flag, back-off after a word only, interval
-                    look-ahead, canonical numbering) written a second time with dictionaries - the
+                    look-ahead that always lets the tail of the last word through to a final C.L
+                    state, canonical numbering) written a second time with dictionaries - the
                     arrays must come out identical, bit for bit;
   compose_naive     textbook epsilon composition with nothing clever: every (C.L state, G state)
                     pair, G's epsilon taken anywhere, no filter, no look-ahead.  A different (larger,
@@ -59,7 +60,16 @@ def _lookahead(cl):
                 if l <= h and (l < lo[c] or h > hi[c]):
                     lo[c], hi[c] = min(lo[c], l), max(hi[c], h)
                     changed = True
-    return lo, hi
+    # states that reach a FINAL C.L state through label-less arcs (the tail of the last word): LA_MAYFIN, csrc/jd_lazy.h
+    mf = [bool(np.isfinite(cl["fin_w"][c])) for c in range(S)]
+    changed = True
+    while changed:
+        changed = False
+        for c in range(S):
+            if not mf[c] and any(mf[t] for t in eps_next[c]):
+                mf[c] = True
+                changed = True
+    return lo, hi, mf
 
 
 def _finish(states, arcs_of, fin_of, init_key, order_key):
@@ -78,7 +88,7 @@ def _finish(states, arcs_of, fin_of, init_key, order_key):
 
 def compose_filtered(cl, cl_init, g, g_init, pushing=False):
     G = _sorted_g(g)
-    lo, hi = _lookahead(cl)
+    lo, hi, mf = _lookahead(cl)
     glabels = [[a[0] for a in row] for row in G]
 
     def any_in(gs, l, h):
@@ -104,7 +114,7 @@ def compose_filtered(cl, cl_init, g, g_init, pushing=False):
         for a in range(int(cl["row_ptr"][c]), int(cl["row_ptr"][c + 1])):
             x, t, ww, i = int(cl["olab"][a]), int(cl["to"][a]), np.float32(cl["w"][a]), int(cl["ilab"][a])
             if x == 0:
-                if any_in(gs, lo[t], hi[t]):
+                if any_in(gs, lo[t], hi[t]) or (mf[t] and np.isfinite(g["fin_w"][gs])):
                     if pushing:
                         ww = np.float32(np.float32(ww + np.float32(potential(gs, lo[t], hi[t]))) - p_src)
                     out.append(((t, gs, 0), ww, i, 0))

@@ -79,3 +79,32 @@ def test_filtered_composition_equals_textbook_composition(seed, n_tri, with_sp):
         assert abs(a - b) <= 1e-3 * max(1.0, abs(a)) and abs(a - c) <= 1e-3 * max(1.0, abs(a)), (ws, a, b, c)
         checked += 1
     assert checked == 25
+
+
+@pytest.mark.parametrize("seed,n_tri,with_sp", [(5, 30, True), (6, 0, False)])
+def test_sentence_end_reaches_a_terminal_final_state(seed, n_tri, with_sp):
+    """C.L ends in `root -m:</s>-> x -m:eps-> FINAL` (a terminal final state, no arcs out) and G in a terminal `</s>`
+    state (final, no arcs, no back-off): the look-ahead interval of x is EMPTY and the G state has no arc at all, yet
+    the label-less tail has to be followed (the reference always follows the transitions before the C.L final states,
+    WFSTOnTheFlyDecoder.cpp:2665-2697) - else no composed state is final."""
+    from juicer_amd import synth
+    V = 25
+    am = synth.make_models(seed, n_gmm=100, n_hmm=45, n_mix=2, n_tm=8, sep=0.6, with_tee=with_sp)
+    cl, g = synth.make_cl_g(seed, am, n_words=V, n_succ=3, n_tri=n_tri, with_sp=with_sp, terminal=True)
+    ccl, ci = _csr_of(cl, 1.0)
+    cg, gi = _csr_of(g, 3.0)
+    naive = compose_naive(ccl, ci, cg, gi)
+    for pushing in (False, True):
+        filt = compose_filtered(ccl, ci, cg, gi, pushing=pushing)
+        assert np.isfinite(filt["fin_w"]).any()                         # (round 2: none - every sentence end was cut off)
+        rng = np.random.default_rng(seed)
+        for _ in range(15):
+            h, ws = 0, []
+            for _ in range(int(rng.integers(1, 5))):
+                wd = int(g.succ[h, rng.integers(0, g.succ.shape[1])]) if rng.random() < 0.6 else int(rng.integers(0, V))
+                ws.append(wd + 1)
+                h = 1 + wd
+            a, b = _best(naive, ws + [V + 1]), _best(filt, ws + [V + 1])
+            assert np.isfinite(a), ws
+            assert abs(a - b) <= 1e-3 * max(1.0, abs(a)), (ws, a, b)
+            assert not np.isfinite(_best(naive, ws)) and not np.isfinite(_best(filt, ws))   # a sentence has to end

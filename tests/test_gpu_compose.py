@@ -91,6 +91,45 @@ def test_decoding_the_device_composed_graph(built, c, pushing):
             assert rel_close(gs[u].score, o.score) and rel_close(gs[u].lm, o.lm) and rel_close(gs[u].tot_score, o.tot_score)
 
 
+@pytest.mark.parametrize("pushing", [False, True], ids=["plain", "pushing"])
+@pytest.mark.parametrize("lazy", [False, True], ids=["composed", "search_driven"])
+def test_sentence_end_in_terminal_final_states(built, pushing, lazy):
+    """C.L ends in `root -m:</s>-> x -m:eps-> FINAL` (terminal) and G in a terminal `</s>` state: x has an EMPTY
+    look-ahead interval and the G state no arc at all, yet the tail is followed (LA_MAYFIN, csrc/jd_lazy.h; the
+    reference always follows the transitions before the C.L final states, WFSTOnTheFlyDecoder.cpp:2665-2697).
+    Checked against the CPU oracle on TEXTBOOK composition (which has no look-ahead to get wrong)."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    seed, V, lm = 5, 40, 2.0
+    am = synth.make_models(seed, n_gmm=100, n_hmm=45, n_mix=2, n_tm=8, sep=0.6, with_tee=True)
+    cl, g = synth.make_cl_g(seed, am, n_words=V, n_succ=4, n_tri=30, with_sp=True, terminal=True)
+    ncl, ng = capi.Network.from_synth(cl, 1.0, 0.0), capi.Network.from_synth(g, lm, 0.0)
+    models = capi.Models.from_htk(am)
+    comp = capi.Network.compose(ncl, ng, pushing=pushing)
+    want_arrays = compose_filtered(ncl.csr(), ncl.init_state, ng.csr(), ng.init_state, pushing=pushing)
+    got_arrays = comp.csr()
+    assert comp.n_states == want_arrays["n_states"] and np.isfinite(got_arrays["fin_w"]).any()
+    for k in ("row_ptr", "to", "ilab", "olab"):
+        assert np.array_equal(got_arrays[k], want_arrays[k]), k
+    assert np.array_equal(got_arrays["w"].view(np.uint32), want_arrays["w"].view(np.uint32))
+    net = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18, pushing=pushing) if lazy else comp
+    nv = compose_naive(ncl.csr(), ncl.init_state, ng.csr(), ng.init_state)
+    fs = np.nonzero(np.isfinite(nv["fin_w"]))[0].astype(np.int32)
+    onet = OracleNet.from_csr(nv["n_states"], nv["init"], nv["row_ptr"], nv["to"], nv["w"], nv["ilab"], nv["olab"], fs, nv["fin_w"][fs])
+    feats = [synth.sample_utterance(seed + 1000 + u, g, am, 4 + u, end_word=V)[0] for u in range(3)]
+    kw = dict(main_beam=400.0)
+    gs = capi.Decoder(net, models, max_streams=len(feats), **kw).decode_batch(feats)
+    od = OracleDecoder(onet, OracleAM(am), **kw)
+    for u, x in enumerate(feats):
+        o = od.decode(x)
+        assert gs[u].n == o.n and o.n > 0
+        assert int(gs[u].label[0]) == V + 1                          # (newest first: the sentence end)
+        assert np.array_equal(gs[u].label, o.label) and np.array_equal(gs[u].time, o.time)
+        assert rel_close(gs[u].ac, o.ac) and rel_close(gs[u].tot_lm, o.tot_lm)
+        if not pushing:
+            assert rel_close(gs[u].score, o.score) and rel_close(gs[u].lm, o.lm) and rel_close(gs[u].tot_score, o.tot_score)
+
+
 def test_compose_errors(built):
     from juicer_amd import capi, synth
     am, cl, g, ncl, ng = _case(CASES[0])
