@@ -163,6 +163,21 @@ int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t max_mix,
                      const int32_t *hmm_gmm, const int32_t *hmm_tm,
                      int32_t n_tm, const int32_t *tm_nstates, const float *transp);
 
+/*
+ * Build models from the PREPARED arrays of a loaded HTKFlatModels / HTKModels object - what
+ * `WFSTDecoderLite(network, models, ...)` (WFSTDecoderLite.h:81-89) is handed by juicer.cpp:577-586:
+ * det = fDets, mean = fMeans, ivar = fVars (inverse variances) of HTKFlatModels.h:48-52 re-laid as
+ * [n_gmm][max_mix] / [n_gmm][max_mix][D]; hmm_tee[h] = getTeeLogProb(h) (Models.h:61); trP[t] =
+ * getTransMat(h) rows (Models.h:63, [n_tm][max_n][max_n], LOG_ZERO where there is no transition),
+ * se[t][j] = getSEIndex(h)[j] (Models.h:64, [n_tm][max_n][2]).  Nothing is recomputed.
+ * include/juicer_amd_decoder.hpp's exact-signature constructor fills these from an IModels*.
+ */
+int jd_am_create_flat(jd_am **out, int32_t D, int32_t n_gmm, int32_t max_mix, const int32_t *n_mix,
+                      const float *det, const float *mean, const float *ivar,
+                      int32_t n_hmm, int32_t max_n, const int32_t *hmm_nstates,
+                      const int32_t *hmm_gmm, const int32_t *hmm_tm, const float *hmm_tee,
+                      int32_t n_tm, const int32_t *tm_nstates, const float *trP, const int16_t *se);
+
 /* HTK MMF text (HTKModels::Load, HTKModels.cpp:221-282): the subset the reference's
  * flex/bison front-end accepts (htkparse.l.lpp:21-268, htkparse.y.ypp:113-147,414-685):
  * ~o, ~v (ignored), ~s, ~t, ~h with shared or inline states / <TRANSP>, <NUMMIXES>/<MIXTURE>
@@ -314,10 +329,13 @@ int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
 
 /*
  * The same loop sharded over the GPUs of ONE node from C++ (no Python, no torchrun): one decoder
- * and one host thread per device, utterances in contiguous shards, no data-path collective, and
- * ONE RCCL all-gather (over xGMI) of fixed-size padded 1-best records at the end; results come back
- * in utterance order.  devices == NULL means devices 0 .. n_devices-1.  RCCL is loaded with
- * dlopen on first use.  jd_hyp storage is owned by the jd_multi and valid until its next decode.
+ * and one host thread per device, utterances dealt by length (longest first, each to the device
+ * with the fewest frames so far), no data-path collective, and ONE RCCL all-gather (over xGMI) of
+ * padded 1-best records at the end - a record is as long as the batch's longest hypothesis; results
+ * come back in the caller's utterance order.  An utterance that fails leaves an empty hypothesis,
+ * the others are returned and the call reports the first error.  devices == NULL means devices
+ * 0 .. n_devices-1.  RCCL is loaded with dlopen on first use.  jd_hyp storage is owned by the
+ * jd_multi and valid until its next decode.
  */
 typedef struct jd_multi jd_multi;
 int jd_multi_create(jd_multi **out, const jd_net *net, const jd_am *am,

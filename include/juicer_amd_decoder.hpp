@@ -56,23 +56,154 @@ public:
 }
 #endif
 
+#if defined(DECODER_H) && defined(WFST_NETWORK_INC) && defined(_HTKFLATMODELS_H)
+// ---- Inside the Juicer tree, with "WFSTNetwork.h" and "HTKFlatModels.h" included as well (juicer.cpp includes
+// both): the objects juicer.cpp has ALREADY built (setupNetworks / setupModels, juicer.cpp:664-900) are walked
+// into the C ABI's arrays, so that GpuWFSTDecoder has the reference constructor's own signature
+//     WFSTDecoderLite(WFSTNetwork*, IModels*, real, real, real, real, int)      src/WFSTDecoderLite.h:81-89
+// Nothing is loaded a second time and nothing is recomputed: arc weights carry the scale and penalty the
+// network was loaded with, the Gaussian tables are HTKFlatModels::init()'s.
+#define JUICER_AMD_HAVE_BRIDGE 1
+#include <limits>
+namespace JuicerAmd {
+
+// WFSTNetwork -> CSR through its public getters (src/WFSTNetwork.h:129-167)
+inline jd_net *netFromJuicer(Juicer::WFSTNetwork *network)
+{
+    const int nStates = network->getNumStates();
+    std::vector<int32_t> row((size_t)nStates + 1, 0), to, in, outl, fstate;
+    std::vector<float> w, fweight;
+    to.reserve((size_t)network->getNumTransitions()); in.reserve(to.capacity()); outl.reserve(to.capacity()); w.reserve(to.capacity());
+    for (int s = 0; s < nStates; ++s) {
+        const int n = network->getNumTransitionsOfOneState(s);
+        for (int k = 0; k < n; ++k) {                                   // the state's arcs in their stored order (:709-721)
+            const Juicer::WFSTTransition *t = network->getOneTransition(network->getTransID(s, k));
+            to.push_back(t->toState); w.push_back(t->weight); in.push_back(t->inLabel); outl.push_back(t->outLabel);
+        }
+        row[(size_t)s + 1] = (int32_t)to.size();
+        if (network->isFinalState(s)) { fstate.push_back(s); fweight.push_back(network->getFinalStateWeight(s)); }
+    }
+    jd_net *net = 0;
+    if (jd_net_create_csr(&net, nStates, network->getInitState(), &row[0], to.empty() ? 0 : &to[0], w.empty() ? 0 : &w[0],
+                          in.empty() ? 0 : &in[0], outl.empty() ? 0 : &outl[0], (int32_t)fstate.size(),
+                          fstate.empty() ? 0 : &fstate[0], fweight.empty() ? 0 : &fweight[0]) != JD_OK) {
+        fprintf(stderr, "juicer_amd: %s\n", jd_last_error());
+        exit(1);
+    }
+    return net;
+}
+
+// HTKFlatModels keeps its tables protected and IModels (src/Models.h:29-67) has no getter for them: they are read
+// through pointers to members formed in a derived class (well-defined: &Derived::member of a protected base member
+// has the base's member-pointer type and applies to any object of the base)
+struct FlatModelsView_ : public Juicer::HTKFlatModels {
+    template <typename T, typename C> static T get(C *m, T C::*p) { return m->*p; }
+    static jd_am *make(Juicer::HTKFlatModels *m)
+    {
+        const int D = m->getInputVecSize(), nHMM = m->getNumHMMs();
+        const int nGMM = get<int, Juicer::HTKModels>(m, &FlatModelsView_::nGMMs);
+        const int nTM = get<int, Juicer::HTKModels>(m, &FlatModelsView_::nTransMats);
+        if (get<bool, Juicer::HTKModels>(m, &FlatModelsView_::hybridMode)) {
+            fprintf(stderr, "juicer_amd: hybrid (ANN posterior) models: build them with jd_am_create_hybrid\n");
+            exit(1);
+        }
+        const Juicer::GMM *gmms = get<Juicer::GMM *, Juicer::HTKModels>(m, &FlatModelsView_::gMMs);
+        const Juicer::HMM *hmms = get<Juicer::HMM *, Juicer::HTKModels>(m, &FlatModelsView_::hMMs);
+        const Juicer::TransMatrix *tms = get<Juicer::TransMatrix *, Juicer::HTKModels>(m, &FlatModelsView_::transMats);
+        const Juicer::FMixture *fmix = get<Juicer::FMixture *, Juicer::HTKFlatModels>(m, &FlatModelsView_::fMixtures);
+        const float *fdets = get<real *, Juicer::HTKFlatModels>(m, &FlatModelsView_::fDets);
+        const float *fmeans = get<real *, Juicer::HTKFlatModels>(m, &FlatModelsView_::fMeans);
+        const float *fvars = get<real *, Juicer::HTKFlatModels>(m, &FlatModelsView_::fVars);
+        const int stride = get<int, Juicer::HTKFlatModels>(m, &FlatModelsView_::fvecSize4);
+        int maxMix = 1, maxN = 3;
+        for (int g = 0; g < nGMM; ++g) {
+            if (gmms[g].mixtureInd != g) {                              // HTKFlatModels indexes its tables by GMM (HTKFlatModels.h:61-63)
+                fprintf(stderr, "juicer_amd: GMM %d shares mixture %d (HTKFlatModels assumes mixtureInd == gmmInd)\n", g, gmms[g].mixtureInd);
+                exit(1);
+            }
+            if (fmix[g].compNum > maxMix) maxMix = fmix[g].compNum;
+        }
+        for (int t = 0; t < nTM; ++t) if (tms[t].nStates > maxN) maxN = tms[t].nStates;
+        std::vector<int32_t> nMix((size_t)nGMM), hmmN((size_t)nHMM), hmmTm((size_t)nHMM), hmmGmm((size_t)nHMM * maxN, -1), tmN((size_t)nTM);
+        std::vector<float> det((size_t)nGMM * maxMix, JD_LOG_ZERO), mean((size_t)nGMM * maxMix * D, 0.0f), ivar((size_t)nGMM * maxMix * D, 0.0f);
+        std::vector<float> tee((size_t)nHMM), trP((size_t)nTM * maxN * maxN, JD_LOG_ZERO);
+        std::vector<int16_t> se((size_t)nTM * maxN * 2, 0);
+        for (int g = 0; g < nGMM; ++g) {                                // fDet / fMean / fVar of HTKFlatModels.h:67-69
+            nMix[(size_t)g] = fmix[g].compNum;
+            for (int c = 0; c < fmix[g].compNum; ++c) {
+                const size_t src = (size_t)fmix[g].compInd + c, dst = (size_t)g * maxMix + c;
+                det[dst] = fdets[src];
+                for (int k = 0; k < D; ++k) { mean[dst * D + k] = fmeans[src * stride + k]; ivar[dst * D + k] = fvars[src * stride + k]; }
+            }
+        }
+        for (int t = 0; t < nTM; ++t) {                                 // createTrPandSEIndex, HTKModels.cpp:2330-2390
+            const int n = tms[t].nStates;
+            tmN[(size_t)t] = n;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) trP[((size_t)t * maxN + i) * maxN + j] = tms[t].trP[i][j];
+            for (int j = 1; j < n; ++j) { se[((size_t)t * maxN + j) * 2] = tms[t].seIndexes[j].start; se[((size_t)t * maxN + j) * 2 + 1] = tms[t].seIndexes[j].end; }
+        }
+        for (int h = 0; h < nHMM; ++h) {
+            hmmN[(size_t)h] = hmms[h].nStates; hmmTm[(size_t)h] = hmms[h].transMatrixInd; tee[(size_t)h] = m->getTeeLogProb(h);
+            for (int j = 1; j < hmms[h].nStates - 1; ++j) hmmGmm[(size_t)h * maxN + j] = hmms[h].gmmInds[j];
+        }
+        jd_am *am = 0;
+        if (jd_am_create_flat(&am, D, nGMM, maxMix, &nMix[0], &det[0], &mean[0], &ivar[0], nHMM, maxN, &hmmN[0], &hmmGmm[0], &hmmTm[0],
+                              &tee[0], nTM, &tmN[0], &trP[0], &se[0]) != JD_OK) {
+            fprintf(stderr, "juicer_amd: %s\n", jd_last_error());
+            exit(1);
+        }
+        return am;
+    }
+};
+inline jd_am *modelsFromJuicer(Juicer::IModels *models)
+{
+    Juicer::HTKFlatModels *flat = dynamic_cast<Juicer::HTKFlatModels *>(models);
+    if (!flat) {                                                        // (juicer.cpp:762-771 builds HTKFlatModels under OPT_FLATMODEL)
+        fprintf(stderr, "juicer_amd: GpuWFSTDecoder needs the models as HTKFlatModels (OPT_FLATMODEL)\n");
+        exit(1);
+    }
+    return FlatModelsView_::make(flat);
+}
+struct BridgedInputs_ {                  // owns what was walked out of the reference's objects (a base: built before the decoder)
+    jd_net *bridgedNet_; jd_am *bridgedAm_;
+    BridgedInputs_() : bridgedNet_(0), bridgedAm_(0) {}
+    BridgedInputs_(Juicer::WFSTNetwork *n, Juicer::IModels *m) : bridgedNet_(netFromJuicer(n)), bridgedAm_(modelsFromJuicer(m)) {}
+    ~BridgedInputs_() { jd_net_destroy(bridgedNet_); jd_am_destroy(bridgedAm_); }
+};
+}
+#else
+namespace JuicerAmd { struct BridgedInputs_ { jd_net *bridgedNet_; jd_am *bridgedAm_; BridgedInputs_() : bridgedNet_(0), bridgedAm_(0) {} }; }
+#endif
+
 namespace JuicerAmd {
 
 // Drop-in for `new WFSTDecoderLite(network, models, phoneStartBeam, mainBeam,
 // phoneEndBeam, wordEmitBeam, maxHyps)` (juicer.cpp:577-586).  Like the reference it
 // does not own the network / models.  Errors follow Torch3 error(): message + exit.
-class GpuWFSTDecoder : public IDecoder {
+class GpuWFSTDecoder : private BridgedInputs_, public IDecoder {
 public:
     GpuWFSTDecoder(const jd_net *network, const jd_am *models, float phoneStartPruneWin, float emitPruneWin,
                    float phoneEndPruneWin, float wordPruneWin, int maxEmitHyps, int device = 0,
                    int blockSize = 5, int flushFrames = 64)
         : dec_(0), vecSize_(jd_am_vec_size(models)), nextFrame_(0), flush_(flushFrames)
     {
-        check(jd_dec_create(&dec_, network, models, phoneStartPruneWin, emitPruneWin, phoneEndPruneWin,
-                            wordPruneWin, maxEmitHyps, blockSize, device, 1));
-        if (const char *e = getenv("PartialTraceInterval"))            // WFSTDecoderLite.cpp:116-119 (GetEnv, default 0)
-            setPartialDecodeOptions(atoi(e));
+        create(network, models, phoneStartPruneWin, emitPruneWin, phoneEndPruneWin, wordPruneWin, maxEmitHyps, device, blockSize);
     }
+#ifdef JUICER_AMD_HAVE_BRIDGE
+    // The reference constructor's own signature (src/WFSTDecoderLite.h:81-89; call site juicer.cpp:582-586):
+    //     decoder = new GpuWFSTDecoder(network, models, phoneStartBeam, mainBeam, phoneEndBeam, wordEmitBeam, maxHyps);
+    // Like the reference it does not own network / models; it keeps its own copies of what it read from them.
+    GpuWFSTDecoder(Juicer::WFSTNetwork *network_, Juicer::IModels *models_, real phoneStartPruneWin_, real emitPruneWin_,
+                   real phoneEndPruneWin_, real wordPruneWin_, int maxEmitHyps_)
+        : BridgedInputs_(network_, models_), dec_(0), vecSize_(jd_am_vec_size(bridgedAm_)), nextFrame_(0), flush_(64)
+    {
+        int device = 0, blockSize = 5;
+        if (const char *e = getenv("JUICER_AMD_DEVICE")) device = atoi(e);
+        if (const char *e = getenv("JUICER_AMD_BLOCKSIZE")) blockSize = atoi(e);   // (-blockSize reaches the models only, juicer.cpp:255)
+        create(bridgedNet_, bridgedAm_, phoneStartPruneWin_, emitPruneWin_, phoneEndPruneWin_, wordPruneWin_, maxEmitHyps_, device, blockSize);
+    }
+#endif
     virtual ~GpuWFSTDecoder() { jd_dec_destroy(dec_); }
 
     bool modelLevelOutput() { return false; }      // WFSTDecoderLite.h:106
@@ -144,6 +275,13 @@ public:
     }
 
 private:
+    void create(const jd_net *network, const jd_am *models, float startWin, float emitWin, float endWin, float wordWin,
+                int maxEmitHyps, int device, int blockSize)
+    {
+        check(jd_dec_create(&dec_, network, models, startWin, emitWin, endWin, wordWin, maxEmitHyps, blockSize, device, 1));
+        if (const char *e = getenv("PartialTraceInterval"))            // WFSTDecoderLite.cpp:116-119 (GetEnv, default 0)
+            setPartialDecodeOptions(atoi(e));
+    }
     void flush()
     {
         if (pending_.empty()) return;

@@ -69,7 +69,7 @@ class Hyp:
 EXPORTS = [
     "jd_net_create_arcs", "jd_net_create_csr", "jd_net_load_fsm", "jd_net_num_arcs", "jd_net_num_states",
     "jd_net_init_state", "jd_net_destroy", "jd_net_get_csr", "jd_net_load_jwnt", "jd_net_save_jwnt",
-    "jd_am_load_jmbi", "jd_am_save_jmbi", "jd_am_create_htk", "jd_am_num_hmms", "jd_am_num_gmms",
+    "jd_am_load_jmbi", "jd_am_save_jmbi", "jd_am_create_htk", "jd_am_create_flat", "jd_am_num_hmms", "jd_am_num_gmms",
     "jd_am_vec_size", "jd_am_max_states", "jd_am_max_mix", "jd_am_num_transmats", "jd_am_get_topology", "jd_am_load_mmf", "jd_am_get_flat", "jd_am_get_trans", "jd_am_destroy",
     "jd_dec_create", "jd_dec_destroy", "jd_dec_set_capacity", "jd_stream_init", "jd_stream_push",
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",

@@ -865,6 +865,7 @@ struct jd_dec {
     int4 *d_work = nullptr; int work_cap = 0;
     int *d_status = nullptr; int *h_status = nullptr;
     bool xl_ok = true;                    // XCD-local launches allowed (JD_XCD_LOCAL=0 or one failed placement check switch them off)
+    double xl_slack = 1.04;               // ... when the packed plan is predicted to end no later than this times the unpacked one (JD_XL_SLACK)
     long long *d_dbg = nullptr;           // in-kernel cycle accounting (jd_dec_debug_trace)
     // chunked pipeline
     int Fc = 128;                         // frames per scoring chunk of the streaming API (jd_stream_push)
@@ -956,6 +957,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     C.max_hyps = max_hyps;
     C.x_chunks = 2;
     if (const char *e = getenv("JD_XCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) C.x_chunks = v; }   // development
+    C.exp = 0;
+    if (const char *e = getenv("JD_EXP")) C.exp = atoi(e);                                                    // development
     C.hist_min = 0; C.hist_max = 0; C.hist_nbins = 0;
     if (max_hyps > 0) {                          // WFSTDecoderLite.cpp:76-82, Histogram.cpp:29-37
         float mn = (main_beam > 0.0) ? (float)(-main_beam - 800.0) : -1000.0f;
@@ -1055,6 +1058,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_MODEL_A")) d->model_a_us = atof(e);
     if (const char *e = getenv("JD_MODEL_B")) d->model_b_us = atof(e);
     if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0;                      // development
+    if (const char *e = getenv("JD_XL_SLACK")) { const double v = atof(e); if (v >= 1.0 && v <= 10.0) d->xl_slack = v; }
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
     hipError_t e;
@@ -1508,7 +1512,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
                     for (int k : member[(size_t)b]) { pos[(size_t)k] = at; at += cwx[(size_t)k]; }
                 }
                 for (int k = 0; k < n_work; ++k) { tau_plain = std::max(tau_plain, t_of(k, cw[(size_t)k])); tau_xl = std::max(tau_xl, t_of(k, cwx[(size_t)k])); }
-                if (tau_xl > 1.04 * tau_plain) fits = false;
+                if (tau_xl > d->xl_slack * tau_plain) fits = false;
             }
             if (fits) {
                 for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = pos[(size_t)k]; work[(size_t)k].w = cwx[(size_t)k]; }

@@ -325,6 +325,60 @@ extern "C" int jd_am_create_htk(jd_am **out, int32_t D, int32_t n_gmm, int32_t m
     return JD_OK;
 }
 
+// Models from the PREPARED arrays a loaded HTKFlatModels holds (HTKFlatModels.cpp:94-177: fDets, fMeans, fVars =
+// inverse variances; HTKModels.cpp:2330-2390: trP, SEIndex; :581-593 teeWeight): nothing is recomputed, so the
+// values are the reference's own, bit for bit.  What include/juicer_amd_decoder.hpp's exact-signature
+// constructor hands over after walking an IModels*.
+extern "C" int jd_am_create_flat(jd_am **out, int32_t D, int32_t n_gmm, int32_t max_mix, const int32_t *n_mix,
+                                 const float *det, const float *mean, const float *ivar, int32_t n_hmm, int32_t max_n,
+                                 const int32_t *hmm_nstates, const int32_t *hmm_gmm, const int32_t *hmm_tm,
+                                 const float *hmm_tee, int32_t n_tm, const int32_t *tm_nstates, const float *trP,
+                                 const int16_t *se)
+{
+    if (!out || !n_mix || !det || !mean || !ivar || !hmm_nstates || !hmm_gmm || !hmm_tm || !hmm_tee || !tm_nstates || !trP || !se ||
+        D <= 0 || n_gmm <= 0 || max_mix <= 0 || n_hmm <= 0 || max_n < 3 || n_tm <= 0)
+        return jd_fail(JD_EINVAL, "jd_am_create_flat: bad argument");
+    if (max_n > JD_MAXN)
+        return jd_fail(JD_EINVAL, "jd_am_create_flat: HMMs with more than %d states are not supported", JD_MAXN);
+    jd_am *a = new jd_am();
+    a->D = D; a->n_gmm = n_gmm; a->max_mix = max_mix; a->n_hmm = n_hmm; a->max_n = max_n; a->n_tm = n_tm;
+    const size_t gm = (size_t)n_gmm * max_mix;
+    a->n_mix.assign(n_mix, n_mix + n_gmm);
+    a->det.assign(gm, LZ); a->mean.assign(gm * D, 0.0f); a->ivar.assign(gm * D, 0.0f);
+    for (int32_t g = 0; g < n_gmm; ++g) {
+        if (n_mix[g] < 1 || n_mix[g] > max_mix) { delete a; return jd_fail(JD_EINVAL, "n_mix[%d] out of range", g); }
+        for (int32_t m = 0; m < n_mix[g]; ++m) {                      // (components beyond n_mix keep the padding values)
+            const size_t gi = (size_t)g * max_mix + m;
+            a->det[gi] = det[gi];
+            memcpy(&a->mean[gi * D], &mean[gi * D], (size_t)D * sizeof(float));
+            memcpy(&a->ivar[gi * D], &ivar[gi * D], (size_t)D * sizeof(float));
+        }
+    }
+    a->tm_n.assign(tm_nstates, tm_nstates + n_tm);
+    for (int32_t t = 0; t < n_tm; ++t)
+        if (tm_nstates[t] < 3 || tm_nstates[t] > max_n) { delete a; return jd_fail(JD_EINVAL, "tm_nstates[%d] out of range", t); }
+    a->trP.assign(trP, trP + (size_t)n_tm * max_n * max_n);
+    a->se.assign(se, se + (size_t)n_tm * max_n * 2);
+    a->hmm_n.assign(hmm_nstates, hmm_nstates + n_hmm);
+    a->hmm_tm.assign(hmm_tm, hmm_tm + n_hmm);
+    a->hmm_tee.assign(hmm_tee, hmm_tee + n_hmm);
+    a->hmm_gmm.assign((size_t)n_hmm * max_n, -1);
+    for (int32_t h = 0; h < n_hmm; ++h) {
+        const int32_t n = hmm_nstates[h], t = hmm_tm[h];
+        if (t < 0 || t >= n_tm || tm_nstates[t] != n) {
+            delete a;
+            return jd_fail(JD_EINVAL, "HTKModels::addHMM - curr->nStates != hmm->transmat->n_states (hmm %d)", h);
+        }
+        for (int32_t j = 1; j < n - 1; ++j) {
+            const int32_t g = hmm_gmm[(size_t)h * max_n + j];
+            if (g < 0 || g >= n_gmm) { delete a; return jd_fail(JD_EINVAL, "hmm %d state %d: bad gmm index", h, j); }
+            a->hmm_gmm[(size_t)h * max_n + j] = g;
+        }
+    }
+    *out = a;
+    return JD_OK;
+}
+
 // HTKModels::Load(phonesListFName, priorsFName, statesPerModel), HTKModels.cpp:74-218: hybrid ANN / HMM
 // models.  One HMM per phone with statesPerModel states whose emitting states all score
 // x[phone] - log(prior[phone]) (calcOutput, :481-512 / HTKFlatModels.cpp:190-222); ONE transition matrix:

@@ -1,8 +1,9 @@
 // jd_multi.cpp - the utterance loop of DecoderBatchTest::run (src/DecoderBatchTest.cpp:738-771)
 // sharded over the GPUs of one node from C++: one jd_dec per device, one host thread per device,
-// utterances in contiguous shards (they are independent: the reference decodes them serially), no
-// data-path collective - and ONE RCCL all-gather of fixed-size padded 1-best records at the end,
-// after which every device holds every hypothesis (the host reads them from the first one).
+// utterances dealt by length (longest first, each to the device with the fewest frames so far: they
+// are independent - the reference decodes them serially), no data-path collective - and ONE RCCL
+// all-gather of padded 1-best records at the end, after which every device holds every hypothesis
+// (the host reads them from the first one).  A record is as long as the batch's longest hypothesis.
 //
 // RCCL is loaded with dlopen when the first multi-device decoder is created: libjuicer_amd.so has
 // no link-time dependency on it (a process that already carries PyTorch's own copy must not get a
@@ -22,8 +23,7 @@
 
 #include "jd_internal.h"
 
-#define JM_MAX_WORDS 256
-#define JM_REC (5 + 5 * JM_MAX_WORDS)          // n, n_frames, tot[3], label[L], time[L], score[L], ac[L], lm[L]
+#define JM_HDR 6                               // record = n, n_frames, tot[3], utterance, label[L], time[L], score[L], ac[L], lm[L]
 
 namespace {
 struct Rccl {
@@ -61,7 +61,7 @@ struct jd_multi {
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> stream;
     std::vector<int32_t *> d_send, d_recv;
-    size_t cap_per_dev = 0;                        // records per device the buffers hold
+    size_t cap_per_dev = 0;                        // 32-bit words per device the gather buffers hold
     // storage behind the jd_hyp pointers handed out (valid until the next decode)
     std::vector<std::vector<int32_t>> label, time;
     std::vector<std::vector<float>> score, ac, lm;
@@ -160,16 +160,36 @@ extern "C" int jd_multi_create_lazy(jd_multi **out, const jd_net *cl, const jd_n
                         block_size, n_devices, devices, max_streams_per_device);
 }
 
-static void pack(const jd_hyp &h, int32_t *r)
+// Longest-processing-time-first: utterances by decreasing length, each to the shard with the fewest frames
+// so far.  A batch's duration is its slowest device's; contiguous shards of a list sorted by
+// anything else than length can differ by the length of their longest utterances.
+static void lpt_shards(int32_t n_utts, const int32_t *n_frames, int N, std::vector<std::vector<int>> &idx)
 {
-    memset(r, 0, JM_REC * sizeof(int32_t));
-    const int k = std::max(0, std::min((int)h.n, JM_MAX_WORDS));
-    r[0] = h.n; r[1] = h.stats.n_frames;
+    idx.assign((size_t)N, {});
+    std::vector<int> order((size_t)n_utts);
+    for (int u = 0; u < n_utts; ++u) order[(size_t)u] = u;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_frames[a] > n_frames[b]; });
+    std::vector<long long> load((size_t)N, 0);
+    for (int u : order) {
+        int best = 0;
+        for (int d = 1; d < N; ++d)
+            if (load[(size_t)d] < load[(size_t)best] || (load[(size_t)d] == load[(size_t)best] && idx[(size_t)d].size() < idx[(size_t)best].size())) best = d;
+        idx[(size_t)best].push_back(u);
+        load[(size_t)best] += std::max(n_frames[u], 0) + 1;               // (+1: empty utterances are spread as well)
+    }
+}
+
+static void pack(const jd_hyp &h, int utt, int32_t *r, size_t L)
+{
+    const size_t rec = JM_HDR + 5 * L;
+    memset(r, 0, rec * sizeof(int32_t));
+    const size_t k = (size_t)std::max(0, (int)h.n);
+    r[0] = h.n; r[1] = h.stats.n_frames; r[5] = utt;
     memcpy(r + 2, &h.tot_score, 4); memcpy(r + 3, &h.tot_ac, 4); memcpy(r + 4, &h.tot_lm, 4);
     if (k) {
-        memcpy(r + 5, h.label, (size_t)k * 4); memcpy(r + 5 + JM_MAX_WORDS, h.time, (size_t)k * 4);
-        memcpy(r + 5 + 2 * JM_MAX_WORDS, h.score, (size_t)k * 4); memcpy(r + 5 + 3 * JM_MAX_WORDS, h.ac, (size_t)k * 4);
-        memcpy(r + 5 + 4 * JM_MAX_WORDS, h.lm, (size_t)k * 4);
+        memcpy(r + JM_HDR, h.label, k * 4); memcpy(r + JM_HDR + L, h.time, k * 4);
+        memcpy(r + JM_HDR + 2 * L, h.score, k * 4); memcpy(r + JM_HDR + 3 * L, h.ac, k * 4);
+        memcpy(r + JM_HDR + 4 * L, h.lm, k * 4);
     }
 }
 
@@ -177,61 +197,73 @@ extern "C" int jd_multi_decode_batch(jd_multi *m, int32_t n_utts, const float *c
 {
     if (!m || !feats || !n_frames || !out || n_utts < 0) return jd_fail(JD_EINVAL, "jd_multi_decode_batch: bad argument");
     const int N = m->n_dev;
-    const size_t per = (size_t)(n_utts + N - 1) / (size_t)N;                 // records every device contributes (padded)
-    // ---- contiguous shards, one host thread per device
-    std::vector<int> lo((size_t)N), hi((size_t)N), rcs((size_t)N, JD_OK);
+    // ---- shards balanced by frames, one host thread per device
+    std::vector<std::vector<int>> idx;
+    lpt_shards(n_utts, n_frames, N, idx);
+    size_t per = 0;                                                          // records every device contributes (padded)
+    for (int d = 0; d < N; ++d) per = std::max(per, idx[(size_t)d].size());
+    std::vector<int> rcs((size_t)N, JD_OK);
     std::vector<std::string> errs((size_t)N);
     std::vector<std::vector<jd_hyp>> local((size_t)N);
-    {
-        const int base = n_utts / N, rem = n_utts % N;
-        for (int d = 0; d < N; ++d) { lo[(size_t)d] = d * base + std::min(d, rem); hi[(size_t)d] = lo[(size_t)d] + base + (d < rem ? 1 : 0); }
-    }
-    std::vector<std::vector<int32_t>> send((size_t)N);
     std::vector<std::thread> th;
     for (int d = 0; d < N; ++d)
         th.emplace_back([&, d]() {
-            const int n = hi[(size_t)d] - lo[(size_t)d];
-            local[(size_t)d].resize((size_t)std::max(n, 0));
-            if (n > 0) {
-                rcs[(size_t)d] = jd_decode_batch(m->dec[(size_t)d], n, feats + lo[(size_t)d], n_frames + lo[(size_t)d], local[(size_t)d].data());
-                if (rcs[(size_t)d]) errs[(size_t)d] = jd_last_error();       // (thread-local in the library)
-            }
-            send[(size_t)d].assign(per * JM_REC, 0);
-            for (size_t i = 0; i < per; ++i) {
-                int32_t *r = send[(size_t)d].data() + i * JM_REC;
-                if ((int)i < n && rcs[(size_t)d] == JD_OK) {
-                    if (local[(size_t)d][i].n > JM_MAX_WORDS) { rcs[(size_t)d] = JD_ENOMEM; errs[(size_t)d] = "hypothesis longer than the gather record"; }
-                    pack(local[(size_t)d][i], r);
-                } else r[0] = -2;                                            // padding
-            }
+            const std::vector<int> &mine = idx[(size_t)d];
+            const int n = (int)mine.size();
+            local[(size_t)d].resize((size_t)n);
+            if (n == 0) return;
+            std::vector<const float *> f((size_t)n);
+            std::vector<int32_t> nf((size_t)n);
+            for (int i = 0; i < n; ++i) { f[(size_t)i] = feats[mine[(size_t)i]]; nf[(size_t)i] = n_frames[mine[(size_t)i]]; }
+            // (an utterance that fails leaves an empty hypothesis and the error; the others of the shard are decoded)
+            rcs[(size_t)d] = jd_decode_batch(m->dec[(size_t)d], n, f.data(), nf.data(), local[(size_t)d].data());
+            if (rcs[(size_t)d]) errs[(size_t)d] = jd_last_error();           // (thread-local in the library)
         });
     for (auto &t : th) t.join();
+    int first_err = JD_OK;
+    std::string first_msg;
     for (int d = 0; d < N; ++d)
-        if (rcs[(size_t)d]) return jd_fail(rcs[(size_t)d], "device %d: %s", m->devices[(size_t)d], errs[(size_t)d].c_str());
-    // ---- the one collective: all-gather of the padded records (RCCL over xGMI between the GPUs)
-    if (per > m->cap_per_dev) {
+        if (rcs[(size_t)d] && first_err == JD_OK) { first_err = rcs[(size_t)d]; first_msg = "device " + std::to_string(m->devices[(size_t)d]) + ": " + errs[(size_t)d]; }
+    // ---- the one collective: all-gather of the padded records (RCCL over xGMI between the GPUs); a record holds
+    // the longest hypothesis of the batch
+    size_t L = 1;
+    for (int d = 0; d < N; ++d)
+        for (const jd_hyp &h : local[(size_t)d]) L = std::max(L, (size_t)std::max(0, (int)h.n));
+    const size_t rec = JM_HDR + 5 * L, words = per * rec;
+    std::vector<std::vector<int32_t>> send((size_t)N);
+    for (int d = 0; d < N; ++d) {
+        send[(size_t)d].assign(words, 0);
+        for (size_t i = 0; i < per; ++i) {
+            int32_t *r = send[(size_t)d].data() + i * rec;
+            if (i < idx[(size_t)d].size()) pack(local[(size_t)d][i], idx[(size_t)d][i], r, L);
+            else r[0] = -2;                                                  // padding
+        }
+    }
+    if (words > m->cap_per_dev) {
         for (int d = 0; d < N; ++d) {
             if (hipSetDevice(m->devices[(size_t)d]) != hipSuccess) return jd_fail(JD_EHIP, "hipSetDevice failed");
             if (m->d_send[(size_t)d]) (void)hipFree(m->d_send[(size_t)d]);
             if (m->d_recv[(size_t)d]) (void)hipFree(m->d_recv[(size_t)d]);
             m->d_send[(size_t)d] = m->d_recv[(size_t)d] = nullptr;
-            if (hipMalloc(&m->d_send[(size_t)d], per * JM_REC * sizeof(int32_t)) != hipSuccess ||
-                hipMalloc(&m->d_recv[(size_t)d], per * JM_REC * sizeof(int32_t) * (size_t)N) != hipSuccess)
+            if (hipMalloc(&m->d_send[(size_t)d], words * sizeof(int32_t)) != hipSuccess ||
+                hipMalloc(&m->d_recv[(size_t)d], words * sizeof(int32_t) * (size_t)N) != hipSuccess) {
+                m->cap_per_dev = 0;
                 return jd_fail(JD_EHIP, "jd_multi_decode_batch: hipMalloc of the gather buffers failed");
+            }
         }
-        m->cap_per_dev = per;
+        m->cap_per_dev = words;
     }
-    std::vector<int32_t> all(per * JM_REC * (size_t)N);
+    std::vector<int32_t> all(words * (size_t)N);
     if (per > 0) {
         for (int d = 0; d < N; ++d) {
             if (hipSetDevice(m->devices[(size_t)d]) != hipSuccess ||
-                hipMemcpyAsync(m->d_send[(size_t)d], send[(size_t)d].data(), per * JM_REC * sizeof(int32_t), hipMemcpyHostToDevice,
+                hipMemcpyAsync(m->d_send[(size_t)d], send[(size_t)d].data(), words * sizeof(int32_t), hipMemcpyHostToDevice,
                                m->stream[(size_t)d]) != hipSuccess)
                 return jd_fail(JD_EHIP, "jd_multi_decode_batch: upload of the records failed");
         }
         ncclResult_t nr = g_rccl.GroupStart();
         for (int d = 0; d < N && nr == ncclSuccess; ++d)
-            nr = g_rccl.AllGather(m->d_send[(size_t)d], m->d_recv[(size_t)d], per * JM_REC, ncclInt32, m->comm[(size_t)d], m->stream[(size_t)d]);
+            nr = g_rccl.AllGather(m->d_send[(size_t)d], m->d_recv[(size_t)d], words, ncclInt32, m->comm[(size_t)d], m->stream[(size_t)d]);
         const ncclResult_t ne = g_rccl.GroupEnd();
         if (nr != ncclSuccess || ne != ncclSuccess)
             return jd_fail(JD_EHIP, "ncclAllGather failed: %s", g_rccl.GetErrorString(nr != ncclSuccess ? nr : ne));
@@ -242,29 +274,32 @@ extern "C" int jd_multi_decode_batch(jd_multi *m, int32_t n_utts, const float *c
             hipMemcpy(all.data(), m->d_recv[0], all.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
             return jd_fail(JD_EHIP, "jd_multi_decode_batch: download of the gathered records failed");
     }
-    // ---- unpack in global utterance order (the padding records carry n = -2)
+    // ---- unpack into the caller's order (a record names its utterance; the padding records carry n = -2)
     m->label.assign((size_t)n_utts, {}); m->time.assign((size_t)n_utts, {});
     m->score.assign((size_t)n_utts, {}); m->ac.assign((size_t)n_utts, {}); m->lm.assign((size_t)n_utts, {});
-    int u = 0;
+    int seen = 0;
     for (int d = 0; d < N; ++d)
         for (size_t i = 0; i < per; ++i) {
-            const int32_t *r = all.data() + ((size_t)d * per + i) * JM_REC;
+            const int32_t *r = all.data() + ((size_t)d * per + i) * rec;
             if (r[0] == -2) continue;
-            if (u >= n_utts) return jd_fail(JD_EHIP, "jd_multi_decode_batch: more records gathered than utterances");
+            const int u = r[5];
+            if (u < 0 || u >= n_utts || i >= idx[(size_t)d].size() || idx[(size_t)d][i] != u)
+                return jd_fail(JD_EHIP, "jd_multi_decode_batch: gathered record %zu of device %d names utterance %d", i, d, u);
             jd_hyp &H = out[u];
             H = local[(size_t)d][i];                                         // statistics stay local; the rest comes from the gather
-            const int k = std::max(0, (int)r[0]);
+            const size_t k = (size_t)std::max(0, (int)r[0]);
             H.n = r[0];
             memcpy(&H.tot_score, r + 2, 4); memcpy(&H.tot_ac, r + 3, 4); memcpy(&H.tot_lm, r + 4, 4);
-            m->label[(size_t)u].assign(r + 5, r + 5 + k); m->time[(size_t)u].assign(r + 5 + JM_MAX_WORDS, r + 5 + JM_MAX_WORDS + k);
-            m->score[(size_t)u].resize((size_t)k); m->ac[(size_t)u].resize((size_t)k); m->lm[(size_t)u].resize((size_t)k);
-            memcpy(m->score[(size_t)u].data(), r + 5 + 2 * JM_MAX_WORDS, (size_t)k * 4);
-            memcpy(m->ac[(size_t)u].data(), r + 5 + 3 * JM_MAX_WORDS, (size_t)k * 4);
-            memcpy(m->lm[(size_t)u].data(), r + 5 + 4 * JM_MAX_WORDS, (size_t)k * 4);
+            m->label[(size_t)u].assign(r + JM_HDR, r + JM_HDR + k); m->time[(size_t)u].assign(r + JM_HDR + L, r + JM_HDR + L + k);
+            m->score[(size_t)u].resize(k); m->ac[(size_t)u].resize(k); m->lm[(size_t)u].resize(k);
+            memcpy(m->score[(size_t)u].data(), r + JM_HDR + 2 * L, k * 4);
+            memcpy(m->ac[(size_t)u].data(), r + JM_HDR + 3 * L, k * 4);
+            memcpy(m->lm[(size_t)u].data(), r + JM_HDR + 4 * L, k * 4);
             H.label = m->label[(size_t)u].data(); H.time = m->time[(size_t)u].data();
             H.score = m->score[(size_t)u].data(); H.ac = m->ac[(size_t)u].data(); H.lm = m->lm[(size_t)u].data();
-            ++u;
+            ++seen;
         }
-    if (u != n_utts) return jd_fail(JD_EHIP, "jd_multi_decode_batch: %d records gathered for %d utterances", u, n_utts);
+    if (seen != n_utts) return jd_fail(JD_EHIP, "jd_multi_decode_batch: %d records gathered for %d utterances", seen, n_utts);
+    if (first_err) return jd_fail(first_err, "%s", first_msg.c_str());
     return JD_OK;
 }

@@ -62,6 +62,7 @@ struct DecConst {
     unsigned cap_slots, cap_items, cap_new; int cap_paths;
     int gc_threshold;   // a launch stops early (for the collection, k_gc_*) when more Path records than this are in use
     int x_chunks;       // phase X: chunks per wave the item lists are cut into (dynamic hand-out balances the arc walks)
+    int exp;            // development experiments (JD_EXP)
 };
 
 // An active arc instance (NetInst, WFSTDecoderLite.h:66-75) is a record of 16-byte fields: header
@@ -940,6 +941,12 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             return C.arcs[b];
         };
         if (lane < tot) Bk_nx = arc_at(b_nx);
+        // ... and so is its ArcState: the recombination atomic of the next pass then finds the line in the L2
+        // instead of being carried out at the memory side (measured, tools/traffic_probe: 16-17 G scattered
+        // atomics / s against 49 G scattered loads / s; the heavy workloads ran at 13-15 G atomics / s before
+        // this load went ahead of them: configs[1] -8 %, the configs[4] graph -17 %, configs[3] -19 %)
+        int lv_nx = 0;
+        if (lane < tot) lv_nx = CL(&V.ast[b_nx].live);
         XFINE(3);                                                      // prefix + hop 3: the first 64 arcs
 #pragma nounroll
         for (int a0 = 0; a0 < tot; a0 += 64) {
@@ -947,10 +954,12 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const int a = a0 + lane;
             const int g = g_nx, b = b_nx;
             const JdArc Bk = Bk_nx;
+            const int lv_pf = lv_nx;
             if (a0 + 64 < tot) {                                       // next pass's arc records: in flight during this one
                 g_nx = owner_of(a + 64);
                 b_nx = __shfl(alo, g_nx) + (a + 64 - wpfx[g_nx]);
                 if (a + 64 < tot) Bk_nx = arc_at(b_nx);
+                if (a + 64 < tot) lv_nx = CL(&V.ast[b_nx].live);
             }
             Tok tg;
             tg.score = __shfl(t.score, g); tg.ac = __shfl(t.ac, g);
@@ -975,7 +984,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             unsigned long long old = 0ULL, skc = 0ULL;
             float tmax = 0.0f;
             if (entry) {
-                lv = CL(&as->live);
+                lv = lv_pf;                                            // (read one pass ahead: nobody changes it during phase X except to 2, below)
                 old = GMAX(&as->key, ((unsigned long long)so << 32) | iig);
                 if (can_filter) tmax = C.hmm_tmax0[inl - 1];
             }

@@ -2,8 +2,10 @@
 
 Utterances are independent (the reference decodes them serially,
 DecoderBatchTest.cpp:738-771), so the batch is sharded across ranks with no
-data-path collective; the only exchange is ONE gather of fixed-size padded
-1-best records at the end (RCCL over xGMI on GPUs, gloo in the CPU tests).
+data-path collective - contiguously (weak scaling: every rank generates its own
+utterances) or balanced by length (shard_lpt: a fixed batch over N ranks); the
+only exchange is ONE gather of padded 1-best records at the end (RCCL over xGMI
+on GPUs, gloo in the CPU tests).
 """
 from __future__ import annotations
 
@@ -20,23 +22,42 @@ def shard_range(n_utts: int, rank: int, world: int):
     return lo, hi
 
 
-def pack_hyps(hyps: Sequence, max_words: int):
-    """Fixed-size records: ints [n, max_words*2 + 2], floats [n, max_words*3 + 3]."""
+def shard_lpt(n_frames: Sequence[int], world: int) -> List[List[int]]:
+    """Length-balanced shards: utterances by decreasing length, each to the rank with the fewest
+    frames so far (longest-processing-time-first; ties go to the rank with fewer utterances, then the lower rank).
+    Returns one list of utterance indices per rank, the same on every rank that calls it with the same lengths
+    (csrc/jd_multi.cpp deals a node's devices the same way).  A step lasts as long as its slowest rank:
+    contiguous shards differ by whatever their longest utterances differ."""
+    order = sorted(range(len(n_frames)), key=lambda u: (-int(n_frames[u]), u))
+    load = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for u in order:
+        r = min(range(world), key=lambda k: (load[k], len(out[k]), k))
+        out[r].append(u)
+        load[r] += max(int(n_frames[u]), 0) + 1
+    return out
+
+
+def pack_hyps(hyps: Sequence, max_words: int, truncate: bool = False):
+    """Fixed-size records: ints [n, max_words*2 + 2], floats [n, max_words*3 + 3].  truncate: a longer hypothesis
+    keeps its word count in the record and loses the words beyond max_words (gather_hyps then asks again)."""
     n = len(hyps)
     ints = np.zeros((n, 2 + 2 * max_words), dtype=np.int32)
     flts = np.zeros((n, 3 + 3 * max_words), dtype=np.float32)
     for i, h in enumerate(hyps):
         k = max(int(h.n), 0)
         if k > max_words:
-            raise ValueError("hypothesis with %d words exceeds the gather record (%d)" % (k, max_words))
+            if not truncate:
+                raise ValueError("hypothesis with %d words exceeds the gather record (%d)" % (k, max_words))
+            k = max_words
         ints[i, 0] = h.n
         ints[i, 1] = h.stats.get("n_frames", 0) if isinstance(h.stats, dict) else 0
-        ints[i, 2:2 + k] = h.label
-        ints[i, 2 + max_words:2 + max_words + k] = h.time
+        ints[i, 2:2 + k] = h.label[:k]
+        ints[i, 2 + max_words:2 + max_words + k] = h.time[:k]
         flts[i, 0:3] = (h.tot_score, h.tot_ac, h.tot_lm)
-        flts[i, 3:3 + k] = h.score
-        flts[i, 3 + max_words:3 + max_words + k] = h.ac
-        flts[i, 3 + 2 * max_words:3 + 2 * max_words + k] = h.lm
+        flts[i, 3:3 + k] = h.score[:k]
+        flts[i, 3 + max_words:3 + max_words + k] = h.ac[:k]
+        flts[i, 3 + 2 * max_words:3 + 2 * max_words + k] = h.lm[:k]
     return ints, flts
 
 
@@ -53,31 +74,53 @@ def unpack_hyps(ints: np.ndarray, flts: np.ndarray, max_words: int) -> List[dict
     return out
 
 
-def gather_hyps(hyps: Sequence, per_rank: int, max_words: int = 256, device=None) -> List[dict]:
-    """all_gather the 1-best records of every rank; returns them in global
-    utterance order.  Every rank contributes exactly `per_rank` records (pad
-    with n=-2 records when a shard is short)."""
+def gather_hyps(hyps: Sequence, per_rank: int, max_words: int = 256, device=None, index: Sequence[int] = None) -> List[dict]:
+    """all_gather the 1-best records of every rank - the ONE collective of a step.  Every rank contributes
+    exactly `per_rank` records (pad with n=-2 records when a shard is short).  A record holds max_words
+    words; a hypothesis that is longer travels truncated with its true word count, every rank sees that in
+    the gathered records and the gather is repeated once with records of that length (no hypothesis is ever
+    refused; an ordinary step is one collective).  index: the global utterance index of each of this rank's
+    hypotheses (shard_lpt) - the result is then in global utterance order; without it the result is rank
+    after rank (= global order for contiguous shards)."""
     import torch
     import torch.distributed as dist
-    ints, flts = pack_hyps(hyps, max_words)
-    if ints.shape[0] < per_rank:
-        pad = per_rank - ints.shape[0]
-        ints = np.concatenate([ints, np.full((pad, ints.shape[1]), 0, np.int32)])
-        ints[-pad:, 0] = -2
-        flts = np.concatenate([flts, np.zeros((pad, flts.shape[1]), np.float32)])
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        keep = ints[:, 0] != -2
-        return unpack_hyps(ints[keep], flts[keep], max_words)
-    world = dist.get_world_size()
-    ti = torch.from_numpy(ints)
-    tf = torch.from_numpy(flts)
-    if device is not None:
-        ti, tf = ti.to(device), tf.to(device)
-    li = [torch.empty_like(ti) for _ in range(world)]
-    lf = [torch.empty_like(tf) for _ in range(world)]
-    dist.all_gather(li, ti)          # the one collective of the whole path (RCCL over xGMI on GPUs)
-    dist.all_gather(lf, tf)
-    gi = torch.cat(li).cpu().numpy()
-    gf = torch.cat(lf).cpu().numpy()
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    max_words = max(1, int(max_words))
+    for attempt in range(2):
+        ints, flts = pack_hyps(hyps, max_words, truncate=True)
+        if index is not None:                           # (the index rides in a column of its own, behind the record)
+            ints = np.concatenate([ints, np.asarray(index, np.int32).reshape(-1, 1)], axis=1)
+        if ints.shape[0] < per_rank:
+            pad = per_rank - ints.shape[0]
+            ints = np.concatenate([ints, np.full((pad, ints.shape[1]), 0, np.int32)])
+            ints[-pad:, 0] = -2
+            flts = np.concatenate([flts, np.zeros((pad, flts.shape[1]), np.float32)])
+        if multi:
+            world = dist.get_world_size()
+            ti = torch.from_numpy(ints)
+            tf = torch.from_numpy(flts).view(torch.int32)          # one collective: the float words ride behind the int words
+            t = torch.cat([ti, tf], dim=1).contiguous()
+            if device is not None:
+                t = t.to(device)
+            lt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(lt, t)                                 # RCCL over xGMI on GPUs
+            g = torch.cat(lt).cpu()
+            gi = g[:, :ints.shape[1]].numpy()
+            gf = g[:, ints.shape[1]:].contiguous().view(torch.float32).numpy()
+        else:
+            gi, gf = ints, flts
+        longest = int(gi[:, 0].max()) if gi.shape[0] else 0
+        if longest <= max_words:
+            break
+        max_words = longest                                        # (the same decision on every rank: all see the same records)
     keep = gi[:, 0] != -2
-    return unpack_hyps(gi[keep], gf[keep], max_words)
+    gi, gf = gi[keep], gf[keep]
+    out = unpack_hyps(gi, gf, max_words)
+    if index is not None:
+        ordered = [None] * len(out)
+        for h, u in zip(out, gi[:, -1]):
+            ordered[int(u)] = h
+        if any(h is None for h in ordered):
+            raise ValueError("gathered records do not cover utterances 0..%d" % (len(out) - 1))
+        out = ordered
+    return out

@@ -199,11 +199,57 @@ def test_adapter_compiles_inside_the_juicer_tree():
                            os.path.join(mock, "adapter_in_tree.cpp")])
     subprocess.check_call(["g++", "-std=c++98", "-Wall", "-fsyntax-only", "-I", mock, "-I", inc, "-x", "c++",
                            "-include", "Decoder.h", os.path.join(inc, "juicer_amd_decoder.hpp")])   # Juicer is C++98-era
+    # ... and with WFSTNetwork.h / HTKFlatModels.h in front of it as well: the exact-signature constructor and its bridge
+    subprocess.check_call(["g++", "-std=c++98", "-Wall", "-fsyntax-only", "-I", mock, "-I", inc, "-x", "c++", "-include", "Decoder.h",
+                           "-include", "WFSTNetwork.h", "-include", "HTKFlatModels.h", os.path.join(inc, "juicer_amd_decoder.hpp")])
     with tempfile.NamedTemporaryFile("w", suffix=".cpp") as f:
         f.write('#include "juicer_amd_decoder.hpp"\nJuicerAmd::IDecoder *p = 0;\n'
                 'int main() { return DHHTYPE == 1 ? 0 : 1; }\n')          # DecHypHistPool.h:106
         f.flush()
         subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, f.name])
+
+
+def test_exact_signature_seam_round_trip(built, tmp_path):
+    """`GpuWFSTDecoder(WFSTNetwork*, IModels*, real, real, real, real, int)` - WFSTDecoderLite's own constructor
+    signature (WFSTDecoderLite.h:81-89, call site juicer.cpp:582-586) - walks the objects juicer.cpp has already built
+    into the C ABI through WFSTNetwork's public getters (WFSTNetwork.h:129-167) and HTKFlatModels' tables.  Here the
+    walk is RUN (no GPU: netFromJuicer / modelsFromJuicer only) against mocks of those declarations
+    (tests/mock_juicer/) filled from a synthetic case, and what the C ABI then holds must be the same arrays, bit
+    for bit - with and without the 4-aligned vector stride of OPT_ALIGN4 (HTKFlatModels.cpp:117-125)."""
+    import subprocess
+    from bridge_helper import build_program, read_arrays, write_case
+    from juicer_amd import capi, synth
+    exe = build_program(tmp_path)
+    am, net, feats, _ = synth.config_mixed(n_utts=1)                  # 3..8-state HMMs, skips, a tee model
+    gnet, gam = capi.Network.from_synth(net, 7.5, -2.0), capi.Models.from_htk(am)
+    for pad in (0, 1):
+        write_case(tmp_path / "case.bin", gnet, gam, feats[0], (0.0, 150.0, 0.0, 0.0, 0.0), pad=pad)
+        subprocess.check_call([exe, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")])
+        i4, f4, i2 = np.int32, np.float32, np.int16
+        (meta, row, to, w, il, ol, fin, nm, det, mean, ivar, hn, hg, ht, tee, trP, se) = read_arrays(
+            tmp_path / "out.bin", [i4, i4, i4, f4, i4, i4, f4, i4, f4, f4, f4, i4, i4, i4, f4, f4, i2])
+        c = gnet.csr()
+        assert meta.tolist() == [gnet.n_states, gnet.init_state, gam.n_gmms, gam.max_mix, gam.n_hmms, gam.max_states, gam.n_tm, gam.vec_size]
+        for got, want in ((row, c["row_ptr"]), (to, c["to"]), (il, c["ilab"]), (ol, c["olab"])):
+            assert np.array_equal(got, want)
+        assert np.array_equal(w.view(np.uint32), c["w"].view(np.uint32))
+        assert np.array_equal(np.isfinite(fin), np.isfinite(c["fin_w"])) and np.array_equal(fin[np.isfinite(fin)], c["fin_w"][np.isfinite(fin)])
+        hn0, hg0, ht0, nm0 = gam.topology()
+        det0, mean0, ivar0 = gam.flat()
+        trP0, se0, tee0 = gam.trans()
+        assert np.array_equal(nm, nm0) and np.array_equal(hn, hn0) and np.array_equal(ht, ht0)
+        for h in range(gam.n_hmms):                                    # (entry / exit slots carry no tied state)
+            assert np.array_equal(hg.reshape(hg0.shape)[h, 1:hn0[h] - 1], hg0[h, 1:hn0[h] - 1])
+        for g in range(gam.n_gmms):
+            k = nm0[g]
+            assert np.array_equal(det.reshape(det0.shape)[g, :k].view(np.uint32), det0[g, :k].view(np.uint32))
+            assert np.array_equal(mean.reshape(mean0.shape)[g, :k].view(np.uint32), mean0[g, :k].view(np.uint32))
+            assert np.array_equal(ivar.reshape(ivar0.shape)[g, :k].view(np.uint32), ivar0[g, :k].view(np.uint32))
+        assert np.array_equal(tee.view(np.uint32), tee0.view(np.uint32))
+        for t in np.unique(ht0):
+            n = int(hn0[np.nonzero(ht0 == t)[0][0]])
+            assert np.array_equal(trP.reshape(trP0.shape)[t, :n, :n].view(np.uint32), trP0[t, :n, :n].view(np.uint32))
+            assert np.array_equal(se.reshape(se0.shape)[t, 1:n], se0[t, 1:n])
 
 
 def test_csr_input_is_validated(built):

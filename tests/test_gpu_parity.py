@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import assert_hyp_matches, bit_exact
+from helpers import assert_hyp_matches, bit_exact, rel_close
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +45,7 @@ def test_gmm_kernel_matches_oracle(small):
     frac = diff.mean()
     ulp = np.abs(g.view(np.int32).astype(np.int64) - o.view(np.int32).astype(np.int64)).max()
     print("gmm mismatches: %d of %d (max ulp %d)" % (diff.sum(), diff.size, ulp))
-    assert ulp <= 1 and frac <= 1e-5
+    assert ulp == 0 and frac == 0.0                       # bit for bit: a 1-ulp likelihood can flip a threshold decision
 
 
 def test_gmm_kernel_generic_dim(built):
@@ -914,3 +914,25 @@ def test_hybrid_models(built):
             assert_hyp_matches(gd.stream_finish(0), od.decode_certified(feats[0]), "hybrid streaming")
     with pytest.raises(capi.JuicerAmdError):
         capi.Models.from_hybrid(am.priors, 2)                        # statesPerModel <= 2 (HTKModels.cpp:82-83)
+
+
+def test_exact_signature_constructor_decodes(small, tmp_path):
+    """The drop-in line itself: `decoder = new GpuWFSTDecoder(network, models, phoneStartBeam, mainBeam, phoneEndBeam,
+    wordEmitBeam, maxHyps)` with a Juicer::WFSTNetwork* and a Juicer::IModels* (WFSTDecoderLite.h:81-89,
+    juicer.cpp:582-586), driven frame by frame with the look-ahead protocol of DecoderSingleTest.cpp:267-295, compiled
+    against mocks of the reference's declarations (tests/mock_juicer/): the DecHyp chain equals the oracle's."""
+    import subprocess
+    from bridge_helper import build_program, read_arrays, write_case
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    exe = build_program(tmp_path)
+    beams = dict(start_beam=120.0, main_beam=150.0, end_beam=100.0, word_beam=80.0, max_hyps=200)
+    od = OracleDecoder(onet, oam, **beams)
+    for u in (0, 1):
+        write_case(tmp_path / "case.bin", gnet, gam, feats[u], (beams["start_beam"], beams["main_beam"], beams["end_beam"],
+                                                               beams["word_beam"], beams["max_hyps"]), pad=u)
+        subprocess.check_call([exe, str(tmp_path / "case.bin"), str(tmp_path / "out.bin"), "decode"], timeout=240)
+        lab, tim, sc, tot = read_arrays(tmp_path / "out.bin", [np.int32, np.int32, np.float32, np.float32])
+        o = od.decode(feats[u])
+        assert o.n > 0 and lab.tolist() == o.label.tolist() and tim.tolist() == o.time.tolist()
+        assert rel_close(sc, o.score) and rel_close(tot, [o.tot_score, o.tot_ac, o.tot_lm])

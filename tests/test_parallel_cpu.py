@@ -19,13 +19,20 @@ def _worker(rank, world, port, n_utts, q):
     from juicer_amd import parallel, synth
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
     am, net, feats, _ = synth.config_small(n_utts=n_utts)
-    lo, hi = parallel.shard_range(n_utts, rank, world)
     od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=150.0)   # stand-in producer of hyps on CPU
+    ser = lambda hs: [(h["n"], h["label"].tolist(), h["time"].tolist(), float(h["tot_score"])) for h in hs]
+    # contiguous shards (weak scaling: every rank brings its own utterances)
+    lo, hi = parallel.shard_range(n_utts, rank, world)
     mine = [od.decode(feats[u]) for u in range(lo, hi)]
     per_rank = (n_utts + world - 1) // world
     allh = parallel.gather_hyps(mine, per_rank, max_words=64)
+    # length-balanced shards of one fixed batch (BASELINE.json configs[2]); records of 3 words, so that the longer
+    # hypotheses force the gather to be repeated with longer records
+    shards = parallel.shard_lpt([f.shape[0] for f in feats], world)
+    mine = [od.decode(feats[u]) for u in shards[rank]]
+    balanced = parallel.gather_hyps(mine, max(len(x) for x in shards), max_words=3, index=shards[rank])
     if rank == 0:
-        q.put([(h["n"], h["label"].tolist(), h["time"].tolist(), float(h["tot_score"])) for h in allh])
+        q.put((ser(allh), ser(balanced)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,14 +73,35 @@ def test_gather_world_size_2(built):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_utts, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got, balanced = q.get(timeout=120)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     am, net, feats, _ = synth.config_small(n_utts=n_utts)
     od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=150.0)
     want = [od.decode(f) for f in feats]
-    assert len(got) == n_utts
-    for g, w in zip(got, want):
-        assert g[0] == w.n and g[1] == w.label.tolist() and g[2] == w.time.tolist()
-        assert g[3] == pytest.approx(w.tot_score, rel=1e-6)
+    assert max(w.n for w in want) > 3                                # (the balanced gather had to ask twice)
+    for res in (got, balanced):
+        assert len(res) == n_utts
+        for g, w in zip(res, want):
+            assert g[0] == w.n and g[1] == w.label.tolist() and g[2] == w.time.tolist()
+            assert g[3] == pytest.approx(w.tot_score, rel=1e-6)
+
+
+def test_length_balanced_shards():
+    """shard_lpt: every utterance exactly once, and the heaviest rank carries at most the lightest one's frames plus
+    one utterance (the longest-processing-time-first bound)."""
+    from juicer_amd import parallel
+    rng = np.random.default_rng(3)
+    for n, w in ((0, 2), (1, 4), (7, 3), (64, 8), (512, 8)):
+        T = rng.integers(300, 1001, size=n).tolist()
+        sh = parallel.shard_lpt(T, w)
+        assert sorted(u for s in sh for u in s) == list(range(n)) and len(sh) == w
+        load = [sum(T[u] for u in s) for s in sh]
+        if n >= w:
+            assert max(load) - min(load) <= max(T)
+    # contiguous shards of the same 512 utterances are far worse balanced than the dealt ones
+    T = rng.integers(300, 1001, size=512).tolist()
+    lpt = [sum(T[u] for u in s) for s in parallel.shard_lpt(T, 8)]
+    cont = [sum(T[slice(*parallel.shard_range(512, r, 8))]) for r in range(8)]
+    assert max(lpt) - min(lpt) < max(cont) - min(cont)
