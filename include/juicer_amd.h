@@ -270,9 +270,11 @@ int jd_dec_set_capacity(jd_dec *d, int64_t max_slots, int64_t max_paths, int64_t
 /* WFSTDecoderLite::setMaxAllocModels (WFSTDecoderLite.cpp:807-820; environment variable
  * MaxAllocModels, default 10, :73-74), same argument convention: < 100 a percentage of the network's
  * transitions, 100..7999 a memory limit in MB (of 40 + 24 * maxNStates bytes per instance), otherwise
- * a number of instances.  The reference drops its cached NetInst objects between utterances when
- * more than this many are allocated (:164-169); here it sizes the per-stream arena of instance
- * records (equivalent to jd_dec_set_capacity's max_slots).  Before the first decode. */
+ * a number of instances.  A SOFT limit, as in the reference, which drops its cached NetInst objects
+ * between utterances when more than this many are allocated (:164-169) and never fails a decode
+ * because of it: here nothing is cached between utterances (one arena of records per stream, reused
+ * wholesale), so the value can only RAISE that arena above its automatic size, never lower it - a
+ * hard capacity is jd_dec_set_capacity's max_slots.  Before the first decode. */
 int jd_dec_set_max_alloc_models(jd_dec *d, int32_t max_alloc_models);
 
 /* IDecoder::init() (Decoder.h:26) for stream s. */

@@ -849,6 +849,7 @@ struct jd_dec {
     std::vector<void *> allocs;
     bool arenas_ready = false;
     int64_t cap_slots = 0, cap_paths = 0, cap_items = 0, cap_new = 0;
+    int64_t slots_hint = 0;               // jd_dec_set_max_alloc_models
     int res_cap = 8192;
     int *d_res = nullptr;                 // result arena, see ensure_arenas
     int n_cus = 256;
@@ -1090,20 +1091,23 @@ extern "C" int jd_dec_set_capacity(jd_dec *d, int64_t max_slots, int64_t max_pat
 }
 
 // setMaxAllocModels (WFSTDecoderLite.cpp:807-820): same argument convention - below 100 a percentage
-// of the network's transitions, 100..7999 a memory limit in MB, from 8000 a number of instances.  The
-// reference compares it with the NetInst objects its pools have handed out and drops them all between
-// two utterances when there are more (:164-169) - a cap on what stays cached, never an error.  Here
-// instance memory is one arena of records per stream, reused wholesale by every utterance: the limit
-// sizes that arena (a stream that needs more live instances in one frame fails with JD_ENOMEM).
+// of the network's transitions, 100..7999 a memory limit in MB, from 8000 a number of instances.  In the
+// reference it is a SOFT limit: it is compared with the NetInst objects the pools have handed out, and when there
+// are more they are all dropped between two utterances (:164-169) - a cap on what stays cached, never a
+// reason for a decode to fail.  Here instance memory is one arena of records per stream that every utterance
+// reuses wholesale, so nothing is cached from one utterance to the next and there is nothing to drop: the value
+// is validated and kept as a hint that can only RAISE the arena above its automatic size (a caller who asks
+// for room for more instances gets it), never lower it.  A hard capacity is jd_dec_set_capacity's business.
 extern "C" int jd_dec_set_max_alloc_models(jd_dec *d, int32_t max_alloc_models)
 {
     if (!d || max_alloc_models <= 0) return jd_fail(JD_EINVAL, "setMaxAllocModels: maxAllocModels > 0");
     if (d->arenas_ready) return jd_fail(JD_ESTATE, "jd_dec_set_max_alloc_models: arenas already allocated");
     int64_t n;
+    // (a lazily composed network's n_arcs is the capacity it may grow into: the most it can ever hold)
     if (max_alloc_models < 100) n = d->net->n_arcs * max_alloc_models / 100;                        // :809-811
     else if (max_alloc_models < 8000) n = (int64_t)max_alloc_models * 1024 * 1024 / (40 + 24 * (int64_t)d->am->max_n);   // :812-814, sizeof(NetInst) + sizeof(Token) * nStatePools
     else n = max_alloc_models;                                                                       // :815-817
-    d->cap_slots = std::max<int64_t>(std::min<int64_t>(n, d->net->n_arcs + 65536), 64 * SW);   // (one instance per arc at most)
+    d->slots_hint = std::min<int64_t>(n, d->net->n_arcs + 65536);      // (one instance per arc at most)
     return JD_OK;
 }
 
@@ -1154,7 +1158,10 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
             return std::max<int64_t>(std::min<int64_t>(hi, (int64_t)share), std::min(lo, hi));
         };
         const int64_t lim_rec = (0xe0000000LL / (2 * rec_bytes)) & ~63LL, lim_item = 0xe0000000LL / 64;
-        if (d->cap_slots <= 0) d->cap_slots = pick(0.5 * budget / rec_b, 1 << 19, std::min<int64_t>(d->net->n_arcs + 65536, lim_rec));
+        if (d->cap_slots <= 0) {
+            d->cap_slots = pick(0.5 * budget / rec_b, 1 << 19, std::min<int64_t>(d->net->n_arcs + 65536, lim_rec));
+            if (d->slots_hint > d->cap_slots) d->cap_slots = std::min<int64_t>(d->slots_hint, lim_rec);   // setMaxAllocModels: more room, never less
+        }
         if (d->cap_items <= 0) d->cap_items = pick(0.2 * budget / item_b, 1 << 21, std::min<int64_t>(std::max<int64_t>(2 * d->net->n_arcs + 65536, 1 << 21), lim_item));
         // (records and items stop at their addressing limits: what they leave of the budget goes to the Path
         // records - every collection of those is a stop of the stream's launch - up to 16 per arc of the

@@ -737,8 +737,9 @@ def test_partial_decoding_schedule(small):
 
 
 def test_max_alloc_models(small):
-    """setMaxAllocModels (WFSTDecoderLite.cpp:807-820): percentage / MB / count forms size the
-    instance-record arena; results do not depend on it, and too small a limit is a named JD_ENOMEM."""
+    """setMaxAllocModels (WFSTDecoderLite.cpp:807-820) is a SOFT limit in the reference (it decides whether cached
+    NetInst objects are dropped between utterances, :164-169): whatever its value - percentage / MB / count form,
+    generous or tiny - results do not depend on it and no decode fails because of it."""
     from juicer_amd import capi, synth
     from oracle.oracle import OracleDecoder
     gnet, gam, onet, oam, feats, _ = small
@@ -752,12 +753,15 @@ def test_max_alloc_models(small):
         assert_hyp_matches(gd.decode_batch(feats[:1])[0], want, "MaxAllocModels %d" % v)
         with pytest.raises(capi.JuicerAmdError):                        # only before the arenas exist
             gd.set_max_alloc_models(v)
-    gd = capi.Decoder(gnet, gam, max_streams=1)                         # no beam: an instance on most arcs
-    gd.set_max_alloc_models(60)                                         # 60 % of the arcs (:809-811)
-    with pytest.raises(capi.JuicerAmdError) as ei:
-        gd.decode_batch(feats[:1])
-    assert ei.value.code == capi.JD_ENOMEM and "instance slots" in str(ei.value)
-    assert "capacity %d," % ((n_arcs * 60 // 100) & ~63) in str(ei.value), str(ei.value)
+    # the reference's default (MaxAllocModels = 10: 10 % of the transitions, WFSTDecoderLite.cpp:73) with NO beam - an
+    # instance on most arcs, far more than the limit: the reference decodes that, so does this
+    od0 = OracleDecoder(onet, oam)
+    want0 = od0.decode_certified(feats[0])
+    for v in (10, 1):
+        gd = capi.Decoder(gnet, gam, max_streams=1)
+        gd.set_max_alloc_models(v)
+        assert_hyp_matches(gd.decode_batch(feats[:1])[0], want0, "MaxAllocModels %d, no beam" % v)
+    assert n_arcs > 0
     with pytest.raises(capi.JuicerAmdError):
         capi.Decoder(gnet, gam, max_streams=1).set_max_alloc_models(0)  # assert(maxAllocModels_ > 0) :808
 
