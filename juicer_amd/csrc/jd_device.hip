@@ -569,8 +569,9 @@ __device__ __forceinline__ void jd_for_each_tip(const DecConst &C, const StreamC
     const int nw = c.lst_nw;
     const Geo g = make_geo(C, nw);
     const int p = c.frame & 1;
-    auto entry_tip = [&](int arc) -> int {
-        const unsigned long long kv = S.ast[arc].key;
+    // the pending entry token of the arcs leaving state st: the best token that arrived there in the last frame
+    auto entry_tip = [&](int st) -> int {
+        const unsigned long long kv = S.srec[st].e[p ^ 1];
         if (kv == 0ULL) return -1;
         return S.items[2 * ((size_t)(p ^ 1) * C.cap_items + (size_t)(kv & 0xffffffffULL))].w;
     };
@@ -580,18 +581,30 @@ __device__ __forceinline__ void jd_for_each_tip(const DecConst &C, const StreamC
         for (int q = lane; q < n_rec; q += 64) {
             const char *r = seg + (size_t)(q >> 6) * RL::CHUNK_BYTES + (size_t)(q & 63) * 16;
             const int4 h0 = *(const int4 *)r;
-            int tip = entry_tip(h0.x);
+            int tip = entry_tip(h0.z);                                  // (h0.z: the source state of the instance's arc)
             const int n = h0.y & 0xff;
             for (int j = 1; j <= NE && tip < 0; ++j)
                 if (j < n - 1) tip = ((const int4 *)(r + (size_t)(RL::HF + j - 1) * 1024))->w;
             f(tip);
         }
-        const int n_new = min(S.tot[(size_t)TOT_NEW * MAXW + w], (int)g.seg_new);
-        for (int q = lane; q < n_new; q += 64) f(entry_tip(S.newl[(size_t)w * g.seg_new + q]));
-        const int n_cl = min(S.tot[(size_t)TOT_CLEAN * MAXW + w], (int)g.seg_new);
-        for (int q = lane; q < n_cl; q += 64) {
-            const int b = S.cleanl[(size_t)w * g.seg_new + q];
-            if (S.ast[b].live != 2) f(entry_tip(b));                    // (2: a later candidate put it on the new list)
+    }
+    // ... and the arcs entered in the last frame that have no record yet (the reference attached an instance to every
+    // one of them, hopeless or not): all of them hold the token that arrived at their source state, so every state
+    // of the last frame's dirty list that has an arc with a model is one tip
+    const int dn = c.dirty_nw[p ^ 1];
+    const Geo gd = make_geo(C, dn > 0 ? dn : nw);
+    const int *dl = S.dirtyl + (size_t)(p ^ 1) * C.cap_new;
+    for (int w = wid; w < gd.nw; w += 16) {
+        const int n_d = min(S.tot[(size_t)(TOT_DIRTY0 + (p ^ 1)) * MAXW + w], (int)gd.seg_new);
+        for (int q = lane; q < n_d; q += 64) {
+            const int st = dl[(size_t)w * gd.seg_new + q];
+            bool has_model = false;
+            if (C.lazy) {
+                const int4 row = C.lazy->rows[st];
+                for (int a = row.x; a < row.x + row.y && !has_model; ++a) has_model = (C.lazy->arcs[a].in & ~TEE_FLAG) != 0;
+            } else
+                for (int a = C.row_ptr[st]; a < C.row_ptr[st + 1] && !has_model; ++a) has_model = (C.arcs[a].in & ~TEE_FLAG) != 0;
+            if (has_model) f(entry_tip(st));
         }
     }
 }
@@ -1111,29 +1124,19 @@ extern "C" int jd_dec_set_max_alloc_models(jd_dec *d, int32_t max_alloc_models)
     return JD_OK;
 }
 
-// reset a stream's per-state records: no bids; the CSR row of the state (row_ptr == nullptr: a lazy graph, rows live elsewhere)
+// reset a stream's per-state records: no bids, no arrivals; the CSR row of the state (row_ptr == nullptr: a lazy
+// graph, rows live elsewhere)
 __global__ void jd_reset_srec_kernel(StateRec *srec, const int *row_ptr, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const int rs = row_ptr ? row_ptr[i] : 0, cnt = row_ptr ? row_ptr[i + 1] - rs : 0;
-        srec[i] = StateRec{0ULL, 0ULL, 0ULL, rs, cnt};
+        srec[i] = StateRec{0ULL, 0ULL, {0ULL, 0ULL}, rs, cnt, {0, 0, 0, 0, 0, 0}};
     }
 }
 static void reset_srec(StateRec *srec, const int *d_row_ptr, int64_t n_states)
 {
     hipLaunchKernelGGL(jd_reset_srec_kernel, dim3((unsigned)((n_states + 255) / 256)), dim3(256), 0, 0, srec, d_row_ptr, (long long)n_states);
-}
-
-// reset a stream's per-arc search state: no candidate, no instance
-__global__ void jd_reset_ast_kernel(ArcState *ast, long long n)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ast[i] = ArcState{0ULL, 0, 0};
-}
-static void reset_ast(ArcState *ast, int64_t n_arcs)
-{
-    hipLaunchKernelGGL(jd_reset_ast_kernel, dim3((unsigned)((n_arcs + 255) / 256)), dim3(256), 0, 0, ast, (long long)n_arcs);
 }
 
 static int ensure_arenas_try(jd_dec *d, double mem_fraction)
@@ -1150,7 +1153,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const double n_arcs = (double)d->net->n_arcs, n_states = (double)d->net->n_states;
-        const double fixed = n_arcs * sizeof(ArcState) + n_states * (double)sizeof(StateRec) + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
+        const double fixed = n_arcs * 1.0 + n_states * (double)sizeof(StateRec) + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
         const double budget = std::max(0.0, mem_fraction * (double)free_b / B - fixed);
         const double rec_b = 2.0 * rec_bytes, item_b = 2.0 * (sizeof(Tok) + sizeof(int4)) + 32.0;
         const double path_b = 2.0 * sizeof(PathRec) + 4.0;
@@ -1199,10 +1202,10 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
                      if (blk) (p) = (typename std::remove_reference<decltype(p)>::type)(blk + off); off += bytes_; } while (0)
 #define ARENAS() do { \
         A(S.rec, 2 * d->cap_slots * (rec_bytes / 4)); \
-        A(S.ast, d->net->n_arcs); \
+        A(S.live, d->net->n_arcs); \
         A(S.srec, d->net->n_states); \
         A(S.items, 4 * d->cap_items); \
-        A(S.newl, d->cap_new); A(S.cleanl, d->cap_new); A(S.dirtyl, d->cap_new); \
+        A(S.newl, d->cap_new); A(S.dirtyl, 2 * d->cap_new); \
         A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW); \
         A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths); A(S.gc_state, sizeof(GcState) / 4); \
         A(S.hist, 2 * HIST_MAX_BINS); } while (0)
@@ -1221,7 +1224,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
 #undef ARENAS
 #undef A
         S.res_cap = d->res_cap;
-        reset_ast(S.ast, d->net->n_arcs);
+        HIPCHK(hipMemset(S.live, 0, (size_t)d->net->n_arcs));          // per arc: no instance
         reset_srec(S.srec, d->d_row_ptr, d->net->n_states);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemset(S.hist, 0, 2 * HIST_MAX_BINS * sizeof(int)));
@@ -1345,7 +1348,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
             }
         }
         if (K.error) {      // arenas may be inconsistent after an abort: wipe them for the next init
-            reset_ast(S.ast, d->net->n_arcs);
+            HIPCHK(hipMemset(S.live, 0, (size_t)d->net->n_arcs));
             reset_srec(S.srec, d->d_row_ptr, d->net->n_states);
             HIPCHK(hipDeviceSynchronize());
             HIPCHK(hipMemset(S.tot, 0, TOT_N * MAXW * sizeof(int)));

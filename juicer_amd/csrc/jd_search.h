@@ -12,20 +12,21 @@
 // chains):
 //
 //   phase A  HMM-internal propagation of every active arc instance AND of every arc that was
-//            first entered in the previous frame.  An instance pulls its entry token itself: the
-//            previous frame's expansion left the best candidate of each arc in a 64-bit key
-//            (ordered score << 32 | frontier item) - so there is no separate "resolve" pass, and a
-//            new instance is only ever written if something in it survives its first frame.
-//   phase X  frontier expansion (propagateToken): exit tokens; the epsilon / tee closure of what a
-//            wave produces is expanded by that wave right away (a per-wave queue in LDS; what does
-//            not fit goes to a further round behind a barrier), atomic-max recombination into the
-//            per-arc keys.
+//            first entered in the previous frame.  An instance PULLS its entry token itself: the
+//            previous frame's expansion left the best token that arrived at each STATE in a 64-bit
+//            key (ordered score << 32 | frontier item), and all tokens at a state add the same arc
+//            weight - so there is no separate "resolve" pass, no per-arc word is ever written, and
+//            a new instance is only ever written if something in it survives its first frame.
+//   phase X  frontier expansion (propagateToken): exit tokens and the epsilon / tee closure of what
+//            a wave produces (expanded by that wave right away: a per-wave queue in LDS; what does
+//            not fit goes to a further round behind a barrier) ARRIVE at their states - one atomic
+//            max per arrival on the state's key is the whole Viterbi recombination (:560-582).
 //
 // No list is shared for appending: every wave owns a segment of each output list (instance
 // records, frontier items, newly entered arcs) and publishes its fill count at the end of the
 // phase; readers turn the counts into a prefix over fixed-size chunks and take chunks
 // round-robin, so reading is balanced whatever the writers did.  The only returning atomics left
-// are the per-arc recombination (first-touch detection) and the Path-record reservation.
+// are the arrivals (one per token and state, not per arc) and the Path-record reservation.
 //
 // Memory model (MI355X_MICROARCH.md, inter-workgroup visibility): every mutable per-stream word
 // is written with agent-scope (sc1, write-through) stores or atomics and read with sc1 loads, which
@@ -67,11 +68,11 @@ struct DecConst {
 
 // An active arc instance (NetInst, WFSTDecoderLite.h:66-75) is a record of 16-byte fields: header
 // (arc, topology, tied-state ids, arc weight) + the tokens of its emitting states.  Entry and exit
-// tokens are never stored: the entry token is pulled from the arc's key in phase A, the exit token
+// tokens are never stored: the entry token is pulled from the source state's arrival key in phase A, the exit token
 // is consumed by phase X of the same frame (:964).  ONE LANE owns one instance, so records are
 // stored in chunks of 64 as structure-of-arrays: field f of record l of a chunk sits at byte
 // f * 1024 + l * 16 of the chunk - every load / store of a wave covers 1 KiB of consecutive bytes.
-//   field 0 = arc, nStates | transMat << 8, outLabel, toState
+//   field 0 = arc, nStates | transMat << 8 | REC_LABELLED, source state, destination state
 //   field 1 = g0, g1, g2, arc weight          (tied-state ids of emitting states 1..3)
 //   NE == 6: field 2 = g3, g4, g5, -
 //   then one field per emitting state: its token
@@ -83,20 +84,23 @@ template <int NE> struct RecLayout {
     static constexpr int CHUNK_BYTES = FIELDS * 1024;  // 64 records
 };
 #define OOB_OFF 0xf0000000u          // byte offset beyond every arena: buffer loads return 0, stores are dropped
+#define REC_LABELLED 0x40000000      // bit 30 of a record's second header word: the instance's arc carries a word label
 
-// per-state search state, ONE 32-byte record (half a 64-byte sector) so that everything an exit token or a
-// closure item needs of its state arrives with one memory transaction: the three recombination keys and the
-// state's CSR row.  (Round 2 kept them in four arrays: three sectors fetched, two written back, per token.)
+// per-state search state, ONE 64-byte record (one memory sector) so that everything a token needs of the state it
+// arrives at comes with one transaction: the recombination keys and the state's CSR row.
 //   key0  best exit token arriving at the state this frame (bid in phase A, reset by its winner in phase X)
 //   keyL  ... among the tokens whose arc carries a word label (own threshold, :952-962)
-//   keyC  best closure item so far (running maximum, zeroed through the dirty list)
+//   e[p]  best ARRIVAL at the state in a frame of parity p: (ordered score << 32) | frontier item.  Every token that
+//         reaches the state in phase X - exit tokens past their threshold, epsilon / tee closure items - raises it
+//         with an atomic max; it is what the arcs leaving the state PULL their entry tokens from in the next frame's
+//         phase A (all arrivals at a state add the same arc weight and float addition is monotone, so the best arrival
+//         is the best candidate of every out-arc: propagateToken's per-arc comparison :560-582, done once per state).
+//         Frame f writes e[f & 1], frame f + 1 reads it, frame f + 2 zeroes it through the dirty list of that parity.
 //   rs, cnt  first out-arc and out-degree (a per-stream copy of row_ptr; unused on lazy graphs, whose rows grow)
-struct __align__(32) StateRec { unsigned long long key0, keyL, keyC; int rs, cnt; };
-
-// per-arc search state: recombination key of this frame + "an instance of this arc is in the list"
-//   live: 0 = no instance, 1 = an instance of this arc is in the list, 2 = no instance yet but the arc
-//         is on the new list of this frame (it will be tried in the next phase A)
-struct __align__(16) ArcState { unsigned long long key; int live; int pad; };
+// Round 2 kept one 16-byte {key, flag} record per ARC instead: an atomic, a poll and a reset per visited arc and frame,
+// each a 64-byte sector for 8 useful bytes - the memory side carried out 13-15 G atomics / s on the heavy workloads,
+// about what it can do (tools/traffic_probe: 16-17 G / s).
+struct __align__(64) StateRec { unsigned long long key0, keyL, e[2]; int rs, cnt; int pad[6]; };
 
 // per-stream scalars.  Line 0 is written by the host-side helper kernels and by workgroup 0 of the
 // stream's cluster at the END of a launch (nobody reads it while a launch runs, except at its
@@ -108,7 +112,8 @@ struct __align__(128) StreamCtl {
     int lst_nw;         // number of wave segments the current lists were written with
     int n_rec_hint;     // instances in the current list (statistics / capacity planning only)
     float best_emit;    // bestEmitScore left by the last processed frame (:321)
-    int pad0[24];
+    int dirty_nw[2];    // number of wave segments the dirty list of each frame parity was written with (it lives two frames)
+    int pad0[22];
     __align__(128) int new_all[2];           // arcs entered without an instance in a frame of that parity (listed or not)
     __align__(128) unsigned bar;             // cluster barrier (zeroed by the host before every launch)
     __align__(128) unsigned xbar, xmask;     // placement handshake of an XCD-local launch (agent scope; zeroed with bar)
@@ -124,14 +129,14 @@ struct __align__(128) StreamCtl {
 
 struct StreamDev {      // per-stream arenas
     int *rec;                         // instance records, [2][cap_slots] by frame parity: list f&1 is read by frame f
-    ArcState *ast;                    // per ARC
+    unsigned char *live;              // per ARC: 1 = an instance of this arc is in the list (set at its birth, cleared at its death)
     StateRec *srec;                   // per STATE: recombination keys + the CSR row (see StateRec)
     int4 *items;                      // frontier items of a frame, [2][cap_items] by frame parity: 32 bytes each,
                                       // token + {arc, out, to, flag}; flag 1 = a closure item that needs no
                                       // expansion in a later round (done by its producer, or superseded)
-    int *newl;                        // arcs entered this frame that have no instance and may survive the next frame
-    int *cleanl;                      // arcs entered this frame whose first candidate was hopeless (key clean-up, see phase X)
-    int *dirtyl;                      // states whose closure key (StateRec::keyC) became non-zero this frame
+    int2 *newl;                       // {arc, source state}: arcs without an instance whose source state received a token this
+                                      // frame that may survive the next one (they are tried in the next phase A)
+    int *dirtyl;                      // [2][cap_new] by frame parity: states whose e[parity] became non-zero in that frame
     int *tot;                         // published per-wave fill counts, TOT_N arrays of MAXW
     int *item_end;                    // per wave: items written in the last processed frame (k_gc_*)
     PathRec *paths; int *hist;        // hist: [2][HIST_MAX_BINS] by frame parity
@@ -140,7 +145,7 @@ struct StreamDev {      // per-stream arenas
     // result of jd_finish_kernel
     int res_n; int *res_label; int *res_time; float *res_score, *res_ac, *res_lm; int res_cap;
 };
-enum { TOT_REC0 = 0, TOT_REC1 = 1, TOT_NEW = 2, TOT_CLEAN = 3, TOT_DIRTY = 4, TOT_EXIT = 5,
+enum { TOT_REC0 = 0, TOT_REC1 = 1, TOT_NEW = 2, TOT_DIRTY0 = 3, TOT_DIRTY1 = 4, TOT_EXIT = 5,
        TOT_CL0 = 6, TOT_CL1 = 7,        // closure items left for the next round: size of the range that holds them (0: none)
        TOT_CLS0 = 8, TOT_CLS1 = 9,      // ... and where that range starts in the wave's item segment
        TOT_N = 10 };
@@ -264,15 +269,16 @@ struct SearchShared {
 
 // Turn the published per-wave fill counts of up to NLISTS lists into chunk prefixes (LDS).  The
 // loads of all lists are in flight together and the scans share two barriers.  All SNT threads
-// call it.  K = records per chunk; segcap = capacity of a wave segment (counts are clamped to it).
-struct ListSrc { const int *tot; int K; unsigned segcap; };
+// call it.  K = records per chunk; segcap = capacity of a wave segment (counts are clamped to it); nw = the wave
+// segments the list was written with (lists of different ages may come from launches of different geometries).
+struct ListSrc { const int *tot; int K; unsigned segcap; int nw; };
 template <int N>
-__device__ __forceinline__ void build_lists(SearchShared &sh, const ListSrc (&src)[N], int nw, int (&Q)[N], int (&items)[N])
+__device__ __forceinline__ void build_lists(SearchShared &sh, const ListSrc (&src)[N], int (&Q)[N], int (&items)[N])
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int c[N], n[N], x[N], y[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) c[k] = (tid < nw) ? CL(src[k].tot + tid) : 0;
+    for (int k = 0; k < N; ++k) c[k] = (tid < src[k].nw) ? CL(src[k].tot + tid) : 0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         if (c[k] < 0) c[k] = 0;
@@ -298,8 +304,8 @@ __device__ __forceinline__ void build_lists(SearchShared &sh, const ListSrc (&sr
         int base = 0, total = 0, it = 0;
 #pragma unroll
         for (int w = 0; w < SW; ++w) { const int s = sh.wsum[k][w]; if (w < wid) base += s; total += s; it += sh.wsum2[k][w]; }
-        if (tid < nw) { sh.pfx[k][tid] = base + x[k] - n[k]; sh.cnt[k][tid] = c[k]; }
-        if (tid == 0) sh.pfx[k][nw] = total;
+        if (tid < src[k].nw) { sh.pfx[k][tid] = base + x[k] - n[k]; sh.cnt[k][tid] = c[k]; }
+        if (tid == 0) sh.pfx[k][src[k].nw] = total;
         Q[k] = RFL(total); items[k] = RFL(it);
     }
     __syncthreads();
@@ -418,7 +424,7 @@ struct StreamView {     // wave-uniform descriptors of one stream's arenas
     unsigned rec_par, item_par;                 // byte offset of parity 1 in them
     __amdgpu_buffer_rsrc_t lrows, larcs;        // lazy graphs: the rows and the arc arena (read with `sc1` loads)
     __amdgpu_buffer_rsrc_t srec_r;              // the per-state records, for 16-byte loads
-    ArcState *ast; StateRec *srec; int *newl, *cleanl, *dirtyl; int *tot; PathRec *paths; int *hist;
+    unsigned char *live; StateRec *srec; int2 *newl; int *dirtyl; unsigned dirty_par; int *tot; PathRec *paths; int *hist;
 };
 
 // byte offset of chunk ci of wave segment w in a record list (parity offset added by the caller)
@@ -435,8 +441,9 @@ __device__ __forceinline__ unsigned rec_chunk_off(unsigned seg_rec, int w, int c
 // loads of a pass are issued back to back (no divergent load branches: lanes without work read
 // out of range and get zeros).  Waves take chunks of 64 (of ONE writer segment); survivors and exit
 // tokens go to the wave's own output segments - no atomics, no barriers.  Work items, in this
-// order: chunks of instance records (list 0), of newly entered arcs (1), of arcs whose keys only
-// need cleaning (2), of states whose closure keys need zeroing (3).
+// order: chunks of instance records (list 0), of newly entered arcs (1), of states whose arrival keys
+// of the frame before the previous one need zeroing (2).  An instance PULLS its entry token: the best
+// arrival at its arc's source state in the previous frame (StateRec::e) plus the arc's weight.
 //
 // LR: every transition matrix of the model set is plain left-to-right (state j is entered from j-1 and
 // itself, the exit state from the last emitting state; no skips): the predecessor loops become one
@@ -469,7 +476,7 @@ __device__ __forceinline__ unsigned rec_chunk_off(unsigned seg_rec, int w, int c
 
 template <int NE, bool TRPL, bool LR, bool XL, bool LZY>
 __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
-                                        const Geo &gin, const Geo &gout, const int (&Q)[4], int jw, int Cw, int gw, int p,
+                                        const Geo &gin, const Geo &gd, const Geo &gout, const int (&Q)[3], int jw, int Cw, int gw, int p,
                                         float normalise, float emitTh, float startTh, const float *llrow,
                                         int &out_cnt, int &exit_cnt)
 {
@@ -484,18 +491,18 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     const unsigned rcur = p ? V.rec_par : 0u, rnext = p ? 0u : V.rec_par;           // byte offsets of the two lists
     const unsigned iprev = p ? 0u : V.item_par, icur = p ? V.item_par : 0u;
     const unsigned item_base = (unsigned)gw * gout.seg_item;
-    const int Q01 = Q[0] + Q[1], Q012 = Q01 + Q[2], Qall = Q012 + Q[3];
+    const int Q01 = Q[0] + Q[1], Qall = Q01 + Q[2];
     int c_insts = 0, c_pemit = 0, c_emit = 0, c_end = 0, c_surv = 0;
     unsigned mo = 0u;
     // The pass loop is software-pipelined two deep.  A pass is a chain of dependent memory round trips
-    // (record -> arc key + likelihoods -> winning item) followed by arithmetic and stores, and with
+    // (record -> source state's arrival key + likelihoods -> winning item) followed by arithmetic and stores, and with
     // two waves per SIMD nothing else hides them; the memory counter is in-order, so a wait for a
     // load also waits for every store issued before it.  Hence: the NEXT chunk's record is requested
     // while this chunk's item is in flight (stage R), and its key + likelihoods right BEFORE this
     // chunk's stores (stage K) - by the time they are needed they are there, and no wait has a store
     // in front of it.  Chunks come in increasing order per workgroup (records, then new arcs, then
-    // the two clean-up lists), so the clean-up chunks form a plain loop of their own at the end.
-    auto stage_r = [&](int u, bool &is_new, bool &valid, int &nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1])
+    // the clean-up list), so the clean-up chunks form a plain loop of their own at the end.
+    auto stage_r = [&](int u, bool &is_new, bool &valid, int2 &nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1])
         __attribute__((always_inline)) {
         is_new = u >= Q[0];
         const int ru = is_new ? u - Q[0] : u;
@@ -504,30 +511,34 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         const int w = find_seg(pfx, gin.nw, ru);
         const int ci = ru - RFL(pfx[w]);
         valid = ci * 64 + lane < RFL(cnt[w]);
-        nb = 0;
+        nb = make_int2(0, 0);
         if (!is_new) {
             const unsigned off = valid ? rcur + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u : OOB_OFF;
             h0 = ld16(V.rec, off); h1 = ld16(V.rec, off + 1024u);
             if (NE == 6) h2 = ld16(V.rec, off + 2048u);
 #pragma unroll
             for (int j = 1; j <= NE; ++j) tk[j] = as_tok(ld16(V.rec, off + (unsigned)(HF + j - 1) * 1024u));
-        } else if (valid) nb = CL(V.newl + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
+        } else if (valid) {
+            const unsigned long long e = CL((const unsigned long long *)(V.newl + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane)));
+            nb = make_int2((int)(unsigned)e, (int)(unsigned)(e >> 32));  // {arc, source state}
+        }
     };
-    auto stage_k = [&](bool is_new, bool valid, int nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1],
+    auto stage_k = [&](bool is_new, bool valid, int2 nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1],
                        unsigned long long &kv, float (&outp)[NE]) __attribute__((always_inline)) {
         if (is_new) {                                                  // attachNetInst :751-774, from the arc's template
             JdArc Bk;
             int4 a0, a1 = make_int4(0, 0, 0, 0);
             if (LZY) {                                                 // the arena, and the template by HMM
-                const v4i r = ld16(V.larcs, (unsigned)nb * 16u);
+                const v4i r = ld16(V.larcs, (unsigned)nb.x * 16u);
                 Bk = JdArc{r.x, __int_as_float(r.y), r.z, r.w};
-            } else Bk = C.arcs[nb];
+            } else Bk = C.arcs[nb.x];
             {   // the template by HMM (a table of a few tens of KB: L2 hits; a per-arc copy would be a second random sector)
                 const int hm = max((Bk.in & ~TEE_FLAG) - 1, 0);        // (arcs on the new list carry a model; idle lanes read arc 0)
                 a0 = ((const int4 *)C.aux_h)[(NE == 3) ? hm : 2 * hm];
                 if (NE == 6) a1 = ((const int4 *)C.aux_h)[2 * hm + 1];
             }
-            h0 = (v4i){nb, valid ? a0.x : 0, Bk.out, Bk.to};
+            // header: arc, nStates | transMat << 8 | (the arc carries a word label) << 30, source state, destination state
+            h0 = (v4i){nb.x, valid ? (a0.x | (Bk.out != 0 ? REC_LABELLED : 0)) : 0, nb.y, Bk.to};
             h1 = (v4i){a0.y, a0.z, a0.w, __float_as_int(Bk.w)};
             if (NE == 6) h2 = (v4i){a1.x, a1.y, a1.z, 0};
 #pragma unroll
@@ -535,7 +546,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         }
         const int n = h0.y & 0xff;
         kv = 0ULL;
-        if (valid) kv = CL(&V.ast[h0.x].key);                          // the arc's key and the likelihoods: in flight together
+        if (valid) kv = CL(&V.srec[h0.z].e[p ^ 1]);                    // the best arrival at the source state and the likelihoods: in flight together
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int gj = (j == 0) ? h1.x : (j == 1) ? h1.y : (j == 2) ? h1.z : (j == 3) ? h2.x : (j == 4) ? h2.y : h2.z;
@@ -544,7 +555,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     };
     int u = grab_chunk(sh, jw, Cw);
     bool is_new = false, valid = false;
-    int nb = 0;
+    int2 nb = make_int2(0, 0);
     v4i h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, h2 = {0, 0, 0, 0};
     Tok tk[NE + 1];
     unsigned long long kv = 0ULL;
@@ -557,22 +568,21 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         FINE(0);                                                       // (development build) the wait for stage K
         const int arc = h0.x;
         const int n = h0.y & 0xff;                                     // 0 for lanes without an instance
-        const int tm = h0.y >> 8;
-        // entry token = the best candidate phase X of the previous frame left in the arc's key (:560-582)
+        const int tm = (h0.y >> 8) & 0x3fffff;
+        // entry token = the best token that arrived at the arc's source state in the previous frame, over the arc (:560-582)
         v4i itv = {0, 0, 0, 0};
         if (kv != 0ULL) itv = ld16(V.items, iprev + (unsigned)(kv & 0xffffffffULL) * 32u);
         // stage R of the next chunk (issued after the item load: the wait for the item leaves it in flight)
         bool n_is_new = false, n_valid = false;
-        int n_nb = 0;
+        int2 n_nb = make_int2(0, 0);
         v4i nh0 = {0, 0, 0, 0}, nh1 = {0, 0, 0, 0}, nh2 = {0, 0, 0, 0};
         Tok ntk[NE + 1];
         if (un < Q01) stage_r(un, n_is_new, n_valid, n_nb, nh0, nh1, nh2, ntk);
-        if (kv != 0ULL) CS(&V.ast[arc].key, 0ULL);
         FINE(1);                                                       // the winning item (+ the next record)
         tk[0] = null_tok();
         if (kv != 0ULL) {
             const Tok it = as_tok(itv);
-            tk[0].score = o2f((unsigned)(kv >> 32));
+            tk[0].score = o2f((unsigned)(kv >> 32)) + __int_as_float(h1.w);   // :562 newScore = tok.score + weight
             tk[0].ac = it.ac; tk[0].lm = it.lm + __int_as_float(h1.w); tk[0].path = it.path;
             if (tk[0].score < startTh) tk[0] = null_tok();            // :915-918 (a candidate is never LOG_ZERO)
         }
@@ -688,8 +698,8 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 c_surv += nsurv;
             }
             // the arc's "has an instance" flag changes at birth and death only (returnNetInst :777-797)
-            if (valid && is_new) CS(&V.ast[arc].live, slot_live ? 1 : 0);
-            if (valid && !slot_live && !is_new) CS(&V.ast[arc].live, 0);
+            if (valid && is_new && slot_live) CS(&V.live[arc], (unsigned char)1);
+            if (valid && !slot_live && !is_new) CS(&V.live[arc], (unsigned char)0);
         }
         // exit tokens: frontier items of round 0 in this wave's item segment, bidding for their
         // destination state (state-level recombination, see phase X); tokens leaving word-labelled
@@ -701,8 +711,9 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 const unsigned k = item_base + (unsigned)(exit_cnt + rank_in(be));
                 const unsigned ioff = has_exit ? icur + k * 32u : OOB_OFF;
                 st16(V.items, ioff, as_v4(ex));
-                st16(V.items, ioff + 16u, (v4i){arc, h0.z, h0.w, 0});
-                if (has_exit) GMAX((h0.z != 0 ? &V.srec[h0.w].keyL : &V.srec[h0.w].key0), ((unsigned long long)f2o(ex.score) << 32) | k);
+                const int lab = (h0.y & REC_LABELLED) ? 1 : 0;         // (the label itself is read from the arc when a Path record is written)
+                st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, 0});
+                if (has_exit) GMAX((lab ? &V.srec[h0.w].keyL : &V.srec[h0.w].key0), ((unsigned long long)f2o(ex.score) << 32) | k);
                 exit_cnt += nex;
                 c_end += nex;
             }
@@ -717,19 +728,16 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
 #pragma unroll
         for (int j = 0; j < NE; ++j) outp[j] = noutp[j];
     }
-    // key clean-up.  (2) arcs whose first candidate of the previous frame was hopeless and that did not
-    // make it onto the new list afterwards keep a stale key - nobody else consumes it; (3) closure keys
-    // are running maxima that nobody resets during their frame
+    // key clean-up: the arrival keys e[p] of the frame before the previous one have been pulled from (by the
+    // previous frame's phase A) and are written again by this frame's phase X, behind the barrier
 #pragma nounroll
     for (; u < Qall; u = grab_chunk(sh, jw, Cw)) {
-        const int k = (u >= Q012) ? 3 : 2;
-        const int ru = u - (k == 3 ? Q012 : Q01);
-        const int w = find_seg(sh.pfx[k], gin.nw, ru);
-        const int ci = ru - RFL(sh.pfx[k][w]);
-        if (ci * 64 + lane < RFL(sh.cnt[k][w])) {
-            const int b = CL((k == 3 ? V.dirtyl : V.cleanl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
-            if (k == 3) CS(&V.srec[b].keyC, 0ULL);
-            else if (CL(&V.ast[b].live) != 2) CS(&V.ast[b].key, 0ULL);
+        const int ru = u - Q01;
+        const int w = find_seg(sh.pfx[2], gd.nw, ru);                 // (gd: the geometry this list was written with, two frames ago)
+        const int ci = ru - RFL(sh.pfx[2][w]);
+        if (ci * 64 + lane < RFL(sh.cnt[2][w])) {
+            const int b = CL(V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)w * gd.seg_new + (unsigned)(ci * 64 + lane));
+            CS(&V.srec[b].e[p], 0ULL);
         }
     }
     // per-wave totals -> workgroup counters (LDS)
@@ -752,24 +760,39 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
 // l, l+64, ... of the concatenated ranges, so a history state with thousands of out-arcs occupies
 // the whole wave and items with few arcs share a pass.
 //
-// State-level recombination.  All items at one state add the same arc weights and float addition
-// is monotone, so only the best item at a state can win anything downstream.  Exit tokens (round
-// 0) bid for their state in phase A; after the barrier exactly the best one finds its own index in
-// the state's key and is expanded.  Closure items (a token that has just traversed an epsilon arc
-// or a tee model, :533-540 / :584-600) are produced while the expansion runs, so their keys are
-// RUNNING maxima: an item is expanded iff it is the best arrival at its state so far (checked when
-// it is produced and again when it is taken up) - the best one is always expanded, a state at most
-// O(log arrivals) times, results are the same.  A wave expands the closure items it produces
-// itself, right away (QCAP of them wait in LDS); the rest is left for a further round.
+// State-level recombination.  All tokens at one state add the same arc weights and float addition
+// is monotone, so only the best token at a state can win anything downstream.  Exit tokens (round
+// 0) bid for their state in phase A; after the barrier exactly the best one (per threshold class)
+// finds its own index in the state's key, and if it passes its threshold it ARRIVES: an atomic max
+// on the state's arrival key e[p] (StateRec).  Closure items (a token that has just traversed an
+// epsilon arc or a tee model, :533-540 / :584-600) arrive the same way when they are produced, and are
+// expanded iff they are the best arrival at their state so far (a running maximum).
+// The arrival key is all that the next frame needs of this expansion: phase A of the next frame
+// pulls the entry token of every arc leaving the state from it.  What an arrival still does here:
+//   * it walks the state's arcs to send its token on through epsilon arcs and tee models (closure
+//     items; a wave expands the ones it produces itself right away, QCAP of them wait in LDS, the
+//     rest is left for a further round) - only the best arrival SO FAR does (running maximum: the
+//     best one always does, a state is walked O(log arrivals) times, results are the same);
+//   * it lists the arcs of the state that have no instance yet for the next phase A (new list), so
+//     that they are tried - attachNetInst :751-774 happens there, and only if the instance survives
+//     its first frame.  No per-arc word is written: which arrival lists an arc is decided by the
+//     chain of maxima the atomic on e[p] orders the arrivals in (below).
 //
 // Hopeless candidates.  An entry token with (score + max_j trP[0][j]) - bestA <= -mainBeam
 // (bestA = this frame's best emitting score) fails :409 next frame whatever happens: that frame
 // normalises by bestEmitScore >= bestA, its emit threshold is >= -mainBeam, float ops are
 // monotone.  The reference attaches an instance for it, counts it and lets it die.  Here the arc
-// is counted (new_all) but only put on the new list - i.e. tried in the next phase A - once a
-// candidate arrives that is not hopeless; an arc whose first candidate was hopeless goes to the
-// clean-up list so that its key does not outlive the frame.
-struct XOut { int item_cnt; int new_cnt; int clean_cnt; int dirty_cnt; };
+// is counted (new_all, by the FIRST arrival at its state) but only listed by the first arrival
+// whose token is not hopeless for it: an arrival knows the best score before it (the atomic's old
+// value) and lists exactly the arcs that are hopeful for its own score and were not for that one -
+// every arc once, whatever order the arrivals are expanded in.
+//
+// Items (32 bytes): token + {x, label, state, flags}.  Exit tokens (round 0): x = their arc (the start
+// token: -1), label = 1 if the arc carries a word label (the label is read from the arc when the Path
+// record is written).  Closure items and slices: x = ordered score of the best arrival BEFORE this one
+// (0: none - this one is the first), label = the arc's word label.  flags & 3: 0 = to be expanded in
+// a later round, 1 = done (expanded by its producer, or superseded), 2 = a slice (>> 2: its number).
+struct XOut { int item_cnt; int new_cnt; int dirty_cnt; };
 template <bool XL, bool LZY>
 __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
                                         const Geo &gin, const Geo &gout, int Q, int KX, int round, int jw, int Cw, int gw,
@@ -784,12 +807,25 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
     const bool can_filter = !init && C.emit_win > 0.0f && bestA > LZ;
     const bool tee_lds = C.n_hmm <= TEE_LDS_MAX;
     const unsigned item_base = (unsigned)gw * gout.seg_item, new_base = (unsigned)gw * gout.seg_new;
+    int *const dirty_seg = V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)new_base;
     int *wpfx = sh.wpfx[wid];
     v4i *qtok = sh.qtok[wid], *qinfo = sh.qinfo[wid];
     int2 *qrow = sh.qrow[wid];
     int q_n = 0;                                                       // closure items waiting in this wave's queue
     int c_arcs = 0, c_paths = 0, c_pend = 0, c_new = 0;
     unsigned mo = 0u;
+    // states whose arrival key became non-zero: zeroed by the phase A of the frame after the next one
+    auto list_dirty = [&](bool first, int state) __attribute__((always_inline)) {
+        const unsigned long long bf = __ballot(first);
+        if (bf) {
+            const int nf = __popcll(bf);
+            if (out.dirty_cnt + nf > (int)gout.seg_new) { if (lane == 0) CS(&c.err[p], (int)JDE_NEW); }
+            else {
+                if (first) CS(dirty_seg + (unsigned)(out.dirty_cnt + rank_in(bf)), state);
+                out.dirty_cnt += nf;
+            }
+        }
+    };
 #pragma nounroll
     for (;;) {
         // ---- a batch of up to 64 items: the wave's own closure queue first, else the next chunk
@@ -809,6 +845,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             info = qinfo[lane & (QCAP - 1)];
             row_q = qrow[lane & (QCAP - 1)];
             ii = (unsigned)info.w;                                     // (the queue keeps the item's index here)
+            info.w = 0;
             q_n = 0;
         } else {
             const int u = grab_chunk(sh, jw, Cw);
@@ -819,36 +856,41 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             ii = (unsigned)w * gin.seg_item + (unsigned)(RFL(sh.start[w]) + ci * KX + lane);
             const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
             t = as_tok(ld16(V.items, ioff));
-            info = ld16(V.items, ioff + 16u);                          // {arc, out, to, flag}; arc -1 = the start token
+            info = ld16(V.items, ioff + 16u);
             exit_kind = round == 0;
             if (!exit_kind && (info.w & 3) == 1) valid = false;        // expanded by its producer / superseded
             if (!exit_kind && (info.w & 3) == 2) slice_no = info.w >> 2;
         }
         XFINE(0);                                                      // hop 1: the items
         const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
-        const bool real = valid && info.x >= 0 && slice_no == 0;       // an item that traversed an arc (a slice has been through all this)
-        const int state = !valid ? 0 : (info.x >= 0) ? info.z : C.init_state;
-        // second level, in flight together: the state's record (its key and its CSR row: one 64-byte sector), the
-        // Path reservation.  A closure item this wave queued for itself brought its row along - the record was read
-        // when its key was bid for - and has just been found the best arrival at its state: it needs no load at all.
+        const bool start_tok = valid && exit_kind && info.x < 0;       // recognitionStart's token: it has traversed no arc
+        const bool real = valid && !start_tok && slice_no == 0;        // an item that traversed an arc (a slice has been through all this)
+        const int state = !valid ? 0 : start_tok ? C.init_state : info.z;
+        // second level, in flight together: the state's record (keys and CSR row: one 64-byte sector), the word label
+        // of an exit token's arc, the Path reservation.  A closure item this wave queued for itself brought its row
+        // along - the record was read when it arrived - and has just been found the best arrival at its state: it
+        // needs no load at all.
         int rs, rs1;
         float fin_lazy = 0.0f;
-        unsigned long long *sk = (!exit_kind ? &V.srec[state].keyC : (info.y != 0) ? &V.srec[state].keyL : &V.srec[state].key0);
         unsigned long long kv = 0ULL;
+        int label = exit_kind ? 0 : info.y;
         const bool carried = !LZY && from_q;                           // (wave-uniform)
         if (carried) { rs = row_q.x; rs1 = row_q.x + row_q.y; }
         else {
-            const unsigned soff = real || (valid && !LZY) ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
-            v4i slo = {0, 0, 0, 0};
-            if (exit_kind) slo = ld16(V.srec_r, soff);                 // {key0, keyL}
-            const v4i shi = ld16(V.srec_r, soff + 16u);                // {keyC, first arc, arcs}
+            const unsigned soff = (real || (valid && !LZY)) ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
+            v4i sk = {0, 0, 0, 0};
+            if (real && exit_kind) sk = ld16(V.srec_r, soff);          // {key0, keyL}
+            const v4i srow = ld16(V.srec_r, soff + 32u);               // {first arc, arcs}
+            if (exit_kind && real && info.y != 0) {                    // (labelled exit tokens: a few per cent of the items)
+                if (LZY) label = ld16(V.larcs, (unsigned)info.x * 16u).w;
+                else label = C.arcs[info.x].out;
+            }
             if (LZY) {                                                 // {first arc, arcs, status, final weight}: ready by the invariant
                 const v4i r = ld16(V.lrows, (unsigned)state * 16u);
                 rs = r.x; rs1 = r.x + r.y; fin_lazy = __int_as_float(r.w);
                 if (valid && r.z < LZ_EXPANDED) CS(&c.err[p], (int)JDE_LAZY_INV);   // (cannot happen: the invariant of jd_lazy.h)
-            } else { rs = shi.z; rs1 = shi.z + shi.w; }
-            const int klo = !exit_kind ? shi.x : (info.y != 0) ? slo.z : slo.x, khi = !exit_kind ? shi.y : (info.y != 0) ? slo.w : slo.y;
-            if (real) kv = ((unsigned long long)(unsigned)khi << 32) | (unsigned)klo;
+            } else { rs = srow.x; rs1 = srow.x + srow.y; }
+            kv = ((unsigned long long)(unsigned)(info.y != 0 ? sk.w : sk.y) << 32) | (unsigned)(info.y != 0 ? sk.z : sk.x);
         }
         bool have = valid;
         if (real && exit_kind && !init) {                              // :952-962
@@ -865,12 +907,15 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             if (lane == first) pbase = GADD(&c.n_paths, __popcll(blab));
             pbase = __shfl(pbase, first);
         }
-        XFINE(1);                                                      // hop 2: row bounds, state key, Path reservation
+        XFINE(1);                                                      // hop 2: state record, label, Path reservation
         if (real) {
-            const bool winner = carried || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
+            // (a closure item was the best arrival at its state when it was produced - else it was never listed for a
+            // later round - and that makes it responsible for the arcs its score was the first to make hopeful, see
+            // above: it is expanded even if a better arrival has come since)
+            const bool winner = !exit_kind || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
             // every state that received exit-token bids is cleaned up by its winner, expanded or not (an
             // item below its threshold still holds the key of its state if it was the best one there)
-            if (winner && exit_kind) CS(sk, 0ULL);
+            if (winner && exit_kind) CS(info.y != 0 ? &V.srec[state].keyL : &V.srec[state].key0, 0ULL);
             have = have && winner;
         }
         if (have && real) {
@@ -878,11 +923,11 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 const int pp = pbase + rank_in(blab);
                 if (pp < C.cap_paths) {
                     PathRec pr;
-                    pr.prev = t.path; pr.frame = pframe; pr.label = info.y; pr.pad0 = 0;
+                    pr.prev = t.path; pr.frame = pframe; pr.label = label; pr.pad0 = 0;
                     pr.score = t.score; pr.ac = t.ac; pr.lm = t.lm; pr.pad1 = 0.0f;
                     V.paths[pp] = pr;                                  // read by later launches only
                     t.path = pp;
-                    st16(V.items, ioff, as_v4(t));                     // the candidates of this item carry the new history
+                    st16(V.items, ioff, as_v4(t));                     // the tokens pulled from this item carry the new history
                     ++c_paths;
                 } else CS(&c.err[p], (int)JDE_PATHS);
             }
@@ -896,7 +941,14 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 }
             }
         }
-        XFINE(2);                                                      // winners: key reset, Path record, final state
+        // ---- arrival of an exit token (and of the start token) at its state: the atomic's old value is the best
+        // arrival before it.  (Closure items arrived when they were produced and carry that value; a slice carries
+        // its item's.)  The answer is first needed by the arc passes: its round trip runs beside the first arcs'.
+        unsigned eo = exit_kind ? 0u : (unsigned)info.x;               // ordered score of the best arrival before this one (0: none)
+        unsigned long long eold = 0ULL;
+        const bool arrive = have && exit_kind;
+        if (arrive) eold = GMAX(&V.srec[state].e[p], ((unsigned long long)f2o(t.score) << 32) | ii);
+        XFINE(2);                                                      // winners: key reset, Path record, final state, arrival
         // ---- A state with thousands of out-arcs (a history with 10^4 successors) would keep this wave busy
         // for hundreds of passes while the cluster waits at the barrier: the wave walks the first X_SLICE
         // arcs itself and hands the rest on as SLICES - items of the next round (flag 2 + slice number)
@@ -905,20 +957,23 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         if (slice_no > 0) { alo = rs + slice_no * X_SLICE; ahi = min(rs1, alo + X_SLICE); }
         int n_slices = 0;
         if (have && slice_no == 0 && rs1 - rs > X_SLICE) { n_slices = (rs1 - rs - 1) / X_SLICE; ahi = rs + X_SLICE; }
-        for (unsigned long long bs = __ballot(n_slices > 0); bs; bs &= bs - 1) {
-            const int src = __ffsll((long long)bs) - 1;
-            const int ns = __shfl(n_slices, src);
-            const v4i tv = {__shfl(__float_as_int(t.score), src), __shfl(__float_as_int(t.ac), src), __shfl(__float_as_int(t.lm), src), __shfl(t.path, src)};
-            const int sx = __shfl(info.x, src), sy = __shfl(info.y, src), sz = __shfl(info.z, src);
-            for (int j0 = 0; j0 < ns; j0 += 64) {
-                const int nj = min(64, ns - j0);
-                if (out.item_cnt + nj > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); break; }
-                if (lane < nj) {
-                    const unsigned k = item_base + (unsigned)(out.item_cnt + lane);
-                    st16(V.items, icur + k * 32u, tv);
-                    st16(V.items, icur + k * 32u + 16u, (v4i){sx, sy, sz, 2 | ((j0 + lane + 1) << 2)});
+        if (__ballot(n_slices > 0)) {
+            if (arrive) eo = (unsigned)(eold >> 32);                   // (the slices carry it: wait for the arrival's answer here)
+            for (unsigned long long bs = __ballot(n_slices > 0); bs; bs &= bs - 1) {
+                const int src = __ffsll((long long)bs) - 1;
+                const int ns = __shfl(n_slices, src);
+                const v4i tv = {__shfl(__float_as_int(t.score), src), __shfl(__float_as_int(t.ac), src), __shfl(__float_as_int(t.lm), src), __shfl(t.path, src)};
+                const int sx = __shfl((int)eo, src), sy = __shfl(label, src), sz = __shfl(state, src);
+                for (int j0 = 0; j0 < ns; j0 += 64) {
+                    const int nj = min(64, ns - j0);
+                    if (out.item_cnt + nj > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); break; }
+                    if (lane < nj) {
+                        const unsigned k = item_base + (unsigned)(out.item_cnt + lane);
+                        st16(V.items, icur + k * 32u, tv);
+                        st16(V.items, icur + k * 32u + 16u, (v4i){sx, sy, sz, 2 | ((j0 + lane + 1) << 2)});
+                    }
+                    out.item_cnt += nj; deferred += nj;
                 }
-                out.item_cnt += nj; deferred += nj;
             }
         }
         // ---- pooled arc walk: exclusive prefix of the items' out-degrees
@@ -940,59 +995,50 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             if (LZY) { const v4i r = ld16(V.larcs, (unsigned)b * 16u); return JdArc{r.x, __int_as_float(r.y), r.z, r.w}; }
             return C.arcs[b];
         };
-        if (lane < tot) Bk_nx = arc_at(b_nx);
-        // ... and so is its ArcState: the recombination atomic of the next pass then finds the line in the L2
-        // instead of being carried out at the memory side (measured, tools/traffic_probe: 16-17 G scattered
-        // atomics / s against 49 G scattered loads / s; the heavy workloads ran at 13-15 G atomics / s before
-        // this load went ahead of them: configs[1] -8 %, the configs[4] graph -17 %, configs[3] -19 %)
+        // ... and so is its "has an instance" flag (a byte per arc: the arcs of a state share a sector)
         int lv_nx = 0;
-        if (lane < tot) lv_nx = CL(&V.ast[b_nx].live);
-        XFINE(3);                                                      // prefix + hop 3: the first 64 arcs
+        if (lane < tot) { Bk_nx = arc_at(b_nx); lv_nx = CL(V.live + b_nx); }
+        if (arrive) eo = (unsigned)(eold >> 32);
+        list_dirty(arrive && eold == 0ULL, state);
+        XFINE(3);                                                      // prefix + hop 3: the first 64 arcs (+ the arrival's answer)
 #pragma nounroll
         for (int a0 = 0; a0 < tot; a0 += 64) {
             XFINE_COUNT(6);
             const int a = a0 + lane;
             const int g = g_nx, b = b_nx;
             const JdArc Bk = Bk_nx;
-            const int lv_pf = lv_nx;
+            const int lv = lv_nx;
             if (a0 + 64 < tot) {                                       // next pass's arc records: in flight during this one
                 g_nx = owner_of(a + 64);
                 b_nx = __shfl(alo, g_nx) + (a + 64 - wpfx[g_nx]);
-                if (a + 64 < tot) Bk_nx = arc_at(b_nx);
-                if (a + 64 < tot) lv_nx = CL(&V.ast[b_nx].live);
+                if (a + 64 < tot) { Bk_nx = arc_at(b_nx); lv_nx = CL(V.live + b_nx); }
             }
             Tok tg;
             tg.score = __shfl(t.score, g); tg.ac = __shfl(t.ac, g);
             tg.lm = __shfl(t.lm, g); tg.path = __shfl(t.path, g);
-            const unsigned iig = (unsigned)__shfl((int)ii, g);
-            bool mk = false, touch = false, clean = false;
+            const unsigned eog = (unsigned)__shfl((int)eo, g);         // best arrival at the owner's state before it (ordered; 0: none)
+            const int sg = __shfl(state, g);
+            bool mk = false, touch = false;
             Tok un = null_tok();
-            int tb = -1;
-            // Everything a pass READS is requested before anything is waited for - one memory round trip:
-            // the arc's recombination key (atomic max) with its instance flag and the model's constant, and
-            // the closure key of the destination state of every arc that can produce a closure item (as a
-            // pre-filter: hot history states receive many arrivals, and an atomic on a contended key costs
-            // far more than this load - measured: without it a pass takes 2.4 us instead of 2.1).
+            // Everything a pass READS is requested before anything is waited for - one memory round trip: the
+            // model's constant of an entry arc, and the state record of the destination of every arc that can
+            // produce a closure item (its arrival key as a pre-filter: hot history states receive many arrivals,
+            // and an atomic on a contended key costs far more than this load; its row for the item to carry).
             const bool on = a < tot;
             const int inl = Bk.in & ~TEE_FLAG;
             const bool entry = on && inl != 0;
             const bool is_tee = entry && (Bk.in & TEE_FLAG) != 0;
             const float ns = tg.score + Bk.w;                          // (:535 / :562: the same sum either way)
             const unsigned so = f2o(ns);
-            ArcState *as = V.ast + b;
-            int lv = 0;
-            unsigned long long old = 0ULL, skc = 0ULL;
+            unsigned long long skc = 0ULL;
             float tmax = 0.0f;
-            if (entry) {
-                lv = lv_pf;                                            // (read one pass ahead: nobody changes it during phase X except to 2, below)
-                old = GMAX(&as->key, ((unsigned long long)so << 32) | iig);
-                if (can_filter) tmax = C.hmm_tmax0[inl - 1];
-            }
-            int2 nrow = make_int2(0, 0);                               // the destination's CSR row comes with its closure key
+            if (entry && lv == 0 && can_filter) tmax = C.hmm_tmax0[inl - 1];
+            int2 nrow = make_int2(0, 0);
             {
-                const v4i shi = ld16(V.srec_r, ((on && inl == 0) || is_tee) ? (unsigned)Bk.to * (unsigned)sizeof(StateRec) + 16u : OOB_OFF);
-                skc = ((unsigned long long)(unsigned)shi.y << 32) | (unsigned)shi.x;
-                nrow = make_int2(shi.z, shi.w);
+                const unsigned doff = ((on && inl == 0) || is_tee) ? (unsigned)Bk.to * (unsigned)sizeof(StateRec) : OOB_OFF;
+                const v4i se = ld16(V.srec_r, doff + 16u), sr = ld16(V.srec_r, doff + 32u);
+                skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
+                nrow = make_int2(sr.x, sr.y);
             }
             if (on) ++c_arcs;
             if (on && inl == 0) {                                      // :533-540 epsilon input
@@ -1009,30 +1055,26 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 un.path = tg.path;
                 mk = ns2 > ((Bk.out != 0) ? wordTh : endTh);
             }
-            if (entry) {                                               // :560-582 entry-token recombination
-                tb = b;
+            if (entry) {                                               // :560-582 entry-token recombination: pulled by the next phase A
                 mo = so > mo ? so : mo;                                // :572-573
-                if (lv != 1) {                                         // no instance: attachNetInst :751-774
-                    if (old == 0ULL) ++c_new;
+                if (lv == 0) {                                         // no instance: attachNetInst :751-774
+                    if (eog == 0u) ++c_new;                            // (counted once, by the first arrival at the state)
                     if (can_filter) {
                         const bool mine = (ns + tmax) - bestA > -C.emit_win;
-                        const bool before = old != 0ULL && (o2f((unsigned)(old >> 32)) + tmax) - bestA > -C.emit_win;
-                        touch = mine && !before;                       // the first candidate that may survive
-                        clean = old == 0ULL && !mine;
-                    } else touch = old == 0ULL;
-                    if (touch) CS(&as->live, 2);
+                        const bool before = eog != 0u && ((o2f(eog) + Bk.w) + tmax) - bestA > -C.emit_win;
+                        touch = mine && !before;                       // the first arrival whose candidate may survive
+                    } else touch = eog == 0u;
                 }
             }
-            // newly entered arcs -> this wave's segments of the new / clean-up lists
-            const unsigned long long bt = __ballot(touch), bc = __ballot(clean);
-            if (bt | bc) {
-                const int nt = __popcll(bt), nc = __popcll(bc);
-                if (out.new_cnt + nt > (int)gout.seg_new || out.clean_cnt + nc > (int)gout.seg_new) {
-                    if (lane == 0) CS(&c.err[p], (int)JDE_NEW);
-                } else {
-                    if (touch) CS(V.newl + (size_t)new_base + (unsigned)(out.new_cnt + rank_in(bt)), tb);
-                    if (clean) CS(V.cleanl + (size_t)new_base + (unsigned)(out.clean_cnt + rank_in(bc)), tb);
-                    out.new_cnt += nt; out.clean_cnt += nc;
+            // arcs to be tried in the next phase A -> this wave's segment of the new list
+            const unsigned long long bt = __ballot(touch);
+            if (bt) {
+                const int nt = __popcll(bt);
+                if (out.new_cnt + nt > (int)gout.seg_new) { if (lane == 0) CS(&c.err[p], (int)JDE_NEW); }
+                else {
+                    if (touch) CS((unsigned long long *)(V.newl + (size_t)new_base + (unsigned)(out.new_cnt + rank_in(bt))),
+                                  ((unsigned long long)(unsigned)sg << 32) | (unsigned)b);
+                    out.new_cnt += nt;
                 }
             }
             // closure items: the best arrival at its state so far is kept (running maximum), written to
@@ -1046,34 +1088,28 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 else if (np) {
                     const unsigned k = item_base + (unsigned)(out.item_cnt + rank_in(bp));
                     bool keep = false, first = false;
+                    unsigned ceo = 0u;
                     if (pass) {
                         const unsigned long long key = ((unsigned long long)sou << 32) | k;
-                        const unsigned long long cold = GMAX(&V.srec[Bk.to].keyC, key);
-                        keep = key > cold; first = cold == 0ULL;
+                        const unsigned long long cold = GMAX(&V.srec[Bk.to].e[p], key);
+                        keep = key > cold; first = cold == 0ULL; ceo = (unsigned)(cold >> 32);
                     }
-                    const unsigned long long bk = __ballot(keep), bf = __ballot(first);
+                    const unsigned long long bk = __ballot(keep);
                     const int room = QCAP - q_n;
                     const bool inq = keep && rank_in(bk) < room;       // expanded by this wave, right after this batch
                     if (pass) {
                         st16(V.items, icur + k * 32u, as_v4(un));
-                        st16(V.items, icur + k * 32u + 16u, (v4i){b, Bk.out, Bk.to, (keep && !inq) ? 0 : 1});
+                        st16(V.items, icur + k * 32u + 16u, (v4i){(int)ceo, Bk.out, Bk.to, (keep && !inq) ? 0 : 1});
                     }
                     if (inq) {
                         const int qi = q_n + rank_in(bk);
-                        qtok[qi] = as_v4(un); qinfo[qi] = (v4i){b, Bk.out, Bk.to, (int)k}; qrow[qi] = nrow;
+                        qtok[qi] = as_v4(un); qinfo[qi] = (v4i){(int)ceo, Bk.out, Bk.to, (int)k}; qrow[qi] = nrow;
                     }
                     const int nk = __popcll(bk);
                     const int n_inq = nk < room ? nk : room;
                     q_n += n_inq; deferred += nk - n_inq;
                     out.item_cnt += np;
-                    if (bf) {                                          // closure keys used this frame: zeroed by the next phase A
-                        const int nf = __popcll(bf);
-                        if (out.dirty_cnt + nf > (int)gout.seg_new) { if (lane == 0) CS(&c.err[p], (int)JDE_NEW); }
-                        else {
-                            if (first) CS(V.dirtyl + (size_t)new_base + (unsigned)(out.dirty_cnt + rank_in(bf)), Bk.to);
-                            out.dirty_cnt += nf;
-                        }
-                    }
+                    list_dirty(first, Bk.to);
                 }
             }
         }
@@ -1114,13 +1150,16 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     const int old_nw = RFL(c.lst_nw);
     Geo gin = make_geo(C, old_nw > 0 ? old_nw : NW);
     const Geo gout = make_geo(C, NW);
+    // geometry of the two dirty lists (each lives two frames, so it may come from the launch before the previous one)
+    const int dn0 = RFL(c.dirty_nw[0]), dn1 = RFL(c.dirty_nw[1]);
+    Geo gd0 = make_geo(C, dn0 > 0 ? dn0 : NW), gd1 = make_geo(C, dn1 > 0 ? dn1 : NW);
     StreamView V;
     V.rec = mk_rsrc(S.rec, 2ULL * C.cap_slots * RL::REC_BYTES);
     V.items = mk_rsrc(S.items, 2ULL * C.cap_items * 32u);
     V.rec_par = C.cap_slots * (unsigned)RL::REC_BYTES; V.item_par = C.cap_items * 32u;
-    V.ast = S.ast; V.srec = S.srec;
+    V.live = S.live; V.srec = S.srec;
     V.srec_r = mk_rsrc(S.srec, (unsigned long long)C.n_states * sizeof(StateRec));
-    V.newl = S.newl; V.cleanl = S.cleanl; V.dirtyl = S.dirtyl;
+    V.newl = S.newl; V.dirtyl = S.dirtyl; V.dirty_par = C.cap_new;
     V.tot = S.tot; V.paths = S.paths; V.hist = S.hist;
     if (LZY) {
         V.lrows = mk_rsrc(C.lazy->rows, (unsigned long long)C.lazy->max_states * 16ULL);
@@ -1182,24 +1221,25 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
 
     // =============================================================== recognitionStart (:139-228), part 1
     if (needs_init) {
-        // drop whatever the previous utterance left behind: instance flags, pending candidates, closure keys
+        // drop whatever the previous utterance left behind: instance flags, arrival keys (both parities)
         const int p0 = f & 1;
-        const ListSrc src[4] = {{tot_of(TOT_REC0 + p0), 64, gin.seg_rec}, {tot_of(TOT_NEW), 64, gin.seg_new},
-                                {tot_of(TOT_CLEAN), 64, gin.seg_new}, {tot_of(TOT_DIRTY), 64, gin.seg_new}};
-        int Q[4], items[4];
-        build_lists<4>(sh, src, gin.nw, Q, items);
-        const int Qall = Q[0] + Q[1] + Q[2] + Q[3];
+        const ListSrc src[3] = {{tot_of(TOT_REC0 + p0), 64, gin.seg_rec, gin.nw}, {tot_of(TOT_DIRTY0), 64, gd0.seg_new, gd0.nw},
+                                {tot_of(TOT_DIRTY1), 64, gd1.seg_new, gd1.nw}};
+        int Q[3], items[3];
+        build_lists<3>(sh, src, Q, items);
+        const int Qall = Q[0] + Q[1] + Q[2];
         for (int u = gw; u < Qall; u += NW) {
-            const int kind = (u >= Q[0] + Q[1] + Q[2]) ? 3 : (u >= Q[0] + Q[1]) ? 2 : (u >= Q[0]) ? 1 : 0;
-            const int ru = u - (kind == 3 ? Q[0] + Q[1] + Q[2] : kind == 2 ? Q[0] + Q[1] : kind == 1 ? Q[0] : 0);
-            const int w = find_seg(sh.pfx[kind], gin.nw, ru);
+            const int kind = (u >= Q[0] + Q[1]) ? 2 : (u >= Q[0]) ? 1 : 0;
+            const int ru = u - (kind == 2 ? Q[0] + Q[1] : kind == 1 ? Q[0] : 0);
+            const Geo &gk = kind == 0 ? gin : kind == 1 ? gd0 : gd1;
+            const int w = find_seg(sh.pfx[kind], gk.nw, ru);
             const int ci = ru - RFL(sh.pfx[kind][w]);
             if (ci * 64 + lane < RFL(sh.cnt[kind][w])) {
-                int b;
-                if (kind == 0) b = ld16(V.rec, (p0 ? V.rec_par : 0u) + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u).x;
-                else b = CL((kind == 1 ? V.newl : kind == 2 ? V.cleanl : V.dirtyl) + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane));
-                if (kind == 3) CS(&V.srec[b].keyC, 0ULL);
-                else { CS(&V.ast[b].key, 0ULL); CS(&V.ast[b].live, 0); }
+                if (kind == 0) CS(&V.live[ld16(V.rec, (p0 ? V.rec_par : 0u) + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u).x], (unsigned char)0);
+                else {
+                    const int b = CL(V.dirtyl + (kind == 2 ? V.dirty_par : 0u) + (size_t)w * gk.seg_new + (unsigned)(ci * 64 + lane));
+                    CS(&V.srec[b].e[0], 0ULL); CS(&V.srec[b].e[1], 0ULL);
+                }
             }
         }
         if (use_hist) for (int b = jw * SNT + tid; b < 2 * HIST_MAX_BINS; b += Cw * SNT) CS(V.hist + b, 0);
@@ -1218,9 +1258,10 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         // every workgroup has read the old lists (possibly written with another geometry): they are
         // gone, this launch's geometry applies and every segment starts empty - except wave 0's
         // "exit" segment, which holds the start token.  (Visible to the others after the next barrier.)
-        gin = gout;
+        gin = gout; gd0 = gout; gd1 = gout;
         if (lane == 0) {
             CS(tot_of(TOT_REC0) + gw, 0); CS(tot_of(TOT_REC1) + gw, 0);
+            CS(tot_of(TOT_DIRTY0) + gw, 0); CS(tot_of(TOT_DIRTY1) + gw, 0);
             CS(tot_of(TOT_EXIT) + gw, gw == 0 ? 1 : 0);
         }
         cluster_barrier<XL>(sh, c, Cw, nbar, t_limit);
@@ -1252,12 +1293,12 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             float emitTh = (C.emit_win > 0.0f ? -C.emit_win : LZ);                   // :331
             if (use_hist)                                              // bins of the previous frame (parity p^1)
                 for (int b = tid; b < C.hist_nbins; b += SNT) sh.hprev[b] = CL(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b);
-            const ListSrc src[4] = {{tot_of(TOT_REC0 + p), 64, gin.seg_rec}, {tot_of(TOT_NEW), 64, gin.seg_new},
-                                    {tot_of(TOT_CLEAN), 64, gin.seg_new}, {tot_of(TOT_DIRTY), 64, gin.seg_new}};
-            int Q[4], items[4];
+            const ListSrc src[3] = {{tot_of(TOT_REC0 + p), 64, gin.seg_rec, gin.nw}, {tot_of(TOT_NEW), 64, gin.seg_new, gin.nw},
+                                    {tot_of(TOT_DIRTY0 + p), 64, (p ? gd1 : gd0).seg_new, (p ? gd1 : gd0).nw}};
+            int Q[3], items[3];
             int new_prev = 0;                                          // arcs entered in the previous frame (read with the lists' counts)
             if (jw == 0 && tid == 0) new_prev = CL(&c.new_all[p ^ 1]);
-            build_lists<4>(sh, src, gin.nw, Q, items);
+            build_lists<3>(sh, src, Q, items);
             if (use_hist) {                                            // every workgroup evaluates the same threshold
                 float th = hist_threshold(C, sh.hprev, lane);
                 th -= normalise;                                                     // :325
@@ -1270,9 +1311,9 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const float *llrow = A.ll + (size_t)ll_slot * A.ll_stride + (size_t)(f - A.f0) * C.G;
             int out_cnt = 0;
             CLK(0);                                                    // thresholds + work lists
-            if (lr) phase_a<NE, true, true, XL, LZY>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else if (trp_lds) phase_a<NE, true, false, XL, LZY>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else phase_a<NE, false, false, XL, LZY>(C, sh, c, V, gin, gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            if (lr) phase_a<NE, true, true, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else if (trp_lds) phase_a<NE, true, false, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else phase_a<NE, false, false, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
             CLK(1);                                                    // phase A (wave 0's share)
             if (lane == 0) {
                 CS(tot_of(TOT_REC0 + (p ^ 1)) + gw, out_cnt);
@@ -1298,7 +1339,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         unsigned bx_raw = 0u;
         int err_raw = 0, np_raw = 0, stop_raw = 0;
         const bool last_frame = !init && f >= T - 1;
-        XOut xo = {exit_cnt, 0, 0, 0};
+        XOut xo = {exit_cnt, 0, 0};
         for (int round = 0;; ++round) {
             // Items are taken in chunks of KX per wave pass.  The arcs of a chunk are walked by ONE wave,
             // so when there are fewer than 64 items per wave the chunks shrink to spread the arc walk
@@ -1309,8 +1350,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 unsigned ba_raw = 0u;
                 if (!init) ba_raw = CL(&c.bestA[p]);
                 if (tid < gin.nw) sh.start[tid] = 0;
-                const ListSrc src[1] = {{tot_of(TOT_EXIT), KX, gin.seg_item}};
-                build_lists<1>(sh, src, gin.nw, Q1, n1);
+                const ListSrc src[1] = {{tot_of(TOT_EXIT), KX, gin.seg_item, gin.nw}};
+                build_lists<1>(sh, src, Q1, n1);
                 if (jw == 0 && !init) {                                // housekeeping for the frame after this one (stores:
                     // after the list's loads, so that nothing waits for their acknowledgement)
                     if (tid == 0) {
@@ -1329,8 +1370,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 bx_raw = CL(&c.bestX[p]); err_raw = CL(&c.err[p]); np_raw = CL(&c.n_paths);   // final if this round has nothing to do
                 stop_raw = CL(&c.stop_req);
                 if (tid < gin.nw) sh.start[tid] = CL(tot_of(TOT_CLS0 + (round & 1)) + tid);
-                const ListSrc src[1] = {{tot_of(TOT_CL0 + (round & 1)), KX, gin.seg_item}};
-                build_lists<1>(sh, src, gin.nw, Q1, n1);
+                const ListSrc src[1] = {{tot_of(TOT_CL0 + (round & 1)), KX, gin.seg_item, gin.nw}};
+                build_lists<1>(sh, src, Q1, n1);
                 if (Q1[0] == 0) break;
             }
             int Q = Q1[0];
@@ -1347,8 +1388,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 CS(tot_of(TOT_CL0 + ((round + 1) & 1)) + gw, deferred > 0 ? xo.item_cnt - round_start : 0);
                 CS(tot_of(TOT_CLS0 + ((round + 1) & 1)) + gw, round_start);
                 CS(tot_of(TOT_NEW) + gw, xo.new_cnt);
-                CS(tot_of(TOT_CLEAN) + gw, xo.clean_cnt);
-                CS(tot_of(TOT_DIRTY) + gw, xo.dirty_cnt);
+                CS(tot_of(TOT_DIRTY0 + p) + gw, xo.dirty_cnt);
             }
             __syncthreads();
             if (tid == 0) {
@@ -1371,7 +1411,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             for (int i0 = 0; i0 < xo.new_cnt && ok; i0 += 64) {
                 int dest = -1;
                 if (i0 + lane < xo.new_cnt) {
-                    const int b = CL(V.newl + nbase + (unsigned)(i0 + lane));
+                    const int b = (int)(unsigned)CL((const unsigned long long *)(V.newl + nbase + (unsigned)(i0 + lane)));
                     dest = ld16(V.larcs, (unsigned)b * 16u).x;
                     if (lz_status(L, dest) == LZ_CLOSED) dest = -1;
                 }
@@ -1381,6 +1421,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             if ((!ok || lz_failed(L)) && lane == 0) CS(&c.err[p], (int)JDE_LAZY);
         }
         my_item_end = xo.item_cnt;
+        if (p) gd1 = gout; else gd0 = gout;                                              // (this frame's dirty list: written by this launch)
         // ---- frame end
         {
             const unsigned bx = (unsigned)RFL((int)bx_raw);
@@ -1429,6 +1470,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         if (jw == 0) {
             const int e0 = CL(&c.err[0]), e1 = CL(&c.err[1]);
             c.frame = f; c.best_emit = best_emit; c.lst_nw = NW; c.needs_init = 0;
+            c.dirty_nw[0] = gd0.nw; c.dirty_nw[1] = gd1.nw;
             if (e0 | e1) c.error = e0 ? e0 : e1;
             else if (f < f_stop) {                                     // stopped early: collect Path records / re-plan, then go on
                 atomicAdd(A.status, 1);
