@@ -1130,8 +1130,8 @@ __global__ void jd_reset_srec_kernel(StateRec *srec, const int *row_ptr, long lo
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const int rs = row_ptr ? row_ptr[i] : 0, cnt = row_ptr ? row_ptr[i + 1] - rs : 0;
-        srec[i] = StateRec{0ULL, 0ULL, {0ULL, 0ULL}, rs, cnt, {0, 0, 0, 0, 0, 0}};
+        (void)row_ptr;
+        srec[i] = StateRec{0ULL, 0ULL, {0ULL, 0ULL}};
     }
 }
 static void reset_srec(StateRec *srec, const int *d_row_ptr, int64_t n_states)

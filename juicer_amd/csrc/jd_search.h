@@ -86,8 +86,7 @@ template <int NE> struct RecLayout {
 #define OOB_OFF 0xf0000000u          // byte offset beyond every arena: buffer loads return 0, stores are dropped
 #define REC_LABELLED 0x40000000      // bit 30 of a record's second header word: the instance's arc carries a word label
 
-// per-state search state, ONE 64-byte record (one memory sector) so that everything a token needs of the state it
-// arrives at comes with one transaction: the recombination keys and the state's CSR row.
+// per-state search state, ONE 32-byte record (half a memory sector): the recombination keys of a state.
 //   key0  best exit token arriving at the state this frame (bid in phase A, reset by its winner in phase X)
 //   keyL  ... among the tokens whose arc carries a word label (own threshold, :952-962)
 //   e[p]  best ARRIVAL at the state in a frame of parity p: (ordered score << 32) | frontier item.  Every token that
@@ -96,11 +95,12 @@ template <int NE> struct RecLayout {
 //         phase A (all arrivals at a state add the same arc weight and float addition is monotone, so the best arrival
 //         is the best candidate of every out-arc: propagateToken's per-arc comparison :560-582, done once per state).
 //         Frame f writes e[f & 1], frame f + 1 reads it, frame f + 2 zeroes it through the dirty list of that parity.
-//   rs, cnt  first out-arc and out-degree (a per-stream copy of row_ptr; unused on lazy graphs, whose rows grow)
+// The state's CSR row comes from row_ptr (shared by the streams, cache-resident; a per-stream copy inside this
+// record was measured: no faster, and 64-byte records cost configs[3] 5 %).
 // Round 2 kept one 16-byte {key, flag} record per ARC instead: an atomic, a poll and a reset per visited arc and frame,
 // each a 64-byte sector for 8 useful bytes - the memory side carried out 13-15 G atomics / s on the heavy workloads,
 // about what it can do (tools/traffic_probe: 16-17 G / s).
-struct __align__(64) StateRec { unsigned long long key0, keyL, e[2]; int rs, cnt; int pad[6]; };
+struct __align__(32) StateRec { unsigned long long key0, keyL, e[2]; };
 
 // per-stream scalars.  Line 0 is written by the host-side helper kernels and by workgroup 0 of the
 // stream's cluster at the END of a launch (nobody reads it while a launch runs, except at its
@@ -866,7 +866,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         const bool start_tok = valid && exit_kind && info.x < 0;       // recognitionStart's token: it has traversed no arc
         const bool real = valid && !start_tok && slice_no == 0;        // an item that traversed an arc (a slice has been through all this)
         const int state = !valid ? 0 : start_tok ? C.init_state : info.z;
-        // second level, in flight together: the state's record (keys and CSR row: one 64-byte sector), the word label
+        // second level, in flight together: the state's keys, its CSR row, the word label
         // of an exit token's arc, the Path reservation.  A closure item this wave queued for itself brought its row
         // along - the record was read when it arrived - and has just been found the best arrival at its state: it
         // needs no load at all.
@@ -880,7 +880,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const unsigned soff = (real || (valid && !LZY)) ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
             v4i sk = {0, 0, 0, 0};
             if (real && exit_kind) sk = ld16(V.srec_r, soff);          // {key0, keyL}
-            const v4i srow = ld16(V.srec_r, soff + 32u);               // {first arc, arcs}
+            int2 srow = make_int2(0, 0);
+            if (!LZY) { const int sti = valid ? state : 0; srow = make_int2(C.row_ptr[sti], C.row_ptr[sti + 1]); }   // (static, shared by the streams: cached loads)
             if (exit_kind && real && info.y != 0) {                    // (labelled exit tokens: a few per cent of the items)
                 if (LZY) label = ld16(V.larcs, (unsigned)info.x * 16u).w;
                 else label = C.arcs[info.x].out;
@@ -889,7 +890,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 const v4i r = ld16(V.lrows, (unsigned)state * 16u);
                 rs = r.x; rs1 = r.x + r.y; fin_lazy = __int_as_float(r.w);
                 if (valid && r.z < LZ_EXPANDED) CS(&c.err[p], (int)JDE_LAZY_INV);   // (cannot happen: the invariant of jd_lazy.h)
-            } else { rs = srow.x; rs1 = srow.x + srow.y; }
+            } else { rs = srow.x; rs1 = srow.y; }
             kv = ((unsigned long long)(unsigned)(info.y != 0 ? sk.w : sk.y) << 32) | (unsigned)(info.y != 0 ? sk.z : sk.x);
         }
         bool have = valid;
@@ -1036,9 +1037,9 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             int2 nrow = make_int2(0, 0);
             {
                 const unsigned doff = ((on && inl == 0) || is_tee) ? (unsigned)Bk.to * (unsigned)sizeof(StateRec) : OOB_OFF;
-                const v4i se = ld16(V.srec_r, doff + 16u), sr = ld16(V.srec_r, doff + 32u);
+                const v4i se = ld16(V.srec_r, doff + 16u);
+                if (!LZY) { const int ti = doff != OOB_OFF ? Bk.to : 0; const int r0 = C.row_ptr[ti]; nrow = make_int2(r0, C.row_ptr[ti + 1] - r0); }
                 skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
-                nrow = make_int2(sr.x, sr.y);
             }
             if (on) ++c_arcs;
             if (on && inl == 0) {                                      // :533-540 epsilon input

@@ -185,3 +185,97 @@ def test_configs3_full_size(built):
         assert gs[v].n > 0
         t = gs[v].time[::-1]
         assert np.all(np.diff(t) >= 0) and t[-1] <= feats[v].shape[0] - 1
+
+
+def test_north_star_workload_parity(built):
+    """BASELINE.json north_star at its size: the 14.3 M-arc trigram-shaped composed graph bench.py's north_star leg
+    decodes (5000 tied states x 16 mixtures), mainBeam 200 - two utterances against the CPU oracle, certified not
+    to depend on the visiting order of equal-score tokens (the oracle manages ~100 frames / s here), the reference's
+    statistics bit-equal, plus the batch properties."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, words = synth.config_c4(seed=0, n_utts=8, n_words=10000, n_tri_hist=100_000)
+    assert net.n_arcs > 10_000_000 and am.n_gmm == 5000
+    kw = dict(main_beam=200.0)
+    gs = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=8, **kw).decode_batch(feats)
+    od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+    order = np.argsort([f.shape[0] for f in feats])
+    for u in order[:2]:                                               # the two shortest: the oracle's minutes are the test's
+        o = od.decode_certified(feats[u])
+        print("north star: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties, oracle %.1f frames/s"
+              % (u, feats[u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"], feats[u].shape[0] / o.cpu_seconds))
+        assert_hyp_matches(gs[u], o, "north star utt %d" % u)
+        assert o.n > 0 and o.stats["tot_insts_in"] / o.stats["n_frames"] > 50_000
+    for v in range(8):
+        assert gs[v].n > 0
+
+
+@pytest.fixture(scope="module")
+def clg_pair(built):
+    """BASELINE.json configs[4] at bench.py's size: lexicon tree (20 k words) and back-off trigram G, apart."""
+    from juicer_amd import capi, synth
+    am = synth.make_models(0, n_gmm=3000, n_hmm=2000, n_mix=16, n_tm=8, sep=0.6, with_tee=True)
+    cl, g = synth.make_cl_g(0, am, n_words=20000, n_succ=40, n_tri=200000, n_succ3=8, with_sp=True)
+    ncl, ng = capi.Network.from_synth(cl, 1.0, 0.0), capi.Network.from_synth(g, 10.0, 0.0)
+    feats = [synth.sample_utterance(100 + u, g, am, 8)[0] for u in range(6)]
+    return dict(am=am, g=g, ncl=ncl, ng=ng, feats=feats, gam=capi.Models.from_htk(am))
+
+
+def test_configs4_bench_size_composed_graph_vs_oracle(clg_pair):
+    """configs[4] at the size bench.py runs it: C.L o G composed ON THE DEVICE (8.4 M arcs), decoded at mainBeam 200 by
+    the static search - and by the CPU oracle on the SAME device-composed CSR (read back through the C ABI): words,
+    times, scores and the reference's statistics.  Then the search-driven composition (nothing composed beforehand)
+    on the same pair: bit-identical hypotheses."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    p = clg_pair
+    net = capi.Network.compose(p["ncl"], p["ng"], max_states=1 << 26, max_arcs=1 << 27)
+    assert net.n_arcs > 8_000_000
+    kw = dict(main_beam=200.0)
+    gs = capi.Decoder(net, p["gam"], max_streams=len(p["feats"]), **kw).decode_batch(p["feats"])
+    c = net.csr()
+    fs = np.nonzero(np.isfinite(c["fin_w"]))[0].astype(np.int32)
+    od = OracleDecoder(OracleNet.from_csr(net.n_states, net.init_state, c["row_ptr"], c["to"], c["w"], c["ilab"], c["olab"], fs, c["fin_w"][fs]),
+                       OracleAM(p["am"]), **kw)
+    for u in range(2):
+        o = od.decode_certified(p["feats"][u])
+        print("configs[4] graph: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties, oracle %.1f frames/s"
+              % (u, p["feats"][u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"], p["feats"][u].shape[0] / o.cpu_seconds))
+        assert_hyp_matches(gs[u], o, "configs[4] utt %d" % u)
+        assert o.n > 0
+    lazy = capi.Network.lazy(p["ncl"], p["ng"], p["gam"], max_states=1 << 22, max_arcs=1 << 23)
+    got = capi.Decoder(lazy, p["gam"], max_streams=len(p["feats"]), **kw).decode_batch(p["feats"])
+    ns, na = lazy.lazy_size()
+    assert 0 < ns < net.n_states
+    for a, b in zip(got, gs):
+        assert a.n == b.n and a.n > 0 and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
+        for k in ("score", "ac", "lm"):
+            assert np.array_equal(np.asarray(getattr(a, k), np.float32).view(np.uint32), np.asarray(getattr(b, k), np.float32).view(np.uint32)), k
+
+
+def test_device_composition_at_100k_arcs_vs_python_reference(built):
+    """jd_net_compose against the same definition written in Python dictionaries (tests/compose_ref.py) on a pair whose
+    composition has > 100 k arcs (1500 words, 6000 trigram histories): identical arrays, bit for bit, with and without
+    weight pushing; and the search-driven composition of that pair decodes like the composed graph."""
+    from compose_ref import compose_filtered
+    from juicer_amd import capi, synth
+    am = synth.make_models(3, n_gmm=300, n_hmm=200, n_mix=2, n_tm=8, sep=0.6, with_tee=True)
+    cl, g = synth.make_cl_g(3, am, n_words=1500, n_succ=12, n_tri=6000, n_succ3=4, with_sp=True)
+    ncl, ng = capi.Network.from_synth(cl, 1.0, 0.0), capi.Network.from_synth(g, 5.0, 0.0)
+    models = capi.Models.from_htk(am)
+    feats = [synth.sample_utterance(3000 + u, g, am, 5 + u)[0] for u in range(3)]
+    for pushing in (False, True):
+        dev = capi.Network.compose(ncl, ng, pushing=pushing)
+        want = compose_filtered(ncl.csr(), ncl.init_state, ng.csr(), ng.init_state, pushing=pushing)
+        got = dev.csr()
+        assert dev.n_arcs > 100_000 and dev.n_states == want["n_states"] and dev.init_state == want["init"]
+        for k in ("row_ptr", "to", "ilab", "olab"):
+            assert np.array_equal(got[k], want[k]), k
+        assert np.array_equal(got["w"].view(np.uint32), want["w"].view(np.uint32))
+        assert np.array_equal(got["fin_w"].view(np.uint32), want["fin_w"].view(np.uint32))
+        a = capi.Decoder(dev, models, max_streams=3, main_beam=250.0).decode_batch(feats)
+        lazy = capi.Network.lazy(ncl, ng, models, max_states=1 << 18, max_arcs=1 << 19, pushing=pushing)
+        b = capi.Decoder(lazy, models, max_streams=3, main_beam=250.0).decode_batch(feats)
+        for x, y in zip(a, b):
+            assert x.n == y.n and x.n > 0 and np.array_equal(x.label, y.label) and np.array_equal(x.time, y.time)
+            assert np.array_equal(np.asarray(x.score, np.float32).view(np.uint32), np.asarray(y.score, np.float32).view(np.uint32))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of k_search in one of bench.py's extra legs: tools/leg_pmc.sh north|c3|clg  (GPU box, through gpurun).
+# HBM traffic of k_search in one of bench.py's workloads: tools/leg_pmc.sh c2|north|c3|clg  (GPU box, through gpurun).
 # Two PMC passes, each with --kernel-trace only; summary -> gpurun_out/prof_<leg>/pmc_summary.json
 set -u
 cd "$(dirname "$0")/.." || exit 1
@@ -16,7 +16,9 @@ for set in "FETCH_SIZE SQ_WAVES" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
 done
 python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
 python - "$OUT" "$LEG" <<'PY'
-import json, sys
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
 d = json.load(open(sys.argv[1] + "/pmc_summary.json"))
 tot_f = tot_w = 0.0
 for k, v in d.items():
@@ -24,9 +26,16 @@ for k, v in d.items():
         print(k, {c: (x["launches"], round(x["mean"], 1), round(x["max"], 1)) for c, x in v.items()})
         tot_f += v["FETCH_SIZE"]["mean"] * v["FETCH_SIZE"]["launches"]
         tot_w += v["WRITE_SIZE"]["mean"] * v["WRITE_SIZE"]["launches"]
-# tools/run_leg.py <leg> 2 = a warm-up pass and a timed pass of the same batch: HBM bytes of one pass, all k_search launches
-# ((2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE reports half of a wide read, MI355X_MICROARCH.md)
-out = {"leg": sys.argv[2], "passes": 2, "k_search_hbm_bytes_per_pass": (2.0 * tot_f + tot_w) * 1024.0 / 2.0,
+# tools/run_leg.py <leg> 2 = a warm-up pass and a timed pass of the same batch: HBM bytes of ONE pass, all k_search
+# launches, calibrated (bench.calibrated_traffic: the counters tally scattered accesses and writes exactly and wide
+# coalesced reads at half - the launch's wide reads are its instance records, 80 B per instance processed)
+leg = json.load(open(sys.argv[1] + "/leg_under_pmc1.json"))
+wide = 80.0 * leg["per_stream_frame"]["tot_insts_in"] * leg["frames_per_step"]
+out = {"leg": sys.argv[2], "passes": 2, "k_search_hbm_bytes_per_pass": bench.calibrated_traffic(tot_f / 2.0, tot_w / 2.0, wide),
+       "uncalibrated_2xFETCH_plus_WRITE_bytes_per_pass": (2.0 * tot_f + tot_w) * 1024.0 / 2.0,
+       "FETCH_SIZE_KiB_per_pass": tot_f / 2.0, "WRITE_SIZE_KiB_per_pass": tot_w / 2.0, "wide_read_bytes_per_pass": wide,
+       "algorithmic_bytes_per_pass": leg["roofline"]["algorithmic_bytes_per_launch"] * leg["roofline"]["launches_per_step"],
+       "search_ms_under_pmc": leg["search_ms"], "source_hash": bench.kernel_source_hash(),
        "source": "tools/leg_pmc.sh: rocprofv3 --kernel-trace --pmc, FETCH_SIZE and WRITE_SIZE in separate runs of `python tools/run_leg.py %s 2`" % sys.argv[2]}
 json.dump(out, open(sys.argv[1] + "/leg_traffic.json", "w"), indent=1)
 print(out)

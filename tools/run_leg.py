@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One of bench.py's extra legs on its own (GPU box): python tools/run_leg.py north|c3|hyps|clg [passes [utterances of the c3 leg]]"""
+"""One of bench.py's workloads on its own (GPU box): python tools/run_leg.py c2|north|c3|hyps|clg [passes [utterances of the c3 leg]]"""
 import json
 import os
 import sys
@@ -22,6 +22,9 @@ elif which == "clg":
 elif which == "c3":
     a, n, f, _ = synth.config_c4(seed=0, n_utts=n_utts or 8)
     out = bench.run_leg("configs[3]", a, n, f, 300.0, 0, dev, passes=passes, pmc_leg="c3" if not n_utts or n_utts == 8 else None)
+elif which == "c2":
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
+    out = bench.run_leg("configs[1]", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c2")
 else:
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
     out = bench.run_leg("configs[1] + histogram pruning", a, n, f, 150.0, 6000, dev, passes=passes)
