@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -840,6 +841,9 @@ extern "C" int jd_am_score_frames(const jd_am *a, int32_t device, const float *f
     return JD_OK;
 }
 
+#define JD_MAX_DEVICES 64
+static std::mutex g_search_mu[JD_MAX_DEVICES];     // one persistent search launch at a time per device (launch_search)
+
 struct HostResult {
     std::vector<int32_t> label, time;
     std::vector<float> score, ac, lm;
@@ -880,7 +884,7 @@ struct jd_dec {
     int *d_status = nullptr; int *h_status = nullptr;
     bool xl_ok = true;                    // XCD-local launches allowed (JD_XCD_LOCAL=0 or one failed placement check switch them off)
     double xl_slack = 1.04;               // ... when the packed plan is predicted to end no later than this times the unpacked one (JD_XL_SLACK)
-    long long *d_dbg = nullptr;           // in-kernel cycle accounting (jd_dec_debug_trace)
+    long long *d_dbg = nullptr, *d_dbg_buf = nullptr;   // in-kernel cycle accounting (jd_dec_debug_trace): in use / allocated
     // chunked pipeline
     int Fc = 128;                         // frames per scoring chunk of the streaming API (jd_stream_push)
     int Fw_env = 0;                       // JD_FC: frames per chunk of the batch path (0 = as long as the longest utterance)
@@ -1430,7 +1434,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     const int n_work = (int)work_in.size();
     SearchArgs A;
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work;
-    const int nwg = std::max(1, d->n_cus);
+    const int nwg = std::max(1, d->n_cus * WG_PER_CU);
     // a wave segment holds at least one 64-record chunk of instances and 512 frontier items (one wave
     // writes the whole epsilon closure of the items it expands)
     const int cw_cap = (int)std::max<int64_t>(1, std::min<int64_t>(d->cap_slots / (64 * SW), d->cap_items / (512 * SW)));
@@ -1551,8 +1555,16 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
     A.status = d->d_status; A.dbg = d->d_dbg; A.rebalance_at = rebalance_at;
     A.xl_selftest = getenv("JD_XL_SELFTEST") ? 1 : 0;                 // (test knob, see SearchArgs)
-        hipEvent_t e0, e1;
-        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev0, ev1;
+        HIPCHK(hipEventCreate(&ev0.e)); HIPCHK(hipEventCreate(&ev1.e));
+        const hipEvent_t e0 = ev0.e, e1 = ev1.e;
+        // k_search is persistent and its clusters spin at barriers of their own: ALL its workgroups have to be resident
+        // at once (one per CU).  Two such launches dispatched side by side - two decoders of this process on one device,
+        // driven from two host threads - could each hold part of the CUs and wait for the rest until the barriers time
+        // out: launches on one device are serialised here, from dispatch to completion.  (Other PROCESSES on the device
+        // are outside this lock: the dispatcher starts the workgroups of a kernel in order, and a kernel that cannot
+        // become fully resident ends in JDE_BARRIER after 30 s instead of hanging.)
+        std::lock_guard<std::mutex> search_lock(g_search_mu[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)]);
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
         HIPCHK(hipEventRecord(e0, st));
         if (d->C.lazy) {   // (the graph's own words are agent scope in either flavour: jd_lazy.h)
@@ -1580,7 +1592,6 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             d->xl_ok = false;
             if (getenv("JD_VERBOSE")) fprintf(stderr, "k_search: %d cluster(s) not on one XCD - agent-scope launches from here on\n", d->h_status[1]);
         }
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         d->timing.search_launches += 1;
         d->timing.cluster_wgs = A.Cw;
         if (d->h_status[0] == 0 && d->h_status[1] == 0) break;
@@ -1701,7 +1712,12 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     hipLaunchKernelGGL(jd_set_T_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, 0, nb, d->d_T);
     HIPCHK(hipGetLastError());
 
-    std::vector<hipEvent_t> gs((size_t)n_chunks), ge((size_t)n_chunks);
+    struct Events {                                                    // (destroyed on every way out, error paths included)
+        std::vector<hipEvent_t> v;
+        ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+    } ev_gs, ev_ge;
+    ev_gs.v.assign((size_t)n_chunks, nullptr); ev_ge.v.assign((size_t)n_chunks, nullptr);
+    std::vector<hipEvent_t> &gs = ev_gs.v, &ge = ev_ge.v;
     for (int c = 0; c < n_chunks; ++c) { HIPCHK(hipEventCreate(&gs[(size_t)c])); HIPCHK(hipEventCreate(&ge[(size_t)c])); }
     auto w0 = std::chrono::steady_clock::now();
     // Scoring runs one chunk ahead of the search on its own stream.  launch_search returns when its
@@ -1762,7 +1778,6 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     for (int c = 0; c < n_chunks; ++c) {
         float gms = 0.0f;
         if (hipEventElapsedTime(&gms, gs[(size_t)c], ge[(size_t)c]) == hipSuccess) d->timing.gmm_ms += gms;
-        (void)hipEventDestroy(gs[(size_t)c]); (void)hipEventDestroy(ge[(size_t)c]);
     }
     d->timing.gmm_wait_ms += waited_ms;
     d->timing.gmm_launches += n_chunks;
@@ -2002,12 +2017,13 @@ extern "C" int jd_dec_debug_trace(jd_dec *d, int32_t enable, int64_t *fetch)
         HIPCHK(hipMemcpy(fetch, d->d_dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
     } else if (fetch) memset(fetch, 0, n * sizeof(int64_t));
     if (enable >= 0 && !fetch) {
-        if (!d->d_dbg) {
+        if (!d->d_dbg_buf) {                                           // (one buffer per decoder, kept when tracing is switched off)
             long long *p = nullptr;
             HIPCHK(hipMalloc(&p, n * sizeof(long long)));
             d->allocs.push_back(p);
-            d->d_dbg = p;
+            d->d_dbg_buf = p;
         }
+        d->d_dbg = d->d_dbg_buf;
         HIPCHK(hipMemset(d->d_dbg, 0, n * sizeof(long long)));
     } else if (enable < 0) d->d_dbg = nullptr;
     return JD_OK;

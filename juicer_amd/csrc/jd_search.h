@@ -34,7 +34,12 @@
 // arrives at a barrier.  Static data (graph, models, likelihoods) uses plain cached loads.
 #pragma once
 
+#ifndef SW
 #define SW 8                         // waves per search workgroup
+#endif
+#ifndef WG_PER_CU
+#define WG_PER_CU 1                  // search workgroups resident per CU
+#endif
 #define SNT (SW * 64)                // threads per search workgroup
 #define MAXW SNT                      // most waves one cluster may have (one thread per wave when the lists are set up)
 #define MAXCW (MAXW / SW)
@@ -1419,7 +1424,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 for (unsigned long long bm = __ballot(dest >= 0); bm && ok; bm &= bm - 1)
                     ok = lz_close(L, C.hmm_tee, __shfl(dest, __ffsll((long long)bm) - 1), lzq[wid], t_limit);
             }
-            if ((!ok || lz_failed(L)) && lane == 0) CS(&c.err[p], (int)JDE_LAZY);
+            // (raised behind the frame's last barrier, so into BOTH parities: the next frame's error check reads the other one)
+            if ((!ok || lz_failed(L)) && lane == 0) { CS(&c.err[p], (int)JDE_LAZY); CS(&c.err[p ^ 1], (int)JDE_LAZY); }
         }
         my_item_end = xo.item_cnt;
         if (p) gd1 = gout; else gd0 = gout;                                              // (this frame's dirty list: written by this launch)
@@ -1472,7 +1478,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const int e0 = CL(&c.err[0]), e1 = CL(&c.err[1]);
             c.frame = f; c.best_emit = best_emit; c.lst_nw = NW; c.needs_init = 0;
             c.dirty_nw[0] = gd0.nw; c.dirty_nw[1] = gd1.nw;
-            if (e0 | e1) c.error = e0 ? e0 : e1;
+            // (a network out of room is the cause; "a token on an unexpanded state" what follows from it)
+            if (e0 | e1) c.error = (e0 == (int)JDE_LAZY || e1 == (int)JDE_LAZY) ? (int)JDE_LAZY : (e0 ? e0 : e1);
             else if (f < f_stop) {                                     // stopped early: collect Path records / re-plan, then go on
                 atomicAdd(A.status, 1);
                 if (stop_seen) atomicAdd(A.status + 3, 1);
@@ -1488,7 +1495,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
 // the clusters by the streams' recent load.  All workgroups of the grid must be resident at once:
 // the host sizes the grid to the device (one 512-thread workgroup per CU).
 template <int NE, bool XL, bool LZY>
-__global__ __launch_bounds__(SNT) void k_search(SearchArgs A)
+__global__ __launch_bounds__(SNT, WG_PER_CU) void k_search(SearchArgs A)
 {
     __shared__ SearchShared sh;
     int k, kstep, jw, Cw;

@@ -32,6 +32,16 @@ def main():
             ok = ok and g["n"] == r.n and r.n > 0 and np.array_equal(g["label"], r.label) and np.array_equal(g["time"], r.time)
             ok = ok and np.array_equal(g["score"].view(np.uint32), r.score.view(np.uint32))
             ok = ok and np.float32(g["tot_ac"]).view(np.uint32) == np.float32(r.tot_ac).view(np.uint32)
+    # the same batch dealt by length (BASELINE.json configs[2]'s sharding), short gather records (a longer hypothesis
+    # makes the gather ask again)
+    shards = parallel.shard_lpt([f.shape[0] for f in feats], world)
+    mine = capi.Decoder(gnet, gam, device=0, max_streams=max(1, len(shards[rank])), **kw).decode_batch([feats[u] for u in shards[rank]])
+    bal = parallel.gather_hyps(mine, max(len(x) for x in shards), max_words=2, index=shards[rank])
+    if rank == 0:
+        ok = ok and len(bal) == len(feats)
+        for g, r in zip(bal, ref):
+            ok = ok and g["n"] == r.n and np.array_equal(g["label"], r.label) and np.array_equal(g["time"], r.time)
+            ok = ok and np.array_equal(g["score"].view(np.uint32), r.score.view(np.uint32))
         print("multirank: %d records gathered from %d ranks, identical to the single-rank decode: %s" % (len(allh), world, ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -40,3 +40,16 @@ def test_bench_spawns_its_own_ranks(built):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["gathered_hyps"] == 12 and d["value"] > 0
+
+
+def test_bench_strong_scaling_mode(built):
+    """`--total-utts N` (BASELINE.json configs[2] with N = 512): ONE batch dealt over the ranks by length; every
+    utterance comes back exactly once and the line says "strong"."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--total-utts", "11",
+           "--arcs", "60000", "--no-cpu-baseline", "--no-extra-legs"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gathered_hyps"] == 11 and d["value"] > 0
