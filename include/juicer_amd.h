@@ -294,12 +294,16 @@ int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out);
  *
  * jd_dec_set_partial_interval = setPartialDecodeOptions (:892-896; the reference takes the value
  * from the environment variable PartialTraceInterval, :116-119; 0 = off, the default).  With an
- * interval > 0 jd_stream_push traces on the reference's schedule - together with the path
- * collection of the first frame f with f - lastPathCollectFrame > 100, if
- * f - lastPartialTraceFrame > interval (:362-368) - and jd_stream_finish completes the list from
- * the best token (:245-251).  Of the two collection triggers only this frame rule exists here;
- * the other one (nPath / nPathNew > 12 with nPath > 10000) counts the reference allocator's live
- * Path objects.  It decides when a trace is taken, never what a trace at a given frame finds.
+ * interval > 0 jd_stream_push traces on the reference's schedule - together with a path
+ * collection, if f - lastPartialTraceFrame > interval (:362-368) - and jd_stream_finish completes
+ * the list from the best token (:245-251).  A collection runs after frame f under the reference's
+ * two triggers (:362): f - lastPathCollectFrame > 100, or nPath / nPathNew > 12 with nPath > 10000.
+ * The first is exact.  The second counts Path objects; the counts here are this build's own - the
+ * records in its arena and the number its last collection kept - which are at most the
+ * reference's (the reference also creates a Path for every token that then loses its state's
+ * recombination), so the count trigger fires no earlier than the reference's.  The schedule decides
+ * when a trace is taken, never what a trace at a given frame finds.
+ * jd_stream_collect_info: collections of the stream's utterance so far and lastPathCollectFrame.
  *
  * jd_stream_partial returns the stream's partialPaths - (output label, frame) of each record,
  * oldest first; *n is the full length, at most cap entries are written - after, if trace_now != 0,
@@ -308,6 +312,7 @@ int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out);
  * ends up with is the hypothesis itself (jd_hyp.label / .time, newest first).
  */
 int jd_dec_set_partial_interval(jd_dec *d, int32_t interval);
+int jd_stream_collect_info(jd_dec *d, int32_t s, int32_t *n_collections, int32_t *last_collect_frame);
 int jd_stream_partial(jd_dec *d, int32_t s, int32_t trace_now, int32_t cap, int32_t *n,
                       int32_t *labels, int32_t *times, int32_t *found);
 

@@ -75,7 +75,7 @@ EXPORTS = [
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
-    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
+    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
 ]
 
 _lib = None
@@ -377,6 +377,12 @@ class Decoder:
     # -- PARTIAL_DECODING (WFSTDecoderLite.cpp:822-896)
     def set_partial_interval(self, interval: int):
         _check(lib().jd_dec_set_partial_interval(self.h, C.c_int32(interval)))
+
+    def stream_collect_info(self, s: int = 0):
+        """(collectPaths runs of the stream's utterance so far, lastPathCollectFrame) - counted while PARTIAL_DECODING is on."""
+        n, last = C.c_int32(0), C.c_int32(-1)
+        _check(lib().jd_stream_collect_info(self.h, C.c_int32(s), C.byref(n), C.byref(last)))
+        return n.value, last.value
 
     def stream_partial(self, s: int = 0, trace_now: bool = False):
         """(found, partialPaths as [(label, frame)], oldest first); trace_now runs tracePartialPath first."""

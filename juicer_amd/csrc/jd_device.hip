@@ -377,7 +377,8 @@ __global__ __launch_bounds__(1024) void k_gc_begin(DecConst C, StreamCtl *ctl, S
     gc_ctx(C, ctl, work, s_single, G, x);
     const StreamCtl &c = ctl[x.s];
     StreamDev &S = streams[x.s];
-    const bool active = c.started && !c.needs_init && c.error == 0 && x.np > C.gc_threshold && x.nw > 0;
+    const bool active = c.started && !c.needs_init && c.error == 0 && x.nw > 0 &&
+                        (x.np > C.gc_threshold || (C.path_rule && path_rule_fires(x.np, c.path_new)));
     GcState *gs = (GcState *)S.gc_state;
     if (x.blk == 0 && threadIdx.x == 0) { gs->active = active ? 1 : 0; gs->kept = 0; }
     if (!active) return;
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(1024) void k_gc_remap(DecConst C, StreamCtl *ctl, S
         if (c.best_final.path >= 0) c.best_final.path = idx[c.best_final.path];
         PathRec *tmp = S.paths; S.paths = S.paths2; S.paths2 = tmp;
         c.n_paths = gs->kept;
+        c.path_new = gs->kept; c.n_collect += 1;      // nPathNew = nPath (:745)
     }
 }
 
@@ -899,8 +901,10 @@ struct jd_dec {
     // PARTIAL_DECODING (WFSTDecoderLite.h:199-205), streaming API
     int partial_interval = 0;                  // partialTraceInterval
     std::vector<int> last_collect, last_trace; // lastPathCollectFrame, lastPartialTraceFrame
+    std::vector<int> n_collect_host;           // collections of the stream's utterance so far (jd_stream_collect_info)
     std::vector<std::vector<int32_t>> partial_label, partial_time;   // partialPaths, oldest first
     int *d_partial_out = nullptr;
+    bool return_on_collect = false, collected_now = false;   // jd_stream_push: launch_search comes back after a collection by the count rule
     float *d_push = nullptr; size_t push_cap = 0;
     // results
     std::vector<HostResult> results;
@@ -1088,6 +1092,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     d->stream_T.assign((size_t)max_streams, 0);
     d->stream_started.assign((size_t)max_streams, 0);
     d->last_collect.assign((size_t)max_streams, -1);
+    d->n_collect_host.assign((size_t)max_streams, 0);
     d->last_trace.assign((size_t)max_streams, -1);
     d->partial_label.resize((size_t)max_streams);
     d->partial_time.resize((size_t)max_streams);
@@ -1603,6 +1608,9 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         if (d->h_status[0] > d->h_status[3]) {                             // (not when every stop was for a re-plan)
             launch_gc(d->C, d->d_ctl, d->d_streams, d->d_work, n_work, 0, ne3, d->n_cus, st);
             HIPCHK(hipGetLastError());
+            // PARTIAL_DECODING: the trace rides on the collection (:362-368) - the caller has to see the stream as it
+            // stands right after one (jd_stream_push; it goes on from there)
+            if (d->return_on_collect) { HIPCHK(hipStreamSynchronize(st)); d->collected_now = true; return JD_OK; }
         }
         // A stream that stopped for a collection after n frames will, by and large, stop again after as many
         // (its records per frame change slowly): what it has ahead IN THE NEXT LAUNCH is the smaller of that
@@ -1864,6 +1872,7 @@ extern "C" int jd_stream_init(jd_dec *d, int32_t s)
     d->stream_T[(size_t)s] = 0;
     d->stream_started[(size_t)s] = 1;
     d->last_collect[(size_t)s] = -1; d->last_trace[(size_t)s] = -1;    // WFSTDecoderLite.cpp:179-181, 202-206
+    d->n_collect_host[(size_t)s] = 0;
     d->partial_label[(size_t)s].clear(); d->partial_time[(size_t)s].clear();
     return JD_OK;
 }
@@ -1905,10 +1914,8 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
     hipStream_t st = d->s_search;
     for (int done = 0, n = 0; done < n_frames; done += n) {
         n = std::min(Fc, n_frames - done);
-        // PARTIAL_DECODING rides on the path collection's frame rule (:362-368): collection happens
-        // after the first frame f with f - lastPathCollectFrame > 100, and the trace with it when the
-        // interval has passed.  (The reference's other collection trigger, nPath / nPathNew > 12 with
-        // nPath > 10000, counts its allocator's live Path objects and has no counterpart here.)
+        // PARTIAL_DECODING rides on the path collection (:362-368): a chunk ends at the frame rule's frame
+        // (the first frame f with f - lastPathCollectFrame > 100)
         const int f_collect = d->last_collect[(size_t)s] + 101;
         if (d->partial_interval > 0) n = std::min(n, std::max(1, f_collect + 1 - d->stream_T[(size_t)s]));
         if ((size_t)n * D > d->push_cap) {
@@ -1932,17 +1939,56 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
         hipLaunchKernelGGL(jd_set_T_kernel, dim3(1), dim3(64), 0, st, d->d_ctl, s, 1, d->d_T + s);
         rc = launch_gmm(d->am, d->amb, d->d_push, d->d_row_src, n, d->d_ll[0], st);
         if (rc) return rc;
-        rc = launch_search(d, std::vector<int2>(1, make_int2(s, 0)), d->d_ll[0], (long long)Fc * G, f0, Tnew, st);
-        if (rc) return rc;
-        d->stream_T[(size_t)s] = Tnew;
-        if (d->partial_interval > 0 && Tnew - 1 == f_collect) {
-            d->last_collect[(size_t)s] = f_collect;                    // :746
-            if (f_collect - d->last_trace[(size_t)s] > d->partial_interval) {
-                rc = trace_partial(d, s, nullptr);
-                if (rc) return rc;
+        if (d->partial_interval <= 0) {
+            rc = launch_search(d, std::vector<int2>(1, make_int2(s, 0)), d->d_ll[0], (long long)Fc * G, f0, Tnew, st);
+            if (rc) return rc;
+            d->stream_T[(size_t)s] = Tnew;
+            continue;
+        }
+        // PARTIAL_DECODING: collectPaths runs after a frame when the count rule fires (path_rule_fires, evaluated by
+        // the kernel after every frame: the launch then stops, the collection runs and launch_search comes back) or
+        // the frame rule does (the chunk ends there), and the trace rides on it (:362-368)
+        for (;;) {
+            d->return_on_collect = true; d->collected_now = false;
+            rc = launch_search(d, std::vector<int2>(1, make_int2(s, 0)), d->d_ll[0], (long long)Fc * G, f0, Tnew, st);
+            d->return_on_collect = false;
+            if (rc) return rc;
+            StreamCtl hc;
+            HIPCHK(hipMemcpy(&hc, d->d_ctl + s, sizeof hc, hipMemcpyDeviceToHost));
+            if (hc.error != 0) { d->stream_T[(size_t)s] = Tnew; break; }   // (reported by jd_stream_finish)
+            const int at = hc.frame - 1;                               // the last frame processed
+            bool collected = d->collected_now;
+            if (!collected && hc.frame >= Tnew && (at - d->last_collect[(size_t)s] > 100 || path_rule_fires(hc.n_paths, hc.path_new))) {
+                // the rule fires behind the chunk's last frame (the kernel looks before a frame, not after the last one)
+                DecConst Cg = d->C;
+                Cg.gc_threshold = -1;                                  // (every started stream collects)
+                launch_gc(Cg, d->d_ctl, d->d_streams, nullptr, 1, s, d->am->max_n <= 5, d->n_cus, st);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(st));
+                collected = true;
             }
+            d->stream_T[(size_t)s] = hc.frame;
+            if (collected) {
+                d->last_collect[(size_t)s] = at;                       // :746
+                d->n_collect_host[(size_t)s] += 1;
+                if (at - d->last_trace[(size_t)s] > d->partial_interval) {
+                    rc = trace_partial(d, s, nullptr);
+                    if (rc) return rc;
+                }
+            }
+            if (hc.frame >= Tnew) break;
         }
     }
+    return JD_OK;
+}
+
+// collectPaths runs (WFSTDecoderLite.cpp:362) of stream s since its init, and the frame after which the last one ran
+// (lastPathCollectFrame, :746; -1: none yet).  Counted while PARTIAL_DECODING is on (jd_dec_set_partial_interval > 0).
+extern "C" int jd_stream_collect_info(jd_dec *d, int32_t s, int32_t *n_collections, int32_t *last_collect_frame)
+{
+    if (!d || s < 0 || s >= d->max_streams) return jd_fail(JD_EINVAL, "jd_stream_collect_info: bad argument");
+    if (n_collections) *n_collections = d->n_collect_host[(size_t)s];
+    if (last_collect_frame) *last_collect_frame = d->last_collect[(size_t)s];
     return JD_OK;
 }
 
@@ -1952,6 +1998,7 @@ extern "C" int jd_dec_set_partial_interval(jd_dec *d, int32_t interval)
 {
     if (!d || interval < 0) return jd_fail(JD_EINVAL, "jd_dec_set_partial_interval: traceInterval >= 0");
     d->partial_interval = interval;
+    d->C.path_rule = interval > 0 ? 1 : 0;             // (the kernel then watches collectPaths' count rule as well)
     return JD_OK;
 }
 

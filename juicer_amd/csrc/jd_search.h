@@ -37,6 +37,9 @@
 #ifndef SW
 #define SW 8                         // waves per search workgroup
 #endif
+#ifndef JD_KBOUNDS
+#define JD_KBOUNDS __launch_bounds__(SNT, WG_PER_CU)
+#endif
 #ifndef WG_PER_CU
 #define WG_PER_CU 1                  // search workgroups resident per CU
 #endif
@@ -45,7 +48,9 @@
 #define MAXCW (MAXW / SW)
 #define TEE_FLAG 0x40000000          // bit 30 of the device arc's in-label: the arc's HMM is a tee model
 #define TRP_LDS_MAX 4096             // floats of transition tables cached in LDS (else read from HBM)
+#ifndef TEE_LDS_MAX
 #define TEE_LDS_MAX 2048             // HMMs whose tee log-probability is cached in LDS
+#endif
 
 enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_INSTS, ST_N };
 enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_LAZY = -45, JDE_LAZY_INV = -46, JDE_BARRIER = -50 };
@@ -69,6 +74,7 @@ struct DecConst {
     int gc_threshold;   // a launch stops early (for the collection, k_gc_*) when more Path records than this are in use
     int x_chunks;       // phase X: chunks per wave the item lists are cut into (dynamic hand-out balances the arc walks)
     int exp;            // development experiments (JD_EXP)
+    int path_rule;      // PARTIAL_DECODING is on: a stream also stops for a collection by the reference's count rule (path_rule_fires)
 };
 
 // An active arc instance (NetInst, WFSTDecoderLite.h:66-75) is a record of 16-byte fields: header
@@ -118,7 +124,9 @@ struct __align__(128) StreamCtl {
     int n_rec_hint;     // instances in the current list (statistics / capacity planning only)
     float best_emit;    // bestEmitScore left by the last processed frame (:321)
     int dirty_nw[2];    // number of wave segments the dirty list of each frame parity was written with (it lives two frames)
-    int pad0[22];
+    int path_new;       // Path records the last collection kept (nPathNew, WFSTDecoderLite.cpp:745; 0: none yet in this utterance)
+    int n_collect;      // collections in this utterance
+    int pad0[20];
     __align__(128) int new_all[2];           // arcs entered without an instance in a frame of that parity (listed or not)
     __align__(128) unsigned bar;             // cluster barrier (zeroed by the host before every launch)
     __align__(128) unsigned xbar, xmask;     // placement handshake of an XCD-local launch (agent scope; zeroed with bar)
@@ -248,7 +256,7 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v)
 }
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 
-#define NLISTS 4
+#define NLISTS 3
 struct SearchShared {
     int pfx[NLISTS][MAXW + 1]; int cnt[NLISTS][MAXW];   // chunk prefix / fill counts of the lists a phase reads
     int start[MAXW];                           // per writer wave: where its items of the current round begin
@@ -357,6 +365,15 @@ __device__ __forceinline__ int grab_chunk(SearchShared &sh, int jw, int Cw)
     int k = 0;
     if ((threadIdx.x & 63) == 0) k = atomicAdd(&sh.next, 1);
     return jw + RFL(k) * Cw;
+}
+
+// collectPaths' count trigger (WFSTDecoderLite.cpp:360-362): nPath / nPathNew > 12 and nPath > 10000, with the IEEE float
+// division of the reference (nPathNew = 0 before the first collection: the ratio is +inf).  The counts are this
+// build's own: its Path records in use and the number its last collection kept - at most the reference's, which
+// also creates records for tokens that lose their state's recombination.
+__device__ __host__ __forceinline__ bool path_rule_fires(int n_path, int n_path_new)
+{
+    return n_path > 10000 && (float)n_path / (float)n_path_new > 12.0f;
 }
 
 // ---- cluster barrier: all Cw workgroups of one stream.  target = Cw * (number of this barrier).
@@ -1154,6 +1171,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     if (!needs_init && f >= f_stop) return;
     float best_emit = __int_as_float(RFL(__float_as_int(c.best_emit)));
     const int old_nw = RFL(c.lst_nw);
+    const int path_new = needs_init ? 0 : RFL(c.path_new);
     Geo gin = make_geo(C, old_nw > 0 ? old_nw : NW);
     const Geo gout = make_geo(C, NW);
     // geometry of the two dirty lists (each lives two frames, so it may come from the launch before the previous one)
@@ -1253,6 +1271,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             CS(&c.bestA[0], 0u); CS(&c.bestA[1], 0u); CS(&c.bestX[0], 0u); CS(&c.bestX[1], 0u);
             CS(&c.new_all[0], 0); CS(&c.new_all[1], 0);
             CS(&c.n_paths, 0); CS(&c.final_key, 0ULL); CS(&c.err[0], 0); CS(&c.err[1], 0);
+            c.path_new = 0; c.n_collect = 0;
             for (int k = 0; k < ST_N; ++k) CS(&c.st[k], 0LL);
             c.best_final = null_tok();
             // the start token (:221-226) is the only item of round 0, in wave 0's segment (parity 1)
@@ -1286,7 +1305,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         const int p = init ? 1 : (f & 1);
         // stop early when the Path arena needs collecting (k_gc_* run between launches); n_paths only
         // changes in phase X, so every workgroup of the cluster reads the same value here
-        if (!init && frames_done > 0 && (np_seen > C.gc_threshold || stop_seen)) break;
+        if (!init && frames_done > 0 && (np_seen > C.gc_threshold || stop_seen || (C.path_rule && path_rule_fires(np_seen, path_new)))) break;
         long long t0 = 0;
         const bool clk_on = A.dbg != nullptr && tid == 0;
 #define CLK(slot) do { if (clk_on) { const long long tn_ = wall_clock64(); sh.clk[slot] += tn_ - t0; t0 = tn_; } } while (0)
@@ -1495,7 +1514,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
 // the clusters by the streams' recent load.  All workgroups of the grid must be resident at once:
 // the host sizes the grid to the device (one 512-thread workgroup per CU).
 template <int NE, bool XL, bool LZY>
-__global__ __launch_bounds__(SNT, WG_PER_CU) void k_search(SearchArgs A)
+__global__ JD_KBOUNDS void k_search(SearchArgs A)
 {
     __shared__ SearchShared sh;
     int k, kstep, jw, Cw;

@@ -12,9 +12,10 @@
  * Compile with:  gcc -O2 -ffp-contract=off  (no -march=native, no -ffast-math)
  * so that every float operation rounds exactly once, in the reference's order.
  *
- * Deliberate omissions that do not change results: Path garbage collection
- * (collectPaths, WFSTDecoderLite.cpp:699-747 only frees unreachable records; its
- * frame-rule schedule is kept for the PARTIAL_DECODING trace, see jo_process_frame), LogFile.
+ * Deliberate omissions that do not change results: freeing Path records (collectPaths,
+ * WFSTDecoderLite.cpp:699-747, only frees unreachable ones; WHEN it runs - both triggers of :362,
+ * with the allocator's live count it reads - is kept for the PARTIAL_DECODING trace, see
+ * jo_process_frame), LogFile.
  */
 #include "juicer_oracle.h"
 
@@ -433,6 +434,11 @@ struct jo_dec {
     int32_t *hook;                        /* WFSTTransition::hook, per arc        */
     Inst *insts; Tok *toks; int32_t n_insts, cap_insts, maxN;
     PathRec *paths; int64_t n_paths, cap_paths;
+    /* live Path objects as the reference's allocator counts them (nPath: ++ in createNewNoRefPath :618, -- in
+     * destroyPath :626, i.e. in collectPaths only) and their number right after the last collection (nPathNew :745) */
+    int64_t nPath, nPathNew, paths_at_collect;
+    unsigned char *pmark; int64_t cap_pmark;
+    int32_t n_collections;
     int32_t active, newActive, newActiveLast;
     Tok *tokenBuf; Tok bestFinal;
     float normaliseScore, bestEmitScore;
@@ -458,7 +464,7 @@ void jo_dec_destroy(jo_dec *d)
 {
     if (!d) return;
     if (d->hist) { free(d->hist->cnt); free(d->hist); }
-    free(d->hook); free(d->insts); free(d->toks); free(d->paths); free(d->tokenBuf);
+    free(d->hook); free(d->insts); free(d->toks); free(d->paths); free(d->tokenBuf); free(d->pmark);
     free(d->cacheT); free(d->cache);
     free(d->r_label); free(d->r_time); free(d->r_score); free(d->r_ac); free(d->r_lm);
     free(d->partialPaths); free(d->jointCount); free(d->p_label); free(d->p_time);
@@ -577,6 +583,7 @@ static int32_t new_path(jo_dec *d)
         d->paths = (PathRec *)realloc(d->paths, sizeof(PathRec) * (size_t)d->cap_paths);
     }
     ++d->st.tot_paths;
+    ++d->nPath;                                                     /* createNewNoRefPath :618 */
     return (int32_t)d->n_paths++;
 }
 
@@ -667,6 +674,7 @@ int jo_init(jo_dec *d)
     for (int32_t i = 0; i < d->n_insts; ++i) d->hook[d->insts[i].arc] = -1;
     d->n_insts = 0; d->active = d->newActive = d->newActiveLast = -1;
     d->n_paths = 0;
+    d->nPath = d->nPathNew = d->paths_at_collect = 0; d->n_collections = 0;   /* resetPathLists :695 */
     if (d->hist) hist_reset(d->hist);                               /* :186-187 */
     d->normaliseScore = 0.0f; d->bestEmitScore = LZ;                /* :189-191 */
     d->startTh = d->endTh = d->wordTh = d->emitTh = LZ;             /* :197-200 */
@@ -845,6 +853,13 @@ int jo_trace_partial(jo_dec *d)
 }
 
 /* setPartialDecodeOptions, :892-896 */
+int jo_path_counts(const jo_dec *d, int64_t out[4])
+{
+    if (!d || !out) return fail(-1, "jo_path_counts: null");
+    out[0] = d->n_collections; out[1] = d->lastPathCollectFrame; out[2] = d->nPath; out[3] = d->nPathNew;
+    return 0;
+}
+
 int jo_set_partial_interval(jo_dec *d, int32_t interval)
 {
     if (!d || interval < 0) return fail(-1, "setPartialDecodeOptions: traceInterval >= 0");
@@ -888,16 +903,34 @@ int jo_process_frame(jo_dec *d, const float *const *rows, int32_t frame, int32_t
     d->endTh = (d->endWin > 0.0 ? (d->bestEmitScore - d->endWin) : LZ);        /* :349 */
     d->wordTh = (d->wordWin > 0.0 ? (d->bestEmitScore - d->wordWin) : LZ);     /* :350 */
     do_external(d);                                                 /* :353 */
-    /* path collection :355-370.  collectPaths itself is omitted (it only frees unreachable
-     * records); what is kept is WHEN it runs, because the partial trace rides on it.  Of the two
-     * triggers only the frame rule is modelled: the other one (nPath / nPathNew > 12 and
-     * nPath > 10000) depends on the allocator's count of live Path objects, which this
-     * restatement does not keep.  It changes the frames at which a trace is taken, never what a
-     * trace at a given frame finds. */
-    if (d->currFrame - d->lastPathCollectFrame > 100) {
-        d->lastPathCollectFrame = d->currFrame;                     /* :746 */
-        if (d->partialTraceInterval > 0 && (d->currFrame - d->lastPartialTraceFrame > d->partialTraceInterval))
-            jo_trace_partial(d);                                    /* :365-368 */
+    /* path collection :355-370.  collectPaths (:699-747) frees the Path objects no token of an active instance
+     * reaches, directly or through prev links; records are never freed here (that changes no result), but what the
+     * reference's allocator would hold is COUNTED, because both of its triggers are modelled and the second one
+     * reads that count:  (nPath / nPathNew > 12 and nPath > 10000)  or  (currFrame - lastPathCollectFrame > 100).
+     * nPathNew is 0 until the first collection: nPath / 0 is +inf for nPath > 0 (IEEE float division, :360), so
+     * before it the first trigger is nPath > 10000 alone; 0 / 0 is NaN and compares false. */
+    {
+        const float pathRatio = (float)d->nPath / (float)d->nPathNew;
+        if ((pathRatio > 12. && d->nPath > 10000) || (d->currFrame - d->lastPathCollectFrame > 100)) {
+            /* survivors of collectPaths: the Paths reachable from the tokens of the active instances */
+            if (d->n_paths > d->cap_pmark) {
+                d->cap_pmark = d->n_paths * 2 + 64;
+                d->pmark = (unsigned char *)realloc(d->pmark, (size_t)d->cap_pmark);
+            }
+            memset(d->pmark, 0, (size_t)d->n_paths);
+            int64_t live = 0;
+            for (int32_t inst = d->active; inst >= 0; inst = d->insts[inst].next)
+                for (int32_t i = 0; i < d->insts[inst].n; ++i)
+                    for (int32_t q = d->toks[(size_t)inst * d->maxN + i].path; q >= 0 && !d->pmark[q]; q = d->paths[q].prev) {
+                        d->pmark[q] = 1;
+                        ++live;
+                    }
+            d->nPath = d->nPathNew = live;                          /* :745 */
+            ++d->n_collections;
+            d->lastPathCollectFrame = d->currFrame;                 /* :746 */
+            if (d->partialTraceInterval > 0 && (d->currFrame - d->lastPartialTraceFrame > d->partialTraceInterval))
+                jo_trace_partial(d);                                /* :365-368 */
+        }
     }
     if (d->trace && frame < d->trace_cap) d->trace[frame] = d->bestEmitScore;
     if (d->err == -5) return fail(-5, "Histogram::addScore - score > maxScore");

@@ -96,6 +96,10 @@ int jo_decode_utt_threading(jo_dec *d, const float *feats, int32_t T, jo_hyp *ou
 int jo_set_partial_interval(jo_dec *d, int32_t interval);
 int jo_trace_partial(jo_dec *d);
 int jo_partial_get(jo_dec *d, int32_t *n, const int32_t **labels, const int32_t **times);
+/* The reference's Path bookkeeping behind its collection schedule (WFSTDecoderLite.cpp:358-370): out[0] = collectPaths
+ * calls so far in this utterance, out[1] = lastPathCollectFrame, out[2] = nPath (live Path objects as the reference's
+ * allocator counts them), out[3] = nPathNew (their number right after the last collection). */
+int jo_path_counts(const jo_dec *d, int64_t out[4]);
 
 /* equal-score recombinations of the last utterance by kind: [0] bestFinalToken, [1] entry token,
  * [2] HMM-internal (lowest predecessor wins: not order dependent), [3] entry-token ties whose

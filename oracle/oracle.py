@@ -260,12 +260,17 @@ class OracleDecoder:
         snaps = {}
         _check(L.jo_init(self.h))
         n_frames, n_data = 0, min(20, T)                                # DecoderSingleTest.cpp:267-277
-        last_collect, last_trace, before = -1, -1, 0
+        last_trace, before = -1, 0
+        counts = (C.c_int64 * 4)()
+        n_coll = 0
+        self.collect_frames = []                                        # frames after which collectPaths ran (:362)
         while n_data > 0:                                               # :280-295
             _check(L.jo_process_frame(self.h, C.c_void_p(rows_addr + n_frames * psz), C.c_int32(n_frames), C.c_int32(n_data)))
             f = n_frames
-            if f - last_collect > 100:                                  # the schedule jo_process_frame follows
-                last_collect = f
+            _check(L.jo_path_counts(self.h, counts))
+            if counts[0] > n_coll:                                      # jo_process_frame collected after this frame
+                n_coll = int(counts[0])
+                self.collect_frames.append(f)
                 if interval > 0 and f - last_trace > interval:
                     lst = self._partial_list()
                     snaps[f] = (len(lst) > before, lst)

@@ -705,12 +705,14 @@ def test_partial_decoding_traces(cfg_name, request):
     assert n_found >= 4 and n_found < n_traces, "vacuous: %d of %d traces found a record" % (n_found, n_traces)
 
 
-def test_partial_decoding_schedule(small):
-    """setPartialDecodeOptions(interval): traces ride on the path collection's frame rule (:362-368)
-    whatever the push sizes are, and finish() completes the list from the best token (:245-251)."""
+def test_partial_decoding_schedule(small_tree):
+    """setPartialDecodeOptions(interval): traces ride on the path collections (:362-368) whatever the push sizes
+    are, and finish() completes the list from the best token (:245-251).  On this graph (lexicon-tree hub: few Path
+    objects per frame) only collectPaths' frame rule fires in the reference - asserted on the oracle, which models
+    both triggers - and the schedule here is the reference's exactly."""
     from juicer_amd import capi
     from oracle.oracle import OracleDecoder
-    gnet, gam, onet, oam, feats, _ = small
+    gnet, gam, onet, oam, feats, _ = small_tree
     kw = dict(main_beam=150.0)
     od = OracleDecoder(onet, oam, **kw)
     gd = capi.Decoder(gnet, gam, max_streams=1, **kw)
@@ -719,6 +721,7 @@ def test_partial_decoding_schedule(small):
     for interval, step in ((1, 37), (150, 64), (150, 1000)):
         snaps, final = od.decode_partial(x, interval=interval)
         assert len(snaps) >= 2
+        assert od.collect_frames == list(range(100, x.shape[0], 101))  # the frame rule alone: 100, 201, 302, ...
         gd.set_partial_interval(interval)
         gd.stream_init(0)
         seen = {}
@@ -729,10 +732,51 @@ def test_partial_decoding_schedule(small):
             due = [f for f in sorted(snaps) if f <= last]
             _, lst = gd.stream_partial(0)
             assert lst == (snaps[due[-1]][1] if due else []), "interval %d, after frame %d" % (interval, last)
+            done = [f for f in od.collect_frames if f <= last]
+            assert gd.stream_collect_info(0) == (len(done), done[-1] if done else -1)
             seen[last] = lst
         g = gd.stream_finish(0)
         _, lst = gd.stream_partial(0)
         assert lst == final == list(zip(g.label.tolist()[::-1], g.time.tolist()[::-1]))
+    gd.set_partial_interval(0)
+
+
+def test_partial_decoding_count_rule(built):
+    """collectPaths' other trigger (:360-362): nPath / nPathNew > 12 with nPath > 10000.  A back-off state that fans out
+    into one eps:word arc per word of a 400-word vocabulary makes hundreds of Path records per frame: collections
+    (and the traces that ride on them) come every few dozen frames, long before the frame rule's 101.  The counts
+    are this build's own records (at most the reference's, which also keeps a Path for every token that loses its
+    state's recombination), so the reference fires at least as often - checked against the oracle, which models
+    both triggers on the reference's counts; every traced list is a prefix of the final result, which is the
+    oracle's."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small(seed=31, n_utts=2, n_words=400, n_succ=5, n_gmm=120, n_hmm=45, hub="flat")
+    x = np.concatenate(feats)[:330]
+    kw = dict(main_beam=250.0)
+    od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+    snaps, final = od.decode_partial(x, interval=1)
+    assert od.collect_frames[0] < 100
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=1, **kw)
+    gd.set_partial_interval(1)
+    gd.stream_init(0)
+    prev, colls = [], []
+    for pos in range(0, x.shape[0], 16):
+        gd.stream_push(0, x[pos:pos + 16])
+        n, last = gd.stream_collect_info(0)
+        colls.append((n, last))
+        _, lst = gd.stream_partial(0)
+        assert lst[:len(prev)] == prev and all(t <= min(x.shape[0], pos + 16) - 1 for _, t in lst)
+        prev = lst
+    n_first100 = max(n for (n, last), pos in zip(colls, range(0, x.shape[0], 16)) if pos + 16 <= 100)
+    assert n_first100 >= 1, "the count rule did not fire in the first 100 frames"       # (the frame rule cannot: 100 is its first frame)
+    assert colls[-1][0] <= len(od.collect_frames)                      # never more often than the reference
+    lasts = [last for _, last in colls if last >= 0]
+    assert all(b - a <= 101 for a, b in zip([-1] + lasts, lasts) if b != a)
+    g = gd.stream_finish(0)
+    _, lst = gd.stream_partial(0)
+    assert lst == final == list(zip(g.label.tolist()[::-1], g.time.tolist()[::-1])) and lst[:len(prev)] == prev
+    assert_hyp_matches(g, od.decode_certified(x), "count rule")
     gd.set_partial_interval(0)
 
 

@@ -103,9 +103,11 @@ def test_oracle_rejects_bad_input(built):
 
 def test_oracle_partial_decoding(built):
     """PARTIAL_DECODING restatement (WFSTDecoderLite.cpp:822-896): every traced list is a prefix of the
-    final result (a converged record can no longer change), the scheduled traces sit on the path
-    collection frames (100, 201, 302, ...: the first frame f with f - lastPathCollectFrame > 100) and
-    respect the interval, and recognitionFinish completes the list to the whole best path."""
+    final result (a converged record can no longer change), the scheduled traces sit on path
+    collection frames - BOTH of collectPaths' triggers are modelled (:362): the frame rule (the first frame f with
+    f - lastPathCollectFrame > 100) and the count rule (nPath / nPathNew > 12 with nPath > 10000, on the live Path
+    objects the reference's allocator would hold) - and respect the interval, and recognitionFinish completes the
+    list to the whole best path."""
     from juicer_amd import synth
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
     am, net, feats, _ = synth.config_small()
@@ -128,10 +130,24 @@ def test_oracle_partial_decoding(built):
     for interval in (1, 150, 250):
         snaps, final = od.decode_partial(x, interval=interval)
         assert final == best
-        frames = sorted(snaps)
-        assert all((f + 1) % 101 == 0 for f in frames)                  # 100, 201, 302, ...
-        assert all(b - a > interval for a, b in zip(frames, frames[1:]))
-        assert frames and frames[0] == 100 * (1 + interval // 101) + interval // 101
+        coll = od.collect_frames
+        # this graph (every back-off fans out into one eps:word arc per word) creates ~170 Path objects per frame: the
+        # count rule fires every few frames, long before the frame rule's 101
+        assert coll[0] < 100 and len(coll) > 3 * (x.shape[0] // 101)
+        assert all(b - a <= 101 for a, b in zip([-1] + coll, coll))
+        want, last = [], -1                                             # a trace rides on a collection when the interval has passed
+        for f in coll:
+            if f - last > interval:
+                want.append(f)
+                last = f
+        assert sorted(snaps) == want
+    # the lexicon-tree shape of a determinised C.L.G creates few Path objects: there only the frame rule fires
+    am2, net2, feats2, _ = synth.config_small(hub="tree")
+    od2 = OracleDecoder(OracleNet(net2), OracleAM(am2), main_beam=150.0)
+    x2 = np.concatenate(feats2)
+    snaps2, _ = od2.decode_partial(x2, interval=150)
+    assert od2.collect_frames == list(range(100, x2.shape[0], 101))     # 100, 201, 302, ...
+    assert sorted(snaps2) == [f for f in od2.collect_frames if (f + 1) % 202 == 0]
     # the decoder is reusable afterwards and unaffected
     o2 = od.decode(x)
     assert o2.n == o.n and np.array_equal(o2.label, o.label)
