@@ -58,7 +58,7 @@ static jd_am *load_jdam(const char *path)
 static bool file_exists(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != 0; }
 
 // One utterance: .jdf, or an HTK parameter file (big-endian: int32 nSamples, int32 sampPeriod,
-// int16 sampSize, int16 parmKind; _C compressed files are not supported, a _K checksum is ignored).
+// int16 sampSize, int16 parmKind; plain float samples or _C compressed 16-bit ones, a _K checksum is ignored).
 static bool load_features(const char *path, int D, std::vector<float> &x, int32_t &T)
 {
     FILE *f = fopen(path, "rb");
@@ -83,13 +83,30 @@ static bool load_features(const char *path, int D, std::vector<float> &x, int32_
             const uint32_t v = (uint32_t)raw[4 * i] << 24 | (uint32_t)raw[4 * i + 1] << 16 | (uint32_t)raw[4 * i + 2] << 8 | raw[4 * i + 3];
             memcpy(&x[i], &v, 4);
         }
+    } else if (nS >= 4 && (parmKind & 0x400) && sampSize == D * 2 && size >= 12 + 8L * D + (long)(nS - 4) * sampSize) {
+        // HTK _C: 16-bit samples, value = (sample + B[k]) / A[k]; the A and B vectors (big-endian floats) sit in front of
+        // the data and count as 4 of the header's nSamples (HTK Book, "Storage of parameter files: compression")
+        T = nS - 4;
+        x.resize((size_t)T * D);
+        fseek(f, 12, SEEK_SET);
+        std::vector<unsigned char> ab((size_t)D * 8), raw((size_t)T * D * 2);
+        if (fread(ab.data(), 1, ab.size(), f) != ab.size() || (!raw.empty() && fread(raw.data(), 1, raw.size(), f) != raw.size())) { fclose(f); return false; }
+        std::vector<float> A((size_t)D), B((size_t)D);
+        for (int k = 0; k < 2 * D; ++k) {
+            const uint32_t v = (uint32_t)ab[4 * k] << 24 | (uint32_t)ab[4 * k + 1] << 16 | (uint32_t)ab[4 * k + 2] << 8 | ab[4 * k + 3];
+            memcpy(k < D ? &A[(size_t)k] : &B[(size_t)(k - D)], &v, 4);
+        }
+        for (size_t i = 0; i < x.size(); ++i) {
+            const int16_t sv = (int16_t)((uint16_t)raw[2 * i] << 8 | raw[2 * i + 1]);
+            x[i] = ((float)sv + B[i % (size_t)D]) / A[i % (size_t)D];
+        }
     } else if (le[0] >= 0 && le[1] == D && size == 8 + (long)le[0] * D * 4) {                             // .jdf
         T = le[0];
         x.resize((size_t)T * D);
         fseek(f, 8, SEEK_SET);
         if (!x.empty() && fread(x.data(), 4, x.size(), f) != x.size()) { fclose(f); return false; }
     } else {
-        fprintf(stderr, "jd_batch_test: %s is neither an uncompressed HTK parameter file nor a .jdf file of vecSize %d\n", path, D);
+        fprintf(stderr, "jd_batch_test: %s is neither an HTK parameter file (plain or _C) nor a .jdf file of vecSize %d\n", path, D);
         fclose(f);
         return false;
     }

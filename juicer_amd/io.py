@@ -215,3 +215,22 @@ def write_htk(path, feats, samp_period: int = 100000, parm_kind: int = 6 | 0x100
         f.write(np.asarray([x.shape[0], samp_period], ">i4").tobytes())
         f.write(np.asarray([x.shape[1] * 4, parm_kind], ">i2").tobytes())
         f.write(x.astype(">f4").tobytes())
+
+
+def write_htk_compressed(path, feats, samp_period: int = 100000, parm_kind: int = 6 | 0x100 | 0x200 | 0x2000):
+    """HTK _C parameter file (HTK Book, "Storage of parameter files"): per component A = 2 * 32767 / (max - min),
+    B = (max + min) * 32767 / (max - min); samples stored as big-endian int16 x * A - B; the A and B vectors
+    (big-endian float32) come first and count as 4 samples in the header.  Returns what a reader gets back:
+    (sample + B) / A in float32."""
+    x = np.ascontiguousarray(feats, dtype=np.float32)
+    lo, hi = x.min(axis=0).astype(np.float64), x.max(axis=0).astype(np.float64)
+    span = np.where(hi > lo, hi - lo, 1.0)
+    A = (2.0 * 32767.0 / span).astype(np.float32)
+    B = ((hi + lo) * 32767.0 / span).astype(np.float32)
+    q = np.clip(np.rint(x.astype(np.float64) * A - B), -32767, 32767).astype(np.int16)
+    with open(path, "wb") as f:
+        f.write(np.asarray([x.shape[0] + 4, samp_period], ">i4").tobytes())
+        f.write(np.asarray([x.shape[1] * 2, parm_kind | 0x400], ">i2").tobytes())
+        f.write(A.astype(">f4").tobytes()); f.write(B.astype(">f4").tobytes())
+        f.write(q.astype(">i2").tobytes())
+    return (q.astype(np.float32) + B) / A

@@ -447,6 +447,22 @@ def test_binary_caches_and_htk_feature_files(small, tmp_path):
         o = od.decode_certified(x)
         body = base[u].split("[")[0].replace("Actual :", "").split()
         assert [int(w) for w in body] == (o.label[::-1] - 1).tolist()
+    # HTK _C parameter files (16-bit samples with per-component scale and offset, what HTK corpora usually hold): the
+    # harness decodes what the file says - the words the library gives on the de-quantised vectors
+    d_c = tmp_path / "c"
+    d_c.mkdir()
+    deq = []
+    with open(d_c / "list.txt", "w") as f:
+        for u, x in enumerate(feats):
+            deq.append(jio.write_htk_compressed(d_c / ("u%d.htk" % u), x))
+            f.write("%s\n" % (d_c / ("u%d.htk" % u)))
+    comp, _ = run(d_txt, d_c / "list.txt")
+    want = capi.Decoder(gnet, gam, main_beam=150.0, max_streams=len(feats)).decode_batch(deq)
+    assert len(comp) == len(feats)
+    for u, h in enumerate(want):
+        body = comp[u].split("[")[0].replace("Actual :", "").split()
+        assert h.n > 0 and [int(w) for w in body] == (h.label[::-1] - 1).tolist()
+        assert_hyp_matches(h, od.decode_certified(deq[u]), "compressed utt %d" % u)
     # library level: binary-loaded handles decode bit-identically to the originals
     capi.Network.from_synth(net).save_jwnt(str(tmp_path / "n.bin"))
     capi.Models.from_htk(am).save_jmbi(str(tmp_path / "a.bin"))
