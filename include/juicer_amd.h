@@ -112,12 +112,25 @@ void    jd_net_destroy(jd_net *n);
  * tight when words are numbered in the lexicon tree's depth-first order).  Exact definition and the
  * state / arc numbering: csrc/jd_compose.hip.  max_states / max_arcs bound the result (0: a default
  * derived from the inputs); JD_ENOMEM names the one that was too small.  There is no CPU path.
- * pushing != 0: the weight part of the reference's -pushing (doLabelAndWeightPushing, juicer.cpp:240,
- * 931-935) - the best grammar weight reachable below a lexicon-tree node is paid on the way into it, so the
- * beam prunes on it; path totals are the same up to float association.
+ * pushing: the reference's -pushing (doLabelAndWeightPushing, juicer.cpp:240, 931-935) is JD_PUSH_WEIGHTS |
+ * JD_PUSH_LABELS.  JD_PUSH_WEIGHTS: the best grammar weight reachable below a lexicon-tree node is paid on the way
+ * into it, so the beam prunes on it; path totals are the same up to float association.  JD_PUSH_LABELS: C.L is
+ * composed with its output labels pushed towards the initial state (jd_net_push_labels).
  */
+#define JD_PUSH_WEIGHTS 1
+#define JD_PUSH_LABELS 2
 int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t device,
                    int64_t max_states, int64_t max_arcs, int32_t pushing);
+
+/*
+ * Label pushing on a C.L transducer (the reference: WFSTLabelPushingNetwork gives every transition the set of output
+ * labels that can follow it, WFSTNetwork.cpp:1643-1764, and the on-the-fly decoder takes the G transition as soon as
+ * the set is one label): every output label moves towards the initial state, up to the first arc behind which it is
+ * the only label that can follow.  The result has the same states, arcs and weights and accepts the same label
+ * sequences at the same costs; a hypothesis' word-end times become the frames in which its words were identified.
+ * Host code (no device needed); exact rule: csrc/jd_compose.hip, cl_push_labels.  n_moved (may be NULL): labels moved.
+ */
+int jd_net_push_labels(jd_net **out, const jd_net *cl, int64_t *n_moved);
 
 /*
  * Dynamic composition proper (WFSTOnTheFlyDecoder: C.L o G expanded where the search goes, never as a
@@ -126,16 +139,24 @@ int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t devi
  * that leads to it (csrc/jd_lazy.h).  What has been expanded stays, shared by every decoder and stream on
  * the network, so later utterances find most of what they need.  `am` says which input labels are tee
  * models; max_states / max_arcs are the room the network may grow into (0: 2^22 states, 2^24 arcs;
- * decoding fails with JD_ENOMEM when it runs out).  The decoder must be created on the same device; the
+ * see jd_net_lazy_set_high_water for what happens when it fills up).  The decoder must be created on the same device; the
  * network has no arc table to read back (jd_net_get_csr / jd_net_save_jwnt refuse it).  Results are those
  * of decoding on jd_net_compose's network (pushing: as there, applied arc by arc as states are expanded).
  * There is no CPU path.
  */
 int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *g, const jd_am *am, int32_t device,
                        int64_t max_states, int64_t max_arcs, int32_t pushing);
-/* Forget everything expanded so far and start again from the start state (where the reference bounds its
- * memory with an LRU cache, WFSTOnTheFlyDecoder.h:210-371): for a network about to run out of room, or one that
- * has (which also clears the failure).  No stream of a decoder on the network may be inside an utterance. */
+/* Bounded look-ahead memory (the reference: an LRU cache of composed transitions, WFSTOnTheFlyDecoder.h:210-371).
+ * Eviction here is by arena GENERATION: when an utterance (or batch) begins while no stream of any decoder on the
+ * network is inside one, and the arena is past its high-water mark - `fraction` of either capacity, default 0.9 -
+ * or has run out of room, everything expanded so far is dropped and the arena starts again from the start state.
+ * A batch that runs out of room under way is decoded again on a fresh generation, so JD_ENOMEM means ONE batch
+ * needs more than the capacities; it is never a sticky state of the network.  jd_net_lazy_generation counts the
+ * generations begun so far (0: nothing has been dropped yet). */
+int jd_net_lazy_set_high_water(jd_net *n, double fraction);
+int jd_net_lazy_generation(const jd_net *n, int64_t *generation);
+/* The same by hand: forget everything expanded so far.  JD_ESTATE while a stream of a decoder on the network is
+ * inside an utterance. */
 int jd_net_lazy_reset(jd_net *n);
 /* composed states and arcs materialised so far */
 int jd_net_lazy_size(const jd_net *n, int64_t *states, int64_t *arcs);
@@ -262,11 +283,16 @@ int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am,
 void jd_dec_destroy(jd_dec *d);
 
 /* Per-stream arena capacities, in records (call before the first init; 0 keeps the default).
- * Defaults are taken from the free HBM when the arenas are first allocated: half of it is split
- * over max_streams, each stream's share going 50/20/30 to instance records (128 B, two lists),
+ * Defaults are taken from the free HBM when the arenas are first allocated: 70 % of it is split
+ * over max_streams, each stream's share going 50/20/30 to instance records (80 B, two lists),
  * frontier items and Path records, never below 2^19 / 2^21 / 2^21 and never above what the
  * graph can need (one instance per arc).  An overflow is reported as JD_ENOMEM naming the arena. */
 int jd_dec_set_capacity(jd_dec *d, int64_t max_slots, int64_t max_paths, int64_t max_items);
+/* The stream arenas of a decoder are one slab of device memory; jd_dec_destroy keeps the largest one per device
+ * for the next decoder created there (a decoder's set-up time is the driver clearing the memory it hands out:
+ * seconds for the default sizes).  This gives the cached slab of `device` back to the driver (also: environment
+ * JD_ARENA_CACHE=0 never keeps one). */
+int jd_release_cached_memory(int32_t device);
 /* WFSTDecoderLite::setMaxAllocModels (WFSTDecoderLite.cpp:807-820; environment variable
  * MaxAllocModels, default 10, :73-74), same argument convention: < 100 a percentage of the network's
  * transitions, 100..7999 a memory limit in MB (of 40 + 24 * maxNStates bytes per instance), otherwise

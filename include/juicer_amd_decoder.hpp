@@ -304,13 +304,15 @@ private:
 // modelLevelOutput, latticeGeneration, doLabelAndWeightPushing, true)` (juicer.cpp:594-598): C.L and G stay
 // apart and are composed where the search goes (jd_net_create_lazy).  The composed network is owned here and
 // keeps what has been expanded from one utterance to the next.  modelLevelOutput / latticeGeneration are not
-// offered (as in GpuWFSTDecoder); maxStates / maxArcs: the room the network may grow into (0 = defaults).
+// offered (as in GpuWFSTDecoder); doPushing: JD_PUSH_WEIGHTS | JD_PUSH_LABELS is the reference's doLabelAndWeightPushing
+// = true; maxStates / maxArcs: the room the network may grow into (0 = defaults; when it fills up the arena starts
+// again between utterances, jd_net_lazy_set_high_water).
 struct LazyNetHolder_ {
     jd_net *lazyNet_;
-    LazyNetHolder_(const jd_net *cl, const jd_net *g, const jd_am *models, int device, long long maxStates, long long maxArcs, bool pushing)
+    LazyNetHolder_(const jd_net *cl, const jd_net *g, const jd_am *models, int device, long long maxStates, long long maxArcs, int pushing)
         : lazyNet_(0)
     {
-        if (jd_net_create_lazy(&lazyNet_, cl, g, models, device, maxStates, maxArcs, pushing ? 1 : 0) != JD_OK) {
+        if (jd_net_create_lazy(&lazyNet_, cl, g, models, device, maxStates, maxArcs, pushing) != JD_OK) {
             fprintf(stderr, "juicer_amd: %s\n", jd_last_error());
             exit(1);
         }
@@ -320,7 +322,7 @@ struct LazyNetHolder_ {
 class GpuWFSTOnTheFlyDecoder : private LazyNetHolder_, public GpuWFSTDecoder {
 public:
     GpuWFSTOnTheFlyDecoder(const jd_net *clNetwork, const jd_net *gNetwork, const jd_am *models, float emitPruneWin,
-                           float phoneEndPruneWin, int maxEmitHyps, bool doPushing = false, int device = 0,
+                           float phoneEndPruneWin, int maxEmitHyps, int doPushing = 0, int device = 0,
                            long long maxStates = 0, long long maxArcs = 0, int blockSize = 5, int flushFrames = 64)
         : LazyNetHolder_(clNetwork, gNetwork, models, device, maxStates, maxArcs, doPushing),
           GpuWFSTDecoder(lazyNet_, models, 0.0f, emitPruneWin, phoneEndPruneWin, 0.0f, maxEmitHyps, device, blockSize, flushFrames) {}

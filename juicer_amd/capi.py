@@ -76,6 +76,7 @@ EXPORTS = [
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
     "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
+    "jd_net_lazy_set_high_water", "jd_net_lazy_generation", "jd_release_cached_memory", "jd_net_push_labels",
 ]
 
 _lib = None
@@ -181,23 +182,40 @@ class Network:
         return cls(h)
 
     @classmethod
-    def compose(cls, cl: "Network", g: "Network", device: int = 0, max_states: int = 0, max_arcs: int = 0, pushing: bool = False):
+    def compose(cls, cl: "Network", g: "Network", device: int = 0, max_states: int = 0, max_arcs: int = 0, pushing: bool = False,
+                push_labels: bool = False):
         """C.L o G on the device (jd_net_compose): the dynamic-composition row's first step."""
         h = C.c_void_p()
         _check(lib().jd_net_compose(C.byref(h), cl.h, g.h, C.c_int32(device), C.c_int64(max_states), C.c_int64(max_arcs),
-                                    C.c_int32(1 if pushing else 0)))
+                                    C.c_int32((1 if pushing else 0) | (2 if push_labels else 0))))
         return cls(h)
 
     @classmethod
-    def lazy(cls, cl: "Network", g: "Network", am: "Models", device: int = 0, max_states: int = 0, max_arcs: int = 0, pushing: bool = False):
+    def lazy(cls, cl: "Network", g: "Network", am: "Models", device: int = 0, max_states: int = 0, max_arcs: int = 0, pushing: bool = False,
+             push_labels: bool = False):
         """C.L o G expanded by the search, where it goes (jd_net_create_lazy)."""
         h = C.c_void_p()
         _check(lib().jd_net_create_lazy(C.byref(h), cl.h, g.h, am.h, C.c_int32(device), C.c_int64(max_states), C.c_int64(max_arcs),
-                                        C.c_int32(1 if pushing else 0)))
+                                        C.c_int32((1 if pushing else 0) | (2 if push_labels else 0))))
         return cls(h)
+
+    def push_labels(self):
+        """C.L with its output labels pushed towards the initial state (jd_net_push_labels): (network, labels moved)."""
+        h, n = C.c_void_p(), C.c_int64(0)
+        _check(lib().jd_net_push_labels(C.byref(h), self.h, C.byref(n)))
+        return type(self)(h), n.value
 
     def lazy_reset(self):
         _check(lib().jd_net_lazy_reset(self.h))
+
+    def lazy_set_high_water(self, fraction: float):
+        """The fill beyond which the arena starts a new generation between utterances (jd_net_lazy_set_high_water)."""
+        _check(lib().jd_net_lazy_set_high_water(self.h, C.c_double(fraction)))
+
+    def lazy_generation(self) -> int:
+        g = C.c_int64(0)
+        _check(lib().jd_net_lazy_generation(self.h, C.byref(g)))
+        return g.value
 
     def lazy_size(self):
         ns, na = C.c_int64(0), C.c_int64(0)

@@ -130,7 +130,8 @@ int main(int argc, char **argv)
         auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "-fsmFName") fsm = nxt(); else if (a == "-inSymsFName") insyms = nxt();
         else if (a == "-gramFsmFName") gramFsm = nxt(); else if (a == "-gramInSymsFName") gramInSyms = nxt();
-        else if (a == "-gramOutSymsFName") gramOutSyms = nxt(); else if (a == "-pushing") pushing = 1;   // juicer.cpp:240
+        else if (a == "-gramOutSymsFName") gramOutSyms = nxt(); else if (a == "-pushing") pushing = JD_PUSH_WEIGHTS | JD_PUSH_LABELS;   // juicer.cpp:240 doLabelAndWeightPushing
+        else if (a == "-weightPushing") pushing = JD_PUSH_WEIGHTS;
         else if (a == "-lazy") lazy = 1;                                         // compose where the search goes (jd_net_create_lazy)
         else if (a == "-outSymsFName") outsyms = nxt(); else if (a == "-modelsFName") amf = nxt();
         else if (a == "-htkModelsFName") mmf = nxt();
@@ -154,7 +155,7 @@ int main(int argc, char **argv)
                         "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles] [-refFName REF] [-removeSentMarks]\n"
                         "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n"
                         "       [-device d | -devices N   (N GPUs of this node: utterances sharded, one RCCL gather of the 1-best)]\n"
-                        "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S] [-pushing] [-lazy]   (-fsmFName is then C.L: composed with G on the\n"
+                        "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S] [-pushing | -weightPushing] [-lazy]   (-fsmFName is then C.L: composed with G on the\n"
                         "        device, as a whole before the search or - with -lazy - by the search, where it goes)]\n");
         return 2;
     }
@@ -371,7 +372,7 @@ int main(int argc, char **argv)
     if (useAdapter) {
         // the reference's serial protocol: one IDecoder, frame by frame with 20-row look-ahead
         JuicerAmd::GpuWFSTDecoder *decp = lazy_cl
-            ? new JuicerAmd::GpuWFSTOnTheFlyDecoder(lazy_cl, lazy_g, am, mainBeam, endBeam, maxHyps, pushing != 0, device)
+            ? new JuicerAmd::GpuWFSTOnTheFlyDecoder(lazy_cl, lazy_g, am, mainBeam, endBeam, maxHyps, pushing, device)
             : new JuicerAmd::GpuWFSTDecoder(net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, device);
         JuicerAmd::GpuWFSTDecoder &dec = *decp;
         if (lazy_cl) fprintf(stderr, "C.L (%lld arcs) o G (%lld arcs): composed by the search on device %d\n", (long long)jd_net_num_arcs(lazy_cl),

@@ -327,13 +327,92 @@ static void cl_lookahead(const jd_net *cl, std::vector<int2> &la)
         if (mf[(size_t)c]) la[(size_t)c].y = (int)((unsigned)la[(size_t)c].y | LA_MAYFIN);
 }
 
+// Label pushing, the other half of the reference's -pushing (doLabelAndWeightPushing, juicer.cpp:240, 931-935).  The
+// reference gives every C.L transition the SET of output labels that can follow it (WFSTLabelPushingNetwork::
+// assignOutlabsToTrans, WFSTNetwork.cpp:1643-1764, loops included) and its on-the-fly decoder takes the G transition
+// as soon as that set has shrunk to one label - the word is known, and with it the grammar state, before its last
+// model has been decoded.  Stated on the transducer: every output label moves towards the initial state, up to the
+// first arc behind which it is the only label that can follow.  With the look-ahead intervals above: a state c is
+// SINGLE when its interval is one label w(c) and no final state can be reached from it without a label; single
+// states joined by label-less arcs (they share their label) form a region.  A label-less arc INTO a single state
+// from outside such a run of "already emitted" states gets the label, the arcs that carried it lose it:
+//   E(c)   single, entered by label-less arcs only (and not the initial state): w(c) has been emitted when c is reached
+//   arc c0 -i:eps-> c, E(c), not E(c0)   becomes  -i:w(c)->        arc c0 -i:w-> c, E(c0)   becomes  -i:eps->
+// A region in which some state is entered both ways (by a label-carrying arc, or as the initial state, AND by a
+// label-less arc) could not say whether its label is out yet: it is left as it is.  Arcs, weights and states are
+// unchanged and correspond one to one, every complete path keeps its label sequence (tests/test_compose_ref_cpu.py
+// walks random paths through both); what moves is WHEN a word's label is passed - the times of a hypothesis' word
+// ends become the frames in which the words were identified.
+static void cl_push_labels(const jd_net *cl, std::vector<JdArc> &arcs, int64_t *n_moved)
+{
+    std::vector<int2> la;
+    cl_lookahead(cl, la);
+    const int S = cl->n_states;
+    auto single = [&](int c) { const int2 I = la[(size_t)c]; return I.x == la_hi(I) && !la_mayfin(I); };
+    std::vector<int> comp((size_t)S);
+    for (int c = 0; c < S; ++c) comp[(size_t)c] = c;
+    auto find = [&](int c) { while (comp[(size_t)c] != c) { comp[(size_t)c] = comp[(size_t)comp[(size_t)c]]; c = comp[(size_t)c]; } return c; };
+    std::vector<char> pend((size_t)S, 0), lessin((size_t)S, 0);
+    pend[(size_t)cl->init] = 1;
+    for (int c0 = 0; c0 < S; ++c0)
+        for (int a = cl->row_ptr[(size_t)c0]; a < cl->row_ptr[(size_t)c0 + 1]; ++a) {
+            const JdArc &arc = cl->arcs[(size_t)a];
+            if (arc.out != 0) { pend[(size_t)arc.to] = 1; continue; }
+            lessin[(size_t)arc.to] = 1;
+            if (single(c0) && single(arc.to)) { const int x = find(c0), y = find(arc.to); if (x != y) comp[(size_t)x] = y; }
+        }
+    std::vector<char> bad((size_t)S, 0);
+    for (int c = 0; c < S; ++c)
+        if (single(c) && pend[(size_t)c] && lessin[(size_t)c]) bad[(size_t)find(c)] = 1;
+    auto emitted = [&](int c) { return single(c) && !pend[(size_t)c] && !bad[(size_t)find(c)]; };
+    arcs = cl->arcs;
+    int64_t moved = 0;
+    for (int c0 = 0; c0 < S; ++c0)
+        for (int a = cl->row_ptr[(size_t)c0]; a < cl->row_ptr[(size_t)c0 + 1]; ++a) {
+            JdArc &arc = arcs[(size_t)a];
+            if (arc.out == 0) {
+                if (emitted(arc.to) && !emitted(c0)) { arc.out = la[(size_t)arc.to].x; ++moved; }
+            } else if (emitted(c0)) arc.out = 0;
+        }
+    if (n_moved) *n_moved = moved;
+}
+
+static jd_net *net_with_arcs(const jd_net *n, std::vector<JdArc> &&arcs)
+{
+    jd_net *r = new jd_net();
+    r->n_states = n->n_states; r->init = n->init; r->n_final = n->n_final; r->n_arcs = n->n_arcs;
+    r->row_ptr = n->row_ptr; r->arcs = std::move(arcs); r->fin_w = n->fin_w; r->max_in = n->max_in;
+    r->lm_scale = n->lm_scale; r->ins_penalty = n->ins_penalty;
+    return r;
+}
+
+// the C.L transducer with its output labels pushed towards the initial state (host code: no device needed)
+extern "C" int jd_net_push_labels(jd_net **out, const jd_net *cl, int64_t *n_moved)
+{
+    if (!out || !cl) return jd_fail(JD_EINVAL, "jd_net_push_labels: null argument");
+    if (cl->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_push_labels: the input must be an ordinary network");
+    std::vector<JdArc> arcs;
+    cl_push_labels(cl, arcs, n_moved);
+    *out = net_with_arcs(cl, std::move(arcs));
+    return JD_OK;
+}
+
 extern "C" int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, int32_t device, int64_t max_states, int64_t max_arcs,
                               int32_t pushing)
 {
     if (!out || !cl || !g) return jd_fail(JD_EINVAL, "jd_net_compose: null argument");
+    if (pushing < 0 || pushing > 3) return jd_fail(JD_EINVAL, "jd_net_compose: pushing is a combination of JD_PUSH_WEIGHTS and JD_PUSH_LABELS");
     std::vector<JdArc> g_sorted;
     int rc = sorted_g_arcs(g, g_sorted);
     if (rc) return rc;
+    struct Owned { jd_net *p = nullptr; ~Owned() { delete p; } } pushed;   // C.L with its labels pushed (JD_PUSH_LABELS)
+    if (pushing & 2) {
+        if (cl->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_compose: the inputs must be ordinary networks");
+        std::vector<JdArc> pa;
+        cl_push_labels(cl, pa, nullptr);
+        pushed.p = net_with_arcs(cl, std::move(pa));
+        cl = pushed.p;
+    }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
         return jd_fail(JD_ENODEV, "jd_net_compose: no HIP device %d (the composition runs on the GPU; there is no CPU path)", device);
@@ -377,7 +456,7 @@ extern "C" int jd_net_compose(jd_net **out, const jd_net *cl, const jd_net *g, i
         DAL(A.st_c, int, max_states); DAL(A.st_g, int, max_states); DAL(A.n_states, int, 1);
         DAL(A.arc_start, long long, max_states); DAL(A.arc_cnt, int, max_states); DAL(A.arcs, JdArc, max_arcs);
         DAL(A.n_arcs, unsigned long long, 1); DAL(A.fin, float, max_states); DAL(A.err, int, 1);
-        A.max_states = (int)max_states; A.max_arcs = max_arcs; A.push = pushing ? 1 : 0;
+        A.max_states = (int)max_states; A.max_arcs = max_arcs; A.push = (pushing & 1) ? 1 : 0;
         CHK(hipMemset(A.keys, 0, cap * 8)); CHK(hipMemset(A.vals, 0xff, cap * 4));
         CHK(hipMemset(A.n_arcs, 0, 8)); CHK(hipMemset(A.err, 0, 4));
         // the start pair is state 0 of the discovery order
@@ -501,9 +580,17 @@ extern "C" int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *
 {
     if (!out || !cl || !g || !am) return jd_fail(JD_EINVAL, "jd_net_create_lazy: null argument");
     if (cl->lazy_dev || g->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_create_lazy: the inputs must be ordinary networks");
+    if (pushing < 0 || pushing > 3) return jd_fail(JD_EINVAL, "jd_net_create_lazy: pushing is a combination of JD_PUSH_WEIGHTS and JD_PUSH_LABELS");
     std::vector<JdArc> g_sorted;
     int rc = sorted_g_arcs(g, g_sorted);
     if (rc) return rc;
+    struct Owned { jd_net *p = nullptr; ~Owned() { delete p; } } pushed;   // C.L with its labels pushed (JD_PUSH_LABELS)
+    if (pushing & 2) {
+        std::vector<JdArc> pa;
+        cl_push_labels(cl, pa, nullptr);
+        pushed.p = net_with_arcs(cl, std::move(pa));
+        cl = pushed.p;
+    }
     if (cl->max_in > am->n_hmm) return jd_fail(JD_EINVAL, "network input label %d exceeds the number of HMMs %d", cl->max_in, am->n_hmm);
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
@@ -543,7 +630,7 @@ extern "C" int jd_net_create_lazy(jd_net **out, const jd_net *cl, const jd_net *
         LAL(L.st_c, int, max_states); LAL(L.st_g, int, max_states); LAL(L.rows, int4, max_states);
         LAL(L.arcs, JdArc, max_arcs); LAL(L.n_states, int, 1); LAL(L.n_arcs, unsigned long long, 1); LAL(L.err, int, 1);
         LAL(d_ok, int, 2); LAL(d_tee, float, am->hmm_tee.size()); LAL(d_L, LazyDev, 1);
-        L.max_states = (int)max_states; L.max_arcs = max_arcs; L.push = pushing ? 1 : 0;
+        L.max_states = (int)max_states; L.max_arcs = max_arcs; L.push = (pushing & 1) ? 1 : 0;
         CHK(hipMemcpy(d_tee, am->hmm_tee.data(), am->hmm_tee.size() * 4, hipMemcpyHostToDevice));
         CHK(hipMemcpy(d_L, &L, sizeof L, hipMemcpyHostToDevice));
         n->lazy_tee = d_tee; n->lazy_ok = d_ok; n->lazy_cf0 = (uint32_t)cl->init | LZ_FLAG; n->lazy_g0 = g->init;
@@ -567,6 +654,8 @@ done:
 extern "C" int jd_net_lazy_reset(jd_net *n)
 {
     if (!n || !n->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_lazy_reset: not a lazily composed network");
+    std::lock_guard<std::mutex> lk(n->lazy_mu);
+    if (n->lazy_busy > 0) return jd_fail(JD_ESTATE, "jd_net_lazy_reset: %d utterance(s) are being decoded on the network", n->lazy_busy);
     if (hipSetDevice(n->lazy_device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return jd_fail(JD_EHIP, "jd_net_lazy_reset: device %d", n->lazy_device);
     LazyDev L;
     if (hipMemcpy(&L, n->lazy_dev, sizeof L, hipMemcpyDeviceToHost) != hipSuccess) return jd_fail(JD_EHIP, "jd_net_lazy_reset: copy failed");
@@ -574,6 +663,78 @@ extern "C" int jd_net_lazy_reset(jd_net *n)
     const int rc = lazy_start(n, L, h_ok);
     if (rc) return rc;
     if (h_ok[1] != n->init) return jd_fail(JD_ESTATE, "jd_net_lazy_reset: the start state moved");   // (first insertion: always 0)
+    ++n->lazy_generation;
+    return JD_OK;
+}
+
+// Bounded look-ahead memory.  The reference keeps what it composes in an LRU cache and evicts entry by entry
+// (WFSTOnTheFlyDecoder.h:210-371) - its tokens hold pointers into cache entries that are pinned while in use.  Here
+// instance records hold arc and state NUMBERS of one shared arena that thousands of lanes append to; evicting single
+// states would need every stream's records re-validated.  So eviction is by GENERATION: the arena starts again, at a
+// moment when no stream of any decoder is inside an utterance (records of a finished utterance are dead), when it is
+// past its high-water mark (jd_net_lazy_set_high_water, default 0.9 of either capacity) or has run out of room.  A
+// batch that runs out of room under way is decoded again on a fresh generation (jd_decode_batch_device), so running
+// out is only an error when ONE batch needs more than the capacities - never a sticky state of the network.
+static int lazy_fill(const jd_net *n, const LazyDev &L, int *ns, unsigned long long *na, int *err)
+{
+    int rc = JD_OK;
+    CHK(hipMemcpy(ns, L.n_states, 4, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(na, L.n_arcs, 8, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(err, L.err, 4, hipMemcpyDeviceToHost));
+done:
+    (void)n;
+    return rc;
+}
+
+int jd_lazy_enter(const jd_net *n, int n_utts, bool *failed)
+{
+    if (failed) *failed = false;
+    if (!n || !n->lazy_dev) return JD_OK;
+    std::lock_guard<std::mutex> lk(n->lazy_mu);
+    if (hipSetDevice(n->lazy_device) != hipSuccess) return jd_fail(JD_EHIP, "hipSetDevice(%d) failed", n->lazy_device);
+    LazyDev L;
+    if (hipMemcpy(&L, n->lazy_dev, sizeof L, hipMemcpyDeviceToHost) != hipSuccess) return jd_fail(JD_EHIP, "lazily composed network: copy failed");
+    int ns = 0, err = 0;
+    unsigned long long na = 0;
+    int rc = lazy_fill(n, L, &ns, &na, &err);
+    if (rc) return rc;
+    const bool past = (double)ns > n->lazy_high_water * (double)L.max_states || (double)na > n->lazy_high_water * (double)L.max_arcs;
+    if ((err != 0 || past) && n->lazy_busy == 0) {
+        if (hipDeviceSynchronize() != hipSuccess) return jd_fail(JD_EHIP, "lazily composed network: device %d", n->lazy_device);
+        int h_ok[2] = {0, 0};
+        rc = lazy_start(const_cast<jd_net *>(n), L, h_ok);
+        if (rc) return rc;
+        if (h_ok[1] != n->init) return jd_fail(JD_ESTATE, "lazily composed network: the start state moved");
+        ++n->lazy_generation;
+        err = 0;
+        if (getenv("JD_VERBOSE")) fprintf(stderr, "lazy network: generation %lld starts (%d states, %llu arcs dropped)\n", (long long)n->lazy_generation, ns, na);
+    }
+    if (failed) *failed = err != 0;
+    n->lazy_busy += n_utts;
+    return JD_OK;
+}
+
+void jd_lazy_leave(const jd_net *n, int n_utts)
+{
+    if (!n || !n->lazy_dev) return;
+    std::lock_guard<std::mutex> lk(n->lazy_mu);
+    n->lazy_busy = n->lazy_busy > n_utts ? n->lazy_busy - n_utts : 0;
+}
+
+extern "C" int jd_net_lazy_set_high_water(jd_net *n, double fraction)
+{
+    if (!n || !n->lazy_dev) return jd_fail(JD_EINVAL, "jd_net_lazy_set_high_water: not a lazily composed network");
+    if (!(fraction > 0.0 && fraction <= 1.0)) return jd_fail(JD_EINVAL, "jd_net_lazy_set_high_water: fraction in (0, 1]");
+    std::lock_guard<std::mutex> lk(n->lazy_mu);
+    n->lazy_high_water = fraction;
+    return JD_OK;
+}
+
+extern "C" int jd_net_lazy_generation(const jd_net *n, int64_t *generation)
+{
+    if (!n || !n->lazy_dev || !generation) return jd_fail(JD_EINVAL, "jd_net_lazy_generation: not a lazily composed network");
+    std::lock_guard<std::mutex> lk(n->lazy_mu);
+    *generation = n->lazy_generation;
     return JD_OK;
 }
 

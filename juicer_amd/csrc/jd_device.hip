@@ -846,6 +846,57 @@ extern "C" int jd_am_score_frames(const jd_am *a, int32_t device, const float *f
 #define JD_MAX_DEVICES 64
 static std::mutex g_search_mu[JD_MAX_DEVICES];     // one persistent search launch at a time per device (launch_search)
 
+// The stream arenas of a decoder are ONE slab, and the slab of a destroyed decoder is kept (one per device, the
+// largest) for the next decoder on that device: what a decoder's set-up costs is the driver clearing the bytes it
+// hands out (25-60 GB/s, tools/alloc_probe.py - seconds for the default 70 % of a 288 GB device, every time a
+// decoder follows another one), and nothing in the arenas needs to be clear except what ensure_arenas clears itself.
+// JD_ARENA_CACHE=0 switches it off; jd_release_cached_memory gives the slab back.
+struct ArenaSlab { void *p = nullptr; size_t bytes = 0; };
+static std::mutex g_slab_mu;
+static ArenaSlab g_slab[JD_MAX_DEVICES];
+static size_t slab_cached_bytes(int device)
+{
+    std::lock_guard<std::mutex> lk(g_slab_mu);
+    return (device >= 0 && device < JD_MAX_DEVICES) ? g_slab[device].bytes : 0;
+}
+static int slab_take(int device, size_t bytes, ArenaSlab *out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_slab_mu);
+        if (device >= 0 && device < JD_MAX_DEVICES && g_slab[device].p) {
+            ArenaSlab &c = g_slab[device];
+            if (c.bytes >= bytes) { *out = c; c = ArenaSlab(); return JD_OK; }
+            (void)hipFree(c.p);                                        // too small: its bytes go towards the new one
+            c = ArenaSlab();
+        }
+    }
+    void *q = nullptr;
+    const hipError_t e = hipMalloc(&q, std::max<size_t>(bytes, 256));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return jd_fail(e == hipErrorOutOfMemory ? JD_ENOMEM : JD_EHIP, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
+    out->p = q; out->bytes = std::max<size_t>(bytes, 256);
+    return JD_OK;
+}
+static void slab_give(int device, ArenaSlab sl)
+{
+    if (!sl.p) return;
+    const char *e = getenv("JD_ARENA_CACHE");
+    const bool keep = !(e && atoi(e) == 0) && device >= 0 && device < JD_MAX_DEVICES;
+    std::lock_guard<std::mutex> lk(g_slab_mu);
+    if (keep && g_slab[device].bytes < sl.bytes) std::swap(g_slab[device], sl);
+    if (sl.p) (void)hipFree(sl.p);
+}
+extern "C" int jd_release_cached_memory(int32_t device)
+{
+    if (device < 0 || device >= JD_MAX_DEVICES) return jd_fail(JD_EINVAL, "jd_release_cached_memory: bad device");
+    ArenaSlab sl;
+    { std::lock_guard<std::mutex> lk(g_slab_mu); std::swap(sl, g_slab[device]); }
+    if (sl.p) { if (hipSetDevice(device) != hipSuccess) return jd_fail(JD_EHIP, "hipSetDevice(%d) failed", device); (void)hipFree(sl.p); }
+    return JD_OK;
+}
+
 struct HostResult {
     std::vector<int32_t> label, time;
     std::vector<float> score, ac, lm;
@@ -866,6 +917,7 @@ struct jd_dec {
     StreamCtl *d_ctl = nullptr;
     std::vector<StreamDev> h_streams;          // host mirror (arena pointers)
     std::vector<void *> allocs;
+    ArenaSlab slab;                       // the stream arenas (ensure_arenas)
     bool arenas_ready = false;
     int64_t cap_slots = 0, cap_paths = 0, cap_items = 0, cap_new = 0;
     int64_t slots_hint = 0;               // jd_dec_set_max_alloc_models
@@ -909,6 +961,10 @@ struct jd_dec {
     // results
     std::vector<HostResult> results;
     jd_timing timing{};
+    // lazily composed networks (jd_lazy_enter / jd_lazy_leave): a stream of the last fetch ran out of graph room;
+    // streams of the streaming API that are inside an utterance
+    bool lazy_failed = false;
+    std::vector<char> lazy_in;
 };
 
 template <typename T>
@@ -939,7 +995,10 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     (void)hipDeviceSynchronize();
+    for (char in : d->lazy_in) if (in) jd_lazy_leave(d->net, 1);      // (utterances the caller never finished)
     for (void *p : d->allocs) (void)hipFree(p);
+    slab_give(d->device, d->slab);
+    d->slab = ArenaSlab();
     free_am_gmm(d->amb);
     for (int i = 0; i < 2; ++i)
         if (d->d_ll[i]) (void)hipFree(d->d_ll[i]);
@@ -1091,6 +1150,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     }
     d->stream_T.assign((size_t)max_streams, 0);
     d->stream_started.assign((size_t)max_streams, 0);
+    d->lazy_in.assign((size_t)max_streams, 0);
     d->last_collect.assign((size_t)max_streams, -1);
     d->n_collect_host.assign((size_t)max_streams, 0);
     d->last_trace.assign((size_t)max_streams, -1);
@@ -1161,6 +1221,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         // item arenas are addressed with 32-bit byte offsets (buffer descriptors): < 4 GiB each.
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        free_b += slab_cached_bytes(d->device);                        // (the cached slab is this decoder's to take)
         const double n_arcs = (double)d->net->n_arcs, n_states = (double)d->net->n_states;
         const double fixed = n_arcs * 1.0 + n_states * (double)sizeof(StateRec) + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
         const double budget = std::max(0.0, mem_fraction * (double)free_b / B - fixed);
@@ -1199,12 +1260,14 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
     d->h_streams.assign((size_t)B, StreamDev());
     rc = dmalloc(d, &d->d_res, (size_t)B * 5 * d->res_cap);
     if (rc) return rc;
+    size_t stream_bytes = 0;                                           // (the same for every stream: known after the first sizing pass)
     for (int s = 0; s < B; ++s) {
         StreamDev &S = d->h_streams[(size_t)s];
         memset(&S, 0, sizeof S);
-        // ONE allocation per stream, carved up into 256-byte aligned pieces (two passes over the same list:
-        // sizes, then pointers).  What a decoder's set-up costs is the BYTES: the driver hands out cleared
-        // memory at 25-60 GB/s (tools/alloc_probe.py), i.e. seconds for the default 70 % of a 288 GB device.
+        // ONE slab for all streams (slab_take: the previous decoder's when there is one), a stream's share carved
+        // up into 256-byte aligned pieces (two passes over the same list: sizes, then pointers).  What a decoder's
+        // set-up costs is the BYTES the driver has to clear: 25-60 GB/s (tools/alloc_probe.py), i.e. seconds for
+        // the default 70 % of a 288 GB device.
         char *blk = nullptr;
         size_t off = 0;
 #define A(p, n) do { const size_t bytes_ = (std::max<size_t>((size_t)(n), 1) * sizeof(*(p)) + 255) & ~(size_t)255; \
@@ -1219,8 +1282,12 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths); A(S.gc_state, sizeof(GcState) / 4); \
         A(S.hist, 2 * HIST_MAX_BINS); } while (0)
         ARENAS();
-        rc = dmalloc(d, &blk, off);
-        if (rc) return rc;
+        if (s == 0) {
+            stream_bytes = off;
+            rc = slab_take(d->device, stream_bytes * (size_t)B, &d->slab);
+            if (rc) return rc;
+        }
+        blk = (char *)d->slab.p + (size_t)s * stream_bytes;
         off = 0;
         ARENAS();
         {   // the five result arrays of all streams live in one arena [stream][array][res_cap]:
@@ -1290,6 +1357,8 @@ static int ensure_arenas(jd_dec *d)
         if (rc == JD_OK) return JD_OK;
         for (size_t i = mark; i < d->allocs.size(); ++i) (void)hipFree(d->allocs[i]);
         d->allocs.resize(mark);
+        slab_give(d->device, d->slab);
+        d->slab = ArenaSlab();
         if (d->h_status) { (void)hipHostFree(d->h_status); d->h_status = nullptr; }
         if (d->d_ll[0]) { (void)hipFree(d->d_ll[0]); d->d_ll[0] = nullptr; d->ll_cap[0] = 0; }
         d->d_res = nullptr; d->d_streams = nullptr; d->d_T = nullptr; d->d_ctl = nullptr; d->d_status = nullptr;
@@ -1338,11 +1407,12 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
             else if (K.error == JDE_LAZY_INV)
                 first_err = jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)", s0 + i, K.frame);
             else if (K.error == JDE_LAZY) {
+                d->lazy_failed = true;
                 LazyDev L;
                 int why = 0;
                 if (hipMemcpy(&L, d->net->lazy_dev, sizeof L, hipMemcpyDeviceToHost) == hipSuccess) (void)hipMemcpy(&why, L.err, sizeof why, hipMemcpyDeviceToHost);
                 first_err = jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of %s at frame %d (capacity %d states, %lld arcs): "
-                                    "create it with larger max_states / max_arcs, or jd_net_lazy_reset it between utterances", s0 + i,
+                                    "what was being decoded at once needs a network with larger max_states / max_arcs", s0 + i,
                                     why == 1 ? "states" : why == 2 ? "arcs" : "stack closing a state (epsilon / tee arcs more than a hundred deep, or a cycle of them)",
                                     K.frame, d->net->n_states, (long long)d->net->n_arcs);
             }
@@ -1820,17 +1890,37 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
             const int u = order[(size_t)(u0 + i)];
             ustart[(size_t)i] = offs[u]; ulen[(size_t)i] = offs[u + 1] - offs[u];
         }
-        rc = decode_wave(d, nb, d_feats, ustart.data(), ulen.data(), (hipStream_t)hip_stream);
-        if (rc) return rc;
-        rc = fetch_results(d, 0, nb, out, 0, order.data() + u0);
-        if (rc && first_err == JD_OK) first_err = rc;
+        for (int attempt = 0;; ++attempt) {
+            // (lazily composed networks: the wave's utterances enter the network - which starts a new arena generation
+            // when nobody is inside an utterance and it is nearly full, or has run out of room)
+            bool net_failed = false;
+            rc = jd_lazy_enter(d->net, nb, &net_failed);
+            if (rc) return rc;
+            if (net_failed) {
+                jd_lazy_leave(d->net, nb);
+                return jd_fail(JD_ENOMEM, "the lazily composed network has run out of room and utterances of other decoders are inside it: "
+                               "it starts again when they are through (capacity %d states, %lld arcs)", d->net->n_states, (long long)d->net->n_arcs);
+            }
+            d->lazy_failed = false;
+            rc = decode_wave(d, nb, d_feats, ustart.data(), ulen.data(), (hipStream_t)hip_stream);
+            const int rf = rc ? rc : fetch_results(d, 0, nb, out, 0, order.data() + u0);
+            jd_lazy_leave(d->net, nb);
+            if (rc) return rc;
+            // out of graph room under way: once more - jd_lazy_enter gives the wave a fresh generation to itself
+            if (d->lazy_failed && attempt == 0) continue;
+            if (rf && first_err == JD_OK) first_err = rf;
+            break;
+        }
     }
     if (d->load_frames > 0.0) {                                        // the load this batch had -> the next batch's cluster sizes
         const double scale = std::min(1e5, std::max(0.25, d->load_sum / d->load_frames / 23700.0));
         d->load_scale = (d->load_scale == 1.0) ? scale : 0.5 * (d->load_scale + scale);
         d->load_sum = d->load_frames = 0.0;
     }
-    for (int s = 0; s < d->max_streams; ++s) { d->stream_started[(size_t)s] = 0; d->stream_T[(size_t)s] = 0; }
+    for (int s = 0; s < d->max_streams; ++s) {
+        d->stream_started[(size_t)s] = 0; d->stream_T[(size_t)s] = 0;
+        if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }   // (the batch took the stream over)
+    }
     return first_err;
 }
 
@@ -1866,6 +1956,11 @@ extern "C" int jd_stream_init(jd_dec *d, int32_t s)
     if (rc) return rc;
     rc = ensure_arenas(d);
     if (rc) return rc;
+    if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }   // (an utterance that was never finished)
+    bool net_failed = false;
+    rc = jd_lazy_enter(d->net, 1, &net_failed);                       // (may start a new arena generation)
+    if (rc) return rc;
+    d->lazy_in[(size_t)s] = d->net->lazy_dev != nullptr;
     rc = mark_init(d, s, 1, d->s_search);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(d->s_search));
@@ -2041,6 +2136,7 @@ extern "C" int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out)
     std::vector<jd_hyp> tmp((size_t)d->max_streams);
     rc = fetch_results(d, s, 1, tmp.data(), s);
     *out = tmp[(size_t)s];
+    if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }   // the utterance has left the network
     if (d->partial_interval > 0 && out->n >= 0) {                      // :245-251 one more trace, from the best token
         std::vector<int32_t> &L = d->partial_label[(size_t)s], &Tm = d->partial_time[(size_t)s];
         L.resize((size_t)out->n); Tm.resize((size_t)out->n);

@@ -4,6 +4,7 @@
 #define JD_INTERNAL_H
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,7 +34,19 @@ struct jd_net {
     void (*lazy_free)(jd_net *) = nullptr;
     void *lazy_tee = nullptr, *lazy_ok = nullptr;      // device: tee log-probabilities by HMM, the init kernel's answer
     uint32_t lazy_cf0 = 0; int32_t lazy_g0 = 0;        // the start pair
+    // bounded look-ahead memory (jd_lazy_enter / jd_lazy_leave, jd_compose.hip): utterances inside the network, arena
+    // generations so far, and the fill (of states or arcs) beyond which the arena starts again between utterances
+    mutable std::mutex lazy_mu;
+    mutable int lazy_busy = 0;
+    mutable int64_t lazy_generation = 0;
+    double lazy_high_water = 0.9;
 };
+
+// Utterances enter and leave a lazily composed network (no-ops on ordinary ones).  jd_lazy_enter starts a new arena
+// GENERATION - everything expanded so far is dropped - when nobody is inside an utterance and the arena is past its
+// high-water mark or has run out of room; *failed = the network is (still) out of room, i.e. others are inside it.
+int jd_lazy_enter(const jd_net *n, int n_utts, bool *failed);
+void jd_lazy_leave(const jd_net *n, int n_utts);
 
 struct jd_am {
     int32_t D = 0, n_gmm = 0, max_mix = 0, n_hmm = 0, max_n = 0, n_tm = 0;

@@ -256,9 +256,11 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v)
 }
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 
-#define NLISTS 3
+#define NLISTS 4
 struct SearchShared {
-    int pfx[NLISTS][MAXW + 1]; int cnt[NLISTS][MAXW];   // chunk prefix / fill counts of the lists a phase reads
+    // slot 0: the item list of phase X (chunk prefix / fill counts per writer segment, build_lists); slots 1..3: the
+    // lists of phase A, PACKED (build_packed: entry prefix / writer segment of every non-empty segment)
+    int pfx[NLISTS][MAXW + 1]; int cnt[NLISTS][MAXW];
     int start[MAXW];                           // per writer wave: where its items of the current round begin
     int hist[HIST_MAX_BINS];                   // this workgroup's share of the frame's histogram
     int hprev[HIST_MAX_BINS];                  // the stream's bins of the previous frame
@@ -343,6 +345,54 @@ __device__ __forceinline__ int rebuild_list(SearchShared &sh, int k, int nw, int
     return RFL(total);
 }
 
+// Phase A reads its lists PACKED: a chunk is 64 consecutive entries of the concatenation of the writers' segments,
+// whatever segments they sit in.  (Chunks of ONE segment, as phase X takes them, leave every writer wave's last
+// chunk partly empty: with 32-64 writer waves per stream and a few hundred new arcs per frame most chunks of the
+// new list held a handful of entries, and a fifth of the record chunks were tails.)  Per list: the non-empty
+// segments in order - sh.cnt[slot][i] = the i-th one's writer wave, sh.pfx[slot][i] = entries before it,
+// sh.pfx[slot][ns] = all entries.  Loads of all lists in flight together, two barriers; all SNT threads call it.
+template <int N>
+__device__ __forceinline__ void build_packed(SearchShared &sh, const ListSrc (&src)[N], int slot0, int (&Q)[N], int (&items)[N], int (&ns)[N])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int c[N], x[N], y[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[k] = (tid < src[k].nw) ? CL(src[k].tot + tid) : 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (c[k] < 0) c[k] = 0;
+        if ((unsigned)c[k] > src[k].segcap) c[k] = (int)src[k].segcap;
+        x[k] = c[k] > 0 ? 1 : 0; y[k] = c[k];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int u = __shfl_up(x[k], o), v = __shfl_up(y[k], o);
+            if (lane >= o) { x[k] += u; y[k] += v; }
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { sh.wsum[k][wid] = x[k]; sh.wsum2[k][wid] = y[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int bx = 0, tx = 0, by = 0, ty = 0;
+#pragma unroll
+        for (int w = 0; w < SW; ++w) {
+            const int s = sh.wsum[k][w], t = sh.wsum2[k][w];
+            if (w < wid) { bx += s; by += t; }
+            tx += s; ty += t;
+        }
+        if (c[k] > 0) { const int i = bx + x[k] - 1; sh.cnt[slot0 + k][i] = tid; sh.pfx[slot0 + k][i] = by + y[k] - c[k]; }
+        if (tid == 0) sh.pfx[slot0 + k][tx] = ty;
+        Q[k] = RFL((ty + 63) >> 6); items[k] = RFL(ty); ns[k] = RFL(tx);
+    }
+    __syncthreads();
+}
+
 // largest w in [0, nw) with pfx[w] <= r (r < pfx[nw], wave-uniform): two ballot steps.  Empty
 // segments (equal prefix values) are skipped because the LAST of equal entries is returned.
 __device__ __forceinline__ int find_seg(const int *pfx, int nw, int r)
@@ -355,6 +405,30 @@ __device__ __forceinline__ int find_seg(const int *pfx, int nw, int r)
     int i2 = base + lane; if (i2 > nw) i2 = nw;
     const unsigned long long m2 = __ballot(lane < stride && pfx[i2] <= r);
     return RFL(base + __popcll(m2) - 1);
+}
+
+// Entry `lane` of chunk ru of a packed list (build_packed): its writer segment and its index there.  The segments
+// in the table are non-empty, so the 64 boundaries behind the chunk's first segment cover the chunk: the lanes mark
+// the boundaries that fall into it in a wave-private scratch row, and a lane's segment is the first one plus the
+// boundaries at or before it.
+__device__ __forceinline__ void packed_lane(const int *cp, const int *sg, int ns, int total, int ru, int *scratch,
+                                            bool &valid, int &w, int &idx)
+{
+    const int lane = threadIdx.x & 63;
+    const int base = ru << 6;
+    const int w0 = find_seg(cp, ns, base);
+    const int j = w0 + 1 + lane;
+    const int r = (j < ns ? cp[j] : 0x3fffffff) - base;               // (> 0: segments are non-empty)
+    // (lanes talk to each other through the row: wavefront-scope atomics, or the compiler - which sees one thread -
+    // concludes that a lane that marks nothing reads back its own zero and skips the load)
+    __hip_atomic_store(&scratch[lane], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (r < 64) __hip_atomic_store(&scratch[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned long long B = __ballot(__hip_atomic_load(&scratch[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != 0);
+    const int g = base + lane;
+    valid = g < total;
+    const int wi = valid ? w0 + __popcll(B & (~0ULL >> (63 - lane))) : w0;
+    w = sg[wi]; idx = g - cp[wi];
 }
 
 // Chunks of a phase are dealt to workgroups round-robin (chunk u belongs to workgroup u % Cw) and,
@@ -498,7 +572,8 @@ __device__ __forceinline__ unsigned rec_chunk_off(unsigned seg_rec, int w, int c
 
 template <int NE, bool TRPL, bool LR, bool XL, bool LZY>
 __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
-                                        const Geo &gin, const Geo &gd, const Geo &gout, const int (&Q)[3], int jw, int Cw, int gw, int p,
+                                        const Geo &gin, const Geo &gd, const Geo &gout, const int (&Q)[3], const int (&LN)[3], const int (&NS)[3],
+                                        int jw, int Cw, int gw, int p,
                                         float normalise, float emitTh, float startTh, const float *llrow,
                                         int &out_cnt, int &exit_cnt)
 {
@@ -506,6 +581,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     typedef RecLayout<NE> RL;
     constexpr int HF = RL::HF;
     const int lane = threadIdx.x & 63;
+    int *const scratch = sh.wpfx[RFL(threadIdx.x >> 6)];               // (phase X's row of this wave: free during phase A)
     const int MN = C.max_n;
     const bool use_hist = C.max_hyps > 0;
     const float *trP_all = TRPL ? sh.trP : C.trP;
@@ -528,20 +604,17 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         __attribute__((always_inline)) {
         is_new = u >= Q[0];
         const int ru = is_new ? u - Q[0] : u;
-        const int *pfx = sh.pfx[is_new ? 1 : 0];
-        const int *cnt = sh.cnt[is_new ? 1 : 0];
-        const int w = find_seg(pfx, gin.nw, ru);
-        const int ci = ru - RFL(pfx[w]);
-        valid = ci * 64 + lane < RFL(cnt[w]);
+        int w, idx;                                                    // (per lane: the writer segment and the entry's index in it)
+        packed_lane(sh.pfx[is_new ? 2 : 1], sh.cnt[is_new ? 2 : 1], is_new ? NS[1] : NS[0], is_new ? LN[1] : LN[0], ru, scratch, valid, w, idx);
         nb = make_int2(0, 0);
         if (!is_new) {
-            const unsigned off = valid ? rcur + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u : OOB_OFF;
+            const unsigned off = valid ? rcur + rec_chunk_off<NE>(gin.seg_rec, w, idx >> 6) + (unsigned)(idx & 63) * 16u : OOB_OFF;
             h0 = ld16(V.rec, off); h1 = ld16(V.rec, off + 1024u);
             if (NE == 6) h2 = ld16(V.rec, off + 2048u);
 #pragma unroll
             for (int j = 1; j <= NE; ++j) tk[j] = as_tok(ld16(V.rec, off + (unsigned)(HF + j - 1) * 1024u));
         } else if (valid) {
-            const unsigned long long e = CL((const unsigned long long *)(V.newl + (size_t)w * gin.seg_new + (unsigned)(ci * 64 + lane)));
+            const unsigned long long e = CL((const unsigned long long *)(V.newl + (size_t)w * gin.seg_new + (unsigned)idx));
             nb = make_int2((int)(unsigned)e, (int)(unsigned)(e >> 32));  // {arc, source state}
         }
     };
@@ -754,11 +827,11 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     // previous frame's phase A) and are written again by this frame's phase X, behind the barrier
 #pragma nounroll
     for (; u < Qall; u = grab_chunk(sh, jw, Cw)) {
-        const int ru = u - Q01;
-        const int w = find_seg(sh.pfx[2], gd.nw, ru);                 // (gd: the geometry this list was written with, two frames ago)
-        const int ci = ru - RFL(sh.pfx[2][w]);
-        if (ci * 64 + lane < RFL(sh.cnt[2][w])) {
-            const int b = CL(V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)w * gd.seg_new + (unsigned)(ci * 64 + lane));
+        bool on;
+        int w, idx;
+        packed_lane(sh.pfx[3], sh.cnt[3], NS[2], LN[2], u - Q01, scratch, on, w, idx);
+        if (on) {                                                      // (gd: the geometry this list was written with, two frames ago)
+            const int b = CL(V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)w * gd.seg_new + (unsigned)idx);
             CS(&V.srec[b].e[p], 0ULL);
         }
     }
@@ -1320,10 +1393,10 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 for (int b = tid; b < C.hist_nbins; b += SNT) sh.hprev[b] = CL(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b);
             const ListSrc src[3] = {{tot_of(TOT_REC0 + p), 64, gin.seg_rec, gin.nw}, {tot_of(TOT_NEW), 64, gin.seg_new, gin.nw},
                                     {tot_of(TOT_DIRTY0 + p), 64, (p ? gd1 : gd0).seg_new, (p ? gd1 : gd0).nw}};
-            int Q[3], items[3];
+            int Q[3], items[3], nseg[3];
             int new_prev = 0;                                          // arcs entered in the previous frame (read with the lists' counts)
             if (jw == 0 && tid == 0) new_prev = CL(&c.new_all[p ^ 1]);
-            build_lists<3>(sh, src, Q, items);
+            build_packed<3>(sh, src, 1, Q, items, nseg);
             if (use_hist) {                                            // every workgroup evaluates the same threshold
                 float th = hist_threshold(C, sh.hprev, lane);
                 th -= normalise;                                                     // :325
@@ -1336,9 +1409,9 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const float *llrow = A.ll + (size_t)ll_slot * A.ll_stride + (size_t)(f - A.f0) * C.G;
             int out_cnt = 0;
             CLK(0);                                                    // thresholds + work lists
-            if (lr) phase_a<NE, true, true, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else if (trp_lds) phase_a<NE, true, false, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else phase_a<NE, false, false, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            if (lr) phase_a<NE, true, true, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, items, nseg, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else if (trp_lds) phase_a<NE, true, false, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, items, nseg, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            else phase_a<NE, false, false, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, items, nseg, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
             CLK(1);                                                    // phase A (wave 0's share)
             if (lane == 0) {
                 CS(tot_of(TOT_REC0 + (p ^ 1)) + gw, out_cnt);

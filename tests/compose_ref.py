@@ -165,3 +165,45 @@ def compose_naive(cl, cl_init, g, g_init):
                 states.add(dk)
                 queue.append(dk)
     return _finish(states, arcs_of, fin_of, start, lambda k: k)
+
+
+def push_labels(cl, cl_init):
+    """Label pushing on C.L (csrc/jd_compose.hip, cl_push_labels; the reference: WFSTLabelPushingNetwork's label sets,
+    WFSTNetwork.cpp:1643-1764), written a second time: every output label moves towards the initial state, up to the
+    first arc behind which it is the only label that can follow.  Returns (new olab array, labels moved)."""
+    lo, hi, mf = _lookahead(cl)
+    S = len(cl["row_ptr"]) - 1
+    single = [lo[c] == hi[c] and not mf[c] for c in range(S)]
+    arcs = [(c, a, int(cl["to"][a]), int(cl["olab"][a])) for c in range(S) for a in range(int(cl["row_ptr"][c]), int(cl["row_ptr"][c + 1]))]
+    lab_in, less_in = [False] * S, [False] * S
+    lab_in[cl_init] = True                              # nothing has been emitted on the way to the initial state
+    nbr = {c: [] for c in range(S)}
+    for c, _, t, o in arcs:
+        if o:
+            lab_in[t] = True
+        else:
+            less_in[t] = True
+            if single[c] and single[t]:
+                nbr[c].append(t); nbr[t].append(c)
+    region = [-1] * S
+    for c in range(S):                                  # runs of single states joined by label-less arcs
+        if single[c] and region[c] < 0:
+            region[c] = c
+            todo = [c]
+            while todo:
+                x = todo.pop()
+                for y in nbr[x]:
+                    if region[y] < 0:
+                        region[y] = c
+                        todo.append(y)
+    bad = {region[c] for c in range(S) if single[c] and lab_in[c] and less_in[c]}
+    emitted = [single[c] and not lab_in[c] and region[c] not in bad for c in range(S)]
+    olab = np.array(cl["olab"], np.int32, copy=True)
+    moved = 0
+    for c, a, t, o in arcs:
+        if o == 0 and emitted[t] and not emitted[c]:
+            olab[a] = lo[t]
+            moved += 1
+        elif o != 0 and emitted[c]:
+            olab[a] = 0
+    return olab, moved

@@ -108,3 +108,81 @@ def test_sentence_end_reaches_a_terminal_final_state(seed, n_tri, with_sp):
             assert np.isfinite(a), ws
             assert abs(a - b) <= 1e-3 * max(1.0, abs(a)), (ws, a, b)
             assert not np.isfinite(_best(naive, ws)) and not np.isfinite(_best(filt, ws))   # a sentence has to end
+
+
+@pytest.mark.parametrize("seed,n_tri,with_sp,terminal", [(5, 30, True, False), (6, 0, False, False), (8, 40, True, True)])
+def test_label_pushing_moves_labels_and_keeps_every_path(seed, n_tri, with_sp, terminal):
+    """jd_net_push_labels (host code of the library, no device needed) against the same rule written in Python, and
+    against what label pushing has to preserve: every complete path keeps its label sequence (arcs correspond one to
+    one, so random walks through the original transducer are replayed on the pushed one), and the composition of the
+    pushed C.L with G accepts the same word sequences at the same best weights as textbook composition of the
+    original pair.  On a lexicon tree every label ends up on the first arc behind which its word is the only one left."""
+    from juicer_amd import capi, synth
+    from compose_ref import push_labels
+    V = 25
+    am = synth.make_models(seed, n_gmm=100, n_hmm=45, n_mix=2, n_tm=8, sep=0.6, with_tee=with_sp)
+    cl, g = synth.make_cl_g(seed, am, n_words=V, n_succ=3, n_tri=n_tri, with_sp=with_sp, terminal=terminal)
+    ncl = capi.Network.from_synth(cl, 1.0, 0.0)
+    pushed_net, moved = ncl.push_labels()
+    c0, c1 = ncl.csr(), pushed_net.csr()
+    for k in ("row_ptr", "to", "ilab", "fin_w"):
+        assert np.array_equal(c0[k], c1[k]), k
+    assert np.array_equal(c0["w"].view(np.uint32), c1["w"].view(np.uint32))
+    want, want_moved = push_labels(c0, ncl.init_state)
+    assert np.array_equal(c1["olab"], want) and moved == want_moved
+    assert moved > 0 and not np.array_equal(c0["olab"], c1["olab"])
+    # every word still has exactly as many label-carrying arcs as it has (shared) emission points; labels are a
+    # permutation-free move: the multiset of labels can only shrink where unique suffixes were shared
+    assert set(np.unique(c1["olab"])) == set(np.unique(c0["olab"]))
+    # random complete paths: same label sequence
+    rp, to = c0["row_ptr"], c0["to"]
+    fin = np.isfinite(c0["fin_w"])
+    rng = np.random.default_rng(seed)
+    done = 0
+    for _ in range(400):
+        s, a_seq = ncl.init_state, []
+        for _ in range(60):
+            if fin[s] and a_seq and rng.random() < 0.3:
+                break
+            if rp[s] == rp[s + 1]:
+                break
+            a = int(rng.integers(rp[s], rp[s + 1]))
+            a_seq.append(a)
+            s = int(to[a])
+        if not fin[s]:
+            continue
+        l0 = [int(c0["olab"][a]) for a in a_seq if c0["olab"][a]]
+        l1 = [int(c1["olab"][a]) for a in a_seq if c1["olab"][a]]
+        assert l0 == l1
+        done += 1
+    assert done >= 20
+    # a label never moves away from the initial state: along every arc sequence above the k-th label of the pushed
+    # transducer is passed no later than the k-th label of the original (checked on prefixes of complete paths too)
+    for _ in range(200):
+        s, n0, n1 = ncl.init_state, 0, 0
+        for _ in range(40):
+            if rp[s] == rp[s + 1]:
+                break
+            a = int(rng.integers(rp[s], rp[s + 1]))
+            n0 += int(c0["olab"][a] != 0); n1 += int(c1["olab"][a] != 0)
+            assert n1 >= n0
+            s = int(to[a])
+    # composed with G: same weighted language as textbook composition of the original pair
+    ccl, ci = _csr_of(cl, 1.0)
+    cg, gi = _csr_of(g, 3.0)
+    assert np.array_equal(ccl["olab"], c0["olab"])                      # (the loader keeps the file's arc order)
+    pcl = dict(ccl, olab=want)
+    naive = compose_naive(ccl, ci, cg, gi)
+    for pushing in (False, True):
+        filt = compose_filtered(pcl, ci, cg, gi, pushing=pushing)
+        for _ in range(15):
+            h, ws = 0, []
+            for _ in range(int(rng.integers(1, 5))):
+                wd = int(g.succ[h, rng.integers(0, g.succ.shape[1])]) if rng.random() < 0.6 else int(rng.integers(0, V))
+                ws.append(wd + 1)
+                h = 1 + wd
+            if terminal:
+                ws.append(V + 1)
+            a, b = _best(naive, ws), _best(filt, ws)
+            assert np.isfinite(a), ws
+            assert abs(a - b) <= 1e-3 * max(1.0, abs(a)), (ws, a, b)

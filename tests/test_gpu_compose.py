@@ -178,3 +178,55 @@ def test_batch_test_cli_with_separate_grammar(built, tmp_path):
     for u in range(3):
         assert gs[u].n > 0
         assert [int(w) for w in lines[u].split()] == (gs[u].label[::-1] - 1).tolist()
+
+
+@pytest.mark.parametrize("weights", [False, True], ids=["labels", "labels+weights"])
+@pytest.mark.parametrize("c", CASES[:2], ids=lambda c: "seed%d" % c["seed"])
+def test_label_pushing(built, c, weights):
+    """The other half of the reference's -pushing (doLabelAndWeightPushing, juicer.cpp:240): C.L is composed with its
+    output labels pushed towards the initial state (jd_net_push_labels; the rule is checked on its own by
+    tests/test_compose_ref_cpu.py).  The device composition equals the offline one on the pushed C.L bit for bit; the
+    search-driven composition decodes like the composed graph bit for bit; and against the CPU oracle on TEXTBOOK
+    composition of the ORIGINAL pair the words and the path totals are the same - what moves is when a word's label
+    is passed: its time is the frame in which the word was identified, never later than its end."""
+    from juicer_amd import capi, synth
+    from compose_ref import push_labels
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, cl, g, ncl, ng = _case(c)
+    models = capi.Models.from_htk(am)
+    dev = capi.Network.compose(ncl, ng, pushing=weights, push_labels=True)
+    ccl = ncl.csr()
+    olab, moved = push_labels(ccl, ncl.init_state)
+    assert moved > 0
+    want = compose_filtered(dict(ccl, olab=olab), ncl.init_state, ng.csr(), ng.init_state, pushing=weights)
+    got = dev.csr()
+    assert dev.n_states == want["n_states"] and dev.init_state == want["init"]
+    for k in ("row_ptr", "to", "ilab", "olab"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["w"].view(np.uint32), want["w"].view(np.uint32))
+    assert np.array_equal(got["fin_w"].view(np.uint32), want["fin_w"].view(np.uint32))
+    # the same through the pushed network as an object of its own
+    pcl, n = ncl.push_labels()
+    assert n == moved
+    again = capi.Network.compose(pcl, ng, pushing=weights).csr()
+    assert all(np.array_equal(again[k], got[k]) for k in got)
+    feats = [synth.sample_utterance(c["seed"] + 1000 + u, g, am, 6 + u)[0] for u in range(3)]
+    kw = dict(main_beam=400.0)
+    gs = capi.Decoder(dev, models, max_streams=len(feats), **kw).decode_batch(feats)
+    lz = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18, pushing=weights, push_labels=True)
+    ls = capi.Decoder(lz, models, max_streams=len(feats), **kw).decode_batch(feats)
+    nv = compose_naive(ccl, ncl.init_state, ng.csr(), ng.init_state)
+    fs = np.nonzero(np.isfinite(nv["fin_w"]))[0].astype(np.int32)
+    onet = OracleNet.from_csr(nv["n_states"], nv["init"], nv["row_ptr"], nv["to"], nv["w"], nv["ilab"], nv["olab"], fs, nv["fin_w"][fs])
+    od = OracleDecoder(onet, OracleAM(am), **kw)
+    earlier = 0
+    for u, x in enumerate(feats):
+        a, b = gs[u], ls[u]
+        assert a.n == b.n and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
+        assert np.array_equal(np.asarray(a.score, np.float32).view(np.uint32), np.asarray(b.score, np.float32).view(np.uint32))
+        o = od.decode(x)
+        assert a.n == o.n and o.n > 0 and np.array_equal(a.label, o.label)
+        assert np.all(a.time <= o.time)
+        earlier += int(np.sum(a.time < o.time))
+        assert rel_close(a.tot_ac, o.tot_ac) and rel_close(a.tot_lm, o.tot_lm)
+    assert earlier > 0

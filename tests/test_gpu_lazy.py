@@ -192,14 +192,15 @@ def test_lazy_reset(built):
     for a, b in zip(again, first):
         _same(a, b)
     assert lazy.lazy_size()[0] == s1[0]
-    # a network that ran out of room stays failed until it is reset
+    # a network too small for ONE utterance: every decode fails (after a second try on a fresh arena generation)
     small = capi.Network.lazy(ncl, ng, models, max_states=300, max_arcs=1 << 18)
     t0 = small.lazy_size()
     d2 = capi.Decoder(small, models, main_beam=250.0)
-    for _ in range(2):
+    for k in range(2):
         with pytest.raises(capi.JuicerAmdError) as ei:
             d2.decode_batch(feats[:1])
         assert ei.value.code == capi.JD_ENOMEM
+        assert small.lazy_generation() == 2 * k + 1    # (the failed network started again before the retry, and before the next call)
     small.lazy_reset()
     assert small.lazy_size() == t0
     with pytest.raises(capi.JuicerAmdError):
@@ -258,3 +259,67 @@ def test_lazy_epsilon_cycle(built):
     assert want.n > 0
     _same(got, want)
     assert lazy.lazy_size()[0] <= static.n_states
+
+
+def test_lazy_generations(built):
+    """Bounded look-ahead memory (the reference: an LRU cache, WFSTOnTheFlyDecoder.h:210-371): the arena starts a new
+    GENERATION between utterances when it is past its high-water mark, and a batch that runs out of room under way is
+    decoded again on a fresh one - results are those of the composed graph, the network never stays failed."""
+    from juicer_amd import capi, synth
+    c = CASES[0]
+    am, g, ncl, ng = _case(c)
+    models = capi.Models.from_htk(am)
+    feats = [synth.sample_utterance(c["seed"] + 700 + u, g, am, 9)[0] for u in range(8)]
+    kw = dict(main_beam=300.0, max_streams=2)
+    want = capi.Decoder(capi.Network.compose(ncl, ng), models, **kw).decode_batch(feats)
+    assert sum(h.n for h in want) > 0
+    # what one wave of two utterances needs on its own, and what the four waves need together
+    big = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    dec = capi.Decoder(big, models, **kw)
+    alone = []
+    for w in range(4):
+        big.lazy_reset()
+        dec.decode_batch(feats[2 * w:2 * w + 2])
+        alone.append(big.lazy_size())
+    big.lazy_reset()
+    dec.decode_batch(feats)
+    together = big.lazy_size()
+    gen0 = big.lazy_generation()
+    assert gen0 == 5                                   # (the resets above; nothing was dropped by the network itself)
+    need_s, need_a = max(a[0] for a in alone), max(a[1] for a in alone)
+    assert together[0] > need_s and together[1] > need_a
+    # 1. high-water mark (set between the start state's closure and what a wave leaves behind): every wave that
+    # begins behind another one gets a new generation
+    net = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    mark = 0.5 * (net.lazy_size()[0] + min(a[0] for a in alone)) / float(1 << 16)
+    net.lazy_set_high_water(mark)
+    got = capi.Decoder(net, models, **kw).decode_batch(feats)
+    for a, b in zip(got, want):
+        _same(a, b)
+    assert net.lazy_generation() == 3                  # before waves 2, 3 and 4
+    # 2. room for any one wave but not for all four: some wave runs out under way and is decoded again
+    cap_s, cap_a = (need_s + together[0]) // 2, (need_a + together[1]) // 2
+    for cs, ca in ((cap_s, 1 << 18), (1 << 16, cap_a)):
+        net = capi.Network.lazy(ncl, ng, models, max_states=cs, max_arcs=ca)
+        net.lazy_set_high_water(1.0)                   # (never ahead of time)
+        d = capi.Decoder(net, models, **kw)
+        got = d.decode_batch(feats)
+        for a, b in zip(got, want):
+            _same(a, b)
+        assert net.lazy_generation() >= 1
+        ns, na = net.lazy_size()
+        assert ns <= cs and na <= ca
+        again = d.decode_batch(feats[:2])              # and the network goes on working
+        _same(again[0], want[0]); _same(again[1], want[1])
+    # 3. the streaming interface: generations begin at jd_stream_init, never inside an utterance
+    net = capi.Network.lazy(ncl, ng, models, max_states=1 << 16, max_arcs=1 << 18)
+    net.lazy_set_high_water(mark)
+    d = capi.Decoder(net, models, main_beam=300.0, max_streams=2)
+    for u in range(3):
+        d.stream_init(0)
+        with pytest.raises(capi.JuicerAmdError):       # an utterance is inside the network: no reset by hand either
+            net.lazy_reset()
+        for k in range(0, feats[u].shape[0], 37):
+            d.stream_push(0, feats[u][k:k + 37])
+        _same(d.stream_finish(0), want[u])
+    assert net.lazy_generation() == 2
