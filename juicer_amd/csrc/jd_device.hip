@@ -320,7 +320,11 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
                         sum += z1; sum += z2;
                     }
                     const double dm = (double)dg[m];
-                    jd_log_add2x2(acc0, acc1, (float)(-0.5 * (double)sum.x + dm), (float)(-0.5 * (double)sum.y + dm), stab, setab);   // :254
+                    const float c0 = (float)(-0.5 * (double)sum.x + dm), c1 = (float)(-0.5 * (double)sum.y + dm);   // :254
+                    // logAdd(LOG_ZERO, c) is c for every c > LOG_ZERO and LOG_ZERO else (the difference is below -18.42,
+                    // or the sum rounds back): the first mixture needs no exponential and no logarithm
+                    if (m == 0) { acc0 = LZ < c0 ? c0 : LZ; acc1 = LZ < c1 ? c1 : LZ; }
+                    else jd_log_add2x2(acc0, acc1, c0, c1, stab, setab);
                 }
             }
             so[lane * (GMM_GT + 1) + gl] = acc0;
@@ -965,6 +969,7 @@ struct jd_dec {
     // streams of the streaming API that are inside an utterance
     bool lazy_failed = false;
     std::vector<char> lazy_in;
+    bool occupancy_ok = false;            // k_search fits a CU the way launch_search's grid assumes (checked at the first launch)
 };
 
 template <typename T>
@@ -1639,6 +1644,25 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // out: launches on one device are serialised here, from dispatch to completion.  (Other PROCESSES on the device
         // are outside this lock: the dispatcher starts the workgroups of a kernel in order, and a kernel that cannot
         // become fully resident ends in JDE_BARRIER after 30 s instead of hanging.)
+        if (!d->occupancy_ok) {
+            // ... and the kernel must fit a CU the way the grid assumes: asked of the runtime once per decoder, for the
+            // flavours it may launch (a build with other SW / WG_PER_CU / LDS sizes, or a device with smaller CUs,
+            // fails here with a message instead of after a 30 s barrier time-out)
+            const bool lz = d->C.lazy != nullptr;
+            const void *fn[2] = {
+                lz ? (ne3 ? (const void *)k_search<3, false, true> : (const void *)k_search<6, false, true>)
+                   : (ne3 ? (const void *)k_search<3, false, false> : (const void *)k_search<6, false, false>),
+                lz ? (ne3 ? (const void *)k_search<3, true, true> : (const void *)k_search<6, true, true>)
+                   : (ne3 ? (const void *)k_search<3, true, false> : (const void *)k_search<6, true, false>)};
+            for (int v = 0; v < 2; ++v) {
+                int per_cu = 0;
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn[v], SNT, 0));
+                if (per_cu < WG_PER_CU)
+                    return jd_fail(JD_EHIP, "k_search needs %d workgroup(s) of %d threads resident per CU, the device takes %d: "
+                                   "its clusters could not all be resident at once", WG_PER_CU, SNT, per_cu);
+            }
+            d->occupancy_ok = true;
+        }
         std::lock_guard<std::mutex> search_lock(g_search_mu[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)]);
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
         HIPCHK(hipEventRecord(e0, st));

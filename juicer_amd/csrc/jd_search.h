@@ -215,6 +215,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigne
 // the enclosing function's `XL_`.
 __device__ __forceinline__ v4i ld16(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX_SC1); }
 template <typename T> __device__ __forceinline__ T CL(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A pointer the kernel LOADS from memory (the per-stream arena pointers of StreamDev) is a generic pointer to the
+// compiler, and every access through it a FLAT instruction: one that may touch LDS, so it counts on the LDS counter
+// as well - and since the LDS counter cannot tell a flat load's return from a ds_read's, every wait for an LDS result
+// (list look-ups, the queue, shuffles through ds_bpermute) while a flat load is in flight becomes a wait for that
+// load: the software pipelines of both phases stalled at their first LDS operation (s_waitcnt vmcnt(0) lgkmcnt(0)
+// right behind the arc walk's "one pass ahead" loads).  Hence: the arena pointers are address_space(1) (GLOBAL)
+// pointers in the kernel (StreamView), and these are the accessors for them.
+#define GAS __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ T CL(const GAS T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <bool XL> __device__ __forceinline__ void st16x(__amdgpu_buffer_rsrc_t r, unsigned off, v4i v)
 {
     if (XL) __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0);
@@ -224,6 +233,21 @@ template <bool XL, typename T> __device__ __forceinline__ void CSx(T *p, T v)
 {
     if (XL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XL, typename T> __device__ __forceinline__ void CSx(GAS T *p, T v)
+{
+    if (XL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XL, typename T, typename U> __device__ __forceinline__ T GMAXx(GAS T *p, U v)
+{
+    return XL ? __hip_atomic_fetch_max(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+              : __hip_atomic_fetch_max(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XL, typename T, typename U> __device__ __forceinline__ T GADDx(GAS T *p, U v)
+{
+    return XL ? __hip_atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+              : __hip_atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool XL, typename T, typename U> __device__ __forceinline__ T GMAXx(T *p, U v)
 {
@@ -286,7 +310,7 @@ struct SearchShared {
 // loads of all lists are in flight together and the scans share two barriers.  All SNT threads
 // call it.  K = records per chunk; segcap = capacity of a wave segment (counts are clamped to it); nw = the wave
 // segments the list was written with (lists of different ages may come from launches of different geometries).
-struct ListSrc { const int *tot; int K; unsigned segcap; int nw; };
+struct ListSrc { const GAS int *tot; int K; unsigned segcap; int nw; };
 template <int N>
 __device__ __forceinline__ void build_lists(SearchShared &sh, const ListSrc (&src)[N], int (&Q)[N], int (&items)[N])
 {
@@ -520,7 +544,8 @@ struct StreamView {     // wave-uniform descriptors of one stream's arenas
     unsigned rec_par, item_par;                 // byte offset of parity 1 in them
     __amdgpu_buffer_rsrc_t lrows, larcs;        // lazy graphs: the rows and the arc arena (read with `sc1` loads)
     __amdgpu_buffer_rsrc_t srec_r;              // the per-state records, for 16-byte loads
-    unsigned char *live; StateRec *srec; int2 *newl; int *dirtyl; unsigned dirty_par; int *tot; PathRec *paths; int *hist;
+    GAS unsigned char *live; GAS StateRec *srec; GAS unsigned long long *newl; GAS int *dirtyl; unsigned dirty_par; GAS int *tot;
+    GAS v4i *paths; GAS int *hist;              // (global pointers, not generic ones: see GAS)
 };
 
 // byte offset of chunk ci of wave segment w in a record list (parity offset added by the caller)
@@ -614,7 +639,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
 #pragma unroll
             for (int j = 1; j <= NE; ++j) tk[j] = as_tok(ld16(V.rec, off + (unsigned)(HF + j - 1) * 1024u));
         } else if (valid) {
-            const unsigned long long e = CL((const unsigned long long *)(V.newl + (size_t)w * gin.seg_new + (unsigned)idx));
+            const unsigned long long e = CL(V.newl + (size_t)w * gin.seg_new + (unsigned)idx);
             nb = make_int2((int)(unsigned)e, (int)(unsigned)(e >> 32));  // {arc, source state}
         }
     };
@@ -902,7 +927,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
     const bool can_filter = !init && C.emit_win > 0.0f && bestA > LZ;
     const bool tee_lds = C.n_hmm <= TEE_LDS_MAX;
     const unsigned item_base = (unsigned)gw * gout.seg_item, new_base = (unsigned)gw * gout.seg_new;
-    int *const dirty_seg = V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)new_base;
+    GAS int *const dirty_seg = V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)new_base;
     int *wpfx = sh.wpfx[wid];
     v4i *qtok = sh.qtok[wid], *qinfo = sh.qinfo[wid];
     int2 *qrow = sh.qrow[wid];
@@ -1018,10 +1043,9 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             if (info.y != 0) {
                 const int pp = pbase + rank_in(blab);
                 if (pp < C.cap_paths) {
-                    PathRec pr;
-                    pr.prev = t.path; pr.frame = pframe; pr.label = label; pr.pad0 = 0;
-                    pr.score = t.score; pr.ac = t.ac; pr.lm = t.lm; pr.pad1 = 0.0f;
-                    V.paths[pp] = pr;                                  // read by later launches only
+                    // PathRec {prev, frame, label, -; score, ac, lm, -}: two plain 16-byte stores (read by later launches only)
+                    V.paths[2 * (size_t)pp] = (v4i){t.path, pframe, label, 0};
+                    V.paths[2 * (size_t)pp + 1] = (v4i){__float_as_int(t.score), __float_as_int(t.ac), __float_as_int(t.lm), 0};
                     t.path = pp;
                     st16(V.items, ioff, as_v4(t));                     // the tokens pulled from this item carry the new history
                     ++c_paths;
@@ -1143,7 +1167,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 un.lm = tg.lm + Bk.w;
                 mk = un.score > endTh;
             } else if (is_tee) {                                       // :584-600 tee model
-                const float tee = tee_lds ? sh.tee[inl - 1] : C.hmm_tee[inl - 1];
+                const float tee = tee_lds ? sh.tee[inl - 1] : CL(C.hmm_tee + (inl - 1));   // (an atomic load: never merged with the LDS one into a flat load)
                 const float ns2 = ns + tee;
                 un.score = ns2;
                 un.ac = tg.ac + tee;
@@ -1168,7 +1192,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 const int nt = __popcll(bt);
                 if (out.new_cnt + nt > (int)gout.seg_new) { if (lane == 0) CS(&c.err[p], (int)JDE_NEW); }
                 else {
-                    if (touch) CS((unsigned long long *)(V.newl + (size_t)new_base + (unsigned)(out.new_cnt + rank_in(bt))),
+                    if (touch) CS(V.newl + (size_t)new_base + (unsigned)(out.new_cnt + rank_in(bt)),
                                   ((unsigned long long)(unsigned)sg << 32) | (unsigned)b);
                     out.new_cnt += nt;
                 }
@@ -1254,10 +1278,10 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     V.rec = mk_rsrc(S.rec, 2ULL * C.cap_slots * RL::REC_BYTES);
     V.items = mk_rsrc(S.items, 2ULL * C.cap_items * 32u);
     V.rec_par = C.cap_slots * (unsigned)RL::REC_BYTES; V.item_par = C.cap_items * 32u;
-    V.live = S.live; V.srec = S.srec;
+    V.live = (GAS unsigned char *)S.live; V.srec = (GAS StateRec *)S.srec;
     V.srec_r = mk_rsrc(S.srec, (unsigned long long)C.n_states * sizeof(StateRec));
-    V.newl = S.newl; V.dirtyl = S.dirtyl; V.dirty_par = C.cap_new;
-    V.tot = S.tot; V.paths = S.paths; V.hist = S.hist;
+    V.newl = (GAS unsigned long long *)S.newl; V.dirtyl = (GAS int *)S.dirtyl; V.dirty_par = C.cap_new;
+    V.tot = (GAS int *)S.tot; V.paths = (GAS v4i *)S.paths; V.hist = (GAS int *)S.hist;
     if (LZY) {
         V.lrows = mk_rsrc(C.lazy->rows, (unsigned long long)C.lazy->max_states * 16ULL);
         V.larcs = mk_rsrc(C.lazy->arcs, (unsigned long long)C.lazy->max_arcs * 16ULL);
@@ -1509,7 +1533,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             for (int i0 = 0; i0 < xo.new_cnt && ok; i0 += 64) {
                 int dest = -1;
                 if (i0 + lane < xo.new_cnt) {
-                    const int b = (int)(unsigned)CL((const unsigned long long *)(V.newl + nbase + (unsigned)(i0 + lane)));
+                    const int b = (int)(unsigned)CL(V.newl + nbase + (unsigned)(i0 + lane));
                     dest = ld16(V.larcs, (unsigned)b * 16u).x;
                     if (lz_status(L, dest) == LZ_CLOSED) dest = -1;
                 }
@@ -1555,7 +1579,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         return;
     }
     // ---- end of the launch: persist the stream state (read by the next launch / the host kernels)
-    if (lane == 0) CS(S.item_end + gw, my_item_end);
+    if (lane == 0) CS((GAS int *)S.item_end + gw, my_item_end);
     if (tid == 0) {
         for (int k = 0; k < ST_N; ++k) if (sh.acc[k]) atomicAdd((unsigned long long *)&c.st[k], (unsigned long long)sh.acc[k]);
         if (A.dbg) {
