@@ -440,7 +440,7 @@ __device__ __forceinline__ void packed_lane(const int *cp, const int *sg, int ns
 {
     const int lane = threadIdx.x & 63;
     const int base = ru << 6;
-    const int w0 = find_seg(cp, ns, base);
+    const int w0 = max(find_seg(cp, ns, base), 0);                     // (an empty list: nothing is valid, the look-ups stay in range)
     const int j = w0 + 1 + lane;
     const int r = (j < ns ? cp[j] : 0x3fffffff) - base;               // (> 0: segments are non-empty)
     // (lanes talk to each other through the row: wavefront-scope atomics, or the compiler - which sees one thread -
@@ -627,21 +627,27 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     // the clean-up list), so the clean-up chunks form a plain loop of their own at the end.
     auto stage_r = [&](int u, bool &is_new, bool &valid, int2 &nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1])
         __attribute__((always_inline)) {
+        // Every load of this stage is issued whatever kind of chunk this is, and even when the lists are through (u >= Q01):
+        // lanes without a record read out of range (zeros, no memory access), lanes without a new arc read entry 0.  A
+        // load inside a branch - even a wave-uniform one - reaches the registers that carry it to the next pass through
+        // a copy at the join, and the compiler waits for the load right there: the pipeline below would be no pipeline.
+        const bool any = u < Q01;
         is_new = u >= Q[0];
-        const int ru = is_new ? u - Q[0] : u;
+        const int ql = is_new ? Q[1] : Q[0];
+        int ru = is_new ? u - Q[0] : u;
+        ru = ru < ql ? ru : ql - 1;
+        ru = ru > 0 ? ru : 0;
         int w, idx;                                                    // (per lane: the writer segment and the entry's index in it)
         packed_lane(sh.pfx[is_new ? 2 : 1], sh.cnt[is_new ? 2 : 1], is_new ? NS[1] : NS[0], is_new ? LN[1] : LN[0], ru, scratch, valid, w, idx);
-        nb = make_int2(0, 0);
-        if (!is_new) {
-            const unsigned off = valid ? rcur + rec_chunk_off<NE>(gin.seg_rec, w, idx >> 6) + (unsigned)(idx & 63) * 16u : OOB_OFF;
-            h0 = ld16(V.rec, off); h1 = ld16(V.rec, off + 1024u);
-            if (NE == 6) h2 = ld16(V.rec, off + 2048u);
+        valid = valid && any;
+        const bool rec = valid && !is_new, fresh = valid && is_new;
+        const unsigned off = rec ? rcur + rec_chunk_off<NE>(gin.seg_rec, w, idx >> 6) + (unsigned)(idx & 63) * 16u : OOB_OFF;
+        h0 = ld16(V.rec, off); h1 = ld16(V.rec, off + 1024u);
+        if (NE == 6) h2 = ld16(V.rec, off + 2048u);
 #pragma unroll
-            for (int j = 1; j <= NE; ++j) tk[j] = as_tok(ld16(V.rec, off + (unsigned)(HF + j - 1) * 1024u));
-        } else if (valid) {
-            const unsigned long long e = CL(V.newl + (size_t)w * gin.seg_new + (unsigned)idx);
-            nb = make_int2((int)(unsigned)e, (int)(unsigned)(e >> 32));  // {arc, source state}
-        }
+        for (int j = 1; j <= NE; ++j) tk[j] = as_tok(ld16(V.rec, off + (unsigned)(HF + j - 1) * 1024u));
+        const unsigned long long e = CL(V.newl + (fresh ? (size_t)w * gin.seg_new + (unsigned)idx : (size_t)0));
+        nb = fresh ? make_int2((int)(unsigned)e, (int)(unsigned)(e >> 32)) : make_int2(0, 0);   // {arc, source state}
     };
     auto stage_k = [&](bool is_new, bool valid, int2 nb, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1],
                        unsigned long long &kv, float (&outp)[NE]) __attribute__((always_inline)) {
@@ -665,8 +671,11 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             for (int j = 1; j <= NE; ++j) tk[j] = null_tok();
         }
         const int n = h0.y & 0xff;
-        kv = 0ULL;
-        if (valid) kv = CL(&V.srec[h0.z].e[p ^ 1]);                    // the best arrival at the source state and the likelihoods: in flight together
+        {   // the best arrival at the source state (StateRec::e[p ^ 1]) and the likelihoods: in flight together (no branch:
+            // lanes without an instance read out of range)
+            const v4i ev = ld16(V.srec_r, valid ? (unsigned)h0.z * (unsigned)sizeof(StateRec) + 16u : OOB_OFF);
+            kv = ((unsigned long long)(unsigned)(p ? ev.y : ev.w) << 32) | (unsigned)(p ? ev.x : ev.z);
+        }
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int gj = (j == 0) ? h1.x : (j == 1) ? h1.y : (j == 2) ? h1.z : (j == 3) ? h2.x : (j == 4) ? h2.y : h2.z;
@@ -680,7 +689,8 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     Tok tk[NE + 1];
     unsigned long long kv = 0ULL;
     float outp[NE];
-    if (u < Q01) { stage_r(u, is_new, valid, nb, h0, h1, h2, tk); stage_k(is_new, valid, nb, h0, h1, h2, tk, kv, outp); }
+    stage_r(u, is_new, valid, nb, h0, h1, h2, tk);
+    stage_k(is_new, valid, nb, h0, h1, h2, tk, kv, outp);
 #pragma nounroll
     while (u < Q01) {
         FINE_START();
@@ -690,14 +700,13 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         const int n = h0.y & 0xff;                                     // 0 for lanes without an instance
         const int tm = (h0.y >> 8) & 0x3fffff;
         // entry token = the best token that arrived at the arc's source state in the previous frame, over the arc (:560-582)
-        v4i itv = {0, 0, 0, 0};
-        if (kv != 0ULL) itv = ld16(V.items, iprev + (unsigned)(kv & 0xffffffffULL) * 32u);
+        const v4i itv = ld16(V.items, kv != 0ULL ? iprev + (unsigned)(kv & 0xffffffffULL) * 32u : OOB_OFF);   // (no branch, see stage_r)
         // stage R of the next chunk (issued after the item load: the wait for the item leaves it in flight)
         bool n_is_new = false, n_valid = false;
         int2 n_nb = make_int2(0, 0);
         v4i nh0 = {0, 0, 0, 0}, nh1 = {0, 0, 0, 0}, nh2 = {0, 0, 0, 0};
         Tok ntk[NE + 1];
-        if (un < Q01) stage_r(un, n_is_new, n_valid, n_nb, nh0, nh1, nh2, ntk);
+        stage_r(un, n_is_new, n_valid, n_nb, nh0, nh1, nh2, ntk);
         FINE(1);                                                       // the winning item (+ the next record)
         tk[0] = null_tok();
         if (kv != 0ULL) {
@@ -797,7 +806,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         // stage K of the next chunk: its record has arrived during the arithmetic
         unsigned long long nkv = 0ULL;
         float noutp[NE];
-        if (un < Q01) stage_k(n_is_new, n_valid, n_nb, nh0, nh1, nh2, ntk, nkv, noutp);
+        stage_k(n_is_new, n_valid, n_nb, nh0, nh1, nh2, ntk, nkv, noutp);
         c_emit += __popc(live_mask);
         const bool has_exit = ex.score > LZ;
         const bool slot_live = live_mask != 0;
@@ -990,43 +999,50 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         // of an exit token's arc, the Path reservation.  A closure item this wave queued for itself brought its row
         // along - the record was read when it arrived - and has just been found the best arrival at its state: it
         // needs no load at all.
-        int rs, rs1;
-        float fin_lazy = 0.0f;
-        unsigned long long kv = 0ULL;
-        int label = exit_kind ? 0 : info.y;
-        const bool carried = !LZY && from_q;                           // (wave-uniform)
-        if (carried) { rs = row_q.x; rs1 = row_q.x + row_q.y; }
-        else {
-            const unsigned soff = (real || (valid && !LZY)) ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
-            v4i sk = {0, 0, 0, 0};
-            if (real && exit_kind) sk = ld16(V.srec_r, soff);          // {key0, keyL}
-            int2 srow = make_int2(0, 0);
-            if (!LZY) { const int sti = valid ? state : 0; srow = make_int2(C.row_ptr[sti], C.row_ptr[sti + 1]); }   // (static, shared by the streams: cached loads)
-            if (exit_kind && real && info.y != 0) {                    // (labelled exit tokens: a few per cent of the items)
-                if (LZY) label = ld16(V.larcs, (unsigned)info.x * 16u).w;
-                else label = C.arcs[info.x].out;
-            }
-            if (LZY) {                                                 // {first arc, arcs, status, final weight}: ready by the invariant
-                const v4i r = ld16(V.lrows, (unsigned)state * 16u);
-                rs = r.x; rs1 = r.x + r.y; fin_lazy = __int_as_float(r.w);
-                if (valid && r.z < LZ_EXPANDED) CS(&c.err[p], (int)JDE_LAZY_INV);   // (cannot happen: the invariant of jd_lazy.h)
-            } else { rs = srow.x; rs1 = srow.y; }
-            kv = ((unsigned long long)(unsigned)(info.y != 0 ? sk.w : sk.y) << 32) | (unsigned)(info.y != 0 ? sk.z : sk.x);
-        }
         bool have = valid;
         if (real && exit_kind && !init) {                              // :952-962
             have = t.score > ((info.y != 0) ? wordTh : endTh);
             if (have) ++c_pend;
         }
-        // Path records (:497-509) are reserved for every labelled item that passed its threshold,
-        // winner or not, so that the reservation is in flight together with the key load
+        // Path records (:497-509) are reserved for every labelled item that passed its threshold, winner or not, so that
+        // the reservation is in flight together with the loads below: it is issued BEHIND them (the compiler waits
+        // for a returning atomic where it stands, and that wait then is the wait for the loads as well)
         const bool labelled = real && have && info.y != 0;
         const unsigned long long blab = __ballot(labelled);
         int pbase = 0;
-        if (blab) {
-            const int first = __ffsll((long long)blab) - 1;
-            if (lane == first) pbase = GADD(&c.n_paths, __popcll(blab));
-            pbase = __shfl(pbase, first);
+        auto reserve = [&]() __attribute__((always_inline)) {
+            if (blab) {
+                const int first = __ffsll((long long)blab) - 1;
+                if (lane == first) pbase = GADD(&c.n_paths, __popcll(blab));
+                pbase = __shfl(pbase, first);
+            }
+        };
+        int rs, rs1;
+        float fin_lazy = 0.0f;
+        unsigned long long kv = 0ULL;
+        int label = exit_kind ? 0 : info.y;
+        const bool carried = !LZY && from_q;                           // (wave-uniform)
+        if (carried) { rs = row_q.x; rs1 = row_q.x + row_q.y; reserve(); }
+        else {
+            // (no load sits in a branch of its own: a load inside a branch is waited for at the branch's end, and these
+            // would be three round trips one after the other instead of one)
+            const unsigned soff = (real || (valid && !LZY)) ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
+            const v4i sk = ld16(V.srec_r, (real && exit_kind) ? soff : OOB_OFF);   // {key0, keyL}
+            int2 srow = make_int2(0, 0);
+            if (!LZY) { const int sti = valid ? state : 0; srow = make_int2(C.row_ptr[sti], C.row_ptr[sti + 1]); }   // (static, shared by the streams: cached loads)
+            const bool lab_on = exit_kind && real && info.y != 0;      // (labelled exit tokens: a few per cent of the items)
+            int lb;
+            if (LZY) lb = ld16(V.larcs, lab_on ? (unsigned)info.x * 16u : OOB_OFF).w;
+            else lb = C.arcs[lab_on ? info.x : 0].out;
+            v4i lr = {0, 0, 0, 0};
+            if (LZY) lr = ld16(V.lrows, (unsigned)state * 16u);        // {first arc, arcs, status, final weight}: ready by the invariant
+            reserve();
+            label = lab_on ? lb : label;
+            if (LZY) {
+                rs = lr.x; rs1 = lr.x + lr.y; fin_lazy = __int_as_float(lr.w);
+                if (valid && lr.z < LZ_EXPANDED) CS(&c.err[p], (int)JDE_LAZY_INV);   // (cannot happen: the invariant of jd_lazy.h)
+            } else { rs = srow.x; rs1 = srow.y; }
+            kv = ((unsigned long long)(unsigned)(info.y != 0 ? sk.w : sk.y) << 32) | (unsigned)(info.y != 0 ? sk.z : sk.x);
         }
         XFINE(1);                                                      // hop 2: state record, label, Path reservation
         if (real) {
@@ -1066,9 +1082,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         // its item's.)  The answer is first needed by the arc passes: its round trip runs beside the first arcs'.
         unsigned eo = exit_kind ? 0u : (unsigned)info.x;               // ordered score of the best arrival before this one (0: none)
         unsigned long long eold = 0ULL;
-        const bool arrive = have && exit_kind;
-        if (arrive) eold = GMAX(&V.srec[state].e[p], ((unsigned long long)f2o(t.score) << 32) | ii);
-        XFINE(2);                                                      // winners: key reset, Path record, final state, arrival
+        const bool arrive = have && exit_kind;                         // (the atomic itself: behind the first arcs' loads, below)
+        XFINE(2);                                                      // winners: key reset, Path record, final state
         // ---- A state with thousands of out-arcs (a history with 10^4 successors) would keep this wave busy
         // for hundreds of passes while the cluster waits at the barrier: the wave walks the first X_SLICE
         // arcs itself and hands the rest on as SLICES - items of the next round (flag 2 + slice number)
@@ -1077,25 +1092,6 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         if (slice_no > 0) { alo = rs + slice_no * X_SLICE; ahi = min(rs1, alo + X_SLICE); }
         int n_slices = 0;
         if (have && slice_no == 0 && rs1 - rs > X_SLICE) { n_slices = (rs1 - rs - 1) / X_SLICE; ahi = rs + X_SLICE; }
-        if (__ballot(n_slices > 0)) {
-            if (arrive) eo = (unsigned)(eold >> 32);                   // (the slices carry it: wait for the arrival's answer here)
-            for (unsigned long long bs = __ballot(n_slices > 0); bs; bs &= bs - 1) {
-                const int src = __ffsll((long long)bs) - 1;
-                const int ns = __shfl(n_slices, src);
-                const v4i tv = {__shfl(__float_as_int(t.score), src), __shfl(__float_as_int(t.ac), src), __shfl(__float_as_int(t.lm), src), __shfl(t.path, src)};
-                const int sx = __shfl((int)eo, src), sy = __shfl(label, src), sz = __shfl(state, src);
-                for (int j0 = 0; j0 < ns; j0 += 64) {
-                    const int nj = min(64, ns - j0);
-                    if (out.item_cnt + nj > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); break; }
-                    if (lane < nj) {
-                        const unsigned k = item_base + (unsigned)(out.item_cnt + lane);
-                        st16(V.items, icur + k * 32u, tv);
-                        st16(V.items, icur + k * 32u + 16u, (v4i){sx, sy, sz, 2 | ((j0 + lane + 1) << 2)});
-                    }
-                    out.item_cnt += nj; deferred += nj;
-                }
-            }
-        }
         // ---- pooled arc walk: exclusive prefix of the items' out-degrees
         const int deg = have ? ahi - alo : 0;
         int incl = deg;
@@ -1115,11 +1111,34 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             if (LZY) { const v4i r = ld16(V.larcs, (unsigned)b * 16u); return JdArc{r.x, __int_as_float(r.y), r.z, r.w}; }
             return C.arcs[b];
         };
-        // ... and so is its "has an instance" flag (a byte per arc: the arcs of a state share a sector)
+        // ... and so is its "has an instance" flag (a byte per arc: the arcs of a state share a sector).  These loads are
+        // UNCONDITIONAL (lanes without an arc read arc 0): a load inside a branch reaches the loop-carried registers
+        // through a copy at the join, and the compiler waits for it right there - the "pass ahead" was a pass behind.
         int lv_nx = 0;
-        if (lane < tot) { Bk_nx = arc_at(b_nx); lv_nx = CL(V.live + b_nx); }
-        if (arrive) eo = (unsigned)(eold >> 32);
+        { const int bq = lane < tot ? b_nx : 0; Bk_nx = arc_at(bq); lv_nx = CL(V.live + bq); }
+        // the arrival (see above), issued behind the first arcs' loads: the compiler waits for a returning atomic where it
+        // stands, so this way the two round trips are one
+        if (arrive) { eold = GMAX(&V.srec[state].e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
         list_dirty(arrive && eold == 0ULL, state);
+        if (__ballot(n_slices > 0)) {
+            for (unsigned long long bs = __ballot(n_slices > 0); bs; bs &= bs - 1) {
+                const int src = __ffsll((long long)bs) - 1;
+                const int ns = __shfl(n_slices, src);
+                const v4i tv = {__shfl(__float_as_int(t.score), src), __shfl(__float_as_int(t.ac), src), __shfl(__float_as_int(t.lm), src), __shfl(t.path, src)};
+                const int sx = __shfl((int)eo, src), sy = __shfl(label, src), sz = __shfl(state, src);
+                for (int j0 = 0; j0 < ns; j0 += 64) {
+                    const int nj = min(64, ns - j0);
+                    if (out.item_cnt + nj > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); break; }
+                    if (lane < nj) {
+                        const unsigned k = item_base + (unsigned)(out.item_cnt + lane);
+                        st16(V.items, icur + k * 32u, tv);
+                        st16(V.items, icur + k * 32u + 16u, (v4i){sx, sy, sz, 2 | ((j0 + lane + 1) << 2)});
+                    }
+                    out.item_cnt += nj; deferred += nj;
+                }
+            }
+        }
+
         XFINE(3);                                                      // prefix + hop 3: the first 64 arcs (+ the arrival's answer)
 #pragma nounroll
         for (int a0 = 0; a0 < tot; a0 += 64) {
@@ -1128,11 +1147,10 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const int g = g_nx, b = b_nx;
             const JdArc Bk = Bk_nx;
             const int lv = lv_nx;
-            if (a0 + 64 < tot) {                                       // next pass's arc records: in flight during this one
-                g_nx = owner_of(a + 64);
-                b_nx = __shfl(alo, g_nx) + (a + 64 - wpfx[g_nx]);
-                if (a + 64 < tot) { Bk_nx = arc_at(b_nx); lv_nx = CL(V.live + b_nx); }
-            }
+            // the next pass's arcs (LDS look-ups only; the loads are issued BEHIND this pass's own, see below)
+            g_nx = owner_of(a + 64);
+            const int alo_nx = __shfl(alo, g_nx);                      // (every lane takes part: its owner may be a lane that has no next arc itself)
+            b_nx = (a + 64 < tot) ? alo_nx + (a + 64 - wpfx[g_nx]) : 0;
             Tok tg;
             tg.score = __shfl(t.score, g); tg.ac = __shfl(t.ac, g);
             tg.lm = __shfl(t.lm, g); tg.path = __shfl(t.path, g);
@@ -1151,13 +1169,15 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const float ns = tg.score + Bk.w;                          // (:535 / :562: the same sum either way)
             const unsigned so = f2o(ns);
             unsigned long long skc = 0ULL;
-            float tmax = 0.0f;
-            if (entry && lv == 0 && can_filter) tmax = C.hmm_tmax0[inl - 1];
+            const float tmax = C.hmm_tmax0[entry ? inl - 1 : 0];       // (used for entry arcs without an instance; unconditional, see above)
             int2 nrow = make_int2(0, 0);
             {
                 const unsigned doff = ((on && inl == 0) || is_tee) ? (unsigned)Bk.to * (unsigned)sizeof(StateRec) : OOB_OFF;
                 const v4i se = ld16(V.srec_r, doff + 16u);
                 if (!LZY) { const int ti = doff != OOB_OFF ? Bk.to : 0; const int r0 = C.row_ptr[ti]; nrow = make_int2(r0, C.row_ptr[ti + 1] - r0); }
+                // the next pass's arc records and flags: in flight during this pass, and - issued behind the loads this
+                // pass waits for (loads return in order) - not waited for before the next one
+                Bk_nx = arc_at(b_nx); lv_nx = CL(V.live + b_nx);
                 skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
             }
             if (on) ++c_arcs;
