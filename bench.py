@@ -99,7 +99,7 @@ def leg_traffic(leg, launches):
 
 
 def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, gnet=None, pmc_leg=None, oracle_feats=None,
-            oracle_net=None):
+            oracle_net=None, ahead=True):
     """One extra workload: warm-up pass + timed passes on one GPU (value = the MEDIAN pass), its own roofline.
     gnet: a network that exists already (composed on the device); net is then only asked for its size.
     pmc_leg: the name the leg's PMC passes are filed under (leg_traffic).  oracle_utts: that many utterances are
@@ -118,14 +118,21 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
     hyps, runs = None, []
+    gmm_alone = None
     for i in range(passes):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        if ahead:                                                      # the next pass's table is scored beside this pass's search
+            dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
         hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
+        tm_i = dec.last_timing()
+        if not tm_i["prefetched"]:
+            gmm_alone = tm_i["gmm_ms"]                                 # (the warm-up pass scores its own table, on its own)
         if i > 0 or passes == 1:
-            runs.append((dt, dec.last_timing()))
+            runs.append((dt, tm_i))
+    dec.prefetch_scores(0, None)
     runs.sort(key=lambda r: r[0])
     best, tm = runs[(len(runs) - 1) // 2]                             # the median pass (the lower one of an even number)
     frames = int(offs[-1])
@@ -135,7 +142,8 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
            "value": round(frames / best, 1), "unit": "frames/s", "xRT": round(frames / best / 100.0, 2),
            "frames_per_step": frames, "ms_per_step": round(best * 1e3, 3),
            "timed_passes": len(runs), "ms_per_step_min": round(runs[0][0] * 1e3, 3), "ms_per_step_max": round(runs[-1][0] * 1e3, 3),
-           "search_ms": round(tm["search_ms"], 3), "gmm_ms": round(tm["gmm_ms"], 3),
+           "search_ms": round(tm["search_ms"], 3), "gmm_ms": round(gmm_alone if gmm_alone is not None else tm["gmm_ms"], 3),
+           "scored_ahead": bool(tm["prefetched"]),
            "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
                                                                               "tot_proc_end_hyps", "tot_arcs_visited")},
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
@@ -258,6 +266,8 @@ def main():
     ap.add_argument("--cpu-sample-utts", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true")
+    ap.add_argument("--no-score-ahead", action="store_true",
+                    help="score every batch's table right before its search (serial) instead of beside the previous batch's search")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -324,7 +334,14 @@ def main():
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
 
+    ahead = not args.no_score_ahead
+
     def step():
+        # One step = one pass over one batch: its search, and one scoring of a batch's likelihood table.  Batches follow
+        # each other, so the table of the NEXT batch (here: the same synthetic batch again) is scored on the CUs this
+        # batch's search leaves idle (jd_dec_prefetch_scores) - K timed steps hold K searches and K scorings either way.
+        if ahead:
+            dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
         hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
         allh = parallel.gather_hyps(hyps, per_rank, device=dev, index=shard) if world > 1 else hyps
         return hyps, allh
@@ -337,16 +354,26 @@ def main():
         step()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0}
+    acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0}
     tm = {}
     hyps = None
+    each = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         hyps, allh = step()
+        each.append(round((time.perf_counter() - ts) * 1e3, 3))
         tm = dec.last_timing()
         for k in acc:
             acc[k] += tm[k]
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
+    # (outside the timed region) the same step in the serial order: what the scoring kernel takes on its own
+    dec.prefetch_scores(0, None)
+    t1 = time.perf_counter()
+    dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
+    torch.cuda.synchronize()
+    serial_ms = (time.perf_counter() - t1) * 1e3
+    tm_serial = dec.last_timing()
     if world > 1:
         t = torch.tensor([elapsed, float(frames_local)], dtype=torch.float64, device=dev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -382,14 +409,23 @@ def main():
     # the companion kernel is VALU-bound: per (frame pair, mixture) 4 packed fp32 instructions per dimension
     # + ~116 for the two logAdd steps, 4 cycles each on 1024 SIMDs
     gmm_valu_ms = (frames_local / 128.0) * G * M * (4.0 * D + 116.0) * 4.0 / 1024.0 / 2.4e9 * 1e3
+    gmm_ms = tm_serial["gmm_ms"]                                   # the kernel on its own (the serial step behind the timed region)
+    n_ahead = acc["prefetched"]
     roofline["gmm"] = {"kernel": "jd_gmm_kernel39" if D == 39 else "jd_gmm_kernel", "bound": "valu",
-                       "ms_per_step": round(acc["gmm_ms"] / steps, 3),
+                       "ms_per_step": round(gmm_ms, 3),
                        "valu_bound_ms": round(gmm_valu_ms, 3),
-                       "frac": round(gmm_valu_ms / max(acc["gmm_ms"] / steps, 1e-9), 4),
-                       "valu_tflops": round(gmm_flops / max(acc["gmm_ms"] / steps, 1e-9) / 1e9, 3),
+                       "frac": round(gmm_valu_ms / max(gmm_ms, 1e-9), 4),
+                       "valu_tflops": round(gmm_flops / max(gmm_ms, 1e-9) / 1e9, 3),
                        "algorithmic_bytes_per_launch": round(gmm_bytes, 1),
                        "search_waited_ms_per_step": round(acc["gmm_wait_ms"] / steps, 3),
-                       "note": "scored before the search starts: serial step time (k_search holds the register file)"}
+                       "scored_ahead_steps": int(n_ahead),
+                       "span_beside_search_ms": round(acc["gmm_ms"] / steps, 3) if n_ahead else None,
+                       "serial_order_ms_per_step": round(serial_ms, 3),
+                       "serial_order_search_ms": round(tm_serial["search_ms"], 3),
+                       "note": ("the next batch's table is scored beside this batch's search, on the CUs its clusters leave "
+                                "(jd_dec_prefetch_scores): ms_per_step is the kernel on its own, measured in a serial-order step "
+                                "behind the timed region; search_waited is what a step still waited for its table")
+                               if n_ahead else "scored before the search starts: serial step time (k_search holds the register file)"}
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample
     cpu = None
@@ -426,6 +462,7 @@ def main():
     name = "configs[1]" if default_cfg else "configs[1]-shaped (non-default size / pruning)"
     out = {"metric": "frames/sec decoded", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
            "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "ms_each_step": each if steps <= 32 else None,
            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic", "xRT": round(fps / 100.0, 1),
            "config": {"workload": "%s: %d-arc composed C.L.G, %d tied states x %d mix, D=%d, "

@@ -361,6 +361,24 @@ int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
                            const int64_t *offs, void *hip_stream, jd_hyp *out);
 
 /*
+ * Scoring one batch ahead.  The reference scores and searches in turn (HTKFlatModels::calcOutput is
+ * called from the search, src/HTKFlatModels.cpp:190-262; its two-thread organisation overlaps them on
+ * two cores).  Here the batch path scores a whole batch's likelihood table and then searches it with a
+ * persistent kernel whose clusters leave their CUs as their utterances end; announcing the NEXT batch
+ * (same arguments as the jd_decode_batch_device call that will decode it; at most max_streams
+ * utterances) before decoding the current one lets the scoring kernel of that next batch run on the
+ * CUs the current search leaves idle, into a second table.  The announced decode then finds its table
+ * scored.  The device buffer of the announced batch must stay valid and unchanged until that decode
+ * (offs is copied); a decode with other arguments simply drops the table - results never depend on the
+ * announcement.  n_utts = 0 drops whatever was announced or scored ahead.  Calling this is optional.
+ * While the scoring runs the search launch is not re-planned under way when the scoring is a sizeable part
+ * of the step (measured on the decoder's last batches: from a tenth of the search on), so that its blocks find
+ * CUs; else it is slotted in at the re-planning cuts.
+ */
+int jd_dec_prefetch_scores(jd_dec *d, int32_t n_utts, const float *d_feats,
+                           const int64_t *offs, void *hip_stream);
+
+/*
  * The same loop sharded over the GPUs of ONE node from C++ (no Python, no torchrun): one decoder
  * and one host thread per device, utterances dealt by length (longest first, each to the device
  * with the fewest frames so far), no data-path collective, and ONE RCCL all-gather (over xGMI) of
@@ -399,6 +417,9 @@ typedef struct jd_timing {
     int64_t gmm_frames;       /* stream-frames scored                           */
     int64_t gmm_states;       /* tied states scored per frame                    */
     int64_t search_frames;    /* stream-frames decoded                          */
+    int32_t prefetched;       /* waves whose table had been scored ahead (jd_dec_prefetch_scores): their gmm_ms is the
+                                 span of that scoring beside the previous search, and gmm_wait_ms what was left of it */
+    int32_t reserved0;
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 

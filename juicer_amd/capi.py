@@ -47,7 +47,8 @@ class Timing(C.Structure):
                 ("gmm_wait_ms", C.c_double),
                 ("gmm_launches", C.c_int32), ("search_launches", C.c_int32),
                 ("relaunches", C.c_int32), ("cluster_wgs", C.c_int32),
-                ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64), ("search_frames", C.c_int64)]
+                ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64), ("search_frames", C.c_int64),
+                ("prefetched", C.c_int32), ("reserved0", C.c_int32)]
 
 
 @dataclass
@@ -77,6 +78,7 @@ EXPORTS = [
     "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
     "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
     "jd_net_lazy_set_high_water", "jd_net_lazy_generation", "jd_release_cached_memory", "jd_net_push_labels",
+    "jd_dec_prefetch_scores",
 ]
 
 _lib = None
@@ -439,6 +441,15 @@ class Decoder:
         if raw:
             return hyps
         return [_hyp_from_c(hyps[i]) for i in range(n)]
+
+    def prefetch_scores(self, d_feats_ptr: int, offs, hip_stream: int = 0):
+        """Announce the batch the NEXT decode_batch_device call will decode (same arguments): its likelihood table is
+        scored on the CUs the current batch's search leaves idle (jd_dec_prefetch_scores).  The device buffer and the
+        offsets must stay as they are until that call."""
+        offs = np.ascontiguousarray(offs if offs is not None else [0], dtype=np.int64)
+        n = offs.shape[0] - 1                                          # (one entry = no utterance: drops what was scored ahead)
+        _check(lib().jd_dec_prefetch_scores(self.h, C.c_int32(n), C.c_void_p(d_feats_ptr), _p(offs, C.c_int64),
+                                            C.c_void_p(hip_stream)))
 
     def last_timing(self) -> dict:
         t = Timing()

@@ -705,11 +705,14 @@ __global__ void jd_set_T_kernel(StreamCtl *ctl, int s0, int n, const int *T)
 }
 
 // before every k_search launch: the cluster barriers of the streams it advances start at zero
-__global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int *status)
+__global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int *status, int scoring_ahead)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { StreamCtl &c = ctl[work[i].x]; c.bar = 0u; c.xbar = 0u; c.xmask = 0u; c.stop_req = 0; }
-    if (i == 0) { status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0; }
+    if (i == 0) {
+        status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0;
+        if (scoring_ahead) status[4] = 1;      // (cleared on the scoring stream, behind the scoring kernel: pf_launch)
+    }
 }
 
 // --------------------------------------------------------------- host runtime
@@ -906,6 +909,28 @@ struct HostResult {
     std::vector<float> score, ac, lm;
 };
 
+// How one wave of utterances is laid out in likelihood tables (plan_wave): frames per chunk, the rows of every chunk
+// (stream after stream, packed) and the source frame of every row.
+struct WavePlan {
+    int nb = 0, Fc = 128, n_chunks = 1, maxT = 0;
+    std::vector<int> T;                        // frames per stream
+    std::vector<size_t> chunk_row0;            // first entry of chunk c in row_src
+    std::vector<int> row_off, chunk_rows;      // [chunk][stream]: first row of the stream in the chunk's table; rows per chunk (a multiple of the scoring tile)
+    std::vector<int> row_src;                  // row -> frame of d_feats (-1: unused)
+    size_t max_rows = 0, n_rows_all = 0;
+};
+// A batch announced with jd_dec_prefetch_scores: scored on the scoring stream WHILE the batch before it is searched
+// (the blocks of the scoring kernel take the CUs that clusters of the persistent search leave as their streams end).
+struct Prefetch {
+    int state = 0;                             // 0 none, 1 announced, 2 scoring enqueued (table d_ll[buf], event ev1)
+    const float *feats = nullptr; int nb = 0;
+    std::vector<int64_t> ustart, ulen;
+    WavePlan plan;
+    int buf = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void drop() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; state = 0; feats = nullptr; }
+};
+
 struct jd_dec {
     const jd_net *net = nullptr;
     const jd_am *am = nullptr;
@@ -948,9 +973,17 @@ struct jd_dec {
     int Fw_env = 0;                       // JD_FC: frames per chunk of the batch path (0 = as long as the longest utterance)
     float *d_ll[2] = {nullptr, nullptr};
     size_t ll_cap[2] = {0, 0};            // floats
-    int *d_row_src = nullptr; size_t row_src_cap = 0;
+    int *d_row_src[2] = {nullptr, nullptr}; size_t row_src_cap[2] = {0, 0};   // row -> source frame tables, one per likelihood table
     int *d_T = nullptr;
     hipStream_t s_gmm = nullptr, s_search = nullptr;
+    // scoring one batch ahead (jd_dec_prefetch_scores): the table of the NEXT batch is scored while this one is searched
+    int cur_buf = 0;                      // the likelihood table a single-chunk wave uses (the other one takes the prefetch)
+    Prefetch pf_next, pf_ready;           // announced (scored during the next decode) / scored or being scored (used by the next decode)
+    bool pf_armed = false;                // decode_wave: the coming launch_search may start the announced scoring
+    int pf_rebalance = -1;                // re-planning a launch beside which a table is scored: -1 by the measured ratio (launch_search),
+                                          // JD_PF_REBALANCE=0: never while the scoring runs, =1: like any other launch
+    double gmm_ms_per_row = 0.0, search_ms_per_frame = 0.0;   // measured on this decoder's last waves (scoring on its own / search)
+    int *h_resident = nullptr, *d_resident = nullptr; int launch_seq = 0;   // host-mapped word: k_search's last workgroup has started
     // streaming API state
     std::vector<int> stream_T;                 // frames pushed so far
     std::vector<int> stream_started;
@@ -1007,7 +1040,10 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     free_am_gmm(d->amb);
     for (int i = 0; i < 2; ++i)
         if (d->d_ll[i]) (void)hipFree(d->d_ll[i]);
-    if (d->d_row_src) (void)hipFree(d->d_row_src);
+    for (int i = 0; i < 2; ++i)
+        if (d->d_row_src[i]) (void)hipFree(d->d_row_src[i]);
+    d->pf_next.drop(); d->pf_ready.drop();
+    if (d->h_resident) (void)hipHostFree(d->h_resident);
     if (d->d_push) (void)hipFree(d->d_push);
     if (d->d_work) (void)hipFree(d->d_work);
     if (d->h_status) (void)hipHostFree(d->h_status);
@@ -1147,12 +1183,23 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_XL_SLACK")) { const double v = atof(e); if (v >= 1.0 && v <= 10.0) d->xl_slack = v; }
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
+    if (const char *e = getenv("JD_PF_REBALANCE")) d->pf_rebalance = atoi(e) != 0;                // development
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&d->s_gmm, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&d->s_search, hipStreamNonBlocking)) != hipSuccess) {
+    // the search stream has the highest priority, the scoring stream the lowest: when a table is scored while a search
+    // runs (jd_dec_prefetch_scores) a search launch that needs CUs gets them before further scoring blocks do
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if ((e = hipStreamCreateWithPriority(&d->s_gmm, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&d->s_search, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
         jd_dec_destroy(d);
         return jd_fail(JD_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
+    if ((e = hipHostMalloc((void **)&d->h_resident, 64, hipHostMallocMapped)) != hipSuccess ||
+        (e = hipHostGetDevicePointer((void **)&d->d_resident, d->h_resident, 0)) != hipSuccess) {
+        jd_dec_destroy(d);
+        return jd_fail(JD_EHIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    *d->h_resident = 0;
     d->stream_T.assign((size_t)max_streams, 0);
     d->stream_started.assign((size_t)max_streams, 0);
     d->lazy_in.assign((size_t)max_streams, 0);
@@ -1319,7 +1366,9 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
     if (rc) return rc;
     rc = dmalloc(d, &d->d_ctl, (size_t)B);
     if (rc) return rc;
-    rc = dmalloc(d, &d->d_status, 4);
+    rc = dmalloc(d, &d->d_status, 8);
+    if (rc) return rc;
+    HIPCHK(hipMemset(d->d_status, 0, 8 * sizeof(int)));
     if (rc) return rc;
     HIPCHK(hipHostMalloc((void **)&d->h_status, 4 * sizeof(int)));
     {
@@ -1495,6 +1544,7 @@ static int learn_load(jd_dec *d, const std::vector<int2> &work_in)
 // per CU in total, all resident at once (the clusters synchronise with barriers of their own).  A
 // launch stops a stream early when its Path arena needs collecting; the collection (k_gc_*) runs
 // after such a launch and the launch is repeated until every stream is through.
+static int pf_launch(jd_dec *d);
 static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const float *ll, long long ll_stride, int f0, int f_end,
                          hipStream_t st, const std::vector<double> *weight_first = nullptr)
 {
@@ -1630,11 +1680,13 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             for (int k = 0; k < n_work; ++k) tau = std::max(tau, std::max((*weight)[(size_t)k], 1.0) * (a_us + b_us / std::max(work[(size_t)k].w, 1)));
             if (tau > d->rebalance_min_us) rebalance_at = std::max(1, (int)(d->rebalance_frac * grid));
         }
+
     } else if (d->xl_ok && A.Cw > 1 && (grid & 7) == 0 && ((grid >> 3) % A.Cw) == 0) xl = true;   // uniform clusters that tile the eighths
     HIPCHK(hipMemcpyAsync(d->d_work, work.data(), (size_t)n_work * sizeof(int4), hipMemcpyHostToDevice, st));
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
     A.status = d->d_status; A.dbg = d->d_dbg; A.rebalance_at = rebalance_at;
     A.xl_selftest = getenv("JD_XL_SELFTEST") ? 1 : 0;                 // (test knob, see SearchArgs)
+    A.resident = d->d_resident; A.launch_seq = ++d->launch_seq;
         struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev0, ev1;
         HIPCHK(hipEventCreate(&ev0.e)); HIPCHK(hipEventCreate(&ev1.e));
         const hipEvent_t e0 = ev0.e, e1 = ev1.e;
@@ -1664,7 +1716,23 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             d->occupancy_ok = true;
         }
         std::lock_guard<std::mutex> search_lock(g_search_mu[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)]);
-        hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status);
+        // (a launch beside which the next batch's table is scored is not cut short for a re-plan while that scoring runs -
+        // status[4]: its blocks sit on the CUs that finished clusters left, and a relaunch would wait for them to drain)
+        // Whether that pays depends on what the scoring is against the search: where it is a fifth of it (configs[1]) the
+        // whole scoring fits the tail the clusters leave and the step is the one uncut launch (47.3 -> 40.9 ms; re-planned
+        // at will: 46.3); where it is a few per cent (the 14 M-arc graph: 13 of 340 ms) the tail begins late, the scoring
+        // would hold the re-planning up for the whole launch (348 against 343 ms serial) and is better slotted in at the
+        // cuts (340).  Decided by the measured costs of this decoder's last waves.
+        bool hold_replan = false;
+        if (d->pf_armed && d->pf_next.state == 1) {
+            double frames_now = 0.0;
+            if (weight) for (double w : *weight) frames_now += w;
+            const double est_gmm = d->gmm_ms_per_row * (double)d->pf_next.plan.chunk_rows[0];
+            const double est_search = d->search_ms_per_frame * frames_now;
+            hold_replan = d->pf_rebalance == 0 || (d->pf_rebalance < 0 && est_gmm > 0.0 && est_search > 0.0 && est_gmm >= 0.1 * est_search);
+        }
+        hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status,
+                           hold_replan ? 1 : 0);
         HIPCHK(hipEventRecord(e0, st));
         if (d->C.lazy) {   // (the graph's own words are agent scope in either flavour: jd_lazy.h)
             if (ne3) { if (xl) hipLaunchKernelGGL((k_search<3, true, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<3, false, true>), dim3(grid), dim3(SNT), 0, st, A); }
@@ -1674,6 +1742,16 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         else { if (xl) hipLaunchKernelGGL((k_search<6, true, false>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, false>), dim3(grid), dim3(SNT), 0, st, A); }
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipGetLastError());
+        if (d->pf_armed && d->pf_next.state == 1) {
+            // the next batch's table is scored beside this launch (jd_dec_prefetch_scores): its kernel is enqueued once
+            // the search is resident - the last workgroup of the grid says so in a host-mapped word - so that scoring
+            // blocks never sit on a CU a search workgroup is waiting for (2 ms: it goes ahead anyway)
+            const auto tr0 = std::chrono::steady_clock::now();
+            while (__atomic_load_n(d->h_resident, __ATOMIC_ACQUIRE) != A.launch_seq &&
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count() < 2.0) { }
+            const int pr = pf_launch(d);
+            if (pr) return pr;
+        }
         HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         float ms = 0.0f;
@@ -1730,29 +1808,28 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     return JD_OK;
 }
 
-// Decode one wave of nb <= max_streams utterances held in device memory.
-// Stream u decodes frames [ustart[u], ustart[u] + ulen[u]) of d_feats.
-static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *ustart, const int64_t *ulen,
-                       hipStream_t user_stream)
+// Lay a wave of nb <= max_streams utterances out in likelihood tables.
+// Frames per chunk.  A search launch lasts as long as its slowest stream and streams do not wait
+// for each other inside a launch, so the fewer launches the better: one chunk covers the longest
+// utterance when the likelihood table (frames of the batch x tied states floats, 288 GB of HBM to
+// draw on) fits a quarter of the free memory; otherwise the batch is decoded in several chunks,
+// scored alternately into two tables.  A chunk's table holds the frames the streams really have
+// in it, packed stream after stream (only the last 128-row scoring tile of a chunk is partly empty).
+static int plan_wave(jd_dec *d, int nb, const int64_t *ustart, const int64_t *ulen, WavePlan &P)
 {
     const int G = d->am->n_gmm;
-    std::vector<int> T((size_t)nb);
-    int maxT = 0;
+    P = WavePlan();
+    P.nb = nb;
+    P.T.assign((size_t)nb, 0);
+    long long sumT = 0;
     for (int u = 0; u < nb; ++u) {
         const int64_t t = ulen[u];
         if (t < 0 || t > 0x3fffffff) return jd_fail(JD_EINVAL, "utterance %d: bad frame count", u);
-        T[(size_t)u] = (int)t;
-        maxT = std::max(maxT, (int)t);
+        P.T[(size_t)u] = (int)t;
+        P.maxT = std::max(P.maxT, (int)t);
+        sumT += t;
     }
-    // Frames per chunk.  A search launch lasts as long as its slowest stream and streams do not wait
-    // for each other inside a launch, so the fewer launches the better: one chunk covers the longest
-    // utterance when the likelihood table (frames of the batch x tied states floats, 288 GB of HBM to
-    // draw on) fits a quarter of the free memory; otherwise the batch is decoded in several chunks,
-    // scored alternately into two tables.  A chunk's table holds the frames the streams really have
-    // in it, packed stream after stream (only the last 128-row scoring tile of a chunk is partly empty).
-    long long sumT = 0;
-    for (int u = 0; u < nb; ++u) sumT += T[(size_t)u];
-    int Fc = std::max(128, (maxT + 127) / 128 * 128);
+    int Fc = std::max(128, (P.maxT + 127) / 128 * 128);
     {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -1762,54 +1839,138 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
             Fc = std::max(128, (int)(0.5 * have / per_frame) / 128 * 128);
         if (d->Fw_env > 0) Fc = d->Fw_env;
     }
-    const int n_chunks = std::max(1, (maxT + Fc - 1) / Fc);            // chunk 0 also carries recognitionStart
+    P.Fc = Fc;
+    const int n_chunks = P.n_chunks = std::max(1, (P.maxT + Fc - 1) / Fc);   // chunk 0 also carries recognitionStart
     // rows of a chunk: stream u's frames [c0, min(T_u, c1)) start at row_off[c][u]
-    std::vector<size_t> chunk_row0((size_t)n_chunks + 1, 0);            // first entry of chunk c in the row table
-    std::vector<int> row_off((size_t)n_chunks * nb, 0), chunk_rows((size_t)n_chunks, 0);
-    size_t max_rows = 0;
+    P.chunk_row0.assign((size_t)n_chunks + 1, 0);
+    P.row_off.assign((size_t)n_chunks * nb, 0); P.chunk_rows.assign((size_t)n_chunks, 0);
     for (int c = 0; c < n_chunks; ++c) {
         long long r = 0;
         for (int u = 0; u < nb; ++u) {
-            row_off[(size_t)c * nb + u] = (int)r;
-            r += std::max(0, std::min(T[(size_t)u], (c + 1) * Fc) - c * Fc);
+            P.row_off[(size_t)c * nb + u] = (int)r;
+            r += std::max(0, std::min(P.T[(size_t)u], (c + 1) * Fc) - c * Fc);
         }
         if (r > 0x7fffff00LL) return jd_fail(JD_EINVAL, "more than 2^31 frames in one chunk");
-        chunk_rows[(size_t)c] = (int)((r + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2);
-        chunk_row0[(size_t)c + 1] = chunk_row0[(size_t)c] + (size_t)chunk_rows[(size_t)c];
-        max_rows = std::max(max_rows, (size_t)chunk_rows[(size_t)c]);
+        P.chunk_rows[(size_t)c] = (int)((r + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2);
+        P.chunk_row0[(size_t)c + 1] = P.chunk_row0[(size_t)c] + (size_t)P.chunk_rows[(size_t)c];
+        P.max_rows = std::max(P.max_rows, (size_t)P.chunk_rows[(size_t)c]);
     }
-    max_rows = std::max<size_t>(max_rows, GMM_ROWS2);
-    for (int i = 0; i < std::min(2, n_chunks); ++i)
-        if (max_rows * G > d->ll_cap[i]) {
-            if (d->d_ll[i]) (void)hipFree(d->d_ll[i]);
-            d->d_ll[i] = nullptr; d->ll_cap[i] = 0;
-            HIPCHK(hipMalloc(&d->d_ll[i], max_rows * G * sizeof(float)));
-            d->ll_cap[i] = max_rows * G;
-        }
+    P.max_rows = std::max<size_t>(P.max_rows, GMM_ROWS2);
     // row -> source frame table for all chunks
-    const size_t n_rows_all = std::max<size_t>(chunk_row0[(size_t)n_chunks], 1);
-    if (n_rows_all > d->row_src_cap) {
-        if (d->d_row_src) (void)hipFree(d->d_row_src);
-        HIPCHK(hipMalloc(&d->d_row_src, n_rows_all * sizeof(int)));
-        d->row_src_cap = n_rows_all;
-    }
-    std::vector<int> row_src(n_rows_all, -1);
+    P.n_rows_all = std::max<size_t>(P.chunk_row0[(size_t)n_chunks], 1);
+    P.row_src.assign(P.n_rows_all, -1);
     for (int c = 0; c < n_chunks; ++c)
         for (int u = 0; u < nb; ++u) {
-            const int n = std::max(0, std::min(T[(size_t)u], (c + 1) * Fc) - c * Fc);
-            int *dst = row_src.data() + chunk_row0[(size_t)c] + (size_t)row_off[(size_t)c * nb + u];
+            const int n = std::max(0, std::min(P.T[(size_t)u], (c + 1) * Fc) - c * Fc);
+            int *dst = P.row_src.data() + P.chunk_row0[(size_t)c] + (size_t)P.row_off[(size_t)c * nb + u];
             for (int dt = 0; dt < n; ++dt) {
                 const int64_t src = ustart[u] + (int64_t)c * Fc + dt;
                 if (src > 0x7fffffff) return jd_fail(JD_EINVAL, "more than 2^31 frames in one batch");
                 dst[dt] = (int)src;
             }
         }
+    return JD_OK;
+}
+
+// table i holds `floats`, its row table `rows` entries (grown, never shrunk)
+static int ensure_table(jd_dec *d, int i, size_t floats, size_t rows)
+{
+    if (floats > d->ll_cap[i]) {
+        if (d->d_ll[i]) (void)hipFree(d->d_ll[i]);
+        d->d_ll[i] = nullptr; d->ll_cap[i] = 0;
+        HIPCHK(hipMalloc(&d->d_ll[i], floats * sizeof(float)));
+        d->ll_cap[i] = floats;
+    }
+    if (rows > d->row_src_cap[i]) {
+        if (d->d_row_src[i]) (void)hipFree(d->d_row_src[i]);
+        d->d_row_src[i] = nullptr; d->row_src_cap[i] = 0;
+        HIPCHK(hipMalloc(&d->d_row_src[i], rows * sizeof(int)));
+        d->row_src_cap[i] = rows;
+    }
+    return JD_OK;
+}
+
+// Forget what was scored or announced ahead (the scoring stream is drained first: a table being written is not re-used)
+static void pf_discard(jd_dec *d)
+{
+    if (d->pf_ready.state == 2 || d->pf_next.state == 2) (void)hipStreamSynchronize(d->s_gmm);
+    d->pf_ready.drop(); d->pf_next.drop();
+}
+
+// Start the announced scoring (pf_next) into the table the running wave does not use.  Called by launch_search right
+// behind the dispatch of a persistent search launch, once that launch is resident: the scoring kernel's blocks then
+// only ever get the CUs that clusters of the search have left.
+static int pf_launch(jd_dec *d)
+{
+    Prefetch &F = d->pf_next;
+    if (F.state != 1) return JD_OK;
+    const int buf = d->cur_buf ^ 1;
+    const int G = d->am->n_gmm;
+    int rc = ensure_table(d, buf, F.plan.max_rows * G, F.plan.n_rows_all);
+    if (rc) return rc;
+    HIPCHK(hipEventCreate(&F.ev0)); HIPCHK(hipEventCreate(&F.ev1));
+    HIPCHK(hipMemcpyAsync(d->d_row_src[buf], F.plan.row_src.data(), F.plan.n_rows_all * sizeof(int), hipMemcpyHostToDevice, d->s_gmm));
+    HIPCHK(hipEventRecord(F.ev0, d->s_gmm));
+    rc = launch_gmm(d->am, d->amb, F.feats, d->d_row_src[buf], F.plan.chunk_rows[0], d->d_ll[buf], d->s_gmm, 0, true);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(F.ev1, d->s_gmm));
+    HIPCHK(hipMemsetAsync(d->d_status + 4, 0, sizeof(int), d->s_gmm)); // the search may be re-planned again
+    F.buf = buf; F.state = 2;
+    return JD_OK;
+}
+
+// Announce a wave (pf_next): it is scored beside the next search launch of a wave that leaves a table free.  A wave
+// whose table would be cut into chunks is not announced (it is scored when it is decoded, as ever).
+static int pf_announce(jd_dec *d, int nb, const float *d_feats, const int64_t *ustart, const int64_t *ulen)
+{
+    if (d->pf_next.state == 2) (void)hipStreamSynchronize(d->s_gmm);
+    d->pf_next.drop();
+    if (nb <= 0 || nb > d->max_streams) return JD_OK;
+    Prefetch &F = d->pf_next;
+    F.ustart.assign(ustart, ustart + nb);
+    F.ulen.assign(ulen, ulen + nb);
+    const int rc = plan_wave(d, nb, F.ustart.data(), F.ulen.data(), F.plan);
+    if (rc) { F.drop(); return rc; }
+    if (F.plan.n_chunks != 1) { F.drop(); return JD_OK; }
+    F.feats = d_feats; F.nb = nb; F.state = 1;
+    return JD_OK;
+}
+
+// Decode one wave of nb <= max_streams utterances held in device memory.
+// Stream u decodes frames [ustart[u], ustart[u] + ulen[u]) of d_feats.
+static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *ustart, const int64_t *ulen,
+                       hipStream_t user_stream)
+{
+    const int G = d->am->n_gmm;
+    const double gmm_before = d->timing.gmm_ms, search_before = d->timing.search_ms;
+    // a table scored ahead for exactly this wave (jd_dec_prefetch_scores)?
+    bool prefetched = false;
+    {
+        Prefetch &R = d->pf_ready;
+        if (R.state == 2) {
+            prefetched = R.feats == d_feats && R.nb == nb && std::equal(ustart, ustart + nb, R.ustart.begin()) &&
+                         std::equal(ulen, ulen + nb, R.ulen.begin());
+            if (!prefetched) { (void)hipStreamSynchronize(d->s_gmm); R.drop(); }
+        }
+    }
+    WavePlan plan_local;
+    int rc = JD_OK;
+    if (!prefetched) { rc = plan_wave(d, nb, ustart, ulen, plan_local); if (rc) return rc; }
+    const WavePlan &P = prefetched ? d->pf_ready.plan : plan_local;
+    const std::vector<int> &T = P.T;
+    const int Fc = P.Fc, n_chunks = P.n_chunks, maxT = P.maxT;
+    if (prefetched) d->cur_buf = d->pf_ready.buf;                      // (single-chunk by construction)
+    const int b0 = (n_chunks == 1) ? d->cur_buf : 0;                   // table of chunk c: b0 ^ (c & 1)
+    if (n_chunks > 1 && d->pf_next.state == 1) d->pf_next.drop();      // (both tables are in use)
+    if (!prefetched)
+        for (int i = 0; i < std::min(2, n_chunks); ++i) { rc = ensure_table(d, b0 ^ i, P.max_rows * G, i == 0 ? P.n_rows_all : 0); if (rc) return rc; }
     // the caller's features may have been produced asynchronously on its stream (NULL = the
     // default stream): the decoder's own streams are non-blocking, so order against it explicitly
     HIPCHK(hipStreamSynchronize(user_stream));
-    HIPCHK(hipMemcpyAsync(d->d_row_src, row_src.data(), n_rows_all * sizeof(int), hipMemcpyHostToDevice, d->s_gmm));
+    if (!prefetched)
+        HIPCHK(hipMemcpyAsync(d->d_row_src[b0], P.row_src.data(), P.n_rows_all * sizeof(int), hipMemcpyHostToDevice, d->s_gmm));
     HIPCHK(hipMemcpyAsync(d->d_T, T.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, d->s_search));
-    int rc = mark_init(d, 0, nb, d->s_search);
+    rc = mark_init(d, 0, nb, d->s_search);
     if (rc) return rc;
     hipLaunchKernelGGL(jd_set_T_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, 0, nb, d->d_T);
     HIPCHK(hipGetLastError());
@@ -1820,7 +1981,11 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     } ev_gs, ev_ge;
     ev_gs.v.assign((size_t)n_chunks, nullptr); ev_ge.v.assign((size_t)n_chunks, nullptr);
     std::vector<hipEvent_t> &gs = ev_gs.v, &ge = ev_ge.v;
-    for (int c = 0; c < n_chunks; ++c) { HIPCHK(hipEventCreate(&gs[(size_t)c])); HIPCHK(hipEventCreate(&ge[(size_t)c])); }
+    if (prefetched) {                                                  // the scoring's own events (Events destroys them)
+        gs[0] = d->pf_ready.ev0; ge[0] = d->pf_ready.ev1;
+        d->pf_ready.ev0 = d->pf_ready.ev1 = nullptr;
+    } else
+        for (int c = 0; c < n_chunks; ++c) { HIPCHK(hipEventCreate(&gs[(size_t)c])); HIPCHK(hipEventCreate(&ge[(size_t)c])); }
     auto w0 = std::chrono::steady_clock::now();
     // Scoring runs one chunk ahead of the search on its own stream.  launch_search returns when its
     // chunk is through (it synchronises to learn whether a stream stopped for garbage collection),
@@ -1829,15 +1994,14 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         HIPCHK(hipEventRecord(gs[(size_t)c], d->s_gmm));
         // (a later chunk is launched while the previous one is searched: k_search holds every CU's
         // registers, so its workgroups start as the search's clusters finish - they fill the tail)
-        if (chunk_rows[(size_t)c] == 0) { HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm)); return JD_OK; }
-        int r = launch_gmm(d->am, d->amb, d_feats, d->d_row_src + chunk_row0[(size_t)c], chunk_rows[(size_t)c], d->d_ll[c & 1], d->s_gmm,
+        if (P.chunk_rows[(size_t)c] == 0) { HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm)); return JD_OK; }
+        int r = launch_gmm(d->am, d->amb, d_feats, d->d_row_src[b0] + P.chunk_row0[(size_t)c], P.chunk_rows[(size_t)c], d->d_ll[b0 ^ (c & 1)], d->s_gmm,
                            0, true);
         if (r) return r;
         HIPCHK(hipEventRecord(ge[(size_t)c], d->s_gmm));
         return JD_OK;
     };
-    rc = score_chunk(0);
-    if (rc) return rc;
+    if (!prefetched) { rc = score_chunk(0); if (rc) return rc; }
     double waited_ms = 0.0;
     std::vector<int2> work;
     std::vector<double> weight;
@@ -1851,16 +2015,17 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         work.clear(); weight.clear();
         for (int u = 0; u < nb; ++u)
             if (c == 0 || T[(size_t)u] > c0) {
-                work.push_back(make_int2(u, row_off[(size_t)c * nb + u]));   // {stream, its first row in the chunk's table}
+                work.push_back(make_int2(u, P.row_off[(size_t)c * nb + u]));   // {stream, its first row in the chunk's table}
                 weight.push_back((double)(std::min(T[(size_t)u], c1) - c0));
             }
+        const float *ll = d->d_ll[b0 ^ (c & 1)];
         if (d->load_scale == 1.0 && d->weighted && c == 0 && nb > 1 && std::min(maxT, c1) - c0 > 128) {
             // the decoder's very first batch: nothing is known about the load yet, and the cluster sizes depend
             // on it (a frame of 2 M instances is not a frame of 12 k) - a short launch finds out
             const int c_mid = c0 + 32;
             std::vector<double> wp(weight.size());
             for (size_t i = 0; i < wp.size(); ++i) wp[i] = std::min(weight[i], 32.0);
-            rc = launch_search(d, work, d->d_ll[c & 1], (long long)G, c0, c_mid, d->s_search, &wp);
+            rc = launch_search(d, work, ll, (long long)G, c0, c_mid, d->s_search, &wp);
             if (rc) return rc;
             if (d->load_scale == 1.0) { rc = learn_load(d, work); if (rc) return rc; }
             std::vector<int2> w2; std::vector<double> wt2;
@@ -1868,12 +2033,14 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
                 if (T[(size_t)work[i].x] > c_mid) { w2.push_back(work[i]); wt2.push_back((double)(std::min(T[(size_t)work[i].x], c1) - c_mid)); }
             work.swap(w2); weight.swap(wt2);
         }
-        rc = launch_search(d, work, d->d_ll[c & 1], (long long)G, c0, c1, d->s_search, &weight);
+        d->pf_armed = n_chunks == 1 && d->pf_next.state == 1;          // the next batch's table is scored beside this launch
+        rc = launch_search(d, work, ll, (long long)G, c0, c1, d->s_search, &weight);
+        d->pf_armed = false;
         if (rc) return rc;
     }
     hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, 0, nb);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(d->s_gmm));
+    if (d->pf_next.state != 2) HIPCHK(hipStreamSynchronize(d->s_gmm)); // (a table being scored ahead is waited for by the wave that uses it)
     HIPCHK(hipStreamSynchronize(d->s_search));
     auto w1 = std::chrono::steady_clock::now();
     d->timing.total_ms += std::chrono::duration<double, std::milli>(w1 - w0).count();
@@ -1883,9 +2050,20 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     }
     d->timing.gmm_wait_ms += waited_ms;
     d->timing.gmm_launches += n_chunks;
+    d->timing.prefetched += prefetched ? 1 : 0;
+    {   // what scoring (on its own) and search cost on this decoder: launch_search's choice when a table is scored ahead
+        long long fr = 0, rows = 0;
+        for (int u = 0; u < nb; ++u) fr += T[(size_t)u];
+        for (int c = 0; c < n_chunks; ++c) rows += P.chunk_rows[(size_t)c];
+        if (!prefetched && rows > 0 && d->timing.gmm_ms > gmm_before) d->gmm_ms_per_row = (d->timing.gmm_ms - gmm_before) / (double)rows;
+        if (fr > 0 && d->timing.search_ms > search_before) d->search_ms_per_frame = (d->timing.search_ms - search_before) / (double)fr;
+    }
     for (int u = 0; u < nb; ++u) d->timing.search_frames += T[(size_t)u];
     d->timing.gmm_frames = d->timing.search_frames;
     d->timing.gmm_states = G;
+    // the table scored during this wave belongs to the next one
+    if (prefetched) d->pf_ready.drop();
+    if (d->pf_next.state == 2) { d->pf_ready.drop(); d->pf_ready = std::move(d->pf_next); d->pf_next = Prefetch(); }
     return JD_OK;
 }
 
@@ -1908,11 +2086,31 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
     if (n_utts > d->max_streams)
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offs[a + 1] - offs[a] > offs[b + 1] - offs[b]; });
     std::vector<int64_t> ustart((size_t)d->max_streams), ulen((size_t)d->max_streams);
+    std::vector<int64_t> nstart((size_t)d->max_streams), nlen((size_t)d->max_streams);
+    // Scoring ahead inside the batch: every wave but the last announces the wave behind it, whose table is then scored
+    // beside this wave's search (pf_launch); what the caller announced (the NEXT batch) rides on the last wave.
+    Prefetch callers = std::move(d->pf_next);
+    d->pf_next = Prefetch();
+    if (callers.state != 1) callers.drop();
+    struct Restore { Prefetch &p; ~Restore() { p.drop(); } } callers_guard{callers};
     for (int u0 = 0; u0 < n_utts; u0 += d->max_streams) {
         const int nb = std::min(d->max_streams, n_utts - u0);
         for (int i = 0; i < nb; ++i) {
             const int u = order[(size_t)(u0 + i)];
             ustart[(size_t)i] = offs[u]; ulen[(size_t)i] = offs[u + 1] - offs[u];
+        }
+        if (u0 + nb < n_utts) {
+            const int nn = std::min(d->max_streams, n_utts - (u0 + nb));
+            for (int i = 0; i < nn; ++i) {
+                const int u = order[(size_t)(u0 + nb + i)];
+                nstart[(size_t)i] = offs[u]; nlen[(size_t)i] = offs[u + 1] - offs[u];
+            }
+            rc = pf_announce(d, nn, d_feats, nstart.data(), nlen.data());
+            if (rc) return rc;
+        } else if (callers.state == 1) {
+            if (d->pf_next.state == 2) (void)hipStreamSynchronize(d->s_gmm);
+            d->pf_next.drop();
+            d->pf_next = std::move(callers); callers = Prefetch();
         }
         for (int attempt = 0;; ++attempt) {
             // (lazily composed networks: the wave's utterances enter the network - which starts a new arena generation
@@ -1946,6 +2144,21 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }   // (the batch took the stream over)
     }
     return first_err;
+}
+
+extern "C" int jd_dec_prefetch_scores(jd_dec *d, int32_t n_utts, const float *d_feats, const int64_t *offs, void *hip_stream)
+{
+    if (!d || n_utts < 0 || (n_utts > 0 && (!d_feats || !offs))) return jd_fail(JD_EINVAL, "jd_dec_prefetch_scores: bad argument");
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    if (n_utts == 0) { pf_discard(d); return JD_OK; }                  // nothing: what was scored or announced ahead is dropped
+    // what cannot be scored ahead is scored when it is decoded, as ever: more utterances than streams (several waves,
+    // formed by length: jd_decode_batch_device scores each of them beside the wave before it), a table cut into chunks
+    if (n_utts > d->max_streams) { if (d->pf_next.state == 2) (void)hipStreamSynchronize(d->s_gmm); d->pf_next.drop(); return JD_OK; }
+    HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));             // the features are there
+    std::vector<int64_t> ulen((size_t)n_utts);
+    for (int u = 0; u < n_utts; ++u) ulen[(size_t)u] = offs[u + 1] - offs[u];
+    return pf_announce(d, n_utts, d_feats, offs, ulen.data());
 }
 
 extern "C" int jd_decode_batch(jd_dec *d, int32_t n_utts, const float *const *feats, const int32_t *n_frames,
@@ -2031,6 +2244,7 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
     if (rc) return rc;
     const int D = d->am->D, G = d->am->n_gmm, Fc = d->Fc;
     hipStream_t st = d->s_search;
+    pf_discard(d);                                                     // (the streaming path scores into table 0)
     for (int done = 0, n = 0; done < n_frames; done += n) {
         n = std::min(Fc, n_frames - done);
         // PARTIAL_DECODING rides on the path collection (:362-368): a chunk ends at the frame rule's frame
@@ -2046,17 +2260,18 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
                               hipMemcpyHostToDevice, st));
         std::vector<int> src((size_t)Fc, -1);
         for (int i = 0; i < n; ++i) src[(size_t)i] = i;
-        if ((size_t)Fc > d->row_src_cap) {
-            if (d->d_row_src) (void)hipFree(d->d_row_src);
-            HIPCHK(hipMalloc(&d->d_row_src, (size_t)Fc * sizeof(int)));
-            d->row_src_cap = (size_t)Fc;
+        if ((size_t)Fc > d->row_src_cap[0]) {
+            if (d->d_row_src[0]) (void)hipFree(d->d_row_src[0]);
+            d->d_row_src[0] = nullptr; d->row_src_cap[0] = 0;
+            HIPCHK(hipMalloc(&d->d_row_src[0], (size_t)Fc * sizeof(int)));
+            d->row_src_cap[0] = (size_t)Fc;
         }
-        HIPCHK(hipMemcpyAsync(d->d_row_src, src.data(), (size_t)Fc * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d->d_row_src[0], src.data(), (size_t)Fc * sizeof(int), hipMemcpyHostToDevice, st));
         const int f0 = d->stream_T[(size_t)s];
         const int Tnew = f0 + n;
         HIPCHK(hipMemcpyAsync(d->d_T + s, &Tnew, sizeof(int), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(jd_set_T_kernel, dim3(1), dim3(64), 0, st, d->d_ctl, s, 1, d->d_T + s);
-        rc = launch_gmm(d->am, d->amb, d->d_push, d->d_row_src, n, d->d_ll[0], st);
+        rc = launch_gmm(d->am, d->amb, d->d_push, d->d_row_src[0], n, d->d_ll[0], st);
         if (rc) return rc;
         if (d->partial_interval <= 0) {
             rc = launch_search(d, std::vector<int2>(1, make_int2(s, 0)), d->d_ll[0], (long long)Fc * G, f0, Tnew, st);

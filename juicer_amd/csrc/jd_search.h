@@ -179,8 +179,11 @@ struct SearchArgs {
                              // through, or stopped), every cluster stops after its frame and the host plans the rest anew (0: never)
     int *status;             // [0] += 1 for every stream that stopped early (Path garbage collection, or a re-plan);
                              // [1] += 1 for every cluster of an XCD-local launch that found itself on several XCDs;
-                             // [2] += the workgroups of every cluster that has left its stream; [3] += 1 per stream stopped for a re-plan
+                             // [2] += the workgroups of every cluster that has left its stream; [3] += 1 per stream stopped for a re-plan;
+                             // [4] != 0: the next batch's table is being scored on the CUs finished clusters left - no re-plan meanwhile
     long long *dbg;          // optional: per-workgroup cycle accounting (jd_dec_debug_trace)
+    int *resident; int launch_seq;   // host-mapped word: the LAST workgroup of the grid writes launch_seq into it when it starts
+                             // (workgroups are dispatched in order: the launch is then resident; jd_dec_prefetch_scores)
 };
 
 // ------------------------------------------------------------------ device helpers
@@ -1500,7 +1503,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                         CS(&c.bestA[p ^ 1], 0u); CS(&c.bestX[p ^ 1], 0u); CS(&c.new_all[p ^ 1], 0);
                         // enough of the grid idles: this cluster stops after this frame (every workgroup of it reads the
                         // request behind this round's barrier, i.e. in the same frame)
-                        if (A.rebalance_at > 0 && CL(A.status + 2) >= A.rebalance_at) CS(&c.stop_req, 1);
+                        if (A.rebalance_at > 0 && CL(A.status + 2) >= A.rebalance_at && CL(A.status + 4) == 0) CS(&c.stop_req, 1);
                     }
                     if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) CS(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b, 0);
                 }
@@ -1635,6 +1638,8 @@ __global__ JD_KBOUNDS void k_search(SearchArgs A)
 {
     __shared__ SearchShared sh;
     int k, kstep, jw, Cw;
+    if (A.resident && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(A.resident, A.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // XCD-local launch: workgroup b is expected on XCD b % 8 (observed dispatch order - run_stream checks),
     // so the workgroups are numbered XCD by XCD and the host keeps every cluster inside one eighth of the grid
     const unsigned wg = (XL && !A.xl_selftest) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;

@@ -1000,3 +1000,85 @@ def test_exact_signature_constructor_decodes(small, tmp_path):
         o = od.decode(feats[u])
         assert o.n > 0 and lab.tolist() == o.label.tolist() and tim.tolist() == o.time.tolist()
         assert rel_close(sc, o.score) and rel_close(tot, [o.tot_score, o.tot_ac, o.tot_lm])
+
+
+@pytest.mark.parametrize("hold", ["auto", "0", "1"])
+def test_scores_ahead_of_the_search(small, hold):
+    """jd_dec_prefetch_scores: the NEXT batch's likelihood table is scored beside the current batch's search (on the
+    CUs its clusters leave), into the decoder's second table.  Results never depend on it: batches decoded from a
+    table scored ahead equal the oracle bit for bit, a decode that was not the announced one drops the table, and so
+    does an empty announcement; with re-planning forced at toy size the launch beside the scoring is held (0),
+    re-planned at will (1), or either by the measured ratio (auto)."""
+    import os
+    import torch
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0)
+    od = OracleDecoder(onet, oam, **kw)
+    A = [np.concatenate([feats[(i + j) % len(feats)] for j in range(1 + i % 3)]) for i in range(8)]
+    B = [np.concatenate([feats[(3 * i + j + 1) % len(feats)] for j in range(1 + (i + 1) % 4)]) for i in range(8)]
+    want = {"A": [od.decode_certified(x) for x in A], "B": [od.decode_certified(x) for x in B]}
+    dev = torch.device("cuda", 0)
+
+    def resident(batch):
+        offs = np.zeros(len(batch) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([x.shape[0] for x in batch])
+        return torch.from_numpy(np.concatenate(batch)).to(dev), offs
+    buf = {"A": resident(A), "B": resident(B)}
+    env = {"JD_REBALANCE_MIN_US": "0", "JD_REBALANCE_FRAC": "0.05"}
+    if hold != "auto":
+        env["JD_PF_REBALANCE"] = hold
+    old = {k: os.environ.get(k) for k in list(env) + ["JD_PF_REBALANCE"]}
+    os.environ.pop("JD_PF_REBALANCE", None)
+    os.environ.update(env)
+    try:
+        gd = capi.Decoder(gnet, gam, max_streams=8, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def announce(name):
+        gd.prefetch_scores(buf[name][0].data_ptr(), buf[name][1], 0)
+
+    def decode(name, ahead):
+        gs = gd.decode_batch_device(buf[name][0].data_ptr(), buf[name][1], 0)
+        assert gd.last_timing()["prefetched"] == (1 if ahead else 0), (name, ahead, gd.last_timing())
+        for i, g in enumerate(gs):
+            assert_hyp_matches(g, want[name][i], "scored ahead=%r batch %s utt %d" % (ahead, name, i))
+            assert bit_exact(g, want[name][i])
+    announce("B"); decode("A", False)                   # B's table is scored beside A's search
+    announce("A"); decode("B", True)
+    announce("A"); decode("A", True)                    # (the bench's pattern: the same batch again)
+    decode("A", True)                                   # nothing announced beside it: the next one scores its own
+    decode("B", False)
+    announce("B"); decode("A", False)
+    decode("A", False)                                  # not the announced batch: B's table is dropped
+    announce("B"); decode("A", False)
+    gd.prefetch_scores(0, None)                         # an empty announcement drops it as well
+    decode("B", False)
+    announce("A"); decode("B", False)
+    gs = gd.decode_batch(A)                             # the host-buffer entry has its own device copy: not the announced buffer
+    for i, g in enumerate(gs):
+        assert bit_exact(g, want["A"][i])
+    # more utterances than streams are decoded in waves formed by length: such a batch cannot be announced, but every
+    # wave of it is scored beside the wave before it - and a batch the caller announced rides on the last wave
+    gd3 = capi.Decoder(gnet, gam, max_streams=3, **kw)
+    gd3.prefetch_scores(buf["A"][0].data_ptr(), buf["A"][1], 0)
+    gs = gd3.decode_batch_device(buf["A"][0].data_ptr(), buf["A"][1], 0)
+    assert gd3.last_timing()["prefetched"] == 2                # waves 2 and 3 of 3
+    for i, g in enumerate(gs):
+        assert bit_exact(g, want["A"][i])
+    small3, offs3 = buf["B"][0], buf["B"][1][:4]                # three utterances: one wave
+    gd3.prefetch_scores(small3.data_ptr(), offs3, 0)
+    gs = gd3.decode_batch_device(buf["A"][0].data_ptr(), buf["A"][1], 0)
+    for i, g in enumerate(gs):
+        assert bit_exact(g, want["A"][i])
+    gs = gd3.decode_batch_device(small3.data_ptr(), offs3, 0)
+    assert gd3.last_timing()["prefetched"] == 1
+    for i, g in enumerate(gs):
+        assert bit_exact(g, want["B"][i])
+    gd3.close(); gd.close()
