@@ -284,6 +284,9 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v)
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 
 #define NLISTS 4
+#ifndef JD_PRECOUNT
+#define JD_PRECOUNT 1               // development: 0 = the next frame's list counts are read at its start
+#endif
 struct SearchShared {
     // slot 0: the item list of phase X (chunk prefix / fill counts per writer segment, build_lists); slots 1..3: the
     // lists of phase A, PACKED (build_packed: entry prefix / writer segment of every non-empty segment)
@@ -378,13 +381,19 @@ __device__ __forceinline__ int rebuild_list(SearchShared &sh, int k, int nw, int
 // new list held a handful of entries, and a fifth of the record chunks were tails.)  Per list: the non-empty
 // segments in order - sh.cnt[slot][i] = the i-th one's writer wave, sh.pfx[slot][i] = entries before it,
 // sh.pfx[slot][ns] = all entries.  Loads of all lists in flight together, two barriers; all SNT threads call it.
+// (the counts come from packed_counts: requested by the caller, one frame ahead when it can - see run_stream)
 template <int N>
-__device__ __forceinline__ void build_packed(SearchShared &sh, const ListSrc (&src)[N], int slot0, int (&Q)[N], int (&items)[N], int (&ns)[N])
+__device__ __forceinline__ void packed_counts(const ListSrc (&src)[N], int (&c)[N])
 {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int c[N], x[N], y[N];
+    const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < N; ++k) c[k] = (tid < src[k].nw) ? CL(src[k].tot + tid) : 0;
+}
+template <int N>
+__device__ __forceinline__ void build_packed(SearchShared &sh, const ListSrc (&src)[N], int (&c)[N], int slot0, int (&Q)[N], int (&items)[N], int (&ns)[N])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int x[N], y[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         if (c[k] < 0) c[k] = 0;
@@ -1417,6 +1426,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     // =============================================================== frames (the first pass may be
     // recognitionStart part 2: the expansion of the start token, a frame without phase A that
     // uses item / key parity 1 like a frame "-1")
+    int pre_cnt[3] = {0, 0, 0}, pre_new = 0;                           // next frame's list counts, requested one frame ahead (below)
+    bool pre_ok = false;
     int np_seen = 0;                                                   // Path records in use, as of the last frame end
     bool stop_seen = false;                                            // the host wants to re-plan the launch (SearchArgs::rebalance_at)
     while (!aborted && !failed) {
@@ -1441,9 +1452,15 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const ListSrc src[3] = {{tot_of(TOT_REC0 + p), 64, gin.seg_rec, gin.nw}, {tot_of(TOT_NEW), 64, gin.seg_new, gin.nw},
                                     {tot_of(TOT_DIRTY0 + p), 64, (p ? gd1 : gd0).seg_new, (p ? gd1 : gd0).nw}};
             int Q[3], items[3], nseg[3];
-            int new_prev = 0;                                          // arcs entered in the previous frame (read with the lists' counts)
-            if (jw == 0 && tid == 0) new_prev = CL(&c.new_all[p ^ 1]);
-            build_packed<3>(sh, src, 1, Q, items, nseg);
+            // the lists' fill counts and the arcs entered in the previous frame: requested behind the previous frame's last
+            // barrier, together with what that frame read there anyway (pre_ok) - else now
+            if (!pre_ok) {
+                if (jw == 0 && tid == 0) pre_new = CL(&c.new_all[p ^ 1]);
+                packed_counts<3>(src, pre_cnt);
+            }
+            const int new_prev = pre_new;
+            pre_ok = false;
+            build_packed<3>(sh, src, pre_cnt, 1, Q, items, nseg);
             if (use_hist) {                                            // every workgroup evaluates the same threshold
                 float th = hist_threshold(C, sh.hprev, lane);
                 th -= normalise;                                                     // :325
@@ -1514,10 +1531,19 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             } else {
                 bx_raw = CL(&c.bestX[p]); err_raw = CL(&c.err[p]); np_raw = CL(&c.n_paths);   // final if this round has nothing to do
                 stop_raw = CL(&c.stop_req);
+                {   // ... and so are the lists the NEXT frame's phase A reads (parity p ^ 1: the frame after this one, or
+                    // frame 0 after recognitionStart's pass): their counts ride on this round trip instead of one of their own
+                    const int pn = p ^ 1;
+                    const ListSrc nsrc[3] = {{tot_of(TOT_REC0 + pn), 64, gin.seg_rec, gin.nw}, {tot_of(TOT_NEW), 64, gin.seg_new, gin.nw},
+                                             {tot_of(TOT_DIRTY0 + pn), 64, (pn ? gd1 : gd0).seg_new, (pn ? gd1 : gd0).nw}};
+                    pre_new = 0;
+                    if (jw == 0 && tid == 0) pre_new = CL(&c.new_all[p]);
+                    packed_counts<3>(nsrc, pre_cnt);
+                }
                 if (tid < gin.nw) sh.start[tid] = CL(tot_of(TOT_CLS0 + (round & 1)) + tid);
                 const ListSrc src[1] = {{tot_of(TOT_CL0 + (round & 1)), KX, gin.seg_item, gin.nw}};
                 build_lists<1>(sh, src, Q1, n1);
-                if (Q1[0] == 0) break;
+                if (Q1[0] == 0) { pre_ok = JD_PRECOUNT != 0; break; }
             }
             int Q = Q1[0];
             if (Q < NW * C.x_chunks) {

@@ -26,12 +26,18 @@ offs = np.zeros(len(feats) + 1, dtype=np.int64)
 offs[1:] = np.cumsum([f.shape[0] for f in feats])
 d_feats = torch.from_numpy(np.concatenate(feats)).to(dev)
 torch.cuda.synchronize()
-variants = {"serial": (False, {}), "ahead": (True, {}), "ahead, re-plan held": (True, {"JD_PF_REBALANCE": "0"}),
+# extra variants from the command line: name=ENV1:val,ENV2:val (scored ahead)
+extra = {}
+for a in sys.argv[3:]:
+    nm, _, kv = a.partition("=")
+    extra[nm] = (not nm.startswith("serial"), dict(x.split(":") for x in kv.split(",") if x))
+KNOBS = ("JD_PF_REBALANCE", "JD_REBALANCE", "JD_MODEL_A", "JD_MODEL_B", "JD_REBALANCE_FRAC", "JD_XL_SLACK", "JD_CW", "JD_XCH")
+variants = extra if extra else {"serial": (False, {}), "ahead": (True, {}), "ahead, re-plan held": (True, {"JD_PF_REBALANCE": "0"}),
             "ahead, re-planned at will": (True, {"JD_PF_REBALANCE": "1"}), "serial, never re-planned": (False, {"JD_REBALANCE": "0"})}
 
 
 def make(env):
-    for k in ("JD_PF_REBALANCE", "JD_REBALANCE"):
+    for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
     return capi.Decoder(gnet, gam, main_beam=beam, device=0, max_streams=len(feats))
