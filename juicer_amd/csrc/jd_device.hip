@@ -388,7 +388,10 @@ __global__ __launch_bounds__(1024) void k_gc_begin(DecConst C, StreamCtl *ctl, S
     if (!active) return;
     int lo, hi;
     gc_range(x, lo, hi);
-    for (int q = lo + threadIdx.x; q < hi; q += blockDim.x) S.gc_idx[q] = 0;
+    // (ranges start at multiples of 1024 and the arena is 256-byte aligned: 16-byte stores, a scalar tail)
+    const int hi4 = lo + ((hi - lo) & ~3);
+    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) *(int4 *)(S.gc_idx + q) = make_int4(0, 0, 0, 0);
+    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) S.gc_idx[q] = 0;
 }
 
 template <int NE>
@@ -434,7 +437,9 @@ __global__ __launch_bounds__(1024) void k_gc_sum(DecConst C, StreamCtl *ctl, Str
     __syncthreads();
     int lo, hi, mine = 0;
     gc_range(x, lo, hi);
-    for (int q = lo + threadIdx.x; q < hi; q += blockDim.x) mine += S.gc_idx[q];
+    const int hi4 = lo + ((hi - lo) & ~3);
+    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) { const int4 m = *(const int4 *)(S.gc_idx + q); mine += m.x + m.y + m.z + m.w; }
+    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) mine += S.gc_idx[q];
 #pragma unroll
     for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&sh_sum, mine);
@@ -463,17 +468,28 @@ __global__ __launch_bounds__(1024) void k_gc_scan(DecConst C, StreamCtl *ctl, St
     __syncthreads();
     int lo, hi;
     gc_range(x, lo, hi);
-    for (int b0 = lo; b0 < hi; b0 += 1024) {
-        const int q = b0 + tid;
-        const int m = (q < hi) ? idx[q] : 0;
-        int v = m;
+    // four marks per thread and step (16-byte accesses; a step behind the range's end is done element by element)
+    for (int b0 = lo; b0 < hi; b0 += 4096) {
+        const int q = b0 + 4 * tid;
+        int4 m = make_int4(0, 0, 0, 0);
+        if (q + 3 < hi) m = *(const int4 *)(idx + q);
+        else { if (q < hi) m.x = idx[q]; if (q + 1 < hi) m.y = idx[q + 1]; if (q + 2 < hi) m.z = idx[q + 2]; }
+        const int mine = m.x + m.y + m.z + m.w;
+        int v = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if (lane >= o) v += y; }
         if (lane == 63) sh_w[wid] = v;
         __syncthreads();
         int base = sh_carry, tot = 0;
         for (int w = 0; w < 16; ++w) { const int u = sh_w[w]; if (w < wid) base += u; tot += u; }
-        if (q < hi) idx[q] = m ? base + v - m : -1;
+        base += v - mine;                                              // marks before this thread's four
+        int4 o4;
+        o4.x = m.x ? base : -1; base += m.x;
+        o4.y = m.y ? base : -1; base += m.y;
+        o4.z = m.z ? base : -1; base += m.z;
+        o4.w = m.w ? base : -1;
+        if (q + 3 < hi) *(int4 *)(idx + q) = o4;
+        else { if (q < hi) idx[q] = o4.x; if (q + 1 < hi) idx[q + 1] = o4.y; if (q + 2 < hi) idx[q + 2] = o4.z; }
         __syncthreads();
         if (tid == 0) sh_carry += tot;
         __syncthreads();
@@ -490,14 +506,20 @@ __global__ __launch_bounds__(1024) void k_gc_compact(DecConst C, StreamCtl *ctl,
     const int *idx = S.gc_idx;
     int lo, hi;
     gc_range(x, lo, hi);
-    for (int q = lo + threadIdx.x; q < hi; q += blockDim.x) {
-        const int ni = idx[q];
+    auto move = [&](int q, int ni) {
         if (ni >= 0) {
             PathRec pr = S.paths[q];
             pr.prev = (pr.prev >= 0) ? idx[pr.prev] : -1;
             S.paths2[ni] = pr;
         }
+    };
+    // (most records are dropped: four new indices per 16-byte load, the kept ones' records in flight together)
+    const int hi4 = lo + ((hi - lo) & ~3);
+    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) {
+        const int4 ni = *(const int4 *)(idx + q);
+        move(q, ni.x); move(q + 1, ni.y); move(q + 2, ni.z); move(q + 3, ni.w);
     }
+    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) move(q, idx[q]);
 }
 
 template <int NE>
