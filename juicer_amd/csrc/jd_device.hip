@@ -506,20 +506,29 @@ __global__ __launch_bounds__(1024) void k_gc_compact(DecConst C, StreamCtl *ctl,
     const int *idx = S.gc_idx;
     int lo, hi;
     gc_range(x, lo, hi);
-    auto move = [&](int q, int ni) {
+    // four new indices per 16-byte load; the kept ones' records, then their predecessors' new indices, are requested
+    // together (one chain of dependent round trips per four records, not four)
+    const int hi4 = lo + ((hi - lo) & ~3);
+    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) {
+        const int4 nv = *(const int4 *)(idx + q);
+        const int ni[4] = {nv.x, nv.y, nv.z, nv.w};
+        PathRec pr[4];
+        int np[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (ni[k] >= 0) pr[k] = S.paths[q + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) np[k] = (ni[k] >= 0 && pr[k].prev >= 0) ? idx[pr[k].prev] : -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (ni[k] >= 0) { pr[k].prev = np[k]; S.paths2[ni[k]] = pr[k]; }
+    }
+    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) {
+        const int ni = idx[q];
         if (ni >= 0) {
             PathRec pr = S.paths[q];
             pr.prev = (pr.prev >= 0) ? idx[pr.prev] : -1;
             S.paths2[ni] = pr;
         }
-    };
-    // (most records are dropped: four new indices per 16-byte load, the kept ones' records in flight together)
-    const int hi4 = lo + ((hi - lo) & ~3);
-    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) {
-        const int4 ni = *(const int4 *)(idx + q);
-        move(q, ni.x); move(q + 1, ni.y); move(q + 2, ni.z); move(q + 3, ni.w);
     }
-    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) move(q, idx[q]);
 }
 
 template <int NE>
