@@ -75,676 +75,14 @@ __device__ __forceinline__ int rank_in(unsigned long long bal)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
 }
 
-// glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c, ARM optimized-routines
-// algorithm): N=32 table + cubic in double, rounded once to float.  Replicated
-// so that device logAdd equals the host libm result bit for bit (verified on
-// the host for all 1.2e8 floats in [-18.5, -1e-3]: tests/test_expf.py, through jd_debug_expf).
-#define JD_EXP2F_TAB                                                                              \
-    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,   \
-    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,   \
-    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,   \
-    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,   \
-    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,   \
-    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,   \
-    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,   \
-    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL
-__device__ __constant__ unsigned long long jd_exp2f_tab[32] = {JD_EXP2F_TAB};
-static const unsigned long long jd_exp2f_tab_host[32] = {JD_EXP2F_TAB};     // jd_debug_expf(device = -1)
-
-// one source for the device function and its host twin (jd_debug_expf checks both against libm)
-__host__ __device__ __forceinline__ float jd_expf_impl(float x, const unsigned long long *tab)
-{
-    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0;
-    const double SHIFT = 0x1.8p+52;
-    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
-    const double C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
-    const double C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
-    double z = InvLn2N * (double)x;
-    double kd = z + SHIFT;
-    unsigned long long ki;
-    memcpy(&ki, &kd, sizeof ki);
-    kd -= SHIFT;
-    double r = z - kd;
-    unsigned long long t = tab[ki & 31];
-    t += ki << 47;
-    double s;
-    memcpy(&s, &t, sizeof s);
-    double p = C0 * r + C1;
-    double r2 = r * r;
-    double y = C2 * r + 1.0;
-    y = p * r2 + y;
-    y = y * s;
-    return (float)y;
-}
-__device__ __forceinline__ float jd_expf(float x) { return jd_expf_impl(x, jd_exp2f_tab); }
-
-// HTKFlatModels::logAdd, HTKFlatModels.cpp:266-293
-__device__ __forceinline__ float jd_log_add(float x, float y)
-{
-    if (x < y) { float t = x; x = y; y = t; }
-    float diff = y - x;
-    if (diff < -18.42) return x;
-    return (float)((double)x + log(1.0 + (double)jd_expf(diff)));
-}
-
-// ------------------------------------------------------------------- GMM kernel
-
-// par: [g][m][D][2] = (mean, ivar) interleaved; det: [g][m]; rows: row_src[r] is
-// the frame index into feats (or -1); ll: [n_rows][G].
-template <int DT>
-__global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ feats,
-                                                     const int *__restrict__ row_src, int n_rows,
-                                                     const float *__restrict__ par,
-                                                     const float *__restrict__ det,
-                                                     const int *__restrict__ n_mix, int G, int M, int D,
-                                                     float *__restrict__ ll, int skip_unused)
-{
-    constexpr int DP = (DT > 0) ? (DT | 1) : 0;      // odd row stride: conflict-free per-lane rows
-    extern __shared__ __align__(16) char smem[];
-    const int dp = (DT > 0) ? DP : (D | 1);
-    float *sx = (float *)smem;                        // [64][dp]
-    float *so = sx + GMM_ROWS * dp;                   // [64][GMM_GT+1]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Dn = (DT > 0) ? DT : D;
-    // tiles = (64-row tile, GMM_GT-state group); the grid may be smaller than the number of
-    // tiles (launch_gmm bounds how many wave slots the scoring may hold next to the search)
-    const int n_rt = (n_rows + GMM_ROWS - 1) / GMM_ROWS, n_gt = (G + GMM_GT - 1) / GMM_GT;
-    for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
-    // row tile skewed by the state group: a bounded grid whose size is a multiple of n_rt would
-    // otherwise hand each workgroup the same row tile every time (and the skipped ones no work)
-    const int gt = tile / n_rt;
-    const int r0 = ((tile + gt) % n_rt) * GMM_ROWS;
-    const int g0 = gt * GMM_GT;
-    // a tile whose rows are all unused (stream finished / chunk shorter than its slot) is skipped:
-    // the valid rows of a stream's slot are a prefix of it and slots are multiples of the tile
-    // (rows_per_slot % GMM_ROWS == 0), so the tile's first row decides
-    if (skip_unused && row_src[r0] < 0) continue;
-    __syncthreads();                                  // previous tile's LDS reads are done
-
-    // stage the 64 x D feature tile (coalesced along D)
-    for (int e = tid; e < GMM_ROWS * Dn; e += 256) {
-        int r = e / Dn, j = e - r * Dn;
-        int src = (r0 + r < n_rows) ? row_src[r0 + r] : -1;
-        sx[r * dp + j] = (src >= 0) ? feats[(size_t)src * Dn + j] : 0.0f;
-    }
-    __syncthreads();
-
-    float x[(DT > 0) ? DT : 1];
-    if (DT > 0) {
-#pragma unroll
-        for (int j = 0; j < DT; ++j) x[j] = sx[lane * dp + j];
-    }
-
-    constexpr int GPW = GMM_GT / 4;                   // tied states per wave
-    for (int gi = 0; gi < GPW; ++gi) {
-        const int gl = wid * GPW + gi;                // wave-uniform
-        const int g = g0 + gl;
-        float acc = LZ;
-        if (g < G) {
-            const int nm = n_mix[g];
-            const float *pg = par + (size_t)g * M * Dn * 2;
-            const float *dg = det + (size_t)g * M;
-            for (int m = 0; m < nm; ++m) {
-                const float *pm = pg + (size_t)m * Dn * 2;
-                float sum = 0.0f;
-                if (DT > 0) {
-#pragma unroll
-                    for (int j = 0; j < DT; ++j) {
-                        float xmu = x[j] - pm[2 * j];          // HTKFlatModels.cpp:249
-                        sum += xmu * xmu * pm[2 * j + 1];      // :250  (no contraction)
-                    }
-                } else {
-                    for (int j = 0; j < Dn; ++j) {
-                        float xmu = sx[lane * dp + j] - pm[2 * j];
-                        sum += xmu * xmu * pm[2 * j + 1];
-                    }
-                }
-                float comp = (float)(-0.5 * (double)sum + (double)dg[m]);   // :254
-                acc = jd_log_add(acc, comp);
-            }
-        }
-        so[lane * (GMM_GT + 1) + gl] = acc;
-    }
-    __syncthreads();
-    // coalesced store of the [64 rows][GMM_GT] tile
-    for (int e = tid; e < GMM_ROWS * GMM_GT; e += 256) {
-        int r = e / GMM_GT, c = e - r * GMM_GT;
-        if (r0 + r < n_rows && g0 + c < G) ll[(size_t)(r0 + r) * G + g0 + c] = so[r * (GMM_GT + 1) + c];
-    }
-    }
-}
-
-
-// ---- the D = 39 kernel: TWO frames per lane, packed fp32 arithmetic.
-//
-// A lane owns rows r and r + 64 of a 128-row tile; their vectors sit side by side in register
-// pairs, so every VALU instruction of the distance loop is a packed one (v_pk_add_f32 /
-// v_pk_mul_f32: two IEEE fp32 operations, no contraction - the same roundings as the reference's
-// scalar code, HTKFlatModels.cpp:249-250) with the tied state's (mean, ivar) pairs arriving
-// through the scalar cache.  logAdd (HTKFlatModels.cpp:266-293) evaluates log(1.0 + e), e in
-// (0, 1], in double with a 128-interval table (c = 1 + k/128; log y = -log(invc) + log1p(y invc - 1),
-// degree-7 polynomial: < 1 ulp in double, like the libm the reference links).
-#define GMM_ROWS2 128
-typedef float jd_f2 __attribute__((ext_vector_type(2)));
-struct JdLogTab { double invc, logc; };
-
-// One logAdd step for the two frames of a lane, straight-line (no branch: some lane of a wave always
-// takes the long path) and written pairwise so that the two dependent chains interleave.  etab is
-// the LDS copy of jd_exp2f_tab, tab the LDS copy of the log table.
-__device__ __forceinline__ void jd_log_add2x2(float &a0, float &a1, float c0, float c1, const JdLogTab *tab,
-                                              const unsigned long long *etab)
-{
-    const bool s0 = a0 < c0, s1 = a1 < c1;
-    const float x0 = s0 ? c0 : a0, y0 = s0 ? a0 : c0;
-    const float x1 = s1 ? c1 : a1, y1 = s1 ? a1 : c1;
-    const float d0 = y0 - x0, d1 = y1 - x1;
-    const bool keep0 = d0 < -18.42, keep1 = d1 < -18.42;               // HTKFlatModels.cpp:276 (double compare)
-    // (the clamp keeps the table index in range for the lanes whose result is discarded)
-    const double e0 = (double)jd_expf_impl(fmaxf(d0, -19.0f), etab), e1 = (double)jd_expf_impl(fmaxf(d1, -19.0f), etab);
-    const double yy0 = 1.0 + e0, yy1 = 1.0 + e1;
-    const JdLogTab t0 = tab[(int)(e0 * 128.0 + 0.5)], t1 = tab[(int)(e1 * 128.0 + 0.5)];
-    const double r0 = __builtin_fma(yy0, t0.invc, -1.0), r1 = __builtin_fma(yy1, t1.invc, -1.0);
-    double q0 = 1.0 / 7.0, q1 = 1.0 / 7.0;
-    q0 = __builtin_fma(q0, r0, -1.0 / 6.0); q1 = __builtin_fma(q1, r1, -1.0 / 6.0);
-    q0 = __builtin_fma(q0, r0, 1.0 / 5.0);  q1 = __builtin_fma(q1, r1, 1.0 / 5.0);
-    q0 = __builtin_fma(q0, r0, -1.0 / 4.0); q1 = __builtin_fma(q1, r1, -1.0 / 4.0);
-    q0 = __builtin_fma(q0, r0, 1.0 / 3.0);  q1 = __builtin_fma(q1, r1, 1.0 / 3.0);
-    q0 = __builtin_fma(q0, r0, -1.0 / 2.0); q1 = __builtin_fma(q1, r1, -1.0 / 2.0);
-    q0 = __builtin_fma(q0, r0, 1.0);        q1 = __builtin_fma(q1, r1, 1.0);
-    const float n0 = (float)((double)x0 + (t0.logc + q0 * r0)), n1 = (float)((double)x1 + (t1.logc + q1 * r1));
-    a0 = keep0 ? x0 : n0;
-    a1 = keep1 ? x1 : n1;
-}
-
-__global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restrict__ feats,
-                                                       const int *__restrict__ row_src, int n_rows,
-                                                       const float *__restrict__ par,
-                                                       const float *__restrict__ det,
-                                                       const int *__restrict__ n_mix, int G, int M,
-                                                       float *__restrict__ ll, int skip_unused,
-                                                       const JdLogTab *__restrict__ logtab)
-{
-    constexpr int DT = 39, DP = 39;                   // odd row stride: conflict-free per-lane rows
-    extern __shared__ __align__(16) char smem[];
-    JdLogTab *stab = (JdLogTab *)smem;                // [129] (+ pad)
-    unsigned long long *setab = (unsigned long long *)(smem + 130 * sizeof(JdLogTab));   // [32]
-    float *sx = (float *)(smem + 130 * sizeof(JdLogTab) + 32 * sizeof(unsigned long long));   // [128][DP]
-    float *so = sx;                                   // [128][GMM_GT+1]: the feature tile is in registers by then
-                                                      // (36 KB per workgroup: four of them share a CU's LDS)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < 129; i += 256) stab[i] = logtab[i];
-    if (tid < 32) setab[tid] = jd_exp2f_tab[tid];
-    const int n_rt = (n_rows + GMM_ROWS2 - 1) / GMM_ROWS2, n_gt = (G + GMM_GT - 1) / GMM_GT;
-    for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
-        // row tile skewed by the state group (see jd_gmm_kernel)
-        const int gt = tile / n_rt;
-        const int r0 = ((tile + gt) % n_rt) * GMM_ROWS2;
-        const int g0 = gt * GMM_GT;
-        if (skip_unused && row_src[r0] < 0) continue;
-        __syncthreads();                              // previous tile's LDS reads are done
-        for (int e = tid; e < GMM_ROWS2 * DT; e += 256) {
-            const int r = e / DT, j = e - r * DT;
-            const int src = (r0 + r < n_rows) ? row_src[r0 + r] : -1;
-            sx[r * DP + j] = (src >= 0) ? feats[(size_t)src * DT + j] : 0.0f;
-        }
-        __syncthreads();
-        jd_f2 x[DT];
-#pragma unroll
-        for (int j = 0; j < DT; ++j) { x[j].x = sx[lane * DP + j]; x[j].y = sx[(lane + 64) * DP + j]; }
-        __syncthreads();                              // sx is re-used as the output tile
-        constexpr int GPW = GMM_GT / 4;               // tied states per wave
-        for (int gi = 0; gi < GPW; ++gi) {
-            const int gl = wid * GPW + gi;            // wave-uniform
-            const int g = g0 + gl;
-            float acc0 = LZ, acc1 = LZ;
-            if (g < G) {
-                const int nm = n_mix[g];
-                const float *pg = par + (size_t)g * M * DT * 2;
-                const float *dg = det + (size_t)g * M;
-                for (int m = 0; m < nm; ++m) {
-                    const float *pm = pg + (size_t)m * DT * 2;
-                    jd_f2 sum = {0.0f, 0.0f};
-                    // three dimensions at a time: their squared distances are independent, only the
-                    // running sum is a chain (added in the reference's order)
-#pragma unroll
-                    for (int j = 0; j < DT; j += 3) {
-                        const jd_f2 mu0 = {pm[2 * j], pm[2 * j]}, iv0 = {pm[2 * j + 1], pm[2 * j + 1]};
-                        const jd_f2 mu1 = {pm[2 * j + 2], pm[2 * j + 2]}, iv1 = {pm[2 * j + 3], pm[2 * j + 3]};
-                        const jd_f2 mu2 = {pm[2 * j + 4], pm[2 * j + 4]}, iv2 = {pm[2 * j + 5], pm[2 * j + 5]};
-                        const jd_f2 u0 = x[j] - mu0, u1 = x[j + 1] - mu1, u2 = x[j + 2] - mu2;   // HTKFlatModels.cpp:249
-                        const jd_f2 w0 = u0 * u0, w1 = u1 * u1, w2 = u2 * u2;
-                        const jd_f2 z0 = w0 * iv0, z1 = w1 * iv1, z2 = w2 * iv2;                 // :250  (no contraction)
-                        if (j == 0) sum = z0; else sum += z0;             // (0.0f + z0 == z0: z0 >= +0)
-                        sum += z1; sum += z2;
-                    }
-                    const double dm = (double)dg[m];
-                    const float c0 = (float)(-0.5 * (double)sum.x + dm), c1 = (float)(-0.5 * (double)sum.y + dm);   // :254
-                    // logAdd(LOG_ZERO, c) is c for every c > LOG_ZERO and LOG_ZERO else (the difference is below -18.42,
-                    // or the sum rounds back): the first mixture needs no exponential and no logarithm
-                    if (m == 0) { acc0 = LZ < c0 ? c0 : LZ; acc1 = LZ < c1 ? c1 : LZ; }
-                    else jd_log_add2x2(acc0, acc1, c0, c1, stab, setab);
-                }
-            }
-            so[lane * (GMM_GT + 1) + gl] = acc0;
-            so[(lane + 64) * (GMM_GT + 1) + gl] = acc1;
-        }
-        __syncthreads();
-        for (int e = tid; e < GMM_ROWS2 * GMM_GT; e += 256) {
-            const int r = e / GMM_GT, c = e - r * GMM_GT;
-            if (r0 + r < n_rows && g0 + c < G) ll[(size_t)(r0 + r) * G + g0 + c] = so[r * (GMM_GT + 1) + c];
-        }
-    }
-}
+// ------------------------------------------------------------------- scoring kernels
+#include "jd_gmm.h"
 
 // --------------------------------------------------------------- search kernels
 #include "jd_search.h"
 
-// Path garbage collection = collectPaths (WFSTDecoderLite.cpp:699-747) as a mark-compact: records
-// reachable from a live token, from a frontier item of the last processed frame (the pending
-// entry-token candidates point at those) or from bestFinalToken are kept, everything else is
-// dropped.  No effect on results.  Run between launches for the streams that stopped for it, G
-// 1024-thread workgroups per stream; the steps are separate kernels (a kernel boundary is the
-// barrier between them): begin (decide, clear the marks) - mark - sum (marks per workgroup range) -
-// scan (new indices) - compact (into the second arena, predecessors remapped) - remap (tokens, items,
-// bestFinalToken; swap the arenas).
-#define GC_MAXG 32
-struct GcState { int active, kept; int part[GC_MAXG]; };
-
-struct GcCtx {
-    int s, blk, G, np, nw, p;
-    Geo g;
-};
-__device__ __forceinline__ bool gc_ctx(const DecConst &C, const StreamCtl *ctl, const int4 *work, int s_single, int G, GcCtx &x)
-{
-    const int wi = blockIdx.x / G;
-    x.blk = blockIdx.x % G; x.G = G;
-    x.s = work ? work[wi].x : s_single;
-    const StreamCtl &c = ctl[x.s];
-    x.np = c.n_paths; x.nw = c.lst_nw;
-    x.p = c.frame & 1;                                // list the next frame reads; items of the last frame: parity p^1
-    if (x.nw > 0) x.g = make_geo(C, x.nw);
-    return true;
-}
-// the range of Path records workgroup blk of G looks after (multiples of 1024)
-__device__ __forceinline__ void gc_range(const GcCtx &x, int &lo, int &hi)
-{
-    const long long per = ((((long long)x.np + x.G - 1) / x.G) + 1023) & ~1023LL;
-    lo = (int)min((long long)x.np, per * x.blk);
-    hi = (int)min((long long)x.np, per * (x.blk + 1));
-}
-
-__global__ __launch_bounds__(1024) void k_gc_begin(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
-{
-    GcCtx x;
-    gc_ctx(C, ctl, work, s_single, G, x);
-    const StreamCtl &c = ctl[x.s];
-    StreamDev &S = streams[x.s];
-    const bool active = c.started && !c.needs_init && c.error == 0 && x.nw > 0 &&
-                        (x.np > C.gc_threshold || (C.path_rule && path_rule_fires(x.np, c.path_new)));
-    GcState *gs = (GcState *)S.gc_state;
-    if (x.blk == 0 && threadIdx.x == 0) { gs->active = active ? 1 : 0; gs->kept = 0; }
-    if (!active) return;
-    int lo, hi;
-    gc_range(x, lo, hi);
-    // (ranges start at multiples of 1024 and the arena is 256-byte aligned: 16-byte stores, a scalar tail)
-    const int hi4 = lo + ((hi - lo) & ~3);
-    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) *(int4 *)(S.gc_idx + q) = make_int4(0, 0, 0, 0);
-    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) S.gc_idx[q] = 0;
-}
-
-template <int NE>
-__global__ __launch_bounds__(1024) void k_gc_mark(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
-{
-    typedef RecLayout<NE> RL;
-    GcCtx x;
-    gc_ctx(C, ctl, work, s_single, G, x);
-    StreamDev &S = streams[x.s];
-    if (!((const GcState *)S.gc_state)->active) return;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int *idx = S.gc_idx;
-    auto mark = [&](int q) { while (q >= 0 && atomicExch(&idx[q], 1) == 0) q = S.paths[q].prev; };
-    // tokens of the instance records (structure-of-arrays chunks of 64) ...
-    for (int w = x.blk * 16 + wid; w < x.nw; w += G * 16) {
-        const char *seg = (const char *)S.rec + (size_t)x.p * C.cap_slots * RL::REC_BYTES + (size_t)w * (x.g.seg_rec >> 6) * RL::CHUNK_BYTES;
-        const int n_rec = min(S.tot[(size_t)(TOT_REC0 + x.p) * MAXW + w], (int)x.g.seg_rec);
-        for (int k = lane; k < n_rec * NE; k += 64) {
-            const int q = k / NE, j = k - q * NE + 1;
-            const char *r = seg + (size_t)(q >> 6) * RL::CHUNK_BYTES + (size_t)(q & 63) * 16;
-            const int n = ((const int4 *)r)->y & 0xff;
-            if (j < n - 1) {
-                const int4 t = *(const int4 *)(r + (size_t)(RL::HF + j - 1) * 1024);
-                if (__int_as_float(t.x) > LZ) mark(t.w);
-            }
-        }
-        // ... and of the last frame's frontier items
-        const int n_it = min(S.item_end[w], (int)x.g.seg_item);
-        for (int k = lane; k < n_it; k += 64) mark(S.items[2 * ((size_t)(x.p ^ 1) * C.cap_items + (size_t)w * x.g.seg_item + k)].w);
-    }
-    if (x.blk == 0 && tid == 0) mark(ctl[x.s].best_final.path);
-}
-
-__global__ __launch_bounds__(1024) void k_gc_sum(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
-{
-    GcCtx x;
-    gc_ctx(C, ctl, work, s_single, G, x);
-    StreamDev &S = streams[x.s];
-    GcState *gs = (GcState *)S.gc_state;
-    if (!gs->active) return;
-    __shared__ int sh_sum;
-    if (threadIdx.x == 0) sh_sum = 0;
-    __syncthreads();
-    int lo, hi, mine = 0;
-    gc_range(x, lo, hi);
-    const int hi4 = lo + ((hi - lo) & ~3);
-    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) { const int4 m = *(const int4 *)(S.gc_idx + q); mine += m.x + m.y + m.z + m.w; }
-    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) mine += S.gc_idx[q];
-#pragma unroll
-    for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&sh_sum, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) gs->part[x.blk] = sh_sum;
-}
-
-// exclusive scan of the marks -> new indices (idx[q] = new index, -1 if dropped)
-__global__ __launch_bounds__(1024) void k_gc_scan(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
-{
-    GcCtx x;
-    gc_ctx(C, ctl, work, s_single, G, x);
-    StreamDev &S = streams[x.s];
-    GcState *gs = (GcState *)S.gc_state;
-    if (!gs->active) return;
-    __shared__ int sh_w[16];
-    __shared__ int sh_carry;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int *idx = S.gc_idx;
-    if (tid == 0) {
-        int base = 0, all = 0;
-        for (int b = 0; b < G; ++b) { if (b < x.blk) base += gs->part[b]; all += gs->part[b]; }
-        sh_carry = base;
-        if (x.blk == 0) gs->kept = all;
-    }
-    __syncthreads();
-    int lo, hi;
-    gc_range(x, lo, hi);
-    // four marks per thread and step (16-byte accesses; a step behind the range's end is done element by element)
-    for (int b0 = lo; b0 < hi; b0 += 4096) {
-        const int q = b0 + 4 * tid;
-        int4 m = make_int4(0, 0, 0, 0);
-        if (q + 3 < hi) m = *(const int4 *)(idx + q);
-        else { if (q < hi) m.x = idx[q]; if (q + 1 < hi) m.y = idx[q + 1]; if (q + 2 < hi) m.z = idx[q + 2]; }
-        const int mine = m.x + m.y + m.z + m.w;
-        int v = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if (lane >= o) v += y; }
-        if (lane == 63) sh_w[wid] = v;
-        __syncthreads();
-        int base = sh_carry, tot = 0;
-        for (int w = 0; w < 16; ++w) { const int u = sh_w[w]; if (w < wid) base += u; tot += u; }
-        base += v - mine;                                              // marks before this thread's four
-        int4 o4;
-        o4.x = m.x ? base : -1; base += m.x;
-        o4.y = m.y ? base : -1; base += m.y;
-        o4.z = m.z ? base : -1; base += m.z;
-        o4.w = m.w ? base : -1;
-        if (q + 3 < hi) *(int4 *)(idx + q) = o4;
-        else { if (q < hi) idx[q] = o4.x; if (q + 1 < hi) idx[q + 1] = o4.y; if (q + 2 < hi) idx[q + 2] = o4.z; }
-        __syncthreads();
-        if (tid == 0) sh_carry += tot;
-        __syncthreads();
-    }
-}
-
-// compact into the second arena, remapping prev (prev < q: its new index is final after the scan)
-__global__ __launch_bounds__(1024) void k_gc_compact(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
-{
-    GcCtx x;
-    gc_ctx(C, ctl, work, s_single, G, x);
-    StreamDev &S = streams[x.s];
-    if (!((const GcState *)S.gc_state)->active) return;
-    const int *idx = S.gc_idx;
-    int lo, hi;
-    gc_range(x, lo, hi);
-    // four new indices per 16-byte load; the kept ones' records, then their predecessors' new indices, are requested
-    // together (one chain of dependent round trips per four records, not four)
-    const int hi4 = lo + ((hi - lo) & ~3);
-    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) {
-        const int4 nv = *(const int4 *)(idx + q);
-        const int ni[4] = {nv.x, nv.y, nv.z, nv.w};
-        PathRec pr[4];
-        int np[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (ni[k] >= 0) pr[k] = S.paths[q + k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) np[k] = (ni[k] >= 0 && pr[k].prev >= 0) ? idx[pr[k].prev] : -1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (ni[k] >= 0) { pr[k].prev = np[k]; S.paths2[ni[k]] = pr[k]; }
-    }
-    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) {
-        const int ni = idx[q];
-        if (ni >= 0) {
-            PathRec pr = S.paths[q];
-            pr.prev = (pr.prev >= 0) ? idx[pr.prev] : -1;
-            S.paths2[ni] = pr;
-        }
-    }
-}
-
-template <int NE>
-__global__ __launch_bounds__(1024) void k_gc_remap(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
-{
-    typedef RecLayout<NE> RL;
-    GcCtx x;
-    gc_ctx(C, ctl, work, s_single, G, x);
-    StreamDev &S = streams[x.s];
-    const GcState *gs = (const GcState *)S.gc_state;
-    if (!gs->active) return;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int *idx = S.gc_idx;
-    for (int w = x.blk * 16 + wid; w < x.nw; w += G * 16) {
-        char *seg = (char *)S.rec + (size_t)x.p * C.cap_slots * RL::REC_BYTES + (size_t)w * (x.g.seg_rec >> 6) * RL::CHUNK_BYTES;
-        const int n_rec = min(S.tot[(size_t)(TOT_REC0 + x.p) * MAXW + w], (int)x.g.seg_rec);
-        for (int k = lane; k < n_rec * NE; k += 64) {
-            const int q = k / NE, j = k - q * NE + 1;
-            char *r = seg + (size_t)(q >> 6) * RL::CHUNK_BYTES + (size_t)(q & 63) * 16;
-            const int n = ((const int4 *)r)->y & 0xff;
-            if (j < n - 1) {
-                int4 *t = (int4 *)(r + (size_t)(RL::HF + j - 1) * 1024);
-                if (t->w >= 0) t->w = (__int_as_float(t->x) > LZ) ? idx[t->w] : -1;
-            }
-        }
-        const int n_it = min(S.item_end[w], (int)x.g.seg_item);
-        for (int k = lane; k < n_it; k += 64) {
-            int4 *t = S.items + 2 * ((size_t)(x.p ^ 1) * C.cap_items + (size_t)w * x.g.seg_item + k);   // token half of the item
-            if (t->w >= 0) t->w = idx[t->w];
-        }
-    }
-    if (x.blk == 0 && tid == 0) {                     // (no workgroup of this kernel reads the Path arenas)
-        StreamCtl &c = ctl[x.s];
-        if (c.best_final.path >= 0) c.best_final.path = idx[c.best_final.path];
-        PathRec *tmp = S.paths; S.paths = S.paths2; S.paths2 = tmp;
-        c.n_paths = gs->kept;
-        c.path_new = gs->kept; c.n_collect += 1;      // nPathNew = nPath (:745)
-    }
-}
-
-// the six steps for the streams of a work list (or one stream), on stream st
-static void launch_gc(const DecConst &C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int n_work, int s_single, bool ne3,
-                      int n_cus, hipStream_t st)
-{
-    const int G = std::max(1, std::min(GC_MAXG, n_cus / std::max(1, n_work)));
-    const dim3 grid((unsigned)(n_work * G)), blk(1024);
-    hipLaunchKernelGGL(k_gc_begin, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
-    if (ne3) hipLaunchKernelGGL(k_gc_mark<3>, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
-    else hipLaunchKernelGGL(k_gc_mark<6>, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
-    hipLaunchKernelGGL(k_gc_sum, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
-    hipLaunchKernelGGL(k_gc_scan, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
-    hipLaunchKernelGGL(k_gc_compact, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
-    if (ne3) hipLaunchKernelGGL(k_gc_remap<3>, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
-    else hipLaunchKernelGGL(k_gc_remap<6>, grid, blk, 0, st, C, ctl, streams, work, s_single, G);
-}
-
-// PARTIAL_DECODING: tracePartialPath (WFSTDecoderLite.cpp:824-868) on the state a launch left behind.
-//
-// The reference walks back from the first token with a Path of every active instance, counts the
-// visits per Path record (records newer than the last traced one only) and stops at the first record
-// that all nActiveInsts walks reach: the deepest record common to all of them.  Here: the instances
-// are the records of the next frame's list plus the arcs entered in the last frame that have no
-// record yet (new list, and the clean-up list of the "hopeless" ones - the reference attached an
-// instance for those too); an instance's first token is its entry token - the candidate that won the
-// arc's key in the last phase X - then its emitting states in order.  Path indices grow along a
-// chain (a record is allocated after its predecessor, and the collection keeps the order), so the common
-// record lies on the chain of ANY tip: the chain of the highest tip is written out, every other tip
-// walks down until it meets it, and the shallowest meeting point is the answer.
-// out[0] = found, out[1] = records on the chain from the root to the found one (oldest first in
-// res_label / res_time, at most res_cap of them).
-template <int NE, typename F>
-__device__ __forceinline__ void jd_for_each_tip(const DecConst &C, const StreamCtl &c, const StreamDev &S, F &&f)
-{
-    typedef RecLayout<NE> RL;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nw = c.lst_nw;
-    const Geo g = make_geo(C, nw);
-    const int p = c.frame & 1;
-    // the pending entry token of the arcs leaving state st: the best token that arrived there in the last frame
-    auto entry_tip = [&](int st) -> int {
-        const unsigned long long kv = S.srec[st].e[p ^ 1];
-        if (kv == 0ULL) return -1;
-        return S.items[2 * ((size_t)(p ^ 1) * C.cap_items + (size_t)(kv & 0xffffffffULL))].w;
-    };
-    for (int w = wid; w < nw; w += 16) {
-        const char *seg = (const char *)S.rec + (size_t)p * C.cap_slots * RL::REC_BYTES + (size_t)w * (g.seg_rec >> 6) * RL::CHUNK_BYTES;
-        const int n_rec = min(S.tot[(size_t)(TOT_REC0 + p) * MAXW + w], (int)g.seg_rec);
-        for (int q = lane; q < n_rec; q += 64) {
-            const char *r = seg + (size_t)(q >> 6) * RL::CHUNK_BYTES + (size_t)(q & 63) * 16;
-            const int4 h0 = *(const int4 *)r;
-            int tip = entry_tip(h0.z);                                  // (h0.z: the source state of the instance's arc)
-            const int n = h0.y & 0xff;
-            for (int j = 1; j <= NE && tip < 0; ++j)
-                if (j < n - 1) tip = ((const int4 *)(r + (size_t)(RL::HF + j - 1) * 1024))->w;
-            f(tip);
-        }
-    }
-    // ... and the arcs entered in the last frame that have no record yet (the reference attached an instance to every
-    // one of them, hopeless or not): all of them hold the token that arrived at their source state, so every state
-    // of the last frame's dirty list that has an arc with a model is one tip
-    const int dn = c.dirty_nw[p ^ 1];
-    const Geo gd = make_geo(C, dn > 0 ? dn : nw);
-    const int *dl = S.dirtyl + (size_t)(p ^ 1) * C.cap_new;
-    for (int w = wid; w < gd.nw; w += 16) {
-        const int n_d = min(S.tot[(size_t)(TOT_DIRTY0 + (p ^ 1)) * MAXW + w], (int)gd.seg_new);
-        for (int q = lane; q < n_d; q += 64) {
-            const int st = dl[(size_t)w * gd.seg_new + q];
-            bool has_model = false;
-            if (C.lazy) {
-                const int4 row = C.lazy->rows[st];
-                for (int a = row.x; a < row.x + row.y && !has_model; ++a) has_model = (C.lazy->arcs[a].in & ~TEE_FLAG) != 0;
-            } else
-                for (int a = C.row_ptr[st]; a < C.row_ptr[st + 1] && !has_model; ++a) has_model = (C.arcs[a].in & ~TEE_FLAG) != 0;
-            if (has_model) f(entry_tip(st));
-        }
-    }
-}
-
-template <int NE>
-__global__ __launch_bounds__(1024) void k_partial(DecConst C, StreamCtl *ctl, StreamDev *streams, int s, int last_frame, int *out)
-{
-    StreamCtl &c = ctl[s];
-    StreamDev &S = streams[s];
-    __shared__ int sh_max, sh_bad, sh_cnt, sh_depth, sh_D;
-    const int tid = threadIdx.x;
-    if (tid == 0) { sh_max = -1; sh_bad = 0; sh_cnt = 0; sh_depth = 0; sh_D = 0; out[0] = 0; out[1] = 0; }
-    __syncthreads();
-    if (!c.started || c.needs_init || c.error != 0 || c.lst_nw <= 0) return;
-    {
-        int mx = -1, bad = 0, cnt = 0;
-        jd_for_each_tip<NE>(C, c, S, [&](int tip) { ++cnt; if (tip < 0) bad = 1; else mx = max(mx, tip); });
-        if (mx >= 0) atomicMax(&sh_max, mx);
-        if (bad) atomicOr(&sh_bad, 1);
-        if (cnt) atomicAdd(&sh_cnt, cnt);
-    }
-    __syncthreads();
-    // an instance none of whose tokens has a Path yet: nothing can be common to all (:850-854)
-    if (sh_cnt == 0 || sh_bad || sh_max < 0) return;
-    int *ch = S.gc_idx;                                                // the chain of the highest tip, newest first
-    if (tid == 0) {
-        int n = 0;
-        for (int q = sh_max; q >= 0; q = S.paths[q].prev) ch[n++] = q;
-        sh_depth = n;
-    }
-    __syncthreads();
-    const int depth = sh_depth;
-    {
-        int dmax = 0;
-        jd_for_each_tip<NE>(C, c, S, [&](int tip) {
-            int i = 0, q = tip;
-            for (;;) {
-                while (i < depth && ch[i] > q) ++i;
-                if (i == depth || ch[i] == q) break;
-                q = S.paths[q].prev;
-                if (q < 0) { i = depth; break; }
-            }
-            dmax = max(dmax, i);
-        });
-        if (dmax) atomicMax(&sh_D, dmax);
-    }
-    __syncthreads();
-    const int D0 = sh_D;
-    if (D0 >= depth) return;                                           // no record is common to all
-    if (S.paths[ch[D0]].frame <= last_frame) return;                   // nothing newer than the last traced record (:858)
-    const int n = depth - D0;
-    for (int k = tid; k < n && k < S.res_cap; k += blockDim.x) {       // traceWinningPaths :874-890, oldest first
-        const PathRec pr = S.paths[ch[depth - 1 - k]];
-        S.res_label[k] = pr.label; S.res_time[k] = pr.frame;
-    }
-    if (tid == 0) { out[0] = 1; out[1] = n; }
-}
-
-// recognitionFinish (:230-309): walk the Path chain of bestFinalToken.
-__global__ void jd_finish_kernel(StreamCtl *ctl, StreamDev *streams, int s0, int n)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    StreamDev &S = streams[s0 + s];
-    const StreamCtl &c = ctl[s0 + s];
-    const Tok best = c.best_final;
-    if (!(best.score > LZ) || c.frame == 0) { S.res_n = -1; return; }
-    int k = 0;
-    for (int p = best.path; p >= 0; p = S.paths[p].prev) {
-        if (k < S.res_cap) {
-            const PathRec pr = S.paths[p];
-            S.res_label[k] = pr.label; S.res_time[k] = pr.frame;
-            S.res_score[k] = pr.score; S.res_ac[k] = pr.ac; S.res_lm[k] = pr.lm;
-            if (k == 0) { S.res_score[0] = best.score; S.res_ac[0] = best.ac; S.res_lm[0] = best.lm; }   // :293-300
-        }
-        ++k;
-    }
-    S.res_n = k;
-}
-
-__global__ void jd_mark_init_kernel(StreamCtl *ctl, int s0, int n)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) { ctl[s0 + s].needs_init = 1; ctl[s0 + s].started = 1; ctl[s0 + s].error = 0; ctl[s0 + s].T = 0; }
-}
-
-__global__ void jd_set_T_kernel(StreamCtl *ctl, int s0, int n, const int *T)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) ctl[s0 + s].T = T[s];
-}
-
-// before every k_search launch: the cluster barriers of the streams it advances start at zero
-__global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int *status, int scoring_ahead)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { StreamCtl &c = ctl[work[i].x]; c.bar = 0u; c.xbar = 0u; c.xmask = 0u; c.stop_req = 0; }
-    if (i == 0) {
-        status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0;
-        if (scoring_ahead) status[4] = 1;      // (cleared on the scoring stream, behind the scoring kernel: pf_launch)
-    }
-}
+// ------------------------------------------- Path collection, partial trace, finish, launch helpers
+#include "jd_gc.h"
 
 // --------------------------------------------------------------- host runtime
 

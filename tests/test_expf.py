@@ -1,4 +1,4 @@
-"""Exhaustive check of the kernels' own expf (jd_device.hip: jd_expf, a replica of glibc's
+"""Exhaustive check of the kernels' own expf (csrc/jd_gmm.h: jd_expf, a replica of glibc's
 algorithm) against the host libm for EVERY float32 in [-18.5, -0.001]: the argument range of
 HTKFlatModels::logAdd (HTKFlatModels.cpp:266-293: diff = y - x <= 0, cut at -18.42), plus the
 few values above it.  Bit-exact or the GPU log-likelihoods cannot be."""
