@@ -427,6 +427,13 @@ def main():
                                 "behind the timed region; search_waited is what a step still waited for its table")
                                if n_ahead else "scored before the search starts: serial step time (k_search holds the register file)"}
 
+    # the same batch in the serial order (scored, then searched with re-planning at will): the kernel's own best figure
+    ser = roofline_of(st, MN, tm_serial, leg_traffic("c2", max(1, tm_serial["search_launches"])) if default_cfg else None)
+    roofline["serial_order"] = {"ms_per_step": round(serial_ms, 3), "search_ms": round(tm_serial["search_ms"], 3),
+                                "launches": tm_serial["search_launches"], "achieved": ser["achieved"], "frac": ser["frac"],
+                                "frac_measured": ser["frac_measured"],
+                                "note": "one step behind the timed region, nothing scored ahead: not part of `value`"}
+
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample
     cpu = None
     if not args.no_cpu_baseline and world == 1:                   # (rank 0 at N = 1 only: the other ranks would wait for it)

@@ -130,7 +130,8 @@ int main(int argc, char **argv)
         auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "-fsmFName") fsm = nxt(); else if (a == "-inSymsFName") insyms = nxt();
         else if (a == "-gramFsmFName") gramFsm = nxt(); else if (a == "-gramInSymsFName") gramInSyms = nxt();
-        else if (a == "-gramOutSymsFName") gramOutSyms = nxt(); else if (a == "-pushing") pushing = JD_PUSH_WEIGHTS | JD_PUSH_LABELS;   // juicer.cpp:240 doLabelAndWeightPushing
+        // juicer.cpp:240 doLabelAndWeightPushing
+        else if (a == "-gramOutSymsFName") gramOutSyms = nxt(); else if (a == "-pushing") pushing = JD_PUSH_WEIGHTS | JD_PUSH_LABELS;
         else if (a == "-weightPushing") pushing = JD_PUSH_WEIGHTS;
         else if (a == "-lazy") lazy = 1;                                         // compose where the search goes (jd_net_create_lazy)
         else if (a == "-outSymsFName") outsyms = nxt(); else if (a == "-modelsFName") amf = nxt();

@@ -85,7 +85,8 @@ __device__ int jc_state_id(const ComposeArgs &A, unsigned cf, int g)
     unsigned long long probes = 0;
     while (id < 0) {
         if (!mine) {
-            if (++probes > A.mask) { atomicMax(A.err, (int)JC_ESTATES); return 0; }   // table full (a level far beyond max_states): give up, the host reports it
+            // table full (a level far beyond max_states): give up, the host reports it
+            if (++probes > A.mask) { atomicMax(A.err, (int)JC_ESTATES); return 0; }
             const unsigned long long old = atomicCAS(&A.keys[slot], 0ULL, key);
             if (old == 0ULL) {
                 id = atomicAdd(A.n_states, 1);
@@ -302,7 +303,8 @@ static void cl_lookahead(const jd_net *cl, std::vector<int2> &la)
             if (arc.out != 0) { I.x = std::min(I.x, arc.out); I.y = std::max(I.y, arc.out); ++a; }
             else if (st[(size_t)arc.to] == 2) { const int2 J = la[(size_t)arc.to]; if (J.x <= J.y) { I.x = std::min(I.x, J.x); I.y = std::max(I.y, J.y); } ++a; }
             else if (st[(size_t)arc.to] == 1) { I = FULL; ++a; }       // cycle of label-less arcs
-            else { st[(size_t)arc.to] = 1; stack.push_back({arc.to, cl->row_ptr[(size_t)arc.to]}); }   // (a stays: the arc is read again when the child is done)
+            // (a stays: the arc is read again when the child is done)
+            else { st[(size_t)arc.to] = 1; stack.push_back({arc.to, cl->row_ptr[(size_t)arc.to]}); }
         }
     }
     // a FULL interval below spreads upwards only through the pass above if it was set before the parent

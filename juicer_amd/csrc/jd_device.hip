@@ -284,7 +284,8 @@ struct WavePlan {
     int nb = 0, Fc = 128, n_chunks = 1, maxT = 0;
     std::vector<int> T;                        // frames per stream
     std::vector<size_t> chunk_row0;            // first entry of chunk c in row_src
-    std::vector<int> row_off, chunk_rows;      // [chunk][stream]: first row of the stream in the chunk's table; rows per chunk (a multiple of the scoring tile)
+    // [chunk][stream]: first row of the stream in the chunk's table; rows per chunk (a multiple of the scoring tile)
+    std::vector<int> row_off, chunk_rows;
     std::vector<int> row_src;                  // row -> frame of d_feats (-1: unused)
     size_t max_rows = 0, n_rows_all = 0;
 };
@@ -438,7 +439,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (rc) return rc;
     jd_dec *d = new jd_dec();
     d->net = net; d->am = am; d->device = device; d->max_streams = max_streams; d->block_size = block_size;
-    if (const char *e = getenv("JD_FC")) { const int v = atoi(e); if (v >= 16 && v <= 65536) d->Fw_env = v; }   // development: frames per chunk of a batch
+    // development: frames per chunk of a batch
+    if (const char *e = getenv("JD_FC")) { const int v = atoi(e); if (v >= 16 && v <= 65536) d->Fw_env = v; }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->n_cus = prop.multiProcessorCount;
@@ -608,7 +610,8 @@ extern "C" int jd_dec_set_max_alloc_models(jd_dec *d, int32_t max_alloc_models)
     int64_t n;
     // (a lazily composed network's n_arcs is the capacity it may grow into: the most it can ever hold)
     if (max_alloc_models < 100) n = d->net->n_arcs * max_alloc_models / 100;                        // :809-811
-    else if (max_alloc_models < 8000) n = (int64_t)max_alloc_models * 1024 * 1024 / (40 + 24 * (int64_t)d->am->max_n);   // :812-814, sizeof(NetInst) + sizeof(Token) * nStatePools
+    // :812-814, sizeof(NetInst) + sizeof(Token) * nStatePools
+    else if (max_alloc_models < 8000) n = (int64_t)max_alloc_models * 1024 * 1024 / (40 + 24 * (int64_t)d->am->max_n);
     else n = max_alloc_models;                                                                       // :815-817
     d->slots_hint = std::min<int64_t>(n, d->net->n_arcs + 65536);      // (one instance per arc at most)
     return JD_OK;
@@ -1029,7 +1032,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             }
             if (fits) {
                 for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = pos[(size_t)k]; work[(size_t)k].w = cwx[(size_t)k]; }
-                std::sort(work.begin(), work.end(), [](const int4 &x, const int4 &y) { return x.z < y.z; });   // (the kernel searches by first workgroup)
+                // (the kernel searches by first workgroup)
+                std::sort(work.begin(), work.end(), [](const int4 &x, const int4 &y) { return x.z < y.z; });
                 grid = nwg;
                 xl = true;
             }
@@ -1461,7 +1465,8 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
     Prefetch callers = std::move(d->pf_next);
     d->pf_next = Prefetch();
     if (callers.state != 1) callers.drop();
-    struct Restore { Prefetch &p; ~Restore() { p.drop(); } } callers_guard{callers};
+    // (on an error way out nothing scored or announced ahead survives: the caller may free the features next)
+    struct Restore { jd_dec *d; Prefetch &p; bool ok; ~Restore() { p.drop(); if (!ok) pf_discard(d); } } callers_guard{d, callers, false};
     for (int u0 = 0; u0 < n_utts; u0 += d->max_streams) {
         const int nb = std::min(d->max_streams, n_utts - u0);
         for (int i = 0; i < nb; ++i) {
@@ -1512,6 +1517,7 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         d->stream_started[(size_t)s] = 0; d->stream_T[(size_t)s] = 0;
         if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }   // (the batch took the stream over)
     }
+    callers_guard.ok = true;
     return first_err;
 }
 

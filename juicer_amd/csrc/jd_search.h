@@ -860,7 +860,8 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             }
         }
 #if defined(JD_FINE) && JD_FINE == 1
-        if (threadIdx.x == 0) { const long long tn_ = wall_clock64(); sh.fclk[3] += tn_ - ft_; sh.fclk[4] += 1; }   // issue of stage K + stores (not drained)
+        // issue of stage K + stores (not drained)
+        if (threadIdx.x == 0) { const long long tn_ = wall_clock64(); sh.fclk[3] += tn_ - ft_; sh.fclk[4] += 1; }
 #endif
         // the next chunk becomes the current one
         u = un; is_new = n_is_new; valid = n_valid; nb = n_nb; h0 = nh0; h1 = nh1; h2 = nh2; kv = nkv;
@@ -1041,7 +1042,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const unsigned soff = (real || (valid && !LZY)) ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
             const v4i sk = ld16(V.srec_r, (real && exit_kind) ? soff : OOB_OFF);   // {key0, keyL}
             int2 srow = make_int2(0, 0);
-            if (!LZY) { const int sti = valid ? state : 0; srow = make_int2(C.row_ptr[sti], C.row_ptr[sti + 1]); }   // (static, shared by the streams: cached loads)
+            // (static, shared by the streams: cached loads)
+            if (!LZY) { const int sti = valid ? state : 0; srow = make_int2(C.row_ptr[sti], C.row_ptr[sti + 1]); }
             const bool lab_on = exit_kind && real && info.y != 0;      // (labelled exit tokens: a few per cent of the items)
             int lb;
             if (LZY) lb = ld16(V.larcs, lab_on ? (unsigned)info.x * 16u : OOB_OFF).w;
@@ -1199,7 +1201,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 un.lm = tg.lm + Bk.w;
                 mk = un.score > endTh;
             } else if (is_tee) {                                       // :584-600 tee model
-                const float tee = tee_lds ? sh.tee[inl - 1] : CL(C.hmm_tee + (inl - 1));   // (an atomic load: never merged with the LDS one into a flat load)
+                // (an atomic load: never merged with the LDS one into a flat load)
+                const float tee = tee_lds ? sh.tee[inl - 1] : CL(C.hmm_tee + (inl - 1));
                 const float ns2 = ns + tee;
                 un.score = ns2;
                 un.ac = tg.ac + tee;
