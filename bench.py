@@ -145,7 +145,7 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
            "search_ms": round(tm["search_ms"], 3), "gmm_ms": round(gmm_alone if gmm_alone is not None else tm["gmm_ms"], 3),
            "scored_ahead": bool(tm["prefetched"]),
            "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
-                                                                              "tot_proc_end_hyps", "tot_arcs_visited")},
+                                                                              "tot_proc_end_hyps", "tot_arcs_visited", "tot_paths")},
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
            "roofline": roofline_of(st, am.max_n, tm, leg_traffic(pmc_leg, max(1, tm["search_launches"])) if pmc_leg else None),
            "setup_s": round(time.perf_counter() - t0 - sum(r[0] for r in runs), 1)}
