@@ -638,6 +638,26 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
     if (rc) return rc;
     const int B = d->max_streams, MN = d->am->max_n;
     const int64_t rec_bytes = (MN <= 5) ? RecLayout<3>::REC_BYTES : RecLayout<6>::REC_BYTES;
+    // a stream's arenas: 256-byte aligned pieces of one block (two uses of the same list: sizes with blk = null, then pointers)
+#define A(p, n) do { const size_t bytes_ = (std::max<size_t>((size_t)(n), 1) * sizeof(*(p)) + 255) & ~(size_t)255; \
+                     if (blk) (p) = (typename std::remove_reference<decltype(p)>::type)(blk + off); off += bytes_; } while (0)
+#define ARENAS() do { \
+        A(S.rec, 2 * d->cap_slots * (rec_bytes / 4)); \
+        A(S.live, d->net->n_arcs); \
+        A(S.srec, d->net->n_states); \
+        A(S.items, 4 * d->cap_items); \
+        A(S.newl, d->cap_new); A(S.dirtyl, 2 * d->cap_new); \
+        A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW); \
+        A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths); A(S.gc_state, sizeof(GcState) / 4); \
+        A(S.hist, 2 * HIST_MAX_BINS); } while (0)
+    const bool auto_slots = d->cap_slots <= 0, auto_items = d->cap_items <= 0, auto_paths = d->cap_paths <= 0;
+    // The slab a previous decoder left on this device (slab_take) is there without waiting for the driver to clear
+    // memory - 5-6 s for the default share of a 288 GB device - but only if this decoder's arenas FIT it, and two
+    // decoders never ask for quite the same: the free memory has moved by a table or a network since.  So when the
+    // sizes come out above the cached slab by less than a quarter, they are scaled down to it (second pass).
+    double fit = 1.0;
+    for (int pass = 0; pass < 3; ++pass) {
+    if (pass) { if (auto_slots) d->cap_slots = 0; if (auto_items) d->cap_items = 0; if (auto_paths) d->cap_paths = 0; }
     {   // Capacities the caller did not set: sized for 288 GB of HBM, not for frugality.  70% of the
         // free memory is split over the streams; of a stream's share (after its per-arc / per-state
         // tables) 50% goes to instance records, 20% to frontier items, 30% to Path records - each
@@ -648,7 +668,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         free_b += slab_cached_bytes(d->device);                        // (the cached slab is this decoder's to take)
         const double n_arcs = (double)d->net->n_arcs, n_states = (double)d->net->n_states;
         const double fixed = n_arcs * 1.0 + n_states * (double)sizeof(StateRec) + 2.0 * d->Fc * d->am->n_gmm * sizeof(float);
-        const double budget = std::max(0.0, mem_fraction * (double)free_b / B - fixed);
+        const double budget = std::max(0.0, fit * mem_fraction * (double)free_b / B - fixed);
         const double rec_b = 2.0 * rec_bytes, item_b = 2.0 * (sizeof(Tok) + sizeof(int4)) + 32.0;
         const double path_b = 2.0 * sizeof(PathRec) + 4.0;
         auto pick = [](double share, int64_t lo, int64_t hi) {
@@ -675,6 +695,16 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         d->cap_items = std::max<int64_t>(d->cap_items, 64 * SW);
         d->cap_new = std::min<int64_t>(4 * d->cap_items, 0x7fffff00LL);
     }
+    {
+        StreamDev S;
+        char *blk = nullptr;
+        size_t off = 0;
+        ARENAS();
+        const double need = (double)off * B, cached = (double)slab_cached_bytes(d->device);
+        if (cached <= 0.0 || need <= cached || need > 1.25 * cached || !(auto_slots || auto_items || auto_paths)) break;
+        fit *= 0.998 * cached / need;
+    }
+    }
     d->C.cap_slots = (unsigned)d->cap_slots; d->C.cap_items = (unsigned)d->cap_items; d->C.cap_new = (unsigned)d->cap_new;
     d->C.cap_paths = (int)d->cap_paths;
     // a stream stops for a collection when its Path records pass this mark (checked between frames): half
@@ -694,17 +724,6 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         // the default 70 % of a 288 GB device.
         char *blk = nullptr;
         size_t off = 0;
-#define A(p, n) do { const size_t bytes_ = (std::max<size_t>((size_t)(n), 1) * sizeof(*(p)) + 255) & ~(size_t)255; \
-                     if (blk) (p) = (typename std::remove_reference<decltype(p)>::type)(blk + off); off += bytes_; } while (0)
-#define ARENAS() do { \
-        A(S.rec, 2 * d->cap_slots * (rec_bytes / 4)); \
-        A(S.live, d->net->n_arcs); \
-        A(S.srec, d->net->n_states); \
-        A(S.items, 4 * d->cap_items); \
-        A(S.newl, d->cap_new); A(S.dirtyl, 2 * d->cap_new); \
-        A(S.tot, TOT_N * MAXW); A(S.item_end, MAXW); \
-        A(S.paths, d->cap_paths); A(S.paths2, d->cap_paths); A(S.gc_idx, d->cap_paths); A(S.gc_state, sizeof(GcState) / 4); \
-        A(S.hist, 2 * HIST_MAX_BINS); } while (0)
         ARENAS();
         if (s == 0) {
             stream_bytes = off;
