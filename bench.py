@@ -13,6 +13,16 @@ by torchrun; under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Scaling
 is weak by default (64 utterances per GPU); `--total-utts 512` is BASELINE.json
 configs[2]: ONE fixed batch dealt over the ranks by length (strong scaling).
 
+Batches follow each other, so by default every step announces the batch behind it
+(jd_dec_prefetch_scores) and that batch's likelihood table is scored on the CUs the
+current batch's search leaves idle as its utterances end; the announced batch is the
+same synthetic batch again, scored from its features every time.  The timed region
+of K steps therefore holds K searches and K scorings, like the serial order does: the
+table the first timed step searches was scored during the last warm-up step, the
+table scored during the last timed step is never searched.  --no-score-ahead times
+the serial order; one serial-order step is also run BEHIND the timed region and
+reported as roofline.serial_order / roofline.gmm.serial_order_* (not part of `value`).
+
 After the timed region rank 0 of a 1-GPU run also times (1 warm-up + 3 timed
 passes each: median and minimum) the other single-GPU workloads of BASELINE.json
 and reports them under "legs": the north_star target (10M-arc class graph, beam

@@ -1082,3 +1082,49 @@ def test_scores_ahead_of_the_search(small, hold):
     for i, g in enumerate(gs):
         assert bit_exact(g, want["B"][i])
     gd3.close(); gd.close()
+
+
+def test_scores_ahead_with_collections_and_replans(small):
+    """Scoring ahead together with everything that cuts a launch short: a Path arena so small that streams stop for
+    collections all the time, re-planning forced at toy size (the launches beside a scoring are then held or cut by
+    the measured ratio), waves inside one call.  Every batch equals the oracle bit for bit."""
+    import os
+    import torch
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0)
+    od = OracleDecoder(onet, oam, **kw)
+    batches = [[np.concatenate([feats[(b + 2 * i + j) % len(feats)] for j in range(1 + (i + b) % 4)]) for i in range(10)] for b in range(3)]
+    want = [[od.decode_certified(x) for x in bt] for bt in batches]
+    dev = torch.device("cuda", 0)
+    bufs = []
+    for bt in batches:
+        offs = np.zeros(len(bt) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([x.shape[0] for x in bt])
+        bufs.append((torch.from_numpy(np.concatenate(bt)).to(dev), offs))
+    env = {"JD_REBALANCE_MIN_US": "0", "JD_REBALANCE_FRAC": "0.05"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for streams in (10, 4):                                       # one wave per batch / three waves per batch
+            gd = capi.Decoder(gnet, gam, max_streams=streams, max_paths=1 << 12, **kw)
+            for rep in range(7):
+                b, nxt = rep % 3, (rep + 1) % 3
+                gd.prefetch_scores(bufs[nxt][0].data_ptr(), bufs[nxt][1], 0)
+                gs = gd.decode_batch_device(bufs[b][0].data_ptr(), bufs[b][1], 0)
+                tm = gd.last_timing()
+                if streams == 10:
+                    assert tm["prefetched"] == (1 if rep > 0 else 0), tm
+                else:
+                    assert tm["prefetched"] == 2, tm              # waves 2 and 3 of the call (its first wave is another batch's size)
+                for i, g in enumerate(gs):
+                    assert_hyp_matches(g, want[b][i], "streams %d rep %d utt %d" % (streams, rep, i))
+                    assert bit_exact(g, want[b][i])
+            gd.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
