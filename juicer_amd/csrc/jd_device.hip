@@ -1298,13 +1298,20 @@ static int pf_launch(jd_dec *d)
     if (F.state != 1) return JD_OK;
     const int buf = d->cur_buf ^ 1;
     const int G = d->am->n_gmm;
-    int rc = ensure_table(d, buf, F.plan.max_rows * G, F.plan.n_rows_all);
-    if (rc) return rc;
-    HIPCHK(hipEventCreate(&F.ev0)); HIPCHK(hipEventCreate(&F.ev1));
-    HIPCHK(hipMemcpyAsync(d->d_row_src[buf], F.plan.row_src.data(), F.plan.n_rows_all * sizeof(int), hipMemcpyHostToDevice, d->s_gmm));
-    HIPCHK(hipEventRecord(F.ev0, d->s_gmm));
-    rc = launch_gmm(d->am, d->amb, F.feats, d->d_row_src[buf], F.plan.chunk_rows[0], d->d_ll[buf], d->s_gmm, 0, true);
-    if (rc) return rc;
+    // Scoring ahead is an optimisation: when it cannot be set up (no room for the second table, ...) the announcement
+    // is dropped, the batch is scored when it is decoded, and the search launch beside us may be re-planned again.
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        F.drop();
+        (void)hipMemsetAsync(d->d_status + 4, 0, sizeof(int), d->s_gmm);
+        return JD_OK;
+    };
+    if (ensure_table(d, buf, F.plan.max_rows * G, F.plan.n_rows_all) != JD_OK) return give_up();
+    if (hipEventCreate(&F.ev0) != hipSuccess || hipEventCreate(&F.ev1) != hipSuccess) return give_up();
+    if (hipMemcpyAsync(d->d_row_src[buf], F.plan.row_src.data(), F.plan.n_rows_all * sizeof(int), hipMemcpyHostToDevice, d->s_gmm) != hipSuccess ||
+        hipEventRecord(F.ev0, d->s_gmm) != hipSuccess)
+        return give_up();
+    if (launch_gmm(d->am, d->amb, F.feats, d->d_row_src[buf], F.plan.chunk_rows[0], d->d_ll[buf], d->s_gmm, 0, true) != JD_OK) return give_up();
     HIPCHK(hipEventRecord(F.ev1, d->s_gmm));
     HIPCHK(hipMemsetAsync(d->d_status + 4, 0, sizeof(int), d->s_gmm)); // the search may be re-planned again
     F.buf = buf; F.state = 2;
