@@ -61,20 +61,43 @@ def pack_hyps(hyps: Sequence, max_words: int, truncate: bool = False):
     return ints, flts
 
 
+def _unpack_one(ints: np.ndarray, flts: np.ndarray, max_words: int, i: int) -> dict:
+    n = int(ints[i, 0])
+    k = max(n, 0)
+    return dict(n=n, n_frames=int(ints[i, 1]),
+                label=ints[i, 2:2 + k].copy(), time=ints[i, 2 + max_words:2 + max_words + k].copy(),
+                tot_score=float(flts[i, 0]), tot_ac=float(flts[i, 1]), tot_lm=float(flts[i, 2]),
+                score=flts[i, 3:3 + k].copy(), ac=flts[i, 3 + max_words:3 + max_words + k].copy(),
+                lm=flts[i, 3 + 2 * max_words:3 + 2 * max_words + k].copy())
+
+
 def unpack_hyps(ints: np.ndarray, flts: np.ndarray, max_words: int) -> List[dict]:
-    out = []
-    for i in range(ints.shape[0]):
-        n = int(ints[i, 0])
-        k = max(n, 0)
-        out.append(dict(n=n, n_frames=int(ints[i, 1]),
-                        label=ints[i, 2:2 + k].copy(), time=ints[i, 2 + max_words:2 + max_words + k].copy(),
-                        tot_score=float(flts[i, 0]), tot_ac=float(flts[i, 1]), tot_lm=float(flts[i, 2]),
-                        score=flts[i, 3:3 + k].copy(), ac=flts[i, 3 + max_words:3 + max_words + k].copy(),
-                        lm=flts[i, 3 + 2 * max_words:3 + 2 * max_words + k].copy()))
-    return out
+    return [_unpack_one(ints, flts, max_words, i) for i in range(ints.shape[0])]
 
 
-def gather_hyps(hyps: Sequence, per_rank: int, max_words: int = 256, device=None, index: Sequence[int] = None) -> List[dict]:
+class GatheredHyps(Sequence):
+    """The gathered 1-best records of all ranks, in utterance order: a sequence of dicts {n, n_frames, label, time,
+    score, ac, lm, tot_*} that are made when they are asked for - every rank holds every record after the gather,
+    and turning 512 of them into Python objects takes longer than the collective (a step of the 8-GPU bench would
+    spend a tenth of its time on it)."""
+
+    def __init__(self, ints: np.ndarray, flts: np.ndarray, max_words: int, rows: np.ndarray):
+        self._i, self._f, self._mw, self._rows = ints, flts, max_words, rows
+
+    def __len__(self):
+        return int(self._rows.shape[0])
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[j] for j in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        return _unpack_one(self._i, self._f, self._mw, int(self._rows[k]))
+
+
+def gather_hyps(hyps: Sequence, per_rank: int, max_words: int = 256, device=None, index: Sequence[int] = None) -> "GatheredHyps":
     """all_gather the 1-best records of every rank - the ONE collective of a step.  Every rank contributes
     exactly `per_rank` records (pad with n=-2 records when a shard is short).  A record holds max_words
     words; a hypothesis that is longer travels truncated with its true word count, every rank sees that in
@@ -113,14 +136,12 @@ def gather_hyps(hyps: Sequence, per_rank: int, max_words: int = 256, device=None
         if longest <= max_words:
             break
         max_words = longest                                        # (the same decision on every rank: all see the same records)
-    keep = gi[:, 0] != -2
-    gi, gf = gi[keep], gf[keep]
-    out = unpack_hyps(gi, gf, max_words)
-    if index is not None:
-        ordered = [None] * len(out)
-        for h, u in zip(out, gi[:, -1]):
-            ordered[int(u)] = h
-        if any(h is None for h in ordered):
-            raise ValueError("gathered records do not cover utterances 0..%d" % (len(out) - 1))
-        out = ordered
-    return out
+    rows = np.nonzero(gi[:, 0] != -2)[0]
+    if index is not None:                               # global utterance order: record of utterance u at rows[u]
+        u = gi[rows, -1].astype(np.int64)
+        if not np.array_equal(np.sort(u), np.arange(u.shape[0])):
+            raise ValueError("gathered records do not cover utterances 0..%d" % (u.shape[0] - 1))
+        ordered = np.empty_like(rows)
+        ordered[u] = rows
+        rows = ordered
+    return GatheredHyps(gi, gf, max_words, rows)
