@@ -109,7 +109,7 @@ def leg_traffic(leg, launches):
 
 
 def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, gnet=None, pmc_leg=None, oracle_feats=None,
-            oracle_net=None, ahead=True):
+            oracle_net=None, ahead=True, max_streams=0):
     """One extra workload: warm-up pass + timed passes on one GPU (value = the MEDIAN pass), its own roofline.
     gnet: a network that exists already (composed on the device); net is then only asked for its size.
     pmc_leg: the name the leg's PMC passes are filed under (leg_traffic).  oracle_utts: that many utterances are
@@ -121,7 +121,7 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
     U = len(feats)
     t0 = time.perf_counter()
     dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam,
-                       max_hyps=max_hyps, device=dev.index, max_streams=U)
+                       max_hyps=max_hyps, device=dev.index, max_streams=max_streams or U)
     offs = np.zeros(U + 1, dtype=np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in feats])
     d_feats = torch.from_numpy(np.concatenate(feats)).to(dev)
@@ -502,6 +502,12 @@ def main():
         try:
             no = 0 if args.no_cpu_baseline else 2                   # utterances the CPU oracle decodes per leg
             legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev, oracle_utts=no)
+            # configs[2]'s batch (512 utterances) on ONE GPU: waves of 128 streams inside one call, each wave's table scored
+            # beside the wave before it - what the GPU does when a batch is not bounded by its longest utterance
+            _, _, f512, _ = synth.config_c2(seed=args.seed, n_utts=512, target_arcs=args.arcs)
+            legs["configs2_batch_512_on_one_gpu"] = run_leg("configs[2]'s 512-utterance batch on one GPU, 128 streams", am, net, f512, args.beam, 0, dev,
+                                                            oracle_utts=no, max_streams=128)
+            del f512
             a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=64, n_words=10000, n_tri_hist=100_000)
             legs["north_star_10M_beam200"] = run_leg("north_star target (trigram-shaped)", a4, n4, f4, 200.0, 0, dev,
                                                      oracle_utts=no, pmc_leg="north" if args.seed == 0 else None)
