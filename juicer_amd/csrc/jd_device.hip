@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <queue>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -329,7 +330,11 @@ struct jd_dec {
     int rebalance = 1;                    // cut a launch short and plan the rest anew when part of the grid idles (JD_REBALANCE=0: off)
     double rebalance_frac = 0.2;          // ... this part (JD_REBALANCE_FRAC)
     double rebalance_min_us = 4000.0;     // ... and only launches predicted to last this long (JD_REBALANCE_MIN_US; 0 in tests)
-    double model_a_us = 10.0, model_b_us = 360.0;   // cost model of a stream-frame: a + b / workgroups (launch_search)
+    double model_a_us = 10.0, model_b_us = 360.0;   // cost model of a stream-frame: a + b / workgroups (launch_search), as fitted in round 2
+    double pf_gmm_weight = 1.35;          // scoring beside a search is priced at this times its CU-time on its own (the CUs come late, and piecemeal; JD_PF_GMM_WEIGHT)
+    int plan_min_cw = 2;                  // greedy plan: workgroups every stream starts with (JD_PLAN_MIN_CW)
+    int plan_mode = 0;                    // 0: round 2's constants + bisection; 1: measured curve (model2_*) + greedy whole workgroups (JD_PLAN)
+    double model2_a_us = 24.6, model2_b_us = 61.4;   // ... as measured in round 3 (JD_MODEL2_A / JD_MODEL2_B)
     // b was fitted at configs[1]'s load (23.7 k instances + arcs per stream-frame); it scales with the load,
     // which a decoder learns from the batches it has decoded (first batch: as fitted)
     double load_scale = 1.0, load_sum = 0.0, load_frames = 0.0;
@@ -550,6 +555,11 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_REBALANCE_MIN_US")) d->rebalance_min_us = atof(e);
     if (const char *e = getenv("JD_MODEL_A")) d->model_a_us = atof(e);
     if (const char *e = getenv("JD_MODEL_B")) d->model_b_us = atof(e);
+    if (const char *e = getenv("JD_PLAN")) d->plan_mode = atoi(e) != 0;
+    if (const char *e = getenv("JD_PLAN_MIN_CW")) d->plan_min_cw = std::max(1, atoi(e));
+    if (const char *e = getenv("JD_PF_GMM_WEIGHT")) d->pf_gmm_weight = atof(e);
+    if (const char *e = getenv("JD_MODEL2_A")) d->model2_a_us = atof(e);
+    if (const char *e = getenv("JD_MODEL2_B")) d->model2_b_us = atof(e);
     if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0;                      // development
     if (const char *e = getenv("JD_XL_SLACK")) { const double v = atof(e); if (v >= 1.0 && v <= 10.0) d->xl_slack = v; }
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
@@ -978,7 +988,48 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // configs[1] (DESIGN.md "cluster sizes"); sizing by a stream's measured work per frame (a pilot
         // launch, or the previous chunk's counters) was tried and is slower - the work of the frames
         // ahead is not the work of the frames behind.
-        const double a_us = d->model_a_us, b_us = d->model_b_us * d->load_scale;
+        // plan_mode 1 (JD_PLAN=1; measured, not the default): the MEASURED curve - configs[1]'s longest stream with every
+        // cluster capped at C = 1 .. 8 workgroups takes 86, 56, 46, 41, 38, 35.5, -, 32 us per frame: a + b / C with a = 24.6,
+        // b = 61.4 to within 2 % - and whole workgroups dealt GREEDILY: every stream starts with plan_min_cw, the next one
+        // goes to the stream that would finish last, until the grid is used up; beside a launch the next batch's table is
+        // scored, so workgroups that would shorten the launch below what the chip needs for BOTH (a cluster's barrier
+        // share a * C burns CU-time) are not dealt.  The launch itself gets much shorter (configs[1]: 38.5 -> 35.3 ms
+        // un-cut, 29.6 with every workgroup dealt) but the step does not: scored ahead it is bound by CU-time either
+        // way (38.2-39.2 against 38.3-39.6 ms), in the serial order it gains 5-7 % with b = 61.4 and nothing with a
+        // b that is safe for streams heavier than the longest one (one b serves all streams, and a stream that gets
+        // ONE workgroup on a b that is too small is the straggler), and the configs[4] graph loses 1-2 %.  plan_mode 0:
+        // the constants fitted in round 2 (a = 10, b = 360 - right at 58 ms per step, wrong now, but erring towards
+        // larger short clusters, which is what re-planning and scoring ahead forgive) and the floor of the continuous
+        // solution.
+        const bool greedy = d->plan_mode == 1;
+        const double a_us = greedy ? d->model2_a_us : d->model_a_us, b_us = (greedy ? d->model2_b_us : d->model_b_us) * d->load_scale;
+        std::vector<int> cw((size_t)n_work, 1);
+        int used = 0;
+        if (greedy) {
+            std::priority_queue<std::pair<double, int>> pq;
+            double cu_us = 0.0;                                            // CU-time of the plan so far
+            const int c0 = std::max(1, std::min(std::min(d->plan_min_cw, max_cw), nwg / n_work));   // every stream starts with this many
+            for (int k = 0; k < n_work; ++k) {
+                const double fr = std::max((*weight)[(size_t)k], 1.0);
+                cw[(size_t)k] = c0;
+                pq.push({fr * (a_us + b_us / c0), k});
+                cu_us += fr * (a_us * c0 + b_us);
+            }
+            used = n_work * c0;
+            const double gmm_cu_us = (d->pf_armed && d->pf_next.state == 1)
+                                   ? d->pf_gmm_weight * 1e3 * d->gmm_ms_per_row * (double)d->pf_next.plan.chunk_rows[0] * nwg : 0.0;
+            while (used < nwg && !pq.empty()) {
+                const std::pair<double, int> top = pq.top();
+                const int k = top.second;
+                if (cw[(size_t)k] >= max_cw) break;                        // the launch cannot end sooner than this stream
+                if (gmm_cu_us > 0.0 && top.first <= (cu_us + gmm_cu_us) / nwg) break;
+                pq.pop();
+                const double fr = std::max((*weight)[(size_t)k], 1.0);
+                ++cw[(size_t)k]; ++used;
+                cu_us += fr * a_us;
+                pq.push({fr * (a_us + b_us / cw[(size_t)k]), k});
+            }
+        }
         auto need = [&](double tau, std::vector<double> *out) {
             double tot = 0.0;
             for (int k = 0; k < n_work; ++k) {
@@ -991,14 +1042,13 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             }
             return tot;
         };
+        if (!greedy) {
         double lo_t = 0.0, hi_t = 1.0;
         while (need(hi_t, nullptr) > nwg && hi_t < 1e15) hi_t *= 2.0;
         for (int it = 0; it < 60; ++it) { const double mid = 0.5 * (lo_t + hi_t); if (need(mid, nullptr) > nwg) lo_t = mid; else hi_t = mid; }
         std::vector<double> want((size_t)n_work);
         need(hi_t, &want);
-        std::vector<int> cw((size_t)n_work, 1);
         std::vector<std::pair<double, int>> frac;
-        int used = 0;
         for (int k = 0; k < n_work; ++k) {
             cw[(size_t)k] = std::max(1, std::min(max_cw, (int)want[(size_t)k]));
             used += cw[(size_t)k];
@@ -1013,6 +1063,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             for (int k = 1; k < n_work; ++k) if (cw[(size_t)k] > cw[(size_t)big]) big = k;
             if (cw[(size_t)big] <= 1) break;
             --cw[(size_t)big]; --used;
+        }
         }
         // XCD-local launch (jd_search.h): every cluster inside one eighth of the grid - the clusters go, largest
         // first, into the eighth with the most room; one that fits nowhere shrinks to the room there is, and what
