@@ -276,6 +276,9 @@ typedef struct jd_hyp {
  * disables the histogram (WFSTDecoderLite.cpp:76-82).  block_size mirrors
  * IModels::setBlockSize (1..20, juicer.cpp:255); it never changes results.
  * device = HIP device ordinal; max_streams = utterances decoded concurrently.
+ * Like the reference's decoder (juicer.cpp:647-652) a decoder does not own its network or models: both must
+ * outlive it - jd_dec_destroy still talks to the network (utterances of the streaming interface that were never
+ * finished leave a lazily composed network there).
  */
 int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am,
                   float start_beam, float main_beam, float end_beam, float word_beam,
@@ -312,6 +315,33 @@ int jd_stream_init(jd_dec *d, int32_t s);
 int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t n_frames);
 /* IDecoder::finish() (Decoder.h:28). */
 int jd_stream_finish(jd_dec *d, int32_t s, jd_hyp *out);
+/* jd_stream_push for several streams at once (each at most once per call): ONE scoring launch and ONE search launch
+ * for all of them - the streams may sit at different frames.  Not with partial traces (jd_dec_set_partial_interval). */
+int jd_streams_push(jd_dec *d, int32_t n, const int32_t *streams, const float *const *frames, const int32_t *n_frames);
+/* max_streams / feature vector size of a decoder */
+int jd_dec_info(const jd_dec *d, int32_t *max_streams, int32_t *vec_size);
+
+/* ------------------------------------------------------------------ many IDecoder instances on one decoder
+ *
+ * The reference's harness decodes serially through ONE IDecoder (DecoderBatchTest.cpp:738-771 ->
+ * DecoderSingleTest.cpp:259-324) and scales out as independent processes over split file lists
+ * (doc/userman/juicer_userman.tex:584).  A broker lets N such serial callers - threads of one process - share the
+ * streams of one decoder: each drives its own client with init / push / finish, and a worker thread turns what has
+ * been pushed since its last tick into one scoring launch and one search launch over all the streams concerned
+ * (jd_streams_push).  The decoder must not be used directly while a broker owns it; clients may be driven from
+ * different threads, one thread per client at a time.  jd_hyp arrays stay valid until the client's next init.
+ * Environment: JD_BROKER_TICK_FRAMES (frames of one client per tick, default 256), JD_BROKER_COALESCE_US (how long a
+ * tick waits for the other clients' frames, default 150). */
+typedef struct jd_broker jd_broker;
+typedef struct jd_broker_stats { int64_t ticks, frames, stream_ticks; } jd_broker_stats;   /* launches, frames, streams summed over ticks */
+int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients);   /* n_clients <= the decoder's max_streams */
+void jd_broker_destroy(jd_broker *b);                                    /* (the decoder is the caller's to destroy, afterwards) */
+int jd_broker_open(jd_broker *b, int32_t *client);
+int jd_broker_close(jd_broker *b, int32_t client);
+int jd_broker_init(jd_broker *b, int32_t client);                                              /* IDecoder::init */
+int jd_broker_push(jd_broker *b, int32_t client, const float *frames, int32_t n_frames);       /* IDecoder::processFrame x n: returns once the frames are taken */
+int jd_broker_finish(jd_broker *b, int32_t client, jd_hyp *out);                               /* IDecoder::finish */
+int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out);
 
 /*
  * PARTIAL_DECODING (WFSTDecoderLite.cpp:822-896, compiled in by src/CMakeLists.txt:5): the Path

@@ -312,6 +312,10 @@ struct LazyNetHolder_ {
     LazyNetHolder_(const jd_net *cl, const jd_net *g, const jd_am *models, int device, long long maxStates, long long maxArcs, int pushing)
         : lazyNet_(0)
     {
+        if (pushing < 0 || pushing > (JD_PUSH_WEIGHTS | JD_PUSH_LABELS)) {
+            fprintf(stderr, "juicer_amd: doPushing is a mask of JD_PUSH_WEIGHTS | JD_PUSH_LABELS (got %d)\n", pushing);
+            exit(1);
+        }
         if (jd_net_create_lazy(&lazyNet_, cl, g, models, device, maxStates, maxArcs, pushing) != JD_OK) {
             fprintf(stderr, "juicer_amd: %s\n", jd_last_error());
             exit(1);
@@ -325,6 +329,14 @@ public:
                            float phoneEndPruneWin, int maxEmitHyps, int doPushing = 0, int device = 0,
                            long long maxStates = 0, long long maxArcs = 0, int blockSize = 5, int flushFrames = 64)
         : LazyNetHolder_(clNetwork, gNetwork, models, device, maxStates, maxArcs, doPushing),
+          GpuWFSTDecoder(lazyNet_, models, 0.0f, emitPruneWin, phoneEndPruneWin, 0.0f, maxEmitHyps, device, blockSize, flushFrames) {}
+    // the reference's own argument type: `true` is doLabelAndWeightPushing, i.e. BOTH halves (a bool passed to the int
+    // mask above would silently mean JD_PUSH_WEIGHTS alone)
+    GpuWFSTOnTheFlyDecoder(const jd_net *clNetwork, const jd_net *gNetwork, const jd_am *models, float emitPruneWin,
+                           float phoneEndPruneWin, int maxEmitHyps, bool doLabelAndWeightPushing, int device = 0,
+                           long long maxStates = 0, long long maxArcs = 0, int blockSize = 5, int flushFrames = 64)
+        : LazyNetHolder_(clNetwork, gNetwork, models, device, maxStates, maxArcs,
+                         doLabelAndWeightPushing ? (JD_PUSH_WEIGHTS | JD_PUSH_LABELS) : 0),
           GpuWFSTDecoder(lazyNet_, models, 0.0f, emitPruneWin, phoneEndPruneWin, 0.0f, maxEmitHyps, device, blockSize, flushFrames) {}
     // composed states / arcs materialised so far
     void composedSize(long long &states, long long &arcs) const

@@ -78,7 +78,9 @@ EXPORTS = [
     "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
     "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
     "jd_net_lazy_set_high_water", "jd_net_lazy_generation", "jd_release_cached_memory", "jd_net_push_labels",
-    "jd_dec_prefetch_scores",
+    "jd_dec_prefetch_scores", "jd_streams_push", "jd_dec_info",
+    "jd_broker_create", "jd_broker_destroy", "jd_broker_open", "jd_broker_close", "jd_broker_init", "jd_broker_push",
+    "jd_broker_finish", "jd_broker_get_stats",
 ]
 
 _lib = None
@@ -392,6 +394,15 @@ class Decoder:
         _check(lib().jd_stream_finish(self.h, C.c_int32(s), C.byref(h)))
         return _hyp_from_c(h)
 
+    def streams_push(self, streams, frames):
+        """jd_stream_push for several streams at once: one scoring launch + one search launch (jd_streams_push)."""
+        xs = [_f32(f) for f in frames]
+        n = len(xs)
+        ss = _i32(list(streams))
+        ptrs = (C.POINTER(C.c_float) * n)(*[_p(x, C.c_float) for x in xs])
+        nfr = _i32([x.shape[0] for x in xs])
+        _check(lib().jd_streams_push(self.h, C.c_int32(n), _p(ss, C.c_int32), ptrs, _p(nfr, C.c_int32)))
+
     def set_max_alloc_models(self, v: int):
         """WFSTDecoderLite::setMaxAllocModels (:807-820): percentage / MB / count, see juicer_amd.h."""
         _check(lib().jd_dec_set_max_alloc_models(self.h, C.c_int32(v)))
@@ -472,3 +483,53 @@ class Decoder:
 
     def __del__(self):
         self.close()
+
+
+class BrokerStats(C.Structure):
+    _fields_ = [("ticks", C.c_int64), ("frames", C.c_int64), ("stream_ticks", C.c_int64)]
+
+
+class Broker:
+    """Many serial IDecoder callers (threads) on the streams of one Decoder (jd_broker_*): each caller opens a client
+    and drives it with init / push / finish; a worker thread of the library coalesces what the clients have pushed into
+    one scoring launch and one search launch per tick.  ctypes releases the GIL during the calls, so Python threads
+    do run side by side.  The Decoder must not be used directly while the broker lives."""
+
+    def __init__(self, dec: Decoder, n_clients: int = 0):
+        self.dec = dec
+        self.h = C.c_void_p()
+        _check(lib().jd_broker_create(C.byref(self.h), dec.h, C.c_int32(n_clients or dec.max_streams)))
+
+    def open(self) -> int:
+        c = C.c_int32(-1)
+        _check(lib().jd_broker_open(self.h, C.byref(c)))
+        return c.value
+
+    def close_client(self, client: int):
+        _check(lib().jd_broker_close(self.h, C.c_int32(client)))
+
+    def init(self, client: int):
+        _check(lib().jd_broker_init(self.h, C.c_int32(client)))
+
+    def push(self, client: int, frames):
+        x = _f32(frames)
+        _check(lib().jd_broker_push(self.h, C.c_int32(client), _p(x, C.c_float), C.c_int32(x.shape[0])))
+
+    def finish(self, client: int) -> Hyp:
+        h = CHyp()
+        _check(lib().jd_broker_finish(self.h, C.c_int32(client), C.byref(h)))
+        return _hyp_from_c(h)
+
+    def stats(self) -> dict:
+        st = BrokerStats()
+        _check(lib().jd_broker_get_stats(self.h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in BrokerStats._fields_}
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.jd_broker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+

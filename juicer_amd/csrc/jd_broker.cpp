@@ -1,0 +1,243 @@
+// jd_broker.cpp - many IDecoder instances on the streams of ONE decoder.
+//
+// The reference's harness is serial: DecoderBatchTest::run decodes one list entry after the other through one
+// IDecoder (src/DecoderBatchTest.cpp:738-771 -> DecoderSingleTest::decodeUtterance, src/DecoderSingleTest.cpp:259-324),
+// and its users scale out by running several such processes over split file lists (doc/userman/juicer_userman.tex:584).
+// A GPU decoder serves one utterance at a few hundred times real time but a batch of them at ten thousand: the
+// search is a chain of dependent steps per frame, and the chip is filled by running many utterances side by side.
+// The broker is what lets N serial harness threads do that without knowing of each other: every thread drives its own
+// client with the IDecoder protocol - init, push (processFrame x n), finish - and a worker thread turns whatever has
+// been pushed since its last tick into ONE scoring launch and ONE persistent search launch over all the streams
+// concerned (jd_streams_push).  Clients never touch the decoder: only the worker thread does, so the decoder's
+// single-caller rule holds.  Host code over the C ABI only - nothing here knows about HIP.
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "jd_internal.h"
+
+namespace {
+struct Client {
+    bool open = false;
+    bool want_init = false, want_finish = false;   // requests the worker has not served yet
+    bool inited = false;                           // between init and finish
+    std::vector<float> pending;                    // frames pushed and not yet handed to the decoder
+    int err = JD_OK;                               // first error of a tick that concerned this client (reported by its next call)
+    std::string errmsg;
+    jd_hyp result;                                 // of the last finish (arrays owned by the decoder, valid until the stream's next init)
+};
+}  // namespace
+
+struct jd_broker {
+    jd_dec *dec = nullptr;
+    int D = 0, n_clients = 0;
+    int max_tick_frames = 192;                     // frames of one client a tick takes at most
+    int max_pending_frames = 1024;                 // a push waits while its client holds more than this
+    int coalesce_us = 150;                         // a tick waits this long for the other active clients' frames
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::thread worker;
+    bool stop = false;
+    std::vector<Client> clients;
+    jd_broker_stats stats{};
+};
+
+static int client_error(jd_broker *b, Client &c)
+{
+    if (c.err == JD_OK) return JD_OK;
+    const int e = c.err;
+    c.err = JD_OK;
+    (void)b;
+    return jd_fail(e, "%s", c.errmsg.c_str());
+}
+
+static void broker_loop(jd_broker *b)
+{
+    std::unique_lock<std::mutex> lk(b->mu);
+    std::vector<int> inits, pushers, finishers;
+    std::vector<std::vector<float>> taken((size_t)b->n_clients);
+    for (;;) {
+        auto has_work = [&]() {
+            if (b->stop) return true;
+            for (const Client &c : b->clients)
+                if (c.open && (c.want_init || c.want_finish || (c.inited && !c.pending.empty()))) return true;
+            return false;
+        };
+        b->cv_work.wait(lk, has_work);
+        if (b->stop) return;
+        // a tick is the fuller the more clients have frames waiting: give the ones that are between init and finish
+        // and have nothing pending yet a moment to deliver (they are all being fed at about the same rate)
+        if (b->coalesce_us > 0) {
+            auto all_ready = [&]() {
+                if (b->stop) return true;
+                for (const Client &c : b->clients)
+                    if (c.open && c.inited && !c.want_finish && c.pending.empty()) return false;
+                return true;
+            };
+            b->cv_work.wait_for(lk, std::chrono::microseconds(b->coalesce_us), all_ready);
+            if (b->stop) return;
+        }
+        inits.clear(); pushers.clear(); finishers.clear();
+        for (int i = 0; i < b->n_clients; ++i) {
+            Client &c = b->clients[(size_t)i];
+            if (!c.open) continue;
+            if (c.want_init) inits.push_back(i);
+            // (frames pushed behind an init that has not been served yet go with this tick too: the init comes first)
+            if ((c.inited || c.want_init) && !c.pending.empty()) {
+                const size_t have = c.pending.size() / (size_t)b->D;
+                const size_t take = std::min(have, (size_t)b->max_tick_frames);
+                taken[(size_t)i].assign(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
+                c.pending.erase(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
+                pushers.push_back(i);
+            }
+        }
+        for (int i = 0; i < b->n_clients; ++i) {
+            Client &c = b->clients[(size_t)i];
+            if (c.open && c.want_finish && c.pending.empty()) finishers.push_back(i);   // (its last frames - and its init - go with this tick)
+        }
+        lk.unlock();
+        b->cv_done.notify_all();                                       // (pushes that waited for room)
+        // ---- the decoder is touched from here only
+        long long tick_frames = 0, tick_streams = 0;
+        std::vector<int> rc_of((size_t)b->n_clients, JD_OK);
+        std::vector<std::string> msg_of((size_t)b->n_clients);
+        for (int i : inits) {
+            rc_of[(size_t)i] = jd_stream_init(b->dec, i);
+            if (rc_of[(size_t)i]) msg_of[(size_t)i] = jd_last_error();
+        }
+        if (!pushers.empty()) {
+            std::vector<int32_t> ss, nn;
+            std::vector<const float *> ff;
+            long long fr = 0;
+            for (int i : pushers) {
+                if (rc_of[(size_t)i] != JD_OK) continue;               // (its init failed)
+                ss.push_back(i); ff.push_back(taken[(size_t)i].data()); nn.push_back((int32_t)(taken[(size_t)i].size() / (size_t)b->D));
+                fr += nn.back();
+            }
+            const int rc = ss.empty() ? JD_OK : jd_streams_push(b->dec, (int32_t)ss.size(), ss.data(), ff.data(), nn.data());
+            if (rc) { const std::string m = jd_last_error(); for (int i : pushers) if (rc_of[(size_t)i] == JD_OK) { rc_of[(size_t)i] = rc; msg_of[(size_t)i] = m; } }
+            tick_frames = fr; tick_streams = (long long)ss.size();
+        }
+        std::vector<jd_hyp> res((size_t)b->n_clients);
+        for (int i : finishers) {
+            memset(&res[(size_t)i], 0, sizeof(jd_hyp));
+            const int rc = jd_stream_finish(b->dec, i, &res[(size_t)i]);
+            if (rc && rc_of[(size_t)i] == JD_OK) { rc_of[(size_t)i] = rc; msg_of[(size_t)i] = jd_last_error(); }
+        }
+        lk.lock();
+        if (tick_streams) { b->stats.ticks += 1; b->stats.frames += tick_frames; b->stats.stream_ticks += tick_streams; }
+        for (int i = 0; i < b->n_clients; ++i) {
+            Client &c = b->clients[(size_t)i];
+            if (rc_of[(size_t)i] != JD_OK && c.err == JD_OK) { c.err = rc_of[(size_t)i]; c.errmsg = msg_of[(size_t)i]; }
+        }
+        for (int i : inits) { Client &c = b->clients[(size_t)i]; c.want_init = false; c.inited = rc_of[(size_t)i] == JD_OK; }
+        for (int i : finishers) { Client &c = b->clients[(size_t)i]; c.want_finish = false; c.inited = false; c.result = res[(size_t)i]; }
+        b->cv_done.notify_all();
+    }
+}
+
+extern "C" int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients)
+{
+    if (!out || !dec || n_clients < 1) return jd_fail(JD_EINVAL, "jd_broker_create: bad argument");
+    int32_t ms = 0, D = 0;
+    int rc = jd_dec_info(dec, &ms, &D);
+    if (rc) return rc;
+    if (n_clients > ms) return jd_fail(JD_EINVAL, "jd_broker_create: %d clients on a decoder of %d streams", n_clients, ms);
+    jd_broker *b = new jd_broker();
+    b->dec = dec; b->D = D; b->n_clients = n_clients;
+    b->clients.resize((size_t)n_clients);
+    if (const char *e = getenv("JD_BROKER_TICK_FRAMES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) b->max_tick_frames = v; }
+    if (const char *e = getenv("JD_BROKER_COALESCE_US")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) b->coalesce_us = v; }
+    b->max_pending_frames = 4 * b->max_tick_frames;
+    b->worker = std::thread(broker_loop, b);
+    *out = b;
+    return JD_OK;
+}
+
+extern "C" void jd_broker_destroy(jd_broker *b)
+{
+    if (!b) return;
+    { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; }
+    b->cv_work.notify_all(); b->cv_done.notify_all();
+    if (b->worker.joinable()) b->worker.join();
+    delete b;
+}
+
+extern "C" int jd_broker_open(jd_broker *b, int32_t *client)
+{
+    if (!b || !client) return jd_fail(JD_EINVAL, "jd_broker_open: bad argument");
+    std::lock_guard<std::mutex> lk(b->mu);
+    for (int i = 0; i < b->n_clients; ++i)
+        if (!b->clients[(size_t)i].open) { b->clients[(size_t)i] = Client(); b->clients[(size_t)i].open = true; *client = i; return JD_OK; }
+    return jd_fail(JD_ESTATE, "jd_broker_open: all %d clients are taken", b->n_clients);
+}
+
+extern "C" int jd_broker_close(jd_broker *b, int32_t client)
+{
+    if (!b || client < 0 || client >= b->n_clients) return jd_fail(JD_EINVAL, "jd_broker_close: bad client");
+    std::unique_lock<std::mutex> lk(b->mu);
+    Client &c = b->clients[(size_t)client];
+    if (!c.open) return jd_fail(JD_ESTATE, "jd_broker_close: client %d is not open", client);
+    // (an utterance that was never finished: its frames are dropped; the stream's next init clears what it left)
+    b->cv_done.wait(lk, [&]() { return b->stop || !c.want_init; });
+    c.pending.clear(); c.want_finish = false; c.inited = false; c.open = false;
+    return JD_OK;
+}
+
+extern "C" int jd_broker_init(jd_broker *b, int32_t client)
+{
+    if (!b || client < 0 || client >= b->n_clients) return jd_fail(JD_EINVAL, "jd_broker_init: bad client");
+    std::unique_lock<std::mutex> lk(b->mu);
+    Client &c = b->clients[(size_t)client];
+    if (!c.open) return jd_fail(JD_ESTATE, "jd_broker_init: client %d is not open", client);
+    // (an init that is still waiting to be served - init() twice - is this one)
+    c.pending.clear(); c.want_finish = false; c.err = JD_OK;          // (init() in the middle of an utterance drops it, as the reference does)
+    c.want_init = true;
+    // nobody waits for the worker here: the stream is initialised at the head of the next tick, in front of whatever
+    // frames this client has pushed by then (an error of it comes back with the next call)
+    b->cv_work.notify_all();
+    return JD_OK;
+}
+
+extern "C" int jd_broker_push(jd_broker *b, int32_t client, const float *frames, int32_t n_frames)
+{
+    if (!b || client < 0 || client >= b->n_clients || n_frames < 0 || (n_frames > 0 && !frames)) return jd_fail(JD_EINVAL, "jd_broker_push: bad argument");
+    std::unique_lock<std::mutex> lk(b->mu);
+    Client &c = b->clients[(size_t)client];
+    if (!c.open || !(c.inited || c.want_init) || c.want_finish) return jd_fail(JD_ESTATE, "jd_broker_push: client %d is not between init and finish", client);
+    const int rc = client_error(b, c);
+    if (rc) return rc;
+    b->cv_done.wait(lk, [&]() { return b->stop || (int)(c.pending.size() / (size_t)b->D) <= b->max_pending_frames; });
+    c.pending.insert(c.pending.end(), frames, frames + (size_t)n_frames * (size_t)b->D);
+    b->cv_work.notify_all();
+    return JD_OK;
+}
+
+extern "C" int jd_broker_finish(jd_broker *b, int32_t client, jd_hyp *out)
+{
+    if (!b || client < 0 || client >= b->n_clients || !out) return jd_fail(JD_EINVAL, "jd_broker_finish: bad argument");
+    std::unique_lock<std::mutex> lk(b->mu);
+    Client &c = b->clients[(size_t)client];
+    if (!c.open || !(c.inited || c.want_init)) return jd_fail(JD_ESTATE, "jd_broker_finish: client %d is not between init and finish", client);
+    c.want_finish = true;
+    b->cv_work.notify_all();
+    b->cv_done.wait(lk, [&]() { return b->stop || !c.want_finish; });
+    const int rc = client_error(b, c);
+    if (rc) return rc;
+    *out = c.result;
+    return JD_OK;
+}
+
+extern "C" int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out)
+{
+    if (!b || !out) return jd_fail(JD_EINVAL, "jd_broker_get_stats: bad argument");
+    std::lock_guard<std::mutex> lk(b->mu);
+    *out = b->stats;
+    return JD_OK;
+}

@@ -27,7 +27,12 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <numeric>
 #include <queue>
 #include <cfloat>
@@ -223,6 +228,41 @@ extern "C" int jd_am_score_frames(const jd_am *a, int32_t device, const float *f
 #define JD_MAX_DEVICES 64
 static std::mutex g_search_mu[JD_MAX_DEVICES];     // one persistent search launch at a time per device (launch_search)
 
+// ... and across PROCESSES: the reference's way of using several cores is several processes over split file lists
+// (doc/userman/juicer_userman.tex:584), and two of them pointed at one GPU would each get part of the CUs for their
+// persistent launch and spin at their cluster barriers until the 30 s time-out.  An advisory file lock per device -
+// named after its PCI bus id, so that every process means the same GPU whatever its visible-device order - is held
+// from the dispatch of a search launch to its completion: the processes take turns launch by launch (a launch is
+// milliseconds) and both finish.  JD_GPU_LOCK=0 switches it off, JD_GPU_LOCK_DIR moves the files (default /tmp); a
+// lock file that cannot be opened leaves the launch unguarded, as before.
+struct GpuFileLock {
+    int fd = -2;                                   // -2: not tried yet, -1: unavailable
+    std::mutex mu;
+};
+static GpuFileLock g_gpu_lock[JD_MAX_DEVICES];
+static int gpu_lock_fd(int device)
+{
+    GpuFileLock &L = g_gpu_lock[(size_t)std::min(std::max(device, 0), JD_MAX_DEVICES - 1)];
+    std::lock_guard<std::mutex> lk(L.mu);
+    if (L.fd != -2) return L.fd;
+    L.fd = -1;
+    const char *off = getenv("JD_GPU_LOCK");
+    if (off && atoi(off) == 0) return -1;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *p = bus; *p; ++p) if (*p == ':' || *p == '/') *p = '_';
+    const char *dir = getenv("JD_GPU_LOCK_DIR");
+    char path[512];
+    snprintf(path, sizeof path, "%s/juicer_amd.gpu-%s.lock", dir && *dir ? dir : "/tmp", bus);
+    L.fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+    return L.fd;
+}
+struct GpuLockGuard {
+    int fd;
+    explicit GpuLockGuard(int device) : fd(gpu_lock_fd(device)) { if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) { } }
+    ~GpuLockGuard() { if (fd >= 0) (void)flock(fd, LOCK_UN); }
+};
+
 // The stream arenas of a decoder are ONE slab, and the slab of a destroyed decoder is kept (one per device, the
 // largest) for the next decoder on that device: what a decoder's set-up costs is the driver clearing the bytes it
 // hands out (25-60 GB/s, tools/alloc_probe.py - seconds for the default 70 % of a 288 GB device, every time a
@@ -377,6 +417,9 @@ struct jd_dec {
     // streams of the streaming API that are inside an utterance
     bool lazy_failed = false;
     std::vector<char> lazy_in;
+    // a stream whose last launch ended in an error, or never reported back (a wave that returned early, a push that
+    // failed and was not followed by a finish): its per-state and per-arc words may be anything - wiped before its next init
+    std::vector<char> stream_dirty;
     bool occupancy_ok = false;            // k_search fits a CU the way launch_search's grid assumes (checked at the first launch)
 };
 
@@ -584,6 +627,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     d->stream_T.assign((size_t)max_streams, 0);
     d->stream_started.assign((size_t)max_streams, 0);
     d->lazy_in.assign((size_t)max_streams, 0);
+    d->stream_dirty.assign((size_t)max_streams, 0);
     d->last_collect.assign((size_t)max_streams, -1);
     d->n_collect_host.assign((size_t)max_streams, 0);
     d->last_trace.assign((size_t)max_streams, -1);
@@ -826,9 +870,28 @@ static int ensure_arenas(jd_dec *d)
     }
 }
 
+// After an error the lists a stream's next init would clean up from cannot be trusted (stale bids, arrival keys or
+// instance flags would silently drop tokens of later utterances): everything per state and per arc is wiped.
+static int wipe_stream(jd_dec *d, int s)
+{
+    const StreamDev &S = d->h_streams[(size_t)s];
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(S.live, 0, (size_t)d->net->n_arcs));
+    reset_srec(S.srec, d->d_row_ptr, d->net->n_states);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemset(S.tot, 0, TOT_N * MAXW * sizeof(int)));
+    HIPCHK(hipMemset(S.item_end, 0, MAXW * sizeof(int)));
+    HIPCHK(hipMemset(S.hist, 0, 2 * HIST_MAX_BINS * sizeof(int)));
+    HIPCHK(hipDeviceSynchronize());
+    d->stream_dirty[(size_t)s] = 0;
+    return JD_OK;
+}
+
 // mark streams [s0, s0+n) for re-initialisation (IDecoder::init)
 static int mark_init(jd_dec *d, int s0, int n, hipStream_t st)
 {
+    for (int s = s0; s < s0 + n; ++s)
+        if (d->stream_dirty[(size_t)s]) { const int rc = wipe_stream(d, s); if (rc) return rc; }
     hipLaunchKernelGGL(jd_mark_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d->d_ctl, s0, n);
     HIPCHK(hipGetLastError());
     return JD_OK;
@@ -883,14 +946,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
                                     K.error == JDE_PATHS ? 1 : std::max(K.lst_nw, 1));
             }
         }
-        if (K.error) {      // arenas may be inconsistent after an abort: wipe them for the next init
-            HIPCHK(hipMemset(S.live, 0, (size_t)d->net->n_arcs));
-            reset_srec(S.srec, d->d_row_ptr, d->net->n_states);
-            HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipMemset(S.tot, 0, TOT_N * MAXW * sizeof(int)));
-            HIPCHK(hipMemset(S.item_end, 0, MAXW * sizeof(int)));
-            HIPCHK(hipMemset(S.hist, 0, 2 * HIST_MAX_BINS * sizeof(int)));
-        }
+        if (K.error) d->stream_dirty[(size_t)(s0 + i)] = 1;            // arenas may be inconsistent after an abort: wiped before the next init
         H.stats.n_frames = K.frame;
         H.stats.tot_active_emit_hyps = K.st[ST_EMIT];
         H.stats.tot_active_end_hyps = K.st[ST_END];
@@ -940,6 +996,18 @@ static int learn_load(jd_dec *d, const std::vector<int2> &work_in)
     }
     if (frames > 0.0) d->load_scale = std::min(1e5, std::max(0.25, work / frames / 23700.0));
     return JD_OK;
+}
+
+// the flavours of k_search (jd_search.h): HMMs of up to 5 / 8 states, agent-scope / XCD-local memory model, static / lazily
+// composed graph
+typedef void (*SearchKernel)(SearchArgs);
+static SearchKernel search_kernel(bool ne3, bool xl, bool lazy)
+{
+    static const SearchKernel tab[8] = {
+        k_search<6, false, false>, k_search<6, false, true>, k_search<6, true, false>, k_search<6, true, true>,
+        k_search<3, false, false>, k_search<3, false, true>, k_search<3, true, false>, k_search<3, true, true>,
+    };
+    return tab[(ne3 ? 4 : 0) + (xl ? 2 : 0) + (lazy ? 1 : 0)];
 }
 
 // Advance the streams of `work` ({stream, likelihood slot}) through frames [.., f_end) with ONE
@@ -1146,14 +1214,9 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             // flavours it may launch (a build with other SW / WG_PER_CU / LDS sizes, or a device with smaller CUs,
             // fails here with a message instead of after a 30 s barrier time-out)
             const bool lz = d->C.lazy != nullptr;
-            const void *fn[2] = {
-                lz ? (ne3 ? (const void *)k_search<3, false, true> : (const void *)k_search<6, false, true>)
-                   : (ne3 ? (const void *)k_search<3, false, false> : (const void *)k_search<6, false, false>),
-                lz ? (ne3 ? (const void *)k_search<3, true, true> : (const void *)k_search<6, true, true>)
-                   : (ne3 ? (const void *)k_search<3, true, false> : (const void *)k_search<6, true, false>)};
             for (int v = 0; v < 2; ++v) {
                 int per_cu = 0;
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn[v], SNT, 0));
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)search_kernel(ne3, v != 0, lz), SNT, 0));
                 if (per_cu < WG_PER_CU)
                     return jd_fail(JD_EHIP, "k_search needs %d workgroup(s) of %d threads resident per CU, the device takes %d: "
                                    "its clusters could not all be resident at once", WG_PER_CU, SNT, per_cu);
@@ -1161,6 +1224,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             d->occupancy_ok = true;
         }
         std::lock_guard<std::mutex> search_lock(g_search_mu[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)]);
+        GpuLockGuard process_lock(d->device);                              // (other processes on this GPU: see GpuFileLock)
         // (a launch beside which the next batch's table is scored is not cut short for a re-plan while that scoring runs -
         // status[4]: its blocks sit on the CUs that finished clusters left, and a relaunch would wait for them to drain)
         // Whether that pays depends on what the scoring is against the search: where it is a fifth of it (configs[1]) the
@@ -1179,12 +1243,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status,
                            hold_replan ? 1 : 0);
         HIPCHK(hipEventRecord(e0, st));
-        if (d->C.lazy) {   // (the graph's own words are agent scope in either flavour: jd_lazy.h)
-            if (ne3) { if (xl) hipLaunchKernelGGL((k_search<3, true, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<3, false, true>), dim3(grid), dim3(SNT), 0, st, A); }
-            else { if (xl) hipLaunchKernelGGL((k_search<6, true, true>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, true>), dim3(grid), dim3(SNT), 0, st, A); }
-        }
-        else if (ne3) { if (xl) hipLaunchKernelGGL((k_search<3, true, false>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<3, false, false>), dim3(grid), dim3(SNT), 0, st, A); }
-        else { if (xl) hipLaunchKernelGGL((k_search<6, true, false>), dim3(grid), dim3(SNT), 0, st, A); else hipLaunchKernelGGL((k_search<6, false, false>), dim3(grid), dim3(SNT), 0, st, A); }
+        // the kernel flavour: HMM size class x XCD-local x lazily composed graph
+        hipLaunchKernelGGL(search_kernel(ne3, xl, d->C.lazy != nullptr), dim3(grid), dim3(SNT), 0, st, A);
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipGetLastError());
         if (d->pf_armed && d->pf_next.state == 1) {
@@ -1195,7 +1255,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             while (__atomic_load_n(d->h_resident, __ATOMIC_ACQUIRE) != A.launch_seq &&
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count() < 2.0) { }
             const int pr = pf_launch(d);
-            if (pr) return pr;
+            if (pr) { (void)hipStreamSynchronize(st); return pr; }       // (k_search is in flight: not left behind with the launch lock released)
         }
         HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1478,7 +1538,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
             std::vector<double> wp(weight.size());
             for (size_t i = 0; i < wp.size(); ++i) wp[i] = std::min(weight[i], 32.0);
             rc = launch_search(d, work, ll, (long long)G, c0, c_mid, d->s_search, &wp);
-            if (rc) return rc;
+            if (rc) { for (int u = 0; u < nb; ++u) d->stream_dirty[(size_t)u] = 1; return rc; }
             if (d->load_scale == 1.0) { rc = learn_load(d, work); if (rc) return rc; }
             std::vector<int2> w2; std::vector<double> wt2;
             for (size_t i = 0; i < work.size(); ++i)
@@ -1488,7 +1548,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         d->pf_armed = n_chunks == 1 && d->pf_next.state == 1;          // the next batch's table is scored beside this launch
         rc = launch_search(d, work, ll, (long long)G, c0, c1, d->s_search, &weight);
         d->pf_armed = false;
-        if (rc) return rc;
+        if (rc) { for (int u = 0; u < nb; ++u) d->stream_dirty[(size_t)u] = 1; return rc; }   // (nobody looks at the streams' error words)
     }
     hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, 0, nb);
     HIPCHK(hipGetLastError());
@@ -1539,6 +1599,13 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offs[a + 1] - offs[a] > offs[b + 1] - offs[b]; });
     std::vector<int64_t> ustart((size_t)d->max_streams), ulen((size_t)d->max_streams);
     std::vector<int64_t> nstart((size_t)d->max_streams), nlen((size_t)d->max_streams);
+    // the batch takes every stream over: utterances of the streaming interface that were never finished leave the
+    // (lazily composed) network now - before the first jd_lazy_enter, which starts a new arena generation only when
+    // nobody is inside, or a full network would fail this call and, the release below never reached, every later one
+    for (int s = 0; s < d->max_streams; ++s) {
+        d->stream_started[(size_t)s] = 0; d->stream_T[(size_t)s] = 0;
+        if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }
+    }
     // Scoring ahead inside the batch: every wave but the last announces the wave behind it, whose table is then scored
     // beside this wave's search (pf_launch); what the caller announced (the NEXT batch) rides on the last wave.
     Prefetch callers = std::move(d->pf_next);
@@ -1565,6 +1632,8 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
             d->pf_next.drop();
             d->pf_next = std::move(callers); callers = Prefetch();
         }
+        Prefetch kept;                                                 // (see the retry below)
+        struct KeptGuard { Prefetch &p; ~KeptGuard() { p.drop(); } } kept_guard{kept};
         for (int attempt = 0;; ++attempt) {
             // (lazily composed networks: the wave's utterances enter the network - which starts a new arena generation
             // when nobody is inside an utterance and it is nearly full, or has run out of room)
@@ -1577,12 +1646,23 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
                                "it starts again when they are through (capacity %d states, %lld arcs)", d->net->n_states, (long long)d->net->n_arcs);
             }
             d->lazy_failed = false;
+            const jd_timing t_before = d->timing;                      // (a wave that is decoded twice counts once)
+            const double ls_before = d->load_sum, lf_before = d->load_frames;
             rc = decode_wave(d, nb, d_feats, ustart.data(), ulen.data(), (hipStream_t)hip_stream);
             const int rf = rc ? rc : fetch_results(d, 0, nb, out, 0, order.data() + u0);
             jd_lazy_leave(d->net, nb);
             if (rc) return rc;
+            if (kept.state == 2) {                                     // the retry is through: the table scored beside attempt 0 is the next wave's again
+                if (d->pf_ready.state == 0) { d->pf_ready = std::move(kept); kept = Prefetch(); } else kept.drop();
+            }
             // out of graph room under way: once more - jd_lazy_enter gives the wave a fresh generation to itself
-            if (d->lazy_failed && attempt == 0) continue;
+            if (d->lazy_failed && attempt == 0) {
+                d->timing = t_before; d->load_sum = ls_before; d->load_frames = lf_before;
+                // (what was scored ahead beside attempt 0 belongs to the wave BEHIND this one: the retry, which matches no
+                // announced table, would drop it)
+                if (d->pf_ready.state == 2) { kept = std::move(d->pf_ready); d->pf_ready = Prefetch(); }
+                continue;
+            }
             if (rf && first_err == JD_OK) first_err = rf;
             break;
         }
@@ -1651,6 +1731,11 @@ extern "C" int jd_stream_init(jd_dec *d, int32_t s)
     bool net_failed = false;
     rc = jd_lazy_enter(d->net, 1, &net_failed);                       // (may start a new arena generation)
     if (rc) return rc;
+    if (net_failed) {                                                  // as in jd_decode_batch_device
+        jd_lazy_leave(d->net, 1);
+        return jd_fail(JD_ENOMEM, "the lazily composed network has run out of room and other utterances are inside it: "
+                       "it starts again when they are through (capacity %d states, %lld arcs)", d->net->n_states, (long long)d->net->n_arcs);
+    }
     d->lazy_in[(size_t)s] = d->net->lazy_dev != nullptr;
     rc = mark_init(d, s, 1, d->s_search);
     if (rc) return rc;
@@ -1729,7 +1814,7 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
         if (rc) return rc;
         if (d->partial_interval <= 0) {
             rc = launch_search(d, std::vector<int2>(1, make_int2(s, 0)), d->d_ll[0], (long long)Fc * G, f0, Tnew, st);
-            if (rc) return rc;
+            if (rc) { d->stream_dirty[(size_t)s] = 1; return rc; }
             d->stream_T[(size_t)s] = Tnew;
             continue;
         }
@@ -1740,10 +1825,10 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
             d->return_on_collect = true; d->collected_now = false;
             rc = launch_search(d, std::vector<int2>(1, make_int2(s, 0)), d->d_ll[0], (long long)Fc * G, f0, Tnew, st);
             d->return_on_collect = false;
-            if (rc) return rc;
+            if (rc) { d->stream_dirty[(size_t)s] = 1; return rc; }
             StreamCtl hc;
             HIPCHK(hipMemcpy(&hc, d->d_ctl + s, sizeof hc, hipMemcpyDeviceToHost));
-            if (hc.error != 0) { d->stream_T[(size_t)s] = Tnew; break; }   // (reported by jd_stream_finish)
+            if (hc.error != 0) { d->stream_T[(size_t)s] = Tnew; d->stream_dirty[(size_t)s] = 1; break; }   // (reported by jd_stream_finish)
             const int at = hc.frame - 1;                               // the last frame processed
             bool collected = d->collected_now;
             if (!collected && hc.frame >= Tnew && (at - d->last_collect[(size_t)s] > 100 || path_rule_fires(hc.n_paths, hc.path_new))) {
@@ -1767,6 +1852,77 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
             if (hc.frame >= Tnew) break;
         }
     }
+    return JD_OK;
+}
+
+// jd_stream_push for SEVERAL streams at once: the frames of all of them are scored by ONE launch of the scoring
+// kernel and searched by ONE persistent launch, every stream a cluster of its own - what a broker that serves
+// many IDecoder instances (jd_broker_*, jd_broker.cpp) makes of the pushes that have arrived since its last tick.
+// A call takes any number of frames per stream (the tables are sized for the call).  The streams may sit at
+// different frames: row r of the common table is frame stream_T[s] + (r - first row of s) of stream s.
+// PARTIAL_DECODING rides on single-stream pushes (its traces are taken between launches): not here.
+extern "C" int jd_streams_push(jd_dec *d, int32_t n, const int32_t *streams, const float *const *frames, const int32_t *n_frames)
+{
+    if (!d || n < 0 || (n > 0 && (!streams || !frames || !n_frames))) return jd_fail(JD_EINVAL, "jd_streams_push: bad argument");
+    if (d->partial_interval > 0) return jd_fail(JD_ESTATE, "jd_streams_push: partial traces ride on jd_stream_push");
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    const int D = d->am->D, G = d->am->n_gmm;
+    std::vector<char> seen((size_t)d->max_streams, 0);
+    long long rows = 0;
+    for (int i = 0; i < n; ++i) {
+        const int s = streams[i];
+        if (s < 0 || s >= d->max_streams || n_frames[i] < 0 || (n_frames[i] > 0 && !frames[i]) || seen[(size_t)s])
+            return jd_fail(JD_EINVAL, "jd_streams_push: bad stream %d (each stream once)", s);
+        if (!d->stream_started[(size_t)s]) return jd_fail(JD_ESTATE, "jd_streams_push before jd_stream_init (stream %d)", s);
+        seen[(size_t)s] = 1;
+        rows += n_frames[i];
+    }
+    if (rows == 0) return JD_OK;
+    if (rows > 0x7fffff00LL) return jd_fail(JD_EINVAL, "jd_streams_push: more than 2^31 frames in one call");
+    hipStream_t st = d->s_search;
+    pf_discard(d);                                                     // (the streaming path scores into table 0)
+    const size_t tile_rows = ((size_t)rows + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2;
+    rc = ensure_table(d, 0, tile_rows * (size_t)G, tile_rows);
+    if (rc) return rc;
+    if ((size_t)rows * D > d->push_cap) {
+        if (d->d_push) (void)hipFree(d->d_push);
+        d->d_push = nullptr; d->push_cap = 0;
+        HIPCHK(hipMalloc(&d->d_push, tile_rows * D * sizeof(float)));
+        d->push_cap = tile_rows * D;
+    }
+    // rows: stream after stream, packed; row_src is the identity (the frames are packed the same way)
+    std::vector<int> src(tile_rows, -1), Tnew((size_t)n);
+    std::vector<int2> work;
+    std::vector<double> weight;
+    size_t r0 = 0;
+    int f_end = 0;
+    for (int i = 0; i < n; ++i) {
+        if (n_frames[i] == 0) continue;
+        const int s = streams[i];
+        HIPCHK(hipMemcpyAsync(d->d_push + r0 * D, frames[i], (size_t)n_frames[i] * D * sizeof(float), hipMemcpyHostToDevice, st));
+        for (int k = 0; k < n_frames[i]; ++k) src[r0 + (size_t)k] = (int)(r0 + (size_t)k);
+        Tnew[(size_t)i] = d->stream_T[(size_t)s] + n_frames[i];
+        // (k_search reads row  slot + (f - f0)  with f0 = 0: the slot is the stream's first row minus its first frame)
+        work.push_back(make_int2(s, (int)((long long)r0 - d->stream_T[(size_t)s])));
+        weight.push_back((double)n_frames[i]);
+        f_end = std::max(f_end, Tnew[(size_t)i]);
+        r0 += (size_t)n_frames[i];
+    }
+    {   // frames available, for every stream of the decoder in one go (the others keep theirs)
+        std::vector<int> Tall(d->stream_T.begin(), d->stream_T.end());
+        for (int i = 0; i < n; ++i) if (n_frames[i] > 0) Tall[(size_t)streams[i]] = Tnew[(size_t)i];
+        HIPCHK(hipMemcpyAsync(d->d_T, Tall.data(), Tall.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));                              // (Tall and src are locals)
+        hipLaunchKernelGGL(jd_set_T_kernel, dim3((d->max_streams + 63) / 64), dim3(64), 0, st, d->d_ctl, 0, d->max_streams, d->d_T);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(d->d_row_src[0], src.data(), tile_rows * sizeof(int), hipMemcpyHostToDevice, st));
+    rc = launch_gmm(d->am, d->amb, d->d_push, d->d_row_src[0], (int)rows, d->d_ll[0], st);
+    if (rc) return rc;
+    rc = launch_search(d, work, d->d_ll[0], (long long)G, 0, f_end, st, &weight);
+    if (rc) { for (const int2 &w : work) d->stream_dirty[(size_t)w.x] = 1; return rc; }
+    for (int i = 0; i < n; ++i) if (n_frames[i] > 0) d->stream_T[(size_t)streams[i]] = Tnew[(size_t)i];
     return JD_OK;
 }
 
@@ -1889,6 +2045,14 @@ extern "C" int jd_debug_expf(int32_t device, const float *x, int64_t n, float *o
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dy, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dy);
+    return JD_OK;
+}
+
+extern "C" int jd_dec_info(const jd_dec *d, int32_t *max_streams, int32_t *vec_size)
+{
+    if (!d) return jd_fail(JD_EINVAL, "jd_dec_info: null");
+    if (max_streams) *max_streams = d->max_streams;
+    if (vec_size) *vec_size = d->am->D;
     return JD_OK;
 }
 

@@ -16,7 +16,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <strings.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -39,7 +41,19 @@ Rccl g_rccl;
 
 int load_rccl()
 {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (g_rccl.h) return JD_OK;
+    // RCCL writes its version banner (and, with NCCL_DEBUG set, its log) to stdout when the first communicator is
+    // created; stdout is where the harness writes its results (DecoderBatchTest.cpp:216-230).  RCCL's own switch for
+    // that is NCCL_DEBUG_FILE: its output goes to stderr unless the caller has chosen a file - set once, before the
+    // library is loaded and reads its environment.  RCCL honours the file from level WARN up only: NCCL_DEBUG=VERSION
+    // (what the GPU boxes of this project export; tools/rccl_banner_probe.py) prints the banner on stdout whatever
+    // the file says, so that one level is dropped - at every other level, and with no level, stdout stays clean.
+    // (Round 3 parked file descriptor 1 around ncclCommInitAll with dup2: process-wide, and it swallowed whatever
+    // another thread printed meanwhile.)
+    (void)setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
+    if (const char *lv = getenv("NCCL_DEBUG")) if (strcasecmp(lv, "VERSION") == 0) (void)unsetenv("NCCL_DEBUG");
     void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -123,15 +137,7 @@ static int multi_create(jd_multi **out, const jd_net *net, const jd_net *lazy_cl
             return jd_fail(JD_EHIP, "jd_multi_create: cannot create a stream on device %d", m->devices[(size_t)d]);
         }
     }
-    // RCCL prints a version banner on stdout when its first communicator is created; stdout is where
-    // the harness writes its results (DecoderBatchTest.cpp:216-230), so it is parked meanwhile
-    fflush(stdout);
-    const int keep = dup(1), nul = open("/dev/null", O_WRONLY);
-    if (keep >= 0 && nul >= 0) (void)dup2(nul, 1);
-    const ncclResult_t nr = g_rccl.CommInitAll(m->comm.data(), n_devices, m->devices.data());
-    fflush(stdout);
-    if (keep >= 0) { (void)dup2(keep, 1); close(keep); }
-    if (nul >= 0) close(nul);
+    const ncclResult_t nr = g_rccl.CommInitAll(m->comm.data(), n_devices, m->devices.data());   // (its banner: load_rccl)
     if (nr != ncclSuccess) {
         const char *why = g_rccl.GetErrorString(nr);
         jd_multi_destroy(m);

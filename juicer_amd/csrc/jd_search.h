@@ -1473,7 +1473,9 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const float startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;   // :337
             // arcs entered in the previous frame are instances of this one, tried or not (:899-935)
             if (jw == 0 && tid == 0) atomicAdd(&sh.stat[ST_INSTS], new_prev);
-            const float *llrow = A.ll + (size_t)ll_slot * A.ll_stride + (size_t)(f - A.f0) * C.G;
+            // (signed: streams that sit at different frames share one table - jd_streams_push - and a stream's "slot"
+            // is then its first row minus its first frame)
+            const float *llrow = A.ll + ((long long)ll_slot * A.ll_stride + (long long)(f - A.f0) * (long long)C.G);
             int out_cnt = 0;
             CLK(0);                                                    // thresholds + work lists
             if (lr) phase_a<NE, true, true, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, items, nseg, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);

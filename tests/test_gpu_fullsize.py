@@ -38,6 +38,40 @@ def test_fullsize_oracle_parity(c2):
     assert checked == 6 and exact == 6
 
 
+def test_fullsize_64_stream_batch_oracle_parity(built):
+    """BASELINE.json configs[1] in the shape the headline is quoted on - ONE batch of 64 utterances on 64 streams,
+    mainBeam 150, the next batch's table announced and scored beside the search - with utterances spread over the batch
+    (the longest and the shortest among them) checked against the certified oracle: words, times, the reference's
+    statistics, scores bit for bit."""
+    import torch
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_c2(n_utts=64)
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    kw = dict(main_beam=150.0)
+    gd = capi.Decoder(gnet, gam, max_streams=64, **kw)
+    offs = np.zeros(65, dtype=np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in feats])
+    d_feats = torch.from_numpy(np.concatenate(feats)).to("cuda:0")
+    torch.cuda.synchronize()
+    gd.decode_batch_device(d_feats.data_ptr(), offs, 0)                # (the decoder learns the load; plans as in the bench)
+    gd.prefetch_scores(d_feats.data_ptr(), offs, 0)
+    gd.decode_batch_device(d_feats.data_ptr(), offs, 0)
+    gd.prefetch_scores(d_feats.data_ptr(), offs, 0)
+    gs = gd.decode_batch_device(d_feats.data_ptr(), offs, 0)           # a step as bench.py times it
+    assert gd.last_timing()["prefetched"] == 1
+    lens = [f.shape[0] for f in feats]
+    pick = sorted({int(np.argmax(lens)), int(np.argmin(lens)), 0, 21, 42, 63})
+    od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+    exact = 0
+    for u in pick:
+        o = od.decode_certified(feats[u])
+        assert_hyp_matches(gs[u], o, "c2 batch of 64, utt %d" % u)
+        exact += bit_exact(gs[u], o)
+    assert len(pick) >= 4 and exact == len(pick)
+    assert all(h.n > 0 for h in gs)
+
+
 def test_fullsize_histogram_pruning_parity(c2):
     from juicer_amd import capi
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet

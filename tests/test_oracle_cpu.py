@@ -202,3 +202,18 @@ def test_oracle_hybrid_scoring(built):
         assert o.n > 0
         hit += int(np.array_equal(o.label[::-1], w))
     assert hit >= len(feats) - 1
+
+
+@pytest.mark.parametrize("case", ["tree_hub_12k_arcs", "flat_hub", "mixed_topologies"])
+def test_oracle_vs_vectorised_independent_viterbi(built, case):
+    """The oracle, every beam off, against tests/indep_viterbi_np.py: float64, all arcs at once, its own GMM
+    evaluation (nothing shared with oracle/).  The same anchor faces the HIP path in tests/test_gpu_indep.py."""
+    import indep_cases
+    import indep_viterbi_np as iv
+    from juicer_amd import synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = {"tree_hub_12k_arcs": indep_cases.CASES["tree_hub"], "flat_hub": synth.config_small,
+                         "mixed_topologies": synth.config_mixed}[case]()
+    od = OracleDecoder(OracleNet(net), OracleAM(am))
+    for u, x in enumerate(feats[:2]):
+        indep_cases.check_against_viterbi(od.decode(x), iv.viterbi(net, am, iv.gmm_loglik(am, x)), "%s utt %d" % (case, u))

@@ -31,7 +31,7 @@ extra = {}
 for a in sys.argv[3:]:
     nm, _, kv = a.partition("=")
     extra[nm] = (not nm.startswith("serial"), dict(x.split(":") for x in kv.split(",") if x))
-KNOBS = ("JD_PF_REBALANCE", "JD_REBALANCE", "JD_MODEL_A", "JD_MODEL_B", "JD_PLAN", "JD_MODEL2_A", "JD_MODEL2_B", "JD_PF_GMM_WEIGHT", "JD_PLAN_MIN_CW", "JD_GMM_WAVES", "JD_REBALANCE_FRAC", "JD_XL_SLACK", "JD_CW", "JD_XCH")
+KNOBS = ("JD_PF_REBALANCE", "JD_REBALANCE", "JD_MODEL_A", "JD_MODEL_B", "JD_PLAN", "JD_MODEL2_A", "JD_MODEL2_B", "JD_PF_GMM_WEIGHT", "JD_PLAN_MIN_CW", "JD_GMM_WAVES", "JD_REBALANCE_FRAC", "JD_XL_SLACK", "JD_CW", "JD_XCH", "JD_EXP")
 variants = extra if extra else {"serial": (False, {}), "ahead": (True, {}), "ahead, re-plan held": (True, {"JD_PF_REBALANCE": "0"}),
             "ahead, re-planned at will": (True, {"JD_PF_REBALANCE": "1"}), "serial, never re-planned": (False, {"JD_REBALANCE": "0"})}
 
