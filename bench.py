@@ -23,6 +23,16 @@ table scored during the last timed step is never searched.  --no-score-ahead tim
 the serial order; one serial-order step is also run BEHIND the timed region and
 reported as roofline.serial_order / roofline.gmm.serial_order_* (not part of `value`).
 
+Two batches in flight (default at weak scaling; --no-search-ahead: off).  A batch lasts
+as long as its longest utterance while the clusters of its shorter ones are long
+through, so the decoder is given streams for TWO batches and the announcements run two
+batches ahead: the batch behind the running one then has its table already and its
+utterances are started beside the running batch, one workgroup each.  Every step still
+returns its own batch's 64 results, decoded in full from frame 0; what a step does of
+the next batch's search the next step does not do again, so K timed steps hold K
+batches' worth of search (config.search_ahead_frames_per_step says how much of a
+batch had been searched when its step began).
+
 After the timed region rank 0 of a 1-GPU run also times (1 warm-up + 3 timed
 passes each: median and minimum) the other single-GPU workloads of BASELINE.json
 and reports them under "legs": the north_star target (10M-arc class graph, beam
@@ -278,6 +288,8 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--no-score-ahead", action="store_true",
                     help="score every batch's table right before its search (serial) instead of beside the previous batch's search")
+    ap.add_argument("--no-search-ahead", action="store_true",
+                    help="one batch in flight: the decoder gets streams for one batch only and the announcements run one batch ahead")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -337,8 +349,12 @@ def main():
     gam = capi.Models.from_htk(am)
     # (a rank that holds more than 128 utterances of a fixed batch decodes them in waves of 128 streams, each wave's table
     # scored beside the wave before it: measured faster than one stream per utterance from 256 utterances on)
+    # (weak scaling: batches of U utterances follow each other, and a decoder with room for two of them starts the
+    # utterances of the batch behind the running one beside it - "two batches in flight")
+    ahead = not args.no_score_ahead
+    two_in_flight = ahead and not args.no_search_ahead and not strong
     dec = capi.Decoder(gnet, gam, main_beam=args.beam, max_hyps=args.max_hyps, device=local_rank,
-                       max_streams=min(U, 128) if strong else U)
+                       max_streams=min(U, 128) if strong else (2 * U if two_in_flight else U))
     offs = np.zeros(len(feats) + 1, dtype=np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in feats])
     frames_local = int(offs[-1])
@@ -346,12 +362,14 @@ def main():
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
 
-    ahead = not args.no_score_ahead
-
     def step():
         # One step = one pass over one batch: its search, and one scoring of a batch's likelihood table.  Batches follow
-        # each other, so the table of the NEXT batch (here: the same synthetic batch again) is scored on the CUs this
+        # each other, so the table of a LATER batch (here: the same synthetic batch again) is scored on the CUs this
         # batch's search leaves idle (jd_dec_prefetch_scores) - K timed steps hold K searches and K scorings either way.
+        # With two batches in flight the announcements run two batches ahead (one more before the first step, below):
+        # the batch behind the running one has its table already and its utterances are started beside it - every
+        # step still returns ITS batch's 64 results, decoded in full; what a step does of the next batch's search the
+        # next step does not have to do, and K steps hold K batches' worth of search.
         if ahead:
             dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
         hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
@@ -362,11 +380,14 @@ def main():
         if world > 1:
             dist.barrier(**bar_kw)
 
+    if two_in_flight:
+        dec.prefetch_scores(d_feats.data_ptr(), offs, stream)          # (the announcements run two batches ahead)
     for _ in range(args.warmup):
         step()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0}
+    acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0,
+           "ahead_frames": 0}
     tm = {}
     hyps = None
     each = []
@@ -490,7 +511,10 @@ def main():
                                      args.beam, args.max_hyps),
                       "frames_per_step": int(frames_total), "utts_per_gpu": U, "gathered_hyps": n_gathered,
                       "parallelism": ("one batch of %d utterances dealt by length over %d rank(s)" % (args.total_utts, world)) if strong
-                                     else "utterance-sharded x%d" % world},
+                                     else "utterance-sharded x%d" % world,
+                      "batches_in_flight": 2 if two_in_flight else 1,
+                      "search_ahead_frames_per_step": int(acc["ahead_frames"] // max(steps, 1)),
+                      "streams_per_gpu": dec.max_streams},
            "roofline": roofline, "cpu_baseline": cpu}
 
     # ---- the other single-GPU workloads of BASELINE.json (not part of `value`)

@@ -330,8 +330,8 @@ int jd_dec_info(const jd_dec *d, int32_t *max_streams, int32_t *vec_size);
  * been pushed since its last tick into one scoring launch and one search launch over all the streams concerned
  * (jd_streams_push).  The decoder must not be used directly while a broker owns it; clients may be driven from
  * different threads, one thread per client at a time.  jd_hyp arrays stay valid until the client's next init.
- * Environment: JD_BROKER_TICK_FRAMES (frames of one client per tick, default 256), JD_BROKER_COALESCE_US (how long a
- * tick waits for the other clients' frames, default 150). */
+ * Environment: JD_BROKER_TICK_FRAMES (frames of one client per tick, default 192), JD_BROKER_COALESCE_US (how long a
+ * tick waits for the other open clients' frames, default 300). */
 typedef struct jd_broker jd_broker;
 typedef struct jd_broker_stats { int64_t ticks, frames, stream_ticks; } jd_broker_stats;   /* launches, frames, streams summed over ticks */
 int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients);   /* n_clients <= the decoder's max_streams */
@@ -401,6 +401,13 @@ int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
  * scored.  The device buffer of the announced batch must stay valid and unchanged until that decode
  * (offs is copied); a decode with other arguments simply drops the table - results never depend on the
  * announcement.  n_utts = 0 drops whatever was announced or scored ahead.  Calling this is optional.
+ * Announcements queue up, in the order of the decodes to come (at most three; one more is not taken), and
+ * SEARCHING ahead follows from scoring ahead: a batch lasts as long as its longest utterance while the clusters of
+ * its shorter ones are long through, so when the batch BEHIND the one being decoded has its table already - it was
+ * announced two decodes ahead - and each of the two fills at most half of the decoder's streams, its utterances are
+ * started beside the running batch, one workgroup each, on the other half of the streams; when its turn comes they
+ * are hundreds of frames in (jd_timing.ahead_frames) and the call is that much shorter.  A stream of batches gets
+ * this with two announcements before its first decode and one before every later one (JD_PIPELINE=0 switches it off).
  * While the scoring runs the search launch is not re-planned under way when the scoring is a sizeable part
  * of the step (measured on the decoder's last batches: from a tenth of the search on), so that its blocks find
  * CUs; else it is slotted in at the re-planning cuts.
@@ -449,7 +456,8 @@ typedef struct jd_timing {
     int64_t search_frames;    /* stream-frames decoded                          */
     int32_t prefetched;       /* waves whose table had been scored ahead (jd_dec_prefetch_scores): their gmm_ms is the
                                  span of that scoring beside the previous search, and gmm_wait_ms what was left of it */
-    int32_t reserved0;
+    int32_t ahead_frames;     /* frames of this batch that had been searched beside the batch before it ("two batches in
+                                 flight": announcements two batches ahead, a batch on at most half of the streams) */
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 

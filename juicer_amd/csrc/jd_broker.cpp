@@ -39,7 +39,7 @@ struct jd_broker {
     int D = 0, n_clients = 0;
     int max_tick_frames = 192;                     // frames of one client a tick takes at most
     int max_pending_frames = 1024;                 // a push waits while its client holds more than this
-    int coalesce_us = 150;                         // a tick waits this long for the other active clients' frames
+    int coalesce_us = 300;                         // a tick waits this long for the other open clients' frames
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::thread worker;
@@ -71,13 +71,14 @@ static void broker_loop(jd_broker *b)
         };
         b->cv_work.wait(lk, has_work);
         if (b->stop) return;
-        // a tick is the fuller the more clients have frames waiting: give the ones that are between init and finish
-        // and have nothing pending yet a moment to deliver (they are all being fed at about the same rate)
+        // a tick is the fuller the more clients have frames waiting: give the open ones that have nothing pending yet
+        // a moment to deliver - they are all being fed at about the same rate, and one that has just been handed its
+        // result is about to start its next utterance (a caller that is through closes its client)
         if (b->coalesce_us > 0) {
             auto all_ready = [&]() {
                 if (b->stop) return true;
                 for (const Client &c : b->clients)
-                    if (c.open && c.inited && !c.want_finish && c.pending.empty()) return false;
+                    if (c.open && !c.want_finish && c.pending.empty()) return false;
                 return true;
             };
             b->cv_work.wait_for(lk, std::chrono::microseconds(b->coalesce_us), all_ready);

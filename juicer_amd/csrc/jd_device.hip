@@ -40,6 +40,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <mutex>
 #include <type_traits>
@@ -338,8 +339,10 @@ struct Prefetch {
     std::vector<int64_t> ustart, ulen;
     WavePlan plan;
     int buf = 0;
+    int bank = -1;                             // >= 0: its utterances have been started, on this bank of streams ("two batches in flight")
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    void drop() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; state = 0; feats = nullptr; }
+    void drop_events() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; }
+    void drop() { drop_events(); state = 0; feats = nullptr; bank = -1; }
 };
 
 struct jd_dec {
@@ -386,15 +389,26 @@ struct jd_dec {
     // chunked pipeline
     int Fc = 128;                         // frames per scoring chunk of the streaming API (jd_stream_push)
     int Fw_env = 0;                       // JD_FC: frames per chunk of the batch path (0 = as long as the longest utterance)
-    float *d_ll[2] = {nullptr, nullptr};
-    size_t ll_cap[2] = {0, 0};            // floats
-    int *d_row_src[2] = {nullptr, nullptr}; size_t row_src_cap[2] = {0, 0};   // row -> source frame tables, one per likelihood table
+    float *d_ll_slab = nullptr;           // the three likelihood tables (ensure_slab)
+    float *d_ll[3] = {nullptr, nullptr, nullptr};
+    size_t ll_cap = 0;                    // floats per table
+    int *d_row_src[3] = {nullptr, nullptr, nullptr}; size_t row_src_cap[3] = {0, 0, 0};   // row -> source frame tables, one per likelihood table
     int *d_T = nullptr;
     hipStream_t s_gmm = nullptr, s_search = nullptr;
     // scoring one batch ahead (jd_dec_prefetch_scores): the table of the NEXT batch is scored while this one is searched
-    int cur_buf = 0;                      // the likelihood table a single-chunk wave uses (the other one takes the prefetch)
-    Prefetch pf_next, pf_ready;           // announced (scored during the next decode) / scored or being scored (used by the next decode)
-    bool pf_armed = false;                // decode_wave: the coming launch_search may start the announced scoring
+    std::deque<Prefetch> pf_q;            // the batches ahead, in the order announced: scored, started ("two batches in flight"), or neither yet
+    int fg_buf = -1;                      // the table(s) the wave being decoded uses (-1: none; -2: tables 0 and 1, in chunks)
+    int fg_bank = -1;                     // >= 0: the wave being decoded runs on this bank of streams and the batch behind it may be started beside it
+    int pipeline = 1;                     // two batches in flight (JD_PIPELINE=0: off)
+    bool bg_ran = false;                  // the last launch_search advanced streams of the batch behind, too
+    double bg_wait_us = 1000.0;           // how long the start of a launch waits for the table of the batch behind (JD_BG_WAIT_US)
+    double last_wave_ms = 0.0;            // wall time of the last wave decoded (what a scoring beside the next one has to fit)
+    int score_reserve = -1;               // CUs left to the scoring beside a launch with two batches in flight: -1 by its cost (JD_SCORE_RESERVE)
+    int reserve_now = 0;                  // ... of the launch under way
+    int bg_rebalance = 0;                 // re-plan a launch that runs two batches (JD_BG_REBALANCE)
+    double bg_weight = 0.5;               // the plan counts this part of the frames a stream of the batch behind has ahead (JD_BG_WEIGHT)
+    int fg_cw_cap = 8, bg_cw_cap = 4;     // two batches in flight: largest cluster of the running batch / of the batch behind (JD_FG_CW, JD_BG_CW)
+    bool pf_armed = false;                // decode_wave: the coming launch_search may start the announced scorings
     int pf_rebalance = -1;                // re-planning a launch beside which a table is scored: -1 by the measured ratio (launch_search),
                                           // JD_PF_REBALANCE=0: never while the scoring runs, =1: like any other launch
     double gmm_ms_per_row = 0.0, search_ms_per_frame = 0.0;   // measured on this decoder's last waves (scoring on its own / search)
@@ -456,11 +470,11 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     slab_give(d->device, d->slab);
     d->slab = ArenaSlab();
     free_am_gmm(d->amb);
-    for (int i = 0; i < 2; ++i)
-        if (d->d_ll[i]) (void)hipFree(d->d_ll[i]);
-    for (int i = 0; i < 2; ++i)
+    if (d->d_ll_slab) (void)hipFree(d->d_ll_slab);
+    for (int i = 0; i < 3; ++i)
         if (d->d_row_src[i]) (void)hipFree(d->d_row_src[i]);
-    d->pf_next.drop(); d->pf_ready.drop();
+    for (Prefetch &F : d->pf_q) F.drop();
+    d->pf_q.clear();
     if (d->h_resident) (void)hipHostFree(d->h_resident);
     if (d->d_push) (void)hipFree(d->d_push);
     if (d->d_work) (void)hipFree(d->d_work);
@@ -608,6 +622,13 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
     if (const char *e = getenv("JD_PF_REBALANCE")) d->pf_rebalance = atoi(e) != 0;                // development
+    if (const char *e = getenv("JD_PIPELINE")) d->pipeline = atoi(e) != 0;
+    if (const char *e = getenv("JD_BG_WAIT_US")) d->bg_wait_us = atof(e);
+    if (const char *e = getenv("JD_SCORE_RESERVE")) d->score_reserve = atoi(e);
+    if (const char *e = getenv("JD_BG_REBALANCE")) d->bg_rebalance = atoi(e) != 0;
+    if (const char *e = getenv("JD_BG_WEIGHT")) d->bg_weight = atof(e);
+    if (const char *e = getenv("JD_FG_CW")) d->fg_cw_cap = std::max(1, atoi(e));
+    if (const char *e = getenv("JD_BG_CW")) d->bg_cw_cap = std::max(1, atoi(e));
     hipError_t e;
     // the search stream has the highest priority, the scoring stream the lowest: when a table is scored while a search
     // runs (jd_dec_prefetch_scores) a search launch that needs CUs gets them before further scoring blocks do
@@ -686,6 +707,7 @@ static void reset_srec(StateRec *srec, const int *d_row_ptr, int64_t n_states)
     hipLaunchKernelGGL(jd_reset_srec_kernel, dim3((unsigned)((n_states + 255) / 256)), dim3(256), 0, 0, srec, d_row_ptr, (long long)n_states);
 }
 
+static int ensure_slab(jd_dec *d, size_t floats);
 static int ensure_arenas_try(jd_dec *d, double mem_fraction)
 {
     int rc = check_device(d->device);
@@ -817,7 +839,7 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
     if (rc) return rc;
     HIPCHK(hipMemset(d->d_status, 0, 8 * sizeof(int)));
     if (rc) return rc;
-    HIPCHK(hipHostMalloc((void **)&d->h_status, 4 * sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&d->h_status, 8 * sizeof(int)));
     {
         std::vector<StreamCtl> hc((size_t)B);
         memset(hc.data(), 0, hc.size() * sizeof(StreamCtl));
@@ -827,14 +849,8 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
         }
         HIPCHK(hipMemcpy(d->d_ctl, hc.data(), hc.size() * sizeof(StreamCtl), hipMemcpyHostToDevice));
     }
-    {
-        void *p = nullptr;                                             // streaming API: one stream, one chunk
-        rc = dmalloc(d, (float **)&p, (size_t)d->Fc * d->am->n_gmm);
-        if (rc) return rc;
-        d->allocs.pop_back();                                          // (owned by d_ll: it is re-sized later)
-        d->d_ll[0] = (float *)p;
-    }
-    d->ll_cap[0] = (size_t)d->Fc * d->am->n_gmm;
+    rc = ensure_slab(d, (size_t)d->Fc * d->am->n_gmm);                // streaming API: one stream, one chunk
+    if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());
     d->arenas_ready = true;
     return JD_OK;
@@ -861,7 +877,7 @@ static int ensure_arenas(jd_dec *d)
         slab_give(d->device, d->slab);
         d->slab = ArenaSlab();
         if (d->h_status) { (void)hipHostFree(d->h_status); d->h_status = nullptr; }
-        if (d->d_ll[0]) { (void)hipFree(d->d_ll[0]); d->d_ll[0] = nullptr; d->ll_cap[0] = 0; }
+        if (d->d_ll_slab) { (void)hipFree(d->d_ll_slab); d->d_ll_slab = nullptr; d->ll_cap = 0; for (int i = 0; i < 3; ++i) d->d_ll[i] = nullptr; }
         d->d_res = nullptr; d->d_streams = nullptr; d->d_T = nullptr; d->d_ctl = nullptr; d->d_status = nullptr;
         (void)hipGetLastError();
         if (rc != JD_ENOMEM || attempt == 3 || (u_slots > 0 && u_items > 0 && u_paths > 0)) return rc;
@@ -1016,6 +1032,11 @@ static SearchKernel search_kernel(bool ne3, bool xl, bool lazy)
 // launch stops a stream early when its Path arena needs collecting; the collection (k_gc_*) runs
 // after such a launch and the launch is repeated until every stream is through.
 static int pf_launch(jd_dec *d);
+static bool pf_wants_scoring(const jd_dec *d);
+static double pf_scoring_rows(const jd_dec *d);
+static bool pf_scoring_in_flight(const jd_dec *d);
+static int pf_background(jd_dec *d, int fg_bank, const std::vector<int> *heads, hipStream_t st, std::vector<int2> *work, std::vector<double> *left);
+static int mark_init(jd_dec *d, int s0, int n, hipStream_t st);
 static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const float *ll, long long ll_stride, int f0, int f_end,
                          hipStream_t st, const std::vector<double> *weight_first = nullptr)
 {
@@ -1026,6 +1047,9 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         d->work_cap = (int)work_first.size();
     }
     std::vector<int2> work_in = work_first;
+    std::vector<int2> bg;                                              // streams of the batch behind, advanced beside these (pf_background)
+    std::vector<double> bg_left;                                       // ... and the frames each has ahead
+    std::vector<int> heads;
     std::vector<double> weight_now;
     std::vector<int> frame_before;                                     // per stream: where the previous launch found it
     const std::vector<double> *weight = weight_first;
@@ -1033,9 +1057,46 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     const int max_rounds = (f_end - f0) + 64;                          // every launch makes at least one frame of progress
     for (int it = 0;; ++it) {
     const int n_work = (int)work_in.size();
+    int nwg_all = std::max(1, d->n_cus * WG_PER_CU);
+    // Two batches in flight: the plan below makes the clusters of this batch finish together and the utterances of the
+    // batch behind fill what is left - nothing idles, and the scoring of the table after that, which lives on idle CUs,
+    // would finish long after the launch (and the batch behind the next one start late).  So the scoring gets CUs of its
+    // own: as many as carry its cost over a launch as long as the last wave was (a multiple of eight: the XCD-local
+    // numbering), a third of the chip at most; the search is planned on the rest.
+    int reserve = 0;
+    if (d->fg_bank >= 0 && d->pf_armed && weight && d->weighted && (pf_wants_scoring(d) || pf_scoring_in_flight(d))) {
+        if (it == 0) {
+            d->reserve_now = d->score_reserve;
+            if (d->reserve_now < 0) d->reserve_now = (d->gmm_ms_per_row > 0.0 && d->last_wave_ms > 0.0)
+                                                   ? (int)std::ceil(d->gmm_ms_per_row * pf_scoring_rows(d) * nwg_all / d->last_wave_ms) : 0;
+            d->reserve_now = std::min((d->reserve_now + 7) & ~7, (nwg_all / 3) & ~7);
+        }
+        reserve = d->reserve_now;                                      // (the legs of a re-planned launch leave the same CUs alone)
+    }
+    // two batches in flight: the utterances of the batch behind this one, one workgroup each at least, on a quarter of the grid at most
+    bg.clear();
+    if (d->fg_bank >= 0 && weight && d->weighted) {
+        const bool started = !d->pf_q.empty() && d->pf_q.front().bank >= 0;
+        if (started) {
+            heads.assign((size_t)d->max_streams * 4, 0);
+            HIPCHK(hipMemcpy2D(heads.data(), 16, d->d_ctl, sizeof(StreamCtl), 16, (size_t)d->max_streams, hipMemcpyDeviceToHost));
+        }
+        const int br = pf_background(d, d->fg_bank, started ? &heads : nullptr, st, &bg, &bg_left);
+        if (br) return br;
+        if ((int)bg.size() > nwg_all / 4 || nwg_all - (int)bg.size() < 2 * n_work) { bg.clear(); bg_left.clear(); }
+    }
+    const int n_bg = (int)bg.size();
+    while (reserve > 0 && nwg_all - reserve - n_bg < 2 * n_work) reserve -= 8;
+    nwg_all -= std::max(reserve, 0);
+    if ((int)(n_work + n_bg) > d->work_cap) {
+        if (d->d_work) (void)hipFree(d->d_work);
+        d->d_work = nullptr; d->work_cap = 0;
+        HIPCHK(hipMalloc(&d->d_work, (size_t)(n_work + n_bg) * sizeof(int4)));
+        d->work_cap = n_work + n_bg;
+    }
     SearchArgs A;
-    A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work;
-    const int nwg = std::max(1, d->n_cus * WG_PER_CU);
+    A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work; A.n_prio = 0;
+    const int nwg = nwg_all - n_bg;                                    // what the plan of THESE streams may use
     // a wave segment holds at least one 64-record chunk of instances and 512 frontier items (one wave
     // writes the whole epsilon closure of the items it expands)
     const int cw_cap = (int)std::max<int64_t>(1, std::min<int64_t>(d->cap_slots / (64 * SW), d->cap_items / (512 * SW)));
@@ -1047,7 +1108,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     int grid = A.n_slots * A.Cw;
     bool xl = false;
     int rebalance_at = 0;
-    if (weight && d->weighted && n_work > 1 && max_cw > 1 && nwg >= 2 * n_work) {
+    if (weight && d->weighted && (n_work > 1 || n_bg > 0) && max_cw > 1 && nwg >= 2 * n_work) {
         // Weighted mode.  weight[k] = frames stream k has in this launch.  A stream's frame costs about
         // a + b / workgroups  (a: the barriers and list set-up of a frame; b: the part that divides over
         // the cluster), so stream k finishes after  frames_k * (a + b / C_k).  The launch ends with its
@@ -1069,6 +1130,9 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // the constants fitted in round 2 (a = 10, b = 360 - right at 58 ms per step, wrong now, but erring towards
         // larger short clusters, which is what re-planning and scoring ahead forgive) and the floor of the continuous
         // solution.
+        // (with the batch behind beside it: past eight workgroups a cluster gains little - 32 us per frame against 28 at
+        // sixteen - and the workgroups do more for the streams of the batch behind, JD_FG_CW)
+        const int mcw = n_bg > 0 ? std::min(max_cw, d->fg_cw_cap) : max_cw;
         const bool greedy = d->plan_mode == 1;
         const double a_us = greedy ? d->model2_a_us : d->model_a_us, b_us = (greedy ? d->model2_b_us : d->model_b_us) * d->load_scale;
         std::vector<int> cw((size_t)n_work, 1);
@@ -1076,7 +1140,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         if (greedy) {
             std::priority_queue<std::pair<double, int>> pq;
             double cu_us = 0.0;                                            // CU-time of the plan so far
-            const int c0 = std::max(1, std::min(std::min(d->plan_min_cw, max_cw), nwg / n_work));   // every stream starts with this many
+            const int c0 = std::max(1, std::min(std::min(d->plan_min_cw, mcw), nwg / n_work));   // every stream starts with this many
             for (int k = 0; k < n_work; ++k) {
                 const double fr = std::max((*weight)[(size_t)k], 1.0);
                 cw[(size_t)k] = c0;
@@ -1084,12 +1148,12 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
                 cu_us += fr * (a_us * c0 + b_us);
             }
             used = n_work * c0;
-            const double gmm_cu_us = (d->pf_armed && d->pf_next.state == 1)
-                                   ? d->pf_gmm_weight * 1e3 * d->gmm_ms_per_row * (double)d->pf_next.plan.chunk_rows[0] * nwg : 0.0;
+            const double gmm_cu_us = (d->pf_armed && pf_wants_scoring(d))
+                                   ? d->pf_gmm_weight * 1e3 * d->gmm_ms_per_row * pf_scoring_rows(d) * nwg : 0.0;
             while (used < nwg && !pq.empty()) {
                 const std::pair<double, int> top = pq.top();
                 const int k = top.second;
-                if (cw[(size_t)k] >= max_cw) break;                        // the launch cannot end sooner than this stream
+                if (cw[(size_t)k] >= mcw) break;                        // the launch cannot end sooner than this stream
                 if (gmm_cu_us > 0.0 && top.first <= (cu_us + gmm_cu_us) / nwg) break;
                 pq.pop();
                 const double fr = std::max((*weight)[(size_t)k], 1.0);
@@ -1098,13 +1162,24 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
                 pq.push({fr * (a_us + b_us / cw[(size_t)k]), k});
             }
         }
+        // One plan for both batches: a stream of the batch behind counts with a part of the frames it has ahead
+        // (bg_weight: its turn as the batch the caller waits for is still to come - it has two launches to get through)
+        // and so gets workgroups by its length like everybody else: the long utterances, which are what the NEXT launch
+        // will last as long as, are the ones that get ahead.
+        const int n_plan = greedy ? n_work : n_work + n_bg;
+        const int nwg_plan = greedy ? nwg : nwg + n_bg;
+        const int mcw_bg = std::max(1, std::min(d->bg_cw_cap, max_cw));
+        std::vector<double> wt_plan(weight->begin(), weight->begin() + n_work);
+        if (!greedy) for (int i = 0; i < n_bg; ++i) wt_plan.push_back(d->bg_weight * bg_left[(size_t)i]);
+        if (!greedy) cw.assign((size_t)n_plan, 1);
+        auto cap_of = [&](int k) { return k < n_work ? mcw : mcw_bg; };
         auto need = [&](double tau, std::vector<double> *out) {
             double tot = 0.0;
-            for (int k = 0; k < n_work; ++k) {
-                const double fr = std::max((*weight)[(size_t)k], 1.0);
+            for (int k = 0; k < n_plan; ++k) {
+                const double fr = std::max(wt_plan[(size_t)k], 1.0);
                 const double slack = tau / fr - a_us;
                 double c = slack > 1e-9 ? b_us / slack : 1e9;
-                c = std::min(std::max(c, 1.0), (double)max_cw);
+                c = std::min(std::max(c, 1.0), (double)cap_of(k));
                 if (out) (*out)[(size_t)k] = c;
                 tot += c;
             }
@@ -1112,36 +1187,50 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         };
         if (!greedy) {
         double lo_t = 0.0, hi_t = 1.0;
-        while (need(hi_t, nullptr) > nwg && hi_t < 1e15) hi_t *= 2.0;
-        for (int it = 0; it < 60; ++it) { const double mid = 0.5 * (lo_t + hi_t); if (need(mid, nullptr) > nwg) lo_t = mid; else hi_t = mid; }
-        std::vector<double> want((size_t)n_work);
+        while (need(hi_t, nullptr) > nwg_plan && hi_t < 1e15) hi_t *= 2.0;
+        for (int it = 0; it < 60; ++it) { const double mid = 0.5 * (lo_t + hi_t); if (need(mid, nullptr) > nwg_plan) lo_t = mid; else hi_t = mid; }
+        std::vector<double> want((size_t)n_plan);
         need(hi_t, &want);
         std::vector<std::pair<double, int>> frac;
-        for (int k = 0; k < n_work; ++k) {
-            cw[(size_t)k] = std::max(1, std::min(max_cw, (int)want[(size_t)k]));
+        for (int k = 0; k < n_plan; ++k) {
+            cw[(size_t)k] = std::max(1, std::min(cap_of(k), (int)want[(size_t)k]));
             used += cw[(size_t)k];
             frac.push_back({want[(size_t)k] - (int)want[(size_t)k], k});
         }
         std::sort(frac.begin(), frac.end(), [](const std::pair<double, int> &x, const std::pair<double, int> &y) { return x.first > y.first; });
-        for (int pass = 0; pass < 4 && used < nwg; ++pass)                 // left-over workgroups: largest remainders first
-            for (size_t i = 0; i < frac.size() && used < nwg; ++i)
-                if (cw[(size_t)frac[i].second] < max_cw) { ++cw[(size_t)frac[i].second]; ++used; }
-        while (used > nwg) {                                               // (rounding can only overshoot by the floor of ones)
+        for (int pass = 0; pass < 4 && used < nwg_plan; ++pass)            // left-over workgroups: largest remainders first
+            for (size_t i = 0; i < frac.size() && used < nwg_plan; ++i)
+                if (cw[(size_t)frac[i].second] < cap_of(frac[i].second)) { ++cw[(size_t)frac[i].second]; ++used; }
+        while (used > nwg_plan) {                                          // (rounding can only overshoot by the floor of ones)
             int big = 0;
-            for (int k = 1; k < n_work; ++k) if (cw[(size_t)k] > cw[(size_t)big]) big = k;
+            for (int k = 1; k < n_plan; ++k) if (cw[(size_t)k] > cw[(size_t)big]) big = k;
             if (cw[(size_t)big] <= 1) break;
             --cw[(size_t)big]; --used;
         }
         }
+        // The streams of the batch behind join the plan: one workgroup each, plus what the plan of this batch leaves,
+        // dealt evenly (up to JD_BG_CW) - they are ordinary clusters from here on, only not what the launch waits for.
+        const int n_tot = n_work + n_bg;
+        std::vector<int> cw_all(cw);
+        std::vector<double> wt_all(weight->begin(), weight->begin() + n_work);
+        if (n_bg > 0) {
+            if (greedy) {                                              // (the measured-curve plan deals this batch only: the rest, evenly)
+                const int spare = std::max(0, nwg - used);
+                cw_all.insert(cw_all.end(), (size_t)n_bg, std::max(1, std::min(mcw_bg, 1 + spare / n_bg)));
+            }
+            wt_all.insert(wt_all.end(), (size_t)n_bg, 0.0);            // (not on the launch's critical path)
+            for (int i = 0; i < n_bg; ++i) work.push_back(make_int4(bg[(size_t)i].x, bg[(size_t)i].y, 0, 1));
+        }
+        const int prio_flag = n_bg > 0 ? 0x40000000 : 0;               // (SearchArgs::n_prio: which work items the launch is there for)
         // XCD-local launch (jd_search.h): every cluster inside one eighth of the grid - the clusters go, largest
         // first, into the eighth with the most room; one that fits nowhere shrinks to the room there is, and what
         // an eighth has left over in the end goes to its cluster with the latest predicted finish.  The packed plan
         // is taken if the model says it ends no more than 4 % after the unpacked one (what plain stores and L2
         // atomics are measured to be worth): a cluster squeezed into a corner is a long tail.
-        const int bin = nwg / 8;
-        if (d->xl_ok && (nwg & 7) == 0) {
-            auto t_of = [&](int k, int c) { return std::max((*weight)[(size_t)k], 1.0) * (a_us + b_us / std::max(c, 1)); };
-            std::vector<int> order((size_t)n_work), pos((size_t)n_work, 0), room(8, bin), cwx = cw;
+        const int bin = nwg_all / 8;
+        if (d->xl_ok && (nwg_all & 7) == 0) {
+            auto t_of = [&](int k, int c) { return wt_all[(size_t)k] <= 0.0 ? 0.0 : std::max(wt_all[(size_t)k], 1.0) * (a_us + b_us / std::max(c, 1)); };
+            std::vector<int> order((size_t)n_tot), pos((size_t)n_tot, 0), room(8, bin), cwx = cw_all;
             std::vector<std::vector<int>> member(8);
             std::iota(order.begin(), order.end(), 0);
             std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cwx[(size_t)x] > cwx[(size_t)y]; });
@@ -1160,42 +1249,47 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
                     while (room[(size_t)b] > 0 && !member[(size_t)b].empty()) {
                         int late = -1;
                         for (int k : member[(size_t)b])
-                            if (cwx[(size_t)k] < max_cw && (late < 0 || t_of(k, cwx[(size_t)k]) > t_of(late, cwx[(size_t)late]))) late = k;
+                            if (cwx[(size_t)k] < (k < n_work ? mcw : std::min(d->bg_cw_cap, max_cw)) &&
+                                (late < 0 || t_of(k, cwx[(size_t)k]) > t_of(late, cwx[(size_t)late]))) late = k;
                         if (late < 0) break;
                         ++cwx[(size_t)late]; --room[(size_t)b];
                     }
                     int at = b * bin;
                     for (int k : member[(size_t)b]) { pos[(size_t)k] = at; at += cwx[(size_t)k]; }
                 }
-                for (int k = 0; k < n_work; ++k) { tau_plain = std::max(tau_plain, t_of(k, cw[(size_t)k])); tau_xl = std::max(tau_xl, t_of(k, cwx[(size_t)k])); }
+                for (int k = 0; k < n_work; ++k) { tau_plain = std::max(tau_plain, t_of(k, cw_all[(size_t)k])); tau_xl = std::max(tau_xl, t_of(k, cwx[(size_t)k])); }
                 if (tau_xl > d->xl_slack * tau_plain) fits = false;
             }
             if (fits) {
-                for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = pos[(size_t)k]; work[(size_t)k].w = cwx[(size_t)k]; }
+                for (int k = 0; k < n_tot; ++k) { work[(size_t)k].z = pos[(size_t)k]; work[(size_t)k].w = cwx[(size_t)k] | (k < n_work ? prio_flag : 0); }
                 // (the kernel searches by first workgroup)
                 std::sort(work.begin(), work.end(), [](const int4 &x, const int4 &y) { return x.z < y.z; });
-                grid = nwg;
+                grid = nwg_all;
                 xl = true;
             }
         }
         if (!xl) {
             int first = 0;
-            for (int k = 0; k < n_work; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw[(size_t)k]; first += cw[(size_t)k]; }
+            for (int k = 0; k < n_tot; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw_all[(size_t)k] | (k < n_work ? prio_flag : 0); first += cw_all[(size_t)k]; }
             grid = first;
         }
+        if (n_bg > 0) { A.n_prio = n_work; A.n_work = n_tot; d->bg_ran = true; }
         A.n_slots = 0;
         // Re-planning under way (SearchArgs::rebalance_at): the plan above makes the streams finish together only as
         // far as frames predict work; when a fifth of the grid has run out of work the launch is cut short and the
         // rest planned anew - worth it while the rest is long against the ~0.2 ms a relaunch costs.
+        // (not with the batch behind beside it: a cut stops ITS streams too, every leg pays the launch's set-up again and
+        // the workgroups a finished cluster leaves are few against what the batch behind keeps busy anyway - measured at
+        // configs[1]: 35.4 ms per step with cuts, 30.2 without; JD_BG_REBALANCE=1 brings them back)
         rebalance_at = 0;
-        if (d->rebalance && n_work >= 4) {
+        if (d->rebalance && n_work >= 4 && (n_bg == 0 || d->bg_rebalance)) {
             double tau = 0.0;
-            for (int k = 0; k < n_work; ++k) tau = std::max(tau, std::max((*weight)[(size_t)k], 1.0) * (a_us + b_us / std::max(work[(size_t)k].w, 1)));
+            for (int k = 0; k < n_work; ++k) tau = std::max(tau, std::max((*weight)[(size_t)k], 1.0) * (a_us + b_us / std::max(work[(size_t)k].w & 0xffff, 1)));
             if (tau > d->rebalance_min_us) rebalance_at = std::max(1, (int)(d->rebalance_frac * grid));
         }
 
     } else if (d->xl_ok && A.Cw > 1 && (grid & 7) == 0 && ((grid >> 3) % A.Cw) == 0) xl = true;   // uniform clusters that tile the eighths
-    HIPCHK(hipMemcpyAsync(d->d_work, work.data(), (size_t)n_work * sizeof(int4), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->d_work, work.data(), work.size() * sizeof(int4), hipMemcpyHostToDevice, st));
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
     A.status = d->d_status; A.dbg = d->d_dbg; A.rebalance_at = rebalance_at;
     A.xl_selftest = getenv("JD_XL_SELFTEST") ? 1 : 0;                 // (test knob, see SearchArgs)
@@ -1233,21 +1327,21 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // would hold the re-planning up for the whole launch (348 against 343 ms serial) and is better slotted in at the
         // cuts (340).  Decided by the measured costs of this decoder's last waves.
         bool hold_replan = false;
-        if (d->pf_armed && d->pf_next.state == 1) {
+        if (d->pf_armed && pf_wants_scoring(d)) {
             double frames_now = 0.0;
             if (weight) for (double w : *weight) frames_now += w;
-            const double est_gmm = d->gmm_ms_per_row * (double)d->pf_next.plan.chunk_rows[0];
+            const double est_gmm = d->gmm_ms_per_row * pf_scoring_rows(d);
             const double est_search = d->search_ms_per_frame * frames_now;
             hold_replan = d->pf_rebalance == 0 || (d->pf_rebalance < 0 && est_gmm > 0.0 && est_search > 0.0 && est_gmm >= 0.1 * est_search);
         }
-        hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, n_work, d->d_status,
+        hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((A.n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, A.n_work, d->d_status,
                            hold_replan ? 1 : 0);
         HIPCHK(hipEventRecord(e0, st));
         // the kernel flavour: HMM size class x XCD-local x lazily composed graph
         hipLaunchKernelGGL(search_kernel(ne3, xl, d->C.lazy != nullptr), dim3(grid), dim3(SNT), 0, st, A);
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipGetLastError());
-        if (d->pf_armed && d->pf_next.state == 1) {
+        if (d->pf_armed && pf_wants_scoring(d)) {
             // the next batch's table is scored beside this launch (jd_dec_prefetch_scores): its kernel is enqueued once
             // the search is resident - the last workgroup of the grid says so in a host-mapped word - so that scoring
             // blocks never sit on a CU a search workgroup is waiting for (2 ms: it goes ahead anyway)
@@ -1257,13 +1351,13 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             const int pr = pf_launch(d);
             if (pr) { (void)hipStreamSynchronize(st); return pr; }       // (k_search is in flight: not left behind with the launch lock released)
         }
-        HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(d->h_status, d->d_status, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) d->timing.search_ms += ms;
         if (getenv("JD_VERBOSE")) {                                        // development
             int cmin = 1 << 30, cmax = 0;
-            for (const int4 &w : work) { cmin = std::min(cmin, w.w); cmax = std::max(cmax, w.w); }
+            for (const int4 &w : work) { cmin = std::min(cmin, w.w & 0xffff); cmax = std::max(cmax, w.w & 0xffff); }
             fprintf(stderr, "k_search: %d streams, grid %d (clusters %d..%d workgroups, %s%s), frames [%d, %d): %.3f ms\n", n_work, grid,
                     cmin, cmax, A.n_slots ? "uniform" : "weighted", xl ? ", XCD-local" : "", f0, f_end, ms);
             if (d->h_status[3]) fprintf(stderr, "          cut short for a re-plan: %d streams go on\n", d->h_status[0]);
@@ -1282,8 +1376,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // Some streams stopped for a collection of their Path records (k_gc_*: no-ops for the streams below
         // their mark): the launch is repeated for the streams that are not through, with clusters sized for
         // what each of them still has ahead.
-        if (d->h_status[0] > d->h_status[3]) {                             // (not when every stop was for a re-plan)
-            launch_gc(d->C, d->d_ctl, d->d_streams, d->d_work, n_work, 0, ne3, d->n_cus, st);
+        if (d->h_status[0] > d->h_status[3] + d->h_status[6]) {           // (not when every stop was for a re-plan, or a stream ahead of its turn stopping with the launch)
+            launch_gc(d->C, d->d_ctl, d->d_streams, d->d_work, A.n_work, 0, ne3, d->n_cus, st);
             HIPCHK(hipGetLastError());
             // PARTIAL_DECODING: the trace rides on the collection (:362-368) - the caller has to see the stream as it
             // stands right after one (jd_stream_push; it goes on from there)
@@ -1338,10 +1432,11 @@ static int plan_wave(jd_dec *d, int nb, const int64_t *ustart, const int64_t *ul
     {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const double have = 0.25 * (double)free_b + (double)(d->ll_cap[0] + d->ll_cap[1]) * sizeof(float);
+        // (three tables of one size are kept: ensure_slab)
+        const double have = 0.25 * (double)free_b + 3.0 * (double)d->ll_cap * sizeof(float);
         const double per_frame = (double)nb * G * sizeof(float);       // (a chunk holds at most nb * Fc rows)
-        if ((double)(sumT + 128) * G * sizeof(float) > have && (double)Fc * per_frame > have)
-            Fc = std::max(128, (int)(0.5 * have / per_frame) / 128 * 128);
+        if (3.0 * (double)(sumT + 128) * G * sizeof(float) > have && 3.0 * (double)Fc * per_frame > have)
+            Fc = std::max(128, (int)(have / 3.0 / per_frame) / 128 * 128);
         if (d->Fw_env > 0) Fc = d->Fw_env;
     }
     P.Fc = Fc;
@@ -1377,15 +1472,30 @@ static int plan_wave(jd_dec *d, int nb, const int64_t *ustart, const int64_t *ul
     return JD_OK;
 }
 
-// table i holds `floats`, its row table `rows` entries (grown, never shrunk)
-static int ensure_table(jd_dec *d, int i, size_t floats, size_t rows)
+// The likelihood tables: THREE of one size in one allocation (a search launch addresses the table of every stream it
+// advances as a row of that slab: SearchArgs::ll + slot * G), each with its row -> source frame table.  Three, because
+// three batches can be under way at once ("two batches in flight" below): the one the caller is waiting for, the one
+// behind it whose utterances are already being searched, and the one behind that whose table is being scored.
+// Growing the slab loses what is in it: only when nothing scored ahead is waiting (the callers see to that).
+static int ensure_slab(jd_dec *d, size_t floats)
 {
-    if (floats > d->ll_cap[i]) {
-        if (d->d_ll[i]) (void)hipFree(d->d_ll[i]);
-        d->d_ll[i] = nullptr; d->ll_cap[i] = 0;
-        HIPCHK(hipMalloc(&d->d_ll[i], floats * sizeof(float)));
-        d->ll_cap[i] = floats;
+    if (floats <= d->ll_cap) return JD_OK;
+    if (d->d_ll_slab) (void)hipFree(d->d_ll_slab);
+    d->d_ll_slab = nullptr; d->ll_cap = 0;
+    for (int i = 0; i < 3; ++i) d->d_ll[i] = nullptr;
+    const size_t G = (size_t)d->am->n_gmm;
+    floats = (floats + G - 1) / G * G;                                 // whole rows: a table starts at a row of the slab
+    hipError_t e = hipMalloc(&d->d_ll_slab, 3 * floats * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return jd_fail(e == hipErrorOutOfMemory ? JD_ENOMEM : JD_EHIP, "hipMalloc of %zu bytes (likelihood tables) failed: %s", 3 * floats * sizeof(float), hipGetErrorString(e));
     }
+    d->ll_cap = floats;
+    for (int i = 0; i < 3; ++i) d->d_ll[i] = d->d_ll_slab + (size_t)i * floats;
+    return JD_OK;
+}
+static int ensure_rows(jd_dec *d, int i, size_t rows)
+{
     if (rows > d->row_src_cap[i]) {
         if (d->d_row_src[i]) (void)hipFree(d->d_row_src[i]);
         d->d_row_src[i] = nullptr; d->row_src_cap[i] = 0;
@@ -1394,98 +1504,254 @@ static int ensure_table(jd_dec *d, int i, size_t floats, size_t rows)
     }
     return JD_OK;
 }
+// table i holds `floats`, its row table `rows` entries (grown, never shrunk)
+static int ensure_table(jd_dec *d, int i, size_t floats, size_t rows)
+{
+    int rc = ensure_slab(d, floats);
+    if (rc) return rc;
+    return ensure_rows(d, i, rows);
+}
+static long long table_row0(const jd_dec *d, int buf) { return (long long)buf * (long long)(d->ll_cap / (size_t)d->am->n_gmm); }
 
-// Forget what was scored or announced ahead (the scoring stream is drained first: a table being written is not re-used)
+// Forget what was scored, searched or announced ahead (the scoring stream is drained first: a table being written is
+// not re-used; utterances whose search had been started are simply started again when their batch is decoded)
 static void pf_discard(jd_dec *d)
 {
-    if (d->pf_ready.state == 2 || d->pf_next.state == 2) (void)hipStreamSynchronize(d->s_gmm);
-    d->pf_ready.drop(); d->pf_next.drop();
+    bool scoring = false;
+    for (const Prefetch &F : d->pf_q) if (F.state == 2) scoring = true;
+    if (scoring) (void)hipStreamSynchronize(d->s_gmm);
+    for (Prefetch &F : d->pf_q) F.drop();
+    d->pf_q.clear();
+}
+// ... what has been scored ahead only: the announcements stay (they are scored again, beside the next search)
+static void pf_discard_scored(jd_dec *d)
+{
+    bool scoring = false;
+    for (const Prefetch &F : d->pf_q) if (F.state == 2) scoring = true;
+    if (scoring) (void)hipStreamSynchronize(d->s_gmm);
+    for (Prefetch &F : d->pf_q) { F.drop_events(); F.state = 1; F.bank = -1; }
+}
+// a table that neither the running batch (fg_buf, -1: none) nor a batch scored ahead holds; -1: none
+static int free_table(const jd_dec *d, int fg_buf)
+{
+    for (int t = 0; t < 3; ++t) {
+        bool used = t == fg_buf;
+        for (const Prefetch &F : d->pf_q) if (F.state == 2 && F.buf == t) used = true;
+        if (!used) return t;
+    }
+    return -1;
 }
 
-// Start the announced scoring (pf_next) into the table the running wave does not use.  Called by launch_search right
-// behind the dispatch of a persistent search launch, once that launch is resident: the scoring kernel's blocks then
-// only ever get the CUs that clusters of the search have left.
+// Start the scoring of the batches that have been announced and not scored yet, each into a table nobody holds.  Called
+// by launch_search right behind the dispatch of a persistent search launch, once that launch is resident: the scoring
+// kernel's blocks then only ever get the CUs that clusters of the search have left.
 static int pf_launch(jd_dec *d)
 {
-    Prefetch &F = d->pf_next;
-    if (F.state != 1) return JD_OK;
-    const int buf = d->cur_buf ^ 1;
-    const int G = d->am->n_gmm;
-    // Scoring ahead is an optimisation: when it cannot be set up (no room for the second table, ...) the announcement
-    // is dropped, the batch is scored when it is decoded, and the search launch beside us may be re-planned again.
-    auto give_up = [&]() {
-        (void)hipGetLastError();
-        F.drop();
-        (void)hipMemsetAsync(d->d_status + 4, 0, sizeof(int), d->s_gmm);
-        return JD_OK;
-    };
-    if (ensure_table(d, buf, F.plan.max_rows * G, F.plan.n_rows_all) != JD_OK) return give_up();
-    if (hipEventCreate(&F.ev0) != hipSuccess || hipEventCreate(&F.ev1) != hipSuccess) return give_up();
-    if (hipMemcpyAsync(d->d_row_src[buf], F.plan.row_src.data(), F.plan.n_rows_all * sizeof(int), hipMemcpyHostToDevice, d->s_gmm) != hipSuccess ||
-        hipEventRecord(F.ev0, d->s_gmm) != hipSuccess)
-        return give_up();
-    if (launch_gmm(d->am, d->amb, F.feats, d->d_row_src[buf], F.plan.chunk_rows[0], d->d_ll[buf], d->s_gmm, 0, true) != JD_OK) return give_up();
-    HIPCHK(hipEventRecord(F.ev1, d->s_gmm));
-    HIPCHK(hipMemsetAsync(d->d_status + 4, 0, sizeof(int), d->s_gmm)); // the search may be re-planned again
-    F.buf = buf; F.state = 2;
+    const size_t G = (size_t)d->am->n_gmm;
+    bool any = false;
+    for (Prefetch &F : d->pf_q) {
+        if (F.state != 1) continue;
+        // Scoring ahead is an optimisation: a batch that cannot be scored now (no table free, a table larger than the
+        // slab - which cannot grow while tables are in use) is scored when it is decoded, as ever.
+        const int buf = free_table(d, d->fg_buf);
+        if (buf < 0 || F.plan.max_rows * G > d->ll_cap) break;
+        if (ensure_rows(d, buf, F.plan.n_rows_all) != JD_OK) { (void)hipGetLastError(); break; }
+        if (hipEventCreate(&F.ev0) != hipSuccess || hipEventCreate(&F.ev1) != hipSuccess) { (void)hipGetLastError(); F.drop_events(); break; }
+        if (hipMemcpyAsync(d->d_row_src[buf], F.plan.row_src.data(), F.plan.n_rows_all * sizeof(int), hipMemcpyHostToDevice, d->s_gmm) != hipSuccess ||
+            hipEventRecord(F.ev0, d->s_gmm) != hipSuccess ||
+            launch_gmm(d->am, d->amb, F.feats, d->d_row_src[buf], F.plan.chunk_rows[0], d->d_ll[buf], d->s_gmm, 0, true) != JD_OK ||
+            hipEventRecord(F.ev1, d->s_gmm) != hipSuccess) {
+            (void)hipGetLastError(); F.drop_events(); break;
+        }
+        F.buf = buf; F.state = 2;
+        any = true;
+    }
+    (void)any;
+    HIPCHK(hipMemsetAsync(d->d_status + 4, 0, sizeof(int), d->s_gmm)); // (behind the scoring, if any: the search may be re-planned again)
     return JD_OK;
 }
-
-// Announce a wave (pf_next): it is scored beside the next search launch of a wave that leaves a table free.  A wave
-// whose table would be cut into chunks is not announced (it is scored when it is decoded, as ever).
-static int pf_announce(jd_dec *d, int nb, const float *d_feats, const int64_t *ustart, const int64_t *ulen)
+static bool pf_wants_scoring(const jd_dec *d)
 {
-    if (d->pf_next.state == 2) (void)hipStreamSynchronize(d->s_gmm);
-    d->pf_next.drop();
-    if (nb <= 0 || nb > d->max_streams) return JD_OK;
-    Prefetch &F = d->pf_next;
+    for (const Prefetch &F : d->pf_q) if (F.state == 1) return free_table(d, d->fg_buf) >= 0 && F.plan.max_rows * (size_t)d->am->n_gmm <= d->ll_cap;
+    return false;
+}
+static bool pf_scoring_in_flight(const jd_dec *d)
+{
+    for (const Prefetch &F : d->pf_q)
+        if (F.state == 2 && F.ev1 && hipEventQuery(F.ev1) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return false;
+}
+static double pf_scoring_rows(const jd_dec *d)
+{
+    double rows = 0.0;
+    for (const Prefetch &F : d->pf_q) if (F.state == 1) rows += (double)F.plan.chunk_rows[0];
+    return rows;
+}
+
+// Announce a wave: it joins the queue of batches ahead (at most three; one more is not taken) and is scored beside
+// the next search launch that leaves a table free.  A wave whose table would be cut into chunks is not announced (it
+// is scored when it is decoded, as ever).  front: in front of what the caller announced (the waves of one call).
+static int pf_announce(jd_dec *d, int nb, const float *d_feats, const int64_t *ustart, const int64_t *ulen, bool front = false)
+{
+    if (nb <= 0 || nb > d->max_streams || d->pf_q.size() >= 3) return JD_OK;
+    Prefetch F;
     F.ustart.assign(ustart, ustart + nb);
     F.ulen.assign(ulen, ulen + nb);
     const int rc = plan_wave(d, nb, F.ustart.data(), F.ulen.data(), F.plan);
-    if (rc) { F.drop(); return rc; }
-    if (F.plan.n_chunks != 1) { F.drop(); return JD_OK; }
+    if (rc) return rc;
+    if (F.plan.n_chunks != 1) return JD_OK;
     F.feats = d_feats; F.nb = nb; F.state = 1;
+    if (front) d->pf_q.push_front(std::move(F)); else d->pf_q.push_back(std::move(F));
+    return JD_OK;
+}
+
+// ---- two batches in flight.  A batch of 64 utterances lasts as long as its longest one - a chain of ~1150 dependent
+// frames - while the clusters of the shorter ones are through after half of that: whatever the plan, workgroup-time is
+// burnt waiting.  What a stream of batches allows: the utterances of the batch BEHIND the one the caller
+// is waiting for are started beside it, one workgroup each (no cluster barrier at all), on stream slots of their own
+// (the decoder's streams are two banks of max_streams / 2) - when that batch's turn comes its utterances are hundreds
+// of frames in, and the step is that much shorter.  It takes a table scored one batch earlier, i.e. announcements
+// that run two batches ahead of the decode (jd_dec_prefetch_scores twice before the first decode, once per decode
+// afterwards).  Nothing changes for a caller who does not announce, announces one ahead, or fills more than half of
+// the streams with one batch; results cannot depend on any of it (streams never interact).
+// The batch behind the running one, if its table is there: its unfinished streams as work items for the launch that is
+// being planned (started - initialised, frame counts set - the first time round).  heads: {frame, T, error, needs_init} of
+// every stream, as of now (only read for a batch that has been started before).
+static int pf_background(jd_dec *d, int fg_bank, const std::vector<int> *heads, hipStream_t st, std::vector<int2> *work, std::vector<double> *left)
+{
+    work->clear(); left->clear();
+    if (d->pf_q.empty() || !d->pipeline || d->C.lazy) return JD_OK;
+    Prefetch &F = d->pf_q.front();
+    const int B = d->max_streams / 2;
+    if (F.state != 2 || F.nb > B || F.plan.n_chunks != 1) return JD_OK;
+    if (F.bank < 0) {
+        // its table was scored beside the search before this one and is about ready: worth a moment (JD_BG_WAIT_US)
+        const auto tq0 = std::chrono::steady_clock::now();
+        while (hipEventQuery(F.ev1) != hipSuccess) {
+            (void)hipGetLastError();
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count() > d->bg_wait_us) return JD_OK;   // still being scored
+        }
+        F.bank = fg_bank ^ 1;
+        const int s0 = F.bank * B;
+        int rc = mark_init(d, s0, F.nb, st);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(d->d_T + s0, F.plan.T.data(), (size_t)F.nb * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(jd_set_T_kernel, dim3((F.nb + 63) / 64), dim3(64), 0, st, d->d_ctl, s0, F.nb, d->d_T + s0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));                              // (plan.T may move with the queue)
+        for (int u = 0; u < F.nb; ++u) {
+            work->push_back(make_int2(s0 + u, (int)(table_row0(d, F.buf) + F.plan.row_off[(size_t)u])));
+            left->push_back((double)F.plan.T[(size_t)u]);
+        }
+        return JD_OK;
+    }
+    if (!heads) return JD_OK;
+    const int s0 = F.bank * B;
+    for (int u = 0; u < F.nb; ++u) {
+        const int *h = heads->data() + (size_t)(s0 + u) * 4;
+        if (h[2] == 0 && h[0] < F.plan.T[(size_t)u]) {
+            work->push_back(make_int2(s0 + u, (int)(table_row0(d, F.buf) + F.plan.row_off[(size_t)u])));
+            left->push_back((double)(F.plan.T[(size_t)u] - h[0]));
+        }
+    }
     return JD_OK;
 }
 
 // Decode one wave of nb <= max_streams utterances held in device memory.
-// Stream u decodes frames [ustart[u], ustart[u] + ulen[u]) of d_feats.
+// Stream u decodes frames [ustart[u], ustart[u] + ulen[u]) of d_feats.  *s0_out: the first stream it ran on.
 static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *ustart, const int64_t *ulen,
-                       hipStream_t user_stream)
+                       hipStream_t user_stream, int *s0_out)
 {
     const int G = d->am->n_gmm;
     const double gmm_before = d->timing.gmm_ms, search_before = d->timing.search_ms;
-    // a table scored ahead for exactly this wave (jd_dec_prefetch_scores)?
-    bool prefetched = false;
-    {
-        Prefetch &R = d->pf_ready;
-        if (R.state == 2) {
-            prefetched = R.feats == d_feats && R.nb == nb && std::equal(ustart, ustart + nb, R.ustart.begin()) &&
-                         std::equal(ulen, ulen + nb, R.ulen.begin());
-            if (!prefetched) { (void)hipStreamSynchronize(d->s_gmm); R.drop(); }
+    // is this wave the one at the head of the batches ahead (jd_dec_prefetch_scores)?  An announcement speaks of a batch
+    // BEHIND the decode that follows it (a stream of equal batches announces the very batch it is about to decode):
+    // only a batch whose table has been scored ahead - beside an earlier decode - can be the one decoded now.
+    Prefetch me;
+    bool mine = false;
+    if (!d->pf_q.empty()) {
+        Prefetch &F = d->pf_q.front();
+        mine = F.state == 2 && F.feats == d_feats && F.nb == nb && std::equal(ustart, ustart + nb, F.ustart.begin()) &&
+               std::equal(ulen, ulen + nb, F.ulen.begin());
+        if (mine) { me = std::move(F); d->pf_q.pop_front(); }
+        else {
+            // not the batch that was announced: what has been scored (or searched) ahead is for a batch that is not
+            // coming now - dropped; announcements nothing has been done for yet stay (they are batches BEHIND this one)
+            bool worked = false;
+            for (const Prefetch &Q : d->pf_q) if (Q.state == 2 || Q.bank >= 0) worked = true;
+            if (worked) pf_discard(d);
         }
     }
+    struct MeGuard { Prefetch &p; ~MeGuard() { p.drop(); } } me_guard{me};
+    const bool prefetched = mine;
     WavePlan plan_local;
     int rc = JD_OK;
-    if (!prefetched) { rc = plan_wave(d, nb, ustart, ulen, plan_local); if (rc) return rc; }
-    const WavePlan &P = prefetched ? d->pf_ready.plan : plan_local;
+    if (!mine) { rc = plan_wave(d, nb, ustart, ulen, plan_local); if (rc) return rc; }
+    const WavePlan &P = mine ? me.plan : plan_local;
     const std::vector<int> &T = P.T;
     const int Fc = P.Fc, n_chunks = P.n_chunks, maxT = P.maxT;
-    if (prefetched) d->cur_buf = d->pf_ready.buf;                      // (single-chunk by construction)
-    const int b0 = (n_chunks == 1) ? d->cur_buf : 0;                   // table of chunk c: b0 ^ (c & 1)
-    if (n_chunks > 1 && d->pf_next.state == 1) d->pf_next.drop();      // (both tables are in use)
-    if (!prefetched)
-        for (int i = 0; i < std::min(2, n_chunks); ++i) { rc = ensure_table(d, b0 ^ i, P.max_rows * G, i == 0 ? P.n_rows_all : 0); if (rc) return rc; }
+    // stream bank: the utterances of a batch that fills at most half of the streams run on one of two banks, so that
+    // the batch behind it can be started beside it (pf_background)
+    const int B = d->max_streams / 2;
+    const bool pipe = d->pipeline && B > 0 && nb <= B && n_chunks == 1 && !d->C.lazy;
+    {
+        bool scored = false, started = false;
+        for (const Prefetch &Q : d->pf_q) { if (Q.state == 2) scored = true; if (Q.bank >= 0) started = true; }
+        // a wave in chunks needs tables 0 and 1: nothing scored ahead survives it
+        if (n_chunks > 1 && (scored || started)) pf_discard(d);
+        // a wave outside the banks takes the streams a batch behind it has been started on: that batch starts again when
+        // its turn comes (its table stays)
+        else if (!pipe && started) for (Prefetch &Q : d->pf_q) Q.bank = -1;
+    }
+    const bool resumed = prefetched && pipe && me.bank >= 0;           // its utterances have been started beside the batch before
+    int bank = 0;
+    if (pipe) {
+        bank = resumed ? me.bank : 0;
+        if (!resumed) for (const Prefetch &Q : d->pf_q) if (Q.bank == bank) bank ^= 1;   // (at most one batch ahead holds a bank)
+    }
+    const int s0 = pipe ? bank * B : 0;
+    if (s0_out) *s0_out = s0;
+    // tables: a single-chunk wave sits in one of the three; chunks alternate between tables 0 and 1
+    int b0 = 0;
+    if (n_chunks == 1) {
+        if (prefetched) b0 = me.buf;
+        else {
+            // the three tables are of one size: this wave's, or what a batch announced behind it needs if that is more
+            // (with some room: a slab that has to grow loses whatever was scored ahead)
+            size_t need = P.max_rows * (size_t)G;
+            for (const Prefetch &Q : d->pf_q) need = std::max(need, Q.plan.max_rows * (size_t)G);
+            if (need > d->ll_cap) { pf_discard_scored(d); need += need / 8; }
+            rc = ensure_slab(d, need);
+            if (rc) return rc;
+            b0 = free_table(d, -1);
+            if (b0 < 0) { pf_discard(d); b0 = 0; }
+            rc = ensure_rows(d, b0, P.n_rows_all);
+            if (rc) return rc;
+        }
+    } else {
+        rc = ensure_slab(d, P.max_rows * (size_t)G);
+        if (rc) return rc;
+        for (int i = 0; i < 2; ++i) { rc = ensure_rows(d, i, i == 0 ? P.n_rows_all : 0); if (rc) return rc; }
+    }
+    d->fg_buf = n_chunks == 1 ? b0 : -2;                               // (-2: both of tables 0 / 1 - nothing is scored ahead meanwhile)
+    struct FgGuard { jd_dec *d; ~FgGuard() { d->fg_buf = -1; } } fg_guard{d};
     // the caller's features may have been produced asynchronously on its stream (NULL = the
     // default stream): the decoder's own streams are non-blocking, so order against it explicitly
     HIPCHK(hipStreamSynchronize(user_stream));
     if (!prefetched)
         HIPCHK(hipMemcpyAsync(d->d_row_src[b0], P.row_src.data(), P.n_rows_all * sizeof(int), hipMemcpyHostToDevice, d->s_gmm));
-    HIPCHK(hipMemcpyAsync(d->d_T, T.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, d->s_search));
-    rc = mark_init(d, 0, nb, d->s_search);
-    if (rc) return rc;
-    hipLaunchKernelGGL(jd_set_T_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, 0, nb, d->d_T);
-    HIPCHK(hipGetLastError());
+    std::vector<int> frame0((size_t)nb, 0);                            // where the streams stand (a batch started ahead: hundreds of frames in)
+    if (!resumed) {
+        HIPCHK(hipMemcpyAsync(d->d_T + s0, T.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, d->s_search));
+        rc = mark_init(d, s0, nb, d->s_search);
+        if (rc) return rc;
+        hipLaunchKernelGGL(jd_set_T_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, s0, nb, d->d_T + s0);
+        HIPCHK(hipGetLastError());
+    } else {
+        std::vector<int> head((size_t)nb * 4);
+        HIPCHK(hipMemcpy2D(head.data(), 16, d->d_ctl + s0, sizeof(StreamCtl), 16, (size_t)nb, hipMemcpyDeviceToHost));
+        for (int u = 0; u < nb; ++u) { frame0[(size_t)u] = head[(size_t)u * 4]; d->timing.ahead_frames += head[(size_t)u * 4]; }
+    }
 
     struct Events {                                                    // (destroyed on every way out, error paths included)
         std::vector<hipEvent_t> v;
@@ -1494,8 +1760,8 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     ev_gs.v.assign((size_t)n_chunks, nullptr); ev_ge.v.assign((size_t)n_chunks, nullptr);
     std::vector<hipEvent_t> &gs = ev_gs.v, &ge = ev_ge.v;
     if (prefetched) {                                                  // the scoring's own events (Events destroys them)
-        gs[0] = d->pf_ready.ev0; ge[0] = d->pf_ready.ev1;
-        d->pf_ready.ev0 = d->pf_ready.ev1 = nullptr;
+        gs[0] = me.ev0; ge[0] = me.ev1;
+        me.ev0 = me.ev1 = nullptr;
     } else
         for (int c = 0; c < n_chunks; ++c) { HIPCHK(hipEventCreate(&gs[(size_t)c])); HIPCHK(hipEventCreate(&ge[(size_t)c])); }
     auto w0 = std::chrono::steady_clock::now();
@@ -1517,6 +1783,7 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     double waited_ms = 0.0;
     std::vector<int2> work;
     std::vector<double> weight;
+    long long frames_here = 0;
     for (int c = 0; c < n_chunks; ++c) {
         const auto tw0 = std::chrono::steady_clock::now();
         HIPCHK(hipEventSynchronize(ge[(size_t)c]));                    // scores of this chunk are there
@@ -1524,38 +1791,48 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         if (c + 1 < n_chunks) { rc = score_chunk(c + 1); if (rc) return rc; }
         // a launch lasts as long as its slowest stream: the clusters are sized by the frames ahead of each
         const int c0 = c * Fc, c1 = (c + 1) * Fc;
+        const long long row0 = table_row0(d, b0 ^ (c & 1));            // (k_search reads row  slot + (f - c0)  of the slab)
         work.clear(); weight.clear();
         for (int u = 0; u < nb; ++u)
-            if (c == 0 || T[(size_t)u] > c0) {
-                work.push_back(make_int2(u, P.row_off[(size_t)c * nb + u]));   // {stream, its first row in the chunk's table}
-                weight.push_back((double)(std::min(T[(size_t)u], c1) - c0));
+            if ((c == 0 && frame0[(size_t)u] == 0) || T[(size_t)u] > std::max(c0, frame0[(size_t)u])) {
+                work.push_back(make_int2(s0 + u, (int)(row0 + P.row_off[(size_t)c * nb + u])));   // {stream, its first row in the chunk's table}
+                weight.push_back((double)(std::min(T[(size_t)u], c1) - std::max(c0, frame0[(size_t)u])));
+                frames_here += std::min(T[(size_t)u], c1) - std::max(c0, frame0[(size_t)u]);
             }
-        const float *ll = d->d_ll[b0 ^ (c & 1)];
-        if (d->load_scale == 1.0 && d->weighted && c == 0 && nb > 1 && std::min(maxT, c1) - c0 > 128) {
+        const float *ll = d->d_ll_slab;
+        if (d->load_scale == 1.0 && d->weighted && c == 0 && nb > 1 && std::min(maxT, c1) - c0 > 128 && !resumed) {
             // the decoder's very first batch: nothing is known about the load yet, and the cluster sizes depend
             // on it (a frame of 2 M instances is not a frame of 12 k) - a short launch finds out
             const int c_mid = c0 + 32;
             std::vector<double> wp(weight.size());
             for (size_t i = 0; i < wp.size(); ++i) wp[i] = std::min(weight[i], 32.0);
             rc = launch_search(d, work, ll, (long long)G, c0, c_mid, d->s_search, &wp);
-            if (rc) { for (int u = 0; u < nb; ++u) d->stream_dirty[(size_t)u] = 1; return rc; }
+            if (rc) { for (int u = 0; u < nb; ++u) d->stream_dirty[(size_t)(s0 + u)] = 1; return rc; }
             if (d->load_scale == 1.0) { rc = learn_load(d, work); if (rc) return rc; }
             std::vector<int2> w2; std::vector<double> wt2;
-            for (size_t i = 0; i < work.size(); ++i)
-                if (T[(size_t)work[i].x] > c_mid) { w2.push_back(work[i]); wt2.push_back((double)(std::min(T[(size_t)work[i].x], c1) - c_mid)); }
+            for (size_t i = 0; i < work.size(); ++i) {
+                const int u = work[i].x - s0;
+                if (T[(size_t)u] > c_mid) { w2.push_back(work[i]); wt2.push_back((double)(std::min(T[(size_t)u], c1) - c_mid)); }
+            }
             work.swap(w2); weight.swap(wt2);
         }
-        d->pf_armed = n_chunks == 1 && d->pf_next.state == 1;          // the next batch's table is scored beside this launch
+        d->pf_armed = n_chunks == 1;                                   // batches ahead are scored / started beside this launch
+        d->fg_bank = pipe ? bank : -1;
         rc = launch_search(d, work, ll, (long long)G, c0, c1, d->s_search, &weight);
-        d->pf_armed = false;
-        if (rc) { for (int u = 0; u < nb; ++u) d->stream_dirty[(size_t)u] = 1; return rc; }   // (nobody looks at the streams' error words)
+        d->pf_armed = false; d->fg_bank = -1;
+        if (rc) { for (int u = 0; u < nb; ++u) d->stream_dirty[(size_t)(s0 + u)] = 1; return rc; }   // (nobody looks at the streams' error words)
     }
-    hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, 0, nb);
+    hipLaunchKernelGGL(jd_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, d->d_streams, s0, nb);
     HIPCHK(hipGetLastError());
-    if (d->pf_next.state != 2) HIPCHK(hipStreamSynchronize(d->s_gmm)); // (a table being scored ahead is waited for by the wave that uses it)
+    {   // (a table being scored ahead is waited for by the wave that uses it)
+        bool scoring = false;
+        for (const Prefetch &Q : d->pf_q) if (Q.state == 2) scoring = true;
+        if (!scoring) HIPCHK(hipStreamSynchronize(d->s_gmm));
+    }
     HIPCHK(hipStreamSynchronize(d->s_search));
     auto w1 = std::chrono::steady_clock::now();
     d->timing.total_ms += std::chrono::duration<double, std::milli>(w1 - w0).count();
+    d->last_wave_ms = std::chrono::duration<double, std::milli>(w1 - w0).count();
     for (int c = 0; c < n_chunks; ++c) {
         float gms = 0.0f;
         if (hipEventElapsedTime(&gms, gs[(size_t)c], ge[(size_t)c]) == hipSuccess) d->timing.gmm_ms += gms;
@@ -1564,18 +1841,16 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
     d->timing.gmm_launches += n_chunks;
     d->timing.prefetched += prefetched ? 1 : 0;
     {   // what scoring (on its own) and search cost on this decoder: launch_search's choice when a table is scored ahead
-        long long fr = 0, rows = 0;
-        for (int u = 0; u < nb; ++u) fr += T[(size_t)u];
+        long long rows = 0;
         for (int c = 0; c < n_chunks; ++c) rows += P.chunk_rows[(size_t)c];
         if (!prefetched && rows > 0 && d->timing.gmm_ms > gmm_before) d->gmm_ms_per_row = (d->timing.gmm_ms - gmm_before) / (double)rows;
-        if (fr > 0 && d->timing.search_ms > search_before) d->search_ms_per_frame = (d->timing.search_ms - search_before) / (double)fr;
+        // (a launch that also advanced the batch behind: its frames are not known here - the estimate stays)
+        if (frames_here > 0 && d->timing.search_ms > search_before && !d->bg_ran) d->search_ms_per_frame = (d->timing.search_ms - search_before) / (double)frames_here;
+        d->bg_ran = false;
     }
     for (int u = 0; u < nb; ++u) d->timing.search_frames += T[(size_t)u];
     d->timing.gmm_frames = d->timing.search_frames;
     d->timing.gmm_states = G;
-    // the table scored during this wave belongs to the next one
-    if (prefetched) d->pf_ready.drop();
-    if (d->pf_next.state == 2) { d->pf_ready.drop(); d->pf_ready = std::move(d->pf_next); d->pf_next = Prefetch(); }
     return JD_OK;
 }
 
@@ -1607,19 +1882,25 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }
     }
     // Scoring ahead inside the batch: every wave but the last announces the wave behind it, whose table is then scored
-    // beside this wave's search (pf_launch); what the caller announced (the NEXT batch) rides on the last wave.
-    Prefetch callers = std::move(d->pf_next);
-    d->pf_next = Prefetch();
-    if (callers.state != 1) callers.drop();
+    // beside this wave's search (pf_launch); what the caller announced (the batches behind this one) rides on the last wave.
+    const bool waves = n_utts > d->max_streams;
+    std::deque<Prefetch> callers;
+    if (waves) {
+        // (a batch of several waves is never itself one of the announced ones: what has been worked ahead goes)
+        bool worked = false;
+        for (const Prefetch &Q : d->pf_q) if (Q.state == 2 || Q.bank >= 0) worked = true;
+        if (worked) pf_discard(d);
+        callers.swap(d->pf_q);
+    }
     // (on an error way out nothing scored or announced ahead survives: the caller may free the features next)
-    struct Restore { jd_dec *d; Prefetch &p; bool ok; ~Restore() { p.drop(); if (!ok) pf_discard(d); } } callers_guard{d, callers, false};
+    struct Restore { jd_dec *d; std::deque<Prefetch> &p; bool ok; ~Restore() { for (Prefetch &F : p) F.drop(); if (!ok) pf_discard(d); } } callers_guard{d, callers, false};
     for (int u0 = 0; u0 < n_utts; u0 += d->max_streams) {
         const int nb = std::min(d->max_streams, n_utts - u0);
         for (int i = 0; i < nb; ++i) {
             const int u = order[(size_t)(u0 + i)];
             ustart[(size_t)i] = offs[u]; ulen[(size_t)i] = offs[u + 1] - offs[u];
         }
-        if (u0 + nb < n_utts) {
+        if (waves && u0 + nb < n_utts) {
             const int nn = std::min(d->max_streams, n_utts - (u0 + nb));
             for (int i = 0; i < nn; ++i) {
                 const int u = order[(size_t)(u0 + nb + i)];
@@ -1627,13 +1908,12 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
             }
             rc = pf_announce(d, nn, d_feats, nstart.data(), nlen.data());
             if (rc) return rc;
-        } else if (callers.state == 1) {
-            if (d->pf_next.state == 2) (void)hipStreamSynchronize(d->s_gmm);
-            d->pf_next.drop();
-            d->pf_next = std::move(callers); callers = Prefetch();
+        } else if (waves) {
+            for (Prefetch &F : callers) d->pf_q.push_back(std::move(F));
+            callers.clear();
         }
-        Prefetch kept;                                                 // (see the retry below)
-        struct KeptGuard { Prefetch &p; ~KeptGuard() { p.drop(); } } kept_guard{kept};
+        std::deque<Prefetch> kept;                                     // (see the retry below)
+        struct KeptGuard { std::deque<Prefetch> &p; ~KeptGuard() { for (Prefetch &F : p) F.drop(); } } kept_guard{kept};
         for (int attempt = 0;; ++attempt) {
             // (lazily composed networks: the wave's utterances enter the network - which starts a new arena generation
             // when nobody is inside an utterance and it is nearly full, or has run out of room)
@@ -1648,19 +1928,21 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
             d->lazy_failed = false;
             const jd_timing t_before = d->timing;                      // (a wave that is decoded twice counts once)
             const double ls_before = d->load_sum, lf_before = d->load_frames;
-            rc = decode_wave(d, nb, d_feats, ustart.data(), ulen.data(), (hipStream_t)hip_stream);
-            const int rf = rc ? rc : fetch_results(d, 0, nb, out, 0, order.data() + u0);
+            int s0 = 0;
+            rc = decode_wave(d, nb, d_feats, ustart.data(), ulen.data(), (hipStream_t)hip_stream, &s0);
+            const int rf = rc ? rc : fetch_results(d, s0, nb, out, 0, order.data() + u0);
             jd_lazy_leave(d->net, nb);
             if (rc) return rc;
-            if (kept.state == 2) {                                     // the retry is through: the table scored beside attempt 0 is the next wave's again
-                if (d->pf_ready.state == 0) { d->pf_ready = std::move(kept); kept = Prefetch(); } else kept.drop();
+            if (!kept.empty()) {                                       // the retry is through: the tables scored beside attempt 0 are the next waves' again
+                if (d->pf_q.empty()) d->pf_q.swap(kept);
+                else { for (Prefetch &F : kept) F.drop(); kept.clear(); }
             }
             // out of graph room under way: once more - jd_lazy_enter gives the wave a fresh generation to itself
             if (d->lazy_failed && attempt == 0) {
                 d->timing = t_before; d->load_sum = ls_before; d->load_frames = lf_before;
-                // (what was scored ahead beside attempt 0 belongs to the wave BEHIND this one: the retry, which matches no
+                // (what was scored ahead beside attempt 0 belongs to the waves BEHIND this one: the retry, which matches no
                 // announced table, would drop it)
-                if (d->pf_ready.state == 2) { kept = std::move(d->pf_ready); d->pf_ready = Prefetch(); }
+                kept.swap(d->pf_q);
                 continue;
             }
             if (rf && first_err == JD_OK) first_err = rf;
@@ -1671,10 +1953,6 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         const double scale = std::min(1e5, std::max(0.25, d->load_sum / d->load_frames / 23700.0));
         d->load_scale = (d->load_scale == 1.0) ? scale : 0.5 * (d->load_scale + scale);
         d->load_sum = d->load_frames = 0.0;
-    }
-    for (int s = 0; s < d->max_streams; ++s) {
-        d->stream_started[(size_t)s] = 0; d->stream_T[(size_t)s] = 0;
-        if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }   // (the batch took the stream over)
     }
     callers_guard.ok = true;
     return first_err;
@@ -1688,7 +1966,7 @@ extern "C" int jd_dec_prefetch_scores(jd_dec *d, int32_t n_utts, const float *d_
     if (n_utts == 0) { pf_discard(d); return JD_OK; }                  // nothing: what was scored or announced ahead is dropped
     // what cannot be scored ahead is scored when it is decoded, as ever: more utterances than streams (several waves,
     // formed by length: jd_decode_batch_device scores each of them beside the wave before it), a table cut into chunks
-    if (n_utts > d->max_streams) { if (d->pf_next.state == 2) (void)hipStreamSynchronize(d->s_gmm); d->pf_next.drop(); return JD_OK; }
+    if (n_utts > d->max_streams) return JD_OK;
     HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));             // the features are there
     std::vector<int64_t> ulen((size_t)n_utts);
     for (int u = 0; u < n_utts; ++u) ulen[(size_t)u] = offs[u + 1] - offs[u];

@@ -404,7 +404,7 @@ __global__ void jd_zero_bar_kernel(StreamCtl *ctl, const int4 *work, int n, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { StreamCtl &c = ctl[work[i].x]; c.bar = 0u; c.xbar = 0u; c.xmask = 0u; c.stop_req = 0; }
     if (i == 0) {
-        status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0;
+        status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0; status[5] = 0; status[6] = 0;
         if (scoring_ahead) status[4] = 1;      // (cleared on the scoring stream, behind the scoring kernel: pf_launch)
     }
 }

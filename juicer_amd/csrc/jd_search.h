@@ -177,10 +177,15 @@ struct SearchArgs {
                              // cluster on several XCDs - the placement check has to catch it
     int rebalance_at;        // weighted mode: when this many workgroups of the grid have nothing left to do (their stream is
                              // through, or stopped), every cluster stops after its frame and the host plans the rest anew (0: never)
+    int n_prio;              // weighted mode: n_prio work items (bit 30 of their workgroup count) are the batch the caller is waiting for; the others
+                             // belong to the batch BEHIND it (searched ahead on workgroups the plan leaves, jd_device.hip
+                             // "two batches in flight") and stop after their frame once all of these are through (0: none)
     int *status;             // [0] += 1 for every stream that stopped early (Path garbage collection, or a re-plan);
                              // [1] += 1 for every cluster of an XCD-local launch that found itself on several XCDs;
                              // [2] += the workgroups of every cluster that has left its stream; [3] += 1 per stream stopped for a re-plan;
                              // [4] != 0: the next batch's table is being scored on the CUs finished clusters left - no re-plan meanwhile
+                             // [5] += 1 for every stream of the first n_prio that is through (or failed);
+                             // [6] += 1 for every other stream that stopped because they all were
     long long *dbg;          // optional: per-workgroup cycle accounting (jd_dec_debug_trace)
     int *resident; int launch_seq;   // host-mapped word: the LAST workgroup of the grid writes launch_seq into it when it starts
                              // (workgroups are dispatched in order: the launch is then resident; jd_dec_prefetch_scores)
@@ -1284,7 +1289,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
 // ------------------------------------------------------------------ one stream, one launch
 
 template <int NE, bool XL, bool LZY>
-__device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw)
+__device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw, bool prio)
 {
     constexpr bool XL_ = XL;
     typedef RecLayout<NE> RL;
@@ -1432,7 +1437,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     int pre_cnt[3] = {0, 0, 0}, pre_new = 0;                           // next frame's list counts, requested one frame ahead (below)
     bool pre_ok = false;
     int np_seen = 0;                                                   // Path records in use, as of the last frame end
-    bool stop_seen = false;                                            // the host wants to re-plan the launch (SearchArgs::rebalance_at)
+    int stop_seen = 0;                                                 // the host wants to re-plan the launch (SearchArgs::rebalance_at): 1;
+                                                                       // the batch this stream runs ahead of is through: 2
     while (!aborted && !failed) {
         const bool init = init_pending;
         if (!init && f >= f_stop) break;
@@ -1526,6 +1532,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                         // enough of the grid idles: this cluster stops after this frame (every workgroup of it reads the
                         // request behind this round's barrier, i.e. in the same frame)
                         if (A.rebalance_at > 0 && CL(A.status + 2) >= A.rebalance_at && CL(A.status + 4) == 0) CS(&c.stop_req, 1);
+                        // searched ahead of its batch's turn: the batch the caller waits for is through - so is this launch
+                        if (!prio && A.n_prio > 0 && CL(A.status + 5) >= A.n_prio) CS(&c.stop_req, 2);
                     }
                     if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) CS(V.hist + (size_t)(p ^ 1) * HIST_MAX_BINS + b, 0);
                 }
@@ -1605,7 +1613,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const unsigned bb = ba > bx ? ba : bx;
             best_emit = bb ? o2f(bb) : LZ;                             // :417-418, :572-573
             np_seen = RFL(np_raw);                                     // (n_paths only changes in phase X)
-            stop_seen = RFL(stop_raw) != 0;
+            stop_seen = RFL(stop_raw);
         }
         if (tid == 0)                                                  // totalActiveModels starts with frame 0 (:981)
             for (int k = 0; k < ST_N; ++k) { if (!init || k != ST_MODELS) sh.acc[k] += sh.stat[k]; sh.stat[k] = 0; }
@@ -1652,8 +1660,10 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             if (e0 | e1) c.error = (e0 == (int)JDE_LAZY || e1 == (int)JDE_LAZY) ? (int)JDE_LAZY : (e0 ? e0 : e1);
             else if (f < f_stop) {                                     // stopped early: collect Path records / re-plan, then go on
                 atomicAdd(A.status, 1);
-                if (stop_seen) atomicAdd(A.status + 3, 1);
+                if (stop_seen == 1) atomicAdd(A.status + 3, 1);
+                if (stop_seen == 2) atomicAdd(A.status + 6, 1);
             }
+            if (prio && ((e0 | e1) || f >= f_stop)) atomicAdd(A.status + 5, 1);   // (one of the streams the launch is there for is through)
             if (A.n_slots == 0) atomicAdd(A.status + 2, Cw);           // this cluster's workgroups have nothing left to do in this launch
         }
     }
@@ -1680,8 +1690,9 @@ __global__ JD_KBOUNDS void k_search(SearchArgs A)
         int lo = 0, hi = A.n_work - 1;                                 // last k with first_k <= wg
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (RFL(A.work[mid].z) <= (int)wg) lo = mid; else hi = mid - 1; }
         const int first = RFL(A.work[lo].z);
-        Cw = RFL(A.work[lo].w); jw = (int)wg - first;
+        Cw = RFL(A.work[lo].w) & 0xffff; jw = (int)wg - first;             // (bit 30: one of the streams the launch is there for, n_prio)
         k = (jw < Cw) ? lo : A.n_work; kstep = A.n_work;
     }
-    for (; k < A.n_work; k += kstep) run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw);
+    for (; k < A.n_work; k += kstep)
+        run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw, A.n_slots == 0 && (RFL(A.work[k].w) & 0x40000000) != 0);
 }

@@ -1128,3 +1128,74 @@ def test_scores_ahead_with_collections_and_replans(small):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_two_batches_in_flight(small):
+    """Announcements that run two batches ahead on a decoder whose streams hold two batches: the utterances of the batch
+    behind the running one are started beside it (one workgroup each, the other bank of streams) and are frames in when
+    their turn comes.  Results are those of the oracle bit for bit, whatever was announced, dropped or re-ordered."""
+    import torch
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0)
+    od = OracleDecoder(onet, oam, **kw)
+    mk = lambda k: [np.concatenate([feats[(k * i + j + k) % len(feats)] for j in range(1 + (i + k) % 3)]) for i in range(6)]
+    batches = {n: mk(k) for n, k in (("A", 1), ("B", 2), ("C", 3))}
+    want = {n: [od.decode_certified(x) for x in b] for n, b in batches.items()}
+    dev = torch.device("cuda", 0)
+
+    def resident(batch):
+        offs = np.zeros(len(batch) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([x.shape[0] for x in batch])
+        return torch.from_numpy(np.concatenate(batch)).to(dev), offs
+    buf = {n: resident(b) for n, b in batches.items()}
+    gd = capi.Decoder(gnet, gam, max_streams=12, **kw)                 # two banks of six streams
+
+    def announce(n):
+        gd.prefetch_scores(buf[n][0].data_ptr(), buf[n][1], 0)
+
+    def decode(n, scored=None, ahead=None):
+        gs = gd.decode_batch_device(buf[n][0].data_ptr(), buf[n][1], 0)
+        tm = gd.last_timing()
+        for i, g in enumerate(gs):
+            assert_hyp_matches(g, want[n][i], "batch %s utt %d (%r)" % (n, i, tm))
+            assert bit_exact(g, want[n][i])
+        if scored is not None:
+            assert tm["prefetched"] == (1 if scored else 0), (n, tm)
+        if ahead is not None:
+            assert (tm["ahead_frames"] > 0) == ahead, (n, tm)
+        return tm
+    announce("B"); announce("C")                                      # two ahead of the first decode ...
+    decode("A", scored=False, ahead=False)                            # ... both scored beside it
+    started = 0
+    for n, nxt in (("B", "A"), ("C", "B"), ("A", "C"), ("B", "A"), ("C", "B")):
+        announce(nxt)                                                  # ... and one before every later one
+        tm = decode(n, scored=True)
+        started += 1 if tm["ahead_frames"] > 0 else 0
+    assert started >= 3, started                                      # (the first of them may find its table still being scored)
+    # a decode that is not the announced one drops what was worked ahead; the decoder goes on as if nothing had been
+    decode("C", scored=False, ahead=False)                            # (A is at the head of the queue, started; B behind it)
+    decode("A", scored=False, ahead=False)
+    # a batch that does not fit a bank takes every stream: the batch behind it starts again when its turn comes
+    big = batches["A"] + batches["B"][:4]
+    announce("B"); announce("C"); decode("A")
+    bb, bo = resident(big)
+    gs = gd.decode_batch_device(bb.data_ptr(), bo, 0)
+    for i, g in enumerate(gs):
+        assert bit_exact(g, (want["A"] + want["B"][:4])[i])
+    decode("B", ahead=False); decode("C")
+    # switched off: same results, nothing ahead
+    import os
+    os.environ["JD_PIPELINE"] = "0"
+    try:
+        g0 = capi.Decoder(gnet, gam, max_streams=12, **kw)
+    finally:
+        del os.environ["JD_PIPELINE"]
+    g0.prefetch_scores(buf["B"][0].data_ptr(), buf["B"][1], 0); g0.prefetch_scores(buf["C"][0].data_ptr(), buf["C"][1], 0)
+    for n in ("A", "B", "C"):
+        gs = g0.decode_batch_device(buf[n][0].data_ptr(), buf[n][1], 0)
+        assert g0.last_timing()["ahead_frames"] == 0
+        for i, g in enumerate(gs):
+            assert bit_exact(g, want[n][i])
+    g0.close(); gd.close()

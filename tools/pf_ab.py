@@ -31,31 +31,35 @@ extra = {}
 for a in sys.argv[3:]:
     nm, _, kv = a.partition("=")
     extra[nm] = (not nm.startswith("serial"), dict(x.split(":") for x in kv.split(",") if x))
-KNOBS = ("JD_PF_REBALANCE", "JD_REBALANCE", "JD_MODEL_A", "JD_MODEL_B", "JD_PLAN", "JD_MODEL2_A", "JD_MODEL2_B", "JD_PF_GMM_WEIGHT", "JD_PLAN_MIN_CW", "JD_GMM_WAVES", "JD_REBALANCE_FRAC", "JD_XL_SLACK", "JD_CW", "JD_XCH", "JD_EXP")
+KNOBS = ("JD_PF_REBALANCE", "JD_REBALANCE", "JD_MODEL_A", "JD_MODEL_B", "JD_PLAN", "JD_MODEL2_A", "JD_MODEL2_B", "JD_PF_GMM_WEIGHT", "JD_PLAN_MIN_CW", "JD_GMM_WAVES", "JD_REBALANCE_FRAC", "JD_XL_SLACK", "JD_CW", "JD_XCH", "JD_EXP", "JD_PIPELINE", "JD_SCORE_RESERVE", "JD_FG_CW", "JD_BG_CW", "JD_BG_REBALANCE", "JD_BG_WAIT_US", "JD_BG_WEIGHT")
 variants = extra if extra else {"serial": (False, {}), "ahead": (True, {}), "ahead, re-plan held": (True, {"JD_PF_REBALANCE": "0"}),
             "ahead, re-planned at will": (True, {"JD_PF_REBALANCE": "1"}), "serial, never re-planned": (False, {"JD_REBALANCE": "0"})}
+# a variant named two... : two batches in flight (streams for two batches, announcements two batches ahead)
 
 
-def make(env):
+def make(env, two=False):
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
-    return capi.Decoder(gnet, gam, main_beam=beam, device=0, max_streams=len(feats))
+    return capi.Decoder(gnet, gam, main_beam=beam, device=0, max_streams=(2 if two else 1) * len(feats))
 
 
 want = None
 res = {k: [] for k in variants}
 for r in range(rounds + 1):
     for name, (pf, env) in variants.items():
-        dec = make(env)                                                # (one decoder at a time: each sizes its arenas from the free HBM)
+        two = name.startswith("two")
+        dec = make(env, two)                                           # (one decoder at a time: each sizes its arenas from the free HBM)
         steps = 4
-        for _ in range(2):                                             # warm-up: load learnt, the first table announced
+        if two and pf:
+            dec.prefetch_scores(d_feats.data_ptr(), offs, 0)
+        for _ in range(3 if two else 2):                               # warm-up: load learnt, the first table announced
             if pf:
                 dec.prefetch_scores(d_feats.data_ptr(), offs, 0)
             hy = dec.decode_batch_device(d_feats.data_ptr(), offs, 0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        acc = {"search_ms": 0.0, "gmm_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "prefetched": 0}
+        acc = {"search_ms": 0.0, "gmm_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "prefetched": 0, "ahead_frames": 0}
         for _ in range(steps):
             if pf:
                 dec.prefetch_scores(d_feats.data_ptr(), offs, 0)
