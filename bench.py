@@ -107,10 +107,10 @@ def calibrated_traffic(fetch_kib, write_kib, wide_read_bytes):
 
 def leg_traffic(leg, launches):
     """HBM bytes per k_search launch of a workload, from the committed PMC passes of that workload on its own
-    (profiles/r03_<leg>_traffic.json, tools/leg_pmc.sh): the bytes of all k_search launches of one pass over the
+    (profiles/r04_<leg>_traffic.json, tools/leg_pmc.sh): the bytes of all k_search launches of one pass over the
     step's launches, like `achieved`.  None when there is no such file or when it was taken on other sources."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r03_%s_traffic.json" % leg)))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r04_%s_traffic.json" % leg)))
         if t.get("source_hash") != kernel_source_hash():
             return None
         return round(t["k_search_hbm_bytes_per_pass"] / max(1, launches), 1)
@@ -119,19 +119,24 @@ def leg_traffic(leg, launches):
 
 
 def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, gnet=None, pmc_leg=None, oracle_feats=None,
-            oracle_net=None, ahead=True, max_streams=0):
+            oracle_net=None, ahead=True, max_streams=0, two=None):
     """One extra workload: warm-up pass + timed passes on one GPU (value = the MEDIAN pass), its own roofline.
     gnet: a network that exists already (composed on the device); net is then only asked for its size.
     pmc_leg: the name the leg's PMC passes are filed under (leg_traffic).  oracle_utts: that many utterances are
     decoded by the CPU oracle as well - of the batch itself, or oracle_feats (short utterances on the same graph,
     decoded by the same decoder after the timed passes, where the batch's own would take the oracle minutes);
-    oracle_net: the oracle's copy of the graph when `net` is not a synthetic network object."""
+    oracle_net: the oracle's copy of the graph when `net` is not a synthetic network object.  two: two batches in
+    flight, like the headline (streams for two batches, announcements two passes ahead; default: when the passes
+    are given; default off: it pays where a frame is a chain of dependent steps, not where it is bytes - the heavy legs
+    lose by it, measured: the 14 M-arc graph 119 k -> 55 k frames/s, configs[3] 5.3 k -> 0.8 k)."""
     import torch
     from juicer_amd import capi
     U = len(feats)
     t0 = time.perf_counter()
+    if two is None:
+        two = False
     dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam,
-                       max_hyps=max_hyps, device=dev.index, max_streams=max_streams or U)
+                       max_hyps=max_hyps, device=dev.index, max_streams=(2 * U if two else U) if not max_streams else max_streams)
     offs = np.zeros(U + 1, dtype=np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in feats])
     d_feats = torch.from_numpy(np.concatenate(feats)).to(dev)
@@ -139,6 +144,9 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
     stream = torch.cuda.current_stream().cuda_stream
     hyps, runs = None, []
     gmm_alone = None
+    if two:
+        dec.prefetch_scores(d_feats.data_ptr(), offs, stream)          # (the announcements run two passes ahead)
+        passes += 1                                                    # (... and the pipeline takes a pass more to fill)
     for i in range(passes):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -150,7 +158,7 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
         tm_i = dec.last_timing()
         if not tm_i["prefetched"]:
             gmm_alone = tm_i["gmm_ms"]                                 # (the warm-up pass scores its own table, on its own)
-        if i > 0 or passes == 1:
+        if i > (1 if two else 0) or passes == 1:
             runs.append((dt, tm_i))
     dec.prefetch_scores(0, None)
     runs.sort(key=lambda r: r[0])
@@ -163,7 +171,7 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
            "frames_per_step": frames, "ms_per_step": round(best * 1e3, 3),
            "timed_passes": len(runs), "ms_per_step_min": round(runs[0][0] * 1e3, 3), "ms_per_step_max": round(runs[-1][0] * 1e3, 3),
            "search_ms": round(tm["search_ms"], 3), "gmm_ms": round(gmm_alone if gmm_alone is not None else tm["gmm_ms"], 3),
-           "scored_ahead": bool(tm["prefetched"]),
+           "scored_ahead": bool(tm["prefetched"]), "batches_in_flight": 2 if two else 1, "searched_ahead_frames": int(tm["ahead_frames"]),
            "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
                                                                               "tot_proc_end_hyps", "tot_arcs_visited", "tot_paths")},
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
@@ -428,7 +436,7 @@ def main():
     D, G, M, MN = am.D, am.n_gmm, am.max_mix, am.max_n
     st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals (rank 0)
     default_cfg = (args.arcs == 1_000_000 and args.beam == 150.0 and args.max_hyps == 0 and U == 64 and args.seed == 0 and not strong)
-    # HBM traffic per launch of k_search from the committed PMC passes of this command (profiles/r03_c2_traffic.json,
+    # HBM traffic per launch of k_search from the committed PMC passes of this command (profiles/r04_c2_traffic.json,
     # tools/collect_profiles.sh: separate --pmc runs, calibrated as calibrated_traffic says) - reported only for the
     # default workload and only while the kernel's sources are the ones the passes were taken on (else null)
     step_tm = dict(tm)
@@ -525,12 +533,13 @@ def main():
         legs = {}
         try:
             no = 0 if args.no_cpu_baseline else 2                   # utterances the CPU oracle decodes per leg
-            legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev, oracle_utts=no)
+            legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev, oracle_utts=no,
+                                                   two=two_in_flight, pmc_leg="hyps" if default_cfg else None)
             # configs[2]'s batch (512 utterances) on ONE GPU: waves of 128 streams inside one call, each wave's table scored
             # beside the wave before it - what the GPU does when a batch is not bounded by its longest utterance
             _, _, f512, _ = synth.config_c2(seed=args.seed, n_utts=512, target_arcs=args.arcs)
             legs["configs2_batch_512_on_one_gpu"] = run_leg("configs[2]'s 512-utterance batch on one GPU, 128 streams", am, net, f512, args.beam, 0, dev,
-                                                            oracle_utts=no, max_streams=128)
+                                                            oracle_utts=no, max_streams=128, pmc_leg="c512" if default_cfg else None)
             del f512
             a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=64, n_words=10000, n_tri_hist=100_000)
             legs["north_star_10M_beam200"] = run_leg("north_star target (trigram-shaped)", a4, n4, f4, 200.0, 0, dev,

@@ -347,5 +347,106 @@ public:
     }
 };
 
+// ---- several IDecoder instances on ONE decoder (jd_broker_*, juicer_amd.h).
+//
+// The reference scales out by running juicer several times over split file lists (doc/userman/juicer_userman.tex:584);
+// a GPU wants the utterances of all those runs side by side on one chip.  A pool owns one decoder with a stream per
+// caller and the broker in front of it; every harness thread gets a GpuWFSTPooledDecoder - an IDecoder like any other,
+// driven serially with init / processFrame / finish - and the broker's worker thread turns what the callers have pushed
+// since its last tick into one scoring launch and one search launch:
+//     JuicerAmd::GpuDecoderPool pool(network, models, startBeam, mainBeam, endBeam, wordBeam, maxHyps, nThreads);
+//     ... in thread t:   JuicerAmd::GpuWFSTPooledDecoder decoder(pool);   // then exactly as with WFSTDecoderLite
+class GpuDecoderPool {
+public:
+    GpuDecoderPool(const jd_net *network, const jd_am *models, float phoneStartPruneWin, float emitPruneWin, float phoneEndPruneWin,
+                   float wordPruneWin, int maxEmitHyps, int nCallers, int device = 0, int blockSize = 5)
+        : dec_(0), broker_(0), vecSize_(jd_am_vec_size(models))
+    {
+        check(jd_dec_create(&dec_, network, models, phoneStartPruneWin, emitPruneWin, phoneEndPruneWin, wordPruneWin, maxEmitHyps, blockSize,
+                            device, nCallers));
+        check(jd_broker_create(&broker_, dec_, nCallers));
+    }
+    ~GpuDecoderPool() { jd_broker_destroy(broker_); jd_dec_destroy(dec_); }
+    jd_broker *broker() const { return broker_; }
+    int vecSize() const { return vecSize_; }
+    static void check(int rc)
+    {
+        if (rc != JD_OK) { fprintf(stderr, "juicer_amd: %s\n", jd_last_error()); exit(1); }
+    }
+private:
+    GpuDecoderPool(const GpuDecoderPool &);
+    GpuDecoderPool &operator=(const GpuDecoderPool &);
+    jd_dec *dec_;
+    jd_broker *broker_;
+    int vecSize_;
+};
+
+class GpuWFSTPooledDecoder : public IDecoder {
+public:
+    explicit GpuWFSTPooledDecoder(GpuDecoderPool &pool, int flushFrames = 64)
+        : b_(pool.broker()), client_(-1), vecSize_(pool.vecSize()), nextFrame_(0), flush_(flushFrames)
+    {
+        GpuDecoderPool::check(jd_broker_open(b_, &client_));
+    }
+    virtual ~GpuWFSTPooledDecoder() { if (client_ >= 0) (void)jd_broker_close(b_, client_); }
+    bool modelLevelOutput() { return false; }      // WFSTDecoderLite.h:106
+    LatticeT *getLattice() { return 0; }           // WFSTDecoderLite.h:107
+    void init()
+    {
+        GpuDecoderPool::check(jd_broker_init(b_, client_));
+        pending_.clear();
+        nextFrame_ = 0;
+    }
+    void processFrame(float **inputVec, int currFrame_, int nFrames)
+    {
+        (void)nFrames;
+        if (currFrame_ != nextFrame_) {             // HTKFlatModels::newFrame, HTKFlatModels.cpp:296-297
+            fprintf(stderr, "HTKFlatModels::newFrame - invalid frame\n");
+            exit(1);
+        }
+        pending_.insert(pending_.end(), inputVec[0], inputVec[0] + vecSize_);
+        ++nextFrame_;
+        if ((int)(pending_.size() / vecSize_) >= flush_) flush();
+    }
+    DecHyp *finish()
+    {
+        flush();
+        jd_hyp h;
+        GpuDecoderPool::check(jd_broker_finish(b_, client_, &h));
+        stats_ = h.stats;
+        if (h.n < 0) {
+            fprintf(stderr, "WARNING: no token survived at the end of decoding\n");   // WFSTDecoderLite.cpp:266
+            return 0;
+        }
+        hist_.assign(h.n > 0 ? h.n : 0, DecHypHist());
+        for (int k = 0; k < h.n; ++k) {             // chain order: hist_[0] is hyp->hist (newest word)
+            DecHypHist &d = hist_[k];
+            d.type = DHHTYPE; d.nConnect = 1; d.prev = (k + 1 < h.n) ? &hist_[k + 1] : 0;
+            d.state = h.label[k]; d.time = h.time[k];
+            d.score = h.score[k]; d.acousticScore = h.ac[k]; d.lmScore = h.lm[k];
+        }
+        hyp_ = DecHyp();
+        if (h.n > 0) {
+            hyp_.hist = &hist_[0];
+            hyp_.score = h.tot_score; hyp_.acousticScore = h.tot_ac; hyp_.lmScore = h.tot_lm;
+        }
+        return &hyp_;                               // valid until the next init(), like the reference
+    }
+    const jd_stats &statistics() const { return stats_; }
+private:
+    void flush()
+    {
+        if (pending_.empty()) return;
+        GpuDecoderPool::check(jd_broker_push(b_, client_, &pending_[0], (int)(pending_.size() / vecSize_)));
+        pending_.clear();
+    }
+    jd_broker *b_;
+    int client_, vecSize_, nextFrame_, flush_;
+    std::vector<float> pending_;
+    std::vector<DecHypHist> hist_;
+    DecHyp hyp_;
+    jd_stats stats_;
+};
+
 }  // namespace JuicerAmd
 #endif

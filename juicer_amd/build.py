@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     # the DecoderBatchTest counterpart (C++ host over the C ABI + the IDecoder adapter)
-    cmd2 = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", BATCH_TEST, BATCH_SRC,
+    cmd2 = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", BATCH_TEST, BATCH_SRC,
             "-L", HERE, "-ljuicer_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd2), file=sys.stderr)

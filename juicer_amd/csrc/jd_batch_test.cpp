@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "juicer_amd.h"
@@ -119,7 +120,7 @@ int main(int argc, char **argv)
     const char *fsm = 0, *insyms = 0, *outsyms = 0, *amf = 0, *mmf = 0, *list = 0;
     const char *gramFsm = 0, *gramInSyms = 0, *gramOutSyms = 0;              // juicer.cpp:128-130: separate C.L and G
     float mainBeam = 0, startBeam = 0, endBeam = 0, wordBeam = 0, lmScale = 1.0f, insPen = 0.0f;
-    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0, nDevices = 0, pushing = 0, lazy = 0;
+    int maxHyps = 0, framesPerSec = 100, device = 0, batch = 64, useAdapter = 0, writeBinaryFiles = 0, nDevices = 0, pushing = 0, lazy = 0, nThreads = 0;
     std::string outputFormat = "ref";          // -outputFormat ref|trans|mlf|xmlf|verbose (juicer.cpp:263-264)
     const char *refFName = 0;                  // -refFName: expected results, MLF or one line per file (juicer.cpp:267)
     const char *outputFName = 0;               // -outputFName: "", "stdout", "stderr" or a file (DecoderBatchTest.cpp:216-230)
@@ -143,6 +144,7 @@ int main(int argc, char **argv)
         else if (a == "-framesPerSec") framesPerSec = atoi(nxt()); else if (a == "-device") device = atoi(nxt());
         else if (a == "-batch") batch = atoi(nxt()); else if (a == "-perFrameAdapter") useAdapter = 1;
         else if (a == "-devices") nDevices = atoi(nxt());
+        else if (a == "-threads") nThreads = atoi(nxt());
         else if (a == "-outputFormat") outputFormat = nxt();
         else if (a == "-writeBinaryFiles") writeBinaryFiles = 1;
         else if (a == "-refFName") refFName = nxt(); else if (a == "-removeSentMarks") removeSentMarks = 1;
@@ -156,6 +158,7 @@ int main(int argc, char **argv)
                         "       [-outputFormat ref|trans|mlf|xmlf|verbose] [-writeBinaryFiles] [-refFName REF] [-removeSentMarks]\n"
                         "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n"
                         "       [-device d | -devices N   (N GPUs of this node: utterances sharded, one RCCL gather of the 1-best)]\n"
+                        "       [-threads N   (N serial harness threads - the reference's loop each - through one decoder: the broker)]\n"
                         "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S] [-pushing | -weightPushing] [-lazy]   (-fsmFName is then C.L: composed with G on the\n"
                         "        device, as a whole before the search or - with -lazy - by the search, where it goes)]\n");
         return 2;
@@ -407,6 +410,41 @@ int main(int argc, char **argv)
         }
         delete decp;
         if (lazy_cl) { jd_net_destroy(lazy_cl); jd_net_destroy(lazy_g); }
+    } else if (nThreads > 0) {
+        // -threads N: N harness threads, each the reference's serial loop (init / processFrame x T / finish,
+        // DecoderSingleTest.cpp:259-324) over its share of the list - what N juicer processes over split file lists do
+        // (doc/userman/juicer_userman.tex:584) - through ONE decoder: a GpuWFSTPooledDecoder per thread, the broker behind
+        // them (juicer_amd_decoder.hpp)
+        if (lazy_cl) { fprintf(stderr, "jd_batch_test: -threads works on a composed network\n"); return 1; }
+        JuicerAmd::GpuDecoderPool pool(net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, nThreads, device);
+        struct Res { std::vector<int32_t> lab, tim; std::vector<float> ac, lm; double dt = 0.0; };
+        std::vector<Res> res(files.size());
+        std::vector<std::thread> th;
+        for (int t = 0; t < nThreads; ++t)
+            th.emplace_back([&, t]() {
+                JuicerAmd::GpuWFSTPooledDecoder dec(pool);
+                for (size_t u = (size_t)t; u < files.size(); u += (size_t)nThreads) {
+                    auto t0 = std::chrono::steady_clock::now();
+                    dec.init();
+                    std::vector<float *> rows(nfr[u]);
+                    for (int f = 0; f < nfr[u]; ++f) rows[f] = feats[u].data() + (size_t)f * D;
+                    int nFrames = 0, nData = nfr[u] < 20 ? nfr[u] : 20;      // DecoderSingleTest.cpp:267-295
+                    while (nData > 0) {
+                        dec.processFrame(&rows[nFrames], nFrames, nData);
+                        ++nFrames;
+                        if (nFrames + nData - 1 >= nfr[u]) --nData;
+                    }
+                    JuicerAmd::DecHyp *hyp = dec.finish();
+                    Res &r = res[u];
+                    for (JuicerAmd::DecHypHist *h = hyp ? hyp->hist : 0; h; h = h->prev) {
+                        r.lab.push_back(h->state); r.tim.push_back(h->time); r.ac.push_back(h->acousticScore); r.lm.push_back(h->lmScore);
+                    }
+                    r.dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                }
+            });
+        for (std::thread &t : th) t.join();
+        for (size_t u = 0; u < files.size(); ++u)
+            print_utt(u, (int)res[u].lab.size(), res[u].lab.data(), res[u].tim.data(), res[u].ac.data(), res[u].lm.data(), res[u].dt);
     } else if (nDevices > 0) {
         // -devices N: the utterance loop sharded over N GPUs of this node, one RCCL gather of the 1-best
         jd_multi *mg = 0;

@@ -406,9 +406,11 @@ struct jd_dec {
     int score_reserve = -1;               // CUs left to the scoring beside a launch with two batches in flight: -1 by its cost (JD_SCORE_RESERVE)
     int reserve_now = 0;                  // ... of the launch under way
     int bg_rebalance = 0;                 // re-plan a launch that runs two batches (JD_BG_REBALANCE)
+    double bg_max_load = 4.0;             // two batches in flight up to this load_scale (JD_BG_MAX_LOAD)
     double bg_weight = 0.5;               // the plan counts this part of the frames a stream of the batch behind has ahead (JD_BG_WEIGHT)
     int fg_cw_cap = 8, bg_cw_cap = 4;     // two batches in flight: largest cluster of the running batch / of the batch behind (JD_FG_CW, JD_BG_CW)
     bool pf_armed = false;                // decode_wave: the coming launch_search may start the announced scorings
+    bool pf_retry = false;                // decode_wave: this wave is being decoded again - what was scored beside its first attempt stays
     int pf_rebalance = -1;                // re-planning a launch beside which a table is scored: -1 by the measured ratio (launch_search),
                                           // JD_PF_REBALANCE=0: never while the scoring runs, =1: like any other launch
     double gmm_ms_per_row = 0.0, search_ms_per_frame = 0.0;   // measured on this decoder's last waves (scoring on its own / search)
@@ -627,6 +629,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_SCORE_RESERVE")) d->score_reserve = atoi(e);
     if (const char *e = getenv("JD_BG_REBALANCE")) d->bg_rebalance = atoi(e) != 0;
     if (const char *e = getenv("JD_BG_WEIGHT")) d->bg_weight = atof(e);
+    if (const char *e = getenv("JD_BG_MAX_LOAD")) d->bg_max_load = atof(e);
     if (const char *e = getenv("JD_FG_CW")) d->fg_cw_cap = std::max(1, atoi(e));
     if (const char *e = getenv("JD_BG_CW")) d->bg_cw_cap = std::max(1, atoi(e));
     hipError_t e;
@@ -1621,6 +1624,12 @@ static int pf_background(jd_dec *d, int fg_bank, const std::vector<int> *heads, 
 {
     work->clear(); left->clear();
     if (d->pf_q.empty() || !d->pipeline || d->C.lazy) return JD_OK;
+    // Searching ahead pays where a frame is a chain of dependent steps and workgroups wait - not where it is bytes: a
+    // stream-frame of several hundred thousand instances keeps every workgroup it can get busy, and a second batch on the
+    // same chip only splits them (measured: the 14 M-arc graph 119 k -> 55 k frames/s, configs[3] 5.3 k -> 0.8 k).  The
+    // decoder knows its load from the batches it has decoded (load_scale: instances + arcs per stream-frame over
+    // configs[1]'s 23.7 k); beyond JD_BG_MAX_LOAD times that the batch behind waits for its turn.
+    if (d->load_scale > d->bg_max_load) return JD_OK;
     Prefetch &F = d->pf_q.front();
     const int B = d->max_streams / 2;
     if (F.state != 2 || F.nb > B || F.plan.n_chunks != 1) return JD_OK;
@@ -1677,9 +1686,10 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         else {
             // not the batch that was announced: what has been scored (or searched) ahead is for a batch that is not
             // coming now - dropped; announcements nothing has been done for yet stay (they are batches BEHIND this one)
+            // (a wave that is decoded a second time - the retry of jd_decode_batch_device - finds the waves behind it there)
             bool worked = false;
             for (const Prefetch &Q : d->pf_q) if (Q.state == 2 || Q.bank >= 0) worked = true;
-            if (worked) pf_discard(d);
+            if (worked && !d->pf_retry) pf_discard(d);
         }
     }
     struct MeGuard { Prefetch &p; ~MeGuard() { p.drop(); } } me_guard{me};
@@ -1912,8 +1922,7 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
             for (Prefetch &F : callers) d->pf_q.push_back(std::move(F));
             callers.clear();
         }
-        std::deque<Prefetch> kept;                                     // (see the retry below)
-        struct KeptGuard { std::deque<Prefetch> &p; ~KeptGuard() { for (Prefetch &F : p) F.drop(); } } kept_guard{kept};
+        struct RetryGuard { jd_dec *d; ~RetryGuard() { d->pf_retry = false; } } retry_guard{d};
         for (int attempt = 0;; ++attempt) {
             // (lazily composed networks: the wave's utterances enter the network - which starts a new arena generation
             // when nobody is inside an utterance and it is nearly full, or has run out of room)
@@ -1933,18 +1942,15 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
             const int rf = rc ? rc : fetch_results(d, s0, nb, out, 0, order.data() + u0);
             jd_lazy_leave(d->net, nb);
             if (rc) return rc;
-            if (!kept.empty()) {                                       // the retry is through: the tables scored beside attempt 0 are the next waves' again
-                if (d->pf_q.empty()) d->pf_q.swap(kept);
-                else { for (Prefetch &F : kept) F.drop(); kept.clear(); }
-            }
             // out of graph room under way: once more - jd_lazy_enter gives the wave a fresh generation to itself
             if (d->lazy_failed && attempt == 0) {
                 d->timing = t_before; d->load_sum = ls_before; d->load_frames = lf_before;
                 // (what was scored ahead beside attempt 0 belongs to the waves BEHIND this one: the retry, which matches no
-                // announced table, would drop it)
-                kept.swap(d->pf_q);
+                // announced table, must not drop it)
+                d->pf_retry = true;
                 continue;
             }
+            d->pf_retry = false;
             if (rf && first_err == JD_OK) first_err = rf;
             break;
         }

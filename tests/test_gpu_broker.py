@@ -123,3 +123,60 @@ def test_broker_throughput_at_configs1(built):
     assert ratio >= 0.2                                               # (16 streams are latency-bound: DESIGN.md, "the drop-in seam's own throughput")
     broker.close()
     dec.close()
+
+
+def test_batch_test_cli_harness_threads(built, tmp_path):
+    """jd_batch_test -threads N: N serial harness threads (the reference's init / processFrame / finish loop each, with
+    its 20-row look-ahead) over their shares of the list through ONE decoder - GpuDecoderPool + GpuWFSTPooledDecoder
+    (include/juicer_amd_decoder.hpp) - give the output of the batched path, in list order."""
+    import subprocess
+    from juicer_amd import build as jbuild, io as jio, synth
+    am, net, feats, _ = synth.config_small(n_utts=7)
+    jio.write_fsm(tmp_path / "g.fsm", net)
+    jio.write_jdam(tmp_path / "m.jdam", am)
+    with open(tmp_path / "list.txt", "w") as f:
+        for u, x in enumerate(feats):
+            jio.write_jdf(tmp_path / ("u%d.jdf" % u), x)
+            f.write("%s\n" % (tmp_path / ("u%d.jdf" % u)))
+    base = [jbuild.BATCH_TEST, "-fsmFName", str(tmp_path / "g.fsm"), "-modelsFName", str(tmp_path / "m.jdam"),
+            "-inputFName", str(tmp_path / "list.txt"), "-mainBeam", "150", "-maxHyps", "200", "-outputFormat", "xmlf"]
+    plain = subprocess.run(base, capture_output=True, text=True, timeout=240)
+    assert plain.returncode == 0, plain.stderr
+    for n in (1, 3, 7):
+        th = subprocess.run(base + ["-threads", str(n)], capture_output=True, text=True, timeout=240)
+        assert th.returncode == 0, th.stderr
+        assert th.stdout == plain.stdout, n
+        assert th.stderr.count("RT factor") == len(feats) + 1
+
+
+def test_two_processes_share_one_gpu(built, tmp_path):
+    """The reference's way of using several cores - several processes over split file lists (userman :584) - pointed at ONE
+    GPU: persistent search launches of the two processes take turns (the per-GPU file lock of launch_search) and both
+    finish, with the results of a process that has the GPU to itself."""
+    import subprocess
+    import sys
+    import os
+    code = (
+        "import sys, numpy as np\\n"
+        "sys.path.insert(0, %r)\\n"
+        "from juicer_amd import capi, synth\\n"
+        "am, net, feats, _ = synth.config_small(n_utts=8)\\n"
+        "dec = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=150.0, max_streams=8)\\n"
+        "sig = None\\n"
+        "for it in range(int(sys.argv[1])):\\n"
+        "    hy = dec.decode_batch(feats)\\n"
+        "    s = [(h.n, h.label.tobytes(), h.time.tobytes(), np.asarray(h.score, np.float32).tobytes()) for h in hy]\\n"
+        "    assert sig is None or s == sig\\n"
+        "    sig = s\\n"
+        "import hashlib; print(hashlib.sha256(repr(sig).encode()).hexdigest())\\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JD_GPU_LOCK_DIR=str(tmp_path))
+    alone = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n"), "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert alone.returncode == 0, alone.stderr
+    procs = [subprocess.Popen([sys.executable, "-c", code.replace("\\n", "\n"), "40"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e
+        assert o.strip().splitlines()[-1] == alone.stdout.strip().splitlines()[-1]
+    assert any(f.startswith("juicer_amd.gpu-") for f in os.listdir(tmp_path))

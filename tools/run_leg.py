@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One of bench.py's workloads on its own (GPU box): python tools/run_leg.py c2|north|c3|hyps|clg [passes [utterances of the c3 leg]]"""
+"""One of bench.py's workloads on its own (GPU box): python tools/run_leg.py c2|north|c3|hyps|c512|clg [passes [utterances of the c3 leg]]"""
 import json
 import os
 import sys
@@ -22,10 +22,13 @@ elif which == "clg":
 elif which == "c3":
     a, n, f, _ = synth.config_c4(seed=0, n_utts=n_utts or 8)
     out = bench.run_leg("configs[3]", a, n, f, 300.0, 0, dev, passes=passes, pmc_leg="c3" if not n_utts or n_utts == 8 else None)
-elif which == "c2":
+elif which == "c2":                                                   # (as the headline runs it: two batches in flight)
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
-    out = bench.run_leg("configs[1]", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c2")
+    out = bench.run_leg("configs[1]", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c2", two=True)
+elif which == "c512":
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
+    out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, 128 streams", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c512", max_streams=128)
 else:
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
-    out = bench.run_leg("configs[1] + histogram pruning", a, n, f, 150.0, 6000, dev, passes=passes)
+    out = bench.run_leg("configs[1] + histogram pruning", a, n, f, 150.0, 6000, dev, passes=passes, pmc_leg="hyps", two=True)
 print(json.dumps(out))
