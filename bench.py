@@ -172,6 +172,7 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
            "timed_passes": len(runs), "ms_per_step_min": round(runs[0][0] * 1e3, 3), "ms_per_step_max": round(runs[-1][0] * 1e3, 3),
            "search_ms": round(tm["search_ms"], 3), "gmm_ms": round(gmm_alone if gmm_alone is not None else tm["gmm_ms"], 3),
            "scored_ahead": bool(tm["prefetched"]), "batches_in_flight": 2 if two else 1, "searched_ahead_frames": int(tm["ahead_frames"]),
+           "decode_calls": passes,
            "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
                                                                               "tot_proc_end_hyps", "tot_arcs_visited", "tot_paths")},
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),

@@ -20,6 +20,7 @@ ap.add_argument("--trim", type=int, default=0, help="cut every utterance to this
 ap.add_argument("--c4", type=float, default=0.0, help="trigram-shaped graph of config_c4 at this scale (1.0 = configs[3]) instead of config_c2")
 ap.add_argument("--clg", action="store_true", help="the configs[4] pair (lexicon tree o back-off trigram) composed on the device; with --lazy: by the search")
 ap.add_argument("--lazy", action="store_true")
+ap.add_argument("--two", action="store_true", help="two batches in flight (streams for two batches, announcements two ahead)")
 args = ap.parse_args()
 gnet = None
 if args.clg:
@@ -36,10 +37,23 @@ else:
 if args.trim:
     feats = [f[:args.trim] for f in feats]
 dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=args.beam, max_hyps=args.max_hyps,
-                   max_streams=args.utts)
-dec.decode_batch(feats)
-dec.debug_trace(0)
-h = dec.decode_batch(feats)
+                   max_streams=(2 if args.two else 1) * args.utts)
+if args.two:
+    offs = np.zeros(len(feats) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in feats])
+    d_feats = torch.from_numpy(np.concatenate(feats)).to("cuda:0")
+    torch.cuda.synchronize()
+    dec.prefetch_scores(d_feats.data_ptr(), offs, 0)
+    for _ in range(4):
+        dec.prefetch_scores(d_feats.data_ptr(), offs, 0)
+        dec.decode_batch_device(d_feats.data_ptr(), offs, 0)
+    dec.debug_trace(0)
+    dec.prefetch_scores(d_feats.data_ptr(), offs, 0)
+    h = dec.decode_batch_device(d_feats.data_ptr(), offs, 0)
+else:
+    dec.decode_batch(feats)
+    dec.debug_trace(0)
+    h = dec.decode_batch(feats)
 tm = dec.last_timing()
 buf = dec.debug_trace(0, fetch=True)
 used = buf[buf[:, 8] > 0]
@@ -53,6 +67,10 @@ for k, n in enumerate(names):
     print("%-11s mean %7.2f us/frame   min %7.2f   max %7.2f" % (n, us.mean(), us.min(), us.max()))
 print("sum %.2f us/frame;  search_ms %.2f for %d frames, %d launches, last cluster size %d"
       % (tot, tm["search_ms"], tm["search_frames"], tm["search_launches"], tm["cluster_wgs"]))
+busy = used[:, :8].sum(axis=1) / 100.0 / 1e3                          # ms of accounted time per workgroup
+print("workgroup-time accounted: %.1f ms of %d x %.2f ms = %.1f (%.0f %%); per workgroup: min %.1f, median %.1f, max %.1f ms; frames searched ahead %d"
+      % (busy.sum(), len(used), tm["search_ms"], len(used) * tm["search_ms"], 100.0 * busy.sum() / max(len(used) * tm["search_ms"], 1e-9),
+         busy.min(), float(np.median(busy)), busy.max(), tm.get("ahead_frames", 0)))
 if used[:, 9:16].any():                                               # a -DJD_FINE build: hops inside a phase
     if used[:, 14].any():                                             # JD_FINE=2: phase X (slots 5, 6 are counts)
         names = ["X items", "X rows + key + Path", "X winners", "X prefix + first arcs", "X arc passes"]
