@@ -467,6 +467,11 @@ int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
  * {work lists A, phase A, workgroup wait, cluster barrier 1, work lists X, phase X, workgroup wait,
  *  cluster barriers of X, frames, ...}. */
 int jd_dec_debug_trace(jd_dec *d, int32_t enable, int64_t *fetch);
+/* Diagnostics: what part of a batch's likelihood table does the search read?  The reference scores a tied state only when
+ * a token that passed the emit threshold asks for it (WFSTDecoderLite.cpp:409-411); this build scores every state of
+ * every frame.  enable != 0: from the next decode on every cell (frame, tied state) whose value is added to a token is
+ * marked; enable == 0: *cells_read = the marks, *cells_total = frames x tied states of the last decode, marking stops. */
+int jd_dec_debug_cells(jd_dec *d, int32_t enable, int64_t *cells_read, int64_t *cells_total);
 
 /*
  * Companion kernel on its own: HTKFlatModels::calcGMMOutput

@@ -80,7 +80,7 @@ EXPORTS = [
     "jd_net_lazy_set_high_water", "jd_net_lazy_generation", "jd_release_cached_memory", "jd_net_push_labels",
     "jd_dec_prefetch_scores", "jd_streams_push", "jd_dec_info",
     "jd_broker_create", "jd_broker_destroy", "jd_broker_open", "jd_broker_close", "jd_broker_init", "jd_broker_push",
-    "jd_broker_finish", "jd_broker_get_stats",
+    "jd_broker_finish", "jd_broker_get_stats", "jd_dec_debug_cells",
 ]
 
 _lib = None
@@ -468,6 +468,12 @@ class Decoder:
         t = Timing()
         _check(lib().jd_dec_last_timing(self.h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in Timing._fields_}
+
+    def debug_cells(self, enable: bool):
+        """Mark (enable) / count (not enable -> (cells read, cells of the last decode's table)) the likelihood cells the search reads."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _check(lib().jd_dec_debug_cells(self.h, C.c_int32(1 if enable else 0), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def debug_trace(self, enable: int = 0, fetch: bool = False):
         """In-kernel cycle accounting of k_search: enable, or fetch [1024, 16] int64 sums per workgroup

@@ -382,6 +382,8 @@ struct jd_dec {
     // which a decoder learns from the batches it has decoded (first batch: as fitted)
     double load_scale = 1.0, load_sum = 0.0, load_frames = 0.0;
     int4 *d_work = nullptr; int work_cap = 0;
+    int *d_chain = nullptr;               // SearchArgs::chain of the launch under way (as long as d_work)
+    unsigned *d_cells = nullptr; size_t cells_words = 0;   // diagnostics (jd_dec_debug_cells): a bit per cell of the likelihood slab
     int *d_status = nullptr; int *h_status = nullptr;
     bool xl_ok = true;                    // XCD-local launches allowed (JD_XCD_LOCAL=0 or one failed placement check switch them off)
     double xl_slack = 1.04;               // ... when the packed plan is predicted to end no later than this times the unpacked one (JD_XL_SLACK)
@@ -406,6 +408,8 @@ struct jd_dec {
     int score_reserve = -1;               // CUs left to the scoring beside a launch with two batches in flight: -1 by its cost (JD_SCORE_RESERVE)
     int reserve_now = 0;                  // ... of the launch under way
     int bg_rebalance = 0;                 // re-plan a launch that runs two batches (JD_BG_REBALANCE)
+    int bg_chain = 1;                     // chain streams of the batch behind behind streams of this one that are through early (JD_BG_CHAIN)
+    double bg_chain_frac = 0.5;           // ... "early": within this part of a launch as long as the last one (JD_BG_CHAIN_FRAC)
     double bg_max_load = 4.0;             // two batches in flight up to this load_scale (JD_BG_MAX_LOAD)
     double bg_weight = 0.5;               // the plan counts this part of the frames a stream of the batch behind has ahead (JD_BG_WEIGHT)
     int fg_cw_cap = 8, bg_cw_cap = 4;     // two batches in flight: largest cluster of the running batch / of the batch behind (JD_FG_CW, JD_BG_CW)
@@ -473,6 +477,7 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     d->slab = ArenaSlab();
     free_am_gmm(d->amb);
     if (d->d_ll_slab) (void)hipFree(d->d_ll_slab);
+    if (d->d_cells) (void)hipFree(d->d_cells);
     for (int i = 0; i < 3; ++i)
         if (d->d_row_src[i]) (void)hipFree(d->d_row_src[i]);
     for (Prefetch &F : d->pf_q) F.drop();
@@ -480,6 +485,7 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     if (d->h_resident) (void)hipHostFree(d->h_resident);
     if (d->d_push) (void)hipFree(d->d_push);
     if (d->d_work) (void)hipFree(d->d_work);
+    if (d->d_chain) (void)hipFree(d->d_chain);
     if (d->h_status) (void)hipHostFree(d->h_status);
     if (d->s_gmm) (void)hipStreamDestroy(d->s_gmm);
     if (d->s_search) (void)hipStreamDestroy(d->s_search);
@@ -630,6 +636,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_BG_REBALANCE")) d->bg_rebalance = atoi(e) != 0;
     if (const char *e = getenv("JD_BG_WEIGHT")) d->bg_weight = atof(e);
     if (const char *e = getenv("JD_BG_MAX_LOAD")) d->bg_max_load = atof(e);
+    if (const char *e = getenv("JD_BG_CHAIN")) d->bg_chain = atoi(e) != 0;
+    if (const char *e = getenv("JD_BG_CHAIN_FRAC")) d->bg_chain_frac = atof(e);
     if (const char *e = getenv("JD_FG_CW")) d->fg_cw_cap = std::max(1, atoi(e));
     if (const char *e = getenv("JD_BG_CW")) d->bg_cw_cap = std::max(1, atoi(e));
     hipError_t e;
@@ -1044,14 +1052,19 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
                          hipStream_t st, const std::vector<double> *weight_first = nullptr)
 {
     if (work_first.empty()) return JD_OK;
-    if ((int)work_first.size() > d->work_cap) {
+    if ((int)work_first.size() > d->work_cap || !d->d_chain) {
         if (d->d_work) (void)hipFree(d->d_work);
-        HIPCHK(hipMalloc(&d->d_work, work_first.size() * sizeof(int4)));
-        d->work_cap = (int)work_first.size();
+        if (d->d_chain) (void)hipFree(d->d_chain);
+        d->d_work = nullptr; d->d_chain = nullptr; d->work_cap = 0;
+        const size_t cap = std::max<size_t>(work_first.size(), (size_t)d->max_streams);
+        HIPCHK(hipMalloc(&d->d_work, cap * sizeof(int4)));
+        HIPCHK(hipMalloc(&d->d_chain, cap * sizeof(int)));
+        d->work_cap = (int)cap;
     }
     std::vector<int2> work_in = work_first;
     std::vector<int2> bg;                                              // streams of the batch behind, advanced beside these (pf_background)
     std::vector<double> bg_left;                                       // ... and the frames each has ahead
+    std::vector<int2> bg_chained;                                      // ... and the ones that follow a stream of this batch on its cluster
     std::vector<int> heads;
     std::vector<double> weight_now;
     std::vector<int> frame_before;                                     // per stream: where the previous launch found it
@@ -1077,7 +1090,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         reserve = d->reserve_now;                                      // (the legs of a re-planned launch leave the same CUs alone)
     }
     // two batches in flight: the utterances of the batch behind this one, one workgroup each at least, on a quarter of the grid at most
-    bg.clear();
+    bg.clear(); bg_chained.clear();
     if (d->fg_bank >= 0 && weight && d->weighted) {
         const bool started = !d->pf_q.empty() && d->pf_q.front().bank >= 0;
         if (started) {
@@ -1088,17 +1101,48 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         if (br) return br;
         if ((int)bg.size() > nwg_all / 4 || nwg_all - (int)bg.size() < 2 * n_work) { bg.clear(); bg_left.clear(); }
     }
+    // Streams of this batch that have little left (most of it was searched ahead) are through long before the launch is, and
+    // a cluster cannot be smaller than one workgroup: a stream of the batch behind is CHAINED behind each of them - the
+    // cluster goes on with it instead of idling (k_search, SearchArgs::chain) - the ones with the least ahead of them, which
+    // need the head start least; the workgroups they would have held go to everybody else's plan.  JD_BG_CHAIN=0: off.
+    std::vector<int2> chained;                                         // {work item of the batch behind, stream of this batch it follows}
+    if (!bg.empty() && d->bg_chain && d->last_wave_ms > 0.0) {
+        const double per_frame_us = (d->model2_a_us + d->model2_b_us * d->load_scale);            // one workgroup per stream
+        const double early = d->bg_chain_frac * d->last_wave_ms * 1e3 / per_frame_us;              // frames: through in that part of a launch
+        std::vector<int> fo((size_t)n_work), bo(bg.size());
+        std::iota(fo.begin(), fo.end(), 0); std::iota(bo.begin(), bo.end(), 0);
+        std::sort(fo.begin(), fo.end(), [&](int x, int y) { return (*weight)[(size_t)x] < (*weight)[(size_t)y]; });
+        std::sort(bo.begin(), bo.end(), [&](int x, int y) { return bg_left[(size_t)x] < bg_left[(size_t)y]; });
+        std::vector<char> gone(bg.size(), 0);
+        for (size_t i = 0; i < fo.size() && i < bo.size() / 2 && (*weight)[(size_t)fo[i]] <= early; ++i) {
+            chained.push_back(make_int2(bo[i], work_in[(size_t)fo[i]].x));
+            gone[(size_t)bo[i]] = 1;
+        }
+        if (!chained.empty()) {
+            std::vector<int2> chained_items;
+            std::vector<int2> bg2; std::vector<double> left2;
+            for (size_t i = 0; i < bg.size(); ++i) if (!gone[i]) { bg2.push_back(bg[i]); left2.push_back(bg_left[i]); }
+            for (int2 &c : chained) { const int2 item = bg[(size_t)c.x]; c = make_int2(0, c.y); chained_items.push_back(item); }
+            for (size_t i = 0; i < chained.size(); ++i) chained[i].x = (int)i;
+            bg_chained = chained_items;
+            bg.swap(bg2); bg_left.swap(left2);
+        }
+    }
     const int n_bg = (int)bg.size();
     while (reserve > 0 && nwg_all - reserve - n_bg < 2 * n_work) reserve -= 8;
     nwg_all -= std::max(reserve, 0);
-    if ((int)(n_work + n_bg) > d->work_cap) {
+    if ((int)(n_work + n_bg + chained.size()) > d->work_cap) {
         if (d->d_work) (void)hipFree(d->d_work);
-        d->d_work = nullptr; d->work_cap = 0;
-        HIPCHK(hipMalloc(&d->d_work, (size_t)(n_work + n_bg) * sizeof(int4)));
-        d->work_cap = n_work + n_bg;
+        if (d->d_chain) (void)hipFree(d->d_chain);
+        d->d_work = nullptr; d->d_chain = nullptr; d->work_cap = 0;
+        const size_t cap = (size_t)n_work + (size_t)n_bg + chained.size();
+        HIPCHK(hipMalloc(&d->d_work, cap * sizeof(int4)));
+        HIPCHK(hipMalloc(&d->d_chain, cap * sizeof(int)));
+        d->work_cap = (int)cap;
     }
     SearchArgs A;
-    A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work; A.n_prio = 0;
+    A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work; A.n_prio = 0; A.chain = nullptr;
+    A.cells = (d->d_cells && ll == d->d_ll_slab) ? d->d_cells : nullptr;
     const int nwg = nwg_all - n_bg;                                    // what the plan of THESE streams may use
     // a wave segment holds at least one 64-record chunk of instances and 512 frontier items (one wave
     // writes the whole epsilon closure of the items it expands)
@@ -1277,6 +1321,18 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             grid = first;
         }
         if (n_bg > 0) { A.n_prio = n_work; A.n_work = n_tot; d->bg_ran = true; }
+        if (!chained.empty() && d->d_chain) {
+            // the chained items: behind all the others (no workgroup finds them by its number), each named by the item it follows
+            std::vector<int> chain(work.size() + chained.size(), -1);
+            for (size_t i = 0; i < chained.size(); ++i) {
+                const int at = (int)work.size();
+                for (size_t k = 0; k < (size_t)n_tot; ++k) if (work[k].x == chained[i].y) { chain[k] = at; break; }
+                work.push_back(make_int4(bg_chained[i].x, bg_chained[i].y, 0x7fffffff, 1));
+            }
+            HIPCHK(hipMemcpyAsync(d->d_chain, chain.data(), chain.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));                          // (chain is a local)
+            A.chain = d->d_chain; A.n_work = (int)work.size(); A.n_prio = n_work;
+        }
         A.n_slots = 0;
         // Re-planning under way (SearchArgs::rebalance_at): the plan above makes the streams finish together only as
         // far as frames predict work; when a fifth of the grid has run out of work the launch is cut short and the
@@ -1483,6 +1539,7 @@ static int plan_wave(jd_dec *d, int nb, const int64_t *ustart, const int64_t *ul
 static int ensure_slab(jd_dec *d, size_t floats)
 {
     if (floats <= d->ll_cap) return JD_OK;
+    if (d->d_cells) { (void)hipFree(d->d_cells); d->d_cells = nullptr; d->cells_words = 0; }   // (the diagnostics bitmap is as long as the slab)
     if (d->d_ll_slab) (void)hipFree(d->d_ll_slab);
     d->d_ll_slab = nullptr; d->ll_cap = 0;
     for (int i = 0; i < 3; ++i) d->d_ll[i] = nullptr;
@@ -2329,6 +2386,50 @@ extern "C" int jd_debug_expf(int32_t device, const float *x, int64_t n, float *o
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dy, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dy);
+    return JD_OK;
+}
+
+// Diagnostics: what part of a likelihood table does the search read?  (SURVEY.md 8d's Ug: the reference scores a tied
+// state only when a token that passed the emit threshold asks for it, WFSTDecoderLite.cpp:409-411; here every state of
+// every frame is scored.)  enable != 0: the slab's bitmap is cleared and every cell phase A adds to a token is marked from
+// the next launch on; enable == 0: the marks are counted against the cells of the last decode's frames and marking stops.
+__global__ void jd_popcount_kernel(const unsigned *w, size_t n, unsigned long long *out)
+{
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += (unsigned)__popc(w[i]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+extern "C" int jd_dec_debug_cells(jd_dec *d, int32_t enable, int64_t *cells_read, int64_t *cells_total)
+{
+    if (!d) return jd_fail(JD_EINVAL, "jd_dec_debug_cells: null");
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (enable) {
+        if (d->ll_cap == 0) return jd_fail(JD_ESTATE, "jd_dec_debug_cells: decode a batch first (the tables are sized by it)");
+        const size_t words = (3 * d->ll_cap + 31) / 32 + 2;
+        if (!d->d_cells || d->cells_words != words) {
+            if (d->d_cells) (void)hipFree(d->d_cells);
+            d->d_cells = nullptr;
+            HIPCHK(hipMalloc(&d->d_cells, words * sizeof(unsigned)));
+            d->cells_words = words;
+        }
+        HIPCHK(hipMemset(d->d_cells, 0, words * sizeof(unsigned)));
+        return JD_OK;
+    }
+    unsigned long long n = 0;
+    if (d->d_cells) {
+        unsigned long long *dn = (unsigned long long *)(d->d_cells + d->cells_words - 2);   // (the last two words: the counter)
+        HIPCHK(hipMemset(dn, 0, sizeof(unsigned long long)));
+        hipLaunchKernelGGL(jd_popcount_kernel, dim3(1024), dim3(256), 0, 0, d->d_cells, d->cells_words - 2, dn);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(&n, dn, sizeof n, hipMemcpyDeviceToHost));
+        (void)hipFree(d->d_cells);
+        d->d_cells = nullptr; d->cells_words = 0;
+    }
+    if (cells_read) *cells_read = (int64_t)n;
+    if (cells_total) *cells_total = (int64_t)d->timing.search_frames * d->am->n_gmm;
     return JD_OK;
 }
 

@@ -177,6 +177,10 @@ struct SearchArgs {
                              // cluster on several XCDs - the placement check has to catch it
     int rebalance_at;        // weighted mode: when this many workgroups of the grid have nothing left to do (their stream is
                              // through, or stopped), every cluster stops after its frame and the host plans the rest anew (0: never)
+    unsigned *cells;         // diagnostics (or null): one bit per cell of the likelihood slab, set when phase A adds the cell's value
+                             // to a token (jd_dec_debug_cells: what part of a table the search reads - SURVEY.md 8d's Ug)
+    const int *chain;        // weighted mode (or null): chain[k] = the work item cluster k goes on with when item k is through (-1: none);
+                             // chained items sit behind the others in `work` (first workgroup INT_MAX: no workgroup looks them up)
     int n_prio;              // weighted mode: n_prio work items (bit 30 of their workgroup count) are the batch the caller is waiting for; the others
                              // belong to the batch BEHIND it (searched ahead on workgroups the plan leaves, jd_device.hip
                              // "two batches in flight") and stop after their frame once all of these are through (0: none)
@@ -616,7 +620,7 @@ template <int NE, bool TRPL, bool LR, bool XL, bool LZY>
 __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, StreamCtl &c, const StreamView &V,
                                         const Geo &gin, const Geo &gd, const Geo &gout, const int (&Q)[3], const int (&LN)[3], const int (&NS)[3],
                                         int jw, int Cw, int gw, int p,
-                                        float normalise, float emitTh, float startTh, const float *llrow,
+                                        float normalise, float emitTh, float startTh, const float *llrow, unsigned *cells, long long cell0,
                                         int &out_cnt, int &exit_cnt)
 {
     constexpr bool XL_ = XL;
@@ -739,6 +743,11 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             const float sc = best - normalise;                         // :408
             if (sc > emitTh) {                                         // :409
                 ++c_pemit;
+                if (cells) {                                           // (diagnostics: this cell of the table is read, :411)
+                    const int gj = (j == 1) ? h1.x : (j == 2) ? h1.y : (j == 3) ? h1.z : (j == 4) ? h2.x : (j == 5) ? h2.y : h2.z;
+                    const long long cell = cell0 + gj;
+                    atomicOr(cells + (cell >> 5), 1u << (cell & 31));
+                }
                 nw[j].score = sc + outp[j - 1];
                 nw[j].ac = (src.ac + btp) + outp[j - 1];
                 nw[j].lm = src.lm;
@@ -1484,9 +1493,13 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const float *llrow = A.ll + ((long long)ll_slot * A.ll_stride + (long long)(f - A.f0) * (long long)C.G);
             int out_cnt = 0;
             CLK(0);                                                    // thresholds + work lists
-            if (lr) phase_a<NE, true, true, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, items, nseg, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else if (trp_lds) phase_a<NE, true, false, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, items, nseg, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
-            else phase_a<NE, false, false, XL, LZY>(C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, items, nseg, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt);
+            const long long cell0 = (long long)(llrow - A.ll);       // (diagnostics: the row's first cell in the slab)
+#define PHASE_A_ARGS C, sh, c, V, gin, (p ? gd1 : gd0), gout, Q, items, nseg, jw, Cw, gw, p, normalise, emitTh, startTh, llrow, A.cells, cell0, \
+                     out_cnt, exit_cnt
+            if (lr) phase_a<NE, true, true, XL, LZY>(PHASE_A_ARGS);
+            else if (trp_lds) phase_a<NE, true, false, XL, LZY>(PHASE_A_ARGS);
+            else phase_a<NE, false, false, XL, LZY>(PHASE_A_ARGS);
+#undef PHASE_A_ARGS
             CLK(1);                                                    // phase A (wave 0's share)
             if (lane == 0) {
                 CS(tot_of(TOT_REC0 + (p ^ 1)) + gw, out_cnt);
@@ -1693,6 +1706,14 @@ __global__ JD_KBOUNDS void k_search(SearchArgs A)
         Cw = RFL(A.work[lo].w) & 0xffff; jw = (int)wg - first;             // (bit 30: one of the streams the launch is there for, n_prio)
         k = (jw < Cw) ? lo : A.n_work; kstep = A.n_work;
     }
-    for (; k < A.n_work; k += kstep)
-        run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw, A.n_slots == 0 && (RFL(A.work[k].w) & 0x40000000) != 0);
+    if (A.n_slots > 0) {
+        for (; k < A.n_work; k += kstep) run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw, false);
+        return;
+    }
+    // weighted mode: the cluster's stream, and then what the host has chained behind it (SearchArgs::chain: a stream of
+    // the batch behind put behind a stream that will be through early - the cluster goes on with it instead of idling)
+    while (k >= 0 && k < A.n_work) {
+        run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw, (RFL(A.work[k].w) & 0x40000000) != 0);
+        k = A.chain ? RFL(A.chain[k]) : -1;
+    }
 }
