@@ -416,6 +416,11 @@ def main():
     torch.cuda.synchronize()
     serial_ms = (time.perf_counter() - t1) * 1e3
     tm_serial = dec.last_timing()
+    # (outside the timed region) which part of the likelihood table does the search read?  SURVEY.md 8d's Ug: the reference
+    # scores a tied state only when a token that passed the emit threshold asks for it; every state of every frame is scored here
+    dec.debug_cells(True)
+    dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
+    cells_read, cells_total = dec.debug_cells(False)
     if world > 1:
         t = torch.tensor([elapsed, float(frames_local)], dtype=torch.float64, device=dev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -461,6 +466,8 @@ def main():
                        "algorithmic_bytes_per_launch": round(gmm_bytes, 1),
                        "search_waited_ms_per_step": round(acc["gmm_wait_ms"] / steps, 3),
                        "scored_ahead_steps": int(n_ahead),
+                       "cells_scored": int(cells_total), "cells_read_by_the_search": int(cells_read),
+                       "cells_read_frac": round(cells_read / max(cells_total, 1), 4),
                        "span_beside_search_ms": round(acc["gmm_ms"] / steps, 3) if n_ahead else None,
                        "serial_order_ms_per_step": round(serial_ms, 3),
                        "serial_order_search_ms": round(tm_serial["search_ms"], 3),

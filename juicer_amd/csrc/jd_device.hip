@@ -382,7 +382,6 @@ struct jd_dec {
     // which a decoder learns from the batches it has decoded (first batch: as fitted)
     double load_scale = 1.0, load_sum = 0.0, load_frames = 0.0;
     int4 *d_work = nullptr; int work_cap = 0;
-    int *d_chain = nullptr;               // SearchArgs::chain of the launch under way (as long as d_work)
     unsigned *d_cells = nullptr; size_t cells_words = 0;   // diagnostics (jd_dec_debug_cells): a bit per cell of the likelihood slab
     int *d_status = nullptr; int *h_status = nullptr;
     bool xl_ok = true;                    // XCD-local launches allowed (JD_XCD_LOCAL=0 or one failed placement check switch them off)
@@ -408,8 +407,6 @@ struct jd_dec {
     int score_reserve = -1;               // CUs left to the scoring beside a launch with two batches in flight: -1 by its cost (JD_SCORE_RESERVE)
     int reserve_now = 0;                  // ... of the launch under way
     int bg_rebalance = 0;                 // re-plan a launch that runs two batches (JD_BG_REBALANCE)
-    int bg_chain = 1;                     // chain streams of the batch behind behind streams of this one that are through early (JD_BG_CHAIN)
-    double bg_chain_frac = 0.5;           // ... "early": within this part of a launch as long as the last one (JD_BG_CHAIN_FRAC)
     double bg_max_load = 4.0;             // two batches in flight up to this load_scale (JD_BG_MAX_LOAD)
     double bg_weight = 0.5;               // the plan counts this part of the frames a stream of the batch behind has ahead (JD_BG_WEIGHT)
     int fg_cw_cap = 8, bg_cw_cap = 4;     // two batches in flight: largest cluster of the running batch / of the batch behind (JD_FG_CW, JD_BG_CW)
@@ -485,7 +482,6 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     if (d->h_resident) (void)hipHostFree(d->h_resident);
     if (d->d_push) (void)hipFree(d->d_push);
     if (d->d_work) (void)hipFree(d->d_work);
-    if (d->d_chain) (void)hipFree(d->d_chain);
     if (d->h_status) (void)hipHostFree(d->h_status);
     if (d->s_gmm) (void)hipStreamDestroy(d->s_gmm);
     if (d->s_search) (void)hipStreamDestroy(d->s_search);
@@ -636,8 +632,6 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (const char *e = getenv("JD_BG_REBALANCE")) d->bg_rebalance = atoi(e) != 0;
     if (const char *e = getenv("JD_BG_WEIGHT")) d->bg_weight = atof(e);
     if (const char *e = getenv("JD_BG_MAX_LOAD")) d->bg_max_load = atof(e);
-    if (const char *e = getenv("JD_BG_CHAIN")) d->bg_chain = atoi(e) != 0;
-    if (const char *e = getenv("JD_BG_CHAIN_FRAC")) d->bg_chain_frac = atof(e);
     if (const char *e = getenv("JD_FG_CW")) d->fg_cw_cap = std::max(1, atoi(e));
     if (const char *e = getenv("JD_BG_CW")) d->bg_cw_cap = std::max(1, atoi(e));
     hipError_t e;
@@ -1052,19 +1046,16 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
                          hipStream_t st, const std::vector<double> *weight_first = nullptr)
 {
     if (work_first.empty()) return JD_OK;
-    if ((int)work_first.size() > d->work_cap || !d->d_chain) {
+    if ((int)work_first.size() > d->work_cap) {
         if (d->d_work) (void)hipFree(d->d_work);
-        if (d->d_chain) (void)hipFree(d->d_chain);
-        d->d_work = nullptr; d->d_chain = nullptr; d->work_cap = 0;
+        d->d_work = nullptr; d->work_cap = 0;
         const size_t cap = std::max<size_t>(work_first.size(), (size_t)d->max_streams);
         HIPCHK(hipMalloc(&d->d_work, cap * sizeof(int4)));
-        HIPCHK(hipMalloc(&d->d_chain, cap * sizeof(int)));
         d->work_cap = (int)cap;
     }
     std::vector<int2> work_in = work_first;
     std::vector<int2> bg;                                              // streams of the batch behind, advanced beside these (pf_background)
     std::vector<double> bg_left;                                       // ... and the frames each has ahead
-    std::vector<int2> bg_chained;                                      // ... and the ones that follow a stream of this batch on its cluster
     std::vector<int> heads;
     std::vector<double> weight_now;
     std::vector<int> frame_before;                                     // per stream: where the previous launch found it
@@ -1090,7 +1081,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         reserve = d->reserve_now;                                      // (the legs of a re-planned launch leave the same CUs alone)
     }
     // two batches in flight: the utterances of the batch behind this one, one workgroup each at least, on a quarter of the grid at most
-    bg.clear(); bg_chained.clear();
+    bg.clear();
     if (d->fg_bank >= 0 && weight && d->weighted) {
         const bool started = !d->pf_q.empty() && d->pf_q.front().bank >= 0;
         if (started) {
@@ -1101,47 +1092,17 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         if (br) return br;
         if ((int)bg.size() > nwg_all / 4 || nwg_all - (int)bg.size() < 2 * n_work) { bg.clear(); bg_left.clear(); }
     }
-    // Streams of this batch that have little left (most of it was searched ahead) are through long before the launch is, and
-    // a cluster cannot be smaller than one workgroup: a stream of the batch behind is CHAINED behind each of them - the
-    // cluster goes on with it instead of idling (k_search, SearchArgs::chain) - the ones with the least ahead of them, which
-    // need the head start least; the workgroups they would have held go to everybody else's plan.  JD_BG_CHAIN=0: off.
-    std::vector<int2> chained;                                         // {work item of the batch behind, stream of this batch it follows}
-    if (!bg.empty() && d->bg_chain && d->last_wave_ms > 0.0) {
-        const double per_frame_us = (d->model2_a_us + d->model2_b_us * d->load_scale);            // one workgroup per stream
-        const double early = d->bg_chain_frac * d->last_wave_ms * 1e3 / per_frame_us;              // frames: through in that part of a launch
-        std::vector<int> fo((size_t)n_work), bo(bg.size());
-        std::iota(fo.begin(), fo.end(), 0); std::iota(bo.begin(), bo.end(), 0);
-        std::sort(fo.begin(), fo.end(), [&](int x, int y) { return (*weight)[(size_t)x] < (*weight)[(size_t)y]; });
-        std::sort(bo.begin(), bo.end(), [&](int x, int y) { return bg_left[(size_t)x] < bg_left[(size_t)y]; });
-        std::vector<char> gone(bg.size(), 0);
-        for (size_t i = 0; i < fo.size() && i < bo.size() / 2 && (*weight)[(size_t)fo[i]] <= early; ++i) {
-            chained.push_back(make_int2(bo[i], work_in[(size_t)fo[i]].x));
-            gone[(size_t)bo[i]] = 1;
-        }
-        if (!chained.empty()) {
-            std::vector<int2> chained_items;
-            std::vector<int2> bg2; std::vector<double> left2;
-            for (size_t i = 0; i < bg.size(); ++i) if (!gone[i]) { bg2.push_back(bg[i]); left2.push_back(bg_left[i]); }
-            for (int2 &c : chained) { const int2 item = bg[(size_t)c.x]; c = make_int2(0, c.y); chained_items.push_back(item); }
-            for (size_t i = 0; i < chained.size(); ++i) chained[i].x = (int)i;
-            bg_chained = chained_items;
-            bg.swap(bg2); bg_left.swap(left2);
-        }
-    }
     const int n_bg = (int)bg.size();
     while (reserve > 0 && nwg_all - reserve - n_bg < 2 * n_work) reserve -= 8;
     nwg_all -= std::max(reserve, 0);
-    if ((int)(n_work + n_bg + chained.size()) > d->work_cap) {
+    if ((int)(n_work + n_bg) > d->work_cap) {
         if (d->d_work) (void)hipFree(d->d_work);
-        if (d->d_chain) (void)hipFree(d->d_chain);
-        d->d_work = nullptr; d->d_chain = nullptr; d->work_cap = 0;
-        const size_t cap = (size_t)n_work + (size_t)n_bg + chained.size();
-        HIPCHK(hipMalloc(&d->d_work, cap * sizeof(int4)));
-        HIPCHK(hipMalloc(&d->d_chain, cap * sizeof(int)));
-        d->work_cap = (int)cap;
+        d->d_work = nullptr; d->work_cap = 0;
+        HIPCHK(hipMalloc(&d->d_work, (size_t)(n_work + n_bg) * sizeof(int4)));
+        d->work_cap = n_work + n_bg;
     }
     SearchArgs A;
-    A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work; A.n_prio = 0; A.chain = nullptr;
+    A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work; A.n_prio = 0;
     A.cells = (d->d_cells && ll == d->d_ll_slab) ? d->d_cells : nullptr;
     const int nwg = nwg_all - n_bg;                                    // what the plan of THESE streams may use
     // a wave segment holds at least one 64-record chunk of instances and 512 frontier items (one wave
@@ -1321,18 +1282,6 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             grid = first;
         }
         if (n_bg > 0) { A.n_prio = n_work; A.n_work = n_tot; d->bg_ran = true; }
-        if (!chained.empty() && d->d_chain) {
-            // the chained items: behind all the others (no workgroup finds them by its number), each named by the item it follows
-            std::vector<int> chain(work.size() + chained.size(), -1);
-            for (size_t i = 0; i < chained.size(); ++i) {
-                const int at = (int)work.size();
-                for (size_t k = 0; k < (size_t)n_tot; ++k) if (work[k].x == chained[i].y) { chain[k] = at; break; }
-                work.push_back(make_int4(bg_chained[i].x, bg_chained[i].y, 0x7fffffff, 1));
-            }
-            HIPCHK(hipMemcpyAsync(d->d_chain, chain.data(), chain.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));                          // (chain is a local)
-            A.chain = d->d_chain; A.n_work = (int)work.size(); A.n_prio = n_work;
-        }
         A.n_slots = 0;
         // Re-planning under way (SearchArgs::rebalance_at): the plan above makes the streams finish together only as
         // far as frames predict work; when a fifth of the grid has run out of work the launch is cut short and the

@@ -179,8 +179,6 @@ struct SearchArgs {
                              // through, or stopped), every cluster stops after its frame and the host plans the rest anew (0: never)
     unsigned *cells;         // diagnostics (or null): one bit per cell of the likelihood slab, set when phase A adds the cell's value
                              // to a token (jd_dec_debug_cells: what part of a table the search reads - SURVEY.md 8d's Ug)
-    const int *chain;        // weighted mode (or null): chain[k] = the work item cluster k goes on with when item k is through (-1: none);
-                             // chained items sit behind the others in `work` (first workgroup INT_MAX: no workgroup looks them up)
     int n_prio;              // weighted mode: n_prio work items (bit 30 of their workgroup count) are the batch the caller is waiting for; the others
                              // belong to the batch BEHIND it (searched ahead on workgroups the plan leaves, jd_device.hip
                              // "two batches in flight") and stop after their frame once all of these are through (0: none)
@@ -1706,14 +1704,6 @@ __global__ JD_KBOUNDS void k_search(SearchArgs A)
         Cw = RFL(A.work[lo].w) & 0xffff; jw = (int)wg - first;             // (bit 30: one of the streams the launch is there for, n_prio)
         k = (jw < Cw) ? lo : A.n_work; kstep = A.n_work;
     }
-    if (A.n_slots > 0) {
-        for (; k < A.n_work; k += kstep) run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw, false);
-        return;
-    }
-    // weighted mode: the cluster's stream, and then what the host has chained behind it (SearchArgs::chain: a stream of
-    // the batch behind put behind a stream that will be through early - the cluster goes on with it instead of idling)
-    while (k >= 0 && k < A.n_work) {
-        run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw, (RFL(A.work[k].w) & 0x40000000) != 0);
-        k = A.chain ? RFL(A.chain[k]) : -1;
-    }
+    for (; k < A.n_work; k += kstep)
+        run_stream<NE, XL, LZY>(A, sh, RFL(A.work[k].x), RFL(A.work[k].y), jw, Cw, A.n_slots == 0 && (RFL(A.work[k].w) & 0x40000000) != 0);
 }
