@@ -347,6 +347,11 @@ def main():
         am, net, all_feats, _ = synth.config_c2(seed=args.seed, n_utts=args.total_utts, target_arcs=args.arcs)
         shards = parallel.shard_lpt([f.shape[0] for f in all_feats], world)
         shard = shards[rank]
+        # what the 1-GPU measurements say every rank's share should take (the first real SCALE run can be read against it):
+        # a wave of at most 128 streams lasts as long as its longest utterance's chain of frames (33 us per frame, DESIGN.md
+        # 9) or as its frames take at the rate of the 512-utterances-on-one-GPU leg (1.44 M frames/s), whichever is more
+        predicted_rank_ms = [round(max(max([all_feats[u].shape[0] for u in sh] or [0]) * 33e-3 + 1.5,
+                                       sum(all_feats[u].shape[0] for u in sh) / 1.44e6 * 1e3), 2) for sh in shards]
         per_rank = max(len(x) for x in shards)
         feats = [all_feats[u] for u in shard]
         del all_feats
@@ -529,6 +534,7 @@ def main():
                       "parallelism": ("one batch of %d utterances dealt by length over %d rank(s)" % (args.total_utts, world)) if strong
                                      else "utterance-sharded x%d" % world,
                       "batches_in_flight": 2 if two_in_flight else 1,
+                      "predicted_rank_ms": predicted_rank_ms if strong else None,
                       "search_ahead_frames_per_step": int(acc["ahead_frames"] // max(steps, 1)),
                       "streams_per_gpu": dec.max_streams},
            "roofline": roofline, "cpu_baseline": cpu}

@@ -122,7 +122,10 @@ static void broker_loop(jd_broker *b)
                 fr += nn.back();
             }
             const int rc = ss.empty() ? JD_OK : jd_streams_push(b->dec, (int32_t)ss.size(), ss.data(), ff.data(), nn.data());
-            if (rc) { const std::string m = jd_last_error(); for (int i : pushers) if (rc_of[(size_t)i] == JD_OK) { rc_of[(size_t)i] = rc; msg_of[(size_t)i] = m; } }
+            if (rc) {
+                const std::string m = jd_last_error();
+                for (int i : pushers) if (rc_of[(size_t)i] == JD_OK) { rc_of[(size_t)i] = rc; msg_of[(size_t)i] = m; }
+            }
             tick_frames = fr; tick_streams = (long long)ss.size();
         }
         std::vector<jd_hyp> res((size_t)b->n_clients);
@@ -208,10 +211,12 @@ extern "C" int jd_broker_init(jd_broker *b, int32_t client)
 
 extern "C" int jd_broker_push(jd_broker *b, int32_t client, const float *frames, int32_t n_frames)
 {
-    if (!b || client < 0 || client >= b->n_clients || n_frames < 0 || (n_frames > 0 && !frames)) return jd_fail(JD_EINVAL, "jd_broker_push: bad argument");
+    if (!b || client < 0 || client >= b->n_clients || n_frames < 0 || (n_frames > 0 && !frames))
+        return jd_fail(JD_EINVAL, "jd_broker_push: bad argument");
     std::unique_lock<std::mutex> lk(b->mu);
     Client &c = b->clients[(size_t)client];
-    if (!c.open || !(c.inited || c.want_init) || c.want_finish) return jd_fail(JD_ESTATE, "jd_broker_push: client %d is not between init and finish", client);
+    if (!c.open || !(c.inited || c.want_init) || c.want_finish)
+        return jd_fail(JD_ESTATE, "jd_broker_push: client %d is not between init and finish", client);
     const int rc = client_error(b, c);
     if (rc) return rc;
     b->cv_done.wait(lk, [&]() { return b->stop || (int)(c.pending.size() / (size_t)b->D) <= b->max_pending_frames; });

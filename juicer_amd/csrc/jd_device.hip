@@ -165,7 +165,8 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
     if (n_rows <= 0) return JD_OK;
     if (a->hybrid) {
         const long long n = (long long)n_rows * a->n_gmm;
-        hipLaunchKernelGGL(jd_hybrid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_feats, d_row_src, n_rows, b.log_prior, a->n_gmm, d_ll);
+        hipLaunchKernelGGL(jd_hybrid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_feats, d_row_src, n_rows, b.log_prior,
+                           a->n_gmm, d_ll);
         HIPCHK(hipGetLastError());
         return JD_OK;
     }
@@ -374,7 +375,8 @@ struct jd_dec {
     double rebalance_frac = 0.2;          // ... this part (JD_REBALANCE_FRAC)
     double rebalance_min_us = 4000.0;     // ... and only launches predicted to last this long (JD_REBALANCE_MIN_US; 0 in tests)
     double model_a_us = 10.0, model_b_us = 360.0;   // cost model of a stream-frame: a + b / workgroups (launch_search), as fitted in round 2
-    double pf_gmm_weight = 1.35;          // scoring beside a search is priced at this times its CU-time on its own (the CUs come late, and piecemeal; JD_PF_GMM_WEIGHT)
+    double pf_gmm_weight = 1.35;          // scoring beside a search is priced at this times its CU-time on its own (the CUs come late,
+                                          // and piecemeal; JD_PF_GMM_WEIGHT)
     int plan_min_cw = 2;                  // greedy plan: workgroups every stream starts with (JD_PLAN_MIN_CW)
     int plan_mode = 0;                    // 0: round 2's constants + bisection; 1: measured curve (model2_*) + greedy whole workgroups (JD_PLAN)
     double model2_a_us = 24.6, model2_b_us = 61.4;   // ... as measured in round 3 (JD_MODEL2_A / JD_MODEL2_B)
@@ -399,7 +401,8 @@ struct jd_dec {
     // scoring one batch ahead (jd_dec_prefetch_scores): the table of the NEXT batch is scored while this one is searched
     std::deque<Prefetch> pf_q;            // the batches ahead, in the order announced: scored, started ("two batches in flight"), or neither yet
     int fg_buf = -1;                      // the table(s) the wave being decoded uses (-1: none; -2: tables 0 and 1, in chunks)
-    int fg_bank = -1;                     // >= 0: the wave being decoded runs on this bank of streams and the batch behind it may be started beside it
+    int fg_bank = -1;                     // >= 0: the wave being decoded runs on this bank of streams and the batch behind it may be
+                                          // started beside it
     int pipeline = 1;                     // two batches in flight (JD_PIPELINE=0: off)
     bool bg_ran = false;                  // the last launch_search advanced streams of the batch behind, too
     double bg_wait_us = 1000.0;           // how long the start of a launch waits for the table of the batch behind (JD_BG_WAIT_US)
@@ -762,7 +765,8 @@ static int ensure_arenas_try(jd_dec *d, double mem_fraction)
             d->cap_slots = pick(0.5 * budget / rec_b, 1 << 19, std::min<int64_t>(d->net->n_arcs + 65536, lim_rec));
             if (d->slots_hint > d->cap_slots) d->cap_slots = std::min<int64_t>(d->slots_hint, lim_rec);   // setMaxAllocModels: more room, never less
         }
-        if (d->cap_items <= 0) d->cap_items = pick(0.2 * budget / item_b, 1 << 21, std::min<int64_t>(std::max<int64_t>(2 * d->net->n_arcs + 65536, 1 << 21), lim_item));
+        if (d->cap_items <= 0)
+            d->cap_items = pick(0.2 * budget / item_b, 1 << 21, std::min<int64_t>(std::max<int64_t>(2 * d->net->n_arcs + 65536, 1 << 21), lim_item));
         // (records and items stop at their addressing limits: what they leave of the budget goes to the Path
         // records - every collection of those is a stop of the stream's launch - up to 16 per arc of the
         // graph: small graphs do not write more, and tens of GB take seconds to allocate)
@@ -946,15 +950,18 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
                 first_err = jd_fail(JD_EHIP, "stream %d: a workgroup of the search cluster did not arrive at a barrier "
                                     "(frame %d)", s0 + i, K.frame);
             else if (K.error == JDE_LAZY_INV)
-                first_err = jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)", s0 + i, K.frame);
+                first_err = jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)",
+                                    s0 + i, K.frame);
             else if (K.error == JDE_LAZY) {
                 d->lazy_failed = true;
                 LazyDev L;
                 int why = 0;
-                if (hipMemcpy(&L, d->net->lazy_dev, sizeof L, hipMemcpyDeviceToHost) == hipSuccess) (void)hipMemcpy(&why, L.err, sizeof why, hipMemcpyDeviceToHost);
+                if (hipMemcpy(&L, d->net->lazy_dev, sizeof L, hipMemcpyDeviceToHost) == hipSuccess)
+                    (void)hipMemcpy(&why, L.err, sizeof why, hipMemcpyDeviceToHost);
                 first_err = jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of %s at frame %d (capacity %d states, %lld arcs): "
                                     "what was being decoded at once needs a network with larger max_states / max_arcs", s0 + i,
-                                    why == 1 ? "states" : why == 2 ? "arcs" : "stack closing a state (epsilon / tee arcs more than a hundred deep, or a cycle of them)",
+                                    why == 1 ? "states" : why == 2 ? "arcs"
+                                             : "stack closing a state (epsilon / tee arcs more than a hundred deep, or a cycle of them)",
                                     K.frame, d->net->n_states, (long long)d->net->n_arcs);
             }
             else {
@@ -1103,7 +1110,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     }
     SearchArgs A;
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = d->d_work; A.n_work = n_work; A.n_prio = 0;
-    A.cells = (d->d_cells && ll == d->d_ll_slab) ? d->d_cells : nullptr;
+    A.cells = (d->d_cells && ll == d->d_ll_slab) ? d->d_cells + 2 : nullptr;   // (the first two words: the counter of jd_dec_debug_cells)
     const int nwg = nwg_all - n_bg;                                    // what the plan of THESE streams may use
     // a wave segment holds at least one 64-record chunk of instances and 512 frontier items (one wave
     // writes the whole epsilon closure of the items it expands)
@@ -1237,7 +1244,9 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // atomics are measured to be worth): a cluster squeezed into a corner is a long tail.
         const int bin = nwg_all / 8;
         if (d->xl_ok && (nwg_all & 7) == 0) {
-            auto t_of = [&](int k, int c) { return wt_all[(size_t)k] <= 0.0 ? 0.0 : std::max(wt_all[(size_t)k], 1.0) * (a_us + b_us / std::max(c, 1)); };
+            auto t_of = [&](int k, int c) {
+                return wt_all[(size_t)k] <= 0.0 ? 0.0 : std::max(wt_all[(size_t)k], 1.0) * (a_us + b_us / std::max(c, 1));
+            };
             std::vector<int> order((size_t)n_tot), pos((size_t)n_tot, 0), room(8, bin), cwx = cw_all;
             std::vector<std::vector<int>> member(8);
             std::iota(order.begin(), order.end(), 0);
@@ -1265,11 +1274,17 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
                     int at = b * bin;
                     for (int k : member[(size_t)b]) { pos[(size_t)k] = at; at += cwx[(size_t)k]; }
                 }
-                for (int k = 0; k < n_work; ++k) { tau_plain = std::max(tau_plain, t_of(k, cw_all[(size_t)k])); tau_xl = std::max(tau_xl, t_of(k, cwx[(size_t)k])); }
+                for (int k = 0; k < n_work; ++k) {
+                    tau_plain = std::max(tau_plain, t_of(k, cw_all[(size_t)k]));
+                    tau_xl = std::max(tau_xl, t_of(k, cwx[(size_t)k]));
+                }
                 if (tau_xl > d->xl_slack * tau_plain) fits = false;
             }
             if (fits) {
-                for (int k = 0; k < n_tot; ++k) { work[(size_t)k].z = pos[(size_t)k]; work[(size_t)k].w = cwx[(size_t)k] | (k < n_work ? prio_flag : 0); }
+                for (int k = 0; k < n_tot; ++k) {
+                    work[(size_t)k].z = pos[(size_t)k];
+                    work[(size_t)k].w = cwx[(size_t)k] | (k < n_work ? prio_flag : 0);
+                }
                 // (the kernel searches by first workgroup)
                 std::sort(work.begin(), work.end(), [](const int4 &x, const int4 &y) { return x.z < y.z; });
                 grid = nwg_all;
@@ -1278,7 +1293,11 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         }
         if (!xl) {
             int first = 0;
-            for (int k = 0; k < n_tot; ++k) { work[(size_t)k].z = first; work[(size_t)k].w = cw_all[(size_t)k] | (k < n_work ? prio_flag : 0); first += cw_all[(size_t)k]; }
+            for (int k = 0; k < n_tot; ++k) {
+                work[(size_t)k].z = first;
+                work[(size_t)k].w = cw_all[(size_t)k] | (k < n_work ? prio_flag : 0);
+                first += cw_all[(size_t)k];
+            }
             grid = first;
         }
         if (n_bg > 0) { A.n_prio = n_work; A.n_work = n_tot; d->bg_ran = true; }
@@ -1292,7 +1311,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         rebalance_at = 0;
         if (d->rebalance && n_work >= 4 && (n_bg == 0 || d->bg_rebalance)) {
             double tau = 0.0;
-            for (int k = 0; k < n_work; ++k) tau = std::max(tau, std::max((*weight)[(size_t)k], 1.0) * (a_us + b_us / std::max(work[(size_t)k].w & 0xffff, 1)));
+            for (int k = 0; k < n_work; ++k)
+                tau = std::max(tau, std::max((*weight)[(size_t)k], 1.0) * (a_us + b_us / std::max(work[(size_t)k].w & 0xffff, 1)));
             if (tau > d->rebalance_min_us) rebalance_at = std::max(1, (int)(d->rebalance_frac * grid));
         }
 
@@ -1384,7 +1404,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         // Some streams stopped for a collection of their Path records (k_gc_*: no-ops for the streams below
         // their mark): the launch is repeated for the streams that are not through, with clusters sized for
         // what each of them still has ahead.
-        if (d->h_status[0] > d->h_status[3] + d->h_status[6]) {           // (not when every stop was for a re-plan, or a stream ahead of its turn stopping with the launch)
+        // (not when every stop was for a re-plan, or a stream ahead of its turn stopping with the launch)
+        if (d->h_status[0] > d->h_status[3] + d->h_status[6]) {
             launch_gc(d->C, d->d_ctl, d->d_streams, d->d_work, A.n_work, 0, ne3, d->n_cus, st);
             HIPCHK(hipGetLastError());
             // PARTIAL_DECODING: the trace rides on the collection (:362-368) - the caller has to see the stream as it
@@ -1406,7 +1427,10 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             const int done = h[0] - frame_before[(size_t)w.x];
             frame_before[(size_t)w.x] = h[0];
             // (a launch cut short for a re-plan says nothing about when a stream's arena fills up: then the frames left count)
-            if (left > 0 && h[2] == 0) { rest.push_back(w); weight_now.push_back((double)((done > 0 && d->h_status[3] == 0) ? std::min(left, done) : left)); }
+            if (left > 0 && h[2] == 0) {
+                rest.push_back(w);
+                weight_now.push_back((double)((done > 0 && d->h_status[3] == 0) ? std::min(left, done) : left));
+            }
         }
         if (rest.empty()) break;
         work_in.swap(rest);
@@ -1497,7 +1521,8 @@ static int ensure_slab(jd_dec *d, size_t floats)
     hipError_t e = hipMalloc(&d->d_ll_slab, 3 * floats * sizeof(float));
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        return jd_fail(e == hipErrorOutOfMemory ? JD_ENOMEM : JD_EHIP, "hipMalloc of %zu bytes (likelihood tables) failed: %s", 3 * floats * sizeof(float), hipGetErrorString(e));
+        return jd_fail(e == hipErrorOutOfMemory ? JD_ENOMEM : JD_EHIP, "hipMalloc of %zu bytes (likelihood tables) failed: %s",
+                       3 * floats * sizeof(float), hipGetErrorString(e));
     }
     d->ll_cap = floats;
     for (int i = 0; i < 3; ++i) d->d_ll[i] = d->d_ll_slab + (size_t)i * floats;
@@ -1644,7 +1669,8 @@ static int pf_background(jd_dec *d, int fg_bank, const std::vector<int> *heads, 
         const auto tq0 = std::chrono::steady_clock::now();
         while (hipEventQuery(F.ev1) != hipSuccess) {
             (void)hipGetLastError();
-            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count() > d->bg_wait_us) return JD_OK;   // still being scored
+            const double waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
+            if (waited_us > d->bg_wait_us) return JD_OK;              // still being scored
         }
         F.bank = fg_bank ^ 1;
         const int s0 = F.bank * B;
@@ -1861,7 +1887,8 @@ static int decode_wave(jd_dec *d, int nb, const float *d_feats, const int64_t *u
         for (int c = 0; c < n_chunks; ++c) rows += P.chunk_rows[(size_t)c];
         if (!prefetched && rows > 0 && d->timing.gmm_ms > gmm_before) d->gmm_ms_per_row = (d->timing.gmm_ms - gmm_before) / (double)rows;
         // (a launch that also advanced the batch behind: its frames are not known here - the estimate stays)
-        if (frames_here > 0 && d->timing.search_ms > search_before && !d->bg_ran) d->search_ms_per_frame = (d->timing.search_ms - search_before) / (double)frames_here;
+        if (frames_here > 0 && d->timing.search_ms > search_before && !d->bg_ran)
+            d->search_ms_per_frame = (d->timing.search_ms - search_before) / (double)frames_here;
         d->bg_ran = false;
     }
     for (int u = 0; u < nb; ++u) d->timing.search_frames += T[(size_t)u];
@@ -1909,7 +1936,10 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         callers.swap(d->pf_q);
     }
     // (on an error way out nothing scored or announced ahead survives: the caller may free the features next)
-    struct Restore { jd_dec *d; std::deque<Prefetch> &p; bool ok; ~Restore() { for (Prefetch &F : p) F.drop(); if (!ok) pf_discard(d); } } callers_guard{d, callers, false};
+    struct Restore {
+        jd_dec *d; std::deque<Prefetch> &p; bool ok;
+        ~Restore() { for (Prefetch &F : p) F.drop(); if (!ok) pf_discard(d); }
+    } callers_guard{d, callers, false};
     for (int u0 = 0; u0 < n_utts; u0 += d->max_streams) {
         const int nb = std::min(d->max_streams, n_utts - u0);
         for (int i = 0; i < nb; ++i) {
@@ -2017,6 +2047,9 @@ extern "C" int jd_stream_init(jd_dec *d, int32_t s)
     if (rc) return rc;
     rc = ensure_arenas(d);
     if (rc) return rc;
+    // (the streaming interface names its streams itself: whatever a stream of batches had been started ahead on them is
+    // dropped - the batch concerned starts again when it is decoded)
+    pf_discard(d);
     if (d->lazy_in[(size_t)s]) { d->lazy_in[(size_t)s] = 0; jd_lazy_leave(d->net, 1); }   // (an utterance that was never finished)
     bool net_failed = false;
     rc = jd_lazy_enter(d->net, 1, &net_failed);                       // (may start a new arena generation)
@@ -2046,7 +2079,8 @@ static int trace_partial(jd_dec *d, int s, int *found)
     std::vector<int32_t> &L = d->partial_label[(size_t)s], &Tm = d->partial_time[(size_t)s];
     const int last_frame = Tm.empty() ? -1 : Tm.back();
     hipStream_t st = d->s_search;
-    if (d->am->max_n <= 5) hipLaunchKernelGGL(k_partial<3>, dim3(1), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, s, last_frame, d->d_partial_out);
+    if (d->am->max_n <= 5)
+        hipLaunchKernelGGL(k_partial<3>, dim3(1), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, s, last_frame, d->d_partial_out);
     else hipLaunchKernelGGL(k_partial<6>, dim3(1), dim3(1024), 0, st, d->C, d->d_ctl, d->d_streams, s, last_frame, d->d_partial_out);
     HIPCHK(hipGetLastError());
     int ho[2] = {0, 0};
@@ -2369,9 +2403,9 @@ extern "C" int jd_dec_debug_cells(jd_dec *d, int32_t enable, int64_t *cells_read
     }
     unsigned long long n = 0;
     if (d->d_cells) {
-        unsigned long long *dn = (unsigned long long *)(d->d_cells + d->cells_words - 2);   // (the last two words: the counter)
+        unsigned long long *dn = (unsigned long long *)d->d_cells;      // (the first two words: the counter)
         HIPCHK(hipMemset(dn, 0, sizeof(unsigned long long)));
-        hipLaunchKernelGGL(jd_popcount_kernel, dim3(1024), dim3(256), 0, 0, d->d_cells, d->cells_words - 2, dn);
+        hipLaunchKernelGGL(jd_popcount_kernel, dim3(1024), dim3(256), 0, 0, d->d_cells + 2, d->cells_words - 2, dn);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(&n, dn, sizeof n, hipMemcpyDeviceToHost));
         (void)hipFree(d->d_cells);

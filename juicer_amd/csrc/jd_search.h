@@ -273,8 +273,18 @@ template <bool XL, typename T, typename U> __device__ __forceinline__ T GADDx(T 
 #define CS(p, ...) CSx<XL_>(p, __VA_ARGS__)
 #define GMAX(p, ...) GMAXx<XL_>(p, __VA_ARGS__)
 #define GADD(p, ...) GADDx<XL_>(p, __VA_ARGS__)
-__device__ __forceinline__ Tok as_tok(v4i v) { Tok t; t.score = __int_as_float(v.x); t.ac = __int_as_float(v.y); t.lm = __int_as_float(v.z); t.path = v.w; return t; }
-__device__ __forceinline__ v4i as_v4(const Tok &t) { v4i v; v.x = __float_as_int(t.score); v.y = __float_as_int(t.ac); v.z = __float_as_int(t.lm); v.w = t.path; return v; }
+__device__ __forceinline__ Tok as_tok(v4i v)
+{
+    Tok t;
+    t.score = __int_as_float(v.x); t.ac = __int_as_float(v.y); t.lm = __int_as_float(v.z); t.path = v.w;
+    return t;
+}
+__device__ __forceinline__ v4i as_v4(const Tok &t)
+{
+    v4i v;
+    v.x = __float_as_int(t.score); v.y = __float_as_int(t.ac); v.z = __float_as_int(t.lm); v.w = t.path;
+    return v;
+}
 __device__ __forceinline__ Tok null_tok() { Tok t; t.score = LZ; t.ac = LZ; t.lm = LZ; t.path = -1; return t; }
 __device__ __forceinline__ int wave_sum(int v)
 {
@@ -397,7 +407,8 @@ __device__ __forceinline__ void packed_counts(const ListSrc (&src)[N], int (&c)[
     for (int k = 0; k < N; ++k) c[k] = (tid < src[k].nw) ? CL(src[k].tot + tid) : 0;
 }
 template <int N>
-__device__ __forceinline__ void build_packed(SearchShared &sh, const ListSrc (&src)[N], int (&c)[N], int slot0, int (&Q)[N], int (&items)[N], int (&ns)[N])
+__device__ __forceinline__ void build_packed(SearchShared &sh, const ListSrc (&src)[N], int (&c)[N], int slot0, int (&Q)[N],
+                                             int (&items)[N], int (&ns)[N])
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int x[N], y[N];
@@ -766,7 +777,10 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
             const float4 *lt = (const float4 *)(sh.trP + tm * LRW);
             float tw[LRW];
 #pragma unroll
-            for (int q = 0; q < LRW / 4; ++q) { const float4 v = lt[q]; tw[4 * q] = v.x; tw[4 * q + 1] = v.y; tw[4 * q + 2] = v.z; tw[4 * q + 3] = v.w; }
+            for (int q = 0; q < LRW / 4; ++q) {
+                const float4 v = lt[q];
+                tw[4 * q] = v.x; tw[4 * q + 1] = v.y; tw[4 * q + 2] = v.z; tw[4 * q + 3] = v.w;
+            }
 #pragma unroll
             for (int j = 1; j <= NE; ++j) {                            // :387-424 emitting state j: predecessors j-1 and j
                 nw[j] = null_tok();
@@ -1150,7 +1164,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             for (unsigned long long bs = __ballot(n_slices > 0); bs; bs &= bs - 1) {
                 const int src = __ffsll((long long)bs) - 1;
                 const int ns = __shfl(n_slices, src);
-                const v4i tv = {__shfl(__float_as_int(t.score), src), __shfl(__float_as_int(t.ac), src), __shfl(__float_as_int(t.lm), src), __shfl(t.path, src)};
+                const v4i tv = {__shfl(__float_as_int(t.score), src), __shfl(__float_as_int(t.ac), src),
+                                __shfl(__float_as_int(t.lm), src), __shfl(t.path, src)};
                 const int sx = __shfl((int)eo, src), sy = __shfl(label, src), sz = __shfl(state, src);
                 for (int j0 = 0; j0 < ns; j0 += 64) {
                     const int nj = min(64, ns - j0);
@@ -1403,7 +1418,10 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const int w = find_seg(sh.pfx[kind], gk.nw, ru);
             const int ci = ru - RFL(sh.pfx[kind][w]);
             if (ci * 64 + lane < RFL(sh.cnt[kind][w])) {
-                if (kind == 0) CS(&V.live[ld16(V.rec, (p0 ? V.rec_par : 0u) + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u).x], (unsigned char)0);
+                if (kind == 0) {
+                    const unsigned roff = (p0 ? V.rec_par : 0u) + rec_chunk_off<NE>(gin.seg_rec, w, ci) + (unsigned)lane * 16u;
+                    CS(&V.live[ld16(V.rec, roff).x], (unsigned char)0);
+                }
                 else {
                     const int b = CL(V.dirtyl + (kind == 2 ? V.dirty_par : 0u) + (size_t)w * gk.seg_new + (unsigned)(ci * 64 + lane));
                     CS(&V.srec[b].e[0], 0ULL); CS(&V.srec[b].e[1], 0ULL);

@@ -1185,6 +1185,20 @@ def test_two_batches_in_flight(small):
     for i, g in enumerate(gs):
         assert bit_exact(g, (want["A"] + want["B"][:4])[i])
     decode("B", ahead=False); decode("C")
+    # small Path arenas: streams of both batches stop for collections inside the common launches, and go on
+    gs_ = capi.Decoder(gnet, gam, max_streams=12, max_paths=1 << 14, **kw)
+    gs_.prefetch_scores(buf["B"][0].data_ptr(), buf["B"][1], 0); gs_.prefetch_scores(buf["C"][0].data_ptr(), buf["C"][1], 0)
+    ahead_seen = 0
+    for n, nxt in (("A", "A"), ("B", "B"), ("C", "C"), ("A", "A"), ("B", None), ("C", None)):
+        if nxt:
+            gs_.prefetch_scores(buf[nxt][0].data_ptr(), buf[nxt][1], 0)
+        got = gs_.decode_batch_device(buf[n][0].data_ptr(), buf[n][1], 0)
+        tm = gs_.last_timing()
+        ahead_seen += 1 if tm["ahead_frames"] > 0 else 0
+        for i, g in enumerate(got):
+            assert bit_exact(g, want[n][i]), (n, i, tm)
+    assert ahead_seen >= 2
+    gs_.close()
     # switched off: same results, nothing ahead
     import os
     os.environ["JD_PIPELINE"] = "0"

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Throughput of N serial IDecoder callers (threads) on one decoder through the broker, at configs[1] (GPU box):
+python tools/broker_bench.py [callers ...]   ->  frames/s per caller count against one batch of 64"""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401
+from juicer_amd import capi, synth  # noqa: E402
+
+counts = [int(a) for a in sys.argv[1:]] or [1, 4, 16, 32, 64]
+am, net, feats, _ = synth.config_c2(n_utts=64)
+gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+frames = sum(f.shape[0] for f in feats)
+bd = capi.Decoder(gnet, gam, main_beam=150.0, max_streams=64)
+bd.decode_batch(feats)
+t0 = time.perf_counter()
+bd.decode_batch(feats)
+t_batch = time.perf_counter() - t0
+bd.close()
+print("one batch of 64 (jd_decode_batch, host features): %.0f frames/s" % (frames / t_batch))
+
+
+def drive(broker, utts, chunk):
+    c = broker.open()
+    for x in utts:
+        broker.init(c)
+        for i in range(0, x.shape[0], chunk):
+            broker.push(c, x[i:i + chunk])
+        broker.finish(c)
+    broker.close_client(c)
+
+
+for n in counts:
+    dec = capi.Decoder(gnet, gam, main_beam=150.0, max_streams=n)
+    broker = capi.Broker(dec)
+    best = None
+    for rep in range(2):
+        th = [threading.Thread(target=drive, args=(broker, feats[t::n], 64)) for t in range(n)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    st = broker.stats()
+    print("%3d callers: %8.0f frames/s = %.2f of the batch rate; %.1f streams and %.0f frames per tick"
+          % (n, frames / best, (frames / best) / (frames / t_batch), st["stream_ticks"] / max(st["ticks"], 1), st["frames"] / max(st["ticks"], 1)))
+    broker.close()
+    dec.close()
