@@ -333,7 +333,12 @@ int jd_dec_info(const jd_dec *d, int32_t *max_streams, int32_t *vec_size);
  * Environment: JD_BROKER_TICK_FRAMES (frames of one client per tick, default 192), JD_BROKER_COALESCE_US (how long a
  * tick waits for the other open clients' frames, default 300). */
 typedef struct jd_broker jd_broker;
-typedef struct jd_broker_stats { int64_t ticks, frames, stream_ticks; } jd_broker_stats;   /* launches, frames, streams summed over ticks */
+typedef struct jd_broker_stats {
+    int64_t ticks, frames, stream_ticks;           /* launches, frames, streams summed over ticks */
+    int64_t us_idle, us_coalesce;                  /* worker thread: waiting for work; waiting for the other clients' frames */
+    int64_t us_init, us_push, us_finish;           /* ... inside jd_stream_init / jd_streams_push / jd_stream_finish */
+    int64_t us_search;                             /* of us_push: the search launches (device time) */
+} jd_broker_stats;
 int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients);   /* n_clients <= the decoder's max_streams */
 void jd_broker_destroy(jd_broker *b);                                    /* (the decoder is the caller's to destroy, afterwards) */
 int jd_broker_open(jd_broker *b, int32_t *client);
@@ -354,12 +359,17 @@ int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out);
  * collection, if f - lastPartialTraceFrame > interval (:362-368) - and jd_stream_finish completes
  * the list from the best token (:245-251).  A collection runs after frame f under the reference's
  * two triggers (:362): f - lastPathCollectFrame > 100, or nPath / nPathNew > 12 with nPath > 10000.
- * The first is exact.  The second counts Path objects; the counts here are this build's own - the
- * records in its arena and the number its last collection kept - which are at most the
- * reference's (the reference also creates a Path for every token that then loses its state's
- * recombination), so the count trigger fires no earlier than the reference's.  The schedule decides
- * when a trace is taken, never what a trace at a given frame finds.
+ * The first is exact.  The second counts Path objects: the reference creates one per labelled
+ * propagateToken call (:497-509), i.e. for every exit token and every labelled epsilon / tee arc of the
+ * closure behind it, whether or not the token then wins its entry state, and keeps what the tokens of its
+ * active instances reach (:703-745).  With the end and word beams off (the CLI's default) those are static
+ * properties of the graph, and the decoder counts them without writing the losers: the collections then run
+ * after the reference's own frames (tests: equal to the oracle's frame by frame, counts included).  With
+ * an end or word beam, or a lazily composed network, the rule runs on this build's own records - at most
+ * the reference's, so it fires no earlier - an approximation.  The schedule decides when a trace is
+ * taken, never what a trace at a given frame finds.
  * jd_stream_collect_info: collections of the stream's utterance so far and lastPathCollectFrame.
+ * jd_stream_path_counts: nPath and nPathNew as the trigger reads them, *exact = 1 when they are the reference's.
  *
  * jd_stream_partial returns the stream's partialPaths - (output label, frame) of each record,
  * oldest first; *n is the full length, at most cap entries are written - after, if trace_now != 0,
@@ -369,6 +379,7 @@ int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out);
  */
 int jd_dec_set_partial_interval(jd_dec *d, int32_t interval);
 int jd_stream_collect_info(jd_dec *d, int32_t s, int32_t *n_collections, int32_t *last_collect_frame);
+int jd_stream_path_counts(jd_dec *d, int32_t s, int32_t *n_path, int32_t *n_path_new, int32_t *exact);
 int jd_stream_partial(jd_dec *d, int32_t s, int32_t trace_now, int32_t cap, int32_t *n,
                       int32_t *labels, int32_t *times, int32_t *found);
 

@@ -76,7 +76,7 @@ EXPORTS = [
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
-    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
+    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_stream_path_counts", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
     "jd_net_lazy_set_high_water", "jd_net_lazy_generation", "jd_release_cached_memory", "jd_net_push_labels",
     "jd_dec_prefetch_scores", "jd_streams_push", "jd_dec_info",
     "jd_broker_create", "jd_broker_destroy", "jd_broker_open", "jd_broker_close", "jd_broker_init", "jd_broker_push",
@@ -417,6 +417,12 @@ class Decoder:
         _check(lib().jd_stream_collect_info(self.h, C.c_int32(s), C.byref(n), C.byref(last)))
         return n.value, last.value
 
+    def stream_path_counts(self, s: int = 0):
+        """(nPath, nPathNew, exact): collectPaths' trigger counts; exact = they are the reference's (jd_stream_path_counts)."""
+        a, b, e = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _check(lib().jd_stream_path_counts(self.h, C.c_int32(s), C.byref(a), C.byref(b), C.byref(e)))
+        return a.value, b.value, bool(e.value)
+
     def stream_partial(self, s: int = 0, trace_now: bool = False):
         """(found, partialPaths as [(label, frame)], oldest first); trace_now runs tracePartialPath first."""
         n, found = C.c_int32(0), C.c_int32(0)
@@ -492,7 +498,8 @@ class Decoder:
 
 
 class BrokerStats(C.Structure):
-    _fields_ = [("ticks", C.c_int64), ("frames", C.c_int64), ("stream_ticks", C.c_int64)]
+    _fields_ = [(n, C.c_int64) for n in ("ticks", "frames", "stream_ticks", "us_idle", "us_coalesce", "us_init", "us_push", "us_finish",
+                                         "us_search")]
 
 
 class Broker:

@@ -62,6 +62,7 @@ static void broker_loop(jd_broker *b)
     std::unique_lock<std::mutex> lk(b->mu);
     std::vector<int> inits, pushers, finishers;
     std::vector<std::vector<float>> taken((size_t)b->n_clients);
+    double search_ms_seen = 0.0;                   // (jd_timing accumulates over the streaming calls)
     for (;;) {
         auto has_work = [&]() {
             if (b->stop) return true;
@@ -69,8 +70,14 @@ static void broker_loop(jd_broker *b)
                 if (c.open && (c.want_init || c.want_finish || (c.inited && !c.pending.empty()))) return true;
             return false;
         };
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto us_since = [&](std::chrono::steady_clock::time_point t) {
+            return (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(now() - t).count();
+        };
+        auto t_mark = now();
         b->cv_work.wait(lk, has_work);
         if (b->stop) return;
+        b->stats.us_idle += us_since(t_mark); t_mark = now();
         // a tick is the fuller the more clients have frames waiting: give the open ones that have nothing pending yet
         // a moment to deliver - they are all being fed at about the same rate, and one that has just been handed its
         // result is about to start its next utterance (a caller that is through closes its client)
@@ -83,6 +90,7 @@ static void broker_loop(jd_broker *b)
             };
             b->cv_work.wait_for(lk, std::chrono::microseconds(b->coalesce_us), all_ready);
             if (b->stop) return;
+            b->stats.us_coalesce += us_since(t_mark);
         }
         inits.clear(); pushers.clear(); finishers.clear();
         for (int i = 0; i < b->n_clients; ++i) {
@@ -108,10 +116,13 @@ static void broker_loop(jd_broker *b)
         long long tick_frames = 0, tick_streams = 0;
         std::vector<int> rc_of((size_t)b->n_clients, JD_OK);
         std::vector<std::string> msg_of((size_t)b->n_clients);
+        int64_t us_init = 0, us_push = 0, us_finish = 0, us_search = 0;
+        t_mark = now();
         for (int i : inits) {
             rc_of[(size_t)i] = jd_stream_init(b->dec, i);
             if (rc_of[(size_t)i]) msg_of[(size_t)i] = jd_last_error();
         }
+        us_init = us_since(t_mark); t_mark = now();
         if (!pushers.empty()) {
             std::vector<int32_t> ss, nn;
             std::vector<const float *> ff;
@@ -127,14 +138,37 @@ static void broker_loop(jd_broker *b)
                 for (int i : pushers) if (rc_of[(size_t)i] == JD_OK) { rc_of[(size_t)i] = rc; msg_of[(size_t)i] = m; }
             }
             tick_frames = fr; tick_streams = (long long)ss.size();
+            jd_timing tm;
+            if (!ss.empty() && jd_dec_last_timing(b->dec, &tm) == JD_OK) { us_search = (int64_t)((tm.search_ms - search_ms_seen) * 1e3); search_ms_seen = tm.search_ms; }
         }
+        us_push = us_since(t_mark); t_mark = now();
         std::vector<jd_hyp> res((size_t)b->n_clients);
-        for (int i : finishers) {
-            memset(&res[(size_t)i], 0, sizeof(jd_hyp));
-            const int rc = jd_stream_finish(b->dec, i, &res[(size_t)i]);
-            if (rc && rc_of[(size_t)i] == JD_OK) { rc_of[(size_t)i] = rc; msg_of[(size_t)i] = jd_last_error(); }
+        auto serve_finishes = [&](const std::vector<int> &who) {
+            for (int i : who) {
+                memset(&res[(size_t)i], 0, sizeof(jd_hyp));
+                const int rc = jd_stream_finish(b->dec, i, &res[(size_t)i]);
+                if (rc && rc_of[(size_t)i] == JD_OK) { rc_of[(size_t)i] = rc; msg_of[(size_t)i] = jd_last_error(); }
+            }
+        };
+        serve_finishes(finishers);
+        {   // a caller whose last frames went with this tick and who asked for its result while the search ran is served
+            // now - not at the end of the next tick, which it would sit out
+            std::vector<int> late;
+            lk.lock();
+            for (int i = 0; i < b->n_clients; ++i) {
+                const Client &c = b->clients[(size_t)i];
+                if (c.open && c.want_finish && c.pending.empty() && !c.want_init && c.inited && rc_of[(size_t)i] == JD_OK &&
+                    std::find(finishers.begin(), finishers.end(), i) == finishers.end())
+                    late.push_back(i);
+            }
+            lk.unlock();
+            serve_finishes(late);
+            finishers.insert(finishers.end(), late.begin(), late.end());
         }
+        us_finish = us_since(t_mark);
         lk.lock();
+        b->stats.us_init += us_init; b->stats.us_push += us_push; b->stats.us_finish += us_finish;
+        b->stats.us_search += us_search;
         if (tick_streams) { b->stats.ticks += 1; b->stats.frames += tick_frames; b->stats.stream_ticks += tick_streams; }
         for (int i = 0; i < b->n_clients; ++i) {
             Client &c = b->clients[(size_t)i];

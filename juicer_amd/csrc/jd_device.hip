@@ -356,6 +356,7 @@ struct jd_dec {
     int *d_row_ptr = nullptr; JdArc *d_arcs = nullptr; float *d_fin_w = nullptr; int *d_aux = nullptr;
     int *d_se32 = nullptr;
     float *d_hmm_tee = nullptr, *d_trP = nullptr, *d_hmm_tmax0 = nullptr, *d_lrt = nullptr;
+    int *d_pcount = nullptr;               // per state: Path objects of the reference per arriving token (DecConst::pcount)
     // per-stream state
     StreamDev *d_streams = nullptr;
     StreamCtl *d_ctl = nullptr;
@@ -430,6 +431,7 @@ struct jd_dec {
     int *d_partial_out = nullptr;
     bool return_on_collect = false, collected_now = false;   // jd_stream_push: launch_search comes back after a collection by the count rule
     float *d_push = nullptr; size_t push_cap = 0;
+    char *h_stage = nullptr; size_t stage_cap = 0;     // pinned staging of jd_streams_push
     // results
     std::vector<HostResult> results;
     jd_timing timing{};
@@ -484,6 +486,7 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     d->pf_q.clear();
     if (d->h_resident) (void)hipHostFree(d->h_resident);
     if (d->d_push) (void)hipFree(d->d_push);
+    if (d->h_stage) (void)hipHostFree(d->h_stage);
     if (d->d_work) (void)hipFree(d->d_work);
     if (d->h_status) (void)hipHostFree(d->h_status);
     if (d->s_gmm) (void)hipStreamDestroy(d->s_gmm);
@@ -519,7 +522,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     C.max_hyps = max_hyps;
     C.x_chunks = 2;
     if (const char *e = getenv("JD_XCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) C.x_chunks = v; }   // development
-    C.exp = 0;
+    C.exp = 0; C.path_rule = 0; C.pcount = nullptr;
     if (const char *e = getenv("JD_EXP")) C.exp = atoi(e);                                                    // development
     C.hist_min = 0; C.hist_max = 0; C.hist_nbins = 0;
     if (max_hyps > 0) {                          // WFSTDecoderLite.cpp:76-82, Histogram.cpp:29-37
@@ -2154,8 +2157,12 @@ extern "C" int jd_stream_push(jd_dec *d, int32_t s, const float *frames, int32_t
             HIPCHK(hipMemcpy(&hc, d->d_ctl + s, sizeof hc, hipMemcpyDeviceToHost));
             if (hc.error != 0) { d->stream_T[(size_t)s] = Tnew; d->stream_dirty[(size_t)s] = 1; break; }   // (reported by jd_stream_finish)
             const int at = hc.frame - 1;                               // the last frame processed
-            bool collected = d->collected_now;
-            if (!collected && hc.frame >= Tnew && (at - d->last_collect[(size_t)s] > 100 || path_rule_fires(hc.n_paths, hc.path_new))) {
+            // (with the reference's counts a collection that only the arena asked for is none of the reference's: it neither
+            // counts nor carries a trace, and the launch goes on behind it)
+            const bool ref = d->C.pcount != nullptr;
+            bool collected = ref ? hc.n_collect > d->n_collect_host[(size_t)s] : d->collected_now;
+            if (!collected && hc.frame >= Tnew && (at - d->last_collect[(size_t)s] > 100 ||
+                                                   path_rule_fires(ref ? hc.n_paths_ref : hc.n_paths, ref ? hc.path_new_ref : hc.path_new))) {
                 // the rule fires behind the chunk's last frame (the kernel looks before a frame, not after the last one)
                 DecConst Cg = d->C;
                 Cg.gc_threshold = -1;                                  // (every started stream collects)
@@ -2215,37 +2222,47 @@ extern "C" int jd_streams_push(jd_dec *d, int32_t n, const int32_t *streams, con
         HIPCHK(hipMalloc(&d->d_push, tile_rows * D * sizeof(float)));
         d->push_cap = tile_rows * D;
     }
-    // rows: stream after stream, packed; row_src is the identity (the frames are packed the same way)
-    std::vector<int> src(tile_rows, -1), Tnew((size_t)n);
+    // rows: stream after stream, packed; row_src is the identity (the frames are packed the same way).  Everything the
+    // launch needs from the host - frames, row table, frames available per stream - goes through ONE pinned staging
+    // buffer: a tick of the broker is sixteen callers' frames, and sixteen copies from pageable memory were a tenth of it.
+    const size_t need = (size_t)rows * D * sizeof(float) + tile_rows * sizeof(int) + (size_t)d->max_streams * sizeof(int);
+    if (need > d->stage_cap) {
+        if (d->h_stage) (void)hipHostFree(d->h_stage);
+        d->h_stage = nullptr; d->stage_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&d->h_stage, need + need / 2));
+        d->stage_cap = need + need / 2;
+    }
+    float *h_frames = (float *)d->h_stage;
+    int *h_src = (int *)(d->h_stage + (size_t)rows * D * sizeof(float));
+    int *h_T = h_src + tile_rows;
+    std::vector<int> Tnew((size_t)n);
     std::vector<int2> work;
     std::vector<double> weight;
     size_t r0 = 0;
     int f_end = 0;
+    for (int s = 0; s < d->max_streams; ++s) h_T[s] = d->stream_T[(size_t)s];     // (the other streams keep theirs)
     for (int i = 0; i < n; ++i) {
         if (n_frames[i] == 0) continue;
         const int s = streams[i];
-        HIPCHK(hipMemcpyAsync(d->d_push + r0 * D, frames[i], (size_t)n_frames[i] * D * sizeof(float), hipMemcpyHostToDevice, st));
-        for (int k = 0; k < n_frames[i]; ++k) src[r0 + (size_t)k] = (int)(r0 + (size_t)k);
+        memcpy(h_frames + r0 * D, frames[i], (size_t)n_frames[i] * D * sizeof(float));
         Tnew[(size_t)i] = d->stream_T[(size_t)s] + n_frames[i];
+        h_T[s] = Tnew[(size_t)i];
         // (k_search reads row  slot + (f - f0)  with f0 = 0: the slot is the stream's first row minus its first frame)
         work.push_back(make_int2(s, (int)((long long)r0 - d->stream_T[(size_t)s])));
         weight.push_back((double)n_frames[i]);
         f_end = std::max(f_end, Tnew[(size_t)i]);
         r0 += (size_t)n_frames[i];
     }
-    {   // frames available, for every stream of the decoder in one go (the others keep theirs)
-        std::vector<int> Tall(d->stream_T.begin(), d->stream_T.end());
-        for (int i = 0; i < n; ++i) if (n_frames[i] > 0) Tall[(size_t)streams[i]] = Tnew[(size_t)i];
-        HIPCHK(hipMemcpyAsync(d->d_T, Tall.data(), Tall.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));                              // (Tall and src are locals)
-        hipLaunchKernelGGL(jd_set_T_kernel, dim3((d->max_streams + 63) / 64), dim3(64), 0, st, d->d_ctl, 0, d->max_streams, d->d_T);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipMemcpyAsync(d->d_row_src[0], src.data(), tile_rows * sizeof(int), hipMemcpyHostToDevice, st));
+    for (size_t r = 0; r < tile_rows; ++r) h_src[r] = r < (size_t)rows ? (int)r : -1;
+    HIPCHK(hipMemcpyAsync(d->d_push, h_frames, (size_t)rows * D * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->d_row_src[0], h_src, tile_rows * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->d_T, h_T, (size_t)d->max_streams * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(jd_set_T_kernel, dim3((d->max_streams + 63) / 64), dim3(64), 0, st, d->d_ctl, 0, d->max_streams, d->d_T);
+    HIPCHK(hipGetLastError());
     rc = launch_gmm(d->am, d->amb, d->d_push, d->d_row_src[0], (int)rows, d->d_ll[0], st);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }             // (the staging buffer is the next call's too)
     rc = launch_search(d, work, d->d_ll[0], (long long)G, 0, f_end, st, &weight);
-    if (rc) { for (const int2 &w : work) d->stream_dirty[(size_t)w.x] = 1; return rc; }
+    if (rc) { (void)hipStreamSynchronize(st); for (const int2 &w : work) d->stream_dirty[(size_t)w.x] = 1; return rc; }
     for (int i = 0; i < n; ++i) if (n_frames[i] > 0) d->stream_T[(size_t)streams[i]] = Tnew[(size_t)i];
     return JD_OK;
 }
@@ -2262,11 +2279,86 @@ extern "C" int jd_stream_collect_info(jd_dec *d, int32_t s, int32_t *n_collectio
 
 // setPartialDecodeOptions (WFSTDecoderLite.cpp:892-896; the reference reads PartialTraceInterval
 // from the environment, :116-119)
+// The Path objects WFSTDecoderLite::propagateToken creates behind ONE token that arrives at state q (:497-509 inside
+// the recursion of :533-541 and :583-599): one per labelled epsilon arc and per labelled arc of a tee model that leaves
+// q, plus what arrives behind each of those arcs - with multiplicity, the recursion does not recombine.  Static as
+// long as nothing prunes inside the closure, i.e. with the end and word beams off (the thresholds of :538, :591-596 are
+// LOG_ZERO then).  Saturates at 2^20 (the rule's own mark is 10000).  false: the label-less part of the graph has a
+// cycle (the reference would not come back from it).
+static bool closure_path_counts(const jd_net *net, const jd_am *am, std::vector<int> &P)
+{
+    const int nS = net->n_states;
+    P.assign((size_t)nS, -1);
+    std::vector<char> open((size_t)nS, 0);
+    std::vector<std::pair<int, int>> stack;                           // (state, next arc)
+    auto passes = [&](const JdArc &a) { return a.in == 0 || am->hmm_tee[(size_t)a.in - 1] > LZ; };
+    for (int q0 = 0; q0 < nS; ++q0) {
+        if (P[(size_t)q0] >= 0) continue;
+        stack.assign(1, std::make_pair(q0, net->row_ptr[(size_t)q0]));
+        open[(size_t)q0] = 1;
+        while (!stack.empty()) {
+            const int q = stack.back().first;
+            int &a = stack.back().second;
+            bool descended = false;
+            for (; a < net->row_ptr[(size_t)q + 1]; ++a) {
+                const JdArc &arc = net->arcs[(size_t)a];
+                if (!passes(arc) || P[(size_t)arc.to] >= 0) continue;
+                if (open[(size_t)arc.to]) return false;
+                open[(size_t)arc.to] = 1;
+                stack.push_back(std::make_pair(arc.to, net->row_ptr[(size_t)arc.to]));
+                descended = true;
+                break;
+            }
+            if (descended) continue;
+            long long sum = 0;
+            for (int b = net->row_ptr[(size_t)q]; b < net->row_ptr[(size_t)q + 1]; ++b) {
+                const JdArc &arc = net->arcs[(size_t)b];
+                if (passes(arc)) sum += (arc.out != 0 ? 1 : 0) + P[(size_t)arc.to];
+            }
+            P[(size_t)q] = (int)std::min<long long>(sum, 1 << 20);
+            open[(size_t)q] = 0;
+            stack.pop_back();
+        }
+    }
+    return true;
+}
+
 extern "C" int jd_dec_set_partial_interval(jd_dec *d, int32_t interval)
 {
     if (!d || interval < 0) return jd_fail(JD_EINVAL, "jd_dec_set_partial_interval: traceInterval >= 0");
     d->partial_interval = interval;
     d->C.path_rule = interval > 0 ? 1 : 0;             // (the kernel then watches collectPaths' count rule as well)
+    d->C.pcount = nullptr;
+    if (interval > 0 && !d->net->lazy_dev && d->C.end_win <= 0.0f && d->C.word_win <= 0.0f) {
+        // ... on the reference's own counts where they are a static property of the graph
+        if (!d->d_pcount) {
+            int rc = check_device(d->device);
+            if (rc) return rc;
+            std::vector<int> P;
+            if (closure_path_counts(d->net, d->am, P)) {
+                rc = dupload(d, &d->d_pcount, P.data(), P.size());
+                if (rc) return rc;
+            }
+        }
+        d->C.pcount = d->d_pcount;
+    }
+    return JD_OK;
+}
+
+// nPath and nPathNew of stream s as collectPaths' trigger reads them (WFSTDecoderLite.cpp:360): the reference's counts
+// where this decoder keeps them (*exact = 1), else the records in this build's arena and what its last collection kept
+extern "C" int jd_stream_path_counts(jd_dec *d, int32_t s, int32_t *n_path, int32_t *n_path_new, int32_t *exact)
+{
+    if (!d || s < 0 || s >= d->max_streams) return jd_fail(JD_EINVAL, "jd_stream_path_counts: bad argument");
+    if (!d->stream_started[(size_t)s]) return jd_fail(JD_ESTATE, "jd_stream_path_counts before jd_stream_init");
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    StreamCtl hc;
+    HIPCHK(hipMemcpy(&hc, d->d_ctl + s, sizeof hc, hipMemcpyDeviceToHost));
+    const bool ref = d->C.pcount != nullptr;
+    if (n_path) *n_path = ref ? hc.n_paths_ref : hc.n_paths;
+    if (n_path_new) *n_path_new = ref ? hc.path_new_ref : hc.path_new;
+    if (exact) *exact = ref ? 1 : 0;
     return JD_OK;
 }
 

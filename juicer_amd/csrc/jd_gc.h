@@ -7,13 +7,17 @@
 // Path garbage collection = collectPaths (WFSTDecoderLite.cpp:699-747) as a mark-compact: records
 // reachable from a live token, from a frontier item of the last processed frame (the pending
 // entry-token candidates point at those) or from bestFinalToken are kept, everything else is
-// dropped.  No effect on results.  Run between launches for the streams that stopped for it, G
+// dropped.  No effect on results.  What the REFERENCE keeps is a subset of that - the records the tokens of its
+// active instances reach (:703-719): the emitting tokens of the instance records and the entry token of every
+// state that received a token in the last frame and has an arc with a model; not the exit tokens (nulled, :964), not
+// bestFinalToken.  Those roots mark with bit 1 as well, and their count is the reference's nPathNew (path_new_ref)
+// while everything marked is kept.  Run between launches for the streams that stopped for it, G
 // 1024-thread workgroups per stream; the steps are separate kernels (a kernel boundary is the
 // barrier between them): begin (decide, clear the marks) - mark - sum (marks per workgroup range) -
 // scan (new indices) - compact (into the second arena, predecessors remapped) - remap (tokens, items,
 // bestFinalToken; swap the arenas).
 #define GC_MAXG 32
-struct GcState { int active, kept; int part[GC_MAXG]; };
+struct GcState { int active, kept, kept_ref, by_rule; int part[GC_MAXG], part_ref[GC_MAXG]; };
 
 struct GcCtx {
     int s, blk, G, np, nw, p;
@@ -44,10 +48,12 @@ __global__ __launch_bounds__(1024) void k_gc_begin(DecConst C, StreamCtl *ctl, S
     gc_ctx(C, ctl, work, s_single, G, x);
     const StreamCtl &c = ctl[x.s];
     StreamDev &S = streams[x.s];
-    const bool active = c.started && !c.needs_init && c.error == 0 && x.nw > 0 &&
-                        (x.np > C.gc_threshold || (C.path_rule && path_rule_fires(x.np, c.path_new)));
+    // (gc_threshold < 0: the host asks for this collection - the frame rule, or a count rule that fires behind a chunk's
+    // last frame; only the collections the reference runs too count as such and restart its counts)
+    const bool rule = C.path_rule && (C.gc_threshold < 0 || path_rule_fires(C.pcount ? c.n_paths_ref : x.np, C.pcount ? c.path_new_ref : c.path_new));
+    const bool active = c.started && !c.needs_init && c.error == 0 && x.nw > 0 && (x.np > C.gc_threshold || rule);
     GcState *gs = (GcState *)S.gc_state;
-    if (x.blk == 0 && threadIdx.x == 0) { gs->active = active ? 1 : 0; gs->kept = 0; }
+    if (x.blk == 0 && threadIdx.x == 0) { gs->active = active ? 1 : 0; gs->kept = 0; gs->kept_ref = 0; gs->by_rule = rule ? 1 : 0; }
     if (!active) return;
     int lo, hi;
     gc_range(x, lo, hi);
@@ -67,7 +73,10 @@ __global__ __launch_bounds__(1024) void k_gc_mark(DecConst C, StreamCtl *ctl, St
     if (!((const GcState *)S.gc_state)->active) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int *idx = S.gc_idx;
-    auto mark = [&](int q) { while (q >= 0 && atomicExch(&idx[q], 1) == 0) q = S.paths[q].prev; };
+    // bit 0: kept; bit 1: the reference keeps it too.  (A walk goes on as long as it adds a bit: one that sets both passes
+    // records that an "extra" walk marked before it.)
+    auto mark = [&](int q) { while (q >= 0 && (atomicOr(&idx[q], 1) & 1) == 0) q = S.paths[q].prev; };
+    auto mark_ref = [&](int q) { while (q >= 0 && (atomicOr(&idx[q], 3) & 2) == 0) q = S.paths[q].prev; };
     // tokens of the instance records (structure-of-arrays chunks of 64) ...
     for (int w = x.blk * 16 + wid; w < x.nw; w += G * 16) {
         const char *seg = (const char *)S.rec + (size_t)x.p * C.cap_slots * RL::REC_BYTES + (size_t)w * (x.g.seg_rec >> 6) * RL::CHUNK_BYTES;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_gc_mark(DecConst C, StreamCtl *ctl, St
             const int n = ((const int4 *)r)->y & 0xff;
             if (j < n - 1) {
                 const int4 t = *(const int4 *)(r + (size_t)(RL::HF + j - 1) * 1024);
-                if (__int_as_float(t.x) > LZ) mark(t.w);
+                if (__int_as_float(t.x) > LZ) mark_ref(t.w);
             }
         }
         // ... and of the last frame's frontier items
@@ -86,6 +95,25 @@ __global__ __launch_bounds__(1024) void k_gc_mark(DecConst C, StreamCtl *ctl, St
         for (int k = lane; k < n_it; k += 64) mark(S.items[2 * ((size_t)(x.p ^ 1) * C.cap_items + (size_t)w * x.g.seg_item + k)].w);
     }
     if (x.blk == 0 && tid == 0) mark(ctl[x.s].best_final.path);
+    if (C.pcount != nullptr) {
+        // the entry tokens of the reference's instances: every arc with a model that leaves a state of the last frame's
+        // dirty list holds the best token that arrived there (one Path for all of them)
+        const StreamCtl &c = ctl[x.s];
+        const int dn = c.dirty_nw[x.p ^ 1];
+        const Geo gd = make_geo(C, dn > 0 ? dn : x.nw);
+        const int *dl = S.dirtyl + (size_t)(x.p ^ 1) * C.cap_new;
+        for (int w = x.blk * 16 + wid; w < gd.nw; w += G * 16) {
+            const int n_d = min(S.tot[(size_t)(TOT_DIRTY0 + (x.p ^ 1)) * MAXW + w], (int)gd.seg_new);
+            for (int q = lane; q < n_d; q += 64) {
+                const int st = dl[(size_t)w * gd.seg_new + q];
+                const unsigned long long kv = S.srec[st].e[x.p ^ 1];
+                if (kv == 0ULL) continue;
+                bool has_model = false;
+                for (int a = C.row_ptr[st]; a < C.row_ptr[st + 1] && !has_model; ++a) has_model = (C.arcs[a].in & ~TEE_FLAG) != 0;
+                if (has_model) mark_ref(S.items[2 * ((size_t)(x.p ^ 1) * C.cap_items + (size_t)(kv & 0xffffffffULL))].w);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_gc_sum(DecConst C, StreamCtl *ctl, StreamDev *streams, const int4 *work, int s_single, int G)
@@ -95,19 +123,23 @@ __global__ __launch_bounds__(1024) void k_gc_sum(DecConst C, StreamCtl *ctl, Str
     StreamDev &S = streams[x.s];
     GcState *gs = (GcState *)S.gc_state;
     if (!gs->active) return;
-    __shared__ int sh_sum;
-    if (threadIdx.x == 0) sh_sum = 0;
+    __shared__ int sh_sum, sh_ref;
+    if (threadIdx.x == 0) { sh_sum = 0; sh_ref = 0; }
     __syncthreads();
-    int lo, hi, mine = 0;
+    int lo, hi, mine = 0, ref = 0;
     gc_range(x, lo, hi);
     const int hi4 = lo + ((hi - lo) & ~3);
-    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) { const int4 m = *(const int4 *)(S.gc_idx + q); mine += m.x + m.y + m.z + m.w; }
-    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) mine += S.gc_idx[q];
+    for (int q = lo + 4 * (int)threadIdx.x; q < hi4; q += 4 * (int)blockDim.x) {
+        const int4 m = *(const int4 *)(S.gc_idx + q);
+        mine += (m.x & 1) + (m.y & 1) + (m.z & 1) + (m.w & 1);
+        ref += (m.x >> 1) + (m.y >> 1) + (m.z >> 1) + (m.w >> 1);
+    }
+    for (int q = hi4 + threadIdx.x; q < hi; q += blockDim.x) { const int m = S.gc_idx[q]; mine += m & 1; ref += m >> 1; }
 #pragma unroll
-    for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&sh_sum, mine);
+    for (int o = 32; o; o >>= 1) { mine += __shfl_xor(mine, o); ref += __shfl_xor(ref, o); }
+    if ((threadIdx.x & 63) == 0 && mine) { atomicAdd(&sh_sum, mine); atomicAdd(&sh_ref, ref); }
     __syncthreads();
-    if (threadIdx.x == 0) gs->part[x.blk] = sh_sum;
+    if (threadIdx.x == 0) { gs->part[x.blk] = sh_sum; gs->part_ref[x.blk] = sh_ref; }
 }
 
 // exclusive scan of the marks -> new indices (idx[q] = new index, -1 if dropped)
@@ -123,10 +155,10 @@ __global__ __launch_bounds__(1024) void k_gc_scan(DecConst C, StreamCtl *ctl, St
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int *idx = S.gc_idx;
     if (tid == 0) {
-        int base = 0, all = 0;
-        for (int b = 0; b < G; ++b) { if (b < x.blk) base += gs->part[b]; all += gs->part[b]; }
+        int base = 0, all = 0, ref = 0;
+        for (int b = 0; b < G; ++b) { if (b < x.blk) base += gs->part[b]; all += gs->part[b]; ref += gs->part_ref[b]; }
         sh_carry = base;
-        if (x.blk == 0) gs->kept = all;
+        if (x.blk == 0) { gs->kept = all; gs->kept_ref = ref; }
     }
     __syncthreads();
     int lo, hi;
@@ -137,6 +169,7 @@ __global__ __launch_bounds__(1024) void k_gc_scan(DecConst C, StreamCtl *ctl, St
         int4 m = make_int4(0, 0, 0, 0);
         if (q + 3 < hi) m = *(const int4 *)(idx + q);
         else { if (q < hi) m.x = idx[q]; if (q + 1 < hi) m.y = idx[q + 1]; if (q + 2 < hi) m.z = idx[q + 2]; }
+        m.x &= 1; m.y &= 1; m.z &= 1; m.w &= 1;                        // (bit 1: the reference's survivors, counted by k_gc_sum)
         const int mine = m.x + m.y + m.z + m.w;
         int v = mine;
 #pragma unroll
@@ -228,7 +261,11 @@ __global__ __launch_bounds__(1024) void k_gc_remap(DecConst C, StreamCtl *ctl, S
         if (c.best_final.path >= 0) c.best_final.path = idx[c.best_final.path];
         PathRec *tmp = S.paths; S.paths = S.paths2; S.paths2 = tmp;
         c.n_paths = gs->kept;
-        c.path_new = gs->kept; c.n_collect += 1;      // nPathNew = nPath (:745)
+        c.path_new = gs->kept;                        // nPathNew = nPath (:745)
+        if (C.pcount == nullptr) c.n_collect += 1;
+        else if (gs->by_rule) {                       // a collection of the reference's: its counts start again from its survivors
+            c.n_paths_ref = gs->kept_ref; c.path_new_ref = gs->kept_ref; c.n_collect += 1;
+        }
     }
 }
 

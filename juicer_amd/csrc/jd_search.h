@@ -75,6 +75,9 @@ struct DecConst {
     int x_chunks;       // phase X: chunks per wave the item lists are cut into (dynamic hand-out balances the arc walks)
     int exp;            // development experiments (JD_EXP)
     int path_rule;      // PARTIAL_DECODING is on: a stream also stops for a collection by the reference's count rule (path_rule_fires)
+    const int *pcount;  // ... on the REFERENCE's Path counts: per state, the Path objects the reference creates for one token that
+                        // arrives there (the labelled epsilon / tee arcs of its closure, with multiplicity; jd_dec_set_partial_interval).
+                        // null: the rule runs on this build's own records (end / word beams on, lazily composed network)
 };
 
 // An active arc instance (NetInst, WFSTDecoderLite.h:66-75) is a record of 16-byte fields: header
@@ -125,14 +128,16 @@ struct __align__(128) StreamCtl {
     float best_emit;    // bestEmitScore left by the last processed frame (:321)
     int dirty_nw[2];    // number of wave segments the dirty list of each frame parity was written with (it lives two frames)
     int path_new;       // Path records the last collection kept (nPathNew, WFSTDecoderLite.cpp:745; 0: none yet in this utterance)
-    int n_collect;      // collections in this utterance
-    int pad0[20];
+    int n_collect;      // collections in this utterance (DecConst::pcount: those the reference runs too - its two triggers)
+    int path_new_ref;   // DecConst::pcount: Path objects the reference's last collection kept (nPathNew, :745)
+    int pad0[19];
     __align__(128) int new_all[2];           // arcs entered without an instance in a frame of that parity (listed or not)
     __align__(128) unsigned bar;             // cluster barrier (zeroed by the host before every launch)
     __align__(128) unsigned xbar, xmask;     // placement handshake of an XCD-local launch (agent scope; zeroed with bar)
     __align__(128) unsigned bestA[2];        // ordered-uint best emitting score of phase A, by frame parity
     __align__(128) unsigned bestX[2];        // ... best entry-token candidate of phase X
     __align__(128) int n_paths;              // Path records in use
+    int n_paths_ref;                         // (same line) DecConst::pcount: Path objects the reference holds (nPath, :613 / :626)
     __align__(128) unsigned long long final_key;
     __align__(128) int err[2];               // first error raised during a frame of that parity
     int stop_req;                            // (same line) the cluster is to stop after this frame: the launch is being re-planned
@@ -497,8 +502,9 @@ __device__ __forceinline__ int grab_chunk(SearchShared &sh, int jw, int Cw)
 
 // collectPaths' count trigger (WFSTDecoderLite.cpp:360-362): nPath / nPathNew > 12 and nPath > 10000, with the IEEE float
 // division of the reference (nPathNew = 0 before the first collection: the ratio is +inf).  The counts are this
-// build's own: its Path records in use and the number its last collection kept - at most the reference's, which
-// also creates records for tokens that lose their state's recombination.
+// reference's where DecConst::pcount is there (n_paths_ref / path_new_ref: a Path per labelled propagateToken call, winner
+// or not, and what collectPaths keeps), else this build's own records - at most the reference's, which also creates
+// records for tokens that lose their state's recombination.
 __device__ __host__ __forceinline__ bool path_rule_fires(int n_path, int n_path_new)
 {
     return n_path > 10000 && (float)n_path / (float)n_path_new > 12.0f;
@@ -981,6 +987,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
     int2 *qrow = sh.qrow[wid];
     int q_n = 0;                                                       // closure items waiting in this wave's queue
     int c_arcs = 0, c_paths = 0, c_pend = 0, c_new = 0;
+    int c_ref = 0;                                                     // Path objects the reference creates for this wave's exit tokens
     unsigned mo = 0u;
     // states whose arrival key became non-zero: zeroed by the phase A of the frame after the next one
     auto list_dirty = [&](bool first, int state) __attribute__((always_inline)) {
@@ -1043,6 +1050,11 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             have = t.score > ((info.y != 0) ? wordTh : endTh);
             if (have) ++c_pend;
         }
+        // the reference's own Path count (collectPaths' trigger, :360-362): propagateToken makes one for the arc's label
+        // and one for every labelled epsilon / tee arc of the closure behind it, for EVERY token it is called with -
+        // recombination happens at the entry states only (:560) - where this build expands a state's best arrival alone
+        if (C.pcount != nullptr && ((real && exit_kind && have) || start_tok))
+            c_ref += (start_tok ? 0 : (info.y != 0 ? 1 : 0)) + C.pcount[state];
         // Path records (:497-509) are reserved for every labelled item that passed its threshold, winner or not, so that
         // the reservation is in flight together with the loads below: it is issued BEHIND them (the compiler waits
         // for a returning atomic where it stands, and that wait then is the wait for the loads as well)
@@ -1299,6 +1311,10 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
     }
     mo = wave_umax(mo);
     c_arcs = wave_sum(c_arcs); c_paths = wave_sum(c_paths); c_pend = wave_sum(c_pend); c_new = wave_sum(c_new);
+    if (C.pcount != nullptr) {
+        c_ref = wave_sum(c_ref);
+        if (lane == 0 && c_ref) (void)GADD(&c.n_paths_ref, c_ref);
+    }
     if (lane == 0) {
         if (mo) atomicMax(&sh.best, mo);
         if (c_arcs) atomicAdd(&sh.stat[ST_ARCS], c_arcs);
@@ -1330,7 +1346,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     if (!needs_init && f >= f_stop) return;
     float best_emit = __int_as_float(RFL(__float_as_int(c.best_emit)));
     const int old_nw = RFL(c.lst_nw);
-    const int path_new = needs_init ? 0 : RFL(c.path_new);
+    const bool ref_rule = C.pcount != nullptr;                          // collectPaths' count rule on the reference's counts
+    const int path_new = needs_init ? 0 : RFL(ref_rule ? c.path_new_ref : c.path_new);
     Geo gin = make_geo(C, old_nw > 0 ? old_nw : NW);
     const Geo gout = make_geo(C, NW);
     // geometry of the two dirty lists (each lives two frames, so it may come from the launch before the previous one)
@@ -1432,8 +1449,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         if (jw == 0 && tid == 0) {
             CS(&c.bestA[0], 0u); CS(&c.bestA[1], 0u); CS(&c.bestX[0], 0u); CS(&c.bestX[1], 0u);
             CS(&c.new_all[0], 0); CS(&c.new_all[1], 0);
-            CS(&c.n_paths, 0); CS(&c.final_key, 0ULL); CS(&c.err[0], 0); CS(&c.err[1], 0);
-            c.path_new = 0; c.n_collect = 0;
+            CS(&c.n_paths, 0); CS(&c.n_paths_ref, 0); CS(&c.final_key, 0ULL); CS(&c.err[0], 0); CS(&c.err[1], 0);
+            c.path_new = 0; c.path_new_ref = 0; c.n_collect = 0;
             for (int k = 0; k < ST_N; ++k) CS(&c.st[k], 0LL);
             c.best_final = null_tok();
             // the start token (:221-226) is the only item of round 0, in wave 0's segment (parity 1)
@@ -1462,6 +1479,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     int pre_cnt[3] = {0, 0, 0}, pre_new = 0;                           // next frame's list counts, requested one frame ahead (below)
     bool pre_ok = false;
     int np_seen = 0;                                                   // Path records in use, as of the last frame end
+    int npr_seen = 0;                                                  // ... and the reference's count of them (ref_rule)
     int stop_seen = 0;                                                 // the host wants to re-plan the launch (SearchArgs::rebalance_at): 1;
                                                                        // the batch this stream runs ahead of is through: 2
     while (!aborted && !failed) {
@@ -1470,7 +1488,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         const int p = init ? 1 : (f & 1);
         // stop early when the Path arena needs collecting (k_gc_* run between launches); n_paths only
         // changes in phase X, so every workgroup of the cluster reads the same value here
-        if (!init && frames_done > 0 && (np_seen > C.gc_threshold || stop_seen || (C.path_rule && path_rule_fires(np_seen, path_new)))) break;
+        if (!init && frames_done > 0 && (np_seen > C.gc_threshold || stop_seen || (C.path_rule && path_rule_fires(ref_rule ? npr_seen : np_seen, path_new)))) break;
         long long t0 = 0;
         const bool clk_on = A.dbg != nullptr && tid == 0;
 #define CLK(slot) do { if (clk_on) { const long long tn_ = wall_clock64(); sh.clk[slot] += tn_ - t0; t0 = tn_; } } while (0)
@@ -1539,7 +1557,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         // round trip, not one each.)
         float bestA = LZ, endTh = LZ, wordTh = LZ;
         unsigned bx_raw = 0u;
-        int err_raw = 0, np_raw = 0, stop_raw = 0;
+        int err_raw = 0, np_raw = 0, npr_raw = 0, stop_raw = 0;
         const bool last_frame = !init && f >= T - 1;
         XOut xo = {exit_cnt, 0, 0};
         for (int round = 0;; ++round) {
@@ -1572,6 +1590,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 wordTh = (!init && C.word_win > 0.0f) ? (bestA - C.word_win) : LZ;  // :350
             } else {
                 bx_raw = CL(&c.bestX[p]); err_raw = CL(&c.err[p]); np_raw = CL(&c.n_paths);   // final if this round has nothing to do
+                if (ref_rule) npr_raw = CL(&c.n_paths_ref);                                   // (exit tokens are round 0's)
                 stop_raw = CL(&c.stop_req);
                 {   // ... and so are the lists the NEXT frame's phase A reads (parity p ^ 1: the frame after this one, or
                     // frame 0 after recognitionStart's pass): their counts ride on this round trip instead of one of their own
@@ -1642,6 +1661,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
             const unsigned bb = ba > bx ? ba : bx;
             best_emit = bb ? o2f(bb) : LZ;                             // :417-418, :572-573
             np_seen = RFL(np_raw);                                     // (n_paths only changes in phase X)
+            npr_seen = RFL(npr_raw);
             stop_seen = RFL(stop_raw);
         }
         if (tid == 0)                                                  // totalActiveModels starts with frame 0 (:981)

@@ -264,10 +264,12 @@ class OracleDecoder:
         counts = (C.c_int64 * 4)()
         n_coll = 0
         self.collect_frames = []                                        # frames after which collectPaths ran (:362)
+        self.path_counts = []                                           # (nPath, nPathNew) behind every frame (:360, :745)
         while n_data > 0:                                               # :280-295
             _check(L.jo_process_frame(self.h, C.c_void_p(rows_addr + n_frames * psz), C.c_int32(n_frames), C.c_int32(n_data)))
             f = n_frames
             _check(L.jo_path_counts(self.h, counts))
+            self.path_counts.append((int(counts[2]), int(counts[3])))
             if counts[0] > n_coll:                                      # jo_process_frame collected after this frame
                 n_coll = int(counts[0])
                 self.collect_frames.append(f)

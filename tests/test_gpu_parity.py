@@ -759,12 +759,13 @@ def test_partial_decoding_schedule(small_tree):
 
 def test_partial_decoding_count_rule(built):
     """collectPaths' other trigger (:360-362): nPath / nPathNew > 12 with nPath > 10000.  A back-off state that fans out
-    into one eps:word arc per word of a 400-word vocabulary makes hundreds of Path records per frame: collections
-    (and the traces that ride on them) come every few dozen frames, long before the frame rule's 101.  The counts
-    are this build's own records (at most the reference's, which also keeps a Path for every token that loses its
-    state's recombination), so the reference fires at least as often - checked against the oracle, which models
-    both triggers on the reference's counts; every traced list is a prefix of the final result, which is the
-    oracle's."""
+    into one eps:word arc per word of a 400-word vocabulary makes hundreds of Path objects per frame: collections
+    (and the traces that ride on them) come every few dozen frames, long before the frame rule's 101.  The reference
+    counts a Path for every labelled propagateToken call, winner or not; with the end and word beams off the decoder
+    counts the same objects without writing them (the closure's share is a static property of the state), and its
+    collections keep count of what the reference's would keep: nPath and nPathNew equal the oracle's behind every
+    frame, the collections run after the same frames, every traced list is a prefix of the final result, which is
+    the oracle's."""
     from juicer_amd import capi, synth
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
     am, net, feats, _ = synth.config_small(seed=31, n_utts=2, n_words=400, n_succ=5, n_gmm=120, n_hmm=45, hub="flat")
@@ -772,28 +773,59 @@ def test_partial_decoding_count_rule(built):
     kw = dict(main_beam=250.0)
     od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
     snaps, final = od.decode_partial(x, interval=1)
-    assert od.collect_frames[0] < 100
-    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=1, **kw)
+    assert od.collect_frames[0] < 100 and len(od.collect_frames) >= 4
+    # HMMs of 1..6 emitting states, a lexicon tree below the back-off state (closures several arcs deep, through tee models)
+    am2, net2, feats2, _ = synth.config_mixed(seed=12, n_utts=3, n_words=300, n_succ=6)
+    x2 = np.concatenate(feats2)[:260]
+    od_2 = OracleDecoder(OracleNet(net2), OracleAM(am2), **kw)
+    snaps2, final2 = od_2.decode_partial(x2, interval=1)
+    cases = [(am, net, x, od, snaps, final, p, a) for p, a in ((1, 0), (16, 0), (330, 0), (7, 1 << 15))]   # (a small arena: collections of its own in between)
+    cases += [(am2, net2, x2, od_2, snaps2, final2, p, a) for p, a in ((1, 0), (23, 1 << 15))]
+    # a small vocabulary: the rule fires now and then (after frames 9, 11, 12, ..., 18, 20, 23, ...), not after every frame
+    am3, net3, feats3, _ = synth.config_small(seed=5, n_utts=4, n_words=60)
+    x3 = np.concatenate(feats3)[:600]
+    od_3 = OracleDecoder(OracleNet(net3), OracleAM(am3), **kw)
+    snaps3, final3 = od_3.decode_partial(x3, interval=1)
+    gaps = np.diff(od_3.collect_frames)
+    assert gaps.min() == 1 and gaps.max() >= 3
+    cases += [(am3, net3, x3, od_3, snaps3, final3, p, a) for p, a in ((1, 0), (37, 0))]
+    for am, net, x, od, snaps, final, push, arena in cases:
+        args = dict(max_paths=arena) if arena else {}
+        gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=1, **kw, **args)
+        gd.set_partial_interval(1)
+        gd.stream_init(0)
+        prev, colls = [], []
+        for pos in range(0, x.shape[0], push):
+            gd.stream_push(0, x[pos:pos + push])
+            at = min(x.shape[0], pos + push) - 1
+            n, last = gd.stream_collect_info(0)
+            colls.append((n, last))
+            done = [f for f in od.collect_frames if f <= at]
+            assert (n, last) == (len(done), done[-1] if done else -1), (push, at, n, last, done)
+            npath, nnew, exact = gd.stream_path_counts(0)
+            assert exact and (npath, nnew) == od.path_counts[at], (push, at, npath, nnew, od.path_counts[at])
+            _, lst = gd.stream_partial(0)
+            assert lst[:len(prev)] == prev and all(t <= at for _, t in lst)
+            if at in snaps and push == 1:
+                assert lst == snaps[at][1]
+            prev = lst
+        g = gd.stream_finish(0)
+        _, lst = gd.stream_partial(0)
+        assert lst == final == list(zip(g.label.tolist()[::-1], g.time.tolist()[::-1])) and lst[:len(prev)] == prev
+        assert_hyp_matches(g, od.decode_certified(x), "count rule")
+        gd.set_partial_interval(0)
+        gd.close()
+    am, net, x = cases[0][:3]
+    # with an end beam the closure is pruned by score: the rule runs on this build's own records (documented approximation)
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=1, end_beam=200.0, **kw)
     gd.set_partial_interval(1)
     gd.stream_init(0)
-    prev, colls = [], []
-    for pos in range(0, x.shape[0], 16):
-        gd.stream_push(0, x[pos:pos + 16])
-        n, last = gd.stream_collect_info(0)
-        colls.append((n, last))
-        _, lst = gd.stream_partial(0)
-        assert lst[:len(prev)] == prev and all(t <= min(x.shape[0], pos + 16) - 1 for _, t in lst)
-        prev = lst
-    n_first100 = max(n for (n, last), pos in zip(colls, range(0, x.shape[0], 16)) if pos + 16 <= 100)
-    assert n_first100 >= 1, "the count rule did not fire in the first 100 frames"       # (the frame rule cannot: 100 is its first frame)
-    assert colls[-1][0] <= len(od.collect_frames)                      # never more often than the reference
-    lasts = [last for _, last in colls if last >= 0]
-    assert all(b - a <= 101 for a, b in zip([-1] + lasts, lasts) if b != a)
-    g = gd.stream_finish(0)
-    _, lst = gd.stream_partial(0)
-    assert lst == final == list(zip(g.label.tolist()[::-1], g.time.tolist()[::-1])) and lst[:len(prev)] == prev
-    assert_hyp_matches(g, od.decode_certified(x), "count rule")
-    gd.set_partial_interval(0)
+    gd.stream_push(0, x[:120])
+    assert gd.stream_path_counts(0)[2] is False
+    od2 = OracleDecoder(OracleNet(net), OracleAM(am), end_beam=200.0, **kw)
+    od2.decode_partial(x[:120], interval=1)
+    assert gd.stream_collect_info(0)[0] <= len(od2.collect_frames)      # never more often than the reference
+    gd.close()
 
 
 def test_max_alloc_models(small):

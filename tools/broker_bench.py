@@ -13,6 +13,7 @@ import torch  # noqa: E402,F401
 from juicer_amd import capi, synth  # noqa: E402
 
 counts = [int(a) for a in sys.argv[1:]] or [1, 4, 16, 32, 64]
+CHUNK = int(os.environ.get("JD_BENCH_PUSH_FRAMES", "64"))
 am, net, feats, _ = synth.config_c2(n_utts=64)
 gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
 frames = sum(f.shape[0] for f in feats)
@@ -39,8 +40,10 @@ for n in counts:
     dec = capi.Decoder(gnet, gam, main_beam=150.0, max_streams=n)
     broker = capi.Broker(dec)
     best = None
-    for rep in range(2):
-        th = [threading.Thread(target=drive, args=(broker, feats[t::n], 64)) for t in range(n)]
+    for rep in range(1):
+        # every caller decodes the whole list, each from another starting point: equal work per caller, so that the
+        # rate is the steady state's and not the tail of the caller that drew the longest utterances
+        th = [threading.Thread(target=drive, args=(broker, feats[(t * 64) // n:] + feats[:(t * 64) // n], CHUNK)) for t in range(n)]
         t0 = time.perf_counter()
         for t in th:
             t.start()
@@ -49,7 +52,10 @@ for n in counts:
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     st = broker.stats()
-    print("%3d callers: %8.0f frames/s = %.2f of the batch rate; %.1f streams and %.0f frames per tick"
-          % (n, frames / best, (frames / best) / (frames / t_batch), st["stream_ticks"] / max(st["ticks"], 1), st["frames"] / max(st["ticks"], 1)))
+    tk = max(st["ticks"], 1)
+    print("%3d callers: %8.0f frames/s = %.2f of the batch rate; %.1f streams and %.0f frames per tick; worker us per tick: idle %.0f, coalesce %.0f, "
+          "init %.0f, push %.0f (search kernel %.0f), finish %.0f"
+          % (n, n * frames / best, (n * frames / best) / (frames / t_batch), st["stream_ticks"] / tk, st["frames"] / tk, st["us_idle"] / tk,
+             st["us_coalesce"] / tk, st["us_init"] / tk, st["us_push"] / tk, st["us_search"] / tk, st["us_finish"] / tk))
     broker.close()
     dec.close()
