@@ -105,22 +105,33 @@ def test_broker_throughput_at_configs1(built):
     dec = capi.Decoder(gnet, gam, max_streams=16, **kw)
     broker = capi.Broker(dec)
     out = [None] * 64
-    for rep in range(2):                                               # (the first pass warms the decoder up)
-        threads = [threading.Thread(target=_drive, args=(broker, [(u, feats[u]) for u in range(t, 64, 16)], out, 64)) for t in range(16)]
-        t0 = time.perf_counter()
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        t_broker = time.perf_counter() - t0
-    torch.cuda.synchronize()
+    threads = [threading.Thread(target=_drive, args=(broker, [(u, feats[u]) for u in range(t, 64, 16)], out, 64)) for t in range(16)]
+    for t in threads:                                                  # (this pass warms the decoder up)
+        t.start()
+    for t in threads:
+        t.join()
     for u in range(64):
         assert bit_exact(out[u], want[u]), u
+    # the steady state: every caller decodes the whole list, each from another starting point - equal work per caller, so
+    # that the rate is not the tail of the caller that drew the longest utterances
+    outs = [[None] * 64 for _ in range(16)]
+    order = [[(u % 64, feats[u % 64]) for u in range(4 * t, 4 * t + 64)] for t in range(16)]
+    threads = [threading.Thread(target=_drive, args=(broker, order[t], outs[t], 64)) for t in range(16)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    t_broker = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    for t in range(16):
+        for u in range(64):
+            assert bit_exact(outs[t][u], want[u]), (t, u)
     st = broker.stats()
-    ratio = (frames / t_broker) / (frames / t_batch)
+    ratio = (16 * frames / t_broker) / (frames / t_batch)
     print("16 callers through the broker: %.0f frames/s, one batch of 64: %.0f frames/s (host-inclusive) - ratio %.2f; %.1f streams, %.0f frames per tick"
-          % (frames / t_broker, frames / t_batch, ratio, st["stream_ticks"] / st["ticks"], st["frames"] / st["ticks"]))
-    assert ratio >= 0.2                                               # (16 streams are latency-bound: DESIGN.md, "the drop-in seam's own throughput")
+          % (16 * frames / t_broker, frames / t_batch, ratio, st["stream_ticks"] / st["ticks"], st["frames"] / st["ticks"]))
+    assert ratio >= 0.3                                               # (16 streams are latency-bound: DESIGN.md, "the drop-in seam's own throughput")
     broker.close()
     dec.close()
 
