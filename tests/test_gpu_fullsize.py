@@ -287,6 +287,65 @@ def test_configs4_bench_size_composed_graph_vs_oracle(clg_pair):
             assert np.array_equal(np.asarray(getattr(a, k), np.float32).view(np.uint32), np.asarray(getattr(b, k), np.float32).view(np.uint32)), k
 
 
+def test_configs4_bench_size_lazy_generations(clg_pair):
+    """The search-driven composition at bench size with BOUNDED memory (the reference: an LRU cache,
+    WFSTOnTheFlyDecoder.h:210-371; here whole generations of the arena): six utterances in three waves of two on a
+    network whose arena (a) starts a new generation in front of every wave that begins behind another one (high-water
+    mark), (b) holds any one wave but not the three together, so that a wave runs out of room under way and is decoded
+    again on a fresh generation - hypotheses bit-identical to the fully composed 8.4 M-arc graph's every time."""
+    from juicer_amd import capi
+    p = clg_pair
+    kw = dict(main_beam=200.0, max_streams=2)
+    net = capi.Network.compose(p["ncl"], p["ng"], max_states=1 << 26, max_arcs=1 << 27)
+    want = capi.Decoder(net, p["gam"], **kw).decode_batch(p["feats"])
+    assert all(h.n > 0 for h in want)
+
+    def same(a, b):
+        assert a.n == b.n and np.array_equal(a.label, b.label) and np.array_equal(a.time, b.time)
+        for k in ("score", "ac", "lm"):
+            assert np.array_equal(np.asarray(getattr(a, k), np.float32).view(np.uint32), np.asarray(getattr(b, k), np.float32).view(np.uint32)), k
+
+    big = capi.Network.lazy(p["ncl"], p["ng"], p["gam"], max_states=1 << 22, max_arcs=1 << 23)
+    dec = capi.Decoder(big, p["gam"], **kw)
+    start = big.lazy_size()
+    alone = []
+    for w in range(3):
+        big.lazy_reset()
+        got = dec.decode_batch(p["feats"][2 * w:2 * w + 2])
+        same(got[0], want[2 * w]); same(got[1], want[2 * w + 1])
+        alone.append(big.lazy_size())
+    big.lazy_reset()
+    dec.decode_batch(p["feats"])
+    together = big.lazy_size()
+    need_s, need_a = max(a[0] for a in alone), max(a[1] for a in alone)
+    print("lazily composed configs[4] pair: a wave of two utterances builds %s states / %s arcs, the three waves together %d / %d (of %d / %d composed)"
+          % ([a[0] for a in alone], [a[1] for a in alone], together[0], together[1], net.n_states, net.n_arcs))
+    assert together[0] > need_s + 10000 and together[1] > need_a + 10000   # (the waves share most of what they build)
+    del dec
+    # (a) the high-water mark between the start state's closure and what a wave leaves behind
+    lz = capi.Network.lazy(p["ncl"], p["ng"], p["gam"], max_states=1 << 22, max_arcs=1 << 23)
+    lz.lazy_set_high_water(0.5 * (start[0] + min(a[0] for a in alone)) / float(1 << 22))
+    got = capi.Decoder(lz, p["gam"], **kw).decode_batch(p["feats"])
+    for a, b in zip(got, want):
+        same(a, b)
+    assert lz.lazy_generation() == 2                                   # before waves 2 and 3
+    # (b) room for any one wave, not for the three: states first, then arcs
+    cap_s, cap_a = (need_s + together[0]) // 2, (need_a + together[1]) // 2
+    for cs, ca in ((cap_s, 1 << 23), (1 << 22, cap_a)):
+        lz = capi.Network.lazy(p["ncl"], p["ng"], p["gam"], max_states=cs, max_arcs=ca)
+        lz.lazy_set_high_water(1.0)                                    # (never ahead of time)
+        d = capi.Decoder(lz, p["gam"], **kw)
+        got = d.decode_batch(p["feats"])
+        for a, b in zip(got, want):
+            same(a, b)
+        assert lz.lazy_generation() >= 1
+        ns, na = lz.lazy_size()
+        assert ns <= cs and na <= ca
+        again = d.decode_batch(p["feats"][:2])                         # and the network goes on working
+        same(again[0], want[0]); same(again[1], want[1])
+        del d
+
+
 def test_device_composition_at_100k_arcs_vs_python_reference(built):
     """jd_net_compose against the same definition written in Python dictionaries (tests/compose_ref.py) on a pair whose
     composition has > 100 k arcs (1500 words, 6000 trigram histories): identical arrays, bit for bit, with and without
