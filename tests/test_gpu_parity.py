@@ -1162,6 +1162,58 @@ def test_scores_ahead_with_collections_and_replans(small):
                 os.environ[k] = v
 
 
+def test_error_in_the_batch_behind(built):
+    """A stream of the batch that is searched AHEAD runs into an error (Histogram::addScore's ceiling, Histogram.cpp:78-79:
+    a log-likelihood above +201 at the mean of a sharp density): the error belongs to that batch's decode - not to the
+    decode it ran beside, whose results are the oracle's - and the decoder goes on: the batches behind the failed one
+    are the oracle's bit for bit."""
+    import torch
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small()
+    hmm = int(net.ilab[0]) - 1                                         # first arc out of the initial state
+    g_sharp = int(am.hmm_gmm[hmm, 1])
+    am.var[g_sharp] = 1e-6
+    poison = am.mean[g_sharp, 0][None, :].repeat(30, axis=0).astype(np.float32)
+    gnet, gam, onet, oam = capi.Network.from_synth(net), capi.Models.from_htk(am), OracleNet(net), OracleAM(am)
+    kw = dict(main_beam=150.0, max_hyps=100)
+    od = OracleDecoder(onet, oam, **kw)
+    mk = lambda k: [np.concatenate([feats[(k * i + j + k) % len(feats)] for j in range(1 + (i + k) % 3)]) for i in range(6)]
+    batches = {"A": mk(1), "B": mk(2)[:3] + [poison] + mk(2)[4:], "C": mk(3)}
+    want = {n: [od.decode_certified(x) for x in batches[n]] for n in ("A", "C")}
+    dev = torch.device("cuda", 0)
+
+    def resident(batch):
+        offs = np.zeros(len(batch) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([x.shape[0] for x in batch])
+        return torch.from_numpy(np.concatenate(batch)).to(dev), offs
+    buf = {n: resident(b) for n, b in batches.items()}
+    for streams in (6, 12):                                            # one batch in flight / two
+        gd = capi.Decoder(gnet, gam, max_streams=streams, **kw)
+
+        def decode(n):
+            gs = gd.decode_batch_device(buf[n][0].data_ptr(), buf[n][1], 0)
+            for i, g in enumerate(gs):
+                assert_hyp_matches(g, want[n][i], "streams %d batch %s utt %d" % (streams, n, i))
+                assert bit_exact(g, want[n][i])
+            return gd.last_timing()
+        ahead = 0
+        for rep in range(3):
+            gd.prefetch_scores(buf["B"][0].data_ptr(), buf["B"][1], 0)
+            if rep == 0:
+                gd.prefetch_scores(buf["C"][0].data_ptr(), buf["C"][1], 0)
+            decode("A")                                                # (B is started beside it when there are two banks)
+            gd.prefetch_scores(buf["C"][0].data_ptr(), buf["C"][1], 0) if rep else None
+            with pytest.raises(capi.JuicerAmdError) as ei:
+                gd.decode_batch_device(buf["B"][0].data_ptr(), buf["B"][1], 0)
+            assert ei.value.code == capi.JD_EHIST, str(ei.value)
+            gd.prefetch_scores(buf["A"][0].data_ptr(), buf["A"][1], 0)
+            ahead += 1 if decode("C")["ahead_frames"] > 0 else 0
+        if streams == 12:
+            assert ahead >= 1                                          # C had been started beside the failing batch
+        gd.close()
+
+
 def test_two_batches_in_flight(small):
     """Announcements that run two batches ahead on a decoder whose streams hold two batches: the utterances of the batch
     behind the running one are started beside it (one workgroup each, the other bank of streams) and are frames in when
