@@ -51,6 +51,7 @@
 #define LZ (-3.402823466e+38f)
 #define GMM_ROWS 64             // stream-frames per GMM tile (one per lane)
 #define GMM_GT 64               // tied states per GMM workgroup (16 per wave)
+#define GMM_GT_SMALL 16         // ... of a launch with few rows (jd_gmm_kernel39 only)
 #define HIST_MAX_BINS 2048
 
 struct __align__(16) Tok { float score, ac, lm; int path; };
@@ -171,12 +172,20 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
         return JD_OK;
     }
     const int rows_per_tile = (a->D == 39) ? GMM_ROWS2 : GMM_ROWS;
-    const long long tiles = (long long)((n_rows + rows_per_tile - 1) / rows_per_tile) * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
+    const long long row_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
+    long long tiles = row_tiles * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
+    // few rows (a streaming push, a tick of the broker): tiles of 16 states, four times as many and a quarter as long
+    const bool small_tiles = a->D == 39 && tiles < 1024;
+    if (small_tiles) tiles = row_tiles * ((a->n_gmm + GMM_GT_SMALL - 1) / GMM_GT_SMALL);
     dim3 grid((unsigned)((max_blocks > 0 && tiles > max_blocks) ? max_blocks : tiles));
     if (a->D == 39) {
         const size_t sm = 130 * sizeof(JdLogTab) + 32 * sizeof(unsigned long long) + (size_t)GMM_ROWS2 * std::max(39, GMM_GT + 1) * sizeof(float);
-        hipLaunchKernelGGL(jd_gmm_kernel39, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
-                           b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab);
+        if (small_tiles)
+            hipLaunchKernelGGL(jd_gmm_kernel39<GMM_GT_SMALL>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
+                               b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab);
+        else
+            hipLaunchKernelGGL(jd_gmm_kernel39<GMM_GT>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
+                               b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab);
     } else {
         const int dp = a->D | 1;
         const size_t sm = (size_t)(GMM_ROWS * dp + GMM_ROWS * (GMM_GT + 1)) * sizeof(float);

@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256) void jd_gmm_kernel(const float *__restrict__ f
 }
 
 
-// ---- the D = 39 kernel: TWO frames per lane, packed fp32 arithmetic.
+// ---- the D = 39 kernel: TWO frames per lane, packed fp32 arithmetic.  GT tied states per tile (a quarter of them per
+// wave): 64 for tables, 16 for the few rows of a streaming push - a tile is a chain of GT / 4 states x 16 mixtures per
+// wave (0.3 ms at 64) whatever the number of rows, and a push of 64 frames is 47 such tiles on a chip of 1024 slots.
 //
 // A lane owns rows r and r + 64 of a 128-row tile; their vectors sit side by side in register
 // pairs, so every VALU instruction of the distance loop is a packed one (v_pk_add_f32 /
@@ -186,6 +188,7 @@ __device__ __forceinline__ void jd_log_add2x2(float &a0, float &a1, float c0, fl
     a1 = keep1 ? x1 : n1;
 }
 
+template <int GT>
 __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restrict__ feats,
                                                        const int *__restrict__ row_src, int n_rows,
                                                        const float *__restrict__ par,
@@ -199,18 +202,18 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
     JdLogTab *stab = (JdLogTab *)smem;                // [129] (+ pad)
     unsigned long long *setab = (unsigned long long *)(smem + 130 * sizeof(JdLogTab));   // [32]
     float *sx = (float *)(smem + 130 * sizeof(JdLogTab) + 32 * sizeof(unsigned long long));   // [128][DP]
-    float *so = sx;                                   // [128][GMM_GT+1]: the feature tile is in registers by then
+    float *so = sx;                                   // [128][GT+1]: the feature tile is in registers by then
                                                       // (36 KB per workgroup: four of them share a CU's LDS)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 129; i += 256) stab[i] = logtab[i];
     if (tid < 32) setab[tid] = jd_exp2f_tab[tid];
-    const int n_rt = (n_rows + GMM_ROWS2 - 1) / GMM_ROWS2, n_gt = (G + GMM_GT - 1) / GMM_GT;
+    const int n_rt = (n_rows + GMM_ROWS2 - 1) / GMM_ROWS2, n_gt = (G + GT - 1) / GT;
     for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
         // row tile skewed by the state group (see jd_gmm_kernel)
         const int gt = tile / n_rt;
         const int r0 = ((tile + gt) % n_rt) * GMM_ROWS2;
-        const int g0 = gt * GMM_GT;
+        const int g0 = gt * GT;
         if (skip_unused && row_src[r0] < 0) continue;
         __syncthreads();                              // previous tile's LDS reads are done
         for (int e = tid; e < GMM_ROWS2 * DT; e += 256) {
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
 #pragma unroll
         for (int j = 0; j < DT; ++j) { x[j].x = sx[lane * DP + j]; x[j].y = sx[(lane + 64) * DP + j]; }
         __syncthreads();                              // sx is re-used as the output tile
-        constexpr int GPW = GMM_GT / 4;               // tied states per wave
+        constexpr int GPW = GT / 4;               // tied states per wave
         for (int gi = 0; gi < GPW; ++gi) {
             const int gl = wid * GPW + gi;            // wave-uniform
             const int g = g0 + gl;
@@ -256,13 +259,13 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
                     else jd_log_add2x2(acc0, acc1, c0, c1, stab, setab);
                 }
             }
-            so[lane * (GMM_GT + 1) + gl] = acc0;
-            so[(lane + 64) * (GMM_GT + 1) + gl] = acc1;
+            so[lane * (GT + 1) + gl] = acc0;
+            so[(lane + 64) * (GT + 1) + gl] = acc1;
         }
         __syncthreads();
-        for (int e = tid; e < GMM_ROWS2 * GMM_GT; e += 256) {
-            const int r = e / GMM_GT, c = e - r * GMM_GT;
-            if (r0 + r < n_rows && g0 + c < G) ll[(size_t)(r0 + r) * G + g0 + c] = so[r * (GMM_GT + 1) + c];
+        for (int e = tid; e < GMM_ROWS2 * GT; e += 256) {
+            const int r = e / GT, c = e - r * GT;
+            if (r0 + r < n_rows && g0 + c < G) ll[(size_t)(r0 + r) * G + g0 + c] = so[r * (GT + 1) + c];
         }
     }
 }
