@@ -441,6 +441,7 @@ struct jd_dec {
     bool return_on_collect = false, collected_now = false;   // jd_stream_push: launch_search comes back after a collection by the count rule
     float *d_push = nullptr; size_t push_cap = 0;
     char *h_stage = nullptr; size_t stage_cap = 0;     // pinned staging of jd_streams_push
+    bool xch_forced = false;               // JD_XCH given (development)
     // results
     std::vector<HostResult> results;
     jd_timing timing{};
@@ -530,7 +531,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     C.start_win = start_beam; C.emit_win = main_beam; C.end_win = end_beam; C.word_win = word_beam;
     C.max_hyps = max_hyps;
     C.x_chunks = 2;
-    if (const char *e = getenv("JD_XCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) C.x_chunks = v; }   // development
+    if (const char *e = getenv("JD_XCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) { C.x_chunks = v; d->xch_forced = true; } }   // development
     C.exp = 0; C.path_rule = 0; C.pcount = nullptr;
     if (const char *e = getenv("JD_EXP")) C.exp = atoi(e);                                                    // development
     C.hist_min = 0; C.hist_max = 0; C.hist_nbins = 0;
@@ -1313,6 +1314,9 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             grid = first;
         }
         if (n_bg > 0) { A.n_prio = n_work; A.n_work = n_tot; d->bg_ran = true; }
+        // (two batches in flight: clusters of one or two workgroups - one chunk of items per wave, i.e. full 64-item passes,
+        // does better there than two: 31.2 against 31.9 ms per step; the heavy workloads lose 3-5 % with one)
+        if (n_bg > 0 && !d->xch_forced) A.C.x_chunks = 1;
         A.n_slots = 0;
         // Re-planning under way (SearchArgs::rebalance_at): the plan above makes the streams finish together only as
         // far as frames predict work; when a fifth of the grid has run out of work the launch is cut short and the
