@@ -88,6 +88,52 @@ def test_broker_threads_match_batch(small):
     dec.close()
 
 
+def test_broker_error_stays_with_its_client(built):
+    """One caller's utterance fails (Histogram::addScore's ceiling, Histogram.cpp:78-79: a log-likelihood above +201) in the
+    middle of common launches: the error comes back through THAT caller's finish; its next utterance and everybody else's
+    are those of a batch decode, bit for bit."""
+    from juicer_amd import capi, synth
+    am, net, feats, _ = synth.config_small(n_utts=12)
+    hmm = int(net.ilab[0]) - 1                                         # first arc out of the initial state
+    g_sharp = int(am.hmm_gmm[hmm, 1])
+    am.var[g_sharp] = 1e-6
+    poison = am.mean[g_sharp, 0][None, :].repeat(40, axis=0).astype(np.float32)
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    kw = dict(main_beam=150.0, max_hyps=100)
+    want = capi.Decoder(gnet, gam, max_streams=len(feats), **kw).decode_batch(feats)
+    dec = capi.Decoder(gnet, gam, max_streams=4, **kw)
+    broker = capi.Broker(dec)
+    out, errs = [None] * len(feats), []
+
+    def drive(t):
+        c = broker.open()
+        for k, u in enumerate(range(t, len(feats), 4)):
+            if t == 2 and k == 1:                                      # this caller's second utterance is the one that fails
+                broker.init(c)
+                try:
+                    for i in range(0, poison.shape[0], 9):
+                        broker.push(c, poison[i:i + 9])
+                    broker.finish(c)
+                    errs.append(None)
+                except capi.JuicerAmdError as e:
+                    errs.append(e.code)
+            broker.init(c)
+            for i in range(0, feats[u].shape[0], 31 + 5 * t):
+                broker.push(c, feats[u][i:i + 31 + 5 * t])
+            out[u] = broker.finish(c)
+        broker.close_client(c)
+    threads = [threading.Thread(target=drive, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errs == [capi.JD_EHIST], errs
+    for u in range(len(feats)):
+        assert out[u] is not None and bit_exact(out[u], want[u]), u
+    broker.close()
+    dec.close()
+
+
 def test_broker_throughput_at_configs1(built):
     """16 serial callers (threads) on the configs[1] graph against ONE batch of the same 64 utterances."""
     import torch
