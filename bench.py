@@ -328,6 +328,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # stdout carries ONE JSON line: RCCL's version banner (NCCL_DEBUG=VERSION, exported on the GPU boxes) goes to stderr
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            del os.environ["NCCL_DEBUG"]
         if share_gpu:
             dist.init_process_group("gloo")
         else:
