@@ -338,6 +338,7 @@ typedef struct jd_broker_stats {
     int64_t us_idle, us_coalesce;                  /* worker thread: waiting for work; waiting for the other clients' frames */
     int64_t us_init, us_push, us_finish;           /* ... inside jd_stream_init / jd_streams_push / jd_stream_finish */
     int64_t us_search;                             /* of us_push: the search launches (device time) */
+    int64_t resident;                              /* 1: the worker drives the resident search kernel - a "tick" is then one stream's chunk */
 } jd_broker_stats;
 int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients);   /* n_clients <= the decoder's max_streams */
 void jd_broker_destroy(jd_broker *b);                                    /* (the decoder is the caller's to destroy, afterwards) */

@@ -499,7 +499,7 @@ class Decoder:
 
 class BrokerStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("ticks", "frames", "stream_ticks", "us_idle", "us_coalesce", "us_init", "us_push", "us_finish",
-                                         "us_search")]
+                                         "us_search", "resident")]
 
 
 class Broker:

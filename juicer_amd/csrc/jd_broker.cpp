@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -31,6 +32,12 @@ struct Client {
     int err = JD_OK;                               // first error of a tick that concerned this client (reported by its next call)
     std::string errmsg;
     jd_hyp result;                                 // of the last finish (arrays owned by the decoder, valid until the stream's next init)
+    // the resident kernel's worker (broker_loop_resident): chunks of this client's frames that are scored (or being scored)
+    // and not yet posted - at most two, one per likelihood buffer - and the one its cluster is running
+    int staged_buf[2] = {0, 0}, staged_n[2] = {0, 0}, n_staged = 0;
+    bool running = false; int run_buf = 0;
+    bool fresh = false;                            // initialised and nothing posted yet (recognitionStart is still to run)
+    bool finishing = false;                        // its result is being fetched (the finisher thread)
 };
 }  // namespace
 
@@ -46,6 +53,12 @@ struct jd_broker {
     bool stop = false;
     std::vector<Client> clients;
     jd_broker_stats stats{};
+    bool resident = false;                         // the worker drives the resident search kernel (jd_res_*) instead of ticks
+    // results are fetched by a thread of their own: recognitionFinish's kernel, a synchronisation of the side stream and
+    // three copies back are a third of a millisecond in which the worker would post nothing to anybody
+    std::thread finisher;
+    std::deque<int> fin_q;
+    std::condition_variable cv_fin;
 };
 
 static int client_error(jd_broker *b, Client &c)
@@ -180,6 +193,149 @@ static void broker_loop(jd_broker *b)
     }
 }
 
+
+// The worker over the RESIDENT search kernel (jd_resident.h): no ticks.  Every client's stream has a cluster of its own in a
+// kernel that stays; its frames are scored into one of the stream's two likelihood buffers as they come (on the side
+// stream, beside the search) and posted to the cluster as soon as it is through with the chunk before - every stream at
+// its own pace.  init, finish and the Path collections are small kernels on the side stream between two commands.
+static void broker_loop_resident(jd_broker *b)
+{
+    std::unique_lock<std::mutex> lk(b->mu);
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    std::vector<float> taken;
+    bool on = false;
+    auto idle_since = now();
+    auto fail_all = [&](int rc, const std::string &msg) {              // (lk held)
+        for (Client &c : b->clients)
+            if (c.open && c.err == JD_OK) { c.err = rc; c.errmsg = msg; }
+        for (Client &c : b->clients) { c.want_init = false; c.want_finish = false; c.pending.clear(); c.n_staged = 0; c.running = false; }
+        b->cv_done.notify_all();
+    };
+    for (;;) {
+        bool active = false;
+        for (const Client &c : b->clients)
+            if (c.open && (c.want_init || c.want_finish || c.running || c.finishing || c.n_staged > 0 || (c.inited && !c.pending.empty()))) { active = true; break; }
+        if (b->stop) { if (on) { lk.unlock(); (void)jd_res_stop(b->dec); lk.lock(); } return; }
+        if (!active) {
+            // nothing to do: the kernel leaves the chip after a few milliseconds (other decoders, other processes, a
+            // caller's device-wide synchronisation all wait for it) and comes back with the next request
+            if (on && std::chrono::duration<double, std::milli>(now() - idle_since).count() > 3.0) {
+                lk.unlock(); (void)jd_res_stop(b->dec); lk.lock();
+                on = false;
+                continue;
+            }
+            if (on) b->cv_work.wait_for(lk, std::chrono::microseconds(200));
+            else b->cv_work.wait(lk);
+            continue;
+        }
+        if (!on) {
+            lk.unlock();
+            const int rc = jd_res_start(b->dec, b->n_clients, b->max_tick_frames);
+            const std::string m = rc ? jd_last_error() : "";
+            lk.lock();
+            if (rc) { fail_all(rc, m); continue; }
+            on = true;
+        }
+        bool progress = false;
+        for (int i = 0; i < b->n_clients; ++i) {
+            Client &c = b->clients[(size_t)i];
+            if (!c.open || c.finishing) continue;
+            int rc = JD_OK;
+            // 1. where its cluster stands
+            if (c.running) {
+                int idle = 0, frame = 0, err = 0, stopped = 0;
+                lk.unlock();
+                rc = jd_res_poll(b->dec, i, &idle, &frame, &err, &stopped);
+                if (rc == JD_OK && idle && stopped) { rc = jd_res_collect(b->dec, i); idle = 0; progress = true; }
+                const std::string m = rc ? jd_last_error() : "";
+                lk.lock();
+                if (rc) { fail_all(rc, m); on = false; lk.unlock(); (void)jd_res_stop(b->dec); lk.lock(); break; }
+                if (idle) { c.running = false; progress = true; b->cv_done.notify_all(); }
+            }
+            // 2. IDecoder::init
+            if (!c.running && c.n_staged == 0 && c.want_init) {
+                lk.unlock();
+                rc = jd_res_init(b->dec, i);
+                const std::string m = rc ? jd_last_error() : "";
+                lk.lock();
+                c.want_init = false; c.inited = rc == JD_OK; c.fresh = rc == JD_OK;
+                if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
+                b->cv_done.notify_all();
+                progress = true;
+            }
+            // 3. frames into a free likelihood buffer
+            if (c.inited && !c.want_init && !c.pending.empty() && c.n_staged + (c.running ? 1 : 0) < 2) {
+                int buf = 0;
+                if (c.running && c.run_buf == 0) buf = 1;
+                if (c.n_staged == 1 && c.staged_buf[0] == buf) buf ^= 1;
+                if (!(c.running && c.run_buf == buf)) {
+                    const size_t have = c.pending.size() / (size_t)b->D;
+                    const size_t take = std::min(have, (size_t)b->max_tick_frames);
+                    taken.assign(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
+                    c.pending.erase(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
+                    lk.unlock();
+                    b->cv_done.notify_all();                           // (pushes that waited for room)
+                    rc = jd_res_stage(b->dec, i, buf, taken.data(), (int)take);
+                    const std::string m = rc ? jd_last_error() : "";
+                    lk.lock();
+                    if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
+                    else if (!rc) { c.staged_buf[c.n_staged] = buf; c.staged_n[c.n_staged] = (int)take; c.n_staged += 1; }
+                    progress = true;
+                }
+            }
+            // 4. the next chunk to the cluster (a finish without frames still runs recognitionStart: a chunk of none)
+            if (!c.running && c.inited && (c.n_staged > 0 || (c.fresh && c.want_finish && c.pending.empty()))) {
+                const int buf = c.n_staged > 0 ? c.staged_buf[0] : 0, nf = c.n_staged > 0 ? c.staged_n[0] : 0;
+                lk.unlock();
+                rc = jd_res_post(b->dec, i, buf, nf);
+                const std::string m = rc ? jd_last_error() : "";
+                lk.lock();
+                if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
+                if (c.n_staged > 0) { c.staged_buf[0] = c.staged_buf[1]; c.staged_n[0] = c.staged_n[1]; c.n_staged -= 1; }
+                if (!rc) { c.running = true; c.run_buf = buf; c.fresh = false; b->stats.ticks += 1; b->stats.frames += nf; b->stats.stream_ticks += 1; }
+                progress = true;
+            }
+            // 5. IDecoder::finish (handed to the finisher thread)
+            if (!c.running && c.n_staged == 0 && c.inited && !c.fresh && c.want_finish && c.pending.empty()) {
+                c.finishing = true;
+                b->fin_q.push_back(i);
+                b->cv_fin.notify_one();
+                progress = true;
+            }
+        }
+        if (progress) idle_since = now();
+        else {
+            // (the clusters report through host-mapped words: looking again costs nothing on the device)
+            lk.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            lk.lock();
+            idle_since = now();
+        }
+    }
+}
+
+static void broker_finisher(jd_broker *b)
+{
+    std::unique_lock<std::mutex> lk(b->mu);
+    for (;;) {
+        b->cv_fin.wait(lk, [&]() { return b->stop || !b->fin_q.empty(); });
+        if (b->fin_q.empty()) return;                                  // (stop, and nothing left to hand out)
+        const int i = b->fin_q.front();
+        b->fin_q.pop_front();
+        jd_hyp res;
+        memset(&res, 0, sizeof res);
+        lk.unlock();
+        const int rc = jd_res_finish(b->dec, i, &res);
+        const std::string m = rc ? jd_last_error() : "";
+        lk.lock();
+        Client &c = b->clients[(size_t)i];
+        if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
+        c.want_finish = false; c.inited = false; c.finishing = false; c.result = res;
+        b->cv_done.notify_all();
+        b->cv_work.notify_all();
+    }
+}
+
 extern "C" int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients)
 {
     if (!out || !dec || n_clients < 1) return jd_fail(JD_EINVAL, "jd_broker_create: bad argument");
@@ -193,7 +349,18 @@ extern "C" int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients)
     if (const char *e = getenv("JD_BROKER_TICK_FRAMES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) b->max_tick_frames = v; }
     if (const char *e = getenv("JD_BROKER_COALESCE_US")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) b->coalesce_us = v; }
     b->max_pending_frames = 4 * b->max_tick_frames;
-    b->worker = std::thread(broker_loop, b);
+    // the resident search kernel instead of ticks (JD_BROKER_RESIDENT=0: ticks): not with a lazily composed network or
+    // partial traces - jd_res_start says so and the clients' first calls would fail, so those decoders keep the ticks
+    // ... and not with more clients than the chip has room for clusters AND their scoring side by side: from about 48 streams on
+    // a launch that takes every CU and the scoring in turn (ticks) does better than a static split (measured: 64 callers
+    // 0.83 of the batch rate against 0.57; 32 callers 0.57 against 0.80)
+    b->resident = n_clients <= 40;
+    if (const char *e = getenv("JD_BROKER_RESIDENT")) b->resident = atoi(e) != 0;
+    if (b->resident && !getenv("JD_BROKER_TICK_FRAMES")) { b->max_tick_frames = 256; b->max_pending_frames = 4 * b->max_tick_frames; }   // (whole scoring tiles)
+    if (b->resident && jd_res_start(dec, n_clients, b->max_tick_frames) != JD_OK) b->resident = false;
+    else if (b->resident) (void)jd_res_stop(dec);                      // (it comes back with the first request)
+    b->worker = b->resident ? std::thread(broker_loop_resident, b) : std::thread(broker_loop, b);
+    if (b->resident) b->finisher = std::thread(broker_finisher, b);
     *out = b;
     return JD_OK;
 }
@@ -202,7 +369,8 @@ extern "C" void jd_broker_destroy(jd_broker *b)
 {
     if (!b) return;
     { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; }
-    b->cv_work.notify_all(); b->cv_done.notify_all();
+    b->cv_work.notify_all(); b->cv_done.notify_all(); b->cv_fin.notify_all();
+    if (b->finisher.joinable()) b->finisher.join();
     if (b->worker.joinable()) b->worker.join();
     delete b;
 }
@@ -223,7 +391,10 @@ extern "C" int jd_broker_close(jd_broker *b, int32_t client)
     Client &c = b->clients[(size_t)client];
     if (!c.open) return jd_fail(JD_ESTATE, "jd_broker_close: client %d is not open", client);
     // (an utterance that was never finished: its frames are dropped; the stream's next init clears what it left)
-    b->cv_done.wait(lk, [&]() { return b->stop || !c.want_init; });
+    c.pending.clear(); c.want_finish = false;
+    // (... and what its cluster still has of them runs out first: the stream is somebody else's after this)
+    b->cv_work.notify_all();
+    b->cv_done.wait(lk, [&]() { return b->stop || (!c.want_init && !c.running && c.n_staged == 0); });
     c.pending.clear(); c.want_finish = false; c.inited = false; c.open = false;
     return JD_OK;
 }
@@ -279,5 +450,6 @@ extern "C" int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out)
     if (!b || !out) return jd_fail(JD_EINVAL, "jd_broker_get_stats: bad argument");
     std::lock_guard<std::mutex> lk(b->mu);
     *out = b->stats;
+    out->resident = b->resident ? 1 : 0;
     return JD_OK;
 }

@@ -91,6 +91,7 @@ __device__ __forceinline__ int rank_in(unsigned long long bal)
 
 // ------------------------------------------- Path collection, partial trace, finish, launch helpers
 #include "jd_gc.h"
+#include "jd_resident.h"
 
 // --------------------------------------------------------------- host runtime
 
@@ -160,8 +161,9 @@ static void free_am_gmm(AmDevBuf &b)
 // kernels, which need slots for microseconds at a time, all but stop (measured: 25 ms of
 // scoring cost the search 20 ms).  A bounded grid scores in the background instead.
 // skip_unused: row_src marks unused rows with -1 in whole-tile runs (decode_wave's stream slots).
+// used_row_tiles >= 0: the row tiles that are not skipped (else: all of them)
 static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, const int *d_row_src, int n_rows,
-                      float *d_ll, hipStream_t st, int max_blocks = 0, int skip_unused = 0)
+                      float *d_ll, hipStream_t st, int max_blocks = 0, int skip_unused = 0, int used_row_tiles = -1)
 {
     if (n_rows <= 0) return JD_OK;
     if (a->hybrid) {
@@ -175,7 +177,7 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
     const long long row_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
     long long tiles = row_tiles * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
     // few rows (a streaming push, a tick of the broker): tiles of 16 states, four times as many and a quarter as long
-    const bool small_tiles = a->D == 39 && tiles < 1024;
+    const bool small_tiles = a->D == 39 && (used_row_tiles >= 0 ? (long long)used_row_tiles * ((a->n_gmm + GMM_GT - 1) / GMM_GT) : tiles) < 1024;
     if (small_tiles) tiles = row_tiles * ((a->n_gmm + GMM_GT_SMALL - 1) / GMM_GT_SMALL);
     dim3 grid((unsigned)((max_blocks > 0 && tiles > max_blocks) ? max_blocks : tiles));
     if (a->D == 39) {
@@ -442,6 +444,7 @@ struct jd_dec {
     float *d_push = nullptr; size_t push_cap = 0;
     char *h_stage = nullptr; size_t stage_cap = 0;     // pinned staging of jd_streams_push
     bool xch_forced = false;               // JD_XCH given (development)
+    struct Resident *res = nullptr;        // the resident search kernel of a broker (jd_res_*), or null
     // results
     std::vector<HostResult> results;
     jd_timing timing{};
@@ -478,10 +481,12 @@ static int dupload(jd_dec *d, T **p, const T *src, size_t n)
     return JD_OK;
 }
 
+static void res_free_fwd(jd_dec *d);
 extern "C" void jd_dec_destroy(jd_dec *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    if (d->res) { (void)jd_res_stop(d); res_free_fwd(d); }
     (void)hipDeviceSynchronize();
     for (char in : d->lazy_in) if (in) jd_lazy_leave(d->net, 1);      // (utterances the caller never finished)
     for (void *p : d->allocs) (void)hipFree(p);
@@ -2278,6 +2283,241 @@ extern "C" int jd_streams_push(jd_dec *d, int32_t n, const int32_t *streams, con
     if (rc) { (void)hipStreamSynchronize(st); for (const int2 &w : work) d->stream_dirty[(size_t)w.x] = 1; return rc; }
     for (int i = 0; i < n; ++i) if (n_frames[i] > 0) d->stream_T[(size_t)streams[i]] = Tnew[(size_t)i];
     return JD_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The resident search kernel (jd_resident.h) and its host side: what jd_broker.cpp drives instead of ticks.
+// While it runs it owns the device's search lock (this process) and the GPU's file lock (other processes); nothing here
+// allocates or frees device memory or synchronises the device - either would wait for the kernel.
+struct Resident {
+    bool on = false;
+    int n = 0, Cw = 0, rows = 0;                       // streams [0, n), workgroups per cluster, rows per likelihood buffer
+    ResMail *d_mail = nullptr;
+    ResDone *h_done = nullptr;                         // host-mapped
+    float *d_feat = nullptr, *d_ll = nullptr;          // [n][2][rows] x D / x G
+    int *d_src = nullptr;
+    char *h_stage = nullptr;                           // pinned: the features of every buffer, [n][2][rows] x D
+    std::vector<unsigned> seq;                         // last sequence number posted per stream
+    std::vector<int> T_posted, T_done, err_done;
+    std::vector<int> slot_posted;
+    std::vector<char> busy;                            // a command is posted and its report not yet taken
+    std::unique_lock<std::mutex> search_lock;
+    GpuLockGuard *process_lock = nullptr;
+};
+
+static void res_free(jd_dec *d);
+static void res_free_fwd(jd_dec *d) { res_free(d); }
+static void res_free(jd_dec *d)
+{
+    Resident *R = d->res;
+    if (!R) return;
+    if (R->d_mail) (void)hipFree(R->d_mail);
+    if (R->h_done) (void)hipHostFree(R->h_done);
+    if (R->d_feat) (void)hipFree(R->d_feat);
+    if (R->d_ll) (void)hipFree(R->d_ll);
+    if (R->d_src) (void)hipFree(R->d_src);
+    if (R->h_stage) (void)hipHostFree(R->h_stage);
+    delete R;
+    d->res = nullptr;
+}
+
+// the report of stream s's command, if it is in
+static bool res_harvest(jd_dec *d, int s)
+{
+    Resident *R = d->res;
+    if (!R->busy[(size_t)s]) return true;
+    if (__atomic_load_n(&R->h_done[s].seq, __ATOMIC_ACQUIRE) != R->seq[(size_t)s]) return false;
+    R->T_done[(size_t)s] = R->h_done[s].frame; R->err_done[(size_t)s] = R->h_done[s].error;
+    d->stream_T[(size_t)s] = R->T_done[(size_t)s];
+    R->busy[(size_t)s] = 0;
+    return true;
+}
+
+int jd_res_stop(jd_dec *d)
+{
+    if (!d || !d->res || !d->res->on) return JD_OK;
+    Resident *R = d->res;
+    hipLaunchKernelGGL(jd_res_exit_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_gmm, R->d_mail, R->n);
+    hipError_t e = hipStreamSynchronize(d->s_search);                  // (it also leaves by itself after RES_IDLE_TICKS)
+    (void)hipStreamSynchronize(d->s_gmm);
+    // (a cluster takes a command that is there before it looks at the exit request: whatever was posted is through)
+    bool lost = false;
+    for (int s = 0; s < R->n; ++s) if (!res_harvest(d, s)) { lost = true; R->busy[(size_t)s] = 0; d->stream_dirty[(size_t)s] = 1; }
+    R->on = false;
+    delete R->process_lock; R->process_lock = nullptr;
+    if (R->search_lock.owns_lock()) R->search_lock.unlock();
+    if (e != hipSuccess) return jd_fail(JD_EHIP, "the resident search kernel did not end: %s", hipGetErrorString(e));
+    if (lost) return jd_fail(JD_EHIP, "the resident search kernel ended with a command unanswered");
+    return JD_OK;
+}
+
+// streams [0, n_streams) of the decoder, likelihood buffers of rows_per_buf rows (two per stream)
+int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
+{
+    if (!d || n_streams < 1 || n_streams > d->max_streams || rows_per_buf < 1) return jd_fail(JD_EINVAL, "jd_res_start: bad argument");
+    if (d->net->lazy_dev || d->partial_interval > 0) return jd_fail(JD_ESTATE, "jd_res_start: not with a lazily composed network / partial traces");
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    rc = ensure_arenas(d);
+    if (rc) return rc;
+    pf_discard(d);
+    const int D = d->am->D, G = d->am->n_gmm;
+    const int rows = (rows_per_buf + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2;
+    if (d->res && (d->res->n != n_streams || d->res->rows != rows)) { if (d->res->on) { rc = jd_res_stop(d); if (rc) return rc; } res_free(d); }
+    if (!d->res) {
+        Resident *R = new Resident();
+        d->res = R;
+        R->n = n_streams; R->rows = rows;
+        const size_t tr = (size_t)n_streams * 2 * rows;
+        if (hipMalloc(&R->d_mail, (size_t)n_streams * sizeof(ResMail)) != hipSuccess ||
+            hipHostMalloc((void **)&R->h_done, (size_t)n_streams * sizeof(ResDone), hipHostMallocMapped) != hipSuccess ||
+            hipMalloc(&R->d_feat, tr * D * sizeof(float)) != hipSuccess || hipMalloc(&R->d_ll, tr * G * sizeof(float)) != hipSuccess ||
+            hipMalloc(&R->d_src, (size_t)rows * sizeof(int)) != hipSuccess ||
+            hipHostMalloc((void **)&R->h_stage, tr * D * sizeof(float)) != hipSuccess) {
+            res_free(d);
+            return jd_fail(JD_ENOMEM, "jd_res_start: no memory for %d streams x 2 x %d rows", n_streams, rows);
+        }
+        R->seq.assign((size_t)n_streams, 0u); R->T_posted.assign((size_t)n_streams, 0); R->T_done.assign((size_t)n_streams, 0);
+        R->slot_posted.assign((size_t)n_streams, 0); R->err_done.assign((size_t)n_streams, 0); R->busy.assign((size_t)n_streams, 0);
+        for (int t = 0; t < n_streams; ++t) R->T_done[(size_t)t] = R->T_posted[(size_t)t] = d->stream_T[(size_t)t];
+        std::vector<int> ident((size_t)rows);                          // the row table of every scoring launch: row r is frame r of what was staged
+        for (int r = 0; r < rows; ++r) ident[(size_t)r] = r;
+        HIPCHK(hipMemcpy(R->d_src, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    Resident *R = d->res;
+    if (R->on) return JD_OK;
+    const bool ne3 = d->am->max_n <= 5;
+    if (!d->occupancy_ok) {
+        int per_cu = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ne3 ? (const void *)k_resident<3> : (const void *)k_resident<6>, SNT, 0));
+        if (per_cu < WG_PER_CU) return jd_fail(JD_EHIP, "k_resident does not fit a CU the way its grid assumes");
+    }
+    // clusters: what the arenas allow, and a sixth of the chip left to the scoring, collection and finish kernels
+    const int cw_cap = (int)std::max<int64_t>(1, std::min<int64_t>(d->cap_slots / (64 * SW), d->cap_items / (512 * SW)));
+    // (the scoring of what the streams search: about 1.6 CUs per stream at their pace)
+    const int free_cus = std::min(d->n_cus / 2, std::max(40, (n_streams * 8) / 5));
+    R->Cw = std::max(1, std::min(std::min(d->max_cw, cw_cap), (d->n_cus * WG_PER_CU - free_cus) / n_streams));
+    if (R->Cw * n_streams > d->n_cus * WG_PER_CU) return jd_fail(JD_EINVAL, "jd_res_start: %d streams do not fit the device", n_streams);
+    memset(R->h_done, 0, (size_t)R->n * sizeof(ResDone));
+    std::fill(R->seq.begin(), R->seq.end(), 0u);
+    R->search_lock = std::unique_lock<std::mutex>(g_search_mu[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)]);
+    R->process_lock = new GpuLockGuard(d->device);
+    SearchArgs A;
+    memset(&A, 0, sizeof A);
+    A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = nullptr; A.n_work = R->n; A.Cw = R->Cw; A.n_slots = 0;
+    A.ll = R->d_ll; A.ll_stride = (long long)G; A.f0 = 0; A.f_end = 0x7fffffff;
+    A.status = d->d_status; A.dbg = nullptr; A.cells = nullptr; A.resident = nullptr; A.rebalance_at = 0; A.n_prio = 0;
+    hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->n);
+    if (ne3) hipLaunchKernelGGL(k_resident<3>, dim3((unsigned)(R->n * R->Cw)), dim3(SNT), 0, d->s_search, A, R->d_mail, R->h_done, R->Cw);
+    else hipLaunchKernelGGL(k_resident<6>, dim3((unsigned)(R->n * R->Cw)), dim3(SNT), 0, d->s_search, A, R->d_mail, R->h_done, R->Cw);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        delete R->process_lock; R->process_lock = nullptr; R->search_lock.unlock();
+        return jd_fail(JD_EHIP, "k_resident: %s", hipGetErrorString(e));
+    }
+    R->on = true;
+    if (getenv("JD_VERBOSE")) fprintf(stderr, "k_resident: %d streams, clusters of %d workgroups, %d rows per buffer\n", R->n, R->Cw, R->rows);
+    return JD_OK;
+}
+
+int jd_res_cluster(const jd_dec *d) { return (d && d->res) ? d->res->Cw : 0; }
+
+// IDecoder::init of stream s (idle): recognitionStart runs with the stream's next command
+int jd_res_init(jd_dec *d, int s)
+{
+    Resident *R = d->res;
+    if (!R || !R->on || s < 0 || s >= R->n) return jd_fail(JD_ESTATE, "jd_res_init: no resident kernel for stream %d", s);
+    if (d->stream_dirty[(size_t)s]) {                                  // (after an error: the wipe synchronises the device)
+        int rc = jd_res_stop(d);
+        if (rc) return rc;
+        rc = wipe_stream(d, s);
+        if (rc) return rc;
+        rc = jd_res_start(d, R->n, R->rows);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(jd_mark_init_kernel, dim3(1), dim3(64), 0, d->s_gmm, d->d_ctl, s, 1);
+    HIPCHK(hipGetLastError());
+    d->stream_T[(size_t)s] = 0; d->stream_started[(size_t)s] = 1;
+    R->T_posted[(size_t)s] = 0; R->T_done[(size_t)s] = 0; R->err_done[(size_t)s] = 0;
+    return JD_OK;
+}
+
+// Frames of stream s into its likelihood buffer `buf` (0 / 1, free): one upload from the buffer's own pinned staging
+// region, one scoring launch over its rows (asynchronous, on the side stream)
+int jd_res_stage(jd_dec *d, int s, int buf, const float *frames, int n_frames)
+{
+    Resident *R = d->res;
+    if (!R || !R->on) return jd_fail(JD_ESTATE, "jd_res_stage: no resident kernel");
+    if (s < 0 || s >= R->n || (buf != 0 && buf != 1) || n_frames < 0 || n_frames > R->rows || (n_frames > 0 && !frames))
+        return jd_fail(JD_EINVAL, "jd_res_stage: bad argument");
+    if (n_frames == 0) return JD_OK;
+    const int D = d->am->D, G = d->am->n_gmm;
+    const size_t r0 = ((size_t)s * 2 + (size_t)buf) * (size_t)R->rows;
+    float *hf = (float *)R->h_stage + r0 * D;
+    memcpy(hf, frames, (size_t)n_frames * D * sizeof(float));
+    HIPCHK(hipMemcpyAsync(R->d_feat + r0 * D, hf, (size_t)n_frames * D * sizeof(float), hipMemcpyHostToDevice, d->s_gmm));
+    return launch_gmm(d->am, d->amb, R->d_feat + r0 * D, R->d_src, n_frames, R->d_ll + r0 * G, d->s_gmm);
+}
+
+// The command "frames up to T + n_frames are scored in buffer buf" for stream s (idle), behind what has been staged
+int jd_res_post(jd_dec *d, int s, int buf, int n_frames)
+{
+    Resident *R = d->res;
+    if (!R || !R->on || s < 0 || s >= R->n) return jd_fail(JD_ESTATE, "jd_res_post: no resident kernel for stream %d", s);
+    const int T0 = R->T_done[(size_t)s], T1 = T0 + n_frames;
+    const long long slot = ((long long)s * 2 + buf) * R->rows - T0;    // (k_search reads row  slot + f: see jd_streams_push)
+    R->seq[(size_t)s] += 1;
+    R->busy[(size_t)s] = 1;
+    R->T_posted[(size_t)s] = T1; R->slot_posted[(size_t)s] = (int)slot;
+    hipLaunchKernelGGL(jd_res_post_kernel, dim3(1), dim3(64), 0, d->s_gmm, d->d_ctl, R->d_mail, s, T1, R->seq[(size_t)s], (int)slot);
+    HIPCHK(hipGetLastError());
+    return JD_OK;
+}
+
+// Where stream s stands: *idle = its last command is through (then *frame = frames processed, *error = StreamCtl::error,
+// *stopped = it stopped short of what was posted - a Path collection is due: jd_res_collect)
+int jd_res_poll(jd_dec *d, int s, int *idle, int *frame, int *error, int *stopped)
+{
+    Resident *R = d->res;
+    if (!R || !R->on || s < 0 || s >= R->n) return jd_fail(JD_ESTATE, "jd_res_poll: no resident kernel for stream %d", s);
+    const bool through = res_harvest(d, s);
+    *idle = through ? 1 : 0;
+    if (frame) *frame = R->T_done[(size_t)s];
+    if (error) *error = R->err_done[(size_t)s];
+    if (stopped) *stopped = (through && R->err_done[(size_t)s] == 0 && R->T_done[(size_t)s] < R->T_posted[(size_t)s]) ? 1 : 0;
+    if (through) return JD_OK;
+    if (__atomic_load_n(&R->h_done[s].left, __ATOMIC_ACQUIRE)) return jd_fail(JD_ESTATE, "the resident search kernel has ended (no command for 5 s, or a lost workgroup)");
+    return JD_OK;
+}
+
+// collectPaths for stream s (idle, stopped), then the rest of its command again
+int jd_res_collect(jd_dec *d, int s)
+{
+    Resident *R = d->res;
+    if (!R || !R->on || s < 0 || s >= R->n) return jd_fail(JD_ESTATE, "jd_res_collect: no resident kernel for stream %d", s);
+    launch_gc(d->C, d->d_ctl, d->d_streams, nullptr, 1, s, d->am->max_n <= 5, std::max(8, d->n_cus / 6), d->s_gmm);
+    HIPCHK(hipGetLastError());
+    R->seq[(size_t)s] += 1;
+    R->busy[(size_t)s] = 1;
+    hipLaunchKernelGGL(jd_res_post_kernel, dim3(1), dim3(64), 0, d->s_gmm, d->d_ctl, R->d_mail, s, R->T_posted[(size_t)s], R->seq[(size_t)s],
+                       R->slot_posted[(size_t)s]);
+    HIPCHK(hipGetLastError());
+    return JD_OK;
+}
+
+// IDecoder::finish of stream s (idle, every frame it was given processed)
+int jd_res_finish(jd_dec *d, int s, jd_hyp *out)
+{
+    Resident *R = d->res;
+    if (!R || !R->on || s < 0 || s >= R->n || !out) return jd_fail(JD_ESTATE, "jd_res_finish: no resident kernel for stream %d", s);
+    hipLaunchKernelGGL(jd_finish_kernel, dim3(1), dim3(64), 0, d->s_gmm, d->d_ctl, d->d_streams, s, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(d->s_gmm));
+    std::vector<jd_hyp> tmp((size_t)d->max_streams);
+    const int rc = fetch_results(d, s, 1, tmp.data(), s);
+    *out = tmp[(size_t)s];
+    return rc;
 }
 
 // collectPaths runs (WFSTDecoderLite.cpp:362) of stream s since its init, and the frame after which the last one ran

@@ -69,4 +69,14 @@ struct jd_am {
 
 int jd_fail(int code, const char *fmt, ...);      // sets jd_last_error(), returns code
 
+// The resident search kernel of a broker (jd_device.hip, jd_resident.h) - internal: jd_broker.cpp drives it.
+int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf);
+int jd_res_stop(jd_dec *d);
+int jd_res_cluster(const jd_dec *d);
+int jd_res_init(jd_dec *d, int s);
+int jd_res_stage(jd_dec *d, int s, int buf, const float *frames, int n_frames);
+int jd_res_post(jd_dec *d, int s, int buf, int n_frames);
+int jd_res_poll(jd_dec *d, int s, int *idle, int *frame, int *error, int *stopped);
+int jd_res_collect(jd_dec *d, int s);
+int jd_res_finish(jd_dec *d, int s, jd_hyp *out);
 #endif

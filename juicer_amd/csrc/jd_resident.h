@@ -1,0 +1,122 @@
+// jd_resident.h - the search kernel that STAYS (included by jd_device.hip behind jd_search.h; gfx950 only).
+//
+// k_search is launched per call and lives as long as the longest stream of the call has frames.  A broker that serves
+// many serial IDecoder callers (jd_broker.cpp) pays for that with ticks: every launch waits for its longest stream,
+// streams whose caller is between two utterances sit a launch out, and the host's share of a tick is time the chip
+// idles.  k_resident is the same per-stream machinery (run_stream: one cluster of workgroups per stream, phases and
+// cluster barriers as in k_search) under a loop that takes its work from a MAILBOX per stream: the host posts "frames
+// up to T are scored, their rows start at this slot" (jd_res_post_kernel, enqueued behind the scoring kernel on the side
+// stream), the stream's cluster runs them and reports where it stands in a host-mapped word - every stream at its own
+// pace, no common launch to wait for.  Between two commands other kernels touch the stream's state (recognitionStart's
+// mark, the Path collection, recognitionFinish's walk, the scoring of the next rows): a command begins with an acquire
+// at agent scope (vector L1 and stale L2 lines dropped, the scalar cache too) and ends with a release before anybody is told.
+#pragma once
+
+struct __align__(128) ResMail {
+    unsigned long long word;   // (sequence number << 32) | (likelihood slot as an unsigned 32-bit word): written by jd_res_post_kernel
+    int exit_req;              // != 0: leave the kernel
+    int pad[29];
+};
+struct ResDone {               // host-mapped, one per stream: written by workgroup 0 of the stream's cluster behind every command
+    unsigned seq;              // the command that is through (written last)
+    int frame;                 // StreamCtl::frame behind it: < T when the stream stopped for a Path collection
+    int error;                 // StreamCtl::error
+    int left;                  // 1: the cluster has left the kernel (exit request, or nobody posted anything for RES_IDLE_TICKS)
+};
+#define RES_IDLE_TICKS 500000000LL      // 5 s at 100 MHz without a command: the kernel ends by itself
+
+__global__ void jd_res_post_kernel(StreamCtl *ctl, ResMail *mail, int s, int T, unsigned seq, int ll_slot)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl[s].T = T;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&mail[s].word, ((unsigned long long)seq << 32) | (unsigned)ll_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ void jd_res_exit_kernel(ResMail *mail, int n)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) __hip_atomic_store(&mail[s].exit_req, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void jd_res_reset_kernel(StreamCtl *ctl, ResMail *mail, int n)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) { mail[s].word = 0ULL; mail[s].exit_req = 0; ctl[s].bar = 0u; ctl[s].xbar = 0u; ctl[s].xmask = 0u; ctl[s].stop_req = 0; }
+}
+
+// grid = n_streams x Cw workgroups: workgroup b serves stream b / Cw as member b % Cw of its cluster (agent-scope flavour:
+// nothing is assumed about where the workgroups run).  All of them resident at once, like k_search's.
+template <int NE>
+__global__ JD_KBOUNDS void k_resident(SearchArgs A, ResMail *mail, ResDone *done, int Cw)
+{
+    __shared__ SearchShared sh;
+    __shared__ unsigned long long sh_word;
+    __shared__ int sh_exit;
+    const int s = (int)(blockIdx.x / (unsigned)Cw), jw = (int)(blockIdx.x % (unsigned)Cw);
+    const int tid = threadIdx.x;
+    StreamCtl &c = A.ctl[s];
+    unsigned seen = 0u, nbar = 0u;
+    if (tid == 0) sh.abort = 0;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) {
+            const long long t_idle = wall_clock64() + RES_IDLE_TICKS;
+            unsigned long long w;
+            int ex = 0;
+            unsigned spins = 0;
+            for (;;) {
+                w = __hip_atomic_load(&mail[s].word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w >> 32) != seen) break;
+                ex = __hip_atomic_load(&mail[s].exit_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ex) break;
+                __builtin_amdgcn_s_sleep(16);
+                if ((++spins & 255u) == 0 && wall_clock64() > t_idle) { ex = 1; break; }
+            }
+            sh_word = w; sh_exit = ex;
+        }
+        __syncthreads();
+        const unsigned long long w = sh_word;
+        const int ex = sh_exit;
+        __syncthreads();
+        if (ex) {
+            if (jw == 0 && tid == 0) __hip_atomic_store(&done[s].left, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        const unsigned seq = (unsigned)(w >> 32);
+        const int ll_slot = (int)(unsigned)(w & 0xffffffffULL);
+        // what other kernels wrote since the last command - frames available, the likelihood rows, arenas swapped by a
+        // collection, recognitionStart's mark - is read from memory, not from what this CU or this XCD's L2 still holds
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_s_dcache_inv();
+        run_stream<NE, false, false>(A, sh, s, ll_slot, jw, Cw, true, &nbar);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // every workgroup of the cluster is through with the command (its end-of-launch words are written) before the host
+        // hears of it: the collection and the finish kernels read them
+        if (Cw > 1 && sh.abort == 0) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            ++nbar;
+            if (tid == 0) {
+                constexpr bool XL_ = false;
+                GADD(&c.bar, 1u);
+                const unsigned target = nbar * (unsigned)Cw;
+                const long long t_lim = wall_clock64() + 200000000LL;          // 2 s
+                unsigned spins = 0;
+                while (CL(&c.bar) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023u) == 0 && wall_clock64() > t_lim) break;
+                }
+            }
+            __syncthreads();
+        }
+        if (jw == 0 && tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int fr = __hip_atomic_load(&c.frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int er = __hip_atomic_load(&c.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            done[s].frame = fr; done[s].error = er;
+            __hip_atomic_store(&done[s].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        seen = seq;
+    }
+}

@@ -1326,8 +1326,11 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
 
 // ------------------------------------------------------------------ one stream, one launch
 
+// nbar_io (or null): the cluster's barrier count so far, when the stream's barrier word is NOT zeroed between calls (the
+// resident kernel, jd_resident.h); updated on every normal return.
 template <int NE, bool XL, bool LZY>
-__device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw, bool prio)
+__device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh, int s, int ll_slot, int jw, int Cw, bool prio,
+                                           unsigned *nbar_io = nullptr)
 {
     constexpr bool XL_ = XL;
     typedef RecLayout<NE> RL;
@@ -1385,7 +1388,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
     }
     if (use_hist) for (int b = tid; b < C.hist_nbins; b += SNT) sh.hist[b] = 0;
     __syncthreads();
-    unsigned nbar = 0;
+    unsigned nbar = nbar_io ? *nbar_io : 0u;
     const long long t_limit = wall_clock64() + 3000000000LL;           // 30 s at 100 MHz: a lost workgroup, not a slow one
     if (XL && Cw > 1) {
         // XCD-local launch: nothing promises where workgroups run, so the cluster first makes sure it does
@@ -1690,6 +1693,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         return;
     }
     // ---- end of the launch: persist the stream state (read by the next launch / the host kernels)
+    if (nbar_io) *nbar_io = nbar;
     if (lane == 0) CS((GAS int *)S.item_end + gw, my_item_end);
     if (tid == 0) {
         for (int k = 0; k < ST_N; ++k) if (sh.acc[k]) atomicAdd((unsigned long long *)&c.st[k], (unsigned long long)sh.acc[k]);

@@ -76,7 +76,9 @@ def test_broker_threads_match_batch(small):
     pushes = sum((feats[u].shape[0] + (23 + 7 * (u % 6)) - 1) // (23 + 7 * (u % 6)) for u in range(len(feats)))
     print("broker: %d ticks for %d pushes, %.1f streams per tick" % (st["ticks"], pushes, st["stream_ticks"] / max(st["ticks"], 1)))
     assert st["frames"] == sum(f.shape[0] for f in feats)
-    assert st["ticks"] < pushes and st["stream_ticks"] > st["ticks"]   # launches were shared
+    assert st["ticks"] < pushes                                        # pushes were coalesced
+    if not st["resident"]:
+        assert st["stream_ticks"] > st["ticks"]                        # launches were shared
     # errors come back through the client that caused them: a push outside init .. finish
     c = broker.open()
     with pytest.raises(capi.JuicerAmdError):
