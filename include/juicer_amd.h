@@ -338,7 +338,10 @@ typedef struct jd_broker_stats {
     int64_t us_idle, us_coalesce;                  /* worker thread: waiting for work; waiting for the other clients' frames */
     int64_t us_init, us_push, us_finish;           /* ... inside jd_stream_init / jd_streams_push / jd_stream_finish */
     int64_t us_search;                             /* of us_push: the search launches (device time) */
-    int64_t resident;                              /* 1: the worker drives the resident search kernel - a "tick" is then one stream's chunk */
+    int64_t resident;                              /* > 0: the worker drives the resident search kernel, clusters of this many workgroups -
+                                                      a "tick" is then one stream's chunk, us_search the time from its post to its report,
+                                                      us_coalesce the time its cluster spent on it (device clock), us_idle what the cluster waited for the next
+                                                      chunk of the same utterance, us_push the staging calls, us_finish the result fetches */
 } jd_broker_stats;
 int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients);   /* n_clients <= the decoder's max_streams */
 void jd_broker_destroy(jd_broker *b);                                    /* (the decoder is the caller's to destroy, afterwards) */

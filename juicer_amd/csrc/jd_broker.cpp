@@ -38,6 +38,9 @@ struct Client {
     bool running = false; int run_buf = 0;
     bool fresh = false;                            // initialised and nothing posted yet (recognitionStart is still to run)
     bool finishing = false;                        // its result is being fetched (the finisher thread)
+    std::chrono::steady_clock::time_point t_post, t_idle;   // (statistics) its last command posted / found through
+    bool was_idle = false;
+    std::vector<float> taken;                      // frames on their way into a likelihood buffer
 };
 }  // namespace
 
@@ -202,7 +205,8 @@ static void broker_loop_resident(jd_broker *b)
 {
     std::unique_lock<std::mutex> lk(b->mu);
     auto now = []() { return std::chrono::steady_clock::now(); };
-    std::vector<float> taken;
+    std::vector<int> st_s, st_b, st_n;                                // this round's staging: streams, buffers, frames
+    std::vector<const float *> st_f;
     bool on = false;
     auto idle_since = now();
     auto fail_all = [&](int rc, const std::string &msg) {              // (lk held)
@@ -237,6 +241,37 @@ static void broker_loop_resident(jd_broker *b)
             on = true;
         }
         bool progress = false;
+        auto try_post = [&](int i) {                                   // (lk held)
+            Client &c = b->clients[(size_t)i];
+            int rc = JD_OK;
+            // 4. the next chunk to the cluster (a finish without frames still runs recognitionStart: a chunk of none)
+            if (!c.running && c.inited && (c.n_staged > 0 || (c.fresh && c.want_finish && c.pending.empty()))) {
+                const int buf = c.n_staged > 0 ? c.staged_buf[0] : 0, nf = c.n_staged > 0 ? c.staged_n[0] : 0;
+                lk.unlock();
+                rc = jd_res_post(b->dec, i, buf, nf);
+                const std::string m = rc ? jd_last_error() : "";
+                lk.lock();
+                if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
+                if (c.n_staged > 0) { c.staged_buf[0] = c.staged_buf[1]; c.staged_n[0] = c.staged_n[1]; c.n_staged -= 1; }
+                if (!rc) {
+                    c.running = true; c.run_buf = buf; c.fresh = false; b->stats.ticks += 1; b->stats.frames += nf; b->stats.stream_ticks += 1;
+                    c.t_post = now();
+                    // (statistics: what a cluster waited between two chunks of ONE utterance)
+                    if (c.was_idle) b->stats.us_idle += (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(c.t_post - c.t_idle).count();
+                }
+                progress = true;
+            }
+        };
+        auto try_finish = [&](int i) {                                 // (lk held)
+            Client &c = b->clients[(size_t)i];
+            // 5. IDecoder::finish (handed to the finisher thread)
+            if (!c.running && c.n_staged == 0 && c.inited && !c.fresh && c.want_finish && c.pending.empty()) {
+                c.finishing = true;
+                b->fin_q.push_back(i);
+                b->cv_fin.notify_one();
+                progress = true;
+            }
+        };
         for (int i = 0; i < b->n_clients; ++i) {
             Client &c = b->clients[(size_t)i];
             if (!c.open || c.finishing) continue;
@@ -250,7 +285,11 @@ static void broker_loop_resident(jd_broker *b)
                 const std::string m = rc ? jd_last_error() : "";
                 lk.lock();
                 if (rc) { fail_all(rc, m); on = false; lk.unlock(); (void)jd_res_stop(b->dec); lk.lock(); break; }
-                if (idle) { c.running = false; progress = true; b->cv_done.notify_all(); }
+                if (idle) {
+                    c.running = false; progress = true; b->cv_done.notify_all();
+                    c.t_idle = now(); c.was_idle = true;
+                    b->stats.us_search += (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(c.t_idle - c.t_post).count();
+                }
             }
             // 2. IDecoder::init
             if (!c.running && c.n_staged == 0 && c.want_init) {
@@ -258,12 +297,13 @@ static void broker_loop_resident(jd_broker *b)
                 rc = jd_res_init(b->dec, i);
                 const std::string m = rc ? jd_last_error() : "";
                 lk.lock();
-                c.want_init = false; c.inited = rc == JD_OK; c.fresh = rc == JD_OK;
+                c.want_init = false; c.inited = rc == JD_OK; c.fresh = rc == JD_OK; c.was_idle = false;
                 if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
                 b->cv_done.notify_all();
                 progress = true;
             }
-            // 3. frames into a free likelihood buffer
+            try_post(i);                                                // (what is scored already goes first: a word in host memory)
+            // 3. frames for a free likelihood buffer: taken here, scored below - one launch for all the streams of this round
             if (c.inited && !c.want_init && !c.pending.empty() && c.n_staged + (c.running ? 1 : 0) < 2) {
                 int buf = 0;
                 if (c.running && c.run_buf == 0) buf = 1;
@@ -271,37 +311,33 @@ static void broker_loop_resident(jd_broker *b)
                 if (!(c.running && c.run_buf == buf)) {
                     const size_t have = c.pending.size() / (size_t)b->D;
                     const size_t take = std::min(have, (size_t)b->max_tick_frames);
-                    taken.assign(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
+                    c.taken.assign(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
                     c.pending.erase(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
-                    lk.unlock();
-                    b->cv_done.notify_all();                           // (pushes that waited for room)
-                    rc = jd_res_stage(b->dec, i, buf, taken.data(), (int)take);
-                    const std::string m = rc ? jd_last_error() : "";
-                    lk.lock();
-                    if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
-                    else if (!rc) { c.staged_buf[c.n_staged] = buf; c.staged_n[c.n_staged] = (int)take; c.n_staged += 1; }
-                    progress = true;
+                    st_s.push_back(i); st_b.push_back(buf); st_f.push_back(c.taken.data()); st_n.push_back((int)take);
                 }
             }
-            // 4. the next chunk to the cluster (a finish without frames still runs recognitionStart: a chunk of none)
-            if (!c.running && c.inited && (c.n_staged > 0 || (c.fresh && c.want_finish && c.pending.empty()))) {
-                const int buf = c.n_staged > 0 ? c.staged_buf[0] : 0, nf = c.n_staged > 0 ? c.staged_n[0] : 0;
-                lk.unlock();
-                rc = jd_res_post(b->dec, i, buf, nf);
-                const std::string m = rc ? jd_last_error() : "";
-                lk.lock();
-                if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
-                if (c.n_staged > 0) { c.staged_buf[0] = c.staged_buf[1]; c.staged_n[0] = c.staged_n[1]; c.n_staged -= 1; }
-                if (!rc) { c.running = true; c.run_buf = buf; c.fresh = false; b->stats.ticks += 1; b->stats.frames += nf; b->stats.stream_ticks += 1; }
-                progress = true;
+        }
+        if (!st_s.empty()) {
+            lk.unlock();
+            b->cv_done.notify_all();                                   // (pushes that waited for room)
+            const auto t_st = now();
+            const int rc = jd_res_stage_many(b->dec, (int)st_s.size(), st_s.data(), st_b.data(), st_f.data(), st_n.data());
+            const std::string m = rc ? jd_last_error() : "";
+            lk.lock();
+            b->stats.us_push += (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(now() - t_st).count();
+            for (size_t k = 0; k < st_s.size(); ++k) {
+                Client &c = b->clients[(size_t)st_s[k]];
+                if (rc) { if (c.err == JD_OK) { c.err = rc; c.errmsg = m; } }
+                else { c.staged_buf[c.n_staged] = st_b[k]; c.staged_n[c.n_staged] = st_n[k]; c.n_staged += 1; }
             }
-            // 5. IDecoder::finish (handed to the finisher thread)
-            if (!c.running && c.n_staged == 0 && c.inited && !c.fresh && c.want_finish && c.pending.empty()) {
-                c.finishing = true;
-                b->fin_q.push_back(i);
-                b->cv_fin.notify_one();
-                progress = true;
-            }
+            st_s.clear(); st_b.clear(); st_f.clear(); st_n.clear();
+            progress = true;
+        }
+        for (int i = 0; i < b->n_clients; ++i) {
+            const Client &c = b->clients[(size_t)i];
+            if (!c.open || c.finishing) continue;
+            try_post(i);
+            try_finish(i);
         }
         if (progress) idle_since = now();
         else {
@@ -325,9 +361,11 @@ static void broker_finisher(jd_broker *b)
         jd_hyp res;
         memset(&res, 0, sizeof res);
         lk.unlock();
+        const auto t_f = std::chrono::steady_clock::now();
         const int rc = jd_res_finish(b->dec, i, &res);
         const std::string m = rc ? jd_last_error() : "";
         lk.lock();
+        b->stats.us_finish += (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_f).count();
         Client &c = b->clients[(size_t)i];
         if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
         c.want_finish = false; c.inited = false; c.finishing = false; c.result = res;
@@ -351,10 +389,8 @@ extern "C" int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients)
     b->max_pending_frames = 4 * b->max_tick_frames;
     // the resident search kernel instead of ticks (JD_BROKER_RESIDENT=0: ticks): not with a lazily composed network or
     // partial traces - jd_res_start says so and the clients' first calls would fail, so those decoders keep the ticks
-    // ... and not with more clients than the chip has room for clusters AND their scoring side by side: from about 48 streams on
-    // a launch that takes every CU and the scoring in turn (ticks) does better than a static split (measured: 64 callers
-    // 0.83 of the batch rate against 0.57; 32 callers 0.57 against 0.80)
-    b->resident = n_clients <= 40;
+    // (up to 64 clients: the ready list of a scoring launch and the chip's room for clusters and their scoring side by side)
+    b->resident = n_clients <= 64;
     if (const char *e = getenv("JD_BROKER_RESIDENT")) b->resident = atoi(e) != 0;
     if (b->resident && !getenv("JD_BROKER_TICK_FRAMES")) { b->max_tick_frames = 256; b->max_pending_frames = 4 * b->max_tick_frames; }   // (whole scoring tiles)
     if (b->resident && jd_res_start(dec, n_clients, b->max_tick_frames) != JD_OK) b->resident = false;
@@ -450,6 +486,7 @@ extern "C" int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out)
     if (!b || !out) return jd_fail(JD_EINVAL, "jd_broker_get_stats: bad argument");
     std::lock_guard<std::mutex> lk(b->mu);
     *out = b->stats;
-    out->resident = b->resident ? 1 : 0;
+    out->resident = b->resident ? jd_res_cluster(b->dec) : 0;
+    if (b->resident) out->us_coalesce = jd_res_run_us(b->dec);      // (the clusters' own time on their chunks)
     return JD_OK;
 }

@@ -162,8 +162,10 @@ static void free_am_gmm(AmDevBuf &b)
 // scoring cost the search 20 ms).  A bounded grid scores in the background instead.
 // skip_unused: row_src marks unused rows with -1 in whole-tile runs (decode_wave's stream slots).
 // used_row_tiles >= 0: the row tiles that are not skipped (else: all of them)
+// rt_base (device, or null) / n_rt_list: score these row tiles (first rows) only - D = 39
 static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, const int *d_row_src, int n_rows,
-                      float *d_ll, hipStream_t st, int max_blocks = 0, int skip_unused = 0, int used_row_tiles = -1)
+                      float *d_ll, hipStream_t st, int max_blocks = 0, int skip_unused = 0, int used_row_tiles = -1,
+                      const int *rt_base = nullptr, int n_rt_list = 0)
 {
     if (n_rows <= 0) return JD_OK;
     if (a->hybrid) {
@@ -174,7 +176,8 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
         return JD_OK;
     }
     const int rows_per_tile = (a->D == 39) ? GMM_ROWS2 : GMM_ROWS;
-    const long long row_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
+    if (rt_base && a->D != 39) return jd_fail(JD_EINVAL, "launch_gmm: tile lists are the D = 39 kernel's");
+    const long long row_tiles = rt_base ? n_rt_list : (n_rows + rows_per_tile - 1) / rows_per_tile;
     long long tiles = row_tiles * ((a->n_gmm + GMM_GT - 1) / GMM_GT);
     // few rows (a streaming push, a tick of the broker): tiles of 16 states, four times as many and a quarter as long
     const bool small_tiles = a->D == 39 && (used_row_tiles >= 0 ? (long long)used_row_tiles * ((a->n_gmm + GMM_GT - 1) / GMM_GT) : tiles) < 1024;
@@ -184,10 +187,10 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
         const size_t sm = 130 * sizeof(JdLogTab) + 32 * sizeof(unsigned long long) + (size_t)GMM_ROWS2 * std::max(39, GMM_GT + 1) * sizeof(float);
         if (small_tiles)
             hipLaunchKernelGGL(jd_gmm_kernel39<GMM_GT_SMALL>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
-                               b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab);
+                               b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab, rt_base, n_rt_list);
         else
             hipLaunchKernelGGL(jd_gmm_kernel39<GMM_GT>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
-                               b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab);
+                               b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, b.logtab, rt_base, n_rt_list);
     } else {
         const int dp = a->D | 1;
         const size_t sm = (size_t)(GMM_ROWS * dp + GMM_ROWS * (GMM_GT + 1)) * sizeof(float);
@@ -2290,11 +2293,18 @@ extern "C" int jd_streams_push(jd_dec *d, int32_t n, const int32_t *streams, con
 // The resident search kernel (jd_resident.h) and its host side: what jd_broker.cpp drives instead of ticks.
 // While it runs it owns the device's search lock (this process) and the GPU's file lock (other processes); nothing here
 // allocates or frees device memory or synchronises the device - either would wait for the kernel.
+#define RES_RING 256
+#define RES_RING_W 256
 struct Resident {
     bool on = false;
     int n = 0, Cw = 0, rows = 0;                       // streams [0, n), workgroups per cluster, rows per likelihood buffer
     ResMail *d_mail = nullptr;
-    ResDone *h_done = nullptr;                         // host-mapped
+    ResPost *h_post = nullptr;                         // host-mapped: the commands
+    ResDone *h_done = nullptr;                         // host-mapped: the reports
+    unsigned *d_ready = nullptr;                       // per stream: how far the side stream has come for it
+    std::vector<unsigned> rid;                         // ... and the last number enqueued for it
+    int *h_ring = nullptr, *d_ring = nullptr;          // row-tile lists of the scoring launches (RES_RING slots of RES_RING_W)
+    int ring_turn = 0;
     float *d_feat = nullptr, *d_ll = nullptr;          // [n][2][rows] x D / x G
     int *d_src = nullptr;
     char *h_stage = nullptr;                           // pinned: the features of every buffer, [n][2][rows] x D
@@ -2302,6 +2312,7 @@ struct Resident {
     std::vector<int> T_posted, T_done, err_done;
     std::vector<int> slot_posted;
     std::vector<char> busy;                            // a command is posted and its report not yet taken
+    long long run_ticks = 0;                           // (statistics) what the clusters spent on their commands, 100 MHz ticks
     std::unique_lock<std::mutex> search_lock;
     GpuLockGuard *process_lock = nullptr;
 };
@@ -2313,7 +2324,11 @@ static void res_free(jd_dec *d)
     Resident *R = d->res;
     if (!R) return;
     if (R->d_mail) (void)hipFree(R->d_mail);
+    if (R->h_post) (void)hipHostFree(R->h_post);
     if (R->h_done) (void)hipHostFree(R->h_done);
+    if (R->d_ready) (void)hipFree(R->d_ready);
+    if (R->h_ring) (void)hipHostFree(R->h_ring);
+    if (R->d_ring) (void)hipFree(R->d_ring);
     if (R->d_feat) (void)hipFree(R->d_feat);
     if (R->d_ll) (void)hipFree(R->d_ll);
     if (R->d_src) (void)hipFree(R->d_src);
@@ -2329,6 +2344,7 @@ static bool res_harvest(jd_dec *d, int s)
     if (!R->busy[(size_t)s]) return true;
     if (__atomic_load_n(&R->h_done[s].seq, __ATOMIC_ACQUIRE) != R->seq[(size_t)s]) return false;
     R->T_done[(size_t)s] = R->h_done[s].frame; R->err_done[(size_t)s] = R->h_done[s].error;
+    R->run_ticks += R->h_done[s].run_ticks;
     d->stream_T[(size_t)s] = R->T_done[(size_t)s];
     R->busy[(size_t)s] = 0;
     return true;
@@ -2338,7 +2354,7 @@ int jd_res_stop(jd_dec *d)
 {
     if (!d || !d->res || !d->res->on) return JD_OK;
     Resident *R = d->res;
-    hipLaunchKernelGGL(jd_res_exit_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_gmm, R->d_mail, R->n);
+    for (int s = 0; s < R->n; ++s) __atomic_store_n(&R->h_post[s].exit_req, 1, __ATOMIC_RELEASE);
     hipError_t e = hipStreamSynchronize(d->s_search);                  // (it also leaves by itself after RES_IDLE_TICKS)
     (void)hipStreamSynchronize(d->s_gmm);
     // (a cluster takes a command that is there before it looks at the exit request: whatever was posted is through)
@@ -2370,10 +2386,18 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
         d->res = R;
         R->n = n_streams; R->rows = rows;
         const size_t tr = (size_t)n_streams * 2 * rows;
+        if (n_streams > 64 || 2 * n_streams * ((rows + GMM_ROWS2 - 1) / GMM_ROWS2) > RES_RING_W) {
+            res_free(d);
+            return jd_fail(JD_EINVAL, "jd_res_start: at most 64 streams and %d row tiles per scoring launch", RES_RING_W);
+        }
         if (hipMalloc(&R->d_mail, (size_t)n_streams * sizeof(ResMail)) != hipSuccess ||
+            hipHostMalloc((void **)&R->h_post, (size_t)n_streams * sizeof(ResPost), hipHostMallocMapped) != hipSuccess ||
             hipHostMalloc((void **)&R->h_done, (size_t)n_streams * sizeof(ResDone), hipHostMallocMapped) != hipSuccess ||
+            hipMalloc(&R->d_ready, (size_t)n_streams * sizeof(unsigned)) != hipSuccess ||
+            hipHostMalloc((void **)&R->h_ring, (size_t)RES_RING * RES_RING_W * sizeof(int)) != hipSuccess ||
+            hipMalloc(&R->d_ring, (size_t)RES_RING * RES_RING_W * sizeof(int)) != hipSuccess ||
             hipMalloc(&R->d_feat, tr * D * sizeof(float)) != hipSuccess || hipMalloc(&R->d_ll, tr * G * sizeof(float)) != hipSuccess ||
-            hipMalloc(&R->d_src, (size_t)rows * sizeof(int)) != hipSuccess ||
+            hipMalloc(&R->d_src, tr * sizeof(int)) != hipSuccess ||
             hipHostMalloc((void **)&R->h_stage, tr * D * sizeof(float)) != hipSuccess) {
             res_free(d);
             return jd_fail(JD_ENOMEM, "jd_res_start: no memory for %d streams x 2 x %d rows", n_streams, rows);
@@ -2381,8 +2405,9 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
         R->seq.assign((size_t)n_streams, 0u); R->T_posted.assign((size_t)n_streams, 0); R->T_done.assign((size_t)n_streams, 0);
         R->slot_posted.assign((size_t)n_streams, 0); R->err_done.assign((size_t)n_streams, 0); R->busy.assign((size_t)n_streams, 0);
         for (int t = 0; t < n_streams; ++t) R->T_done[(size_t)t] = R->T_posted[(size_t)t] = d->stream_T[(size_t)t];
-        std::vector<int> ident((size_t)rows);                          // the row table of every scoring launch: row r is frame r of what was staged
-        for (int r = 0; r < rows; ++r) ident[(size_t)r] = r;
+        R->rid.assign((size_t)n_streams, 0u);
+        std::vector<int> ident(tr);                                    // the row table of every scoring launch: row r of the table is row r of the features
+        for (size_t r = 0; r < tr; ++r) ident[r] = (int)r;
         HIPCHK(hipMemcpy(R->d_src, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     Resident *R = d->res;
@@ -2400,7 +2425,9 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     R->Cw = std::max(1, std::min(std::min(d->max_cw, cw_cap), (d->n_cus * WG_PER_CU - free_cus) / n_streams));
     if (R->Cw * n_streams > d->n_cus * WG_PER_CU) return jd_fail(JD_EINVAL, "jd_res_start: %d streams do not fit the device", n_streams);
     memset(R->h_done, 0, (size_t)R->n * sizeof(ResDone));
+    memset(R->h_post, 0, (size_t)R->n * sizeof(ResPost));
     std::fill(R->seq.begin(), R->seq.end(), 0u);
+    std::fill(R->rid.begin(), R->rid.end(), 0u);
     R->search_lock = std::unique_lock<std::mutex>(g_search_mu[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)]);
     R->process_lock = new GpuLockGuard(d->device);
     SearchArgs A;
@@ -2408,9 +2435,9 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = nullptr; A.n_work = R->n; A.Cw = R->Cw; A.n_slots = 0;
     A.ll = R->d_ll; A.ll_stride = (long long)G; A.f0 = 0; A.f_end = 0x7fffffff;
     A.status = d->d_status; A.dbg = nullptr; A.cells = nullptr; A.resident = nullptr; A.rebalance_at = 0; A.n_prio = 0;
-    hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->n);
-    if (ne3) hipLaunchKernelGGL(k_resident<3>, dim3((unsigned)(R->n * R->Cw)), dim3(SNT), 0, d->s_search, A, R->d_mail, R->h_done, R->Cw);
-    else hipLaunchKernelGGL(k_resident<6>, dim3((unsigned)(R->n * R->Cw)), dim3(SNT), 0, d->s_search, A, R->d_mail, R->h_done, R->Cw);
+    hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->d_ready, R->n);
+    if (ne3) hipLaunchKernelGGL(k_resident<3>, dim3((unsigned)(R->n * R->Cw)), dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
+    else hipLaunchKernelGGL(k_resident<6>, dim3((unsigned)(R->n * R->Cw)), dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         delete R->process_lock; R->process_lock = nullptr; R->search_lock.unlock();
@@ -2422,6 +2449,21 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
 }
 
 int jd_res_cluster(const jd_dec *d) { return (d && d->res) ? d->res->Cw : 0; }
+long long jd_res_run_us(const jd_dec *d) { return (d && d->res) ? d->res->run_ticks / 100 : 0; }
+
+// "the side stream has come this far" for these streams: a new ready number each, behind everything enqueued so far
+static int res_bump(jd_dec *d, int n, const int *streams)
+{
+    Resident *R = d->res;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        ReadyList L;
+        L.n = std::min(64, n - i0);
+        for (int i = 0; i < L.n; ++i) { const int s = streams[i0 + i]; R->rid[(size_t)s] += 1; L.s[i] = s; L.id[i] = R->rid[(size_t)s]; }
+        hipLaunchKernelGGL(jd_res_ready_kernel, dim3(1), dim3(64), 0, d->s_gmm, R->d_ready, L);
+        HIPCHK(hipGetLastError());
+    }
+    return JD_OK;
+}
 
 // IDecoder::init of stream s (idle): recognitionStart runs with the stream's next command
 int jd_res_init(jd_dec *d, int s)
@@ -2440,24 +2482,51 @@ int jd_res_init(jd_dec *d, int s)
     HIPCHK(hipGetLastError());
     d->stream_T[(size_t)s] = 0; d->stream_started[(size_t)s] = 1;
     R->T_posted[(size_t)s] = 0; R->T_done[(size_t)s] = 0; R->err_done[(size_t)s] = 0;
-    return JD_OK;
+    return res_bump(d, 1, &s);
 }
 
-// Frames of stream s into its likelihood buffer `buf` (0 / 1, free): one upload from the buffer's own pinned staging
-// region, one scoring launch over its rows (asynchronous, on the side stream)
-int jd_res_stage(jd_dec *d, int s, int buf, const float *frames, int n_frames)
+// Frames of n streams into their likelihood buffers bufs[i] (0 / 1, free): an upload per stream from the buffer's own
+// pinned staging region, ONE scoring launch over the row tiles concerned (asynchronous, on the side stream), and the
+// streams' ready numbers behind it
+int jd_res_stage_many(jd_dec *d, int n, const int *streams, const int *bufs, const float *const *frames, const int *n_frames)
 {
     Resident *R = d->res;
-    if (!R || !R->on) return jd_fail(JD_ESTATE, "jd_res_stage: no resident kernel");
-    if (s < 0 || s >= R->n || (buf != 0 && buf != 1) || n_frames < 0 || n_frames > R->rows || (n_frames > 0 && !frames))
-        return jd_fail(JD_EINVAL, "jd_res_stage: bad argument");
-    if (n_frames == 0) return JD_OK;
-    const int D = d->am->D, G = d->am->n_gmm;
-    const size_t r0 = ((size_t)s * 2 + (size_t)buf) * (size_t)R->rows;
-    float *hf = (float *)R->h_stage + r0 * D;
-    memcpy(hf, frames, (size_t)n_frames * D * sizeof(float));
-    HIPCHK(hipMemcpyAsync(R->d_feat + r0 * D, hf, (size_t)n_frames * D * sizeof(float), hipMemcpyHostToDevice, d->s_gmm));
-    return launch_gmm(d->am, d->amb, R->d_feat + r0 * D, R->d_src, n_frames, R->d_ll + r0 * G, d->s_gmm);
+    if (!R || !R->on) return jd_fail(JD_ESTATE, "jd_res_stage_many: no resident kernel");
+    const int D = d->am->D;
+    const size_t tr = (size_t)R->n * 2 * R->rows;
+    int *list = R->h_ring + (size_t)R->ring_turn * RES_RING_W;
+    int *d_list = R->d_ring + (size_t)R->ring_turn * RES_RING_W;
+    int nt = 0, ns = 0;
+    std::vector<int> who;
+    for (int i = 0; i < n; ++i) {
+        const int s = streams[i], buf = bufs[i], nf = n_frames[i];
+        if (s < 0 || s >= R->n || (buf != 0 && buf != 1) || nf < 0 || nf > R->rows || (nf > 0 && !frames[i]))
+            return jd_fail(JD_EINVAL, "jd_res_stage_many: bad argument");
+        if (nf == 0) continue;
+        const size_t r0 = ((size_t)s * 2 + (size_t)buf) * (size_t)R->rows;
+        float *hf = (float *)R->h_stage + r0 * D;
+        memcpy(hf, frames[i], (size_t)nf * D * sizeof(float));
+        HIPCHK(hipMemcpyAsync(R->d_feat + r0 * D, hf, (size_t)nf * D * sizeof(float), hipMemcpyHostToDevice, d->s_gmm));
+        for (int t = 0; t < (nf + GMM_ROWS2 - 1) / GMM_ROWS2; ++t) list[nt++] = (int)r0 + t * GMM_ROWS2;
+        who.push_back(s);
+        ++ns;
+    }
+    if (ns == 0) return JD_OK;
+    R->ring_turn = (R->ring_turn + 1) % RES_RING;
+    HIPCHK(hipMemcpyAsync(d_list, list, (size_t)nt * sizeof(int), hipMemcpyHostToDevice, d->s_gmm));
+    // (a tile's rows behind the chunk's last frame are scored too - whatever the buffer holds there - and read by nobody)
+    const int rc = launch_gmm(d->am, d->amb, R->d_feat, R->d_src, (int)tr, R->d_ll, d->s_gmm, 0, 0, nt, d_list, nt);
+    if (rc) return rc;
+    return res_bump(d, ns, who.data());
+}
+
+// the command itself: a word in host-mapped memory (the cluster's first workgroup polls it)
+static void res_write_post(Resident *R, int s, int T, int slot)
+{
+    ResPost &P = R->h_post[s];
+    P.T = T;
+    P.ready_id = R->rid[(size_t)s];
+    __atomic_store_n(&P.word, ((unsigned long long)R->seq[(size_t)s] << 32) | (unsigned)slot, __ATOMIC_RELEASE);
 }
 
 // The command "frames up to T + n_frames are scored in buffer buf" for stream s (idle), behind what has been staged
@@ -2470,8 +2539,7 @@ int jd_res_post(jd_dec *d, int s, int buf, int n_frames)
     R->seq[(size_t)s] += 1;
     R->busy[(size_t)s] = 1;
     R->T_posted[(size_t)s] = T1; R->slot_posted[(size_t)s] = (int)slot;
-    hipLaunchKernelGGL(jd_res_post_kernel, dim3(1), dim3(64), 0, d->s_gmm, d->d_ctl, R->d_mail, s, T1, R->seq[(size_t)s], (int)slot);
-    HIPCHK(hipGetLastError());
+    res_write_post(R, s, T1, (int)slot);
     return JD_OK;
 }
 
@@ -2500,9 +2568,9 @@ int jd_res_collect(jd_dec *d, int s)
     HIPCHK(hipGetLastError());
     R->seq[(size_t)s] += 1;
     R->busy[(size_t)s] = 1;
-    hipLaunchKernelGGL(jd_res_post_kernel, dim3(1), dim3(64), 0, d->s_gmm, d->d_ctl, R->d_mail, s, R->T_posted[(size_t)s], R->seq[(size_t)s],
-                       R->slot_posted[(size_t)s]);
-    HIPCHK(hipGetLastError());
+    const int rc = res_bump(d, 1, &s);                                 // (the command waits for the collection)
+    if (rc) return rc;
+    res_write_post(R, s, R->T_posted[(size_t)s], R->slot_posted[(size_t)s]);
     return JD_OK;
 }
 

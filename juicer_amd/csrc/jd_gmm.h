@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
                                                        const float *__restrict__ det,
                                                        const int *__restrict__ n_mix, int G, int M,
                                                        float *__restrict__ ll, int skip_unused,
-                                                       const JdLogTab *__restrict__ logtab)
+                                                       const JdLogTab *__restrict__ logtab,
+                                                       const int *__restrict__ rt_base, int n_rt_list)
 {
     constexpr int DT = 39, DP = 39;                   // odd row stride: conflict-free per-lane rows
     extern __shared__ __align__(16) char smem[];
@@ -208,11 +209,13 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 129; i += 256) stab[i] = logtab[i];
     if (tid < 32) setab[tid] = jd_exp2f_tab[tid];
-    const int n_rt = (n_rows + GMM_ROWS2 - 1) / GMM_ROWS2, n_gt = (G + GT - 1) / GT;
+    // rt_base (or null): the row tiles to score, by first row - the chunks of several streams, each in its own region of
+    // the table (the resident kernel's side, jd_res_stage_many) - instead of every tile of rows [0, n_rows)
+    const int n_rt = rt_base ? n_rt_list : (n_rows + GMM_ROWS2 - 1) / GMM_ROWS2, n_gt = (G + GT - 1) / GT;
     for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
         // row tile skewed by the state group (see jd_gmm_kernel)
         const int gt = tile / n_rt;
-        const int r0 = ((tile + gt) % n_rt) * GMM_ROWS2;
+        const int r0 = rt_base ? rt_base[(tile + gt) % n_rt] : ((tile + gt) % n_rt) * GMM_ROWS2;
         const int g0 = gt * GT;
         if (skip_unused && row_src[r0] < 0) continue;
         __syncthreads();                              // previous tile's LDS reads are done

@@ -5,16 +5,25 @@
 // streams whose caller is between two utterances sit a launch out, and the host's share of a tick is time the chip
 // idles.  k_resident is the same per-stream machinery (run_stream: one cluster of workgroups per stream, phases and
 // cluster barriers as in k_search) under a loop that takes its work from a MAILBOX per stream: the host posts "frames
-// up to T are scored, their rows start at this slot" (jd_res_post_kernel, enqueued behind the scoring kernel on the side
-// stream), the stream's cluster runs them and reports where it stands in a host-mapped word - every stream at its own
-// pace, no common launch to wait for.  Between two commands other kernels touch the stream's state (recognitionStart's
+// up to T are scored, their rows start at this slot", the stream's cluster runs them and reports where it stands in a host-mapped word - every stream at its own
+// pace, no common launch to wait for.  (Round 4, second cut: the command is a word the host writes into host-mapped memory
+// - a post kernel on the side stream waited behind other streams' scoring launches, 0.9 ms per chunk with sixteen streams -
+// and what has to have happened on the side stream before it may start is a number the side stream counts up, ready[s].)  Between two commands other kernels touch the stream's state (recognitionStart's
 // mark, the Path collection, recognitionFinish's walk, the scoring of the next rows): a command begins with an acquire
 // at agent scope (vector L1 and stale L2 lines dropped, the scalar cache too) and ends with a release before anybody is told.
 #pragma once
 
-struct __align__(128) ResMail {
-    unsigned long long word;   // (sequence number << 32) | (likelihood slot as an unsigned 32-bit word): written by jd_res_post_kernel
+struct __align__(64) ResPost {  // host-mapped, one per stream: the HOST writes a command here (no kernel launch in a post)
+    unsigned long long word;   // (sequence number << 32) | (likelihood slot as an unsigned 32-bit word): written last
+    int T;                     // frames available with this command (StreamCtl::T)
+    unsigned ready_id;         // the command may start once the side stream has come this far for the stream (ready[s]): the
+                               // scoring of its rows, recognitionStart's mark, a Path collection
     int exit_req;              // != 0: leave the kernel
+    int pad[11];
+};
+struct __align__(128) ResMail { // device memory, one per stream: workgroup 0 of the cluster passes the command on to the others
+    unsigned long long word;
+    int exit_req;
     int pad[29];
 };
 struct ResDone {               // host-mapped, one per stream: written by workgroup 0 of the stream's cluster behind every command
@@ -22,32 +31,27 @@ struct ResDone {               // host-mapped, one per stream: written by workgr
     int frame;                 // StreamCtl::frame behind it: < T when the stream stopped for a Path collection
     int error;                 // StreamCtl::error
     int left;                  // 1: the cluster has left the kernel (exit request, or nobody posted anything for RES_IDLE_TICKS)
+    long long run_ticks;       // (statistics) 100 MHz ticks the cluster spent on the command
 };
 #define RES_IDLE_TICKS 500000000LL      // 5 s at 100 MHz without a command: the kernel ends by itself
 
-__global__ void jd_res_post_kernel(StreamCtl *ctl, ResMail *mail, int s, int T, unsigned seq, int ll_slot)
+// "the side stream has come this far": enqueued behind a scoring launch / a mark / a collection, for the streams concerned
+struct ReadyList { int n; int s[64]; unsigned id[64]; };
+__global__ void jd_res_ready_kernel(unsigned *ready, ReadyList L)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        ctl[s].T = T;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(&mail[s].word, ((unsigned long long)seq << 32) | (unsigned)ll_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const int i = threadIdx.x;
+    if (i < L.n) __hip_atomic_store(&ready[L.s[i]], L.id[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void jd_res_exit_kernel(ResMail *mail, int n)
+__global__ void jd_res_reset_kernel(StreamCtl *ctl, ResMail *mail, unsigned *ready, int n)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) __hip_atomic_store(&mail[s].exit_req, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void jd_res_reset_kernel(StreamCtl *ctl, ResMail *mail, int n)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) { mail[s].word = 0ULL; mail[s].exit_req = 0; ctl[s].bar = 0u; ctl[s].xbar = 0u; ctl[s].xmask = 0u; ctl[s].stop_req = 0; }
+    if (s < n) { mail[s].word = 0ULL; mail[s].exit_req = 0; ready[s] = 0u; ctl[s].bar = 0u; ctl[s].xbar = 0u; ctl[s].xmask = 0u; ctl[s].stop_req = 0; }
 }
 
 // grid = n_streams x Cw workgroups: workgroup b serves stream b / Cw as member b % Cw of its cluster (agent-scope flavour:
 // nothing is assumed about where the workgroups run).  All of them resident at once, like k_search's.
 template <int NE>
-__global__ JD_KBOUNDS void k_resident(SearchArgs A, ResMail *mail, ResDone *done, int Cw)
+__global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail *mail, const unsigned *ready, ResDone *done, int Cw)
 {
     __shared__ SearchShared sh;
     __shared__ unsigned long long sh_word;
@@ -61,16 +65,42 @@ __global__ JD_KBOUNDS void k_resident(SearchArgs A, ResMail *mail, ResDone *done
     for (;;) {
         if (tid == 0) {
             const long long t_idle = wall_clock64() + RES_IDLE_TICKS;
-            unsigned long long w;
+            unsigned long long w = 0ULL;
             int ex = 0;
             unsigned spins = 0;
-            for (;;) {
-                w = __hip_atomic_load(&mail[s].word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(w >> 32) != seen) break;
-                ex = __hip_atomic_load(&mail[s].exit_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ex) break;
-                __builtin_amdgcn_s_sleep(16);
-                if ((++spins & 255u) == 0 && wall_clock64() > t_idle) { ex = 1; break; }
+            if (jw == 0) {
+                // the cluster's first workgroup reads the host's word (a read across the bus every few microseconds), waits
+                // for the side stream to have come as far as the command says, and passes it on in device memory
+                for (;;) {
+                    w = __hip_atomic_load(&post[s].word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((unsigned)(w >> 32) != seen) break;
+                    ex = __hip_atomic_load(&post[s].exit_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (ex) break;
+                    __builtin_amdgcn_s_sleep(48);
+                    if ((++spins & 255u) == 0 && wall_clock64() > t_idle) { ex = 1; break; }
+                }
+                if (!ex) {
+                    const int T = __hip_atomic_load(&post[s].T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned rid = __hip_atomic_load(&post[s].ready_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    while ((int)(__hip_atomic_load(&ready[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - rid) < 0) {
+                        __builtin_amdgcn_s_sleep(16);
+                        if ((++spins & 255u) == 0 && wall_clock64() > t_idle) { ex = 1; break; }
+                    }
+                    if (!ex) {
+                        __hip_atomic_store(&c.T, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&mail[s].word, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (ex) __hip_atomic_store(&mail[s].exit_req, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (;;) {
+                    w = __hip_atomic_load(&mail[s].word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(w >> 32) != seen) break;
+                    ex = __hip_atomic_load(&mail[s].exit_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ex) break;
+                    __builtin_amdgcn_s_sleep(16);
+                    if ((++spins & 255u) == 0 && wall_clock64() > t_idle + 100000000LL) { ex = 1; break; }   // (a second behind workgroup 0)
+                }
             }
             sh_word = w; sh_exit = ex;
         }
@@ -86,6 +116,7 @@ __global__ JD_KBOUNDS void k_resident(SearchArgs A, ResMail *mail, ResDone *done
         const int ll_slot = (int)(unsigned)(w & 0xffffffffULL);
         // what other kernels wrote since the last command - frames available, the likelihood rows, arenas swapped by a
         // collection, recognitionStart's mark - is read from memory, not from what this CU or this XCD's L2 still holds
+        const long long t_cmd = wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_dcache_inv();
         run_stream<NE, false, false>(A, sh, s, ll_slot, jw, Cw, true, &nbar);
@@ -114,7 +145,7 @@ __global__ JD_KBOUNDS void k_resident(SearchArgs A, ResMail *mail, ResDone *done
             const int fr = __hip_atomic_load(&c.frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int er = __hip_atomic_load(&c.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            done[s].frame = fr; done[s].error = er;
+            done[s].frame = fr; done[s].error = er; done[s].run_ticks = wall_clock64() - t_cmd;
             __hip_atomic_store(&done[s].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         seen = seq;

@@ -53,6 +53,16 @@ for n in counts:
         best = dt if best is None else min(best, dt)
     st = broker.stats()
     tk = max(st["ticks"], 1)
+    if st["resident"]:
+        print("%3d callers: %8.0f frames/s = %.2f of the batch rate; resident kernel, clusters of %d: %.0f frames per chunk, %.0f us from its post to its report "
+              "(%.1f us per frame; the cluster's own clock: %.1f), %.0f us until the next chunk of the utterance is posted; staging call %.0f us, "
+              "result fetch %.0f us per utterance"
+              % (n, n * frames / best, (n * frames / best) / (frames / t_batch), st["resident"], st["frames"] / tk, st["us_search"] / tk,
+                 st["us_search"] / max(st["frames"], 1), st["us_coalesce"] / max(st["frames"], 1), st["us_idle"] / tk, st["us_push"] / tk,
+                 st["us_finish"] / (64.0 * n)))
+        broker.close()
+        dec.close()
+        continue
     print("%3d callers: %8.0f frames/s = %.2f of the batch rate; %.1f streams and %.0f frames per tick; worker us per tick: idle %.0f, coalesce %.0f, "
           "init %.0f, push %.0f (search kernel %.0f), finish %.0f"
           % (n, n * frames / best, (n * frames / best) / (frames / t_batch), st["stream_ticks"] / tk, st["frames"] / tk, st["us_idle"] / tk,
