@@ -340,7 +340,7 @@ typedef struct jd_broker_stats {
     int64_t us_search;                             /* of us_push: the search launches (device time) */
     int64_t resident;                              /* > 0: the worker drives the resident search kernel, clusters of this many workgroups -
                                                       a "tick" is then one stream's chunk, us_search the time from its post to its report,
-                                                      us_coalesce the time its cluster spent on it (device clock), us_idle what the cluster waited for the next
+                                                      us_coalesce the time its cluster spent on it (device clock), us_init the NUMBER of Path collections between chunks, us_idle what the cluster waited for the next
                                                       chunk of the same utterance, us_push the staging calls, us_finish the result fetches */
 } jd_broker_stats;
 int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients);   /* n_clients <= the decoder's max_streams */

@@ -487,6 +487,6 @@ extern "C" int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out)
     std::lock_guard<std::mutex> lk(b->mu);
     *out = b->stats;
     out->resident = b->resident ? jd_res_cluster(b->dec) : 0;
-    if (b->resident) out->us_coalesce = jd_res_run_us(b->dec);      // (the clusters' own time on their chunks)
+    if (b->resident) { out->us_coalesce = jd_res_run_us(b->dec); out->us_init = jd_res_collections(b->dec); }   // (the clusters' own time on their chunks; Path collections)
     return JD_OK;
 }

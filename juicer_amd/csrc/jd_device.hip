@@ -2313,6 +2313,7 @@ struct Resident {
     std::vector<int> slot_posted;
     std::vector<char> busy;                            // a command is posted and its report not yet taken
     long long run_ticks = 0;                           // (statistics) what the clusters spent on their commands, 100 MHz ticks
+    long long n_collect = 0;                           // (statistics) Path collections between commands
     std::unique_lock<std::mutex> search_lock;
     GpuLockGuard *process_lock = nullptr;
 };
@@ -2450,6 +2451,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
 
 int jd_res_cluster(const jd_dec *d) { return (d && d->res) ? d->res->Cw : 0; }
 long long jd_res_run_us(const jd_dec *d) { return (d && d->res) ? d->res->run_ticks / 100 : 0; }
+long long jd_res_collections(const jd_dec *d) { return (d && d->res) ? d->res->n_collect : 0; }
 
 // "the side stream has come this far" for these streams: a new ready number each, behind everything enqueued so far
 static int res_bump(jd_dec *d, int n, const int *streams)
@@ -2568,6 +2570,7 @@ int jd_res_collect(jd_dec *d, int s)
     HIPCHK(hipGetLastError());
     R->seq[(size_t)s] += 1;
     R->busy[(size_t)s] = 1;
+    R->n_collect += 1;
     const int rc = res_bump(d, 1, &s);                                 // (the command waits for the collection)
     if (rc) return rc;
     res_write_post(R, s, R->T_posted[(size_t)s], R->slot_posted[(size_t)s]);

@@ -136,6 +136,73 @@ def test_broker_error_stays_with_its_client(built):
     dec.close()
 
 
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_broker_corner_cases(built, resident, monkeypatch):
+    """Both workers of the broker - the resident search kernel (default) and the ticks - on what the plain path never
+    meets: Path arenas so small that the streams stop for collections all the time, an utterance without frames, init()
+    in the middle of an utterance, HMMs of 1-6 emitting states (the other record layout).  Results are those of the
+    streaming API / a batch decode, bit for bit."""
+    from juicer_amd import capi, synth
+    monkeypatch.setenv("JD_BROKER_RESIDENT", resident)
+    am, net, feats, _ = synth.config_small(n_utts=8)
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    kw = dict(main_beam=150.0)
+    want = capi.Decoder(gnet, gam, max_streams=len(feats), **kw).decode_batch(feats)
+    ref = capi.Decoder(gnet, gam, max_streams=1, **kw)
+    ref.stream_init(0)
+    empty = ref.stream_finish(0)                                       # init() directly followed by finish()
+    ref.close()
+    # small Path arenas: collections between the chunks and inside them
+    dec = capi.Decoder(gnet, gam, max_streams=4, max_paths=1 << 12, **kw)
+    broker = capi.Broker(dec)
+    assert bool(broker.stats()["resident"]) == (resident == "1")
+    out = [None] * len(feats)
+    threads = [threading.Thread(target=_drive, args=(broker, [(u, feats[u]) for u in range(t, len(feats), 4)], out, 50 + 11 * t)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for u in range(len(feats)):
+        assert out[u] is not None and bit_exact(out[u], want[u]), u
+    if resident == "1":
+        assert broker.stats()["us_init"] > 0                          # (resident worker: the number of collections between chunks)
+    # an utterance without frames; init() in the middle of an utterance drops it
+    c = broker.open()
+    broker.init(c)
+    h = broker.finish(c)
+    assert h.n == empty.n and bit_exact(h, empty)
+    broker.init(c)
+    broker.push(c, feats[0][:100])
+    broker.init(c)
+    broker.push(c, feats[1])
+    assert bit_exact(broker.finish(c), want[1])
+    broker.init(c)
+    broker.push(c, feats[2][:37])
+    broker.close_client(c)                                             # (an utterance that was never finished)
+    c = broker.open()
+    broker.init(c)
+    broker.push(c, feats[3])
+    assert bit_exact(broker.finish(c), want[3])
+    broker.close()
+    dec.close()
+    # HMMs of 1-6 emitting states
+    am2, net2, feats2, _ = synth.config_mixed(n_utts=6)
+    gnet2, gam2 = capi.Network.from_synth(net2), capi.Models.from_htk(am2)
+    want2 = capi.Decoder(gnet2, gam2, max_streams=6, **kw).decode_batch(feats2)
+    dec = capi.Decoder(gnet2, gam2, max_streams=3, **kw)
+    broker = capi.Broker(dec)
+    out = [None] * 6
+    threads = [threading.Thread(target=_drive, args=(broker, [(u, feats2[u]) for u in range(t, 6, 3)], out, 40 + 9 * t)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for u in range(6):
+        assert out[u] is not None and bit_exact(out[u], want2[u]), u
+    broker.close()
+    dec.close()
+
+
 def test_broker_throughput_at_configs1(built):
     """16 serial callers (threads) on the configs[1] graph against ONE batch of the same 64 utterances."""
     import torch
