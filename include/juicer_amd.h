@@ -326,12 +326,19 @@ int jd_dec_info(const jd_dec *d, int32_t *max_streams, int32_t *vec_size);
  * The reference's harness decodes serially through ONE IDecoder (DecoderBatchTest.cpp:738-771 ->
  * DecoderSingleTest.cpp:259-324) and scales out as independent processes over split file lists
  * (doc/userman/juicer_userman.tex:584).  A broker lets N such serial callers - threads of one process - share the
- * streams of one decoder: each drives its own client with init / push / finish, and a worker thread turns what has
- * been pushed since its last tick into one scoring launch and one search launch over all the streams concerned
+ * streams of one decoder: each drives its own client with init / push / finish.  Up to 64 clients are served by a search
+ * kernel that STAYS on the device while there is work (csrc/jd_resident.h): every client's stream has a cluster of
+ * workgroups of its own there, the worker thread scores a client's frames as they come (one launch per round for all
+ * the clients that brought some) and hands them to the cluster as soon as it is through with the chunk before - every
+ * stream at its own pace; init, the Path collections and finish are small kernels beside it.  The kernel leaves the
+ * device after 3 ms without work and comes back with the next request; while it is there, other search launches on the
+ * device (this process: they wait for it; other processes: the file lock) and anything that synchronises the whole
+ * device wait for that.  More than 64 clients, a lazily composed network, or JD_BROKER_RESIDENT=0: a worker that turns
+ * what has been pushed since its last TICK into one scoring launch and one search launch over all the streams concerned
  * (jd_streams_push).  The decoder must not be used directly while a broker owns it; clients may be driven from
  * different threads, one thread per client at a time.  jd_hyp arrays stay valid until the client's next init.
- * Environment: JD_BROKER_TICK_FRAMES (frames of one client per tick, default 192), JD_BROKER_COALESCE_US (how long a
- * tick waits for the other open clients' frames, default 300). */
+ * Environment: JD_BROKER_TICK_FRAMES (frames of one client per chunk / tick, default 256 / 192), JD_BROKER_COALESCE_US
+ * (ticks: how long one waits for the other open clients' frames, default 300). */
 typedef struct jd_broker jd_broker;
 typedef struct jd_broker_stats {
     int64_t ticks, frames, stream_ticks;           /* launches, frames, streams summed over ticks */
