@@ -208,7 +208,8 @@ static void broker_loop_resident(jd_broker *b)
     std::vector<int> st_s, st_b, st_n;                                // this round's staging: streams, buffers, frames
     std::vector<const float *> st_f;
     bool on = false;
-    auto idle_since = now();
+    bool draining = false;                                            // somebody waits for the device: no new commands, then the kernel makes room
+    auto idle_since = now(), on_since = now();
     auto fail_all = [&](int rc, const std::string &msg) {              // (lk held)
         for (Client &c : b->clients)
             if (c.open && c.err == JD_OK) { c.err = rc; c.errmsg = msg; }
@@ -238,14 +239,26 @@ static void broker_loop_resident(jd_broker *b)
             const std::string m = rc ? jd_last_error() : "";
             lk.lock();
             if (rc) { fail_all(rc, m); continue; }
-            on = true;
+            on = true; draining = false; on_since = now();
+        }
+        // another decoder's launch (or another broker's kernel) of this process waits for the device: once this kernel has had
+        // 20 ms, the chunks that are running run out, the kernel leaves, and comes back behind the one that waited
+        if (!draining && jd_res_should_yield(b->dec) && std::chrono::duration<double, std::milli>(now() - on_since).count() > 20.0) draining = true;
+        if (draining) {
+            bool any_running = false;
+            for (const Client &c : b->clients) any_running = any_running || c.running || c.finishing;
+            if (!any_running) {
+                lk.unlock(); (void)jd_res_stop(b->dec); std::this_thread::yield(); lk.lock();
+                on = false; draining = false;
+                continue;
+            }
         }
         bool progress = false;
         auto try_post = [&](int i) {                                   // (lk held)
             Client &c = b->clients[(size_t)i];
             int rc = JD_OK;
             // 4. the next chunk to the cluster (a finish without frames still runs recognitionStart: a chunk of none)
-            if (!c.running && c.inited && (c.n_staged > 0 || (c.fresh && c.want_finish && c.pending.empty()))) {
+            if (!draining && !c.running && c.inited && (c.n_staged > 0 || (c.fresh && c.want_finish && c.pending.empty()))) {
                 const int buf = c.n_staged > 0 ? c.staged_buf[0] : 0, nf = c.n_staged > 0 ? c.staged_n[0] : 0;
                 lk.unlock();
                 rc = jd_res_post(b->dec, i, buf, nf);

@@ -32,6 +32,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <numeric>
 #include <queue>
@@ -243,6 +244,7 @@ extern "C" int jd_am_score_frames(const jd_am *a, int32_t device, const float *f
 
 #define JD_MAX_DEVICES 64
 static std::mutex g_search_mu[JD_MAX_DEVICES];     // one persistent search launch at a time per device (launch_search)
+static std::atomic<int> g_search_waiters[JD_MAX_DEVICES];   // ... and who waits for it (a resident kernel makes room: jd_res_should_yield)
 
 // ... and across PROCESSES: the reference's way of using several cores is several processes over split file lists
 // (doc/userman/juicer_userman.tex:584), and two of them pointed at one GPU would each get part of the CUs for their
@@ -1369,7 +1371,10 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             }
             d->occupancy_ok = true;
         }
-        std::lock_guard<std::mutex> search_lock(g_search_mu[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)]);
+        const size_t dev_i = (size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1);
+        g_search_waiters[dev_i].fetch_add(1);
+        std::unique_lock<std::mutex> search_lock(g_search_mu[dev_i]);
+        g_search_waiters[dev_i].fetch_sub(1);
         GpuLockGuard process_lock(d->device);                              // (other processes on this GPU: see GpuFileLock)
         // (a launch beside which the next batch's table is scored is not cut short for a re-plan while that scoring runs -
         // status[4]: its blocks sit on the CUs that finished clusters left, and a relaunch would wait for them to drain)
@@ -2429,7 +2434,12 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     memset(R->h_post, 0, (size_t)R->n * sizeof(ResPost));
     std::fill(R->seq.begin(), R->seq.end(), 0u);
     std::fill(R->rid.begin(), R->rid.end(), 0u);
-    R->search_lock = std::unique_lock<std::mutex>(g_search_mu[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)]);
+    {
+        const size_t dev_i = (size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1);
+        g_search_waiters[dev_i].fetch_add(1);
+        R->search_lock = std::unique_lock<std::mutex>(g_search_mu[dev_i]);
+        g_search_waiters[dev_i].fetch_sub(1);
+    }
     R->process_lock = new GpuLockGuard(d->device);
     SearchArgs A;
     memset(&A, 0, sizeof A);
@@ -2450,6 +2460,11 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
 }
 
 int jd_res_cluster(const jd_dec *d) { return (d && d->res) ? d->res->Cw : 0; }
+// somebody else of this process waits for the device's search lock (another decoder's launch, another broker's kernel)
+int jd_res_should_yield(const jd_dec *d)
+{
+    return (d && d->res && d->res->on) ? g_search_waiters[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)].load() > 0 : 0;
+}
 long long jd_res_run_us(const jd_dec *d) { return (d && d->res) ? d->res->run_ticks / 100 : 0; }
 long long jd_res_collections(const jd_dec *d) { return (d && d->res) ? d->res->n_collect : 0; }
 

@@ -203,6 +203,48 @@ def test_broker_corner_cases(built, resident, monkeypatch):
     dec.close()
 
 
+def test_two_brokers_and_a_batch_decoder_share_the_device(built):
+    """A resident search kernel holds the device while it has work; when another decoder of the process waits for the device
+    - a second broker's kernel, a batch decode - it lets its running chunks run out and makes room: two busy brokers and a
+    batch decoder, all on one GPU from different threads, all finish, results bit for bit."""
+    from juicer_amd import capi, synth
+    am, net, feats, _ = synth.config_small(n_utts=12)
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    kw = dict(main_beam=150.0)
+    want = capi.Decoder(gnet, gam, max_streams=len(feats), **kw).decode_batch(feats)
+    decs = [capi.Decoder(gnet, gam, max_streams=3, **kw) for _ in range(2)]
+    brokers = [capi.Broker(d) for d in decs]
+    assert all(b.stats()["resident"] for b in brokers)
+    bd = capi.Decoder(gnet, gam, max_streams=4, **kw)
+    outs = [[None] * len(feats) for _ in range(2)]
+    batch_out = []
+    order = [(u % len(feats), feats[u % len(feats)]) for u in range(3 * len(feats))]        # every caller: the list three times
+
+    def drive(k, t):
+        mine = {}
+        _drive(brokers[k], [(i, x) for i, (u, x) in enumerate(order) if i % 3 == t], mine, 64)
+        for i, h in mine.items():
+            assert bit_exact(h, want[order[i][0]]), (k, t, i)
+        outs[k][t] = len(mine)
+
+    def batch():
+        for rep in range(6):
+            got = bd.decode_batch(feats[:4])
+            batch_out.append(all(bit_exact(g, w) for g, w in zip(got, want[:4])))
+    threads = [threading.Thread(target=drive, args=(k, t)) for k in range(2) for t in range(3)] + [threading.Thread(target=batch)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "somebody starved"
+    assert batch_out == [True] * 6
+    assert all(outs[k][t] == len(feats) for k in range(2) for t in range(3))
+    for b in brokers:
+        b.close()
+    for d in decs + [bd]:
+        d.close()
+
+
 def test_broker_throughput_at_configs1(built):
     """16 serial callers (threads) on the configs[1] graph against ONE batch of the same 64 utterances."""
     import torch
