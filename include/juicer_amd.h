@@ -345,17 +345,20 @@ typedef struct jd_broker_stats {
     int64_t us_idle, us_coalesce;                  /* worker thread: waiting for work; waiting for the other clients' frames */
     int64_t us_init, us_push, us_finish;           /* ... inside jd_stream_init / jd_streams_push / jd_stream_finish */
     int64_t us_search;                             /* of us_push: the search launches (device time) */
-    int64_t resident;                              /* > 0: the worker drives the resident search kernel, clusters of this many workgroups -
-                                                      a "tick" is then one stream's chunk, us_search the time from its post to its report,
-                                                      us_coalesce the time its cluster spent on it (device clock), us_init the NUMBER of Path collections between chunks, us_idle what the cluster waited for the next
-                                                      chunk of the same utterance, us_push the staging calls, us_finish the result fetches */
+    int64_t resident;                              /* > 0: the worker drives the resident search kernel, clusters of this many workgroups.
+                                                      A "tick" is then one stream's chunk, and: us_search = the time from its post to its
+                                                      report, us_coalesce = the time its cluster spent on it (device clock), us_init = the
+                                                      NUMBER of Path collections between chunks, us_idle = what the cluster waited for the
+                                                      next chunk of the same utterance, us_push = the staging calls, us_finish = the result
+                                                      fetches */
 } jd_broker_stats;
 int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients);   /* n_clients <= the decoder's max_streams */
 void jd_broker_destroy(jd_broker *b);                                    /* (the decoder is the caller's to destroy, afterwards) */
 int jd_broker_open(jd_broker *b, int32_t *client);
 int jd_broker_close(jd_broker *b, int32_t client);
 int jd_broker_init(jd_broker *b, int32_t client);                                              /* IDecoder::init */
-int jd_broker_push(jd_broker *b, int32_t client, const float *frames, int32_t n_frames);       /* IDecoder::processFrame x n: returns once the frames are taken */
+/* IDecoder::processFrame x n: returns once the frames are taken */
+int jd_broker_push(jd_broker *b, int32_t client, const float *frames, int32_t n_frames);
 int jd_broker_finish(jd_broker *b, int32_t client, jd_hyp *out);                               /* IDecoder::finish */
 int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out);
 

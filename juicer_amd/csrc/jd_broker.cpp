@@ -155,7 +155,10 @@ static void broker_loop(jd_broker *b)
             }
             tick_frames = fr; tick_streams = (long long)ss.size();
             jd_timing tm;
-            if (!ss.empty() && jd_dec_last_timing(b->dec, &tm) == JD_OK) { us_search = (int64_t)((tm.search_ms - search_ms_seen) * 1e3); search_ms_seen = tm.search_ms; }
+            if (!ss.empty() && jd_dec_last_timing(b->dec, &tm) == JD_OK) {
+                us_search = (int64_t)((tm.search_ms - search_ms_seen) * 1e3);
+                search_ms_seen = tm.search_ms;
+            }
         }
         us_push = us_since(t_mark); t_mark = now();
         std::vector<jd_hyp> res((size_t)b->n_clients);
@@ -219,7 +222,10 @@ static void broker_loop_resident(jd_broker *b)
     for (;;) {
         bool active = false;
         for (const Client &c : b->clients)
-            if (c.open && (c.want_init || c.want_finish || c.running || c.finishing || c.n_staged > 0 || (c.inited && !c.pending.empty()))) { active = true; break; }
+            if (c.open && (c.want_init || c.want_finish || c.running || c.finishing || c.n_staged > 0 || (c.inited && !c.pending.empty()))) {
+                active = true;
+                break;
+            }
         if (b->stop) { if (on) { lk.unlock(); (void)jd_res_stop(b->dec); lk.lock(); } return; }
         if (!active) {
             // nothing to do: the kernel leaves the chip after a few milliseconds (other decoders, other processes, a
@@ -405,7 +411,10 @@ extern "C" int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients)
     // (up to 64 clients: the ready list of a scoring launch and the chip's room for clusters and their scoring side by side)
     b->resident = n_clients <= 64;
     if (const char *e = getenv("JD_BROKER_RESIDENT")) b->resident = atoi(e) != 0;
-    if (b->resident && !getenv("JD_BROKER_TICK_FRAMES")) { b->max_tick_frames = 256; b->max_pending_frames = 4 * b->max_tick_frames; }   // (whole scoring tiles)
+    if (b->resident && !getenv("JD_BROKER_TICK_FRAMES")) {            // (whole scoring tiles)
+        b->max_tick_frames = 256;
+        b->max_pending_frames = 4 * b->max_tick_frames;
+    }
     if (b->resident && jd_res_start(dec, n_clients, b->max_tick_frames) != JD_OK) b->resident = false;
     else if (b->resident) (void)jd_res_stop(dec);                      // (it comes back with the first request)
     b->worker = b->resident ? std::thread(broker_loop_resident, b) : std::thread(broker_loop, b);
@@ -500,6 +509,9 @@ extern "C" int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out)
     std::lock_guard<std::mutex> lk(b->mu);
     *out = b->stats;
     out->resident = b->resident ? jd_res_cluster(b->dec) : 0;
-    if (b->resident) { out->us_coalesce = jd_res_run_us(b->dec); out->us_init = jd_res_collections(b->dec); }   // (the clusters' own time on their chunks; Path collections)
+    if (b->resident) {                                                 // (the clusters' own time on their chunks; Path collections)
+        out->us_coalesce = jd_res_run_us(b->dec);
+        out->us_init = jd_res_collections(b->dec);
+    }
     return JD_OK;
 }

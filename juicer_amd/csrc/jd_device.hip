@@ -2412,7 +2412,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
         R->slot_posted.assign((size_t)n_streams, 0); R->err_done.assign((size_t)n_streams, 0); R->busy.assign((size_t)n_streams, 0);
         for (int t = 0; t < n_streams; ++t) R->T_done[(size_t)t] = R->T_posted[(size_t)t] = d->stream_T[(size_t)t];
         R->rid.assign((size_t)n_streams, 0u);
-        std::vector<int> ident(tr);                                    // the row table of every scoring launch: row r of the table is row r of the features
+        std::vector<int> ident(tr);            // the row table of every scoring launch: row r of the table is row r of the features
         for (size_t r = 0; r < tr; ++r) ident[r] = (int)r;
         HIPCHK(hipMemcpy(R->d_src, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
     }
@@ -2447,8 +2447,9 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     A.ll = R->d_ll; A.ll_stride = (long long)G; A.f0 = 0; A.f_end = 0x7fffffff;
     A.status = d->d_status; A.dbg = nullptr; A.cells = nullptr; A.resident = nullptr; A.rebalance_at = 0; A.n_prio = 0;
     hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->d_ready, R->n);
-    if (ne3) hipLaunchKernelGGL(k_resident<3>, dim3((unsigned)(R->n * R->Cw)), dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
-    else hipLaunchKernelGGL(k_resident<6>, dim3((unsigned)(R->n * R->Cw)), dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
+    const dim3 rgrid((unsigned)(R->n * R->Cw));
+    if (ne3) hipLaunchKernelGGL(k_resident<3>, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
+    else hipLaunchKernelGGL(k_resident<6>, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         delete R->process_lock; R->process_lock = nullptr; R->search_lock.unlock();
@@ -2572,7 +2573,8 @@ int jd_res_poll(jd_dec *d, int s, int *idle, int *frame, int *error, int *stoppe
     if (error) *error = R->err_done[(size_t)s];
     if (stopped) *stopped = (through && R->err_done[(size_t)s] == 0 && R->T_done[(size_t)s] < R->T_posted[(size_t)s]) ? 1 : 0;
     if (through) return JD_OK;
-    if (__atomic_load_n(&R->h_done[s].left, __ATOMIC_ACQUIRE)) return jd_fail(JD_ESTATE, "the resident search kernel has ended (no command for 5 s, or a lost workgroup)");
+    if (__atomic_load_n(&R->h_done[s].left, __ATOMIC_ACQUIRE))
+        return jd_fail(JD_ESTATE, "the resident search kernel has ended (no command for 5 s, or a lost workgroup)");
     return JD_OK;
 }
 

@@ -5,10 +5,12 @@
 // streams whose caller is between two utterances sit a launch out, and the host's share of a tick is time the chip
 // idles.  k_resident is the same per-stream machinery (run_stream: one cluster of workgroups per stream, phases and
 // cluster barriers as in k_search) under a loop that takes its work from a MAILBOX per stream: the host posts "frames
-// up to T are scored, their rows start at this slot", the stream's cluster runs them and reports where it stands in a host-mapped word - every stream at its own
+// up to T are scored, their rows start at this slot", the stream's cluster runs them and reports where it stands in a
+// host-mapped word - every stream at its own
 // pace, no common launch to wait for.  (Round 4, second cut: the command is a word the host writes into host-mapped memory
 // - a post kernel on the side stream waited behind other streams' scoring launches, 0.9 ms per chunk with sixteen streams -
-// and what has to have happened on the side stream before it may start is a number the side stream counts up, ready[s].)  Between two commands other kernels touch the stream's state (recognitionStart's
+// and what has to have happened on the side stream before it may start is a number the side stream counts up, ready[s].)
+// Between two commands other kernels touch the stream's state (recognitionStart's
 // mark, the Path collection, recognitionFinish's walk, the scoring of the next rows): a command begins with an acquire
 // at agent scope (vector L1 and stale L2 lines dropped, the scalar cache too) and ends with a release before anybody is told.
 #pragma once
@@ -45,7 +47,10 @@ __global__ void jd_res_ready_kernel(unsigned *ready, ReadyList L)
 __global__ void jd_res_reset_kernel(StreamCtl *ctl, ResMail *mail, unsigned *ready, int n)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) { mail[s].word = 0ULL; mail[s].exit_req = 0; ready[s] = 0u; ctl[s].bar = 0u; ctl[s].xbar = 0u; ctl[s].xmask = 0u; ctl[s].stop_req = 0; }
+    if (s < n) {
+        mail[s].word = 0ULL; mail[s].exit_req = 0; ready[s] = 0u;
+        ctl[s].bar = 0u; ctl[s].xbar = 0u; ctl[s].xmask = 0u; ctl[s].stop_req = 0;
+    }
 }
 
 // grid = n_streams x Cw workgroups: workgroup b serves stream b / Cw as member b % Cw of its cluster (agent-scope flavour:

@@ -1491,7 +1491,8 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
         const int p = init ? 1 : (f & 1);
         // stop early when the Path arena needs collecting (k_gc_* run between launches); n_paths only
         // changes in phase X, so every workgroup of the cluster reads the same value here
-        if (!init && frames_done > 0 && (np_seen > C.gc_threshold || stop_seen || (C.path_rule && path_rule_fires(ref_rule ? npr_seen : np_seen, path_new)))) break;
+        if (!init && frames_done > 0 &&
+            (np_seen > C.gc_threshold || stop_seen || (C.path_rule && path_rule_fires(ref_rule ? npr_seen : np_seen, path_new)))) break;
         long long t0 = 0;
         const bool clk_on = A.dbg != nullptr && tid == 0;
 #define CLK(slot) do { if (clk_on) { const long long tn_ = wall_clock64(); sh.clk[slot] += tn_ - t0; t0 = tn_; } } while (0)
