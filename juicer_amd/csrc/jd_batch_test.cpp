@@ -420,6 +420,7 @@ int main(int argc, char **argv)
         struct Res { std::vector<int32_t> lab, tim; std::vector<float> ac, lm; double dt = 0.0; };
         std::vector<Res> res(files.size());
         std::vector<std::thread> th;
+        const auto t_all = std::chrono::steady_clock::now();
         for (int t = 0; t < nThreads; ++t)
             th.emplace_back([&, t]() {
                 JuicerAmd::GpuWFSTPooledDecoder dec(pool);
@@ -443,6 +444,12 @@ int main(int argc, char **argv)
                 }
             });
         for (std::thread &t : th) t.join();
+        {
+            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
+            long tot = 0;
+            for (size_t u = 0; u < files.size(); ++u) tot += nfr[u];
+            fprintf(stderr, "%d harness threads: %ld frames in %.3f s = %.0f frames/s\n", nThreads, tot, wall, wall > 0 ? tot / wall : 0.0);
+        }
         for (size_t u = 0; u < files.size(); ++u)
             print_utt(u, (int)res[u].lab.size(), res[u].lab.data(), res[u].tim.data(), res[u].ac.data(), res[u].lm.data(), res[u].dt);
     } else if (nDevices > 0) {

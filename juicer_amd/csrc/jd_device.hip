@@ -2426,8 +2426,10 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     }
     // clusters: what the arenas allow, and a sixth of the chip left to the scoring, collection and finish kernels
     const int cw_cap = (int)std::max<int64_t>(1, std::min<int64_t>(d->cap_slots / (64 * SW), d->cap_items / (512 * SW)));
-    // (the scoring of what the streams search: about 1.6 CUs per stream at their pace)
-    const int free_cus = std::min(d->n_cus / 2, std::max(40, (n_streams * 8) / 5));
+    // (the scoring of what the streams search: about 1.6 CUs per stream at their pace, and a quarter of the chip at least -
+    // sixteen C++ callers: 407 k frames/s with 24 CUs left, 433 k with 40, 469 k with 64, 462 k with 96)
+    int free_cus = std::min(d->n_cus / 2, std::max(d->n_cus / 4, (n_streams * 8) / 5));
+    if (const char *e = getenv("JD_RES_FREE_CUS")) { const int v = atoi(e); if (v >= 0 && v < d->n_cus) free_cus = v; }   // development
     R->Cw = std::max(1, std::min(std::min(d->max_cw, cw_cap), (d->n_cus * WG_PER_CU - free_cus) / n_streams));
     if (R->Cw * n_streams > d->n_cus * WG_PER_CU) return jd_fail(JD_EINVAL, "jd_res_start: %d streams do not fit the device", n_streams);
     memset(R->h_done, 0, (size_t)R->n * sizeof(ResDone));
