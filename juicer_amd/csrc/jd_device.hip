@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <cerrno>
 #include <numeric>
 #include <queue>
@@ -450,6 +451,10 @@ struct jd_dec {
     char *h_stage = nullptr; size_t stage_cap = 0;     // pinned staging of jd_streams_push
     bool xch_forced = false;               // JD_XCH given (development)
     struct Resident *res = nullptr;        // the resident search kernel of a broker (jd_res_*), or null
+    struct Pipe *pipe = nullptr;           // batches through the resident kernel, utterance by utterance (jd_pipe_*; JD_PIPELINE=3)
+    bool pipe_mode = false;
+    int pipe_depth = 8;                    // likelihood tables = batches announced and not handed back, at most (JD_PIPE_DEPTH)
+    const float *res_ll = nullptr;         // the likelihood slab the resident kernel reads (null: the broker's stream buffers)
     // results
     std::vector<HostResult> results;
     jd_timing timing{};
@@ -487,10 +492,16 @@ static int dupload(jd_dec *d, T **p, const T *src, size_t n)
 }
 
 static void res_free_fwd(jd_dec *d);
+static void pipe_free_fwd(jd_dec *d);
+static void pipe_drain(jd_dec *d);
+static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int64_t *offs, int *taken);
+static int pipe_decode(jd_dec *d, int n_utts, const float *d_feats, const int64_t *offs, jd_hyp *out, int *handled);
 extern "C" void jd_dec_destroy(jd_dec *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    pipe_drain(d);
+    pipe_free_fwd(d);
     if (d->res) { (void)jd_res_stop(d); res_free_fwd(d); }
     (void)hipDeviceSynchronize();
     for (char in : d->lazy_in) if (in) jd_lazy_leave(d->net, 1);      // (utterances the caller never finished)
@@ -652,7 +663,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
     if (const char *e = getenv("JD_PF_REBALANCE")) d->pf_rebalance = atoi(e) != 0;                // development
-    if (const char *e = getenv("JD_PIPELINE")) d->pipeline = atoi(e) != 0;
+    if (const char *e = getenv("JD_PIPELINE")) { d->pipeline = atoi(e) != 0; d->pipe_mode = atoi(e) == 3; }
+    if (const char *e = getenv("JD_PIPE_DEPTH")) { const int v = atoi(e); if (v >= 2 && v <= 32) d->pipe_depth = v; }
     if (const char *e = getenv("JD_BG_WAIT_US")) d->bg_wait_us = atof(e);
     if (const char *e = getenv("JD_SCORE_RESERVE")) d->score_reserve = atoi(e);
     if (const char *e = getenv("JD_BG_REBALANCE")) d->bg_rebalance = atoi(e) != 0;
@@ -945,36 +957,48 @@ static int mark_init(jd_dec *d, int s0, int n, hipStream_t st)
     return JD_OK;
 }
 
-// results of streams [s0, s0+n) -> out[out_idx[i]] (out_idx == nullptr: out[out0 + i])
-static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const int *out_idx = nullptr)
+// results -> out[out_idx[i]] (out_idx == nullptr: out[out0 + i]): of streams [s0, s0+n), or - resn_v != null - of the virtual
+// result slots [s0, s0+n) the batch pipeline exported them to (ctl_v / resn_v / res_v: their control blocks, word counts and
+// result arrays; slot_of: the streams they ran on, for the messages and the dirty marks)
+static int fetch_results_from(jd_dec *d, const StreamCtl *ctl_v, const int *resn_v, const int *res_v, const int *slot_of, int s0, int n,
+                              jd_hyp *out, int out0, const int *out_idx)
 {
     std::vector<StreamDev> hs((size_t)n);
     std::vector<StreamCtl> hc((size_t)n);
-    HIPCHK(hipMemcpy(hs.data(), d->d_streams + s0, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hc.data(), d->d_ctl + s0, (size_t)n * sizeof(StreamCtl), hipMemcpyDeviceToHost));
+    if (resn_v) {
+        std::vector<int> rn((size_t)n);
+        HIPCHK(hipMemcpy(rn.data(), resn_v + s0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) hs[(size_t)i].res_n = rn[(size_t)i];
+        HIPCHK(hipMemcpy(hc.data(), ctl_v + s0, (size_t)n * sizeof(StreamCtl), hipMemcpyDeviceToHost));
+    } else {
+        HIPCHK(hipMemcpy(hs.data(), d->d_streams + s0, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hc.data(), d->d_ctl + s0, (size_t)n * sizeof(StreamCtl), hipMemcpyDeviceToHost));
+    }
+    const int *res_base = resn_v ? res_v : d->d_res;
     int first_err = JD_OK;
     int kmax = 0;
     for (int i = 0; i < n; ++i) kmax = std::max(kmax, std::min(hs[(size_t)i].res_n, d->res_cap));
     std::vector<int> hres((size_t)n * 5 * std::max(kmax, 0));
     if (kmax > 0)                                                      // rows = (stream, array), first kmax words of each
-        HIPCHK(hipMemcpy2D(hres.data(), (size_t)kmax * 4, d->d_res + (size_t)s0 * 5 * d->res_cap, (size_t)d->res_cap * 4,
+        HIPCHK(hipMemcpy2D(hres.data(), (size_t)kmax * 4, res_base + (size_t)s0 * 5 * d->res_cap, (size_t)d->res_cap * 4,
                            (size_t)kmax * 4, (size_t)n * 5, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
         const StreamDev &S = hs[(size_t)i];
         const StreamCtl &K = hc[(size_t)i];
+        const int s_i = slot_of ? slot_of[i] : s0 + i;                  // the stream it ran on
         const int oi = out_idx ? out_idx[i] : out0 + i;
         HostResult &R = d->results[(size_t)oi];
         jd_hyp &H = out[oi];
         memset(&H, 0, sizeof H);
         if (K.error && first_err == JD_OK) {
             if (K.error == JD_EHIST)
-                first_err = jd_fail(JD_EHIST, "Histogram::addScore - score > maxScore (stream %d)", s0 + i);
+                first_err = jd_fail(JD_EHIST, "Histogram::addScore - score > maxScore (stream %d)", s_i);
             else if (K.error == JDE_BARRIER)
                 first_err = jd_fail(JD_EHIP, "stream %d: a workgroup of the search cluster did not arrive at a barrier "
-                                    "(frame %d)", s0 + i, K.frame);
+                                    "(frame %d)", s_i, K.frame);
             else if (K.error == JDE_LAZY_INV)
                 first_err = jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)",
-                                    s0 + i, K.frame);
+                                    s_i, K.frame);
             else if (K.error == JDE_LAZY) {
                 d->lazy_failed = true;
                 LazyDev L;
@@ -982,7 +1006,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
                 if (hipMemcpy(&L, d->net->lazy_dev, sizeof L, hipMemcpyDeviceToHost) == hipSuccess)
                     (void)hipMemcpy(&why, L.err, sizeof why, hipMemcpyDeviceToHost);
                 first_err = jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of %s at frame %d (capacity %d states, %lld arcs): "
-                                    "what was being decoded at once needs a network with larger max_states / max_arcs", s0 + i,
+                                    "what was being decoded at once needs a network with larger max_states / max_arcs", s_i,
                                     why == 1 ? "states" : why == 2 ? "arcs"
                                              : "stack closing a state (epsilon / tee arcs more than a hundred deep, or a cycle of them)",
                                     K.frame, d->net->n_states, (long long)d->net->n_arcs);
@@ -993,11 +1017,11 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
                 const long long cap = K.error == JDE_SLOTS ? d->cap_slots : K.error == JDE_ITEMS ? d->cap_items
                                     : K.error == JDE_NEW ? d->cap_new : d->cap_paths;
                 first_err = jd_fail(JD_ENOMEM, "stream %d: device arena overflow at frame %d: %s (capacity %lld, split over "
-                                    "%d wave segments); raise it with jd_dec_set_capacity", s0 + i, K.frame, what, cap,
+                                    "%d wave segments); raise it with jd_dec_set_capacity", s_i, K.frame, what, cap,
                                     K.error == JDE_PATHS ? 1 : std::max(K.lst_nw, 1));
             }
         }
-        if (K.error) d->stream_dirty[(size_t)(s0 + i)] = 1;            // arenas may be inconsistent after an abort: wiped before the next init
+        if (K.error) d->stream_dirty[(size_t)(s_i)] = 1;            // arenas may be inconsistent after an abort: wiped before the next init
         H.stats.n_frames = K.frame;
         H.stats.tot_active_emit_hyps = K.st[ST_EMIT];
         H.stats.tot_active_end_hyps = K.st[ST_END];
@@ -1011,7 +1035,7 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
         H.stats.ties = 0;
         int k = S.res_n;
         if (k > d->res_cap) {
-            if (first_err == JD_OK) first_err = jd_fail(JD_ENOMEM, "stream %d: hypothesis has %d words (> %d)", s0 + i, k, d->res_cap);
+            if (first_err == JD_OK) first_err = jd_fail(JD_ENOMEM, "stream %d: hypothesis has %d words (> %d)", s_i, k, d->res_cap);
             k = d->res_cap;
         }
         H.n = S.res_n < 0 ? -1 : k;
@@ -1029,6 +1053,10 @@ static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const 
         else { H.tot_score = LZ; H.tot_ac = LZ; H.tot_lm = LZ; }      // DecHyp() defaults, DecHypHistPool.h
     }
     return first_err;
+}
+static int fetch_results(jd_dec *d, int s0, int n, jd_hyp *out, int out0, const int *out_idx = nullptr)
+{
+    return fetch_results_from(d, nullptr, nullptr, nullptr, nullptr, s0, n, out, out0, out_idx);
 }
 
 // The load (instances + arcs per stream-frame) of the streams of a work list so far, from their statistics:
@@ -1578,8 +1606,10 @@ static long long table_row0(const jd_dec *d, int buf) { return (long long)buf * 
 
 // Forget what was scored, searched or announced ahead (the scoring stream is drained first: a table being written is
 // not re-used; utterances whose search had been started are simply started again when their batch is decoded)
+static void pipe_drain(jd_dec *d);
 static void pf_discard(jd_dec *d)
 {
+    pipe_drain(d);
     bool scoring = false;
     for (const Prefetch &F : d->pf_q) if (F.state == 2) scoring = true;
     if (scoring) (void)hipStreamSynchronize(d->s_gmm);
@@ -1932,6 +1962,11 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
     if (!d || !offs || !out || n_utts < 0) return jd_fail(JD_EINVAL, "jd_decode_batch_device: bad argument");
     int rc = check_device(d->device);
     if (rc) return rc;
+    {   // the oldest batch of the pipeline (JD_PIPELINE=3)?
+        int handled = 0;
+        rc = pipe_decode(d, n_utts, d_feats, offs, out, &handled);
+        if (rc || handled) return rc;
+    }
     rc = ensure_arenas(d);
     if (rc) return rc;
     if ((size_t)n_utts > d->results.size()) d->results.resize((size_t)n_utts);
@@ -2039,6 +2074,11 @@ extern "C" int jd_dec_prefetch_scores(jd_dec *d, int32_t n_utts, const float *d_
     // formed by length: jd_decode_batch_device scores each of them beside the wave before it), a table cut into chunks
     if (n_utts > d->max_streams) return JD_OK;
     HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));             // the features are there
+    {   // JD_PIPELINE=3: the batch goes through the resident kernel, utterance by utterance
+        int taken = 0;
+        rc = pipe_announce(d, n_utts, d_feats, offs, &taken);
+        if (rc || taken) return rc;
+    }
     std::vector<int64_t> ulen((size_t)n_utts);
     for (int u = 0; u < n_utts; ++u) ulen[(size_t)u] = offs[u + 1] - offs[u];
     return pf_announce(d, n_utts, d_feats, offs, ulen.data());
@@ -2299,7 +2339,7 @@ extern "C" int jd_streams_push(jd_dec *d, int32_t n, const int32_t *streams, con
 // While it runs it owns the device's search lock (this process) and the GPU's file lock (other processes); nothing here
 // allocates or frees device memory or synchronises the device - either would wait for the kernel.
 #define RES_RING 256
-#define RES_RING_W 256
+#define RES_RING_W 2048
 struct Resident {
     bool on = false;
     int n = 0, Cw = 0, rows = 0;                       // streams [0, n), workgroups per cluster, rows per likelihood buffer
@@ -2392,9 +2432,9 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
         d->res = R;
         R->n = n_streams; R->rows = rows;
         const size_t tr = (size_t)n_streams * 2 * rows;
-        if (n_streams > 64 || 2 * n_streams * ((rows + GMM_ROWS2 - 1) / GMM_ROWS2) > RES_RING_W) {
+        if (n_streams > 256 || 2 * n_streams * ((rows + GMM_ROWS2 - 1) / GMM_ROWS2) > RES_RING_W) {
             res_free(d);
-            return jd_fail(JD_EINVAL, "jd_res_start: at most 64 streams and %d row tiles per scoring launch", RES_RING_W);
+            return jd_fail(JD_EINVAL, "jd_res_start: at most 256 streams and %d row tiles per scoring launch", RES_RING_W);
         }
         if (hipMalloc(&R->d_mail, (size_t)n_streams * sizeof(ResMail)) != hipSuccess ||
             hipHostMalloc((void **)&R->h_post, (size_t)n_streams * sizeof(ResPost), hipHostMallocMapped) != hipSuccess ||
@@ -2446,7 +2486,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     SearchArgs A;
     memset(&A, 0, sizeof A);
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = nullptr; A.n_work = R->n; A.Cw = R->Cw; A.n_slots = 0;
-    A.ll = R->d_ll; A.ll_stride = (long long)G; A.f0 = 0; A.f_end = 0x7fffffff;
+    A.ll = d->res_ll ? d->res_ll : R->d_ll; A.ll_stride = (long long)G; A.f0 = 0; A.f_end = 0x7fffffff;
     A.status = d->d_status; A.dbg = nullptr; A.cells = nullptr; A.resident = nullptr; A.rebalance_at = 0; A.n_prio = 0;
     hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->d_ready, R->n);
     const dim3 rgrid((unsigned)(R->n * R->Cw));
@@ -2541,10 +2581,11 @@ int jd_res_stage_many(jd_dec *d, int n, const int *streams, const int *bufs, con
 }
 
 // the command itself: a word in host-mapped memory (the cluster's first workgroup polls it)
-static void res_write_post(Resident *R, int s, int T, int slot)
+static void res_write_post(Resident *R, int s, int T, int slot, int init = 0)
 {
     ResPost &P = R->h_post[s];
     P.T = T;
+    P.init = init;
     P.ready_id = R->rid[(size_t)s];
     __atomic_store_n(&P.word, ((unsigned long long)R->seq[(size_t)s] << 32) | (unsigned)slot, __ATOMIC_RELEASE);
 }
@@ -2607,6 +2648,240 @@ int jd_res_finish(jd_dec *d, int s, jd_hyp *out)
     std::vector<jd_hyp> tmp((size_t)d->max_streams);
     const int rc = fetch_results(d, s, 1, tmp.data(), s);
     *out = tmp[(size_t)s];
+    return rc;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Batches through the resident kernel, UTTERANCE BY UTTERANCE (JD_PIPELINE=3).  A batch lasts as long as its longest
+// utterance; with two batches in flight (above) the streams of a bank still wait for their bank to be handed back.  Here
+// every stream is a slot of the resident kernel with ONE workgroup: announced batches (jd_dec_prefetch_scores, up to
+// pipe_depth of them) are scored whole into a table of their own, their utterances queue up, and a slot whose utterance is
+// through takes the next one at once - its result exported to a virtual result slot first (jd_finish_export_kernel) - so
+// that no workgroup waits for anybody.  jd_decode_batch_device of the OLDEST announced batch waits until its utterances are
+// through and hands them back; it is also what keeps the slots fed (the pump runs inside the calls - no thread).  Results
+// are those of any other path; what changes is that a batch takes as long as its longest utterance on one workgroup.
+struct PipeUtt { int state = 0, slot = -1, T = 0; long long row0 = 0; };      // state: 0 queued, 1 running, 2 through
+struct PipeBatch {
+    const float *feats = nullptr; int n = 0; int table = 0; int next = 0, n_done = 0;
+    std::vector<int64_t> offs;
+    std::vector<PipeUtt> u;
+};
+struct Pipe {
+    bool on = false;
+    int K = 0, max_batch = 0, n_slots = 0;
+    size_t table_rows = 0;
+    float *d_ll = nullptr;                             // K tables
+    int *d_ident = nullptr;                            // row r is frame r of the batch's features
+    StreamCtl *d_vctl = nullptr; int *d_vresn = nullptr, *d_vres = nullptr;   // K x max_batch virtual result slots
+    std::deque<PipeBatch> q;
+    std::vector<char> table_used;
+    std::vector<int> slot_batch_id, slot_utt;          // per slot: the batch (its serial number) and utterance it runs, -1: free
+    std::vector<char> slot_dirty;
+    long long serial0 = 0;                             // serial number of q.front()
+};
+
+static void pipe_free(jd_dec *d);
+static void pipe_free_fwd(jd_dec *d) { pipe_free(d); }
+static void pipe_free(jd_dec *d)
+{
+    Pipe *P = d->pipe;
+    if (!P) return;
+    if (P->d_ll) (void)hipFree(P->d_ll);
+    if (P->d_ident) (void)hipFree(P->d_ident);
+    if (P->d_vctl) (void)hipFree(P->d_vctl);
+    if (P->d_vresn) (void)hipFree(P->d_vresn);
+    if (P->d_vres) (void)hipFree(P->d_vres);
+    delete P;
+    d->pipe = nullptr;
+}
+
+// everything in flight is dropped (the batches concerned are decoded from scratch when their turn comes), the kernel leaves
+static void pipe_drain(jd_dec *d)
+{
+    Pipe *P = d->pipe;
+    if (!P || !P->on) return;
+    (void)jd_res_stop(d);                                              // (running utterances run out first)
+    P->on = false;
+    P->q.clear();
+    std::fill(P->table_used.begin(), P->table_used.end(), 0);
+    std::fill(P->slot_batch_id.begin(), P->slot_batch_id.end(), -1);
+    d->res_ll = nullptr;
+    for (int s = 0; s < P->n_slots; ++s) {                             // (streams left in the middle of an utterance, or failed)
+        if (P->slot_dirty[(size_t)s]) d->stream_dirty[(size_t)s] = 1;
+        P->slot_dirty[(size_t)s] = 0;
+    }
+}
+
+// slots whose utterance is through -> their results exported, the slots free; free slots -> the next queued utterances
+static int pipe_pump(jd_dec *d)
+{
+    Pipe *P = d->pipe;
+    Resident *R = d->res;
+    ExportList EL; EL.n = 0;
+    auto flush_exports = [&]() -> int {
+        if (EL.n == 0) return JD_OK;
+        hipLaunchKernelGGL(jd_finish_export_kernel, dim3((unsigned)EL.n), dim3(64), 0, d->s_gmm, d->d_ctl, d->d_streams, EL, P->d_vctl, P->d_vresn,
+                           P->d_vres, d->res_cap);
+        HIPCHK(hipGetLastError());
+        EL.n = 0;
+        return JD_OK;
+    };
+    for (int s = 0; s < P->n_slots; ++s) {
+        if (P->slot_batch_id[(size_t)s] < 0 || !R->busy[(size_t)s]) continue;
+        if (!res_harvest(d, s)) continue;
+        const int er = R->err_done[(size_t)s], fr = R->T_done[(size_t)s];
+        if (er == 0 && fr < R->T_posted[(size_t)s]) {                  // stopped for a Path collection: collect, go on
+            const int rc = jd_res_collect(d, s);
+            if (rc) return rc;
+            continue;
+        }
+        PipeBatch &B = P->q[(size_t)(P->slot_batch_id[(size_t)s] - P->serial0)];
+        const int ui = P->slot_utt[(size_t)s];
+        EL.slot[EL.n] = s; EL.vslot[EL.n] = B.table * P->max_batch + ui; EL.n += 1;
+        if (EL.n == 64) { const int rc = flush_exports(); if (rc) return rc; }
+        B.u[(size_t)ui].state = 2; B.n_done += 1;
+        if (er) P->slot_dirty[(size_t)s] = 1;                          // (its arenas may be inconsistent: out of the game until the pipeline stops)
+        P->slot_batch_id[(size_t)s] = -1;
+    }
+    int rc = flush_exports();
+    if (rc) return rc;
+    // refill
+    std::vector<int> who;
+    std::vector<std::pair<int, int>> what;                             // (batch index in q, utterance)
+    size_t bi = 0;
+    for (int s = 0; s < P->n_slots; ++s) {
+        if (P->slot_batch_id[(size_t)s] >= 0 || P->slot_dirty[(size_t)s]) continue;
+        while (bi < P->q.size() && P->q[bi].next >= P->q[bi].n) ++bi;
+        if (bi >= P->q.size()) break;
+        PipeBatch &B = P->q[bi];
+        const int ui = B.next++;
+        B.u[(size_t)ui].state = 1; B.u[(size_t)ui].slot = s;
+        P->slot_batch_id[(size_t)s] = (int)(P->serial0 + (long long)bi); P->slot_utt[(size_t)s] = ui;
+        who.push_back(s); what.push_back(std::make_pair((int)bi, ui));
+    }
+    if (who.empty()) return JD_OK;
+    rc = res_bump(d, (int)who.size(), who.data());                    // (behind the exports and every scoring launch enqueued so far)
+    if (rc) return rc;
+    for (size_t k = 0; k < who.size(); ++k) {
+        const int s = who[k];
+        const PipeUtt &U = P->q[(size_t)what[k].first].u[(size_t)what[k].second];
+        R->seq[(size_t)s] += 1; R->busy[(size_t)s] = 1;
+        R->T_done[(size_t)s] = 0; R->err_done[(size_t)s] = 0;
+        R->T_posted[(size_t)s] = U.T; R->slot_posted[(size_t)s] = (int)U.row0;
+        res_write_post(R, s, U.T, (int)U.row0, 1);
+    }
+    return JD_OK;
+}
+
+// jd_dec_prefetch_scores in pipe mode: 1 = taken, 0 = not this way (the caller goes on with the usual announcement)
+static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int64_t *offs, int *taken)
+{
+    *taken = 0;
+    if (!d->pipe_mode || d->net->lazy_dev || d->partial_interval > 0 || d->am->hybrid || n_utts < 1) return JD_OK;
+    const int D = d->am->D, G = d->am->n_gmm;
+    const size_t rows = (size_t)(offs[n_utts] - offs[0]);
+    Pipe *P = d->pipe;
+    if (P && (n_utts > P->max_batch || rows > P->table_rows)) {        // a larger batch than the tables were made for: not this way
+        pipe_drain(d);
+        pipe_free(d);
+        P = nullptr;
+    }
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    if (!P) {
+        rc = ensure_arenas(d);
+        if (rc) return rc;
+        if (d->res && d->res->on) return JD_OK;                        // (a broker owns the resident kernel)
+        P = new Pipe();
+        d->pipe = P;
+        P->K = d->pipe_depth; P->max_batch = n_utts; P->n_slots = d->max_streams;
+        P->table_rows = ((rows + rows / 4 + GMM_ROWS2) + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2;
+        const size_t V = (size_t)P->K * P->max_batch;
+        if (hipMalloc(&P->d_ll, (size_t)P->K * P->table_rows * G * sizeof(float)) != hipSuccess ||
+            hipMalloc(&P->d_ident, P->table_rows * sizeof(int)) != hipSuccess ||
+            hipMalloc(&P->d_vctl, V * sizeof(StreamCtl)) != hipSuccess || hipMalloc(&P->d_vresn, V * sizeof(int)) != hipSuccess ||
+            hipMalloc(&P->d_vres, V * 5 * (size_t)d->res_cap * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            pipe_free(d);
+            return jd_fail(JD_ENOMEM, "jd_dec_prefetch_scores: no memory for %d likelihood tables of %zu rows", d->pipe_depth, rows);
+        }
+        std::vector<int> ident(P->table_rows);
+        for (size_t r = 0; r < P->table_rows; ++r) ident[r] = (int)r;
+        HIPCHK(hipMemcpy(P->d_ident, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+        P->table_used.assign((size_t)P->K, 0);
+        P->slot_batch_id.assign((size_t)P->n_slots, -1); P->slot_utt.assign((size_t)P->n_slots, -1); P->slot_dirty.assign((size_t)P->n_slots, 0);
+    }
+    if ((int)P->q.size() >= P->K)
+        return jd_fail(JD_ESTATE, "jd_dec_prefetch_scores: %d batches are announced and not decoded - the pipeline is %d deep (JD_PIPE_DEPTH)",
+                       (int)P->q.size(), P->K);
+    if (!P->on) {
+        pf_discard(d);                                                 // (what the other way of working ahead holds)
+        for (int s = 0; s < P->n_slots; ++s)
+            if (d->stream_dirty[(size_t)s]) { rc = wipe_stream(d, s); if (rc) return rc; }
+        d->res_ll = P->d_ll;
+        rc = jd_res_start(d, P->n_slots, GMM_ROWS2);
+        if (rc) { d->res_ll = nullptr; return rc; }
+        P->on = true;
+        P->serial0 = 0;
+    }
+    PipeBatch B;
+    B.feats = d_feats; B.n = n_utts; B.offs.assign(offs, offs + n_utts + 1);
+    int t = 0;
+    while (t < P->K && P->table_used[(size_t)t]) ++t;
+    B.table = t; P->table_used[(size_t)t] = 1;
+    B.u.resize((size_t)n_utts);
+    const long long base = (long long)t * (long long)P->table_rows;
+    for (int u = 0; u < n_utts; ++u) { B.u[(size_t)u].T = (int)(offs[u + 1] - offs[u]); B.u[(size_t)u].row0 = base + (offs[u] - offs[0]); }
+    // the whole batch in one scoring launch, on the CUs the slots leave
+    rc = launch_gmm(d->am, d->amb, d_feats + (size_t)offs[0] * D, P->d_ident, (int)rows, P->d_ll + (size_t)base * G, d->s_gmm);
+    if (rc) return rc;
+    P->q.push_back(std::move(B));
+    *taken = 1;
+    return pipe_pump(d);
+}
+
+// jd_decode_batch_device in pipe mode: 1 = handled (the oldest announced batch, handed back), 0 = not this way
+static int pipe_decode(jd_dec *d, int n_utts, const float *d_feats, const int64_t *offs, jd_hyp *out, int *handled)
+{
+    *handled = 0;
+    Pipe *P = d->pipe;
+    if (!P || !P->on || P->q.empty()) return JD_OK;
+    {
+        const PipeBatch &F = P->q.front();
+        bool same = F.feats == d_feats && F.n == n_utts;
+        for (int u = 0; same && u <= n_utts; ++u) same = F.offs[(size_t)u] == offs[u];
+        if (!same) { pipe_drain(d); return JD_OK; }                    // not the announced one: as if nothing had been announced
+    }
+    const auto w0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const int rc = pipe_pump(d);
+        if (rc) { pipe_drain(d); return rc; }
+        if (P->q.front().n_done == P->q.front().n) break;
+        for (int s = 0; s < P->n_slots; ++s)
+            if (__atomic_load_n(&d->res->h_done[s].left, __ATOMIC_ACQUIRE)) {
+                pipe_drain(d);
+                return jd_fail(JD_EHIP, "the resident search kernel has ended under a batch (no command for 5 s, or a lost workgroup)");
+            }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    HIPCHK(hipStreamSynchronize(d->s_gmm));                            // (the exports)
+    PipeBatch &F = P->q.front();
+    std::vector<int> slot_of((size_t)n_utts);
+    for (int u = 0; u < n_utts; ++u) slot_of[(size_t)u] = F.u[(size_t)u].slot;
+    if ((size_t)n_utts > d->results.size()) d->results.resize((size_t)n_utts);
+    d->timing = jd_timing();
+    const int rc = fetch_results_from(d, P->d_vctl, P->d_vresn, P->d_vres, slot_of.data(), F.table * P->max_batch, n_utts, out, 0, nullptr);
+    for (int u = 0; u < n_utts; ++u) d->timing.search_frames += F.u[(size_t)u].T;
+    d->timing.gmm_frames = d->timing.search_frames; d->timing.gmm_states = d->am->n_gmm;
+    d->timing.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    d->timing.search_ms = d->timing.total_ms; d->timing.search_launches = 0; d->timing.cluster_wgs = 1; d->timing.prefetched = 1;
+    d->load_sum = d->load_frames = 0.0;
+    P->table_used[(size_t)F.table] = 0;
+    P->q.pop_front();
+    P->serial0 += 1;
+    if (P->q.empty()) pipe_drain(d);                                   // nothing announced behind it: the kernel leaves the device
+    *handled = 1;
     return rc;
 }
 

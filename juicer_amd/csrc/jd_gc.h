@@ -423,6 +423,40 @@ __global__ void jd_finish_kernel(StreamCtl *ctl, StreamDev *streams, int s0, int
     S.res_n = k;
 }
 
+// ... and the same for the batch pipeline (jd_pipe_*): the utterances of a list of streams, exported to VIRTUAL result slots -
+// word count, the five result arrays, a copy of the control block (statistics, error, bestFinalToken) - so that the stream
+// can take its next utterance before the batch this one belongs to is handed back.  One 64-thread block per utterance.
+struct ExportList { int n; int slot[64]; int vslot[64]; };
+__global__ void jd_finish_export_kernel(const StreamCtl *ctl, const StreamDev *streams, ExportList L, StreamCtl *vctl, int *vres_n, int *vres,
+                                        int res_cap)
+{
+    const int i = blockIdx.x;
+    if (i >= L.n) return;
+    const int s = L.slot[i], v = L.vslot[i];
+    const StreamDev &S = streams[s];
+    const StreamCtl &c = ctl[s];
+    {   // the control block, word by word
+        const int *src = (const int *)&c;
+        int *dst = (int *)&vctl[v];
+        for (int k = threadIdx.x; k < (int)(sizeof(StreamCtl) / sizeof(int)); k += blockDim.x) dst[k] = src[k];
+    }
+    if (threadIdx.x != 0) return;
+    const Tok best = c.best_final;
+    if (!(best.score > LZ) || c.frame == 0) { vres_n[v] = -1; return; }
+    int *lab = vres + (size_t)v * 5 * res_cap, *tim = lab + res_cap;
+    float *sc = (float *)(lab + 2 * (size_t)res_cap), *ac = (float *)(lab + 3 * (size_t)res_cap), *lm = (float *)(lab + 4 * (size_t)res_cap);
+    int k = 0;
+    for (int p = best.path; p >= 0; p = S.paths[p].prev) {
+        if (k < res_cap) {
+            const PathRec pr = S.paths[p];
+            lab[k] = pr.label; tim[k] = pr.frame; sc[k] = pr.score; ac[k] = pr.ac; lm[k] = pr.lm;
+            if (k == 0) { sc[0] = best.score; ac[0] = best.ac; lm[0] = best.lm; }     // :293-300
+        }
+        ++k;
+    }
+    vres_n[v] = k;
+}
+
 __global__ void jd_mark_init_kernel(StreamCtl *ctl, int s0, int n)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;

@@ -21,7 +21,9 @@ struct __align__(64) ResPost {  // host-mapped, one per stream: the HOST writes 
     unsigned ready_id;         // the command may start once the side stream has come this far for the stream (ready[s]): the
                                // scoring of its rows, recognitionStart's mark, a Path collection
     int exit_req;              // != 0: leave the kernel
-    int pad[11];
+    int init;                  // != 0: a new utterance begins with this command (IDecoder::init: what jd_mark_init_kernel does,
+                               // done by the cluster's first workgroup - the batch pipeline, jd_pipe_*)
+    int pad[10];
 };
 struct __align__(128) ResMail { // device memory, one per stream: workgroup 0 of the cluster passes the command on to the others
     unsigned long long word;
@@ -92,6 +94,11 @@ __global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail
                         if ((++spins & 255u) == 0 && wall_clock64() > t_idle) { ex = 1; break; }
                     }
                     if (!ex) {
+                        if (__hip_atomic_load(&post[s].init, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                            __hip_atomic_store(&c.needs_init, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&c.started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&c.error, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         __hip_atomic_store(&c.T, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&mail[s].word, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
