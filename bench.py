@@ -119,7 +119,7 @@ def leg_traffic(leg, launches):
 
 
 def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, gnet=None, pmc_leg=None, oracle_feats=None,
-            oracle_net=None, ahead=True, max_streams=0, two=None):
+            oracle_net=None, ahead=True, max_streams=0, two=None, pipe=None):
     """One extra workload: warm-up pass + timed passes on one GPU (value = the MEDIAN pass), its own roofline.
     gnet: a network that exists already (composed on the device); net is then only asked for its size.
     pmc_leg: the name the leg's PMC passes are filed under (leg_traffic).  oracle_utts: that many utterances are
@@ -128,15 +128,21 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
     oracle_net: the oracle's copy of the graph when `net` is not a synthetic network object.  two: two batches in
     flight, like the headline (streams for two batches, announcements two passes ahead; default: when the passes
     are given; default off: it pays where a frame is a chain of dependent steps, not where it is bytes - the heavy legs
-    lose by it, measured: the 14 M-arc graph 119 k -> 55 k frames/s, configs[3] 5.3 k -> 0.8 k)."""
+    lose by it, measured: the 14 M-arc graph 119 k -> 55 k frames/s, configs[3] 5.3 k -> 0.8 k).  pipe = (depth, slots): the
+    batches through the resident search kernel, like the headline; every announced batch is decoded (depth calls more)."""
     import torch
     from juicer_amd import capi
     U = len(feats)
     t0 = time.perf_counter()
     if two is None:
         two = False
+    depth = 0
+    if pipe:
+        depth, max_streams, two = pipe[0], pipe[1], False
+        os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = str(depth + 1)
     dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam,
                        max_hyps=max_hyps, device=dev.index, max_streams=(2 * U if two else U) if not max_streams else max_streams)
+    os.environ.pop("JD_PIPELINE", None); os.environ.pop("JD_PIPE_DEPTH", None)
     offs = np.zeros(U + 1, dtype=np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in feats])
     d_feats = torch.from_numpy(np.concatenate(feats)).to(dev)
@@ -147,18 +153,29 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
     if two:
         dec.prefetch_scores(d_feats.data_ptr(), offs, stream)          # (the announcements run two passes ahead)
         passes += 1                                                    # (... and the pipeline takes a pass more to fill)
-    for i in range(passes):
-        torch.cuda.synchronize()
+    if depth:
+        for _ in range(depth):
+            dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
+        passes += depth + 2                                            # (the first batches come back in a burst)
+    n_calls = passes + depth                                           # (pipe: every announced batch is decoded)
+    for i in range(n_calls):
+        if not depth:
+            torch.cuda.synchronize()                                   # (a device-wide synchronisation waits for a resident kernel)
         t1 = time.perf_counter()
-        if ahead:                                                      # the next pass's table is scored beside this pass's search
+        if ahead and (not depth or i < passes):                        # the next pass's table is scored beside this pass's search
             dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
         hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
-        torch.cuda.synchronize()
+        if not depth:
+            torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         tm_i = dec.last_timing()
         if not tm_i["prefetched"]:
             gmm_alone = tm_i["gmm_ms"]                                 # (the warm-up pass scores its own table, on its own)
-        if i > (1 if two else 0) or passes == 1:
+        if depth:
+            if depth + 2 <= i < passes:
+                tm_i = dict(tm_i); tm_i["search_ms"] = dt * 1e3; tm_i["search_launches"] = 1
+                runs.append((dt, tm_i))
+        elif i > (1 if two else 0) or passes == 1:
             runs.append((dt, tm_i))
     dec.prefetch_scores(0, None)
     runs.sort(key=lambda r: r[0])
@@ -171,8 +188,8 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
            "frames_per_step": frames, "ms_per_step": round(best * 1e3, 3),
            "timed_passes": len(runs), "ms_per_step_min": round(runs[0][0] * 1e3, 3), "ms_per_step_max": round(runs[-1][0] * 1e3, 3),
            "search_ms": round(tm["search_ms"], 3), "gmm_ms": round(gmm_alone if gmm_alone is not None else tm["gmm_ms"], 3),
-           "scored_ahead": bool(tm["prefetched"]), "batches_in_flight": 2 if two else 1, "searched_ahead_frames": int(tm["ahead_frames"]),
-           "decode_calls": passes,
+           "scored_ahead": bool(tm["prefetched"]), "batches_in_flight": (depth + 1) if depth else (2 if two else 1),
+           "searched_ahead_frames": int(tm["ahead_frames"]), "decode_calls": n_calls,
            "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
                                                                               "tot_proc_end_hyps", "tot_arcs_visited", "tot_paths")},
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
@@ -299,6 +316,11 @@ def main():
                     help="score every batch's table right before its search (serial) instead of beside the previous batch's search")
     ap.add_argument("--no-search-ahead", action="store_true",
                     help="one batch in flight: the decoder gets streams for one batch only and the announcements run one batch ahead")
+    ap.add_argument("--pipeline-depth", type=int, default=6,
+                    help="weak scaling: batches announced ahead of the one being decoded, through the resident search kernel "
+                         "(JD_PIPELINE=3: every stream a one-workgroup slot that takes the next queued utterance when its own is through); "
+                         "0 = two batches in flight, one launch per step")
+    ap.add_argument("--pipeline-slots", type=int, default=160, help="streams (= workgroups) of the resident pipeline; the other CUs score")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -371,8 +393,17 @@ def main():
     # utterances of the batch behind the running one beside it - "two batches in flight")
     ahead = not args.no_score_ahead
     two_in_flight = ahead and not args.no_search_ahead and not strong
+    # ... or, deeper: the batches' utterances through the slots of a search kernel that stays ("batches through the
+    # resident kernel"): a batch is scored whole when it is announced, a slot takes the next queued utterance the moment its own
+    # is through, and a step hands back the oldest batch - still ITS 64 results, decoded in full
+    # (one rank only: with several, every step gathers the hypotheses through RCCL, whose kernels would have to start beside a
+    # kernel that never leaves - not something a 1-GPU box can try; those runs keep two batches in flight, one launch per step)
+    depth = args.pipeline_depth if (two_in_flight and world == 1 and args.pipeline_depth > 0) else 0
+    if depth:
+        os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = str(depth + 1)
     dec = capi.Decoder(gnet, gam, main_beam=args.beam, max_hyps=args.max_hyps, device=local_rank,
-                       max_streams=min(U, 128) if strong else (2 * U if two_in_flight else U))
+                       max_streams=min(U, 128) if strong else (args.pipeline_slots if depth else (2 * U if two_in_flight else U)))
+    os.environ.pop("JD_PIPELINE", None); os.environ.pop("JD_PIPE_DEPTH", None)
     offs = np.zeros(len(feats) + 1, dtype=np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in feats])
     frames_local = int(offs[-1])
@@ -398,10 +429,18 @@ def main():
         if world > 1:
             dist.barrier(**bar_kw)
 
-    if two_in_flight:
+    if depth:
+        for _ in range(depth):                                         # (the announcements run `depth` batches ahead)
+            dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
+        for _ in range(depth + 2):                                     # the pipeline fills: its first batches come back in a burst
+            step()
+    elif two_in_flight:
         dec.prefetch_scores(d_feats.data_ptr(), offs, stream)          # (the announcements run two batches ahead)
     for _ in range(args.warmup):
         step()
+    # (a device-wide synchronisation waits for every kernel on the device: the pipeline's resident kernel lets its running
+    # commands run out and leaves - jd_dec_quiesce - and comes back with the first timed step, inside the brackets)
+    dec.quiesce()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0,
@@ -416,6 +455,7 @@ def main():
         tm = dec.last_timing()
         for k in acc:
             acc[k] += tm[k]
+    dec.quiesce()
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     # (outside the timed region) the same step in the serial order: what the scoring kernel takes on its own
@@ -458,10 +498,18 @@ def main():
     step_tm["search_ms"] = acc["search_ms"] / steps
     step_tm["search_launches"] = max(1, acc["search_launches"] // steps)
     traffic = leg_traffic("c2", step_tm["search_launches"]) if default_cfg else None
+    if depth:                                                      # (the resident kernel is busy all the time: a batch's share of it is the step)
+        step_tm["search_ms"] = elapsed / steps * 1e3
     roofline = roofline_of(st, MN, step_tm, traffic)
+    if depth:
+        roofline["kernel"] = "k_resident"
+        roofline["launch"] = ("ONE launch spans the run (jd_resident.h): a batch's share of it = the timed region / K steps; "
+                              "avg_launch_us is that share, algorithmic_bytes_per_launch one batch's bytes; traffic = the counted HBM bytes "
+                              "of one batch through the SAME per-stream code with two batches in flight (legs.configs1_two_batches_in_flight: "
+                              "the profiler runs kernels one after the other under --pmc, and this one waits for the scoring beside it)")
     gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
     gmm_bytes = G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / max(1, tm["gmm_launches"])
-    roofline["search_ms_per_step"] = round(acc["search_ms"] / steps, 3)
+    roofline["search_ms_per_step"] = round(step_tm["search_ms"], 3)
     # the companion kernel is VALU-bound: per (frame pair, mixture) 4 packed fp32 instructions per dimension
     # + ~116 for the two logAdd steps, 4 cycles each on 1024 SIMDs
     gmm_valu_ms = (frames_local / 128.0) * G * M * (4.0 * D + 116.0) * 4.0 / 1024.0 / 2.4e9 * 1e3
@@ -537,7 +585,9 @@ def main():
                       "frames_per_step": int(frames_total), "utts_per_gpu": U, "gathered_hyps": n_gathered,
                       "parallelism": ("one batch of %d utterances dealt by length over %d rank(s)" % (args.total_utts, world)) if strong
                                      else "utterance-sharded x%d" % world,
-                      "batches_in_flight": 2 if two_in_flight else 1,
+                      "batches_in_flight": (depth + 1) if depth else (2 if two_in_flight else 1),
+                      "pipeline": ("resident search kernel: %d one-workgroup slots, the other CUs score; announcements %d batches ahead, a slot takes "
+                                   "the next queued utterance when its own is through" % (args.pipeline_slots, depth)) if depth else None,
                       "predicted_rank_ms": predicted_rank_ms if strong else None,
                       "search_ahead_frames_per_step": int(acc["ahead_frames"] // max(steps, 1)),
                       "streams_per_gpu": dec.max_streams},
@@ -551,8 +601,12 @@ def main():
         legs = {}
         try:
             no = 0 if args.no_cpu_baseline else 2                   # utterances the CPU oracle decodes per leg
+            pipe = (depth, args.pipeline_slots) if depth else None
             legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev, oracle_utts=no,
-                                                   two=two_in_flight, pmc_leg="hyps" if default_cfg else None)
+                                                   two=two_in_flight, pipe=pipe, passes=8 if pipe else 4, pmc_leg="hyps" if default_cfg else None)
+            if depth:                                               # the headline's batches with TWO of them in flight, one launch per step
+                legs["configs1_two_batches_in_flight"] = run_leg("configs[1], two batches in flight", am, net, feats, args.beam, args.max_hyps, dev,
+                                                                 two=True, pmc_leg="c2" if default_cfg else None)
             # configs[2]'s batch (512 utterances) on ONE GPU: waves of 128 streams inside one call, each wave's table scored
             # beside the wave before it - what the GPU does when a batch is not bounded by its longest utterance
             _, _, f512, _ = synth.config_c2(seed=args.seed, n_utts=512, target_arcs=args.arcs)

@@ -485,6 +485,11 @@ typedef struct jd_timing {
                                  flight": announcements two batches ahead, a batch on at most half of the streams) */
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
+/* The decoder's work on the device comes to rest: with JD_PIPELINE=3 (announced batches go through a search kernel that stays
+ * on the device, utterance by utterance: jd_dec_prefetch_scores up to JD_PIPE_DEPTH batches ahead) that kernel lets the
+ * commands that are running run out (128 frames at most) and leaves; nothing announced or under way is lost - it comes back
+ * with the next call.  What a caller needs before a device-wide synchronisation while batches are announced. */
+int jd_dec_quiesce(jd_dec *d);
 
 /* Diagnostics: per-workgroup cycle accounting of k_search (100 MHz wall clock).  enable >= 0 with
  * fetch == NULL switches it on and clears it, enable < 0 switches it off; with fetch != NULL

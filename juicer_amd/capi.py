@@ -76,7 +76,7 @@ EXPORTS = [
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
-    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_stream_path_counts", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
+    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_stream_path_counts", "jd_dec_quiesce", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
     "jd_net_lazy_set_high_water", "jd_net_lazy_generation", "jd_release_cached_memory", "jd_net_push_labels",
     "jd_dec_prefetch_scores", "jd_streams_push", "jd_dec_info",
     "jd_broker_create", "jd_broker_destroy", "jd_broker_open", "jd_broker_close", "jd_broker_init", "jd_broker_push",
@@ -416,6 +416,10 @@ class Decoder:
         n, last = C.c_int32(0), C.c_int32(-1)
         _check(lib().jd_stream_collect_info(self.h, C.c_int32(s), C.byref(n), C.byref(last)))
         return n.value, last.value
+
+    def quiesce(self):
+        """The decoder's resident kernel (JD_PIPELINE=3) leaves the device - call before a device-wide synchronisation (jd_dec_quiesce)."""
+        _check(lib().jd_dec_quiesce(self.h))
 
     def stream_path_counts(self, s: int = 0):
         """(nPath, nPathNew, exact): collectPaths' trigger counts; exact = they are the reference's (jd_stream_path_counts)."""

@@ -453,6 +453,7 @@ struct jd_dec {
     struct Resident *res = nullptr;        // the resident search kernel of a broker (jd_res_*), or null
     struct Pipe *pipe = nullptr;           // batches through the resident kernel, utterance by utterance (jd_pipe_*; JD_PIPELINE=3)
     bool pipe_mode = false;
+    bool pipe_on = false;                  // Pipe::on (for the code in front of the struct)
     int pipe_depth = 8;                    // likelihood tables = batches announced and not handed back, at most (JD_PIPE_DEPTH)
     const float *res_ll = nullptr;         // the likelihood slab the resident kernel reads (null: the broker's stream buffers)
     // results
@@ -2072,13 +2073,14 @@ extern "C" int jd_dec_prefetch_scores(jd_dec *d, int32_t n_utts, const float *d_
     if (n_utts == 0) { pf_discard(d); return JD_OK; }                  // nothing: what was scored or announced ahead is dropped
     // what cannot be scored ahead is scored when it is decoded, as ever: more utterances than streams (several waves,
     // formed by length: jd_decode_batch_device scores each of them beside the wave before it), a table cut into chunks
-    if (n_utts > d->max_streams) return JD_OK;
-    HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));             // the features are there
-    {   // JD_PIPELINE=3: the batch goes through the resident kernel, utterance by utterance
+    if (d->pipe_mode) {   // JD_PIPELINE=3: the batch goes through the resident kernel, utterance by utterance (any number of them)
+        HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));         // the features are there
         int taken = 0;
         rc = pipe_announce(d, n_utts, d_feats, offs, &taken);
         if (rc || taken) return rc;
     }
+    if (n_utts > d->max_streams) return JD_OK;
+    HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));             // the features are there
     std::vector<int64_t> ulen((size_t)n_utts);
     for (int u = 0; u < n_utts; ++u) ulen[(size_t)u] = offs[u + 1] - offs[u];
     return pf_announce(d, n_utts, d_feats, offs, ulen.data());
@@ -2423,7 +2425,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     if (rc) return rc;
     rc = ensure_arenas(d);
     if (rc) return rc;
-    pf_discard(d);
+    if (!d->pipe_on) pf_discard(d);                      // (not when the batch pipeline's kernel comes back: jd_dec_quiesce)
     const int D = d->am->D, G = d->am->n_gmm;
     const int rows = (rows_per_buf + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2;
     if (d->res && (d->res->n != n_streams || d->res->rows != rows)) { if (d->res->on) { rc = jd_res_stop(d); if (rc) return rc; } res_free(d); }
@@ -2662,6 +2664,7 @@ int jd_res_finish(jd_dec *d, int s, jd_hyp *out)
 // through and hands them back; it is also what keeps the slots fed (the pump runs inside the calls - no thread).  Results
 // are those of any other path; what changes is that a batch takes as long as its longest utterance on one workgroup.
 struct PipeUtt { int state = 0, slot = -1, T = 0; long long row0 = 0; };      // state: 0 queued, 1 running, 2 through
+#define PIPE_CHUNK 128                  // frames per command: what a slot runs before it looks at its mailbox again (jd_dec_quiesce waits that long)
 struct PipeBatch {
     const float *feats = nullptr; int n = 0; int table = 0; int next = 0, n_done = 0;
     std::vector<int64_t> offs;
@@ -2679,6 +2682,7 @@ struct Pipe {
     std::vector<int> slot_batch_id, slot_utt;          // per slot: the batch (its serial number) and utterance it runs, -1: free
     std::vector<char> slot_dirty;
     long long serial0 = 0;                             // serial number of q.front()
+    int chunk = PIPE_CHUNK;
 };
 
 static void pipe_free(jd_dec *d);
@@ -2702,7 +2706,7 @@ static void pipe_drain(jd_dec *d)
     Pipe *P = d->pipe;
     if (!P || !P->on) return;
     (void)jd_res_stop(d);                                              // (running utterances run out first)
-    P->on = false;
+    P->on = false; d->pipe_on = false;
     P->q.clear();
     std::fill(P->table_used.begin(), P->table_used.end(), 0);
     std::fill(P->slot_batch_id.begin(), P->slot_batch_id.end(), -1);
@@ -2727,17 +2731,28 @@ static int pipe_pump(jd_dec *d)
         EL.n = 0;
         return JD_OK;
     };
+    if (!R->on) {                                                      // (after jd_dec_quiesce: the kernel comes back, the slots go on where they were)
+        const int rc = jd_res_start(d, P->n_slots, GMM_ROWS2);
+        if (rc) return rc;
+    }
     for (int s = 0; s < P->n_slots; ++s) {
-        if (P->slot_batch_id[(size_t)s] < 0 || !R->busy[(size_t)s]) continue;
-        if (!res_harvest(d, s)) continue;
+        if (P->slot_batch_id[(size_t)s] < 0) continue;
+        if (R->busy[(size_t)s] && !res_harvest(d, s)) continue;
         const int er = R->err_done[(size_t)s], fr = R->T_done[(size_t)s];
+        PipeBatch &B = P->q[(size_t)(P->slot_batch_id[(size_t)s] - P->serial0)];
+        const int ui = P->slot_utt[(size_t)s];
+        const PipeUtt &U = B.u[(size_t)ui];
         if (er == 0 && fr < R->T_posted[(size_t)s]) {                  // stopped for a Path collection: collect, go on
             const int rc = jd_res_collect(d, s);
             if (rc) return rc;
             continue;
         }
-        PipeBatch &B = P->q[(size_t)(P->slot_batch_id[(size_t)s] - P->serial0)];
-        const int ui = P->slot_utt[(size_t)s];
+        if (er == 0 && fr < U.T) {                                     // its next frames
+            R->seq[(size_t)s] += 1; R->busy[(size_t)s] = 1;
+            R->T_posted[(size_t)s] = std::min(U.T, fr + P->chunk);
+            res_write_post(R, s, R->T_posted[(size_t)s], (int)U.row0, 0);
+            continue;
+        }
         EL.slot[EL.n] = s; EL.vslot[EL.n] = B.table * P->max_batch + ui; EL.n += 1;
         if (EL.n == 64) { const int rc = flush_exports(); if (rc) return rc; }
         B.u[(size_t)ui].state = 2; B.n_done += 1;
@@ -2768,8 +2783,24 @@ static int pipe_pump(jd_dec *d)
         const PipeUtt &U = P->q[(size_t)what[k].first].u[(size_t)what[k].second];
         R->seq[(size_t)s] += 1; R->busy[(size_t)s] = 1;
         R->T_done[(size_t)s] = 0; R->err_done[(size_t)s] = 0;
-        R->T_posted[(size_t)s] = U.T; R->slot_posted[(size_t)s] = (int)U.row0;
-        res_write_post(R, s, U.T, (int)U.row0, 1);
+        R->T_posted[(size_t)s] = std::min(U.T, P->chunk); R->slot_posted[(size_t)s] = (int)U.row0;
+        res_write_post(R, s, R->T_posted[(size_t)s], (int)U.row0, 1);
+    }
+    return JD_OK;
+}
+
+// The decoder's work on the device comes to rest: a search kernel of its own that stays on the device (the batch pipeline)
+// lets the commands that are running run out (PIPE_CHUNK frames at most) and leaves; nothing that is announced or under
+// way is lost - the kernel comes back with the next call and the slots go on where they were.  What a caller needs before
+// a device-wide synchronisation (hipDeviceSynchronize, torch.cuda.synchronize) while batches are announced.
+extern "C" int jd_dec_quiesce(jd_dec *d)
+{
+    if (!d) return jd_fail(JD_EINVAL, "jd_dec_quiesce: null");
+    if (d->pipe && d->pipe->on && d->res && d->res->on) {
+        int rc = check_device(d->device);
+        if (rc) return rc;
+        rc = jd_res_stop(d);
+        if (rc) return rc;
     }
     return JD_OK;
 }
@@ -2795,8 +2826,10 @@ static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int6
         if (d->res && d->res->on) return JD_OK;                        // (a broker owns the resident kernel)
         P = new Pipe();
         d->pipe = P;
-        P->K = d->pipe_depth; P->max_batch = n_utts; P->n_slots = d->max_streams;
-        P->table_rows = ((rows + rows / 4 + GMM_ROWS2) + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2;
+        // (tables and result slots for batches up to twice this one: a larger one later starts the pipeline again, with larger ones)
+        P->K = d->pipe_depth; P->max_batch = 2 * n_utts; P->n_slots = d->max_streams;
+        if (const char *e = getenv("JD_PIPE_CHUNK")) { const int v = atoi(e); if (v >= 16) P->chunk = v; }   // development
+        P->table_rows = ((2 * rows + 1024) + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2;
         const size_t V = (size_t)P->K * P->max_batch;
         if (hipMalloc(&P->d_ll, (size_t)P->K * P->table_rows * G * sizeof(float)) != hipSuccess ||
             hipMalloc(&P->d_ident, P->table_rows * sizeof(int)) != hipSuccess ||
@@ -2822,7 +2855,7 @@ static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int6
         d->res_ll = P->d_ll;
         rc = jd_res_start(d, P->n_slots, GMM_ROWS2);
         if (rc) { d->res_ll = nullptr; return rc; }
-        P->on = true;
+        P->on = true; d->pipe_on = true;
         P->serial0 = 0;
     }
     PipeBatch B;
@@ -2858,7 +2891,7 @@ static int pipe_decode(jd_dec *d, int n_utts, const float *d_feats, const int64_
         const int rc = pipe_pump(d);
         if (rc) { pipe_drain(d); return rc; }
         if (P->q.front().n_done == P->q.front().n) break;
-        for (int s = 0; s < P->n_slots; ++s)
+        for (int s = 0; s < P->n_slots && d->res->on; ++s)
             if (__atomic_load_n(&d->res->h_done[s].left, __ATOMIC_ACQUIRE)) {
                 pipe_drain(d);
                 return jd_fail(JD_EHIP, "the resident search kernel has ended under a batch (no command for 5 s, or a lost workgroup)");

@@ -1162,6 +1162,89 @@ def test_scores_ahead_with_collections_and_replans(small):
                 os.environ[k] = v
 
 
+def test_batches_through_the_resident_kernel(small, monkeypatch):
+    """JD_PIPELINE=3: announced batches (up to JD_PIPE_DEPTH of them) are scored whole and their utterances go through the
+    one-workgroup slots of a search kernel that stays, a slot taking the next queued utterance the moment its own is through;
+    a decode hands back the oldest batch.  Results are the oracle's bit for bit - with fewer slots than a batch has
+    utterances, with Path arenas so small that the slots stop for collections, across jd_dec_quiesce (the kernel leaves
+    for a device-wide synchronisation and comes back), when a decode is not the announced one (everything under way is
+    dropped), and when an utterance fails (the error is its batch's; the batches behind it are untouched)."""
+    import torch
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    gnet, gam, onet, oam, feats, _ = small
+    kw = dict(main_beam=150.0)
+    od = OracleDecoder(onet, oam, **kw)
+    mk = lambda k: [np.concatenate([feats[(k * i + j + k) % len(feats)] for j in range(1 + (i + k) % 3)]) for i in range(6)]
+    batches = {n: mk(k) for n, k in (("A", 1), ("B", 2), ("C", 3))}
+    want = {n: [od.decode_certified(x) for x in b] for n, b in batches.items()}
+    dev = torch.device("cuda", 0)
+
+    def resident(batch):
+        offs = np.zeros(len(batch) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([x.shape[0] for x in batch])
+        return torch.from_numpy(np.concatenate(batch)).to(dev), offs
+    buf = {n: resident(b) for n, b in batches.items()}
+    monkeypatch.setenv("JD_PIPELINE", "3")
+    monkeypatch.setenv("JD_PIPE_DEPTH", "4")
+    monkeypatch.setenv("JD_PIPE_CHUNK", "50")
+    for streams, extra in ((10, {}), (4, {}), (8, dict(max_paths=1 << 12))):
+        gd = capi.Decoder(gnet, gam, max_streams=streams, **kw, **extra)
+        order = ["A", "B", "C", "A", "C", "B", "B", "A", "C"]
+        ahead = 3
+        for n in order[:ahead]:
+            gd.prefetch_scores(buf[n][0].data_ptr(), buf[n][1], 0)
+        for i, n in enumerate(order):
+            if i + ahead < len(order):
+                nx = order[i + ahead]
+                gd.prefetch_scores(buf[nx][0].data_ptr(), buf[nx][1], 0)
+            if i == 4:
+                gd.quiesce()
+                torch.cuda.synchronize()                               # (returns: the kernel has left)
+            gs = gd.decode_batch_device(buf[n][0].data_ptr(), buf[n][1], 0)
+            tm = gd.last_timing()
+            for u, g in enumerate(gs):
+                assert_hyp_matches(g, want[n][u], "streams %d step %d batch %s utt %d" % (streams, i, n, u))
+                assert bit_exact(g, want[n][u])
+            assert tm["search_launches"] == 0, (streams, i, n, tm)      # (handed back by the pipeline, not by a launch of its own)
+        torch.cuda.synchronize()                                       # nothing announced is left: the kernel has gone
+        # a fifth announcement does not fit a pipeline four deep; a decode that is not the announced one drops everything
+        for n in ("A", "B", "C", "A"):
+            gd.prefetch_scores(buf[n][0].data_ptr(), buf[n][1], 0)
+        with pytest.raises(capi.JuicerAmdError):
+            gd.prefetch_scores(buf["B"][0].data_ptr(), buf["B"][1], 0)
+        gs = gd.decode_batch_device(buf["C"][0].data_ptr(), buf["C"][1], 0)
+        assert gd.last_timing()["search_launches"] > 0
+        for u, g in enumerate(gs):
+            assert bit_exact(g, want["C"][u])
+        gs = gd.decode_batch_device(buf["A"][0].data_ptr(), buf["A"][1], 0)
+        for u, g in enumerate(gs):
+            assert bit_exact(g, want["A"][u])
+        gd.close()
+    # an utterance that fails (Histogram::addScore's ceiling): its batch's decode raises, the batches behind it are the oracle's
+    am, net, f2, _ = synth.config_small()
+    g_sharp = int(am.hmm_gmm[int(net.ilab[0]) - 1, 1])
+    am.var[g_sharp] = 1e-6
+    poison = am.mean[g_sharp, 0][None, :].repeat(30, axis=0).astype(np.float32)
+    gnet2, gam2 = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    kw2 = dict(main_beam=150.0, max_hyps=100)
+    od2 = OracleDecoder(OracleNet(net), OracleAM(am), **kw2)
+    good, bad = [f2[i] for i in range(4)], [f2[0], poison, f2[2], f2[3]]
+    wg = [od2.decode_certified(x) for x in good]
+    bg, bb = resident(good), resident(bad)
+    gd = capi.Decoder(gnet2, gam2, max_streams=3, **kw2)
+    for rep in range(2):
+        gd.prefetch_scores(bg[0].data_ptr(), bg[1], 0); gd.prefetch_scores(bb[0].data_ptr(), bb[1], 0); gd.prefetch_scores(bg[0].data_ptr(), bg[1], 0)
+        for u, g in enumerate(gd.decode_batch_device(bg[0].data_ptr(), bg[1], 0)):
+            assert bit_exact(g, wg[u])
+        with pytest.raises(capi.JuicerAmdError) as ei:
+            gd.decode_batch_device(bb[0].data_ptr(), bb[1], 0)
+        assert ei.value.code == capi.JD_EHIST, str(ei.value)
+        for u, g in enumerate(gd.decode_batch_device(bg[0].data_ptr(), bg[1], 0)):
+            assert bit_exact(g, wg[u])
+    gd.close()
+
+
 def test_error_in_the_batch_behind(built):
     """A stream of the batch that is searched AHEAD runs into an error (Histogram::addScore's ceiling, Histogram.cpp:78-79:
     a log-likelihood above +201 at the mean of a sharp density): the error belongs to that batch's decode - not to the

@@ -21,7 +21,9 @@ for set in "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BU
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
            "FETCH_SIZE SQ_WAVES" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i + 1))
-    timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -- $BENCH < /dev/null > "$OUT/pmc$i.log" 2>&1
+    # (counters: rocprofv3 runs kernels one after the other under --pmc, and the resident kernel of the default run waits for the scoring
+    # kernels beside it - the passes see the same batches with two of them in flight, one k_search launch per step)
+    timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -- $BENCH --pipeline-depth 0 < /dev/null > "$OUT/pmc$i.log" 2>&1
 done
 python tools/pmc_summary.py "$OUT" > "$R/r04_c2_pmc_summary.json"
 for l in ${LEGS:-c2 hyps c512 north c3 clg}; do

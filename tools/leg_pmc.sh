@@ -22,7 +22,7 @@ import bench
 d = json.load(open(sys.argv[1] + "/pmc_summary.json"))
 tot_f = tot_w = 0.0
 for k, v in d.items():
-    if "k_search" in k:
+    if "k_search" in k or "k_resident" in k:
         print(k, {c: (x["launches"], round(x["mean"], 1), round(x["max"], 1)) for c, x in v.items()})
         tot_f += v["FETCH_SIZE"]["mean"] * v["FETCH_SIZE"]["launches"]
         tot_w += v["WRITE_SIZE"]["mean"] * v["WRITE_SIZE"]["launches"]

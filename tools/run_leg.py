@@ -22,9 +22,12 @@ elif which == "clg":
 elif which == "c3":
     a, n, f, _ = synth.config_c4(seed=0, n_utts=n_utts or 8)
     out = bench.run_leg("configs[3]", a, n, f, 300.0, 0, dev, passes=passes, pmc_leg="c3" if not n_utts or n_utts == 8 else None)
-elif which == "c2":                                                   # (as the headline runs it: two batches in flight)
+elif which == "c2pipe":                                               # (as the headline runs it: through the resident kernel, six batches ahead - not
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=64)                   # under --pmc: the profiler runs kernels one after the other, and this one waits for others)
+    out = bench.run_leg("configs[1]", a, n, f, 150.0, 0, dev, passes=passes, pipe=(6, 160))
+elif which in ("c2", "c2two"):                                        # (... with two batches in flight, one launch per step: what the counters can see)
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
-    out = bench.run_leg("configs[1]", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c2", two=True)
+    out = bench.run_leg("configs[1], two batches in flight", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c2", two=True)
 elif which == "c512":
     a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
     out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, 128 streams", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c512", max_streams=128)
