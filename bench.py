@@ -319,11 +319,11 @@ def main():
                     help="score every batch's table right before its search (serial) instead of beside the previous batch's search")
     ap.add_argument("--no-search-ahead", action="store_true",
                     help="one batch in flight: the decoder gets streams for one batch only and the announcements run one batch ahead")
-    ap.add_argument("--pipeline-depth", type=int, default=0,
+    ap.add_argument("--pipeline-depth", type=int, default=6,
                     help="weak scaling: batches announced ahead of the one being decoded, through the resident search kernel "
                          "(JD_PIPELINE=3: every stream a one-workgroup slot that takes the next queued utterance when its own is through); "
-                         "0 (default) = two batches in flight, one launch per step - measured on one box, 20 steps: 30.7-30.9 ms per step "
-                         "against 29.6-30.0 with six batches ahead through 160 slots")
+                         "0 = two batches in flight, one launch per step (what runs with several ranks) - measured on one box, 20 steps: "
+                         "30.7-30.8 ms per step against 26.7 with six batches ahead through 160 slots")
     ap.add_argument("--pipeline-slots", type=int, default=160, help="streams (= workgroups) of the resident pipeline; the other CUs score")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -401,7 +401,8 @@ def main():
     # resident kernel"): a batch is scored whole when it is announced, a slot takes the next queued utterance the moment its own
     # is through, and a step hands back the oldest batch - still ITS 64 results, decoded in full
     # (one rank only: with several, every step gathers the hypotheses through RCCL, whose kernels would have to start beside a
-    # kernel that never leaves - not something a 1-GPU box can try; those runs keep two batches in flight, one launch per step)
+    # kernel that never leaves - and HIP maps streams onto a few hardware queues: tools/resident_alias_probe.py finds one fresh
+    # stream in fourteen queued BEHIND the resident kernel until it leaves; those runs keep two batches in flight, one launch per step)
     depth = args.pipeline_depth if (two_in_flight and world == 1 and args.pipeline_depth > 0) else 0
     if depth:
         os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = str(depth + 1)
@@ -608,7 +609,11 @@ def main():
             pipe = (depth, args.pipeline_slots) if depth else None
             legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev, oracle_utts=no,
                                                    two=two_in_flight, pipe=pipe, passes=8 if pipe else 4, pmc_leg="hyps" if default_cfg else None)
-            if two_in_flight and not depth:                         # the headline's batches through the resident search kernel, six of them ahead
+            if depth:                                               # the headline's batches with TWO of them in flight, one launch per step
+                legs["configs1_two_batches_in_flight"] = run_leg("configs[1], two batches in flight (one k_search launch per step: what runs with "
+                                                                 "several ranks, and what the counters see)", am, net, feats, args.beam, args.max_hyps, dev,
+                                                                 two=True, pmc_leg="c2" if default_cfg else None)
+            elif two_in_flight:                                     # ... or through the resident search kernel, six of them ahead
                 legs["configs1_through_the_resident_kernel"] = run_leg("configs[1], batches through the resident kernel utterance by utterance "
                                                                        "(JD_PIPELINE=3: 160 one-workgroup slots, six batches ahead)", am, net, feats,
                                                                        args.beam, args.max_hyps, dev, pipe=(6, 160), passes=10)

@@ -488,7 +488,11 @@ int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 /* The decoder's work on the device comes to rest: with JD_PIPELINE=3 (announced batches go through a search kernel that stays
  * on the device, utterance by utterance: jd_dec_prefetch_scores up to JD_PIPE_DEPTH batches ahead) that kernel lets the
  * commands that are running run out (128 frames at most) and leaves; nothing announced or under way is lost - it comes back
- * with the next call.  What a caller needs before a device-wide synchronisation while batches are announced. */
+ * with the next call.  What a caller needs before a device-wide synchronisation while batches are announced - and before
+ * it puts work of its own on OTHER streams of the device: HIP maps streams onto a few hardware queues, and a kernel that
+ * is queued behind the resident one waits until it leaves (tools/resident_alias_probe.py: one fresh stream in fourteen;
+ * by itself the kernel leaves after 5 s without a command, and the decode that follows says so).  The same holds while a
+ * broker's resident kernel has work (it leaves after 3 ms without). */
 int jd_dec_quiesce(jd_dec *d);
 
 /* Diagnostics: per-workgroup cycle accounting of k_search (100 MHz wall clock).  enable >= 0 with

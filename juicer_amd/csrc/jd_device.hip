@@ -2667,6 +2667,7 @@ struct PipeUtt { int state = 0, slot = -1, T = 0; long long row0 = 0; };      //
 #define PIPE_CHUNK 128                  // frames per command: what a slot runs before it looks at its mailbox again (jd_dec_quiesce waits that long)
 struct PipeBatch {
     const float *feats = nullptr; int n = 0; int table = 0; int next = 0, n_done = 0;
+    size_t rows = 0, rows_scored = 0;                  // rows of its table, and how many of them have a scoring launch enqueued
     std::vector<int64_t> offs;
     std::vector<PipeUtt> u;
 };
@@ -2683,6 +2684,11 @@ struct Pipe {
     std::vector<char> slot_dirty;
     long long serial0 = 0;                             // serial number of q.front()
     int chunk = PIPE_CHUNK;
+    std::chrono::steady_clock::time_point t_on;        // (statistics)
+    long long frames_done = 0;
+    hipEvent_t ev_piece = nullptr;                     // behind the last scoring launch enqueued
+    bool piece_out = false;
+    size_t piece_rows = 6144;                          // rows per scoring launch (JD_PIPE_PIECE)
 };
 
 static void pipe_free(jd_dec *d);
@@ -2696,6 +2702,7 @@ static void pipe_free(jd_dec *d)
     if (P->d_vctl) (void)hipFree(P->d_vctl);
     if (P->d_vresn) (void)hipFree(P->d_vresn);
     if (P->d_vres) (void)hipFree(P->d_vres);
+    if (P->ev_piece) (void)hipEventDestroy(P->ev_piece);
     delete P;
     d->pipe = nullptr;
 }
@@ -2706,7 +2713,13 @@ static void pipe_drain(jd_dec *d)
     Pipe *P = d->pipe;
     if (!P || !P->on) return;
     (void)jd_res_stop(d);                                              // (running utterances run out first)
-    P->on = false; d->pipe_on = false;
+    if (getenv("JD_VERBOSE") && d->res) {                              // development: how busy the slots were
+        const double wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - P->t_on).count();
+        fprintf(stderr, "pipeline: %d slots for %.1f ms, busy %.1f %% of it on %lld frames (%.1f us per frame on the slot's clock)\n", P->n_slots,
+                wall_us / 1e3, 100.0 * (double)(d->res->run_ticks / 100) / (wall_us * P->n_slots), P->frames_done,
+                P->frames_done ? (double)(d->res->run_ticks / 100) / (double)P->frames_done : 0.0);
+    }
+    P->on = false; d->pipe_on = false; P->piece_out = false;
     P->q.clear();
     std::fill(P->table_used.begin(), P->table_used.end(), 0);
     std::fill(P->slot_batch_id.begin(), P->slot_batch_id.end(), -1);
@@ -2755,20 +2768,36 @@ static int pipe_pump(jd_dec *d)
         }
         EL.slot[EL.n] = s; EL.vslot[EL.n] = B.table * P->max_batch + ui; EL.n += 1;
         if (EL.n == 64) { const int rc = flush_exports(); if (rc) return rc; }
-        B.u[(size_t)ui].state = 2; B.n_done += 1;
+        B.u[(size_t)ui].state = 2; B.n_done += 1; P->frames_done += fr;
         if (er) P->slot_dirty[(size_t)s] = 1;                          // (its arenas may be inconsistent: out of the game until the pipeline stops)
         P->slot_batch_id[(size_t)s] = -1;
     }
     int rc = flush_exports();
     if (rc) return rc;
-    // refill
+    // scoring, a piece at a time: a batch's table in ONE launch holds the side stream for ~20 ms, and the exports and ready
+    // numbers of every slot that finishes meanwhile queue up behind it (measured: slots 12 % idle); the next piece goes out when
+    // the one before it is through, so that those wait for a piece at most
+    if (P->piece_out && hipEventQuery(P->ev_piece) == hipSuccess) P->piece_out = false;
+    if (!P->piece_out)
+        for (PipeBatch &B : P->q) {
+            if (B.rows_scored >= B.rows) continue;
+            const size_t n = std::min(P->piece_rows, B.rows - B.rows_scored);
+            const size_t base = (size_t)B.table * P->table_rows + B.rows_scored;
+            rc = launch_gmm(d->am, d->amb, B.feats + ((size_t)B.offs[0] + B.rows_scored) * (size_t)d->am->D, P->d_ident, (int)n,
+                            P->d_ll + base * (size_t)d->am->n_gmm, d->s_gmm);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(P->ev_piece, d->s_gmm));
+            B.rows_scored += n; P->piece_out = true;
+            break;
+        }
+    // refill (from batches whose scoring is enqueued to the last row: a slot's ready number is counted up behind it)
     std::vector<int> who;
     std::vector<std::pair<int, int>> what;                             // (batch index in q, utterance)
     size_t bi = 0;
     for (int s = 0; s < P->n_slots; ++s) {
         if (P->slot_batch_id[(size_t)s] >= 0 || P->slot_dirty[(size_t)s]) continue;
         while (bi < P->q.size() && P->q[bi].next >= P->q[bi].n) ++bi;
-        if (bi >= P->q.size()) break;
+        if (bi >= P->q.size() || P->q[bi].rows_scored < P->q[bi].rows) break;
         PipeBatch &B = P->q[bi];
         const int ui = B.next++;
         B.u[(size_t)ui].state = 1; B.u[(size_t)ui].slot = s;
@@ -2810,7 +2839,7 @@ static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int6
 {
     *taken = 0;
     if (!d->pipe_mode || d->net->lazy_dev || d->partial_interval > 0 || d->am->hybrid || n_utts < 1) return JD_OK;
-    const int D = d->am->D, G = d->am->n_gmm;
+    const int G = d->am->n_gmm;
     const size_t rows = (size_t)(offs[n_utts] - offs[0]);
     Pipe *P = d->pipe;
     if (P && (n_utts > P->max_batch || rows > P->table_rows)) {        // a larger batch than the tables were made for: not this way
@@ -2829,6 +2858,8 @@ static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int6
         // (tables and result slots for batches up to twice this one: a larger one later starts the pipeline again, with larger ones)
         P->K = d->pipe_depth; P->max_batch = 2 * n_utts; P->n_slots = d->max_streams;
         if (const char *e = getenv("JD_PIPE_CHUNK")) { const int v = atoi(e); if (v >= 16) P->chunk = v; }   // development
+        if (const char *e = getenv("JD_PIPE_PIECE")) { const int v = atoi(e); if (v >= 128) P->piece_rows = (size_t)v / GMM_ROWS2 * GMM_ROWS2; }
+        if (hipEventCreateWithFlags(&P->ev_piece, hipEventDisableTiming) != hipSuccess) { pipe_free(d); return jd_fail(JD_EHIP, "hipEventCreate failed"); }
         P->table_rows = ((2 * rows + 1024) + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2;
         const size_t V = (size_t)P->K * P->max_batch;
         if (hipMalloc(&P->d_ll, (size_t)P->K * P->table_rows * G * sizeof(float)) != hipSuccess ||
@@ -2856,7 +2887,7 @@ static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int6
         rc = jd_res_start(d, P->n_slots, GMM_ROWS2);
         if (rc) { d->res_ll = nullptr; return rc; }
         P->on = true; d->pipe_on = true;
-        P->serial0 = 0;
+        P->serial0 = 0; P->t_on = std::chrono::steady_clock::now(); P->frames_done = 0; d->res->run_ticks = 0;
     }
     PipeBatch B;
     B.feats = d_feats; B.n = n_utts; B.offs.assign(offs, offs + n_utts + 1);
@@ -2866,9 +2897,7 @@ static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int6
     B.u.resize((size_t)n_utts);
     const long long base = (long long)t * (long long)P->table_rows;
     for (int u = 0; u < n_utts; ++u) { B.u[(size_t)u].T = (int)(offs[u + 1] - offs[u]); B.u[(size_t)u].row0 = base + (offs[u] - offs[0]); }
-    // the whole batch in one scoring launch, on the CUs the slots leave
-    rc = launch_gmm(d->am, d->amb, d_feats + (size_t)offs[0] * D, P->d_ident, (int)rows, P->d_ll + (size_t)base * G, d->s_gmm);
-    if (rc) return rc;
+    B.rows = rows; B.rows_scored = 0;                                  // (scored by the pump, a piece at a time, on the CUs the slots leave)
     P->q.push_back(std::move(B));
     *taken = 1;
     return pipe_pump(d);
