@@ -304,8 +304,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--utts-per-gpu", type=int, default=64)
     ap.add_argument("--total-utts", type=int, default=0,
                     help="strong scaling (BASELINE.json configs[2] with 512): ONE batch of this many utterances dealt over the ranks by length")

@@ -11,7 +11,7 @@ R=gpurun_out/r04
 rm -rf "$R"; mkdir -p "$R"
 OUT=gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
-BENCH="python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-extra-legs"
+BENCH="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH < /dev/null > "$OUT/stats.log" 2>&1
 f=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$R/r04_c2_kernel_stats.csv"
