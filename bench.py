@@ -404,65 +404,78 @@ def main():
     # kernel that never leaves - and HIP maps streams onto a few hardware queues: tools/resident_alias_probe.py finds one fresh
     # stream in fourteen queued BEHIND the resident kernel until it leaves; those runs keep two batches in flight, one launch per step)
     depth = args.pipeline_depth if (two_in_flight and world == 1 and args.pipeline_depth > 0) else 0
-    if depth:
-        os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = str(depth + 1)
-    dec = capi.Decoder(gnet, gam, main_beam=args.beam, max_hyps=args.max_hyps, device=local_rank,
-                       max_streams=min(U, 128) if strong else (args.pipeline_slots if depth else (2 * U if two_in_flight else U)))
-    os.environ.pop("JD_PIPELINE", None); os.environ.pop("JD_PIPE_DEPTH", None)
-    offs = np.zeros(len(feats) + 1, dtype=np.int64)
-    offs[1:] = np.cumsum([f.shape[0] for f in feats])
-    frames_local = int(offs[-1])
-    d_feats = torch.from_numpy(np.concatenate(feats) if feats else np.zeros((0, am.D), np.float32)).to(dev)     # inputs resident in HBM
-    torch.cuda.synchronize()
-    stream = torch.cuda.current_stream().cuda_stream
+    pipeline_error = None
+    for depth in ((depth, 0) if depth else (0,)):                      # (should the pipeline fail: the same measurement, two batches in flight)
+      try:
+        if depth:
+            os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = str(depth + 1)
+        dec = capi.Decoder(gnet, gam, main_beam=args.beam, max_hyps=args.max_hyps, device=local_rank,
+                           max_streams=min(U, 128) if strong else (args.pipeline_slots if depth else (2 * U if two_in_flight else U)))
+        os.environ.pop("JD_PIPELINE", None); os.environ.pop("JD_PIPE_DEPTH", None)
+        offs = np.zeros(len(feats) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in feats])
+        frames_local = int(offs[-1])
+        d_feats = torch.from_numpy(np.concatenate(feats) if feats else np.zeros((0, am.D), np.float32)).to(dev)     # inputs resident in HBM
+        torch.cuda.synchronize()
+        stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        # One step = one pass over one batch: its search, and one scoring of a batch's likelihood table.  Batches follow
-        # each other, so the table of a LATER batch (here: the same synthetic batch again) is scored on the CUs this
-        # batch's search leaves idle (jd_dec_prefetch_scores) - K timed steps hold K searches and K scorings either way.
-        # With two batches in flight the announcements run two batches ahead (one more before the first step, below):
-        # the batch behind the running one has its table already and its utterances are started beside it - every
-        # step still returns ITS batch's 64 results, decoded in full; what a step does of the next batch's search the
-        # next step does not have to do, and K steps hold K batches' worth of search.
-        if ahead:
-            dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
-        hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
-        allh = parallel.gather_hyps(hyps, per_rank, device=dev, index=shard) if world > 1 else hyps
-        return hyps, allh
+        def step():
+            # One step = one pass over one batch: its search, and one scoring of a batch's likelihood table.  Batches follow
+            # each other, so the table of a LATER batch (here: the same synthetic batch again) is scored on the CUs this
+            # batch's search leaves idle (jd_dec_prefetch_scores) - K timed steps hold K searches and K scorings either way.
+            # With two batches in flight the announcements run two batches ahead (one more before the first step, below):
+            # the batch behind the running one has its table already and its utterances are started beside it - every
+            # step still returns ITS batch's 64 results, decoded in full; what a step does of the next batch's search the
+            # next step does not have to do, and K steps hold K batches' worth of search.
+            if ahead:
+                dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
+            hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
+            allh = parallel.gather_hyps(hyps, per_rank, device=dev, index=shard) if world > 1 else hyps
+            return hyps, allh
 
-    def barrier():
-        if world > 1:
-            dist.barrier(**bar_kw)
+        def barrier():
+            if world > 1:
+                dist.barrier(**bar_kw)
 
-    if depth:
-        for _ in range(depth):                                         # (the announcements run `depth` batches ahead)
-            dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
-        for _ in range(depth + 2):                                     # the pipeline fills: its first batches come back in a burst
+        if depth:
+            for _ in range(depth):                                         # (the announcements run `depth` batches ahead)
+                dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
+            for _ in range(depth + 2):                                     # the pipeline fills: its first batches come back in a burst
+                step()
+        elif two_in_flight:
+            dec.prefetch_scores(d_feats.data_ptr(), offs, stream)          # (the announcements run two batches ahead)
+        for _ in range(args.warmup):
             step()
-    elif two_in_flight:
-        dec.prefetch_scores(d_feats.data_ptr(), offs, stream)          # (the announcements run two batches ahead)
-    for _ in range(args.warmup):
-        step()
-    # (a device-wide synchronisation waits for every kernel on the device: the pipeline's resident kernel lets its running
-    # commands run out and leaves - jd_dec_quiesce - and comes back with the first timed step, inside the brackets)
-    dec.quiesce()
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0,
-           "ahead_frames": 0}
-    tm = {}
-    hyps = None
-    each = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        hyps, allh = step()
-        each.append(round((time.perf_counter() - ts) * 1e3, 3))
-        tm = dec.last_timing()
-        for k in acc:
-            acc[k] += tm[k]
-    dec.quiesce()
-    torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
+        # (a device-wide synchronisation waits for every kernel on the device: the pipeline's resident kernel lets its running
+        # commands run out and leaves - jd_dec_quiesce - and comes back with the first timed step, inside the brackets)
+        dec.quiesce()
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0,
+               "ahead_frames": 0}
+        tm = {}
+        hyps = None
+        each = []
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            hyps, allh = step()
+            each.append(round((time.perf_counter() - ts) * 1e3, 3))
+            tm = dec.last_timing()
+            for k in acc:
+                acc[k] += tm[k]
+        dec.quiesce()
+        torch.cuda.synchronize(); barrier()
+        elapsed = time.perf_counter() - t0
+        break
+      except capi.JuicerAmdError as e:
+        if not depth:
+            raise
+        pipeline_error = str(e)
+        print("bench.py: the resident pipeline failed (%s): measuring with two batches in flight" % e, file=sys.stderr)
+        try:
+            dec.close()
+        except Exception:
+            pass
     # (outside the timed region) the same step in the serial order: what the scoring kernel takes on its own
     dec.prefetch_scores(0, None)
     t1 = time.perf_counter()
@@ -591,6 +604,7 @@ def main():
                       "parallelism": ("one batch of %d utterances dealt by length over %d rank(s)" % (args.total_utts, world)) if strong
                                      else "utterance-sharded x%d" % world,
                       "batches_in_flight": (depth + 1) if depth else (2 if two_in_flight else 1),
+                      "pipeline_error": pipeline_error,
                       "pipeline": ("resident search kernel: %d one-workgroup slots, the other CUs score; announcements %d batches ahead, a slot takes "
                                    "the next queued utterance when its own is through" % (args.pipeline_slots, depth)) if depth else None,
                       "predicted_rank_ms": predicted_rank_ms if strong else None,
