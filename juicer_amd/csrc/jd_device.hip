@@ -2407,7 +2407,14 @@ int jd_res_stop(jd_dec *d)
     (void)hipStreamSynchronize(d->s_gmm);
     // (a cluster takes a command that is there before it looks at the exit request: whatever was posted is through)
     bool lost = false;
-    for (int s = 0; s < R->n; ++s) if (!res_harvest(d, s)) { lost = true; R->busy[(size_t)s] = 0; d->stream_dirty[(size_t)s] = 1; }
+    for (int s = 0; s < R->n; ++s)
+        if (!res_harvest(d, s)) {
+            R->busy[(size_t)s] = 0;
+            // a command the cluster never saw (it left by itself - idle for 5 s - just before the word was written) has not been
+            // started: the stream stands where its last report says, short of what was posted, and whoever drives it posts the
+            // rest again (the same way as behind a Path collection).  Anything else is a lost workgroup.
+            if (!__atomic_load_n(&R->h_done[s].left, __ATOMIC_ACQUIRE)) { lost = true; d->stream_dirty[(size_t)s] = 1; }
+        }
     R->on = false;
     delete R->process_lock; R->process_lock = nullptr;
     if (R->search_lock.owns_lock()) R->search_lock.unlock();
@@ -2744,6 +2751,13 @@ static int pipe_pump(jd_dec *d)
         EL.n = 0;
         return JD_OK;
     };
+    if (R->on) {
+        // the kernel has gone by itself: nobody gave it a command for 5 s (a caller that was away between two calls) - seen
+        // BEFORE anything is posted to it: the reports are all in, and it comes back like behind jd_dec_quiesce
+        bool left = false;
+        for (int s = 0; s < P->n_slots && !left; ++s) left = __atomic_load_n(&R->h_done[s].left, __ATOMIC_ACQUIRE) != 0;
+        if (left) { const int rc = jd_res_stop(d); if (rc) return rc; }
+    }
     if (!R->on) {                                                      // (after jd_dec_quiesce: the kernel comes back, the slots go on where they were)
         const int rc = jd_res_start(d, P->n_slots, GMM_ROWS2);
         if (rc) return rc;
@@ -2916,15 +2930,23 @@ static int pipe_decode(jd_dec *d, int n_utts, const float *d_feats, const int64_
         if (!same) { pipe_drain(d); return JD_OK; }                    // not the announced one: as if nothing had been announced
     }
     const auto w0 = std::chrono::steady_clock::now();
+    int restarts = 0;
     for (;;) {
         const int rc = pipe_pump(d);
         if (rc) { pipe_drain(d); return rc; }
         if (P->q.front().n_done == P->q.front().n) break;
-        for (int s = 0; s < P->n_slots && d->res->on; ++s)
-            if (__atomic_load_n(&d->res->h_done[s].left, __ATOMIC_ACQUIRE)) {
+        bool left = false;
+        for (int s = 0; s < P->n_slots && d->res->on && !left; ++s) left = __atomic_load_n(&d->res->h_done[s].left, __ATOMIC_ACQUIRE) != 0;
+        if (left) {
+            // the kernel has gone by itself: nobody gave it a command for 5 s (a caller that was away between two calls) - the
+            // reports are taken and it comes back like behind jd_dec_quiesce; a command that was never answered is a lost workgroup
+            const int rs = jd_res_stop(d);
+            if (rs || ++restarts > 3) {
                 pipe_drain(d);
-                return jd_fail(JD_EHIP, "the resident search kernel has ended under a batch (no command for 5 s, or a lost workgroup)");
+                return rs ? rs : jd_fail(JD_EHIP, "the resident search kernel keeps ending under a batch");
             }
+            continue;
+        }
         std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
     HIPCHK(hipStreamSynchronize(d->s_gmm));                            // (the exports)

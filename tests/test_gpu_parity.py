@@ -1201,6 +1201,9 @@ def test_batches_through_the_resident_kernel(small, monkeypatch):
             if i == 4:
                 gd.quiesce()
                 torch.cuda.synchronize()                               # (returns: the kernel has left)
+            if i == 6 and streams == 10:
+                import time
+                time.sleep(5.6)                                        # a caller that is away: the kernel leaves by itself after 5 s, and comes back
             gs = gd.decode_batch_device(buf[n][0].data_ptr(), buf[n][1], 0)
             tm = gd.last_timing()
             for u, g in enumerate(gs):
