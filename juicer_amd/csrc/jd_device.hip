@@ -2359,6 +2359,7 @@ struct Resident {
     std::vector<int> T_posted, T_done, err_done;
     std::vector<int> slot_posted;
     std::vector<char> busy;                            // a command is posted and its report not yet taken
+    std::vector<char> init_pending;                    // ... and it begins an utterance (ResPost::init): a re-post must say so again
     long long run_ticks = 0;                           // (statistics) what the clusters spent on their commands, 100 MHz ticks
     long long n_collect = 0;                           // (statistics) Path collections between commands
     std::unique_lock<std::mutex> search_lock;
@@ -2393,6 +2394,7 @@ static bool res_harvest(jd_dec *d, int s)
     if (__atomic_load_n(&R->h_done[s].seq, __ATOMIC_ACQUIRE) != R->seq[(size_t)s]) return false;
     R->T_done[(size_t)s] = R->h_done[s].frame; R->err_done[(size_t)s] = R->h_done[s].error;
     R->run_ticks += R->h_done[s].run_ticks;
+    R->init_pending[(size_t)s] = 0;
     d->stream_T[(size_t)s] = R->T_done[(size_t)s];
     R->busy[(size_t)s] = 0;
     return true;
@@ -2458,7 +2460,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
             return jd_fail(JD_ENOMEM, "jd_res_start: no memory for %d streams x 2 x %d rows", n_streams, rows);
         }
         R->seq.assign((size_t)n_streams, 0u); R->T_posted.assign((size_t)n_streams, 0); R->T_done.assign((size_t)n_streams, 0);
-        R->slot_posted.assign((size_t)n_streams, 0); R->err_done.assign((size_t)n_streams, 0); R->busy.assign((size_t)n_streams, 0);
+        R->slot_posted.assign((size_t)n_streams, 0); R->err_done.assign((size_t)n_streams, 0); R->busy.assign((size_t)n_streams, 0); R->init_pending.assign((size_t)n_streams, 0);
         for (int t = 0; t < n_streams; ++t) R->T_done[(size_t)t] = R->T_posted[(size_t)t] = d->stream_T[(size_t)t];
         R->rid.assign((size_t)n_streams, 0u);
         std::vector<int> ident(tr);            // the row table of every scoring launch: row r of the table is row r of the features
@@ -2595,6 +2597,7 @@ static void res_write_post(Resident *R, int s, int T, int slot, int init = 0)
     ResPost &P = R->h_post[s];
     P.T = T;
     P.init = init;
+    if (init) R->init_pending[(size_t)s] = 1;
     P.ready_id = R->rid[(size_t)s];
     __atomic_store_n(&P.word, ((unsigned long long)R->seq[(size_t)s] << 32) | (unsigned)slot, __ATOMIC_RELEASE);
 }
@@ -2642,7 +2645,7 @@ int jd_res_collect(jd_dec *d, int s)
     R->n_collect += 1;
     const int rc = res_bump(d, 1, &s);                                 // (the command waits for the collection)
     if (rc) return rc;
-    res_write_post(R, s, R->T_posted[(size_t)s], R->slot_posted[(size_t)s]);
+    res_write_post(R, s, R->T_posted[(size_t)s], R->slot_posted[(size_t)s], R->init_pending[(size_t)s]);
     return JD_OK;
 }
 
