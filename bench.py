@@ -634,8 +634,12 @@ def main():
             # configs[2]'s batch (512 utterances) on ONE GPU: waves of 128 streams inside one call, each wave's table scored
             # beside the wave before it - what the GPU does when a batch is not bounded by its longest utterance
             _, _, f512, _ = synth.config_c2(seed=args.seed, n_utts=512, target_arcs=args.arcs)
-            legs["configs2_batch_512_on_one_gpu"] = run_leg("configs[2]'s 512-utterance batch on one GPU, 128 streams", am, net, f512, args.beam, 0, dev,
-                                                            oracle_utts=no, max_streams=128, pmc_leg="c512" if default_cfg else None)
+            # (through the resident kernel's slots, two such batches ahead: 1.59 M frames/s against 1.43 M in waves of 128 streams - the
+            # counted bytes of the leg are those of the waves, tools/run_leg.py c512)
+            legs["configs2_batch_512_on_one_gpu"] = run_leg("configs[2]'s 512-utterance batch on one GPU" + (", through the resident kernel" if depth else ", 128 streams"),
+                                                            am, net, f512, args.beam, 0, dev, oracle_utts=no, max_streams=128,
+                                                            pipe=(2, args.pipeline_slots) if depth else None, passes=2 if depth else 4,
+                                                            pmc_leg="c512" if default_cfg else None)
             del f512
             a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=64, n_words=10000, n_tri_hist=100_000)
             legs["north_star_10M_beam200"] = run_leg("north_star target (trigram-shaped)", a4, n4, f4, 200.0, 0, dev,

@@ -28,6 +28,10 @@ elif which == "c2pipe":                                               # (as the 
 elif which in ("c2", "c2two"):                                        # (... with two batches in flight, one launch per step: what the counters can see)
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
     out = bench.run_leg("configs[1], two batches in flight", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c2", two=True)
+elif which == "c512pipe":                                             # (the 512-utterance batch through the resident kernel's slots)
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
+    out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, through the resident kernel", a, n, f, 150.0, 0, dev, passes=passes,
+                        pipe=(int(os.environ.get("LEG_DEPTH", "1")), int(os.environ.get("LEG_SLOTS", "160"))))
 elif which == "c512":
     a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
     out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, 128 streams", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c512", max_streams=128)
