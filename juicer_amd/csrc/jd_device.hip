@@ -1967,6 +1967,18 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         int handled = 0;
         rc = pipe_decode(d, n_utts, d_feats, offs, out, &handled);
         if (rc || handled) return rc;
+        // ... or more utterances than streams, nothing announced: through the pipeline's slots as well - a stream takes the next
+        // utterance the moment its own is through, where the waves below end with their longest one
+        if (d->pipe_mode && n_utts > d->max_streams && !d->pipe_on) {
+            HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));     // the features are there
+            int taken = 0;
+            rc = pipe_announce(d, n_utts, d_feats, offs, &taken);
+            if (rc) return rc;
+            if (taken) {
+                rc = pipe_decode(d, n_utts, d_feats, offs, out, &handled);
+                if (rc || handled) return rc;
+            }
+        }
     }
     rc = ensure_arenas(d);
     if (rc) return rc;
