@@ -70,6 +70,27 @@ def test_fullsize_64_stream_batch_oracle_parity(built):
         exact += bit_exact(gs[u], o)
     assert len(pick) >= 4 and exact == len(pick)
     assert all(h.n > 0 for h in gs)
+    gd.close()
+    # ... and the same batches the way bench.py runs them at N = 1: through the resident kernel's 160 one-workgroup slots,
+    # announcements six batches ahead (JD_PIPELINE=3) - every utterance of every batch bit for bit what the launch above found
+    import os
+    os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = "7"
+    try:
+        gp = capi.Decoder(gnet, gam, max_streams=160, **kw)
+    finally:
+        os.environ.pop("JD_PIPELINE", None); os.environ.pop("JD_PIPE_DEPTH", None)
+    for _ in range(6):
+        gp.prefetch_scores(d_feats.data_ptr(), offs, 0)
+    for step in range(9):
+        if step < 3:
+            gp.prefetch_scores(d_feats.data_ptr(), offs, 0)
+        if step == 4:
+            gp.quiesce()
+            torch.cuda.synchronize()
+        got = gp.decode_batch_device(d_feats.data_ptr(), offs, 0)
+        assert gp.last_timing()["search_launches"] == 0               # (handed back by the pipeline)
+        assert all(bit_exact(a, b) for a, b in zip(got, gs)), step
+    gp.close()
 
 
 def test_fullsize_histogram_pruning_parity(c2):
