@@ -2484,7 +2484,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     const bool ne3 = d->am->max_n <= 5;
     if (!d->occupancy_ok) {
         int per_cu = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ne3 ? (const void *)k_resident<3> : (const void *)k_resident<6>, SNT, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ne3 ? (const void *)k_resident<3, false> : (const void *)k_resident<6, false>, SNT, 0));
         if (per_cu < WG_PER_CU) return jd_fail(JD_EHIP, "k_resident does not fit a CU the way its grid assumes");
     }
     // clusters: what the arenas allow, and a sixth of the chip left to the scoring, collection and finish kernels
@@ -2513,8 +2513,12 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     A.status = d->d_status; A.dbg = nullptr; A.cells = nullptr; A.resident = nullptr; A.rebalance_at = 0; A.n_prio = 0;
     hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->d_ready, R->n);
     const dim3 rgrid((unsigned)(R->n * R->Cw));
-    if (ne3) hipLaunchKernelGGL(k_resident<3>, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
-    else hipLaunchKernelGGL(k_resident<6>, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
+    // (one workgroup per stream: the XCD-local flavour of the memory operations - a cluster of one sits on one XCD)
+    bool xl = R->Cw == 1;
+    if (const char *e = getenv("JD_RES_XL")) xl = xl && atoi(e) != 0;   // development
+    typedef void (*ResKernel)(SearchArgs, const ResPost *, ResMail *, const unsigned *, ResDone *, int);
+    const ResKernel rk = ne3 ? (xl ? k_resident<3, true> : k_resident<3, false>) : (xl ? k_resident<6, true> : k_resident<6, false>);
+    hipLaunchKernelGGL(rk, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         delete R->process_lock; R->process_lock = nullptr; R->search_lock.unlock();

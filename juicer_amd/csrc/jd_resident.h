@@ -57,7 +57,10 @@ __global__ void jd_res_reset_kernel(StreamCtl *ctl, ResMail *mail, unsigned *rea
 
 // grid = n_streams x Cw workgroups: workgroup b serves stream b / Cw as member b % Cw of its cluster (agent-scope flavour:
 // nothing is assumed about where the workgroups run).  All of them resident at once, like k_search's.
-template <int NE>
+// XL: the workgroup-scope flavour of the search's memory operations (plain stores, atomics performed in the XCD's L2 - see
+// jd_search.h) - for clusters of ONE workgroup, which sit on one XCD by definition; a command's closing release writes
+// the L2 back for the kernels beside it, its opening acquire drops what they have made stale.
+template <int NE, bool XL>
 __global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail *mail, const unsigned *ready, ResDone *done, int Cw)
 {
     __shared__ SearchShared sh;
@@ -131,7 +134,7 @@ __global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail
         const long long t_cmd = wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_dcache_inv();
-        run_stream<NE, false, false>(A, sh, s, ll_slot, jw, Cw, true, &nbar);
+        run_stream<NE, XL, false>(A, sh, s, ll_slot, jw, Cw, true, &nbar);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         // every workgroup of the cluster is through with the command (its end-of-launch words are written) before the host
         // hears of it: the collection and the finish kernels read them
