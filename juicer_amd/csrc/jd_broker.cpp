@@ -254,7 +254,7 @@ static void broker_loop_resident(jd_broker *b)
             bool any_running = false;
             for (const Client &c : b->clients) any_running = any_running || c.running || c.finishing;
             if (!any_running) {
-                lk.unlock(); (void)jd_res_stop(b->dec); std::this_thread::yield(); lk.lock();
+                lk.unlock(); (void)jd_res_yield(b->dec); lk.lock();
                 on = false; draining = false;
                 continue;
             }

@@ -245,6 +245,7 @@ extern "C" int jd_am_score_frames(const jd_am *a, int32_t device, const float *f
 
 #define JD_MAX_DEVICES 64
 static std::mutex g_search_mu[JD_MAX_DEVICES];     // one persistent search launch at a time per device (launch_search)
+static std::atomic<long long> g_search_turn[JD_MAX_DEVICES];  // counts the holders of the lock: who gives it up for a waiter sees the waiter take it
 static std::atomic<int> g_search_waiters[JD_MAX_DEVICES];   // ... and who waits for it (a resident kernel makes room: jd_res_should_yield)
 
 // ... and across PROCESSES: the reference's way of using several cores is several processes over split file lists
@@ -451,6 +452,8 @@ struct jd_dec {
     char *h_stage = nullptr; size_t stage_cap = 0;     // pinned staging of jd_streams_push
     bool xch_forced = false;               // JD_XCH given (development)
     struct Resident *res = nullptr;        // the resident search kernel of a broker (jd_res_*), or null
+    long long res_yield_turn = -1;             // the lock's turn count when the resident kernel last made room for a waiter
+    std::vector<hipStream_t> res_old_streams;   // search streams the resident kernel gave up (jd_res_start)
     struct Pipe *pipe = nullptr;           // batches through the resident kernel, utterance by utterance (jd_pipe_*; JD_PIPELINE=3)
     bool pipe_mode = false;
     bool pipe_on = false;                  // Pipe::on (for the code in front of the struct)
@@ -523,6 +526,7 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     if (d->h_status) (void)hipHostFree(d->h_status);
     if (d->s_gmm) (void)hipStreamDestroy(d->s_gmm);
     if (d->s_search) (void)hipStreamDestroy(d->s_search);
+    for (hipStream_t st : d->res_old_streams) (void)hipStreamDestroy(st);
     delete d;
 }
 
@@ -1404,6 +1408,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         g_search_waiters[dev_i].fetch_add(1);
         std::unique_lock<std::mutex> search_lock(g_search_mu[dev_i]);
         g_search_waiters[dev_i].fetch_sub(1);
+        g_search_turn[dev_i].fetch_add(1);
         GpuLockGuard process_lock(d->device);                              // (other processes on this GPU: see GpuFileLock)
         // (a launch beside which the next batch's table is scored is not cut short for a re-plan while that scoring runs -
         // status[4]: its blocks sit on the CUs that finished clusters left, and a relaunch would wait for them to drain)
@@ -2501,9 +2506,19 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     std::fill(R->rid.begin(), R->rid.end(), 0u);
     {
         const size_t dev_i = (size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1);
+        if (d->res_yield_turn >= 0) {
+            // this kernel has just made room for somebody who waits for the device (jd_res_yield): a mutex hands itself to
+            // whoever asks first, which may well be the one who let go - so it asks only once the waiter has had its turn
+            const auto t0 = std::chrono::steady_clock::now();
+            while (g_search_turn[dev_i].load() == d->res_yield_turn && g_search_waiters[dev_i].load() > 0 &&
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < 500.0)
+                std::this_thread::sleep_for(std::chrono::microseconds(100));
+            d->res_yield_turn = -1;
+        }
         g_search_waiters[dev_i].fetch_add(1);
         R->search_lock = std::unique_lock<std::mutex>(g_search_mu[dev_i]);
         g_search_waiters[dev_i].fetch_sub(1);
+        g_search_turn[dev_i].fetch_add(1);
     }
     R->process_lock = new GpuLockGuard(d->device);
     SearchArgs A;
@@ -2511,18 +2526,55 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = nullptr; A.n_work = R->n; A.Cw = R->Cw; A.n_slots = 0;
     A.ll = d->res_ll ? d->res_ll : R->d_ll; A.ll_stride = (long long)G; A.f0 = 0; A.f_end = 0x7fffffff;
     A.status = d->d_status; A.dbg = nullptr; A.cells = nullptr; A.resident = nullptr; A.rebalance_at = 0; A.n_prio = 0;
-    hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->d_ready, R->n);
     const dim3 rgrid((unsigned)(R->n * R->Cw));
     // (one workgroup per stream: the XCD-local flavour of the memory operations - a cluster of one sits on one XCD)
     bool xl = R->Cw == 1;
     if (const char *e = getenv("JD_RES_XL")) xl = xl && atoi(e) != 0;   // development
     typedef void (*ResKernel)(SearchArgs, const ResPost *, ResMail *, const unsigned *, ResDone *, int);
     const ResKernel rk = ne3 ? (xl ? k_resident<3, true> : k_resident<3, false>) : (xl ? k_resident<6, true> : k_resident<6, false>);
-    hipLaunchKernelGGL(rk, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
+    // HIP maps streams onto a few hardware queues, and whatever is queued BEHIND a kernel that stays waits until it leaves:
+    // the side stream's scoring, the null stream's copies back.  Which queue a stream gets is the runtime's business
+    // (tools/resident_alias_probe.py: one fresh stream in fourteen lands behind the kernel), so the kernel is started, a
+    // small kernel is sent down the side stream and the null stream, and if either has not come back in 150 ms the
+    // resident kernel leaves again and comes back on a NEW search stream - a few times, then it is an error.
+    hipError_t e = hipSuccess;
+    bool clear = false;
+    ReadyList none; none.n = 0;
+    struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev_side, ev_null;
+    HIPCHK(hipEventCreateWithFlags(&ev_side.e, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_null.e, hipEventDisableTiming));
+    for (int attempt = 0; attempt < 8 && !clear; ++attempt) {
+        hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->d_ready, R->n);
+        hipLaunchKernelGGL(rk, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
+        e = hipGetLastError();
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(jd_res_ready_kernel, dim3(1), dim3(64), 0, d->s_gmm, R->d_ready, none);
+        (void)hipEventRecord(ev_side.e, d->s_gmm);
+        hipLaunchKernelGGL(jd_res_ready_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, R->d_ready, none);
+        (void)hipEventRecord(ev_null.e, (hipStream_t)0);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!clear && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < 150.0) {
+            clear = hipEventQuery(ev_side.e) == hipSuccess && hipEventQuery(ev_null.e) == hipSuccess;
+            if (!clear) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        if (clear) break;
+        // behind the kernel: it leaves (the exit word), what waited for it runs, and the search stream is made anew
+        for (int t = 0; t < R->n; ++t) __atomic_store_n(&R->h_post[t].exit_req, 1, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(d->s_search);
+        (void)hipEventSynchronize(ev_side.e); (void)hipEventSynchronize(ev_null.e);
+        memset(R->h_post, 0, (size_t)R->n * sizeof(ResPost));
+        memset(R->h_done, 0, (size_t)R->n * sizeof(ResDone));
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio_hi) != hipSuccess) { e = hipErrorUnknown; break; }
+        d->res_old_streams.push_back(d->s_search);                     // (destroyed with the decoder: somebody may still hold it)
+        d->s_search = fresh;
+        if (getenv("JD_VERBOSE")) fprintf(stderr, "k_resident: the side stream or the null stream was queued behind it - a new search stream (%d)\n", attempt + 1);
+    }
+    if (e != hipSuccess || !clear) {
         delete R->process_lock; R->process_lock = nullptr; R->search_lock.unlock();
-        return jd_fail(JD_EHIP, "k_resident: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return jd_fail(JD_EHIP, "k_resident: %s", hipGetErrorString(e));
+        return jd_fail(JD_EHIP, "k_resident: no search stream whose hardware queue the side stream and the null stream do not share");
     }
     R->on = true;
     if (getenv("JD_VERBOSE")) fprintf(stderr, "k_resident: %d streams, clusters of %d workgroups, %d rows per buffer\n", R->n, R->Cw, R->rows);
@@ -2530,6 +2582,13 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
 }
 
 int jd_res_cluster(const jd_dec *d) { return (d && d->res) ? d->res->Cw : 0; }
+// the kernel leaves for somebody who waits for the device, and comes back behind them (jd_res_start)
+int jd_res_yield(jd_dec *d)
+{
+    if (!d || !d->res || !d->res->on) return JD_OK;
+    d->res_yield_turn = g_search_turn[(size_t)std::min(std::max(d->device, 0), JD_MAX_DEVICES - 1)].load();
+    return jd_res_stop(d);
+}
 // somebody else of this process waits for the device's search lock (another decoder's launch, another broker's kernel)
 int jd_res_should_yield(const jd_dec *d)
 {

@@ -74,6 +74,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf);
 int jd_res_stop(jd_dec *d);
 int jd_res_cluster(const jd_dec *d);
 int jd_res_should_yield(const jd_dec *d);
+int jd_res_yield(jd_dec *d);
 long long jd_res_collections(const jd_dec *d);
 long long jd_res_run_us(const jd_dec *d);          // (statistics) device time the clusters spent on their commands
 int jd_res_init(jd_dec *d, int s);

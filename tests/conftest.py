@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # a GPU test that hangs must fail, not take the whole run with it (pytest-timeout, where it is installed)
+    if config.pluginmanager.hasplugin("timeout"):
+        for it in items:
+            if "gpu" in it.keywords and not it.get_closest_marker("timeout"):
+                it.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope="session")
 def built():
     """Build the HIP extension and the oracle once per session."""

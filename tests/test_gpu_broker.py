@@ -64,7 +64,7 @@ def test_broker_threads_match_batch(small):
     dec = capi.Decoder(gnet, gam, max_streams=6, **KW)
     broker = capi.Broker(dec)
     out = [None] * len(feats)
-    threads = [threading.Thread(target=_drive, args=(broker, [(u, feats[u]) for u in range(t, len(feats), 6)], out, 23 + 7 * t))
+    threads = [threading.Thread(daemon=True, target=_drive, args=(broker, [(u, feats[u]) for u in range(t, len(feats), 6)], out, 23 + 7 * t))
                for t in range(6)]
     for t in threads:
         t.start()
@@ -124,7 +124,7 @@ def test_broker_error_stays_with_its_client(built):
                 broker.push(c, feats[u][i:i + 31 + 5 * t])
             out[u] = broker.finish(c)
         broker.close_client(c)
-    threads = [threading.Thread(target=drive, args=(t,)) for t in range(4)]
+    threads = [threading.Thread(daemon=True, target=drive, args=(t,)) for t in range(4)]
     for t in threads:
         t.start()
     for t in threads:
@@ -157,7 +157,7 @@ def test_broker_corner_cases(built, resident, monkeypatch):
     broker = capi.Broker(dec)
     assert bool(broker.stats()["resident"]) == (resident == "1")
     out = [None] * len(feats)
-    threads = [threading.Thread(target=_drive, args=(broker, [(u, feats[u]) for u in range(t, len(feats), 4)], out, 50 + 11 * t)) for t in range(4)]
+    threads = [threading.Thread(daemon=True, target=_drive, args=(broker, [(u, feats[u]) for u in range(t, len(feats), 4)], out, 50 + 11 * t)) for t in range(4)]
     for t in threads:
         t.start()
     for t in threads:
@@ -192,7 +192,7 @@ def test_broker_corner_cases(built, resident, monkeypatch):
     dec = capi.Decoder(gnet2, gam2, max_streams=3, **kw)
     broker = capi.Broker(dec)
     out = [None] * 6
-    threads = [threading.Thread(target=_drive, args=(broker, [(u, feats2[u]) for u in range(t, 6, 3)], out, 40 + 9 * t)) for t in range(3)]
+    threads = [threading.Thread(daemon=True, target=_drive, args=(broker, [(u, feats2[u]) for u in range(t, 6, 3)], out, 40 + 9 * t)) for t in range(3)]
     for t in threads:
         t.start()
     for t in threads:
@@ -231,7 +231,7 @@ def test_two_brokers_and_a_batch_decoder_share_the_device(built):
         for rep in range(6):
             got = bd.decode_batch(feats[:4])
             batch_out.append(all(bit_exact(g, w) for g, w in zip(got, want[:4])))
-    threads = [threading.Thread(target=drive, args=(k, t)) for k in range(2) for t in range(3)] + [threading.Thread(target=batch)]
+    threads = [threading.Thread(daemon=True, target=drive, args=(k, t)) for k in range(2) for t in range(3)] + [threading.Thread(daemon=True, target=batch)]
     for t in threads:
         t.start()
     for t in threads:
@@ -262,7 +262,7 @@ def test_broker_throughput_at_configs1(built):
     dec = capi.Decoder(gnet, gam, max_streams=16, **kw)
     broker = capi.Broker(dec)
     out = [None] * 64
-    threads = [threading.Thread(target=_drive, args=(broker, [(u, feats[u]) for u in range(t, 64, 16)], out, 64)) for t in range(16)]
+    threads = [threading.Thread(daemon=True, target=_drive, args=(broker, [(u, feats[u]) for u in range(t, 64, 16)], out, 64)) for t in range(16)]
     for t in threads:                                                  # (this pass warms the decoder up)
         t.start()
     for t in threads:
@@ -273,7 +273,7 @@ def test_broker_throughput_at_configs1(built):
     # that the rate is not the tail of the caller that drew the longest utterances
     outs = [[None] * 64 for _ in range(16)]
     order = [[(u % 64, feats[u % 64]) for u in range(4 * t, 4 * t + 64)] for t in range(16)]
-    threads = [threading.Thread(target=_drive, args=(broker, order[t], outs[t], 64)) for t in range(16)]
+    threads = [threading.Thread(daemon=True, target=_drive, args=(broker, order[t], outs[t], 64)) for t in range(16)]
     t0 = time.perf_counter()
     for t in threads:
         t.start()
