@@ -3009,10 +3009,20 @@ static int pipe_decode(jd_dec *d, int n_utts, const float *d_feats, const int64_
     }
     const auto w0 = std::chrono::steady_clock::now();
     int restarts = 0;
+    long long seen_frames = -1;
+    auto t_progress = w0;
     for (;;) {
         const int rc = pipe_pump(d);
         if (rc) { pipe_drain(d); return rc; }
         if (P->q.front().n_done == P->q.front().n) break;
+        {   // (no utterance through for 30 s: something is stuck - better an error, and the other paths, than a caller that waits for ever)
+            const auto now = std::chrono::steady_clock::now();
+            if (P->frames_done != seen_frames) { seen_frames = P->frames_done; t_progress = now; }
+            else if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
+                pipe_drain(d);
+                return jd_fail(JD_EHIP, "the batch pipeline has not finished an utterance for 30 s");
+            }
+        }
         bool left = false;
         for (int s = 0; s < P->n_slots && d->res->on && !left; ++s) left = __atomic_load_n(&d->res->h_done[s].left, __ATOMIC_ACQUIRE) != 0;
         if (left) {
