@@ -13,6 +13,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(cmd, env, timeout):
+    """subprocess.run whose time limit also holds when the ranks (grandchildren) keep the pipes open: the whole process group goes."""
+    import signal
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError("timed out after %d s:\n%s\n%s" % (timeout, out[-2000:], err[-2000:]))
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
 def _port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -23,7 +36,7 @@ def test_two_ranks_gather_hip_hypotheses(built):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "tests", "mr_worker.py")]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    out = _run(cmd, env, 240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "identical to the single-rank decode: True" in out.stdout
 
@@ -35,7 +48,7 @@ def test_bench_spawns_its_own_ranks(built):
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--utts-per-gpu", "6",
            "--arcs", "60000", "--no-cpu-baseline", "--no-extra-legs"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    out = _run(cmd, env, 240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
@@ -49,7 +62,7 @@ def test_bench_strong_scaling_mode(built):
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--total-utts", "11",
            "--arcs", "60000", "--no-cpu-baseline", "--no-extra-legs"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    out = _run(cmd, env, 240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gathered_hyps"] == 11 and d["value"] > 0
