@@ -394,6 +394,11 @@ int jd_broker_get_stats(jd_broker *b, jd_broker_stats *out);
 int jd_dec_set_partial_interval(jd_dec *d, int32_t interval);
 int jd_stream_collect_info(jd_dec *d, int32_t s, int32_t *n_collections, int32_t *last_collect_frame);
 int jd_stream_path_counts(jd_dec *d, int32_t s, int32_t *n_path, int32_t *n_path_new, int32_t *exact);
+/* Diagnostics / tests (host only): per state, the Path objects WFSTDecoderLite::propagateToken creates behind ONE token that
+ * arrives there with the end and word beams off - one per labelled epsilon arc and per labelled arc of a tee model that
+ * leaves the state, plus what arrives behind each of those arcs, with multiplicity (:497-509 inside :533-541, :583-599);
+ * saturated at 2^20.  out[n_states]; *acyclic = 0: the label-less part of the graph has a cycle, the counts are not used. */
+int jd_debug_closure_path_counts(const jd_net *net, const jd_am *am, int32_t *out, int32_t *acyclic);
 int jd_stream_partial(jd_dec *d, int32_t s, int32_t trace_now, int32_t cap, int32_t *n,
                       int32_t *labels, int32_t *times, int32_t *found);
 

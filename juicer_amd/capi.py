@@ -76,7 +76,7 @@ EXPORTS = [
     "jd_stream_finish", "jd_decode_batch", "jd_decode_batch_device", "jd_dec_last_timing",
     "jd_am_score_frames", "jd_last_error", "jd_version", "jd_dec_debug_trace", "jd_debug_expf",
     "jd_multi_create", "jd_multi_create_lazy", "jd_multi_decode_batch", "jd_multi_destroy",
-    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_stream_path_counts", "jd_dec_quiesce", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
+    "jd_dec_set_partial_interval", "jd_stream_partial", "jd_stream_collect_info", "jd_stream_path_counts", "jd_dec_quiesce", "jd_debug_closure_path_counts", "jd_dec_set_max_alloc_models", "jd_net_compose", "jd_am_create_hybrid", "jd_net_create_lazy", "jd_net_lazy_size", "jd_net_lazy_reset",
     "jd_net_lazy_set_high_water", "jd_net_lazy_generation", "jd_release_cached_memory", "jd_net_push_labels",
     "jd_dec_prefetch_scores", "jd_streams_push", "jd_dec_info",
     "jd_broker_create", "jd_broker_destroy", "jd_broker_open", "jd_broker_close", "jd_broker_init", "jd_broker_push",
@@ -239,6 +239,13 @@ class Network:
         _check(lib().jd_net_get_csr(self.h, _p(rp, C.c_int32), _p(to, C.c_int32), _p(w, C.c_float),
                                     _p(il, C.c_int32), _p(ol, C.c_int32), _p(fw, C.c_float)))
         return dict(row_ptr=rp, to=to, w=w, ilab=il, olab=ol, fin_w=fw)
+
+    def closure_path_counts(self, models):
+        """(per-state Path counts of the reference's propagateToken closure, acyclic) - jd_debug_closure_path_counts (host only)."""
+        out = np.zeros(self.n_states, np.int32)
+        ok = C.c_int32(0)
+        _check(lib().jd_debug_closure_path_counts(self.h, models.h, _p(out, C.c_int32), C.byref(ok)))
+        return out, bool(ok.value)
 
     @property
     def n_arcs(self):

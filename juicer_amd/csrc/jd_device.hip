@@ -3113,6 +3113,19 @@ static bool closure_path_counts(const jd_net *net, const jd_am *am, std::vector<
     return true;
 }
 
+// Diagnostics / tests (host only, no device): the per-state counts of closure_path_counts - what jd_dec_set_partial_interval puts
+// on the device for collectPaths' count trigger - into out[n_states]; *acyclic = 0 when the label-less part of the graph has
+// a cycle (the counts are then not used)
+extern "C" int jd_debug_closure_path_counts(const jd_net *net, const jd_am *am, int32_t *out, int32_t *acyclic)
+{
+    if (!net || !am || !out || !acyclic) return jd_fail(JD_EINVAL, "jd_debug_closure_path_counts: null argument");
+    if (net->lazy_dev) return jd_fail(JD_EINVAL, "jd_debug_closure_path_counts: not for a lazily composed network");
+    std::vector<int> P;
+    *acyclic = closure_path_counts(net, am, P) ? 1 : 0;
+    for (int q = 0; q < net->n_states; ++q) out[q] = P[(size_t)q];
+    return JD_OK;
+}
+
 extern "C" int jd_dec_set_partial_interval(jd_dec *d, int32_t interval)
 {
     if (!d || interval < 0) return jd_fail(JD_EINVAL, "jd_dec_set_partial_interval: traceInterval >= 0");

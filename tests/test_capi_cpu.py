@@ -263,3 +263,46 @@ def test_csr_input_is_validated(built):
         with pytest.raises(capi.JuicerAmdError) as e:
             capi.Network.from_csr(**{**ok, **bad})
         assert e.value.code == capi.JD_EINVAL
+
+
+def test_closure_path_counts_against_the_recursion(built):
+    """collectPaths' count trigger counts the reference's Path objects without writing them: per state, what ONE arriving token
+    makes propagateToken create in its closure (WFSTDecoderLite.cpp:497-509 inside the recursion of :533-541, :583-599: a Path
+    per labelled epsilon arc and per labelled arc of a tee model, recursively, with multiplicity).  The library's post-order
+    walk against the recursion written out in Python, on graphs with a flat 400-word fan-out, a lexicon tree and HMMs of mixed
+    size; a label-less cycle is reported."""
+    import sys
+    from juicer_amd import capi, synth
+    sys.setrecursionlimit(20000)
+    cases = [synth.config_small(seed=31, n_utts=1, n_words=400, n_succ=5, n_gmm=120, n_hmm=45, hub="flat"),
+             synth.config_small(seed=7, n_utts=1, hub="tree"), synth.config_mixed(seed=12, n_utts=1, n_words=120, n_succ=6)]
+    for am, net, _, _ in cases:
+        gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+        got, acyclic = gnet.closure_path_counts(gam)
+        assert acyclic
+        c = gnet.csr()
+        tee = np.zeros(am.n_hmm, bool)
+        for h in range(am.n_hmm):
+            n = int(am.hmm_nstates[h]); a = am.transp[am.hmm_tm[h]]
+            sucs = [j for j in range(n) if a[0, j] > 0]
+            tee[h] = (n - 1) in sucs[1:]                               # (HTKModels.cpp:581-593: not the FIRST successor of state 0)
+        memo = {}
+
+        def count(q):
+            if q in memo:
+                return memo[q]
+            tot = 0
+            for a in range(int(c["row_ptr"][q]), int(c["row_ptr"][q + 1])):
+                il, ol, to = int(c["ilab"][a]), int(c["olab"][a]), int(c["to"][a])
+                if il == 0 or tee[il - 1]:
+                    tot += (1 if ol != 0 else 0) + count(to)
+            memo[q] = min(tot, 1 << 20)
+            return memo[q]
+        want = np.array([count(q) for q in range(gnet.n_states)], np.int64)
+        assert np.array_equal(got.astype(np.int64), want) and want.max() > 0
+    # a cycle of epsilon arcs: the reference would not come back from it; the counts are not used (the rule then runs on this build's own records)
+    cyc = capi.Network.from_arcs(src=[0, 1, 2, 2], dst=[1, 2, 1, 3], ilab=[1, 0, 0, 1], olab=[0, 5, 0, 0], w_file=[0.0, 0.0, 0.0, 0.0],
+                                 fstate=[3], fweight_file=[0.0])
+    am, _, _, _ = synth.config_toy()
+    _, acyclic = cyc.closure_path_counts(capi.Models.from_htk(am))
+    assert not acyclic
