@@ -38,6 +38,10 @@ struct Client {
     bool running = false; int run_buf = 0;
     bool fresh = false;                            // initialised and nothing posted yet (recognitionStart is still to run)
     bool finishing = false;                        // its result is being fetched (the finisher thread)
+    unsigned init_req = 0;                         // counts the client's init() calls: one that arrives while the worker serves
+                                                   // another (outside the lock) is still to be served behind it
+    bool in_flight = false;                        // the worker holds something of this client outside the lock (frames being
+                                                   // staged, a tick it is part of): close waits for that - the slot is somebody else's after it
     std::chrono::steady_clock::time_point t_post, t_idle;   // (statistics) its last command posted / found through
     bool was_idle = false;
     std::vector<float> taken;                      // frames on their way into a likelihood buffer
@@ -78,6 +82,7 @@ static void broker_loop(jd_broker *b)
     std::unique_lock<std::mutex> lk(b->mu);
     std::vector<int> inits, pushers, finishers;
     std::vector<std::vector<float>> taken((size_t)b->n_clients);
+    std::vector<unsigned> init_seen((size_t)b->n_clients, 0u);
     double search_ms_seen = 0.0;                   // (jd_timing accumulates over the streaming calls)
     for (;;) {
         auto has_work = [&]() {
@@ -112,7 +117,7 @@ static void broker_loop(jd_broker *b)
         for (int i = 0; i < b->n_clients; ++i) {
             Client &c = b->clients[(size_t)i];
             if (!c.open) continue;
-            if (c.want_init) inits.push_back(i);
+            if (c.want_init) { inits.push_back(i); init_seen[(size_t)i] = c.init_req; }
             // (frames pushed behind an init that has not been served yet go with this tick too: the init comes first)
             if ((c.inited || c.want_init) && !c.pending.empty()) {
                 const size_t have = c.pending.size() / (size_t)b->D;
@@ -126,6 +131,9 @@ static void broker_loop(jd_broker *b)
             Client &c = b->clients[(size_t)i];
             if (c.open && c.want_finish && c.pending.empty()) finishers.push_back(i);   // (its last frames - and its init - go with this tick)
         }
+        for (int i : inits) b->clients[(size_t)i].in_flight = true;
+        for (int i : pushers) b->clients[(size_t)i].in_flight = true;
+        for (int i : finishers) b->clients[(size_t)i].in_flight = true;
         lk.unlock();
         b->cv_done.notify_all();                                       // (pushes that waited for room)
         // ---- the decoder is touched from here only
@@ -193,8 +201,13 @@ static void broker_loop(jd_broker *b)
             Client &c = b->clients[(size_t)i];
             if (rc_of[(size_t)i] != JD_OK && c.err == JD_OK) { c.err = rc_of[(size_t)i]; c.errmsg = msg_of[(size_t)i]; }
         }
-        for (int i : inits) { Client &c = b->clients[(size_t)i]; c.want_init = false; c.inited = rc_of[(size_t)i] == JD_OK; }
+        for (int i : inits) {
+            Client &c = b->clients[(size_t)i];
+            if (c.init_req == init_seen[(size_t)i]) c.want_init = false;   // (else: init() again meanwhile - the next tick's)
+            c.inited = rc_of[(size_t)i] == JD_OK;
+        }
         for (int i : finishers) { Client &c = b->clients[(size_t)i]; c.want_finish = false; c.inited = false; c.result = res[(size_t)i]; }
+        for (Client &c : b->clients) c.in_flight = false;
         b->cv_done.notify_all();
     }
 }
@@ -312,11 +325,13 @@ static void broker_loop_resident(jd_broker *b)
             }
             // 2. IDecoder::init
             if (!c.running && c.n_staged == 0 && c.want_init) {
+                const unsigned req = c.init_req;
                 lk.unlock();
                 rc = jd_res_init(b->dec, i);
                 const std::string m = rc ? jd_last_error() : "";
                 lk.lock();
-                c.want_init = false; c.inited = rc == JD_OK; c.fresh = rc == JD_OK; c.was_idle = false;
+                if (c.init_req == req) c.want_init = false;           // (else: init() again meanwhile - served in the next round)
+                c.inited = rc == JD_OK; c.fresh = rc == JD_OK; c.was_idle = false;
                 if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
                 b->cv_done.notify_all();
                 progress = true;
@@ -333,6 +348,7 @@ static void broker_loop_resident(jd_broker *b)
                     c.taken.assign(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
                     c.pending.erase(c.pending.begin(), c.pending.begin() + (ptrdiff_t)(take * b->D));
                     st_s.push_back(i); st_b.push_back(buf); st_f.push_back(c.taken.data()); st_n.push_back((int)take);
+                    c.in_flight = true;
                 }
             }
         }
@@ -348,7 +364,9 @@ static void broker_loop_resident(jd_broker *b)
                 Client &c = b->clients[(size_t)st_s[k]];
                 if (rc) { if (c.err == JD_OK) { c.err = rc; c.errmsg = m; } }
                 else { c.staged_buf[c.n_staged] = st_b[k]; c.staged_n[c.n_staged] = st_n[k]; c.n_staged += 1; }
+                c.in_flight = false;
             }
+            b->cv_done.notify_all();
             st_s.clear(); st_b.clear(); st_f.clear(); st_n.clear();
             progress = true;
         }
@@ -452,7 +470,7 @@ extern "C" int jd_broker_close(jd_broker *b, int32_t client)
     c.pending.clear(); c.want_finish = false;
     // (... and what its cluster still has of them runs out first: the stream is somebody else's after this)
     b->cv_work.notify_all();
-    b->cv_done.wait(lk, [&]() { return b->stop || (!c.want_init && !c.running && c.n_staged == 0); });
+    b->cv_done.wait(lk, [&]() { return b->stop || (!c.want_init && !c.running && c.n_staged == 0 && !c.in_flight && !c.finishing); });
     c.pending.clear(); c.want_finish = false; c.inited = false; c.open = false;
     return JD_OK;
 }
@@ -466,6 +484,7 @@ extern "C" int jd_broker_init(jd_broker *b, int32_t client)
     // (an init that is still waiting to be served - init() twice - is this one)
     c.pending.clear(); c.want_finish = false; c.err = JD_OK;          // (init() in the middle of an utterance drops it, as the reference does)
     c.want_init = true;
+    c.init_req += 1;
     // nobody waits for the worker here: the stream is initialised at the head of the next tick, in front of whatever
     // frames this client has pushed by then (an error of it comes back with the next call)
     b->cv_work.notify_all();
