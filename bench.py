@@ -139,10 +139,10 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
     depth = 0
     if pipe:
         depth, max_streams, two = pipe[0], pipe[1], False
-        os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = str(depth + 1)
     dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam,
                        max_hyps=max_hyps, device=dev.index, max_streams=(2 * U if two else U) if not max_streams else max_streams)
-    os.environ.pop("JD_PIPELINE", None); os.environ.pop("JD_PIPE_DEPTH", None)
+    if depth:
+        dec.set_pipeline(capi.FLOW_RESIDENT, depth + 1, max_streams)
     offs = np.zeros(U + 1, dtype=np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in feats])
     d_feats = torch.from_numpy(np.concatenate(feats)).to(dev)
@@ -158,10 +158,13 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
             dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
         passes += depth + 2                                            # (the first batches come back in a burst)
     n_calls = passes + depth                                           # (pipe: every announced batch is decoded)
+    win = None                                                         # pipe: (time, frames the slots had advanced) at the steady window's ends
     for i in range(n_calls):
         if not depth:
             torch.cuda.synchronize()                                   # (a device-wide synchronisation waits for a resident kernel)
         t1 = time.perf_counter()
+        if depth and i == depth + 2:
+            win = [(t1, dec.pipeline_stats()["frames_searched"])]
         if ahead and (not depth or i < passes):                        # the next pass's table is scored beside this pass's search
             dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
         hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
@@ -175,15 +178,20 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
             if depth + 2 <= i < passes:
                 tm_i = dict(tm_i); tm_i["search_ms"] = dt * 1e3; tm_i["search_launches"] = 1
                 runs.append((dt, tm_i))
+            if i == passes - 1 and win:
+                win.append((time.perf_counter(), dec.pipeline_stats()["frames_searched"]))
         elif i > (1 if two else 0) or passes == 1:
             runs.append((dt, tm_i))
     dec.prefetch_scores(0, None)
     runs.sort(key=lambda r: r[0])
     best, tm = runs[(len(runs) - 1) // 2]                             # the median pass (the lower one of an even number)
-    if depth:                                                          # (the pipeline hands its batches back in bursts: the MEAN of the steady passes)
-        best = sum(r[0] for r in runs) / len(runs)
-        tm = dict(tm); tm["search_ms"] = best * 1e3
     frames = int(offs[-1])
+    if depth:                                                          # (the pipeline hands its batches back in bursts: the MEAN of the steady passes,
+        # by the frames its slots really advanced in that window - jd_dec_pipeline_stats)
+        best = sum(r[0] for r in runs) / len(runs)
+        if win and len(win) == 2 and win[1][1] > win[0][1]:
+            best = (win[1][0] - win[0][0]) * frames / float(win[1][1] - win[0][1])
+        tm = dict(tm); tm["search_ms"] = best * 1e3
     st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}
     out = {"workload": "%s: %d-arc composed C.L.G, %d tied states x %d mix, %d utterances, mainBeam %g, maxHyps %d"
                        % (name, net.n_arcs, am.n_gmm, am.max_mix, U, beam, max_hyps),
@@ -304,7 +312,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--utts-per-gpu", type=int, default=64)
     ap.add_argument("--total-utts", type=int, default=0,
@@ -325,6 +333,11 @@ def main():
                          "0 = two batches in flight, one launch per step (what runs with several ranks) - measured on one box, 20 steps: "
                          "30.7-30.8 ms per step against 26.7 with six batches ahead through 160 slots")
     ap.add_argument("--pipeline-slots", type=int, default=160, help="streams (= workgroups) of the resident pipeline; the other CUs score")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="several ranks: 0 = the 1-best records of all timed steps travel in ONE RCCL all_gather at the end of the timed "
+                         "region, behind jd_dec_quiesce (a rank has its own results at once; a collective's kernels must not be queued on a "
+                         "device whose search kernel stays); 1 = one all_gather per step, which runs two batches in flight instead of "
+                         "the resident pipeline")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -400,24 +413,28 @@ def main():
     # ... or, deeper: the batches' utterances through the slots of a search kernel that stays ("batches through the
     # resident kernel"): a batch is scored whole when it is announced, a slot takes the next queued utterance the moment its own
     # is through, and a step hands back the oldest batch - still ITS 64 results, decoded in full
-    # (one rank only: with several, every step gathers the hypotheses through RCCL, whose kernels would have to start beside a
-    # kernel that never leaves - and HIP maps streams onto a few hardware queues: tools/resident_alias_probe.py finds one fresh
-    # stream in fourteen queued BEHIND the resident kernel until it leaves; those runs keep two batches in flight, one launch per step)
-    depth = args.pipeline_depth if (two_in_flight and world == 1 and args.pipeline_depth > 0) else 0
+    # (several ranks: the same path.  What a collective needs - its kernels on a stream of the process - it must not get while a
+    # kernel STAYS on the device: HIP maps streams onto a few hardware queues, tools/resident_alias_probe.py finds one fresh stream
+    # in fourteen queued BEHIND the resident kernel until it leaves.  So the 1-best records of the K steps travel in ONE RCCL
+    # all_gather at the end of the timed region, behind jd_dec_quiesce - utterances are independent, DecoderBatchTest.cpp:738-771:
+    # a rank has its own results the moment its step returns.  --gather-every 1 keeps a collective per step and two batches in flight.)
+    per_step_gather = world > 1 and args.gather_every == 1
+    depth = args.pipeline_depth if (two_in_flight and args.pipeline_depth > 0 and not per_step_gather) else 0
     pipeline_error = None
     for depth in ((depth, 0) if depth else (0,)):                      # (should the pipeline fail: the same measurement, two batches in flight)
       try:
-        if depth:
-            os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = str(depth + 1)
         dec = capi.Decoder(gnet, gam, main_beam=args.beam, max_hyps=args.max_hyps, device=local_rank,
                            max_streams=min(U, 128) if strong else (args.pipeline_slots if depth else (2 * U if two_in_flight else U)))
-        os.environ.pop("JD_PIPELINE", None); os.environ.pop("JD_PIPE_DEPTH", None)
+        if depth:                                                      # the interface: jd_dec_set_pipeline (include/juicer_amd.h)
+            dec.set_pipeline(capi.FLOW_RESIDENT, depth + 1, args.pipeline_slots)
         offs = np.zeros(len(feats) + 1, dtype=np.int64)
         offs[1:] = np.cumsum([f.shape[0] for f in feats])
         frames_local = int(offs[-1])
         d_feats = torch.from_numpy(np.concatenate(feats) if feats else np.zeros((0, am.D), np.float32)).to(dev)     # inputs resident in HBM
         torch.cuda.synchronize()
         stream = torch.cuda.current_stream().cuda_stream
+
+        pending = []                                                   # several ranks: steps whose records have not travelled yet
 
         def step():
             # One step = one pass over one batch: its search, and one scoring of a batch's likelihood table.  Batches follow
@@ -430,8 +447,19 @@ def main():
             if ahead:
                 dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
             hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
-            allh = parallel.gather_hyps(hyps, per_rank, device=dev, index=shard) if world > 1 else hyps
-            return hyps, allh
+            if world > 1 and per_step_gather:
+                return hyps, parallel.gather_hyps(hyps, per_rank, device=dev, index=shard)
+            if world > 1:
+                pending.append((hyps, shard))
+            return hyps, hyps
+
+        def travel():
+            """the records of the steps since the last exchange: ONE all_gather (the resident kernel has left: quiesce)"""
+            if not pending:
+                return None
+            got = parallel.gather_hyps_steps(pending, per_rank, device=dev)
+            del pending[:]
+            return got
 
         def barrier():
             if world > 1:
@@ -449,7 +477,9 @@ def main():
         # (a device-wide synchronisation waits for every kernel on the device: the pipeline's resident kernel lets its running
         # commands run out and leaves - jd_dec_quiesce - and comes back with the first timed step, inside the brackets)
         dec.quiesce()
+        travel()
         barrier(); torch.cuda.synchronize()
+        ps0 = dec.pipeline_stats()
         t0 = time.perf_counter()
         acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0,
                "ahead_frames": 0}
@@ -464,8 +494,12 @@ def main():
             for k in acc:
                 acc[k] += tm[k]
         dec.quiesce()
+        gathered = travel()                                            # (inside the timed region: the one collective of the K steps)
+        if gathered:
+            allh = gathered[-1]
         torch.cuda.synchronize(); barrier()
         elapsed = time.perf_counter() - t0
+        ps1 = dec.pipeline_stats()
         break
       except capi.JuicerAmdError as e:
         if not depth:
@@ -476,26 +510,47 @@ def main():
             dec.close()
         except Exception:
             pass
-    # (outside the timed region) the same step in the serial order: what the scoring kernel takes on its own
+    # `value` counts the frames the device really searched between the two brackets: with batches through the resident kernel
+    # that is what its slots report having advanced (jd_dec_pipeline_stats: a batch handed back inside the region was partly
+    # searched before it, batches announced inside it are partly searched behind it); with one launch per step it is K batches
+    frames_timed = (ps1["frames_searched"] - ps0["frames_searched"]) if depth else frames_local * args.steps
+    # (outside the timed region) what a caller gets who cannot announce that far ahead: ONE batch of 64 at a time.
+    #   serial order:  nothing announced - the batch's table is scored, then it is searched (re-planned at will)
+    #   one ahead:     the next batch announced before each decode - its table is scored beside this batch's search
+    dec.set_pipeline(capi.FLOW_SERIAL)
     dec.prefetch_scores(0, None)
+    dec.decode_batch_device(d_feats.data_ptr(), offs, stream)          # (a launch of this shape has been planned once)
     t1 = time.perf_counter()
     dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
     torch.cuda.synchronize()
     serial_ms = (time.perf_counter() - t1) * 1e3
     tm_serial = dec.last_timing()
+    one_ahead = []
+    dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
+    for i in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
+        dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
+        torch.cuda.synchronize()
+        if i >= 2:
+            one_ahead.append(((time.perf_counter() - t1) * 1e3, dec.last_timing()))
+    one_ahead.sort(key=lambda r: r[0])
+    one_ahead_ms, tm_one = one_ahead[len(one_ahead) // 2]
+    dec.prefetch_scores(0, None)
     # (outside the timed region) which part of the likelihood table does the search read?  SURVEY.md 8d's Ug: the reference
     # scores a tied state only when a token that passed the emit threshold asks for it; every state of every frame is scored here
     dec.debug_cells(True)
     dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
     cells_read, cells_total = dec.debug_cells(False)
     if world > 1:
-        t = torch.tensor([elapsed, float(frames_local)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(frames_local), float(frames_timed)], dtype=torch.float64, device=dev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0]); frames_total = float(tsum[1])
+        elapsed = float(tmax[0]); frames_total = float(tsum[1]); frames_timed_total = float(tsum[2])
         n_gathered = len(allh)
     else:
-        frames_total = float(frames_local)
+        frames_total = float(frames_local); frames_timed_total = float(frames_timed)
         n_gathered = len(hyps)
 
     if rank != 0:
@@ -505,7 +560,7 @@ def main():
         return
 
     steps = args.steps
-    fps = frames_total * steps / elapsed
+    fps = frames_timed_total / elapsed
     D, G, M, MN = am.D, am.n_gmm, am.max_mix, am.max_n
     st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals (rank 0)
     default_cfg = (args.arcs == 1_000_000 and args.beam == 150.0 and args.max_hyps == 0 and U == 64 and args.seed == 0 and not strong)
@@ -516,15 +571,18 @@ def main():
     step_tm["search_ms"] = acc["search_ms"] / steps
     step_tm["search_launches"] = max(1, acc["search_launches"] // steps)
     traffic = leg_traffic("c2", step_tm["search_launches"]) if default_cfg else None
-    if depth:                                                      # (the resident kernel is busy all the time: a batch's share of it is the step)
-        step_tm["search_ms"] = elapsed / steps * 1e3
+    if depth:                                                      # (the resident kernel is busy all the time: a batch's share of it
+        # is the time the slots took for one batch's worth of the frames they really advanced inside the brackets)
+        step_tm["search_ms"] = elapsed * 1e3 * frames_local / max(1.0, float(frames_timed))
     roofline = roofline_of(st, MN, step_tm, traffic)
     if depth:
         roofline["kernel"] = "k_resident"
-        roofline["launch"] = ("ONE launch spans the run (jd_resident.h): a batch's share of it = the timed region / K steps; "
-                              "avg_launch_us is that share, algorithmic_bytes_per_launch one batch's bytes; traffic = the counted HBM bytes "
-                              "of one batch through the SAME per-stream code with two batches in flight (the default run: "
-                              "the profiler runs kernels one after the other under --pmc, and this one waits for the scoring beside it)")
+        roofline["traffic_is"] = "proxy: k_search"
+        roofline["launch"] = ("ONE launch spans the timed region (jd_resident.h): a batch's share of it = the region x (one batch's frames / "
+                              "the frames the slots advanced inside it, jd_dec_pipeline_stats); avg_launch_us is that share, "
+                              "algorithmic_bytes_per_launch one batch's bytes; traffic is a PROXY - the counted HBM bytes of one batch through "
+                              "the same per-stream code as k_search launches (the profiler runs kernels one after the other under --pmc, and "
+                              "k_resident waits for the scoring, export and ready kernels beside it)")
     gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
     gmm_bytes = G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / max(1, tm["gmm_launches"])
     roofline["search_ms_per_step"] = round(step_tm["search_ms"], 3)
@@ -590,12 +648,24 @@ def main():
         except RuntimeError as e:                                 # models with a skip into the exit state (refused like the reference)
             cpu["two_thread_core"] = {"error": str(e)}
 
+    # what ONE batch of 64 costs a caller that does not announce six batches ahead - beside `value`, not inside it
+    one = roofline_of(st, MN, tm_one, leg_traffic("c2", max(1, tm_one["search_launches"])) if default_cfg else None)
+    single_batch = {"serial_order": {"ms": round(serial_ms, 3), "frames_per_s": round(frames_local / serial_ms * 1e3, 1), "frac": ser["frac"],
+                                     "what": "nothing announced: the batch's table is scored, then it is searched"},
+                    "one_ahead": {"ms": round(one_ahead_ms, 3), "frames_per_s": round(frames_local / one_ahead_ms * 1e3, 1), "frac": one["frac"],
+                                  "what": "the next batch announced before each decode (jd_dec_prefetch_scores): its table is scored beside "
+                                          "this batch's search; one batch on the chip at a time (JD_FLOW_SERIAL)"},
+                    "note": "measured behind the timed region on rank 0 (median of 3 / one pass); not part of `value`"}
     name = "configs[1]" if default_cfg else "configs[1]-shaped (non-default size / pruning)"
     out = {"metric": "frames/sec decoded", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
            "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
            "ms_each_step": each if steps <= 32 else None,
            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic", "xRT": round(fps / 100.0, 1),
+           "frames_timed": int(frames_timed_total),
+           "frames_timed_is": ("stream-frames the resident kernel's slots advanced between the two brackets (jd_dec_pipeline_stats), all ranks"
+                               if depth else "steps x the frames of a batch, all ranks"),
+           "single_batch": single_batch,
            "config": {"workload": "%s: %d-arc composed C.L.G, %d tied states x %d mix, D=%d, "
                                   "%s, mainBeam %g, maxHyps %d"
                                   % (name, net.n_arcs, G, M, D, ("%d utterances in all" % args.total_utts) if strong else ("%d utterances per GPU" % U),
@@ -604,6 +674,8 @@ def main():
                       "parallelism": ("one batch of %d utterances dealt by length over %d rank(s)" % (args.total_utts, world)) if strong
                                      else "utterance-sharded x%d" % world,
                       "batches_in_flight": (depth + 1) if depth else (2 if two_in_flight else 1),
+                      "gather": None if world == 1 else ("one all_gather per step" if per_step_gather else
+                                                         "ONE all_gather of the %d steps' records at the end of the timed region (inside it), behind jd_dec_quiesce" % steps),
                       "pipeline_error": pipeline_error,
                       "pipeline": ("resident search kernel: %d one-workgroup slots, the other CUs score; announcements %d batches ahead, a slot takes "
                                    "the next queued utterance when its own is through" % (args.pipeline_slots, depth)) if depth else None,

@@ -437,7 +437,7 @@ int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_feats,
  * announced two decodes ahead - and each of the two fills at most half of the decoder's streams, its utterances are
  * started beside the running batch, one workgroup each, on the other half of the streams; when its turn comes they
  * are hundreds of frames in (jd_timing.ahead_frames) and the call is that much shorter.  A stream of batches gets
- * this with two announcements before its first decode and one before every later one (JD_PIPELINE=0 switches it off).
+ * this with two announcements before its first decode and one before every later one (jd_dec_set_pipeline(d, JD_FLOW_SERIAL, 0, 0) switches it off).
  * While the scoring runs the search launch is not re-planned under way when the scoring is a sizeable part
  * of the step (measured on the decoder's last batches: from a tenth of the search on), so that its blocks find
  * CUs; else it is slotted in at the re-planning cuts.
@@ -490,8 +490,49 @@ typedef struct jd_timing {
                                  flight": announcements two batches ahead, a batch on at most half of the streams) */
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
-/* The decoder's work on the device comes to rest: with JD_PIPELINE=3 (announced batches go through a search kernel that stays
- * on the device, utterance by utterance: jd_dec_prefetch_scores up to JD_PIPE_DEPTH batches ahead) that kernel lets the
+
+/*
+ * How batches that follow each other share the chip - the decoder's counterpart of the reference's constructor-time
+ * configuration (WFSTDecoderLite.h:81-89; its harness decodes list entry after list entry, DecoderBatchTest.cpp:738-771).
+ * Results never depend on it.  Call it any time between two decodes; whatever is announced or under way is dropped.
+ *   JD_FLOW_SERIAL         one batch on the chip at a time (an announced batch is still SCORED beside the running search).
+ *   JD_FLOW_TWO_IN_FLIGHT  (default) the batch behind the running one is started beside it when its table is there:
+ *                          announcements two batches ahead, each batch on at most half of the decoder's streams.
+ *   JD_FLOW_RESIDENT       announced batches go through a search kernel that STAYS on the device, utterance by utterance:
+ *                          every stream is a slot of one workgroup that takes the next queued utterance the moment its
+ *                          own is through; the other CUs score.  depth = batches announced and not yet handed back, at
+ *                          most (2..32; 0 = 8: a likelihood table each); slots = one-workgroup slots (1..max_streams;
+ *                          0 = max_streams).  jd_decode_batch_device must be called for the batches in the order they
+ *                          were announced (anything else drops what is under way and decodes the usual way); a batch
+ *                          larger than the decoder's slots goes through them without any announcement.  See
+ *                          jd_dec_quiesce for what the resident kernel means for the rest of the process.
+ *                          Not with lazily composed networks, hybrid scoring or PARTIAL_DECODING (those decode the
+ *                          usual way).
+ */
+#define JD_FLOW_SERIAL         0
+#define JD_FLOW_TWO_IN_FLIGHT  1
+#define JD_FLOW_RESIDENT       3
+int jd_dec_set_pipeline(jd_dec *d, int32_t mode, int32_t depth, int32_t slots);
+
+/* What JD_FLOW_RESIDENT has done so far (cumulative over the decoder's life; a bench reads it on either side of its
+ * timed region: frames_searched is what the slots really advanced in between, whatever was announced or handed back). */
+typedef struct jd_pipe_stats {
+    int32_t mode, depth, slots;
+    int32_t resident;            /* the kernel is on the device right now                                     */
+    int32_t batches_announced;   /* announced and not yet handed back                                         */
+    int32_t pad0;
+    int64_t frames_searched;     /* stream-frames the slots have advanced (their own reports, command by command) */
+    int64_t utts_through;        /* utterances whose result has been exported                                 */
+    int64_t rows_scored;         /* likelihood rows whose scoring has been enqueued                           */
+    int64_t batches_back;        /* batches handed back by jd_decode_batch_device                              */
+    int64_t collections;         /* Path collections between commands                                         */
+    double slot_busy_us;         /* sum over the slots of their own clocks on their commands                  */
+    double on_us;                /* wall time the resident kernel has been on the device                      */
+} jd_pipe_stats;
+int jd_dec_pipeline_stats(const jd_dec *d, jd_pipe_stats *out);
+
+/* The decoder's work on the device comes to rest: with JD_FLOW_RESIDENT (announced batches go through a search kernel that stays
+ * on the device, utterance by utterance: jd_dec_prefetch_scores up to `depth` batches ahead) that kernel lets the
  * commands that are running run out (128 frames at most) and leaves; nothing announced or under way is lost - it comes back
  * with the next call.  What a caller needs before a device-wide synchronisation while batches are announced - and before
  * it puts work of its own on OTHER streams of the device: HIP maps streams onto a few hardware queues, and a kernel that

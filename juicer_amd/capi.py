@@ -51,6 +51,17 @@ class Timing(C.Structure):
                 ("prefetched", C.c_int32), ("ahead_frames", C.c_int32)]
 
 
+FLOW_SERIAL, FLOW_TWO_IN_FLIGHT, FLOW_RESIDENT = 0, 1, 3      # jd_dec_set_pipeline
+
+
+class PipeStats(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("depth", C.c_int32), ("slots", C.c_int32), ("resident", C.c_int32),
+                ("batches_announced", C.c_int32), ("pad0", C.c_int32),
+                ("frames_searched", C.c_int64), ("utts_through", C.c_int64), ("rows_scored", C.c_int64),
+                ("batches_back", C.c_int64), ("collections", C.c_int64),
+                ("slot_busy_us", C.c_double), ("on_us", C.c_double)]
+
+
 @dataclass
 class Hyp:
     """1-best in DecHyp chain order (index 0 = newest word)."""
@@ -80,7 +91,7 @@ EXPORTS = [
     "jd_net_lazy_set_high_water", "jd_net_lazy_generation", "jd_release_cached_memory", "jd_net_push_labels",
     "jd_dec_prefetch_scores", "jd_streams_push", "jd_dec_info",
     "jd_broker_create", "jd_broker_destroy", "jd_broker_open", "jd_broker_close", "jd_broker_init", "jd_broker_push",
-    "jd_broker_finish", "jd_broker_get_stats", "jd_dec_debug_cells",
+    "jd_broker_finish", "jd_broker_get_stats", "jd_dec_debug_cells", "jd_dec_set_pipeline", "jd_dec_pipeline_stats",
 ]
 
 _lib = None
@@ -425,8 +436,19 @@ class Decoder:
         return n.value, last.value
 
     def quiesce(self):
-        """The decoder's resident kernel (JD_PIPELINE=3) leaves the device - call before a device-wide synchronisation (jd_dec_quiesce)."""
+        """The decoder's resident kernel (FLOW_RESIDENT) leaves the device - call before a device-wide synchronisation (jd_dec_quiesce)."""
         _check(lib().jd_dec_quiesce(self.h))
+
+    def set_pipeline(self, mode: int, depth: int = 0, slots: int = 0):
+        """How batches that follow each other share the chip (jd_dec_set_pipeline): FLOW_SERIAL, FLOW_TWO_IN_FLIGHT (default) or
+        FLOW_RESIDENT (depth = batches announced and not handed back at most, slots = one-workgroup slots of the resident kernel)."""
+        _check(lib().jd_dec_set_pipeline(self.h, C.c_int32(mode), C.c_int32(depth), C.c_int32(slots)))
+
+    def pipeline_stats(self) -> dict:
+        """What FLOW_RESIDENT has done so far, cumulative (jd_dec_pipeline_stats)."""
+        t = PipeStats()
+        _check(lib().jd_dec_pipeline_stats(self.h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in PipeStats._fields_ if not f.startswith("pad")}
 
     def stream_path_counts(self, s: int = 0):
         """(nPath, nPathNew, exact): collectPaths' trigger counts; exact = they are the reference's (jd_stream_path_counts)."""

@@ -126,6 +126,7 @@ int main(int argc, char **argv)
     const char *outputFName = 0;               // -outputFName: "", "stdout", "stderr" or a file (DecoderBatchTest.cpp:216-230)
     int removeSentMarks = 0;                   // -removeSentMarks (juicer.cpp:273)
     std::string sentStartWord, sentEndWord;    // -sentStartWord / -sentEndWord (DecVocabulary)
+    int residentSlots = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto nxt = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -145,6 +146,8 @@ int main(int argc, char **argv)
         else if (a == "-batch") batch = atoi(nxt()); else if (a == "-perFrameAdapter") useAdapter = 1;
         else if (a == "-devices") nDevices = atoi(nxt());
         else if (a == "-threads") nThreads = atoi(nxt());
+        else if (a == "-residentSlots") residentSlots = atoi(nxt());              // jd_dec_set_pipeline(JD_FLOW_RESIDENT): the list through -batch
+                                                                                  // one-workgroup slots of a search kernel that stays
         else if (a == "-outputFormat") outputFormat = nxt();
         else if (a == "-writeBinaryFiles") writeBinaryFiles = 1;
         else if (a == "-refFName") refFName = nxt(); else if (a == "-removeSentMarks") removeSentMarks = 1;
@@ -159,6 +162,8 @@ int main(int argc, char **argv)
                         "       [-sentStartWord W] [-sentEndWord W] [-outSymsFName SYMS] [-outputFName stdout|stderr|FILE]\n"
                         "       [-device d | -devices N   (N GPUs of this node: utterances sharded, one RCCL gather of the 1-best)]\n"
                         "       [-threads N   (N serial harness threads - the reference's loop each - through one decoder: the broker)]\n"
+                        "       [-residentSlots N   (a list longer than N goes through N one-workgroup slots of a search kernel that stays: a slot takes the\n"
+                        "        next utterance the moment its own is through - jd_dec_set_pipeline, JD_FLOW_RESIDENT; -batch is then at least N)]\n"
                         "       [-gramFsmFName G [-gramInSymsFName S] [-gramOutSymsFName S] [-pushing | -weightPushing] [-lazy]   (-fsmFName is then C.L: composed with G on the\n"
                         "        device, as a whole before the search or - with -lazy - by the search, where it goes)]\n");
         return 2;
@@ -478,7 +483,9 @@ int main(int argc, char **argv)
         jd_multi_destroy(mg);
     } else {
         jd_dec *dec = 0;
+        if (residentSlots > batch) batch = residentSlots;
         if (jd_dec_create(&dec, net, am, startBeam, mainBeam, endBeam, wordBeam, maxHyps, 5, device, batch)) die("jd_dec_create");
+        if (residentSlots > 0 && jd_dec_set_pipeline(dec, JD_FLOW_RESIDENT, 2, residentSlots)) die("jd_dec_set_pipeline");
         std::vector<const float *> ptr(files.size());
         for (size_t u = 0; u < files.size(); ++u) ptr[u] = feats[u].data();
         std::vector<jd_hyp> hyps(files.size());

@@ -421,15 +421,15 @@ extern "C" int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients)
     jd_broker *b = new jd_broker();
     b->dec = dec; b->D = D; b->n_clients = n_clients;
     b->clients.resize((size_t)n_clients);
-    if (const char *e = getenv("JD_BROKER_TICK_FRAMES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) b->max_tick_frames = v; }
-    if (const char *e = getenv("JD_BROKER_COALESCE_US")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) b->coalesce_us = v; }
+    if (const char *e = jd_dev_env("JD_BROKER_TICK_FRAMES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) b->max_tick_frames = v; }
+    if (const char *e = jd_dev_env("JD_BROKER_COALESCE_US")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) b->coalesce_us = v; }
     b->max_pending_frames = 4 * b->max_tick_frames;
     // the resident search kernel instead of ticks (JD_BROKER_RESIDENT=0: ticks): not with a lazily composed network or
     // partial traces - jd_res_start says so and the clients' first calls would fail, so those decoders keep the ticks
     // (up to 64 clients: the ready list of a scoring launch and the chip's room for clusters and their scoring side by side)
     b->resident = n_clients <= 64;
-    if (const char *e = getenv("JD_BROKER_RESIDENT")) b->resident = atoi(e) != 0;
-    if (b->resident && !getenv("JD_BROKER_TICK_FRAMES")) {            // (whole scoring tiles)
+    if (const char *e = jd_dev_env("JD_BROKER_RESIDENT")) b->resident = atoi(e) != 0;
+    if (b->resident && !jd_dev_env("JD_BROKER_TICK_FRAMES")) {            // (whole scoring tiles)
         b->max_tick_frames = 256;
         b->max_pending_frames = 4 * b->max_tick_frames;
     }

@@ -457,7 +457,13 @@ struct jd_dec {
     struct Pipe *pipe = nullptr;           // batches through the resident kernel, utterance by utterance (jd_pipe_*; JD_PIPELINE=3)
     bool pipe_mode = false;
     bool pipe_on = false;                  // Pipe::on (for the code in front of the struct)
-    int pipe_depth = 8;                    // likelihood tables = batches announced and not handed back, at most (JD_PIPE_DEPTH)
+    int pipe_depth = 8;                    // likelihood tables = batches announced and not handed back, at most (jd_dec_set_pipeline)
+    int pipe_slots = 0;                    // one-workgroup slots of the resident kernel (0: max_streams)
+    // jd_dec_pipeline_stats: cumulative over the decoder's life
+    long long pipe_frames_searched = 0;    // stream-frames the slots have advanced, as reported command by command
+    long long pipe_utts_through = 0, pipe_rows_scored = 0, pipe_batches_back = 0, pipe_collections = 0;
+    long long pipe_busy_ticks = 0;         // the slots' own clocks on their commands (100 MHz)
+    double pipe_on_us = 0.0;               // wall time the resident kernel has been on the device for the pipeline
     const float *res_ll = nullptr;         // the likelihood slab the resident kernel reads (null: the broker's stream buffers)
     // results
     std::vector<HostResult> results;
@@ -548,7 +554,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     jd_dec *d = new jd_dec();
     d->net = net; d->am = am; d->device = device; d->max_streams = max_streams; d->block_size = block_size;
     // development: frames per chunk of a batch
-    if (const char *e = getenv("JD_FC")) { const int v = atoi(e); if (v >= 16 && v <= 65536) d->Fw_env = v; }
+    if (const char *e = jd_dev_env("JD_FC")) { const int v = atoi(e); if (v >= 16 && v <= 65536) d->Fw_env = v; }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->n_cus = prop.multiProcessorCount;
@@ -557,9 +563,9 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     C.start_win = start_beam; C.emit_win = main_beam; C.end_win = end_beam; C.word_win = word_beam;
     C.max_hyps = max_hyps;
     C.x_chunks = 2;
-    if (const char *e = getenv("JD_XCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) { C.x_chunks = v; d->xch_forced = true; } }   // development
+    if (const char *e = jd_dev_env("JD_XCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) { C.x_chunks = v; d->xch_forced = true; } }   // development
     C.exp = 0; C.path_rule = 0; C.pcount = nullptr;
-    if (const char *e = getenv("JD_EXP")) C.exp = atoi(e);                                                    // development
+    if (const char *e = jd_dev_env("JD_EXP")) C.exp = atoi(e);                                                    // development
     C.hist_min = 0; C.hist_max = 0; C.hist_nbins = 0;
     if (max_hyps > 0) {                          // WFSTDecoderLite.cpp:76-82, Histogram.cpp:29-37
         float mn = (main_beam > 0.0) ? (float)(-main_beam - 800.0) : -1000.0f;
@@ -637,7 +643,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         }
         for (int h = 0; h < am->n_hmm && all_lr; ++h)
             if (am->hmm_n[(size_t)h] != am->tm_n[(size_t)am->hmm_tm[(size_t)h]]) all_lr = false;
-        if (getenv("JD_NO_LR")) all_lr = false;                                  // development: force the general path
+        if (jd_dev_env("JD_NO_LR")) all_lr = false;                                  // development: force the general path
         C.lrt = nullptr;
         if (all_lr) {
             std::vector<float> lrt((size_t)am->n_tm * LRW, LZ);
@@ -651,32 +657,32 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
             C.lrt = d->d_lrt;
         }
     }
-    if (const char *e = getenv("JD_CW")) { const int v = atoi(e); if (v >= 1 && v <= MAXCW) d->max_cw = v; }   // development
-    if (const char *e = getenv("JD_WEIGHTED")) d->weighted = atoi(e) != 0;
-    if (const char *e = getenv("JD_REBALANCE")) d->rebalance = atoi(e) != 0;
-    if (const char *e = getenv("JD_REBALANCE_FRAC")) { const double v = atof(e); if (v > 0.0 && v < 1.0) d->rebalance_frac = v; }
-    if (const char *e = getenv("JD_REBALANCE_MIN_US")) d->rebalance_min_us = atof(e);
-    if (const char *e = getenv("JD_MODEL_A")) d->model_a_us = atof(e);
-    if (const char *e = getenv("JD_MODEL_B")) d->model_b_us = atof(e);
-    if (const char *e = getenv("JD_PLAN")) d->plan_mode = atoi(e) != 0;
-    if (const char *e = getenv("JD_PLAN_MIN_CW")) d->plan_min_cw = std::max(1, atoi(e));
-    if (const char *e = getenv("JD_PF_GMM_WEIGHT")) d->pf_gmm_weight = atof(e);
-    if (const char *e = getenv("JD_MODEL2_A")) d->model2_a_us = atof(e);
-    if (const char *e = getenv("JD_MODEL2_B")) d->model2_b_us = atof(e);
-    if (const char *e = getenv("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0;                      // development
-    if (const char *e = getenv("JD_XL_SLACK")) { const double v = atof(e); if (v >= 1.0 && v <= 10.0) d->xl_slack = v; }
+    if (const char *e = jd_dev_env("JD_CW")) { const int v = atoi(e); if (v >= 1 && v <= MAXCW) d->max_cw = v; }   // development
+    if (const char *e = jd_dev_env("JD_WEIGHTED")) d->weighted = atoi(e) != 0;
+    if (const char *e = jd_dev_env("JD_REBALANCE")) d->rebalance = atoi(e) != 0;
+    if (const char *e = jd_dev_env("JD_REBALANCE_FRAC")) { const double v = atof(e); if (v > 0.0 && v < 1.0) d->rebalance_frac = v; }
+    if (const char *e = jd_dev_env("JD_REBALANCE_MIN_US")) d->rebalance_min_us = atof(e);
+    if (const char *e = jd_dev_env("JD_MODEL_A")) d->model_a_us = atof(e);
+    if (const char *e = jd_dev_env("JD_MODEL_B")) d->model_b_us = atof(e);
+    if (const char *e = jd_dev_env("JD_PLAN")) d->plan_mode = atoi(e) != 0;
+    if (const char *e = jd_dev_env("JD_PLAN_MIN_CW")) d->plan_min_cw = std::max(1, atoi(e));
+    if (const char *e = jd_dev_env("JD_PF_GMM_WEIGHT")) d->pf_gmm_weight = atof(e);
+    if (const char *e = jd_dev_env("JD_MODEL2_A")) d->model2_a_us = atof(e);
+    if (const char *e = jd_dev_env("JD_MODEL2_B")) d->model2_b_us = atof(e);
+    if (const char *e = jd_dev_env("JD_XCD_LOCAL")) d->xl_ok = atoi(e) != 0;                      // development
+    if (const char *e = jd_dev_env("JD_XL_SLACK")) { const double v = atof(e); if (v >= 1.0 && v <= 10.0) d->xl_slack = v; }
     // arena capacities: 0 = sized from the free HBM when the arenas are allocated (ensure_arenas)
     d->cap_slots = d->cap_items = d->cap_paths = d->cap_new = 0;
-    if (const char *e = getenv("JD_PF_REBALANCE")) d->pf_rebalance = atoi(e) != 0;                // development
-    if (const char *e = getenv("JD_PIPELINE")) { d->pipeline = atoi(e) != 0; d->pipe_mode = atoi(e) == 3; }
-    if (const char *e = getenv("JD_PIPE_DEPTH")) { const int v = atoi(e); if (v >= 2 && v <= 32) d->pipe_depth = v; }
-    if (const char *e = getenv("JD_BG_WAIT_US")) d->bg_wait_us = atof(e);
-    if (const char *e = getenv("JD_SCORE_RESERVE")) d->score_reserve = atoi(e);
-    if (const char *e = getenv("JD_BG_REBALANCE")) d->bg_rebalance = atoi(e) != 0;
-    if (const char *e = getenv("JD_BG_WEIGHT")) d->bg_weight = atof(e);
-    if (const char *e = getenv("JD_BG_MAX_LOAD")) d->bg_max_load = atof(e);
-    if (const char *e = getenv("JD_FG_CW")) d->fg_cw_cap = std::max(1, atoi(e));
-    if (const char *e = getenv("JD_BG_CW")) d->bg_cw_cap = std::max(1, atoi(e));
+    if (const char *e = jd_dev_env("JD_PF_REBALANCE")) d->pf_rebalance = atoi(e) != 0;                // development
+    if (const char *e = jd_dev_env("JD_PIPELINE")) { d->pipeline = atoi(e) != 0; d->pipe_mode = atoi(e) == 3; }
+    if (const char *e = jd_dev_env("JD_PIPE_DEPTH")) { const int v = atoi(e); if (v >= 2 && v <= 32) d->pipe_depth = v; }
+    if (const char *e = jd_dev_env("JD_BG_WAIT_US")) d->bg_wait_us = atof(e);
+    if (const char *e = jd_dev_env("JD_SCORE_RESERVE")) d->score_reserve = atoi(e);
+    if (const char *e = jd_dev_env("JD_BG_REBALANCE")) d->bg_rebalance = atoi(e) != 0;
+    if (const char *e = jd_dev_env("JD_BG_WEIGHT")) d->bg_weight = atof(e);
+    if (const char *e = jd_dev_env("JD_BG_MAX_LOAD")) d->bg_max_load = atof(e);
+    if (const char *e = jd_dev_env("JD_FG_CW")) d->fg_cw_cap = std::max(1, atoi(e));
+    if (const char *e = jd_dev_env("JD_BG_CW")) d->bg_cw_cap = std::max(1, atoi(e));
     hipError_t e;
     // the search stream has the highest priority, the scoring stream the lowest: when a table is scored while a search
     // runs (jd_dec_prefetch_scores) a search launch that needs CUs gets them before further scoring blocks do
@@ -1379,7 +1385,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
     HIPCHK(hipMemcpyAsync(d->d_work, work.data(), work.size() * sizeof(int4), hipMemcpyHostToDevice, st));
     A.ll = ll; A.ll_stride = ll_stride; A.f0 = f0; A.f_end = f_end;
     A.status = d->d_status; A.dbg = d->d_dbg; A.rebalance_at = rebalance_at;
-    A.xl_selftest = getenv("JD_XL_SELFTEST") ? 1 : 0;                 // (test knob, see SearchArgs)
+    A.xl_selftest = jd_dev_env("JD_XL_SELFTEST") ? 1 : 0;                 // (test knob, see SearchArgs)
     A.resident = d->d_resident; A.launch_seq = ++d->launch_seq;
         struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev0, ev1;
         HIPCHK(hipEventCreate(&ev0.e)); HIPCHK(hipEventCreate(&ev1.e));
@@ -1974,7 +1980,7 @@ extern "C" int jd_decode_batch_device(jd_dec *d, int32_t n_utts, const float *d_
         if (rc || handled) return rc;
         // ... or more utterances than streams, nothing announced: through the pipeline's slots as well - a stream takes the next
         // utterance the moment its own is through, where the waves below end with their longest one
-        if (d->pipe_mode && n_utts > d->max_streams && !d->pipe_on) {
+        if (d->pipe_mode && n_utts > (d->pipe_slots > 0 ? d->pipe_slots : d->max_streams) && !d->pipe_on) {
             HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));     // the features are there
             int taken = 0;
             rc = pipe_announce(d, n_utts, d_feats, offs, &taken);
@@ -2381,6 +2387,7 @@ struct Resident {
     long long n_collect = 0;                           // (statistics) Path collections between commands
     std::unique_lock<std::mutex> search_lock;
     GpuLockGuard *process_lock = nullptr;
+    std::chrono::steady_clock::time_point t_start;     // when the kernel was last started (jd_dec_pipeline_stats: time on the device)
 };
 
 static void res_free(jd_dec *d);
@@ -2409,6 +2416,10 @@ static bool res_harvest(jd_dec *d, int s)
     Resident *R = d->res;
     if (!R->busy[(size_t)s]) return true;
     if (__atomic_load_n(&R->h_done[s].seq, __ATOMIC_ACQUIRE) != R->seq[(size_t)s]) return false;
+    if (d->pipe_on) {                                                  // (jd_dec_pipeline_stats: frames the slot has advanced)
+        d->pipe_frames_searched += std::max(0, R->h_done[s].frame - R->T_done[(size_t)s]);
+        d->pipe_busy_ticks += R->h_done[s].run_ticks;
+    }
     R->T_done[(size_t)s] = R->h_done[s].frame; R->err_done[(size_t)s] = R->h_done[s].error;
     R->run_ticks += R->h_done[s].run_ticks;
     R->init_pending[(size_t)s] = 0;
@@ -2435,6 +2446,7 @@ int jd_res_stop(jd_dec *d)
             if (!__atomic_load_n(&R->h_done[s].left, __ATOMIC_ACQUIRE)) { lost = true; d->stream_dirty[(size_t)s] = 1; }
         }
     R->on = false;
+    if (d->pipe_on) d->pipe_on_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - R->t_start).count();
     delete R->process_lock; R->process_lock = nullptr;
     if (R->search_lock.owns_lock()) R->search_lock.unlock();
     if (e != hipSuccess) return jd_fail(JD_EHIP, "the resident search kernel did not end: %s", hipGetErrorString(e));
@@ -2497,7 +2509,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     // (the scoring of what the streams search: about 1.6 CUs per stream at their pace, and a quarter of the chip at least -
     // sixteen C++ callers: 407 k frames/s with 24 CUs left, 433 k with 40, 469 k with 64, 462 k with 96)
     int free_cus = std::min(d->n_cus / 2, std::max(d->n_cus / 4, (n_streams * 8) / 5));
-    if (const char *e = getenv("JD_RES_FREE_CUS")) { const int v = atoi(e); if (v >= 0 && v < d->n_cus) free_cus = v; }   // development
+    if (const char *e = jd_dev_env("JD_RES_FREE_CUS")) { const int v = atoi(e); if (v >= 0 && v < d->n_cus) free_cus = v; }   // development
     R->Cw = std::max(1, std::min(std::min(d->max_cw, cw_cap), (d->n_cus * WG_PER_CU - free_cus) / n_streams));
     if (R->Cw * n_streams > d->n_cus * WG_PER_CU) return jd_fail(JD_EINVAL, "jd_res_start: %d streams do not fit the device", n_streams);
     memset(R->h_done, 0, (size_t)R->n * sizeof(ResDone));
@@ -2529,7 +2541,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     const dim3 rgrid((unsigned)(R->n * R->Cw));
     // (one workgroup per stream: the XCD-local flavour of the memory operations - a cluster of one sits on one XCD)
     bool xl = R->Cw == 1;
-    if (const char *e = getenv("JD_RES_XL")) xl = xl && atoi(e) != 0;   // development
+    if (const char *e = jd_dev_env("JD_RES_XL")) xl = xl && atoi(e) != 0;   // development
     typedef void (*ResKernel)(SearchArgs, const ResPost *, ResMail *, const unsigned *, ResDone *, int);
     const ResKernel rk = ne3 ? (xl ? k_resident<3, true> : k_resident<3, false>) : (xl ? k_resident<6, true> : k_resident<6, false>);
     // HIP maps streams onto a few hardware queues, and whatever is queued BEHIND a kernel that stays waits until it leaves:
@@ -2577,6 +2589,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
         return jd_fail(JD_EHIP, "k_resident: no search stream whose hardware queue the side stream and the null stream do not share");
     }
     R->on = true;
+    R->t_start = std::chrono::steady_clock::now();
     if (getenv("JD_VERBOSE")) fprintf(stderr, "k_resident: %d streams, clusters of %d workgroups, %d rows per buffer\n", R->n, R->Cw, R->rows);
     return JD_OK;
 }
@@ -2718,6 +2731,7 @@ int jd_res_collect(jd_dec *d, int s)
     R->seq[(size_t)s] += 1;
     R->busy[(size_t)s] = 1;
     R->n_collect += 1;
+    if (d->pipe_on) d->pipe_collections += 1;
     const int rc = res_bump(d, 1, &s);                                 // (the command waits for the collection)
     if (rc) return rc;
     res_write_post(R, s, R->T_posted[(size_t)s], R->slot_posted[(size_t)s], R->init_pending[(size_t)s]);
@@ -2860,7 +2874,7 @@ static int pipe_pump(jd_dec *d)
         }
         EL.slot[EL.n] = s; EL.vslot[EL.n] = B.table * P->max_batch + ui; EL.n += 1;
         if (EL.n == 64) { const int rc = flush_exports(); if (rc) return rc; }
-        B.u[(size_t)ui].state = 2; B.n_done += 1; P->frames_done += fr;
+        B.u[(size_t)ui].state = 2; B.n_done += 1; P->frames_done += fr; d->pipe_utts_through += 1;
         if (er) P->slot_dirty[(size_t)s] = 1;                          // (its arenas may be inconsistent: out of the game until the pipeline stops)
         P->slot_batch_id[(size_t)s] = -1;
     }
@@ -2879,7 +2893,7 @@ static int pipe_pump(jd_dec *d)
                             P->d_ll + base * (size_t)d->am->n_gmm, d->s_gmm);
             if (rc) return rc;
             HIPCHK(hipEventRecord(P->ev_piece, d->s_gmm));
-            B.rows_scored += n; P->piece_out = true;
+            B.rows_scored += n; P->piece_out = true; d->pipe_rows_scored += (long long)n;
             break;
         }
     // refill (from batches whose scoring is enqueued to the last row: a slot's ready number is counted up behind it)
@@ -2926,6 +2940,50 @@ extern "C" int jd_dec_quiesce(jd_dec *d)
     return JD_OK;
 }
 
+// How batches that follow each other share the chip (include/juicer_amd.h).  Whatever is announced or under way under the old
+// setting is dropped: results never depend on announcements, the batches concerned are decoded from scratch when their turn comes.
+extern "C" int jd_dec_set_pipeline(jd_dec *d, int32_t mode, int32_t depth, int32_t slots)
+{
+    if (!d) return jd_fail(JD_EINVAL, "jd_dec_set_pipeline: null");
+    if (mode != JD_FLOW_SERIAL && mode != JD_FLOW_TWO_IN_FLIGHT && mode != JD_FLOW_RESIDENT)
+        return jd_fail(JD_EINVAL, "jd_dec_set_pipeline: mode %d (JD_FLOW_SERIAL, JD_FLOW_TWO_IN_FLIGHT or JD_FLOW_RESIDENT)", mode);
+    if (mode == JD_FLOW_RESIDENT) {
+        if (depth == 0) depth = 8;
+        if (slots == 0) slots = d->max_streams;
+        if (depth < 2 || depth > 32) return jd_fail(JD_EINVAL, "jd_dec_set_pipeline: depth %d (2..32 batches announced and not handed back)", depth);
+        if (slots < 1 || slots > d->max_streams) return jd_fail(JD_EINVAL, "jd_dec_set_pipeline: %d slots, the decoder has %d streams", slots, d->max_streams);
+        if (d->net->lazy_dev || d->am->hybrid)
+            return jd_fail(JD_ESTATE, "jd_dec_set_pipeline: JD_FLOW_RESIDENT not with a lazily composed network / hybrid scoring");
+    }
+    if (d->res && d->res->on && !d->pipe_on) return jd_fail(JD_ESTATE, "jd_dec_set_pipeline: a broker drives this decoder's resident kernel");
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    pipe_drain(d);
+    pipe_free(d);
+    pf_discard(d);
+    d->pipeline = mode != JD_FLOW_SERIAL;
+    d->pipe_mode = mode == JD_FLOW_RESIDENT;
+    if (d->pipe_mode) { d->pipe_depth = depth; d->pipe_slots = slots; }
+    return JD_OK;
+}
+
+extern "C" int jd_dec_pipeline_stats(const jd_dec *d, jd_pipe_stats *out)
+{
+    if (!d || !out) return jd_fail(JD_EINVAL, "jd_dec_pipeline_stats: null");
+    memset(out, 0, sizeof *out);
+    out->mode = d->pipe_mode ? JD_FLOW_RESIDENT : (d->pipeline ? JD_FLOW_TWO_IN_FLIGHT : JD_FLOW_SERIAL);
+    out->depth = d->pipe_mode ? d->pipe_depth : 0;
+    out->slots = d->pipe_mode ? (d->pipe ? d->pipe->n_slots : (d->pipe_slots > 0 ? d->pipe_slots : d->max_streams)) : 0;
+    out->resident = (d->pipe_on && d->res && d->res->on) ? 1 : 0;
+    out->batches_announced = d->pipe ? (int32_t)d->pipe->q.size() : 0;
+    out->frames_searched = d->pipe_frames_searched; out->utts_through = d->pipe_utts_through; out->rows_scored = d->pipe_rows_scored;
+    out->batches_back = d->pipe_batches_back; out->collections = d->pipe_collections;
+    out->slot_busy_us = (double)d->pipe_busy_ticks / 100.0;
+    out->on_us = d->pipe_on_us;
+    if (out->resident) out->on_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - d->res->t_start).count();
+    return JD_OK;
+}
+
 // jd_dec_prefetch_scores in pipe mode: 1 = taken, 0 = not this way (the caller goes on with the usual announcement)
 static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int64_t *offs, int *taken)
 {
@@ -2948,9 +3006,10 @@ static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int6
         P = new Pipe();
         d->pipe = P;
         // (tables and result slots for batches up to twice this one: a larger one later starts the pipeline again, with larger ones)
-        P->K = d->pipe_depth; P->max_batch = 2 * n_utts; P->n_slots = d->max_streams;
-        if (const char *e = getenv("JD_PIPE_CHUNK")) { const int v = atoi(e); if (v >= 16) P->chunk = v; }   // development
-        if (const char *e = getenv("JD_PIPE_PIECE")) { const int v = atoi(e); if (v >= 128) P->piece_rows = (size_t)v / GMM_ROWS2 * GMM_ROWS2; }
+        P->K = d->pipe_depth; P->max_batch = 2 * n_utts;
+        P->n_slots = (d->pipe_slots > 0 && d->pipe_slots <= d->max_streams) ? d->pipe_slots : d->max_streams;
+        if (const char *e = jd_dev_env("JD_PIPE_CHUNK")) { const int v = atoi(e); if (v >= 16) P->chunk = v; }   // development
+        if (const char *e = jd_dev_env("JD_PIPE_PIECE")) { const int v = atoi(e); if (v >= 128) P->piece_rows = (size_t)v / GMM_ROWS2 * GMM_ROWS2; }
         if (hipEventCreateWithFlags(&P->ev_piece, hipEventDisableTiming) != hipSuccess) { pipe_free(d); return jd_fail(JD_EHIP, "hipEventCreate failed"); }
         P->table_rows = ((2 * rows + 1024) + GMM_ROWS2 - 1) / GMM_ROWS2 * GMM_ROWS2;
         const size_t V = (size_t)P->K * P->max_batch;
@@ -3051,6 +3110,7 @@ static int pipe_decode(jd_dec *d, int n_utts, const float *d_feats, const int64_
     d->load_sum = d->load_frames = 0.0;
     P->table_used[(size_t)F.table] = 0;
     P->q.pop_front();
+    d->pipe_batches_back += 1;
     P->serial0 += 1;
     if (P->q.empty()) pipe_drain(d);                                   // nothing announced behind it: the kernel leaves the device
     *handled = 1;

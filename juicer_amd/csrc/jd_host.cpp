@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -30,6 +31,13 @@ int jd_fail(int code, const char *fmt, ...)
     vsnprintf(g_jd_err, sizeof g_jd_err, fmt, ap);
     va_end(ap);
     return code;
+}
+
+const char *jd_dev_env(const char *name)
+{
+    const char *on = getenv("JD_DEV");
+    if (!on || on[0] == '\0' || (on[0] == '0' && on[1] == '\0')) return nullptr;
+    return getenv(name);
 }
 
 extern "C" const char *jd_last_error(void) { return g_jd_err; }

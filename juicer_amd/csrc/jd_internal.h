@@ -69,6 +69,13 @@ struct jd_am {
 
 int jd_fail(int code, const char *fmt, ...);      // sets jd_last_error(), returns code
 
+// Development knobs (planner constants, forced code paths for the toy-size tests, experiments) are read from the
+// environment only when JD_DEV=1 is exported with them: nothing a caller NEEDS is selected by an environment variable -
+// the header is the interface (jd_dec_set_pipeline, jd_dec_set_capacity, ...).  What stays readable without the gate is
+// operational: JD_VERBOSE (diagnostics on stderr), JD_GPU_LOCK / JD_GPU_LOCK_DIR (the per-GPU file lock between
+// processes), JD_ARENA_CACHE (keep a destroyed decoder's arena slab for the next one).
+const char *jd_dev_env(const char *name);
+
 // The resident search kernel of a broker (jd_device.hip, jd_resident.h) - internal: jd_broker.cpp drives it.
 int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf);
 int jd_res_stop(jd_dec *d);

@@ -97,6 +97,51 @@ class GatheredHyps(Sequence):
         return _unpack_one(self._i, self._f, self._mw, int(self._rows[k]))
 
 
+def _padded_records(hyps, per_rank, max_words, index):
+    """One step's records of this rank: exactly per_rank of them (short shards are padded with n = -2 records)."""
+    ints, flts = pack_hyps(hyps, max_words, truncate=True)
+    if index is not None:                               # (the index rides in a column of its own, behind the record)
+        ints = np.concatenate([ints, np.asarray(index, np.int32).reshape(-1, 1)], axis=1)
+    if ints.shape[0] < per_rank:
+        pad = per_rank - ints.shape[0]
+        ints = np.concatenate([ints, np.full((pad, ints.shape[1]), 0, np.int32)])
+        ints[-pad:, 0] = -2
+        flts = np.concatenate([flts, np.zeros((pad, flts.shape[1]), np.float32)])
+    return ints, flts
+
+
+def _all_gather_records(ints, flts, device):
+    """ONE all_gather of this rank's records (int words, the float words riding behind them); rank after rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return ints, flts
+    world = dist.get_world_size()
+    ti = torch.from_numpy(ints)
+    tf = torch.from_numpy(flts).view(torch.int32)
+    t = torch.cat([ti, tf], dim=1).contiguous()
+    if device is not None:
+        t = t.to(device)
+    lt = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(lt, t)                                     # RCCL over xGMI on GPUs
+    g = torch.cat(lt).cpu()
+    gi = g[:, :ints.shape[1]].numpy()
+    gf = g[:, ints.shape[1]:].contiguous().view(torch.float32).numpy()
+    return gi, gf
+
+
+def _ordered_rows(gi, rows, indexed):
+    rows = rows[gi[rows, 0] != -2]
+    if indexed:                                         # global utterance order: record of utterance u at rows[u]
+        u = gi[rows, -1].astype(np.int64)
+        if not np.array_equal(np.sort(u), np.arange(u.shape[0])):
+            raise ValueError("gathered records do not cover utterances 0..%d" % (u.shape[0] - 1))
+        ordered = np.empty_like(rows)
+        ordered[u] = rows
+        rows = ordered
+    return rows
+
+
 def gather_hyps(hyps: Sequence, per_rank: int, max_words: int = 256, device=None, index: Sequence[int] = None) -> "GatheredHyps":
     """all_gather the 1-best records of every rank - the ONE collective of a step.  Every rank contributes
     exactly `per_rank` records (pad with n=-2 records when a shard is short).  A record holds max_words
@@ -105,43 +150,32 @@ def gather_hyps(hyps: Sequence, per_rank: int, max_words: int = 256, device=None
     refused; an ordinary step is one collective).  index: the global utterance index of each of this rank's
     hypotheses (shard_lpt) - the result is then in global utterance order; without it the result is rank
     after rank (= global order for contiguous shards)."""
-    import torch
-    import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return gather_hyps_steps([(hyps, index)], per_rank, max_words, device)[0]
+
+
+def gather_hyps_steps(steps: Sequence, per_rank: int, max_words: int = 256, device=None) -> List["GatheredHyps"]:
+    """The 1-best records of SEVERAL steps in ONE all_gather (fewer, larger collectives): steps = [(hyps, index or
+    None), ...], every rank with the same number of steps and `per_rank` records per step.  What a rank needs of a
+    step right away it has - its own hypotheses; what the others need of it travels when the caller says so: once
+    per timed region in bench.py, behind jd_dec_quiesce, because a collective's kernels must not be queued on a
+    device whose search kernel STAYS (HIP maps streams onto a few hardware queues).  Returns one
+    GatheredHyps per step, as gather_hyps would have."""
     max_words = max(1, int(max_words))
+    S = len(steps)
+    if S == 0:
+        return []
+    indexed = steps[0][1] is not None
     for attempt in range(2):
-        ints, flts = pack_hyps(hyps, max_words, truncate=True)
-        if index is not None:                           # (the index rides in a column of its own, behind the record)
-            ints = np.concatenate([ints, np.asarray(index, np.int32).reshape(-1, 1)], axis=1)
-        if ints.shape[0] < per_rank:
-            pad = per_rank - ints.shape[0]
-            ints = np.concatenate([ints, np.full((pad, ints.shape[1]), 0, np.int32)])
-            ints[-pad:, 0] = -2
-            flts = np.concatenate([flts, np.zeros((pad, flts.shape[1]), np.float32)])
-        if multi:
-            world = dist.get_world_size()
-            ti = torch.from_numpy(ints)
-            tf = torch.from_numpy(flts).view(torch.int32)          # one collective: the float words ride behind the int words
-            t = torch.cat([ti, tf], dim=1).contiguous()
-            if device is not None:
-                t = t.to(device)
-            lt = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(lt, t)                                 # RCCL over xGMI on GPUs
-            g = torch.cat(lt).cpu()
-            gi = g[:, :ints.shape[1]].numpy()
-            gf = g[:, ints.shape[1]:].contiguous().view(torch.float32).numpy()
-        else:
-            gi, gf = ints, flts
+        packed = [_padded_records(h, per_rank, max_words, ix) for h, ix in steps]
+        ints = np.concatenate([p[0] for p in packed]); flts = np.concatenate([p[1] for p in packed])
+        gi, gf = _all_gather_records(ints, flts, device)
         longest = int(gi[:, 0].max()) if gi.shape[0] else 0
         if longest <= max_words:
             break
         max_words = longest                                        # (the same decision on every rank: all see the same records)
-    rows = np.nonzero(gi[:, 0] != -2)[0]
-    if index is not None:                               # global utterance order: record of utterance u at rows[u]
-        u = gi[rows, -1].astype(np.int64)
-        if not np.array_equal(np.sort(u), np.arange(u.shape[0])):
-            raise ValueError("gathered records do not cover utterances 0..%d" % (u.shape[0] - 1))
-        ordered = np.empty_like(rows)
-        ordered[u] = rows
-        rows = ordered
-    return GatheredHyps(gi, gf, max_words, rows)
+    world = gi.shape[0] // max(1, S * per_rank)
+    out = []
+    for k in range(S):                                             # step k: rank after rank, per_rank records each
+        rows = np.concatenate([np.arange(per_rank, dtype=np.int64) + (r * S + k) * per_rank for r in range(max(1, world))])
+        out.append(GatheredHyps(gi, gf, max_words, _ordered_rows(gi, rows, indexed)))
+    return out

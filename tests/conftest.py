@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The GPU tests force code paths at toy sizes (cluster sizes, re-planning marks, the XCD placement self-test, the broker's
+# tick mode) with DEVELOPMENT knobs, which the library reads only behind JD_DEV=1 (csrc/jd_internal.h: jd_dev_env).  What a
+# caller needs - the batch pipeline, capacities, partial traces - goes through the C ABI in these tests, as in bench.py.
+os.environ.setdefault("JD_DEV", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -4,7 +4,7 @@ size-independent properties on the batch."""
 import numpy as np
 import pytest
 
-from helpers import LE_KEYS, STAT_KEYS, assert_hyp_matches, bit_exact
+from helpers import LE_KEYS, STAT_KEYS, assert_hyp_matches, bit_exact, oracle_certified_many
 
 pytestmark = pytest.mark.gpu
 
@@ -40,9 +40,9 @@ def test_fullsize_oracle_parity(c2):
 
 def test_fullsize_64_stream_batch_oracle_parity(built):
     """BASELINE.json configs[1] in the shape the headline is quoted on - ONE batch of 64 utterances on 64 streams,
-    mainBeam 150, the next batch's table announced and scored beside the search - with utterances spread over the batch
-    (the longest and the shortest among them) checked against the certified oracle: words, times, the reference's
-    statistics, scores bit for bit."""
+    mainBeam 150, the next batch's table announced and scored beside the search - ALL 64 utterances checked against the
+    certified oracle: words, times, the reference's statistics, scores bit for bit; then the same batches through the
+    resident pipeline (the headline's own path), every result of every step against the oracle again."""
     import torch
     from juicer_amd import capi, synth
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
@@ -60,28 +60,23 @@ def test_fullsize_64_stream_batch_oracle_parity(built):
     gd.prefetch_scores(d_feats.data_ptr(), offs, 0)
     gs = gd.decode_batch_device(d_feats.data_ptr(), offs, 0)           # a step as bench.py times it
     assert gd.last_timing()["prefetched"] == 1
-    lens = [f.shape[0] for f in feats]
-    pick = sorted({int(np.argmax(lens)), int(np.argmin(lens)), 0, 21, 42, 63})
-    od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
-    exact = 0
-    for u in pick:
-        o = od.decode_certified(feats[u])
-        assert_hyp_matches(gs[u], o, "c2 batch of 64, utt %d" % u)
-        exact += bit_exact(gs[u], o)
-    assert len(pick) >= 4 and exact == len(pick)
+    # EVERY utterance of the batch against the certified oracle (all host cores: ~35 CPU-seconds at beam 150)
+    want = oracle_certified_many(net, am, feats, **kw)
+    for u in range(64):
+        assert_hyp_matches(gs[u], want[u], "c2 batch of 64, utt %d" % u)
+        assert bit_exact(gs[u], want[u]), u
     assert all(h.n > 0 for h in gs)
     gd.close()
-    # ... and the same batches the way bench.py runs them at N = 1: through the resident kernel's 160 one-workgroup slots,
-    # announcements six batches ahead (JD_PIPELINE=3) - every utterance of every batch bit for bit what the launch above found
-    import os
-    os.environ["JD_PIPELINE"] = "3"; os.environ["JD_PIPE_DEPTH"] = "7"
-    try:
-        gp = capi.Decoder(gnet, gam, max_streams=160, **kw)
-    finally:
-        os.environ.pop("JD_PIPELINE", None); os.environ.pop("JD_PIPE_DEPTH", None)
+    # ... and the same batches the way bench.py runs them: through the resident kernel's 160 one-workgroup slots,
+    # announcements six batches ahead (jd_dec_set_pipeline: JD_FLOW_RESIDENT, seven deep) - every utterance of every
+    # batch DIRECTLY against the oracle (words, times, the reference's statistics, scores bit for bit), not against the launch above
+    gp = capi.Decoder(gnet, gam, max_streams=160, **kw)
+    gp.set_pipeline(capi.FLOW_RESIDENT, 7, 160)
+    f0 = gp.pipeline_stats()["frames_searched"]
     for _ in range(6):
         gp.prefetch_scores(d_feats.data_ptr(), offs, 0)
-    for step in range(9):
+    n_steps = 9
+    for step in range(n_steps):
         if step < 3:
             gp.prefetch_scores(d_feats.data_ptr(), offs, 0)
         if step == 4:
@@ -89,7 +84,11 @@ def test_fullsize_64_stream_batch_oracle_parity(built):
             torch.cuda.synchronize()
         got = gp.decode_batch_device(d_feats.data_ptr(), offs, 0)
         assert gp.last_timing()["search_launches"] == 0               # (handed back by the pipeline)
-        assert all(bit_exact(a, b) for a, b in zip(got, gs)), step
+        for u in range(64):
+            assert_hyp_matches(got[u], want[u], "resident pipeline, step %d utt %d" % (step, u))
+            assert bit_exact(got[u], want[u]), (step, u)
+    ps = gp.pipeline_stats()
+    assert ps["frames_searched"] - f0 == n_steps * int(offs[-1]) and ps["batches_back"] == n_steps, ps
     gp.close()
 
 
@@ -220,8 +219,8 @@ def test_configs3_full_size(built):
     """BASELINE.json configs[3] at FULL size: ~48M-arc trigram-shaped graph (history states with up
     to 10^4 out-arcs, back-off epsilon arcs), 5000 tied states x 16 mixtures, mainBeam 300, 8
     utterances in one batch (~2 million live instances per stream-frame).  The oracle needs
-    ~0.15 s per frame here, so one short utterance is checked against it - certified not to depend
-    on the visiting order of equal-score tokens - plus the batch properties."""
+    ~0.15 s per frame here: all 8 utterances are checked against it, one oracle decoder per host core - certified not to
+    depend on the visiting order of equal-score tokens - plus the batch properties."""
     from juicer_amd import capi, synth
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
     am, net, feats, words = synth.config_c4(n_utts=8, utt_words=(3, 6))
@@ -229,13 +228,18 @@ def test_configs3_full_size(built):
     kw = dict(main_beam=300.0)
     gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=8, **kw)
     gs = gd.decode_batch(feats)
-    u = int(np.argmin([f.shape[0] for f in feats]))
-    o = OracleDecoder(OracleNet(net), OracleAM(am), **kw).decode_certified(feats[u])
-    print("configs[3]: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties, oracle %.1f frames/s"
-          % (u, feats[u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"],
-             feats[u].shape[0] / o.cpu_seconds))
-    assert_hyp_matches(gs[u], o, "configs[3] utt %d" % u)
-    assert o.stats["tot_insts_in"] / o.stats["n_frames"] > 500_000
+    # ALL 8 utterances against the certified oracle (it manages ~7 frames/s on this graph: one decoder per host core)
+    import time
+    t0 = time.time()
+    want = oracle_certified_many(net, am, feats, workers=8, **kw)
+    for u, o in enumerate(want):
+        print("configs[3]: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties, oracle %.1f frames/s"
+              % (u, feats[u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"],
+                 feats[u].shape[0] / o.cpu_seconds))
+        assert_hyp_matches(gs[u], o, "configs[3] utt %d" % u)
+        assert bit_exact(gs[u], o), u
+    print("configs[3]: the oracle took %.0f s for the 8 utterances" % (time.time() - t0))
+    assert max(o.stats["tot_insts_in"] / o.stats["n_frames"] for o in want) > 500_000
     for v in range(8):
         assert gs[v].n > 0
         t = gs[v].time[::-1]
@@ -244,22 +248,20 @@ def test_configs3_full_size(built):
 
 def test_north_star_workload_parity(built):
     """BASELINE.json north_star at its size: the 14.3 M-arc trigram-shaped composed graph bench.py's north_star leg
-    decodes (5000 tied states x 16 mixtures), mainBeam 200 - two utterances against the CPU oracle, certified not
-    to depend on the visiting order of equal-score tokens (the oracle manages ~100 frames / s here), the reference's
-    statistics bit-equal, plus the batch properties."""
+    decodes (5000 tied states x 16 mixtures), mainBeam 200 - all eight utterances against the CPU oracle, certified not
+    to depend on the visiting order of equal-score tokens, the reference's statistics bit-equal, scores bit for bit."""
     from juicer_amd import capi, synth
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
     am, net, feats, words = synth.config_c4(seed=0, n_utts=8, n_words=10000, n_tri_hist=100_000)
     assert net.n_arcs > 10_000_000 and am.n_gmm == 5000
     kw = dict(main_beam=200.0)
     gs = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=8, **kw).decode_batch(feats)
-    od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
-    order = np.argsort([f.shape[0] for f in feats])
-    for u in order[:2]:                                               # the two shortest: the oracle's minutes are the test's
-        o = od.decode_certified(feats[u])
-        print("north star: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties, oracle %.1f frames/s"
-              % (u, feats[u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"], feats[u].shape[0] / o.cpu_seconds))
+    want = oracle_certified_many(net, am, feats, workers=8, **kw)      # all 8 (the oracle manages ~100 frames / s here)
+    for u, o in enumerate(want):
+        print("north star: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties"
+              % (u, feats[u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"]))
         assert_hyp_matches(gs[u], o, "north star utt %d" % u)
+        assert bit_exact(gs[u], o), u
         assert o.n > 0 and o.stats["tot_insts_in"] / o.stats["n_frames"] > 50_000
     for v in range(8):
         assert gs[v].n > 0
@@ -290,13 +292,13 @@ def test_configs4_bench_size_composed_graph_vs_oracle(clg_pair):
     gs = capi.Decoder(net, p["gam"], max_streams=len(p["feats"]), **kw).decode_batch(p["feats"])
     c = net.csr()
     fs = np.nonzero(np.isfinite(c["fin_w"]))[0].astype(np.int32)
-    od = OracleDecoder(OracleNet.from_csr(net.n_states, net.init_state, c["row_ptr"], c["to"], c["w"], c["ilab"], c["olab"], fs, c["fin_w"][fs]),
-                       OracleAM(p["am"]), **kw)
-    for u in range(2):
-        o = od.decode_certified(p["feats"][u])
-        print("configs[4] graph: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties, oracle %.1f frames/s"
-              % (u, p["feats"][u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"], p["feats"][u].shape[0] / o.cpu_seconds))
+    onet = OracleNet.from_csr(net.n_states, net.init_state, c["row_ptr"], c["to"], c["w"], c["ilab"], c["olab"], fs, c["fin_w"][fs])
+    want = oracle_certified_many(onet, OracleAM(p["am"]), p["feats"], workers=6, **kw)   # all six utterances
+    for u, o in enumerate(want):
+        print("configs[4] graph: utterance %d, %d frames, %.0f instances / frame, %d order-dependent ties"
+              % (u, p["feats"][u].shape[0], o.stats["tot_insts_in"] / o.stats["n_frames"], o.stats["ties"]))
         assert_hyp_matches(gs[u], o, "configs[4] utt %d" % u)
+        assert bit_exact(gs[u], o), u
         assert o.n > 0
     lazy = capi.Network.lazy(p["ncl"], p["ng"], p["gam"], max_states=1 << 22, max_arcs=1 << 23)
     got = capi.Decoder(lazy, p["gam"], max_streams=len(p["feats"]), **kw).decode_batch(p["feats"])

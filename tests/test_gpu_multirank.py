@@ -43,16 +43,27 @@ def test_two_ranks_gather_hip_hypotheses(built):
 
 def test_bench_spawns_its_own_ranks(built):
     """`python bench.py --gpus 2` outside torchrun starts two ranks itself (here both on GPU 0 over
-    gloo, JD_BENCH_SHARE_GPU=1 - the numbers are meaningless, the path is what is tested)."""
+    gloo, JD_BENCH_SHARE_GPU=1 - the numbers are meaningless, the path is what is tested).  Several ranks run the
+    headline's own path: batches through the resident kernel, six announced ahead, the steps' 1-best records in ONE
+    all_gather behind jd_dec_quiesce at the end of the timed region; --gather-every 1 keeps a collective per step and
+    two batches in flight."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--utts-per-gpu", "6",
-           "--arcs", "60000", "--no-cpu-baseline", "--no-extra-legs"]
-    out = _run(cmd, env, 240)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--utts-per-gpu", "6",
+            "--arcs", "60000", "--no-cpu-baseline", "--no-extra-legs", "--pipeline-slots", "8"]
+    out = _run(base, env, 400)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["gathered_hyps"] == 12 and d["value"] > 0
+    assert d["config"]["pipeline"] and d["config"]["batches_in_flight"] == 7 and d["config"]["pipeline_error"] is None, d["config"]
+    assert "ONE all_gather" in d["config"]["gather"] and d["roofline"]["kernel"] == "k_resident"
+    assert d["frames_timed"] > 0 and d["single_batch"]["serial_order"]["ms"] > 0 and d["single_batch"]["one_ahead"]["ms"] > 0
+    out = _run(base + ["--gather-every", "1"], env, 400)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["pipeline"] is None and d["config"]["batches_in_flight"] == 2 and d["config"]["gathered_hyps"] == 12
+    assert d["frames_timed"] == 3 * d["config"]["frames_per_step"]
 
 
 def test_bench_strong_scaling_mode(built):

@@ -1185,11 +1185,12 @@ def test_batches_through_the_resident_kernel(small, monkeypatch):
         offs[1:] = np.cumsum([x.shape[0] for x in batch])
         return torch.from_numpy(np.concatenate(batch)).to(dev), offs
     buf = {n: resident(b) for n, b in batches.items()}
-    monkeypatch.setenv("JD_PIPELINE", "3")
-    monkeypatch.setenv("JD_PIPE_DEPTH", "4")
+    monkeypatch.setenv("JD_DEV", "1")                                  # (development knob: 50-frame commands instead of 128)
     monkeypatch.setenv("JD_PIPE_CHUNK", "50")
     for streams, extra in ((10, {}), (4, {}), (8, dict(max_paths=1 << 12))):
         gd = capi.Decoder(gnet, gam, max_streams=streams, **kw, **extra)
+        gd.set_pipeline(capi.FLOW_RESIDENT, 4)                         # the interface: jd_dec_set_pipeline, four batches deep
+        assert gd.pipeline_stats()["mode"] == capi.FLOW_RESIDENT and gd.pipeline_stats()["frames_searched"] == 0
         order = ["A", "B", "C", "A", "C", "B", "B", "A", "C"]
         ahead = 3
         for n in order[:ahead]:
@@ -1211,6 +1212,10 @@ def test_batches_through_the_resident_kernel(small, monkeypatch):
                 assert bit_exact(g, want[n][u])
             assert tm["search_launches"] == 0, (streams, i, n, tm)      # (handed back by the pipeline, not by a launch of its own)
         torch.cuda.synchronize()                                       # nothing announced is left: the kernel has gone
+        ps = gd.pipeline_stats()                                       # every frame of every batch went through the slots, once
+        assert ps["frames_searched"] == sum(sum(x.shape[0] for x in batches[n]) for n in order), ps
+        assert ps["batches_back"] == len(order) and ps["resident"] == 0 and ps["slots"] == streams
+        assert (ps["collections"] > 0) == bool(extra)
         # a fifth announcement does not fit a pipeline four deep; a decode that is not the announced one drops everything
         for n in ("A", "B", "C", "A"):
             gd.prefetch_scores(buf[n][0].data_ptr(), buf[n][1], 0)
@@ -1227,6 +1232,7 @@ def test_batches_through_the_resident_kernel(small, monkeypatch):
         gd.close()
     # more utterances than streams in ONE call, nothing announced: through the slots as well
     gd = capi.Decoder(gnet, gam, max_streams=4, **kw)
+    gd.set_pipeline(capi.FLOW_RESIDENT, 4)
     allf = batches["A"] + batches["B"] + batches["C"]
     for rep in range(2):
         gs = gd.decode_batch(allf)
@@ -1246,6 +1252,7 @@ def test_batches_through_the_resident_kernel(small, monkeypatch):
     wg = [od2.decode_certified(x) for x in good]
     bg, bb = resident(good), resident(bad)
     gd = capi.Decoder(gnet2, gam2, max_streams=3, **kw2)
+    gd.set_pipeline(capi.FLOW_RESIDENT, 4)
     for rep in range(2):
         gd.prefetch_scores(bg[0].data_ptr(), bg[1], 0); gd.prefetch_scores(bb[0].data_ptr(), bb[1], 0); gd.prefetch_scores(bg[0].data_ptr(), bg[1], 0)
         for u, g in enumerate(gd.decode_batch_device(bg[0].data_ptr(), bg[1], 0)):
@@ -1380,12 +1387,8 @@ def test_two_batches_in_flight(small):
     assert ahead_seen >= 2
     gs_.close()
     # switched off: same results, nothing ahead
-    import os
-    os.environ["JD_PIPELINE"] = "0"
-    try:
-        g0 = capi.Decoder(gnet, gam, max_streams=12, **kw)
-    finally:
-        del os.environ["JD_PIPELINE"]
+    g0 = capi.Decoder(gnet, gam, max_streams=12, **kw)
+    g0.set_pipeline(capi.FLOW_SERIAL)
     g0.prefetch_scores(buf["B"][0].data_ptr(), buf["B"][1], 0); g0.prefetch_scores(buf["C"][0].data_ptr(), buf["C"][1], 0)
     for n in ("A", "B", "C"):
         gs = g0.decode_batch_device(buf[n][0].data_ptr(), buf[n][1], 0)
