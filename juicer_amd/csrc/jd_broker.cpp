@@ -31,6 +31,7 @@ struct Client {
     std::vector<float> pending;                    // frames pushed and not yet handed to the decoder
     int err = JD_OK;                               // first error of a tick that concerned this client (reported by its next call)
     std::string errmsg;
+    bool failed = false;                           // its init or its stream failed: every call up to the next init() reports err
     jd_hyp result;                                 // of the last finish (arrays owned by the decoder, valid until the stream's next init)
     // the resident kernel's worker (broker_loop_resident): chunks of this client's frames that are scored (or being scored)
     // and not yet posted - at most two, one per likelihood buffer - and the one its cluster is running
@@ -61,6 +62,7 @@ struct jd_broker {
     std::vector<Client> clients;
     jd_broker_stats stats{};
     bool resident = false;                         // the worker drives the resident search kernel (jd_res_*) instead of ticks
+    int fail_init_of = -1;                         // test hook (JD_DEV=1 JD_BROKER_FAIL_INIT=<client>): that client's inits fail
     // results are fetched by a thread of their own: recognitionFinish's kernel, a synchronisation of the side stream and
     // three copies back are a third of a millisecond in which the worker would post nothing to anybody
     std::thread finisher;
@@ -72,9 +74,19 @@ static int client_error(jd_broker *b, Client &c)
 {
     if (c.err == JD_OK) return JD_OK;
     const int e = c.err;
-    c.err = JD_OK;
+    if (!c.failed) c.err = JD_OK;                  // (a failed init / a failed stream: reported until the next init())
     (void)b;
     return jd_fail(e, "%s", c.errmsg.c_str());
+}
+// An init that failed, or a stream that failed on the device: nothing more can be done for the utterance - what the client has
+// pushed is dropped and whoever waits (a push for room, a finish for its result) is woken with the error.  (lk held)
+static void client_failed(jd_broker *b, Client &c, int rc, const std::string &msg)
+{
+    if (c.err == JD_OK) { c.err = rc; c.errmsg = msg; }
+    c.failed = true;
+    c.pending.clear(); c.n_staged = 0;
+    c.want_finish = false;
+    b->cv_done.notify_all();
 }
 
 static void broker_loop(jd_broker *b)
@@ -143,7 +155,7 @@ static void broker_loop(jd_broker *b)
         int64_t us_init = 0, us_push = 0, us_finish = 0, us_search = 0;
         t_mark = now();
         for (int i : inits) {
-            rc_of[(size_t)i] = jd_stream_init(b->dec, i);
+            rc_of[(size_t)i] = i == b->fail_init_of ? jd_fail(JD_EHIP, "jd_broker: init failure injected for client %d", i) : jd_stream_init(b->dec, i);
             if (rc_of[(size_t)i]) msg_of[(size_t)i] = jd_last_error();
         }
         us_init = us_since(t_mark); t_mark = now();
@@ -205,6 +217,9 @@ static void broker_loop(jd_broker *b)
             Client &c = b->clients[(size_t)i];
             if (c.init_req == init_seen[(size_t)i]) c.want_init = false;   // (else: init() again meanwhile - the next tick's)
             c.inited = rc_of[(size_t)i] == JD_OK;
+            // (a failed init: the frames behind it and a finish that waits for them would wait for ever - pushers need inited, finishers
+            // an empty queue)
+            if (!c.inited && !c.want_init) client_failed(b, c, rc_of[(size_t)i], msg_of[(size_t)i]);
         }
         for (int i : finishers) { Client &c = b->clients[(size_t)i]; c.want_finish = false; c.inited = false; c.result = res[(size_t)i]; }
         for (Client &c : b->clients) c.in_flight = false;
@@ -317,6 +332,17 @@ static void broker_loop_resident(jd_broker *b)
                 const std::string m = rc ? jd_last_error() : "";
                 lk.lock();
                 if (rc) { fail_all(rc, m); on = false; lk.unlock(); (void)jd_res_stop(b->dec); lk.lock(); break; }
+                if (idle && err != 0 && !c.failed) {
+                    // the stream failed on the device (an arena overflow, Histogram's ceiling, a lost workgroup): no more chunks are
+                    // scored or posted for it, the client's next call says why (its finish still fetches - and reports - the same)
+                    lk.unlock();
+                    const int er = jd_res_stream_error(b->dec, i, err, frame);
+                    const std::string em = jd_last_error();
+                    lk.lock();
+                    const bool wf = c.want_finish;
+                    client_failed(b, c, er, em);
+                    c.want_finish = wf;                                  // (a finish under way goes through try_finish as usual)
+                }
                 if (idle) {
                     c.running = false; progress = true; b->cv_done.notify_all();
                     c.t_idle = now(); c.was_idle = true;
@@ -327,18 +353,19 @@ static void broker_loop_resident(jd_broker *b)
             if (!c.running && c.n_staged == 0 && c.want_init) {
                 const unsigned req = c.init_req;
                 lk.unlock();
-                rc = jd_res_init(b->dec, i);
+                rc = i == b->fail_init_of ? jd_fail(JD_EHIP, "jd_broker: init failure injected for client %d", i) : jd_res_init(b->dec, i);
                 const std::string m = rc ? jd_last_error() : "";
                 lk.lock();
                 if (c.init_req == req) c.want_init = false;           // (else: init() again meanwhile - served in the next round)
                 c.inited = rc == JD_OK; c.fresh = rc == JD_OK; c.was_idle = false;
-                if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
+                if (rc && !c.want_init) client_failed(b, c, rc, m);    // (a push that waits for room, a finish: woken with the error)
+                else if (rc && c.err == JD_OK) { c.err = rc; c.errmsg = m; }
                 b->cv_done.notify_all();
                 progress = true;
             }
             try_post(i);                                                // (what is scored already goes first: a word in host memory)
             // 3. frames for a free likelihood buffer: taken here, scored below - one launch for all the streams of this round
-            if (c.inited && !c.want_init && !c.pending.empty() && c.n_staged + (c.running ? 1 : 0) < 2) {
+            if (c.inited && !c.failed && !c.want_init && !c.pending.empty() && c.n_staged + (c.running ? 1 : 0) < 2) {
                 int buf = 0;
                 if (c.running && c.run_buf == 0) buf = 1;
                 if (c.n_staged == 1 && c.staged_buf[0] == buf) buf ^= 1;
@@ -429,6 +456,7 @@ extern "C" int jd_broker_create(jd_broker **out, jd_dec *dec, int32_t n_clients)
     // (up to 64 clients: the ready list of a scoring launch and the chip's room for clusters and their scoring side by side)
     b->resident = n_clients <= 64;
     if (const char *e = jd_dev_env("JD_BROKER_RESIDENT")) b->resident = atoi(e) != 0;
+    if (const char *e = jd_dev_env("JD_BROKER_FAIL_INIT")) b->fail_init_of = atoi(e);
     if (b->resident && !jd_dev_env("JD_BROKER_TICK_FRAMES")) {            // (whole scoring tiles)
         b->max_tick_frames = 256;
         b->max_pending_frames = 4 * b->max_tick_frames;
@@ -482,7 +510,7 @@ extern "C" int jd_broker_init(jd_broker *b, int32_t client)
     Client &c = b->clients[(size_t)client];
     if (!c.open) return jd_fail(JD_ESTATE, "jd_broker_init: client %d is not open", client);
     // (an init that is still waiting to be served - init() twice - is this one)
-    c.pending.clear(); c.want_finish = false; c.err = JD_OK;          // (init() in the middle of an utterance drops it, as the reference does)
+    c.pending.clear(); c.want_finish = false; c.err = JD_OK; c.failed = false;   // (init() in the middle of an utterance drops it, as the reference does)
     c.want_init = true;
     c.init_req += 1;
     // nobody waits for the worker here: the stream is initialised at the head of the next tick, in front of whatever
@@ -497,11 +525,14 @@ extern "C" int jd_broker_push(jd_broker *b, int32_t client, const float *frames,
         return jd_fail(JD_EINVAL, "jd_broker_push: bad argument");
     std::unique_lock<std::mutex> lk(b->mu);
     Client &c = b->clients[(size_t)client];
-    if (!c.open || !(c.inited || c.want_init) || c.want_finish)
-        return jd_fail(JD_ESTATE, "jd_broker_push: client %d is not between init and finish", client);
-    const int rc = client_error(b, c);
+    if (!c.open) return jd_fail(JD_ESTATE, "jd_broker_push: client %d is not open", client);
+    int rc = client_error(b, c);                                       // (a failed init comes back here, not as "not between init and finish")
     if (rc) return rc;
-    b->cv_done.wait(lk, [&]() { return b->stop || (int)(c.pending.size() / (size_t)b->D) <= b->max_pending_frames; });
+    if (!(c.inited || c.want_init) || c.want_finish)
+        return jd_fail(JD_ESTATE, "jd_broker_push: client %d is not between init and finish", client);
+    b->cv_done.wait(lk, [&]() { return b->stop || c.failed || (int)(c.pending.size() / (size_t)b->D) <= b->max_pending_frames; });
+    rc = client_error(b, c);                                           // (... or here, when it failed while this push waited for room)
+    if (rc) return rc;
     c.pending.insert(c.pending.end(), frames, frames + (size_t)n_frames * (size_t)b->D);
     b->cv_work.notify_all();
     return JD_OK;
@@ -512,7 +543,9 @@ extern "C" int jd_broker_finish(jd_broker *b, int32_t client, jd_hyp *out)
     if (!b || client < 0 || client >= b->n_clients || !out) return jd_fail(JD_EINVAL, "jd_broker_finish: bad argument");
     std::unique_lock<std::mutex> lk(b->mu);
     Client &c = b->clients[(size_t)client];
-    if (!c.open || !(c.inited || c.want_init)) return jd_fail(JD_ESTATE, "jd_broker_finish: client %d is not between init and finish", client);
+    if (!c.open) return jd_fail(JD_ESTATE, "jd_broker_finish: client %d is not open", client);
+    if (c.failed && !c.inited) return client_error(b, c);              // (its init failed: there is no utterance to finish)
+    if (!(c.inited || c.want_init)) return jd_fail(JD_ESTATE, "jd_broker_finish: client %d is not between init and finish", client);
     c.want_finish = true;
     b->cv_work.notify_all();
     b->cv_done.wait(lk, [&]() { return b->stop || !c.want_finish; });

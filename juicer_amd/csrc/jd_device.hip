@@ -452,6 +452,7 @@ struct jd_dec {
     char *h_stage = nullptr; size_t stage_cap = 0;     // pinned staging of jd_streams_push
     bool xch_forced = false;               // JD_XCH given (development)
     struct Resident *res = nullptr;        // the resident search kernel of a broker (jd_res_*), or null
+    std::recursive_mutex res_mu;           // jd_res_stop / jd_res_start (the broker's worker) against jd_res_finish (its finisher thread)
     long long res_yield_turn = -1;             // the lock's turn count when the resident kernel last made room for a waiter
     std::vector<hipStream_t> res_old_streams;   // search streams the resident kernel gave up (jd_res_start)
     struct Pipe *pipe = nullptr;           // batches through the resident kernel, utterance by utterance (jd_pipe_*; JD_PIPELINE=3)
@@ -971,6 +972,33 @@ static int mark_init(jd_dec *d, int s0, int n, hipStream_t st)
 // results -> out[out_idx[i]] (out_idx == nullptr: out[out0 + i]): of streams [s0, s0+n), or - resn_v != null - of the virtual
 // result slots [s0, s0+n) the batch pipeline exported them to (ctl_v / resn_v / res_v: their control blocks, word counts and
 // result arrays; slot_of: the streams they ran on, for the messages and the dirty marks)
+// A stream's device-side error word (StreamCtl::error) as the library's code + message
+static int report_stream_error(jd_dec *d, int s_i, int error, int frame, int lst_nw)
+{
+    if (error == JD_EHIST) return jd_fail(JD_EHIST, "Histogram::addScore - score > maxScore (stream %d)", s_i);
+    if (error == JDE_BARRIER)
+        return jd_fail(JD_EHIP, "stream %d: a workgroup of the search cluster did not arrive at a barrier (frame %d)", s_i, frame);
+    if (error == JDE_LAZY_INV)
+        return jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)", s_i, frame);
+    if (error == JDE_LAZY) {
+        d->lazy_failed = true;
+        LazyDev L;
+        int why = 0;
+        if (hipMemcpy(&L, d->net->lazy_dev, sizeof L, hipMemcpyDeviceToHost) == hipSuccess)
+            (void)hipMemcpy(&why, L.err, sizeof why, hipMemcpyDeviceToHost);
+        return jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of %s at frame %d (capacity %d states, %lld arcs): "
+                       "what was being decoded at once needs a network with larger max_states / max_arcs", s_i,
+                       why == 1 ? "states" : why == 2 ? "arcs"
+                                : "stack closing a state (epsilon / tee arcs more than a hundred deep, or a cycle of them)",
+                       frame, d->net->n_states, (long long)d->net->n_arcs);
+    }
+    const char *what = error == JDE_SLOTS ? "instance slots" : error == JDE_ITEMS ? "frontier items"
+                     : error == JDE_PATHS ? "Path records" : error == JDE_NEW ? "newly entered arcs" : "arena";
+    const long long cap = error == JDE_SLOTS ? d->cap_slots : error == JDE_ITEMS ? d->cap_items : error == JDE_NEW ? d->cap_new : d->cap_paths;
+    return jd_fail(JD_ENOMEM, "stream %d: device arena overflow at frame %d: %s (capacity %lld, split over %d wave segments); raise it with "
+                   "jd_dec_set_capacity", s_i, frame, what, cap, error == JDE_PATHS ? 1 : std::max(lst_nw, 1));
+}
+
 static int fetch_results_from(jd_dec *d, const StreamCtl *ctl_v, const int *resn_v, const int *res_v, const int *slot_of, int s0, int n,
                               jd_hyp *out, int out0, const int *out_idx)
 {
@@ -1001,37 +1029,7 @@ static int fetch_results_from(jd_dec *d, const StreamCtl *ctl_v, const int *resn
         HostResult &R = d->results[(size_t)oi];
         jd_hyp &H = out[oi];
         memset(&H, 0, sizeof H);
-        if (K.error && first_err == JD_OK) {
-            if (K.error == JD_EHIST)
-                first_err = jd_fail(JD_EHIST, "Histogram::addScore - score > maxScore (stream %d)", s_i);
-            else if (K.error == JDE_BARRIER)
-                first_err = jd_fail(JD_EHIP, "stream %d: a workgroup of the search cluster did not arrive at a barrier "
-                                    "(frame %d)", s_i, K.frame);
-            else if (K.error == JDE_LAZY_INV)
-                first_err = jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)",
-                                    s_i, K.frame);
-            else if (K.error == JDE_LAZY) {
-                d->lazy_failed = true;
-                LazyDev L;
-                int why = 0;
-                if (hipMemcpy(&L, d->net->lazy_dev, sizeof L, hipMemcpyDeviceToHost) == hipSuccess)
-                    (void)hipMemcpy(&why, L.err, sizeof why, hipMemcpyDeviceToHost);
-                first_err = jd_fail(JD_ENOMEM, "stream %d: the lazily composed network ran out of %s at frame %d (capacity %d states, %lld arcs): "
-                                    "what was being decoded at once needs a network with larger max_states / max_arcs", s_i,
-                                    why == 1 ? "states" : why == 2 ? "arcs"
-                                             : "stack closing a state (epsilon / tee arcs more than a hundred deep, or a cycle of them)",
-                                    K.frame, d->net->n_states, (long long)d->net->n_arcs);
-            }
-            else {
-                const char *what = K.error == JDE_SLOTS ? "instance slots" : K.error == JDE_ITEMS ? "frontier items"
-                                 : K.error == JDE_PATHS ? "Path records" : K.error == JDE_NEW ? "newly entered arcs" : "arena";
-                const long long cap = K.error == JDE_SLOTS ? d->cap_slots : K.error == JDE_ITEMS ? d->cap_items
-                                    : K.error == JDE_NEW ? d->cap_new : d->cap_paths;
-                first_err = jd_fail(JD_ENOMEM, "stream %d: device arena overflow at frame %d: %s (capacity %lld, split over "
-                                    "%d wave segments); raise it with jd_dec_set_capacity", s_i, K.frame, what, cap,
-                                    K.error == JDE_PATHS ? 1 : std::max(K.lst_nw, 1));
-            }
-        }
+        if (K.error && first_err == JD_OK) first_err = report_stream_error(d, s_i, K.error, K.frame, K.lst_nw);
         if (K.error) d->stream_dirty[(size_t)(s_i)] = 1;            // arenas may be inconsistent after an abort: wiped before the next init
         H.stats.n_frames = K.frame;
         H.stats.tot_active_emit_hyps = K.st[ST_EMIT];
@@ -2371,6 +2369,7 @@ struct Resident {
     ResMail *d_mail = nullptr;
     ResPost *h_post = nullptr;                         // host-mapped: the commands
     ResDone *h_done = nullptr;                         // host-mapped: the reports
+    unsigned *h_beat = nullptr;                        // host-mapped: counted up whenever the host looks after the kernel (k_resident: beat)
     unsigned *d_ready = nullptr;                       // per stream: how far the side stream has come for it
     std::vector<unsigned> rid;                         // ... and the last number enqueued for it
     int *h_ring = nullptr, *d_ring = nullptr;          // row-tile lists of the scoring launches (RES_RING slots of RES_RING_W)
@@ -2399,6 +2398,7 @@ static void res_free(jd_dec *d)
     if (R->d_mail) (void)hipFree(R->d_mail);
     if (R->h_post) (void)hipHostFree(R->h_post);
     if (R->h_done) (void)hipHostFree(R->h_done);
+    if (R->h_beat) (void)hipHostFree(R->h_beat);
     if (R->d_ready) (void)hipFree(R->d_ready);
     if (R->h_ring) (void)hipHostFree(R->h_ring);
     if (R->d_ring) (void)hipFree(R->d_ring);
@@ -2421,6 +2421,9 @@ static bool res_harvest(jd_dec *d, int s)
         d->pipe_busy_ticks += R->h_done[s].run_ticks;
     }
     R->T_done[(size_t)s] = R->h_done[s].frame; R->err_done[(size_t)s] = R->h_done[s].error;
+    // (a stream that failed on the device - an arena overflow, a lost workgroup - may hold anything: wiped before its next init,
+    // whether or not anybody fetches its result)
+    if (R->err_done[(size_t)s] != 0) d->stream_dirty[(size_t)s] = 1;
     R->run_ticks += R->h_done[s].run_ticks;
     R->init_pending[(size_t)s] = 0;
     d->stream_T[(size_t)s] = R->T_done[(size_t)s];
@@ -2430,7 +2433,9 @@ static bool res_harvest(jd_dec *d, int s)
 
 int jd_res_stop(jd_dec *d)
 {
-    if (!d || !d->res || !d->res->on) return JD_OK;
+    if (!d) return JD_OK;
+    std::lock_guard<std::recursive_mutex> guard(d->res_mu);            // (a finish that is being fetched goes first)
+    if (!d->res || !d->res->on) return JD_OK;
     Resident *R = d->res;
     for (int s = 0; s < R->n; ++s) __atomic_store_n(&R->h_post[s].exit_req, 1, __ATOMIC_RELEASE);
     hipError_t e = hipStreamSynchronize(d->s_search);                  // (it also leaves by itself after RES_IDLE_TICKS)
@@ -2458,6 +2463,7 @@ int jd_res_stop(jd_dec *d)
 int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
 {
     if (!d || n_streams < 1 || n_streams > d->max_streams || rows_per_buf < 1) return jd_fail(JD_EINVAL, "jd_res_start: bad argument");
+    std::lock_guard<std::recursive_mutex> guard(d->res_mu);
     if (d->net->lazy_dev || d->partial_interval > 0) return jd_fail(JD_ESTATE, "jd_res_start: not with a lazily composed network / partial traces");
     int rc = check_device(d->device);
     if (rc) return rc;
@@ -2479,6 +2485,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
         if (hipMalloc(&R->d_mail, (size_t)n_streams * sizeof(ResMail)) != hipSuccess ||
             hipHostMalloc((void **)&R->h_post, (size_t)n_streams * sizeof(ResPost), hipHostMallocMapped) != hipSuccess ||
             hipHostMalloc((void **)&R->h_done, (size_t)n_streams * sizeof(ResDone), hipHostMallocMapped) != hipSuccess ||
+            hipHostMalloc((void **)&R->h_beat, 64, hipHostMallocMapped) != hipSuccess ||
             hipMalloc(&R->d_ready, (size_t)n_streams * sizeof(unsigned)) != hipSuccess ||
             hipHostMalloc((void **)&R->h_ring, (size_t)RES_RING * RES_RING_W * sizeof(int)) != hipSuccess ||
             hipMalloc(&R->d_ring, (size_t)RES_RING * RES_RING_W * sizeof(int)) != hipSuccess ||
@@ -2488,6 +2495,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
             res_free(d);
             return jd_fail(JD_ENOMEM, "jd_res_start: no memory for %d streams x 2 x %d rows", n_streams, rows);
         }
+        *R->h_beat = 0u;
         R->seq.assign((size_t)n_streams, 0u); R->T_posted.assign((size_t)n_streams, 0); R->T_done.assign((size_t)n_streams, 0);
         R->slot_posted.assign((size_t)n_streams, 0); R->err_done.assign((size_t)n_streams, 0); R->busy.assign((size_t)n_streams, 0); R->init_pending.assign((size_t)n_streams, 0);
         for (int t = 0; t < n_streams; ++t) R->T_done[(size_t)t] = R->T_posted[(size_t)t] = d->stream_T[(size_t)t];
@@ -2542,7 +2550,7 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     // (one workgroup per stream: the XCD-local flavour of the memory operations - a cluster of one sits on one XCD)
     bool xl = R->Cw == 1;
     if (const char *e = jd_dev_env("JD_RES_XL")) xl = xl && atoi(e) != 0;   // development
-    typedef void (*ResKernel)(SearchArgs, const ResPost *, ResMail *, const unsigned *, ResDone *, int);
+    typedef void (*ResKernel)(SearchArgs, const ResPost *, ResMail *, const unsigned *, ResDone *, int, const unsigned *);
     const ResKernel rk = ne3 ? (xl ? k_resident<3, true> : k_resident<3, false>) : (xl ? k_resident<6, true> : k_resident<6, false>);
     // HIP maps streams onto a few hardware queues, and whatever is queued BEHIND a kernel that stays waits until it leaves:
     // the side stream's scoring, the null stream's copies back.  Which queue a stream gets is the runtime's business
@@ -2556,7 +2564,8 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     HIPCHK(hipEventCreateWithFlags(&ev_side.e, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_null.e, hipEventDisableTiming));
     for (int attempt = 0; attempt < 8 && !clear; ++attempt) {
         hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->d_ready, R->n);
-        hipLaunchKernelGGL(rk, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw);
+        __atomic_fetch_add(R->h_beat, 1u, __ATOMIC_RELEASE);
+        hipLaunchKernelGGL(rk, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw, R->h_beat);
         e = hipGetLastError();
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(jd_res_ready_kernel, dim3(1), dim3(64), 0, d->s_gmm, R->d_ready, none);
@@ -2627,6 +2636,7 @@ static int res_bump(jd_dec *d, int n, const int *streams)
 // IDecoder::init of stream s (idle): recognitionStart runs with the stream's next command
 int jd_res_init(jd_dec *d, int s)
 {
+    std::lock_guard<std::recursive_mutex> guard(d->res_mu);            // (the wipe of a failed stream stops and starts the kernel)
     Resident *R = d->res;
     if (!R || !R->on || s < 0 || s >= R->n) return jd_fail(JD_ESTATE, "jd_res_init: no resident kernel for stream %d", s);
     if (d->stream_dirty[(size_t)s]) {                                  // (after an error: the wipe synchronises the device)
@@ -2682,6 +2692,7 @@ int jd_res_stage_many(jd_dec *d, int n, const int *streams, const int *bufs, con
 // the command itself: a word in host-mapped memory (the cluster's first workgroup polls it)
 static void res_write_post(Resident *R, int s, int T, int slot, int init = 0)
 {
+    __atomic_fetch_add(R->h_beat, 1u, __ATOMIC_RELAXED);               // (a sign of life: k_resident's `beat`)
     ResPost &P = R->h_post[s];
     P.T = T;
     P.init = init;
@@ -2710,6 +2721,7 @@ int jd_res_poll(jd_dec *d, int s, int *idle, int *frame, int *error, int *stoppe
 {
     Resident *R = d->res;
     if (!R || !R->on || s < 0 || s >= R->n) return jd_fail(JD_ESTATE, "jd_res_poll: no resident kernel for stream %d", s);
+    __atomic_fetch_add(R->h_beat, 1u, __ATOMIC_RELAXED);               // (a sign of life: k_resident's `beat`)
     const bool through = res_harvest(d, s);
     *idle = through ? 1 : 0;
     if (frame) *frame = R->T_done[(size_t)s];
@@ -2719,6 +2731,12 @@ int jd_res_poll(jd_dec *d, int s, int *idle, int *frame, int *error, int *stoppe
     if (__atomic_load_n(&R->h_done[s].left, __ATOMIC_ACQUIRE))
         return jd_fail(JD_ESTATE, "the resident search kernel has ended (no command for 5 s, or a lost workgroup)");
     return JD_OK;
+}
+
+// the device-side error a poll reported for stream s, as the library's code (jd_last_error() has the text)
+int jd_res_stream_error(jd_dec *d, int s, int dev_error, int frame)
+{
+    return report_stream_error(d, s, dev_error, frame, 1);
 }
 
 // collectPaths for stream s (idle, stopped), then the rest of its command again
@@ -2741,6 +2759,11 @@ int jd_res_collect(jd_dec *d, int s)
 // IDecoder::finish of stream s (idle, every frame it was given processed)
 int jd_res_finish(jd_dec *d, int s, jd_hyp *out)
 {
+    // (the broker's finisher thread, beside its worker: the kernel is neither stopped nor started while a result is fetched -
+    // a stop wipes device state and synchronises the device - and this thread's launches go to the decoder's device)
+    std::lock_guard<std::recursive_mutex> guard(d->res_mu);
+    int rc0 = check_device(d->device);
+    if (rc0) return rc0;
     Resident *R = d->res;
     if (!R || !R->on || s < 0 || s >= R->n || !out) return jd_fail(JD_ESTATE, "jd_res_finish: no resident kernel for stream %d", s);
     hipLaunchKernelGGL(jd_finish_kernel, dim3(1), dim3(64), 0, d->s_gmm, d->d_ctl, d->d_streams, s, 1);
@@ -2843,6 +2866,7 @@ static int pipe_pump(jd_dec *d)
         EL.n = 0;
         return JD_OK;
     };
+    if (R->h_beat) __atomic_fetch_add(R->h_beat, 1u, __ATOMIC_RELAXED);   // (a sign of life: k_resident's `beat`)
     if (R->on) {
         // the kernel has gone by itself: nobody gave it a command for 5 s (a caller that was away between two calls) - seen
         // BEFORE anything is posted to it: the reports are all in, and it comes back like behind jd_dec_quiesce

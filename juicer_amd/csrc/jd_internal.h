@@ -88,6 +88,7 @@ int jd_res_init(jd_dec *d, int s);
 int jd_res_stage_many(jd_dec *d, int n, const int *streams, const int *bufs, const float *const *frames, const int *n_frames);
 int jd_res_post(jd_dec *d, int s, int buf, int n_frames);
 int jd_res_poll(jd_dec *d, int s, int *idle, int *frame, int *error, int *stopped);
+int jd_res_stream_error(jd_dec *d, int s, int dev_error, int frame);   // a poll's device-side error as code + jd_last_error()
 int jd_res_collect(jd_dec *d, int s);
 int jd_res_finish(jd_dec *d, int s, jd_hyp *out);
 #endif

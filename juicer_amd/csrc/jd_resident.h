@@ -37,7 +37,7 @@ struct ResDone {               // host-mapped, one per stream: written by workgr
     int left;                  // 1: the cluster has left the kernel (exit request, or nobody posted anything for RES_IDLE_TICKS)
     long long run_ticks;       // (statistics) 100 MHz ticks the cluster spent on the command
 };
-#define RES_IDLE_TICKS 500000000LL      // 5 s at 100 MHz without a command: the kernel ends by itself
+#define RES_IDLE_TICKS 500000000LL      // 5 s at 100 MHz without a command AND without a sign of life from the host: the kernel ends by itself
 
 // "the side stream has come this far": enqueued behind a scoring launch / a mark / a collection, for the streams concerned
 struct ReadyList { int n; int s[64]; unsigned id[64]; };
@@ -61,7 +61,12 @@ __global__ void jd_res_reset_kernel(StreamCtl *ctl, ResMail *mail, unsigned *rea
 // jd_search.h) - for clusters of ONE workgroup, which sit on one XCD by definition; a command's closing release writes
 // the L2 back for the kernels beside it, its opening acquire drops what they have made stale.
 template <int NE, bool XL>
-__global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail *mail, const unsigned *ready, ResDone *done, int Cw)
+// beat: a host-mapped word the host counts up whenever it looks after the kernel (jd_res_poll / jd_res_post / the batch pipeline's pump).  A cluster
+// without a command does not leave while that word moves: one caller of a broker may pause for as long as it likes while the others keep the
+// kernel busy (round 4 left after 5 s without a command for ITS stream, and the paused caller's next command was never served).  It leaves when
+// the host has given no sign of life for RES_IDLE_TICKS either - a caller that went away between two calls, a process that died - because the
+// kernel holds the device's search lock and the GPU's file lock.
+__global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail *mail, const unsigned *ready, ResDone *done, int Cw, const unsigned *beat)
 {
     __shared__ SearchShared sh;
     __shared__ unsigned long long sh_word;
@@ -74,7 +79,16 @@ __global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail
     __syncthreads();
     for (;;) {
         if (tid == 0) {
-            const long long t_idle = wall_clock64() + RES_IDLE_TICKS;
+            long long t_idle = wall_clock64() + RES_IDLE_TICKS;
+            unsigned last_beat = __hip_atomic_load(beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the time is up: has the host looked after the kernel since this wait began (or since the last time this was asked)?
+            auto host_gone = [&](long long slack) __attribute__((always_inline)) {
+                if (wall_clock64() <= t_idle + slack) return false;
+                const unsigned bt = __hip_atomic_load(beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (bt == last_beat) return true;
+                last_beat = bt; t_idle = wall_clock64() + RES_IDLE_TICKS;
+                return false;
+            };
             unsigned long long w = 0ULL;
             int ex = 0;
             unsigned spins = 0;
@@ -87,14 +101,14 @@ __global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail
                     ex = __hip_atomic_load(&post[s].exit_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (ex) break;
                     __builtin_amdgcn_s_sleep(48);
-                    if ((++spins & 255u) == 0 && wall_clock64() > t_idle) { ex = 1; break; }
+                    if ((++spins & 255u) == 0 && host_gone(0LL)) { ex = 1; break; }
                 }
                 if (!ex) {
                     const int T = __hip_atomic_load(&post[s].T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     const unsigned rid = __hip_atomic_load(&post[s].ready_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     while ((int)(__hip_atomic_load(&ready[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - rid) < 0) {
                         __builtin_amdgcn_s_sleep(16);
-                        if ((++spins & 255u) == 0 && wall_clock64() > t_idle) { ex = 1; break; }
+                        if ((++spins & 255u) == 0 && host_gone(0LL)) { ex = 1; break; }
                     }
                     if (!ex) {
                         if (__hip_atomic_load(&post[s].init, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
@@ -114,7 +128,7 @@ __global__ JD_KBOUNDS void k_resident(SearchArgs A, const ResPost *post, ResMail
                     ex = __hip_atomic_load(&mail[s].exit_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (ex) break;
                     __builtin_amdgcn_s_sleep(16);
-                    if ((++spins & 255u) == 0 && wall_clock64() > t_idle + 100000000LL) { ex = 1; break; }   // (a second behind workgroup 0)
+                    if ((++spins & 255u) == 0 && host_gone(100000000LL)) { ex = 1; break; }   // (a second behind workgroup 0)
                 }
             }
             sh_word = w; sh_exit = ex;

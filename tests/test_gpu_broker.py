@@ -348,3 +348,131 @@ def test_two_processes_share_one_gpu(built, tmp_path):
         assert p.returncode == 0, e
         assert o.strip().splitlines()[-1] == alone.stdout.strip().splitlines()[-1]
     assert any(f.startswith("juicer_amd.gpu-") for f in os.listdir(tmp_path))
+
+
+def test_paused_caller_keeps_its_cluster(built):
+    """One caller pauses for longer than the resident kernel's idle limit (5 s) in the middle of an utterance, and another opens its
+    client that late, while two others keep the kernel busy: the paused stream's cluster must still be there (round 4: a
+    cluster left after 5 s without a command for ITS stream, the paused caller's next chunk was never served and every
+    client's utterance was dropped with an error).  The kernel now leaves only when the HOST shows no sign of life."""
+    import time
+    from juicer_amd import capi, synth
+    am, net, feats, _ = synth.config_small(n_utts=6)
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    kw = dict(main_beam=150.0)
+    want = capi.Decoder(gnet, gam, max_streams=len(feats), **kw).decode_batch(feats)
+    dec = capi.Decoder(gnet, gam, max_streams=4, **kw)
+    broker = capi.Broker(dec)
+    assert broker.stats()["resident"]
+    stop = threading.Event()
+    errs, got, n_busy = [], {}, [0, 0]
+
+    def busy(t):                                                       # utterance after utterance, in small pushes: the kernel never idles
+        try:
+            c = broker.open()
+            k = 0
+            while not stop.is_set():
+                u = 2 + (k + t) % 4
+                broker.init(c)
+                for i in range(0, feats[u].shape[0], 23):
+                    broker.push(c, feats[u][i:i + 23])
+                    time.sleep(0.0005)
+                h = broker.finish(c)
+                assert bit_exact(h, want[u]), ("busy", t, u)
+                k += 1
+            n_busy[t] = k
+            broker.close_client(c)
+        except Exception as e:                                         # noqa: BLE001
+            errs.append(("busy %d" % t, repr(e)))
+
+    def paused():
+        try:
+            c = broker.open()
+            broker.init(c)
+            half = feats[0].shape[0] // 2
+            broker.push(c, feats[0][:half])
+            time.sleep(6.5)                                            # longer than RES_IDLE_TICKS
+            broker.push(c, feats[0][half:])
+            got[0] = broker.finish(c)
+            broker.close_client(c)
+        except Exception as e:                                         # noqa: BLE001
+            errs.append(("paused", repr(e)))
+
+    def late():
+        try:
+            time.sleep(6.0)                                            # a client slot that is first used when the kernel is 6 s old
+            c = broker.open()
+            broker.init(c)
+            for i in range(0, feats[1].shape[0], 40):
+                broker.push(c, feats[1][i:i + 40])
+            got[1] = broker.finish(c)
+            broker.close_client(c)
+        except Exception as e:                                         # noqa: BLE001
+            errs.append(("late", repr(e)))
+    ths = [threading.Thread(daemon=True, target=busy, args=(t,)) for t in range(2)] + [threading.Thread(daemon=True, target=paused),
+                                                                                        threading.Thread(daemon=True, target=late)]
+    for t in ths:
+        t.start()
+    ths[2].join(60); ths[3].join(60)
+    stop.set()
+    ths[0].join(60); ths[1].join(60)
+    assert not any(t.is_alive() for t in ths), "a caller hangs"
+    assert not errs, errs
+    assert bit_exact(got[0], want[0]) and bit_exact(got[1], want[1])
+    assert min(n_busy) > 3
+    broker.close()
+    dec.close()
+
+
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_failed_init_wakes_its_callers(built, resident, monkeypatch):
+    """An init that fails (injected: JD_BROKER_FAIL_INIT) must come back as THE error of the calls behind it - a push that waits for
+    room and a finish used to wait for ever, and the error itself was masked by "not between init and finish"."""
+    from juicer_amd import capi, synth
+    monkeypatch.setenv("JD_BROKER_RESIDENT", resident)
+    monkeypatch.setenv("JD_BROKER_FAIL_INIT", "0")
+    am, net, feats, _ = synth.config_small(n_utts=2)
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    kw = dict(main_beam=150.0)
+    want = capi.Decoder(gnet, gam, max_streams=2, **kw).decode_batch(feats)
+    dec = capi.Decoder(gnet, gam, max_streams=2, **kw)
+    broker = capi.Broker(dec)
+    res = {}
+
+    def doomed():
+        c = broker.open()
+        assert c == 0
+        codes = []
+        broker.init(c)
+        try:
+            for _ in range(40):                                        # far more than a client may have pending: a push has to wait for room
+                broker.push(c, feats[0][:100])
+            codes.append(None)
+        except capi.JuicerAmdError as e:
+            codes.append((e.code, "injected" in str(e)))
+        try:
+            broker.finish(c)
+            codes.append(None)
+        except capi.JuicerAmdError as e:
+            codes.append((e.code, "injected" in str(e)))
+        res["doomed"] = codes
+        broker.close_client(c)
+
+    def fine():
+        import time
+        time.sleep(0.05)
+        c = broker.open()
+        broker.init(c)
+        broker.push(c, feats[1])
+        res["fine"] = broker.finish(c)
+        broker.close_client(c)
+    ths = [threading.Thread(daemon=True, target=doomed), threading.Thread(daemon=True, target=fine)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(60)
+    assert not any(t.is_alive() for t in ths), "a caller hangs behind the failed init"
+    assert res["doomed"] == [(capi.JD_EHIP, True), (capi.JD_EHIP, True)], res["doomed"]
+    assert bit_exact(res["fine"], want[1])
+    broker.close()
+    dec.close()
