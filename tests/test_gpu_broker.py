@@ -439,9 +439,11 @@ def test_failed_init_wakes_its_callers(built, resident, monkeypatch):
     broker = capi.Broker(dec)
     res = {}
 
+    c_doomed, c_fine = broker.open(), broker.open()                   # (both open from the start: the injection goes by client number)
+    assert c_doomed == 0
+
     def doomed():
-        c = broker.open()
-        assert c == 0
+        c = c_doomed
         codes = []
         broker.init(c)
         try:
@@ -459,9 +461,7 @@ def test_failed_init_wakes_its_callers(built, resident, monkeypatch):
         broker.close_client(c)
 
     def fine():
-        import time
-        time.sleep(0.05)
-        c = broker.open()
+        c = c_fine
         broker.init(c)
         broker.push(c, feats[1])
         res["fine"] = broker.finish(c)
