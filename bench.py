@@ -327,12 +327,15 @@ def main():
                     help="score every batch's table right before its search (serial) instead of beside the previous batch's search")
     ap.add_argument("--no-search-ahead", action="store_true",
                     help="one batch in flight: the decoder gets streams for one batch only and the announcements run one batch ahead")
-    ap.add_argument("--pipeline-depth", type=int, default=6,
+    ap.add_argument("--pipeline-depth", type=int, default=9,
                     help="weak scaling: batches announced ahead of the one being decoded, through the resident search kernel "
                          "(JD_PIPELINE=3: every stream a one-workgroup slot that takes the next queued utterance when its own is through); "
                          "0 = two batches in flight, one launch per step (what runs with several ranks) - measured on one box, 20 steps: "
                          "30.7-30.8 ms per step against 26.7 with six batches ahead through 160 slots")
-    ap.add_argument("--pipeline-slots", type=int, default=160, help="streams (= workgroups) of the resident pipeline; the other CUs score")
+    ap.add_argument("--pipeline-slots", type=int, default=256,
+                    help="streams (= one-workgroup slots) of the resident pipeline: two slots per CU on half of the chip (the slot kernel, csrc/jd_slot.h), "
+                         "the other CUs score - measured on one box: 192 slots 1.68 M frames/s, 256 slots 1.80 M (nine batches ahead; 1.65 M with six), "
+                         "320 slots 1.72 M (the scoring starves them); round 4's 160 one-per-CU slots of k_resident: 1.60 M")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="several ranks: 0 = the 1-best records of all timed steps travel in ONE RCCL all_gather at the end of the timed "
                          "region, behind jd_dec_quiesce (a rank has its own results at once; a collective's kernels must not be queued on a "
@@ -677,8 +680,8 @@ def main():
                       "gather": None if world == 1 else ("one all_gather per step" if per_step_gather else
                                                          "ONE all_gather of the %d steps' records at the end of the timed region (inside it), behind jd_dec_quiesce" % steps),
                       "pipeline_error": pipeline_error,
-                      "pipeline": ("resident search kernel: %d one-workgroup slots, the other CUs score; announcements %d batches ahead, a slot takes "
-                                   "the next queued utterance when its own is through" % (args.pipeline_slots, depth)) if depth else None,
+                      "pipeline": ("resident slot kernel: %d one-workgroup slots, two per CU, the other CUs score; announcements %d batches ahead, a slot takes "
+                                   "the next queued utterance (longest first) when its own is through" % (args.pipeline_slots, depth)) if depth else None,
                       "predicted_rank_ms": predicted_rank_ms if strong else None,
                       "search_ahead_frames_per_step": int(acc["ahead_frames"] // max(steps, 1)),
                       "streams_per_gpu": dec.max_streams},
@@ -702,7 +705,7 @@ def main():
             elif two_in_flight:                                     # ... or through the resident search kernel, six of them ahead
                 legs["configs1_through_the_resident_kernel"] = run_leg("configs[1], batches through the resident kernel utterance by utterance "
                                                                        "(JD_PIPELINE=3: 160 one-workgroup slots, six batches ahead)", am, net, feats,
-                                                                       args.beam, args.max_hyps, dev, pipe=(6, 160), passes=10)
+                                                                       args.beam, args.max_hyps, dev, pipe=(9, 256), passes=14)
             # configs[2]'s batch (512 utterances) on ONE GPU: waves of 128 streams inside one call, each wave's table scored
             # beside the wave before it - what the GPU does when a batch is not bounded by its longest utterance
             _, _, f512, _ = synth.config_c2(seed=args.seed, n_utts=512, target_arcs=args.arcs)

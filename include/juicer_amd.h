@@ -488,6 +488,9 @@ typedef struct jd_timing {
                                  span of that scoring beside the previous search, and gmm_wait_ms what was left of it */
     int32_t ahead_frames;     /* frames of this batch that had been searched beside the batch before it ("two batches in
                                  flight": announcements two batches ahead, a batch on at most half of the streams) */
+    int32_t slot_launches;    /* of search_launches: launches of the slot kernel (csrc/jd_slot.h: one workgroup per stream, two per
+                                 CU - batches of more streams than the chip has CUs) */
+    int32_t pad0;
 } jd_timing;
 int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 

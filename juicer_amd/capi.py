@@ -48,7 +48,7 @@ class Timing(C.Structure):
                 ("gmm_launches", C.c_int32), ("search_launches", C.c_int32),
                 ("relaunches", C.c_int32), ("cluster_wgs", C.c_int32),
                 ("gmm_frames", C.c_int64), ("gmm_states", C.c_int64), ("search_frames", C.c_int64),
-                ("prefetched", C.c_int32), ("ahead_frames", C.c_int32)]
+                ("prefetched", C.c_int32), ("ahead_frames", C.c_int32), ("slot_launches", C.c_int32), ("pad0", C.c_int32)]
 
 
 FLOW_SERIAL, FLOW_TWO_IN_FLIGHT, FLOW_RESIDENT = 0, 1, 3      # jd_dec_set_pipeline

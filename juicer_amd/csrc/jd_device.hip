@@ -94,6 +94,7 @@ __device__ __forceinline__ int rank_in(unsigned long long bal)
 // ------------------------------------------- Path collection, partial trace, finish, launch helpers
 #include "jd_gc.h"
 #include "jd_resident.h"
+#include "jd_slot.h"
 
 // --------------------------------------------------------------- host runtime
 
@@ -417,6 +418,7 @@ struct jd_dec {
     int *d_row_src[3] = {nullptr, nullptr, nullptr}; size_t row_src_cap[3] = {0, 0, 0};   // row -> source frame tables, one per likelihood table
     int *d_T = nullptr;
     hipStream_t s_gmm = nullptr, s_search = nullptr;
+    unsigned *h_park = nullptr; int *d_park = nullptr;   // jd_park_kernel's words (host-mapped state; arrival counts and quotas by XCD)
     // scoring one batch ahead (jd_dec_prefetch_scores): the table of the NEXT batch is scored while this one is searched
     std::deque<Prefetch> pf_q;            // the batches ahead, in the order announced: scored, started ("two batches in flight"), or neither yet
     int fg_buf = -1;                      // the table(s) the wave being decoded uses (-1: none; -2: tables 0 and 1, in chunks)
@@ -533,6 +535,8 @@ extern "C" void jd_dec_destroy(jd_dec *d)
     if (d->h_status) (void)hipHostFree(d->h_status);
     if (d->s_gmm) (void)hipStreamDestroy(d->s_gmm);
     if (d->s_search) (void)hipStreamDestroy(d->s_search);
+    if (d->h_park) (void)hipHostFree(d->h_park);
+    if (d->d_park) (void)hipFree(d->d_park);
     for (hipStream_t st : d->res_old_streams) (void)hipStreamDestroy(st);
     delete d;
 }
@@ -1433,6 +1437,15 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
                            hold_replan ? 1 : 0);
         HIPCHK(hipEventRecord(e0, st));
         // the kernel flavour: HMM size class x XCD-local x lazily composed graph
+        // More streams than the chip has CUs, one workgroup each: the slot kernel as a plain launch (jd_slot.h: k_slot_batch) - a
+        // workgroup per stream, two per CU, the dispatcher deals the next one when one leaves - instead of k_search's
+        // one-per-CU workgroups that take their streams one after the other.  (JD_SLOT_BATCH=1 / 0, development: always / never.)
+        bool slot_batch = A.n_slots > 0 && A.Cw == 1 && n_bg == 0 && n_work > nwg_all && !d->C.lazy && !A.cells;
+        if (const char *e = jd_dev_env("JD_SLOT_BATCH")) slot_batch = atoi(e) != 0 && A.Cw == 1 && n_bg == 0 && !d->C.lazy && !A.cells && (A.n_slots > 0 || n_work == 1);
+        if (slot_batch) {
+            if (ne3) hipLaunchKernelGGL(k_slot_batch<3>, dim3((unsigned)n_work), dim3(SNT), 0, st, A);
+            else hipLaunchKernelGGL(k_slot_batch<6>, dim3((unsigned)n_work), dim3(SNT), 0, st, A);
+        } else
         hipLaunchKernelGGL(search_kernel(ne3, xl, d->C.lazy != nullptr), dim3(grid), dim3(SNT), 0, st, A);
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipGetLastError());
@@ -1453,8 +1466,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
         if (getenv("JD_VERBOSE")) {                                        // development
             int cmin = 1 << 30, cmax = 0;
             for (const int4 &w : work) { cmin = std::min(cmin, w.w & 0xffff); cmax = std::max(cmax, w.w & 0xffff); }
-            fprintf(stderr, "k_search: %d streams, grid %d (clusters %d..%d workgroups, %s%s), frames [%d, %d): %.3f ms\n", n_work, grid,
-                    cmin, cmax, A.n_slots ? "uniform" : "weighted", xl ? ", XCD-local" : "", f0, f_end, ms);
+            fprintf(stderr, "%s: %d streams, grid %d (clusters %d..%d workgroups, %s%s), frames [%d, %d): %.3f ms\n", slot_batch ? "k_slot_batch" : "k_search", n_work,
+                    slot_batch ? n_work : grid, cmin, cmax, A.n_slots ? "uniform" : "weighted", xl ? ", XCD-local" : "", f0, f_end, ms);
             if (d->h_status[3]) fprintf(stderr, "          cut short for a re-plan: %d streams go on\n", d->h_status[0]);
         }
         if (d->h_status[1] != 0) {
@@ -1464,6 +1477,7 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             if (getenv("JD_VERBOSE")) fprintf(stderr, "k_search: %d cluster(s) not on one XCD - agent-scope launches from here on\n", d->h_status[1]);
         }
         d->timing.search_launches += 1;
+        if (slot_batch) d->timing.slot_launches += 1;
         d->timing.cluster_wgs = A.Cw;
         if (d->h_status[0] == 0 && d->h_status[1] == 0) break;
         d->timing.relaunches += 1;
@@ -2366,6 +2380,7 @@ extern "C" int jd_streams_push(jd_dec *d, int32_t n, const int32_t *streams, con
 struct Resident {
     bool on = false;
     int n = 0, Cw = 0, rows = 0;                       // streams [0, n), workgroups per cluster, rows per likelihood buffer
+    bool slot = false;                                 // one workgroup per stream: the slot kernel (jd_slot.h), SLOT_WG_PER_CU of them per CU
     ResMail *d_mail = nullptr;
     ResPost *h_post = nullptr;                         // host-mapped: the commands
     ResDone *h_done = nullptr;                         // host-mapped: the reports
@@ -2387,6 +2402,7 @@ struct Resident {
     std::unique_lock<std::mutex> search_lock;
     GpuLockGuard *process_lock = nullptr;
     std::chrono::steady_clock::time_point t_start;     // when the kernel was last started (jd_dec_pipeline_stats: time on the device)
+    hipStream_t st = nullptr;                          // the stream the kernel runs on (the decoder's search stream, or its CU-masked slot stream)
 };
 
 static void res_free(jd_dec *d);
@@ -2438,7 +2454,7 @@ int jd_res_stop(jd_dec *d)
     if (!d->res || !d->res->on) return JD_OK;
     Resident *R = d->res;
     for (int s = 0; s < R->n; ++s) __atomic_store_n(&R->h_post[s].exit_req, 1, __ATOMIC_RELEASE);
-    hipError_t e = hipStreamSynchronize(d->s_search);                  // (it also leaves by itself after RES_IDLE_TICKS)
+    hipError_t e = hipStreamSynchronize(R->st ? R->st : d->s_search);  // (it also leaves by itself after RES_IDLE_TICKS)
     (void)hipStreamSynchronize(d->s_gmm);
     // (a cluster takes a command that is there before it looks at the exit request: whatever was posted is through)
     bool lost = false;
@@ -2478,9 +2494,9 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
         d->res = R;
         R->n = n_streams; R->rows = rows;
         const size_t tr = (size_t)n_streams * 2 * rows;
-        if (n_streams > 256 || 2 * n_streams * ((rows + GMM_ROWS2 - 1) / GMM_ROWS2) > RES_RING_W) {
+        if (n_streams > 1024 || 2 * n_streams * ((rows + GMM_ROWS2 - 1) / GMM_ROWS2) > RES_RING_W) {
             res_free(d);
-            return jd_fail(JD_EINVAL, "jd_res_start: at most 256 streams and %d row tiles per scoring launch", RES_RING_W);
+            return jd_fail(JD_EINVAL, "jd_res_start: at most 1024 streams and %d row tiles per scoring launch", RES_RING_W);
         }
         if (hipMalloc(&R->d_mail, (size_t)n_streams * sizeof(ResMail)) != hipSuccess ||
             hipHostMalloc((void **)&R->h_post, (size_t)n_streams * sizeof(ResPost), hipHostMallocMapped) != hipSuccess ||
@@ -2507,11 +2523,6 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     Resident *R = d->res;
     if (R->on) return JD_OK;
     const bool ne3 = d->am->max_n <= 5;
-    if (!d->occupancy_ok) {
-        int per_cu = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ne3 ? (const void *)k_resident<3, false> : (const void *)k_resident<6, false>, SNT, 0));
-        if (per_cu < WG_PER_CU) return jd_fail(JD_EHIP, "k_resident does not fit a CU the way its grid assumes");
-    }
     // clusters: what the arenas allow, and a sixth of the chip left to the scoring, collection and finish kernels
     const int cw_cap = (int)std::max<int64_t>(1, std::min<int64_t>(d->cap_slots / (64 * SW), d->cap_items / (512 * SW)));
     // (the scoring of what the streams search: about 1.6 CUs per stream at their pace, and a quarter of the chip at least -
@@ -2519,7 +2530,22 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     int free_cus = std::min(d->n_cus / 2, std::max(d->n_cus / 4, (n_streams * 8) / 5));
     if (const char *e = jd_dev_env("JD_RES_FREE_CUS")) { const int v = atoi(e); if (v >= 0 && v < d->n_cus) free_cus = v; }   // development
     R->Cw = std::max(1, std::min(std::min(d->max_cw, cw_cap), (d->n_cus * WG_PER_CU - free_cus) / n_streams));
-    if (R->Cw * n_streams > d->n_cus * WG_PER_CU) return jd_fail(JD_EINVAL, "jd_res_start: %d streams do not fit the device", n_streams);
+    if (d->res_ll) R->Cw = 1;                                          // (the batch pipeline: every stream a slot of ONE workgroup, however few they are)
+    // One workgroup per stream: the slot kernel (jd_slot.h) - compiled for four waves per SIMD, SLOT_WG_PER_CU workgroups per CU,
+    // every per-frame word in LDS.  (JD_RES_SLOT=0, development: k_resident's one-workgroup clusters, one per CU.)
+    R->slot = R->Cw == 1;
+    if (const char *e = jd_dev_env("JD_RES_SLOT")) R->slot = R->slot && atoi(e) != 0;
+    {
+        int per_cu = 0;
+        const void *kf = R->slot ? (ne3 ? (const void *)k_slot<3> : (const void *)k_slot<6>)
+                                 : (ne3 ? (const void *)k_resident<3, false> : (const void *)k_resident<6, false>);
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kf, SNT, 0));
+        const int need = R->slot ? SLOT_WG_PER_CU : WG_PER_CU;
+        if (per_cu < need)
+            return jd_fail(R->slot ? JD_EINVAL : JD_EHIP, "%s: %d workgroup(s) per CU fit, %d streams on %d CUs need %d", R->slot ? "k_slot" : "k_resident",
+                           per_cu, n_streams, d->n_cus, need);
+    }
+    if (!R->slot && R->Cw * n_streams > d->n_cus * WG_PER_CU) return jd_fail(JD_EINVAL, "jd_res_start: %d streams do not fit the device", n_streams);
     memset(R->h_done, 0, (size_t)R->n * sizeof(ResDone));
     memset(R->h_post, 0, (size_t)R->n * sizeof(ResPost));
     std::fill(R->seq.begin(), R->seq.end(), 0u);
@@ -2545,10 +2571,11 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     memset(&A, 0, sizeof A);
     A.C = d->C; A.ctl = d->d_ctl; A.streams = d->d_streams; A.work = nullptr; A.n_work = R->n; A.Cw = R->Cw; A.n_slots = 0;
     A.ll = d->res_ll ? d->res_ll : R->d_ll; A.ll_stride = (long long)G; A.f0 = 0; A.f_end = 0x7fffffff;
-    A.status = d->d_status; A.dbg = nullptr; A.cells = nullptr; A.resident = nullptr; A.rebalance_at = 0; A.n_prio = 0;
+    A.status = d->d_status; A.dbg = d->d_dbg; A.cells = nullptr; A.resident = nullptr; A.rebalance_at = 0; A.n_prio = 0;   // (dbg: jd_dec_debug_trace)
     const dim3 rgrid((unsigned)(R->n * R->Cw));
     // (one workgroup per stream: the XCD-local flavour of the memory operations - a cluster of one sits on one XCD)
     bool xl = R->Cw == 1;
+    const bool slot = R->slot;
     if (const char *e = jd_dev_env("JD_RES_XL")) xl = xl && atoi(e) != 0;   // development
     typedef void (*ResKernel)(SearchArgs, const ResPost *, ResMail *, const unsigned *, ResDone *, int, const unsigned *);
     const ResKernel rk = ne3 ? (xl ? k_resident<3, true> : k_resident<3, false>) : (xl ? k_resident<6, true> : k_resident<6, false>);
@@ -2557,15 +2584,60 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     // (tools/resident_alias_probe.py: one fresh stream in fourteen lands behind the kernel), so the kernel is started, a
     // small kernel is sent down the side stream and the null stream, and if either has not come back in 150 ms the
     // resident kernel leaves again and comes back on a NEW search stream - a few times, then it is an error.
+    // Where the slots go (jd_slot.h, jd_park_kernel): the CUs the scoring keeps are parked while the slot kernel's grid is dealt.
+    R->st = d->s_search;
+    int park_cus = 0;
+    if (slot) {
+        int cus = std::min(d->n_cus, (R->n + SLOT_WG_PER_CU - 1) / SLOT_WG_PER_CU);
+        if (const char *e2 = jd_dev_env("JD_SLOT_CUS")) { const int v = atoi(e2); if (v >= 1 && v <= d->n_cus && v * SLOT_WG_PER_CU >= R->n) cus = v; if (v == 0) cus = d->n_cus; }
+        // (whole CUs per shader engine: 32 engines of n_cus / 32 CUs each, every one keeps the same number for the slots)
+        const int per_se = std::max(1, d->n_cus / 32);
+        const int keep_se = std::min(per_se, (cus + 31) / 32);
+        park_cus = (per_se - keep_se) * 32;
+        if (park_cus > 0 && !d->h_park) {
+            if (hipHostMalloc((void **)&d->h_park, 64, hipHostMallocMapped) != hipSuccess || hipMalloc(&d->d_park, 64 * sizeof(int)) != hipSuccess) {
+                (void)hipGetLastError();
+                park_cus = 0;
+            }
+        }
+    }
     hipError_t e = hipSuccess;
     bool clear = false;
     ReadyList none; none.n = 0;
     struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev_side, ev_null;
     HIPCHK(hipEventCreateWithFlags(&ev_side.e, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_null.e, hipEventDisableTiming));
     for (int attempt = 0; attempt < 8 && !clear; ++attempt) {
-        hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, d->s_search, d->d_ctl, R->d_mail, R->d_ready, R->n);
+        hipLaunchKernelGGL(jd_res_reset_kernel, dim3((R->n + 63) / 64), dim3(64), 0, R->st, d->d_ctl, R->d_mail, R->d_ready, R->n);
         __atomic_fetch_add(R->h_beat, 1u, __ATOMIC_RELEASE);
-        hipLaunchKernelGGL(rk, rgrid, dim3(SNT), 0, d->s_search, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw, R->h_beat);
+        if (slot) {
+            bool parked = false;
+            if (park_cus > 0) {
+                // the CUs of every XCD that the slots are NOT to get: parked until the slots are on theirs
+                d->h_park[0] = d->h_park[1] = d->h_park[2] = d->h_park[3] = d->h_park[4] = 0u;
+                if (hipMemsetAsync(d->d_park, 0, 64 * sizeof(int), d->s_gmm) == hipSuccess) {
+                    hipLaunchKernelGGL(jd_park_kernel, dim3((unsigned)d->n_cus), dim3(64), 0, d->s_gmm, (unsigned *)d->d_park, park_cus / 32, d->h_park);
+                    parked = hipGetLastError() == hipSuccess;
+                }
+                const auto tp = std::chrono::steady_clock::now();
+                while (parked && __atomic_load_n(&d->h_park[0], __ATOMIC_ACQUIRE) + __atomic_load_n(&d->h_park[1], __ATOMIC_ACQUIRE) < (unsigned)d->n_cus &&
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count() < 50.0)
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            unsigned *started = parked ? d->h_park + 4 : nullptr;
+            if (ne3) hipLaunchKernelGGL(k_slot<3>, rgrid, dim3(SNT), 0, R->st, A, R->h_post, R->d_ready, R->h_done, R->h_beat, started);
+            else hipLaunchKernelGGL(k_slot<6>, rgrid, dim3(SNT), 0, R->st, A, R->h_post, R->d_ready, R->h_done, R->h_beat, started);
+            if (parked) {                                              // every slot is on its CU (or 100 ms are over): the parked CUs are the scoring's
+                const auto tp = std::chrono::steady_clock::now();
+                while (__atomic_load_n(&d->h_park[4], __ATOMIC_ACQUIRE) < (unsigned)R->n &&
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count() < 100.0)
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                if (getenv("JD_VERBOSE"))
+                    fprintf(stderr, "k_slot: %u CUs parked (%u left free), %u of %d slots on their CUs after %.2f ms\n", d->h_park[0], d->h_park[1], d->h_park[4], R->n,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count());
+                __atomic_store_n(&d->h_park[2], 1u, __ATOMIC_RELEASE);
+            }
+        } else
+        hipLaunchKernelGGL(rk, rgrid, dim3(SNT), 0, R->st, A, R->h_post, R->d_mail, R->d_ready, R->h_done, R->Cw, R->h_beat);
         e = hipGetLastError();
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(jd_res_ready_kernel, dim3(1), dim3(64), 0, d->s_gmm, R->d_ready, none);
@@ -2580,16 +2652,18 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
         if (clear) break;
         // behind the kernel: it leaves (the exit word), what waited for it runs, and the search stream is made anew
         for (int t = 0; t < R->n; ++t) __atomic_store_n(&R->h_post[t].exit_req, 1, __ATOMIC_RELEASE);
-        (void)hipStreamSynchronize(d->s_search);
+        (void)hipStreamSynchronize(R->st);
         (void)hipEventSynchronize(ev_side.e); (void)hipEventSynchronize(ev_null.e);
         memset(R->h_post, 0, (size_t)R->n * sizeof(ResPost));
         memset(R->h_done, 0, (size_t)R->n * sizeof(ResDone));
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         hipStream_t fresh = nullptr;
-        if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio_hi) != hipSuccess) { e = hipErrorUnknown; break; }
-        d->res_old_streams.push_back(d->s_search);                     // (destroyed with the decoder: somebody may still hold it)
-        d->s_search = fresh;
+        {
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio_hi) != hipSuccess) { e = hipErrorUnknown; break; }
+            d->res_old_streams.push_back(d->s_search);                 // (destroyed with the decoder: somebody may still hold it)
+            d->s_search = fresh; R->st = fresh;
+        }
         if (getenv("JD_VERBOSE")) fprintf(stderr, "k_resident: the side stream or the null stream was queued behind it - a new search stream (%d)\n", attempt + 1);
     }
     if (e != hipSuccess || !clear) {
@@ -2599,7 +2673,8 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     }
     R->on = true;
     R->t_start = std::chrono::steady_clock::now();
-    if (getenv("JD_VERBOSE")) fprintf(stderr, "k_resident: %d streams, clusters of %d workgroups, %d rows per buffer\n", R->n, R->Cw, R->rows);
+    if (getenv("JD_VERBOSE")) fprintf(stderr, "%s: %d streams, clusters of %d workgroups, %d rows per buffer%s\n", R->slot ? "k_slot" : "k_resident", R->n, R->Cw, R->rows,
+                                      park_cus > 0 ? " (the other CUs parked while its grid was dealt)" : "");
     return JD_OK;
 }
 
@@ -2792,6 +2867,7 @@ struct PipeBatch {
     size_t rows = 0, rows_scored = 0;                  // rows of its table, and how many of them have a scoring launch enqueued
     std::vector<int64_t> offs;
     std::vector<PipeUtt> u;
+    std::vector<int> order;                            // its utterances by length, longest first: the order in which slots take them
 };
 struct Pipe {
     bool on = false;
@@ -2929,7 +3005,7 @@ static int pipe_pump(jd_dec *d)
         while (bi < P->q.size() && P->q[bi].next >= P->q[bi].n) ++bi;
         if (bi >= P->q.size() || P->q[bi].rows_scored < P->q[bi].rows) break;
         PipeBatch &B = P->q[bi];
-        const int ui = B.next++;
+        const int ui = B.order[(size_t)B.next++];                      // (longest first: a batch is handed back when its LAST utterance is through)
         B.u[(size_t)ui].state = 1; B.u[(size_t)ui].slot = s;
         P->slot_batch_id[(size_t)s] = (int)(P->serial0 + (long long)bi); P->slot_utt[(size_t)s] = ui;
         who.push_back(s); what.push_back(std::make_pair((int)bi, ui));
@@ -3072,6 +3148,9 @@ static int pipe_announce(jd_dec *d, int n_utts, const float *d_feats, const int6
     B.u.resize((size_t)n_utts);
     const long long base = (long long)t * (long long)P->table_rows;
     for (int u = 0; u < n_utts; ++u) { B.u[(size_t)u].T = (int)(offs[u + 1] - offs[u]); B.u[(size_t)u].row0 = base + (offs[u] - offs[0]); }
+    B.order.resize((size_t)n_utts);
+    std::iota(B.order.begin(), B.order.end(), 0);
+    std::stable_sort(B.order.begin(), B.order.end(), [&](int a, int b) { return B.u[(size_t)a].T > B.u[(size_t)b].T; });
     B.rows = rows; B.rows_scored = 0;                                  // (scored by the pump, a piece at a time, on the CUs the slots leave)
     P->q.push_back(std::move(B));
     *taken = 1;

@@ -67,15 +67,15 @@ def test_fullsize_64_stream_batch_oracle_parity(built):
         assert bit_exact(gs[u], want[u]), u
     assert all(h.n > 0 for h in gs)
     gd.close()
-    # ... and the same batches the way bench.py runs them: through the resident kernel's 160 one-workgroup slots,
-    # announcements six batches ahead (jd_dec_set_pipeline: JD_FLOW_RESIDENT, seven deep) - every utterance of every
+    # ... and the same batches the way bench.py runs them: through the slot kernel's 256 one-workgroup slots (two per CU),
+    # announcements nine batches ahead (jd_dec_set_pipeline: JD_FLOW_RESIDENT, ten deep) - every utterance of every
     # batch DIRECTLY against the oracle (words, times, the reference's statistics, scores bit for bit), not against the launch above
-    gp = capi.Decoder(gnet, gam, max_streams=160, **kw)
-    gp.set_pipeline(capi.FLOW_RESIDENT, 7, 160)
+    gp = capi.Decoder(gnet, gam, max_streams=256, **kw)
+    gp.set_pipeline(capi.FLOW_RESIDENT, 10, 256)
     f0 = gp.pipeline_stats()["frames_searched"]
-    for _ in range(6):
+    for _ in range(9):
         gp.prefetch_scores(d_feats.data_ptr(), offs, 0)
-    n_steps = 9
+    n_steps = 12
     for step in range(n_steps):
         if step < 3:
             gp.prefetch_scores(d_feats.data_ptr(), offs, 0)

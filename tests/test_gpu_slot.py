@@ -1,0 +1,121 @@
+"""The slot kernel (csrc/jd_slot.h: one workgroup per stream, every per-frame word in LDS, compiled for two workgroups per CU)
+against the CPU oracle.  The batch pipeline runs it under a mailbox (tests/test_gpu_parity.py::test_batches_through_the_resident_kernel,
+tests/test_gpu_fullsize.py); here it is the plain launch k_slot_batch that launch_search takes for batches of more streams than
+the chip has CUs - forced at toy size with the development knobs JD_CW=1 (one workgroup per stream) + JD_SLOT_BATCH=1 - so that
+every corner the cluster kernel is tested on is tested on this one too: all pruning combinations, the tee model, HMMs of 1-6
+emitting states (the other record layout), Path collections inside an utterance, the streaming calls with pushes of odd sizes,
+partial traces on the reference's count rule, and a batch of more utterances than CUs."""
+import numpy as np
+import pytest
+
+from helpers import assert_hyp_matches, bit_exact, oracle_certified_many
+
+pytestmark = pytest.mark.gpu
+
+BEAMS = [
+    dict(),
+    dict(main_beam=200.0),
+    dict(main_beam=150.0, end_beam=100.0, word_beam=80.0, start_beam=120.0),
+    dict(main_beam=150.0, max_hyps=200),
+    dict(max_hyps=300),
+    dict(main_beam=120.0, end_beam=90.0, word_beam=70.0, start_beam=100.0, max_hyps=150),
+]
+
+
+@pytest.fixture()
+def slot_kernel(monkeypatch, built):
+    monkeypatch.setenv("JD_DEV", "1")
+    monkeypatch.setenv("JD_CW", "1")
+    monkeypatch.setenv("JD_SLOT_BATCH", "1")
+    return True
+
+
+def _cfg(name):
+    from juicer_amd import synth
+    return {"toy": synth.config_toy, "small": synth.config_small, "mixed": synth.config_mixed}[name]()
+
+
+@pytest.mark.parametrize("cfg", ["toy", "small", "mixed"])
+@pytest.mark.parametrize("bi", range(len(BEAMS)))
+def test_slot_kernel_decode(slot_kernel, cfg, bi):
+    from juicer_amd import capi
+    am, net, feats, _ = _cfg(cfg)
+    kw = BEAMS[bi]
+    big = (1 << 25) if kw.get("main_beam", 0.0) in (0.0, 200.0) and not kw.get("max_hyps") else 0
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=len(feats), max_paths=big, **kw)
+    gs = gd.decode_batch(feats)
+    tm = gd.last_timing()
+    assert tm["slot_launches"] == tm["search_launches"] > 0, tm        # (every launch was the slot kernel's)
+    want = oracle_certified_many(net, am, feats, **kw)
+    for u, o in enumerate(want):
+        assert_hyp_matches(gs[u], o, "%s utt %d %s" % (cfg, u, kw))
+        assert bit_exact(gs[u], o), (cfg, u, kw)
+    gd.close()
+
+
+def test_slot_kernel_path_collections_and_streaming(slot_kernel):
+    """Path arenas so small that a stream stops for collections inside its utterance (the launch is repeated for what is left),
+    and the streaming calls: init / push x n / finish with pushes of odd sizes - the lists a command leaves in HBM are what
+    the next one finds."""
+    from juicer_amd import capi, synth
+    am, net, feats, _ = synth.config_small(n_utts=6)
+    gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+    kw = dict(main_beam=150.0)
+    want = oracle_certified_many(net, am, feats, **kw)
+    gd = capi.Decoder(gnet, gam, max_streams=len(feats), max_paths=1 << 12, **kw)
+    gs = gd.decode_batch(feats)
+    tm = gd.last_timing()
+    assert tm["relaunches"] > 0 and tm["slot_launches"] == tm["search_launches"], tm
+    for u, o in enumerate(want):
+        assert bit_exact(gs[u], o), u
+    gd.close()
+    gd = capi.Decoder(gnet, gam, max_streams=2, **kw)
+    for u, step in ((0, 1), (1, 7), (2, 37), (3, 128), (4, 1000)):
+        s = u % 2
+        gd.stream_init(s)
+        for i in range(0, feats[u].shape[0], step):
+            gd.stream_push(s, feats[u][i:i + step])
+        assert bit_exact(gd.stream_finish(s), want[u]), (u, step)
+    gd.close()
+
+
+def test_slot_kernel_more_utterances_than_cus(built):
+    """What launch_search takes the slot kernel for WITHOUT any knob: one call with more utterances (and streams) than the chip
+    has CUs - a workgroup per stream, two per CU, the dispatcher deals the next one when one leaves."""
+    import torch
+    from juicer_amd import capi, synth
+    am, net, feats, _ = synth.config_small(n_utts=24)
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    many = [feats[u % len(feats)] for u in range(n_cus + 40)]
+    kw = dict(main_beam=150.0, max_hyps=200)
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=len(many), **kw)
+    gs = gd.decode_batch(many)
+    tm = gd.last_timing()
+    assert tm["slot_launches"] > 0 and tm["slot_launches"] == tm["search_launches"], tm
+    want = oracle_certified_many(net, am, feats, **kw)
+    for u, g in enumerate(gs):
+        assert bit_exact(g, want[u % len(feats)]), u
+    gd.close()
+
+
+def test_slot_kernel_partial_traces(slot_kernel):
+    """PARTIAL_DECODING through the slot kernel: the collections run after the oracle's own frames (frame rule and the count
+    rule on the reference's Path counts) and every trace is the oracle's."""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_small(n_utts=2)
+    kw = dict(main_beam=150.0)
+    od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=1, **kw)
+    gd.set_partial_interval(30)
+    for u in range(2):
+        snaps, final = od.decode_partial(feats[u], interval=30)
+        gd.stream_init(0)
+        for i in range(0, feats[u].shape[0], 16):
+            gd.stream_push(0, feats[u][i:i + 16])
+        n_coll, last = gd.stream_collect_info(0)
+        assert n_coll == len(od.collect_frames) and (last == od.collect_frames[-1] if od.collect_frames else last == -1), (n_coll, od.collect_frames)
+        h = gd.stream_finish(0)
+        _, got = gd.stream_partial(0)
+        assert got == final and h.n > 0, u
+    gd.close()
