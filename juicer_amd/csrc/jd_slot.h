@@ -26,14 +26,22 @@
 #endif
 #define SLOT_WG_PER_CU (SLOT_WPE * 4 / SW)
 #define JDE_GEOM -47                 // a stream in the middle of an utterance whose lists were written with another geometry
+#define SLOT_TRP_MAX 2048            // floats of transition tables cached in LDS (else read from HBM)
+#define SLOT_LL_MAX 3072             // tied states whose likelihoods of the frame are staged in LDS (else gathered from HBM)
 
 struct SlotShared {
     // fill counts of the stream's wave-segmented lists (what StreamDev::tot holds between commands)
     int c_rec[2][SW], c_new[SW], c_dirty[2][SW], c_exit[SW], c_cl[2][SW], c_cls[2][SW];
     int pfx[3][SW + 1];                        // phase A: entries before every segment of its three lists (records, new arcs, keys to zero)
     int hist[2][HIST_MAX_BINS];                // Histogram bins by frame parity (this frame's, the previous frame's)
-    float trP[TRP_LDS_MAX]; int se[TRP_LDS_MAX / 4];
-    float tee[TEE_LDS_MAX];
+    float trP[SLOT_TRP_MAX]; int se[SLOT_TRP_MAX / 4];
+    float tee[TEE_LDS_MAX];                    // per HMM: tee transition log-probability ...
+    float tmax[TEE_LDS_MAX];                   // ... and the largest log transition probability out of the entry state (phase X's filter)
+    // The frame's likelihood row.  Phase A gathers three values per instance from it, each a wave instruction that touches up to 64
+    // cache lines of a 12 KB row - and the vector L1 looks up ONE line per cycle: under the counters (profiles/r05_slot_pmc) the L1 of
+    // a CU was busy 88 % of the launch and the gathers a third of phase A's lines.  So the row is brought into LDS once per frame -
+    // by LDS-DMA (global_load_lds: no registers), issued behind phase A for the NEXT frame, landing while the expansion runs.
+    float ll[SLOT_LL_MAX];
     int wpfx[SW][64];                          // phase X: per wave, prefix of the out-degrees of its 64 items
     v4i qtok[SW][QCAP], qinfo[SW][QCAP];       // phase X: per wave, closure items it will expand itself
     int2 qrow[SW][QCAP];
@@ -49,6 +57,14 @@ struct SlotShared {
 };
 
 __device__ __forceinline__ void slot_err(SlotShared &sh, int code) { atomicCAS(&sh.err, 0, code); }
+// The thread's number, opaque to the optimiser.  Under the mailbox loop of k_slot everything a command computes once from the kernel's
+// arguments and the thread's number - loop bounds, list offsets, table addresses - is invariant ACROSS commands, and the compiler hoists
+// it out of that loop and keeps it in registers over everything (53 VGPRs spilled where the plain launch, the same code without a loop
+// around it, spills 7).  What depends on this value is computed where it is used.
+#ifndef SLOT_PHASE_TID
+#define SLOT_PHASE_TID ((int)threadIdx.x)
+#endif
+__device__ __forceinline__ int slot_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 __device__ __forceinline__ int slot_grab(int *next)
 {
     int k = 0;
@@ -68,7 +84,7 @@ __device__ __forceinline__ int slot_prefix8(int v, int &total)
 }
 
 // ------------------------------------------------------------------ phase A (see jd_search.h: phase_a)
-template <int NE, bool TRPL, bool LR>
+template <int NE, bool TRPL, bool LR, bool LLL>
 __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, const StreamView &V, const Geo &g, int Q0, int Q1, int Q2,
                                              int n0, int n1, int n2, int p, float normalise, float emitTh, float startTh,
                                              const float *llrow, int &out_cnt, int &exit_cnt)
@@ -76,7 +92,8 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
     constexpr bool XL_ = true;
     typedef RecLayout<NE> RL;
     constexpr int HF = RL::HF;
-    const int lane = threadIdx.x & 63, wid = RFL(threadIdx.x >> 6);
+    const int tid_ = SLOT_PHASE_TID;
+    const int lane = tid_ & 63, wid = RFL(tid_ >> 6);
     const int MN = C.max_n;
     const bool use_hist = C.max_hyps > 0;
     const float *trP_all = TRPL ? sh.trP : C.trP;
@@ -137,17 +154,23 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const int gj = (j == 0) ? h1.x : (j == 1) ? h1.y : (j == 2) ? h1.z : (j == 3) ? h2.x : (j == 4) ? h2.y : h2.z;
-                outp[j] = llrow[(j + 1 < n - 1) ? gj : 0];             // :411
+                outp[j] = LLL ? sh.ll[(j + 1 < n - 1) ? gj : 0] : llrow[(j + 1 < n - 1) ? gj : 0];   // :411
             }
             kv = ((unsigned long long)(unsigned)(p ? ev.y : ev.w) << 32) | (unsigned)(p ? ev.x : ev.z);
         }
         // entry token = the best token that arrived at the arc's source state in the previous frame, over the arc (:560-582)
         const v4i itv = ld16(V.items, kv != 0ULL ? iprev + (unsigned)(kv & 0xffffffffULL) * 32u : OOB_OFF);
+        // The item is a THIRD round trip behind the record and the key, and all that it brings is the entry token's history (ac, lm,
+        // path): its score is in the key.  Everything that decides - maxima, thresholds, the histogram - runs on scores; with plain
+        // left-to-right models only state 1 can take the entry token, so the item is taken up BEHIND the arithmetic (below), its
+        // round trip running beside it.  (General topologies: any state may take it - they wait for it here.)
         tk[0] = null_tok();
         if (kv != 0ULL) {
-            const Tok it = as_tok(itv);
             tk[0].score = o2f((unsigned)(kv >> 32)) + __int_as_float(h1.w);   // :562 newScore = tok.score + weight
-            tk[0].ac = it.ac; tk[0].lm = it.lm + __int_as_float(h1.w); tk[0].path = it.path;
+            if (!LR) {
+                const Tok it = as_tok(itv);
+                tk[0].ac = it.ac; tk[0].lm = it.lm + __int_as_float(h1.w); tk[0].path = it.path;
+            }
             if (tk[0].score < startTh) tk[0] = null_tok();            // :915-918 (a candidate is never LOG_ZERO)
         }
         Tok nw[NE + 1];
@@ -181,6 +204,7 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
                 const float4 v = lt[q];
                 tw[4 * q] = v.x; tw[4 * q + 1] = v.y; tw[4 * q + 2] = v.z; tw[4 * q + 3] = v.w;
             }
+            bool entry_won = false;
 #pragma unroll
             for (int j = 1; j <= NE; ++j) {                            // :387-424 emitting state j: predecessors j-1 and j
                 nw[j] = null_tok();
@@ -191,6 +215,13 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
                 src.score = 0.0f; src.ac = self ? tk[j].ac : tk[j - 1].ac; src.lm = self ? tk[j].lm : tk[j - 1].lm;
                 src.path = self ? tk[j].path : tk[j - 1].path;
                 if (j < n - 1) emit(j, self ? c1 : c0, self ? sf : a, src);
+                if (j == 1) entry_won = !self;
+            }
+            if ((live_mask & 2) && entry_won) {                        // state 1 took the entry token: its history, from the item (:562-566)
+                const Tok it = as_tok(itv);
+                nw[1].ac = (it.ac + tw[0]) + outp[0];
+                nw[1].lm = it.lm + __int_as_float(h1.w);
+                nw[1].path = it.path;
             }
             // exit state (:443-483): entered from the last emitting state only
             Tok le = null_tok();
@@ -311,8 +342,9 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
                                              float endTh, float wordTh, float bestA, XOut &out, int &deferred)
 {
     constexpr bool XL_ = true;
-    const int lane = threadIdx.x & 63;
-    const int wid = RFL(threadIdx.x >> 6);
+    const int tid_ = SLOT_PHASE_TID;
+    const int lane = tid_ & 63;
+    const int wid = RFL(tid_ >> 6);
     const float INF = __builtin_inff();
     const unsigned icur = p ? V.item_par : 0u;
     const bool can_filter = !init && C.emit_win > 0.0f && bestA > LZ;
@@ -495,7 +527,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
             const float ns = tg.score + Bk.w;                          // (:535 / :562: the same sum either way)
             const unsigned so = f2o(ns);
             unsigned long long skc = 0ULL;
-            const float tmax = C.hmm_tmax0[entry ? inl - 1 : 0];
+            const float tmax = tee_lds ? sh.tmax[entry ? inl - 1 : 0] : C.hmm_tmax0[entry ? inl - 1 : 0];
             int2 nrow = make_int2(0, 0);
             {
                 const unsigned doff = ((on && inl == 0) || is_tee) ? (unsigned)Bk.to * (unsigned)sizeof(StateRec) : OOB_OFF;
@@ -599,7 +631,7 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
     const DecConst &C = A.C;
     StreamCtl &c = A.ctl[s];
     const StreamDev &S = A.streams[s];
-    const int tid = threadIdx.x, lane = tid & 63, wid = RFL(tid >> 6);
+    const int tid = slot_tid(), lane = tid & 63, wid = RFL(tid >> 6);
     const int MN = C.max_n;
     int f = RFL(c.frame);
     const int T = RFL(c.T);
@@ -622,13 +654,24 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
     V.newl = (GAS unsigned long long *)S.newl; V.dirtyl = (GAS int *)S.dirtyl; V.dirty_par = C.cap_new;
     V.tot = (GAS int *)S.tot; V.paths = (GAS v4i *)S.paths; V.hist = (GAS int *)S.hist;
     const bool use_hist = C.max_hyps > 0;
-    const bool lr = C.lrt != nullptr;
-    const bool trp_lds = !lr && (size_t)C.n_tm * MN * MN <= TRP_LDS_MAX && (size_t)C.n_tm * MN <= TRP_LDS_MAX / 4;
+    const bool lr = C.lrt != nullptr && C.n_tm * ((NE == 3) ? 8 : 16) <= SLOT_TRP_MAX;
+    const bool trp_lds = !lr && (size_t)C.n_tm * MN * MN <= SLOT_TRP_MAX && (size_t)C.n_tm * MN <= SLOT_TRP_MAX / 4;
+    const bool ll_lds = C.G <= SLOT_LL_MAX;
+    // frame fr's likelihood row -> LDS, by this wave's share of LDS-DMA loads (64 floats each; nothing is waited for here)
+    auto row_of = [&](int fr) __attribute__((always_inline)) { return A.ll + ((long long)ll_slot * A.ll_stride + (long long)(fr - A.f0) * (long long)C.G); };
+    auto load_row = [&](int fr) __attribute__((always_inline)) {
+        const float *row = row_of(fr);
+        for (int c0 = wid * 64; c0 < C.G; c0 += SW * 64) {
+            const int i = min(c0 + lane, C.G - 1);
+            __builtin_amdgcn_global_load_lds((const GAS float *)(row + i), (__attribute__((address_space(3))) float *)(sh.ll + c0), 4, 0, 0);
+        }
+    };
+    int row_in_lds = -1;                                               // the frame whose row is in sh.ll (or on its way)
     auto tot_of = [&](int k) __attribute__((always_inline)) { return V.tot + (size_t)k * MAXW; };
     __syncthreads();                                                   // the previous command of this slot is done with LDS
 #define SLOT_LOOP _Pragma("clang loop unroll(disable) vectorize(disable)")
     if (lr) SLOT_LOOP for (int i = tid; i < C.n_tm * ((NE == 3) ? 8 : 16); i += SNT) sh.trP[i] = C.lrt[i];
-    if (C.n_hmm <= TEE_LDS_MAX) SLOT_LOOP for (int i = tid; i < C.n_hmm; i += SNT) sh.tee[i] = C.hmm_tee[i];
+    if (C.n_hmm <= TEE_LDS_MAX) SLOT_LOOP for (int i = tid; i < C.n_hmm; i += SNT) { sh.tee[i] = C.hmm_tee[i]; sh.tmax[i] = C.hmm_tmax0[i]; }
     if (trp_lds) {
         SLOT_LOOP for (int i = tid; i < C.n_tm * MN * MN; i += SNT) sh.trP[i] = C.trP[i];
         SLOT_LOOP for (int i = tid; i < C.n_tm * MN; i += SNT) sh.se[i] = C.se32[i];
@@ -727,6 +770,10 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
         if (!init) {
             // ---- frame start (:311-339): thresholds + the work lists of phase A
             const float normalise = (best_emit > LZ) ? best_emit : 0.0f;             // :321
+            if (ll_lds && row_in_lds != f) {                           // (a command's first frame: nobody has asked for its row yet)
+                load_row(f);
+                row_in_lds = f;
+            }
             if (wid == 0) {                                            // entries before every segment of the three lists
                 int t3;
                 const int e0 = slot_prefix8(lane < SW ? sh.c_rec[p][lane] : 0, t3);
@@ -749,22 +796,29 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
                 }
                 if (lane == 0) sh.emitTh = emitTh;
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (this wave's share of the likelihood row has landed)
             __syncthreads();
             const int n0 = RFL(sh.pfx[0][SW]), n1 = RFL(sh.pfx[1][SW]), n2 = RFL(sh.pfx[2][SW]);
             const int Q0 = (n0 + 63) >> 6, Q1 = (n1 + 63) >> 6, Q2 = (n2 + 63) >> 6;
             const float emitTh = __int_as_float(RFL(__float_as_int(sh.emitTh)));
             const float startTh = (C.start_win > 0.0f) ? (best_emit - C.start_win) : LZ;   // :337
-            const float *llrow = A.ll + ((long long)ll_slot * A.ll_stride + (long long)(f - A.f0) * (long long)C.G);
+            const float *llrow = row_of(f);
             int out_cnt = 0;
             SCLK(0);
 #define SLOT_A_ARGS C, sh, V, g, Q0, Q1, Q2, n0, n1, n2, p, normalise, emitTh, startTh, llrow, out_cnt, exit_cnt
 #if defined(SLOT_EXP_NO_A)
 #elif defined(SLOT_EXP_ONLY_LR)
-            slot_phase_a<NE, true, true>(SLOT_A_ARGS);
+            slot_phase_a<NE, true, true, true>(SLOT_A_ARGS);
 #else
-            if (lr) slot_phase_a<NE, true, true>(SLOT_A_ARGS);
-            else if (trp_lds) slot_phase_a<NE, true, false>(SLOT_A_ARGS);
-            else slot_phase_a<NE, false, false>(SLOT_A_ARGS);
+            if (ll_lds) {
+                if (lr) slot_phase_a<NE, true, true, true>(SLOT_A_ARGS);
+                else if (trp_lds) slot_phase_a<NE, true, false, true>(SLOT_A_ARGS);
+                else slot_phase_a<NE, false, false, true>(SLOT_A_ARGS);
+            } else {
+                if (lr) slot_phase_a<NE, true, true, false>(SLOT_A_ARGS);
+                else if (trp_lds) slot_phase_a<NE, true, false, false>(SLOT_A_ARGS);
+                else slot_phase_a<NE, false, false, false>(SLOT_A_ARGS);
+            }
 #endif
 #undef SLOT_A_ARGS
             SCLK(1);
@@ -772,6 +826,10 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
             if (use_hist) SLOT_LOOP for (int b = tid; b < C.hist_nbins; b += SNT) sh.hist[p ^ 1][b] = 0;   // (the next frame's bins: read above, by wave 1, before the barrier)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // records, exit items and bids are out before anybody reads them
             __syncthreads();
+            if (ll_lds && f + 1 < f_stop) {                            // the NEXT frame's row: nobody reads sh.ll before that frame's first barrier
+                load_row(f + 1);
+                row_in_lds = f + 1;
+            }
             SCLK(2);
         }
         // ---- phase X

@@ -2,6 +2,7 @@
 # exploration: what saturates when every CU runs the search (the 512-utterance leg)?  a wider set of counters, one pass each
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
+export JD_DEV=1
 mkdir -p gpurun_out
 OUT=gpurun_out/prof_explore
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -25,7 +26,7 @@ python - "$OUT" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1] + "/pmc_summary.json"))
 for k, v in d.items():
-    if "k_search" in k:
+    if "k_search" in k or "k_slot" in k:
         print(k)
         for c, x in sorted(v.items()):
             print("   %-40s launches %3d  mean %.4g  max %.4g" % (c, x["launches"], x["mean"], x["max"]))

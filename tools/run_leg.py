@@ -32,6 +32,9 @@ elif which == "c512pipe":                                             # (the 512
     a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
     out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, through the resident kernel", a, n, f, 150.0, 0, dev, passes=passes,
                         pipe=(int(os.environ.get("LEG_DEPTH", "1")), int(os.environ.get("LEG_SLOTS", "160"))))
+elif which == "c512slot":                                             # (one launch of the slot kernel, a workgroup per utterance: what the counters see of jd_slot.h)
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
+    out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, 512 streams: k_slot_batch", a, n, f, 150.0, 0, dev, passes=passes, max_streams=512)
 elif which == "c512":
     a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
     out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, 128 streams", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c512", max_streams=128)
