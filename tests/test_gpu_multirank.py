@@ -44,7 +44,7 @@ def test_two_ranks_gather_hip_hypotheses(built):
 def test_bench_spawns_its_own_ranks(built):
     """`python bench.py --gpus 2` outside torchrun starts two ranks itself (here both on GPU 0 over
     gloo, JD_BENCH_SHARE_GPU=1 - the numbers are meaningless, the path is what is tested).  Several ranks run the
-    headline's own path: batches through the resident kernel, six announced ahead, the steps' 1-best records in ONE
+    headline's own path: batches through the resident slot kernel, nine announced ahead, the steps' 1-best records in ONE
     all_gather behind jd_dec_quiesce at the end of the timed region; --gather-every 1 keeps a collective per step and
     two batches in flight."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1")
@@ -56,7 +56,7 @@ def test_bench_spawns_its_own_ranks(built):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["gathered_hyps"] == 12 and d["value"] > 0
-    assert d["config"]["pipeline"] and d["config"]["batches_in_flight"] == 7 and d["config"]["pipeline_error"] is None, d["config"]
+    assert d["config"]["pipeline"] and d["config"]["batches_in_flight"] == 10 and d["config"]["pipeline_error"] is None, d["config"]
     assert "ONE all_gather" in d["config"]["gather"] and d["roofline"]["kernel"] == "k_resident"
     assert d["frames_timed"] > 0 and d["single_batch"]["serial_order"]["ms"] > 0 and d["single_batch"]["one_ahead"]["ms"] > 0
     out = _run(base + ["--gather-every", "1"], env, 400)
