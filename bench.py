@@ -90,7 +90,7 @@ def kernel_source_hash():
     measurement of ONE build; it is reported only while the sources are the ones it was taken on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("jd_search.h", "jd_lazy.h", "jd_gmm.h", "jd_gc.h", "jd_resident.h", "jd_slot.h", "jd_device.hip"):
+    for f in ("jd_search.h", "jd_lazy.h", "jd_gmm.h", "jd_gc.h", "jd_resident.h", "jd_slot.h", "jd_host_resident.h", "jd_device.hip"):
         h.update(open(os.path.join(ROOT, "juicer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -105,12 +105,29 @@ def calibrated_traffic(fetch_kib, write_kib, wide_read_bytes):
     return (fetch_kib + write_kib) * 1024.0 + 0.5 * wide_read_bytes
 
 
+PROFILE_ROUND = "r05"
+
+
+def slot_traffic(frames):
+    """HBM bytes of `frames` stream-frames of configs[1] through the slot kernel (csrc/jd_slot.h), from the committed PMC passes of
+    k_slot_batch - the same per-stream code as the pipeline's k_slot, as a plain launch over the 512-utterance batch of configs[2]
+    (tools/run_leg.py c512slot under tools/leg_pmc.sh; the counters run kernels one after the other, and k_slot waits for the
+    kernels beside it): counted bytes per stream-frame x frames.  None when the passes were taken on other sources."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "%s_c512slot_traffic.json" % PROFILE_ROUND)))
+        if t.get("source_hash") != kernel_source_hash():
+            return None
+        return round(t["k_search_hbm_bytes_per_pass"] / t["frames_per_pass"] * frames, 1)
+    except Exception:
+        return None
+
+
 def leg_traffic(leg, launches):
     """HBM bytes per k_search launch of a workload, from the committed PMC passes of that workload on its own
-    (profiles/r04_<leg>_traffic.json, tools/leg_pmc.sh): the bytes of all k_search launches of one pass over the
+    (profiles/r05_<leg>_traffic.json, tools/leg_pmc.sh): the bytes of all k_search launches of one pass over the
     step's launches, like `achieved`.  None when there is no such file or when it was taken on other sources."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r04_%s_traffic.json" % leg)))
+        t = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (PROFILE_ROUND, leg))))
         if t.get("source_hash") != kernel_source_hash():
             return None
         return round(t["k_search_hbm_bytes_per_pass"] / max(1, launches), 1)
@@ -574,18 +591,20 @@ def main():
     step_tm["search_ms"] = acc["search_ms"] / steps
     step_tm["search_launches"] = max(1, acc["search_launches"] // steps)
     traffic = leg_traffic("c2", step_tm["search_launches"]) if default_cfg else None
+    if depth:
+        traffic = slot_traffic(frames_local) if default_cfg else None
     if depth:                                                      # (the resident kernel is busy all the time: a batch's share of it
         # is the time the slots took for one batch's worth of the frames they really advanced inside the brackets)
         step_tm["search_ms"] = elapsed * 1e3 * frames_local / max(1.0, float(frames_timed))
     roofline = roofline_of(st, MN, step_tm, traffic)
     if depth:
-        roofline["kernel"] = "k_resident"
-        roofline["traffic_is"] = "proxy: k_search"
+        roofline["kernel"] = "k_slot"
+        roofline["traffic_is"] = "proxy: k_slot_batch (the slot kernel's per-stream code as a plain launch, counted on configs[2]'s 512-utterance batch; bytes per stream-frame x the batch's frames)"
         roofline["launch"] = ("ONE launch spans the timed region (jd_resident.h): a batch's share of it = the region x (one batch's frames / "
                               "the frames the slots advanced inside it, jd_dec_pipeline_stats); avg_launch_us is that share, "
-                              "algorithmic_bytes_per_launch one batch's bytes; traffic is a PROXY - the counted HBM bytes of one batch through "
-                              "the same per-stream code as k_search launches (the profiler runs kernels one after the other under --pmc, and "
-                              "k_resident waits for the scoring, export and ready kernels beside it)")
+                              "algorithmic_bytes_per_launch one batch's bytes; traffic is a PROXY - the counted HBM bytes of one batch's frames through "
+                              "the same per-stream code launched as k_slot_batch (the profiler runs kernels one after the other under --pmc, and "
+                              "k_slot waits for the scoring, export and ready kernels beside it)")
     gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
     gmm_bytes = G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / max(1, tm["gmm_launches"])
     roofline["search_ms_per_step"] = round(step_tm["search_ms"], 3)
@@ -711,11 +730,18 @@ def main():
             _, _, f512, _ = synth.config_c2(seed=args.seed, n_utts=512, target_arcs=args.arcs)
             # (through the resident kernel's slots, two such batches ahead: 1.59 M frames/s against 1.43 M in waves of 128 streams - the
             # counted bytes of the leg are those of the waves, tools/run_leg.py c512)
-            legs["configs2_batch_512_on_one_gpu"] = run_leg("configs[2]'s 512-utterance batch on one GPU" + (", through the resident kernel" if depth else ", 128 streams"),
-                                                            am, net, f512, args.beam, 0, dev, oracle_utts=no, max_streams=128,
-                                                            pipe=(2, args.pipeline_slots) if depth else None, passes=2 if depth else 4,
-                                                            pmc_leg="c512" if default_cfg else None)
+            # (512 streams: more than the chip has CUs, so every pass is ONE launch of the slot kernel, a workgroup per utterance, two per CU,
+            # the dispatcher dealing the next one when one leaves - k_slot_batch; measured 2.12 M frames/s against 1.97 M through the
+            # pipeline's 256 slots two batches ahead, 1.43 M in waves of 128 streams on k_search)
+            legs["configs2_batch_512_on_one_gpu"] = run_leg("configs[2]'s 512-utterance batch on one GPU, 512 streams: one launch of the slot kernel per pass",
+                                                            am, net, f512, args.beam, 0, dev, oracle_utts=no, max_streams=512, passes=4,
+                                                            pmc_leg="c512slot" if default_cfg else None)
             del f512
+            # the search's other record layout at bench size: HMMs of 1 .. 6 emitting states with skips (k_slot<6>, general predecessor loop)
+            am6, n6, f6, _ = synth.config_c2_mixed(seed=args.seed, n_utts=64, target_arcs=args.arcs)
+            legs["configs1_mixed_topologies"] = run_leg("configs[1]'s graph with HMMs of 1-6 emitting states (144-byte records, general topologies)", am6, n6, f6,
+                                                        args.beam, 0, dev, oracle_utts=no, pipe=pipe, passes=8 if pipe else 4)
+            del am6, n6, f6
             a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=64, n_words=10000, n_tri_hist=100_000)
             legs["north_star_10M_beam200"] = run_leg("north_star target (trigram-shaped)", a4, n4, f4, 200.0, 0, dev,
                                                      oracle_utts=no, pmc_leg="north" if args.seed == 0 else None)

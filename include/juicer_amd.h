@@ -504,8 +504,8 @@ int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
  *   JD_FLOW_RESIDENT       announced batches go through a search kernel that STAYS on the device, utterance by utterance:
  *                          every stream is a slot of one workgroup that takes the next queued utterance the moment its
  *                          own is through; the other CUs score.  depth = batches announced and not yet handed back, at
- *                          most (2..32; 0 = 8: a likelihood table each); slots = one-workgroup slots (1..max_streams;
- *                          0 = max_streams).  jd_decode_batch_device must be called for the batches in the order they
+ *                          most (2..32; 0 = by the slots: 8, or slots / 32 + 2 - a likelihood table each); slots = one-workgroup
+ *                          slots (1..max_streams; 0 = max_streams): two per CU on the CUs they fill, the others score.  jd_decode_batch_device must be called for the batches in the order they
  *                          were announced (anything else drops what is under way and decodes the usual way); a batch
  *                          larger than the decoder's slots goes through them without any announcement.  See
  *                          jd_dec_quiesce for what the resident kernel means for the rest of the process.

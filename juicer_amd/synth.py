@@ -755,6 +755,20 @@ def config_c2(seed: int = 0, n_utts: int = 64, target_arcs: int = 1_000_000, n_g
     return am, net, feats, words
 
 
+def config_c2_mixed(seed: int = 0, n_utts: int = 64, target_arcs: int = 1_000_000, n_gmm: int = 3000, n_hmm: int = 8000, n_mix: int = 16,
+                    n_words: int = 5000, utt_words=(9, 28)):
+    """configs[1]'s graph size and model count with HMMs of 1 .. 6 emitting states side by side, skips included (make_models_mixed):
+    the search's OTHER record layout (144-byte records, general predecessor loop) at bench size."""
+    am = make_models_mixed(seed, n_gmm=n_gmm, n_hmm=n_hmm, n_mix=n_mix, with_tee=False)
+    net = make_wfst_sized(seed + 100, am, target_arcs, n_words)
+    feats, words = [], []
+    for u in range(n_utts):
+        rng = np.random.default_rng(seed + 300 + u)
+        x, w = sample_utterance(seed + 1000 + u, net, am, int(rng.integers(utt_words[0], utt_words[1] + 1)))
+        feats.append(x); words.append(w)
+    return am, net, feats, words
+
+
 def config_c4(seed: int = 0, n_utts: int = 8, n_words: int = 20000, n_tri_hist: int = 400_000,
               k2_mean: float = 110.0, k3_mean: float = 26.0, n_gmm: int = 5000, n_hmm: int = 12000,
               n_mix: int = 16, sep: float = 1.0, utt_words=(9, 28), utt_offset: int = 0):

@@ -4,6 +4,7 @@
 set -u
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
+export JD_DEV=1
 export JD_BENCH_NO_LAZY=1      # the clg leg: without its search-driven part
 LEG=${1:-north}
 OUT=gpurun_out/prof_$LEG
@@ -22,7 +23,7 @@ import bench
 d = json.load(open(sys.argv[1] + "/pmc_summary.json"))
 tot_f = tot_w = 0.0
 for k, v in d.items():
-    if "k_search" in k or "k_resident" in k:
+    if "k_search" in k or "k_resident" in k or "k_slot" in k:
         print(k, {c: (x["launches"], round(x["mean"], 1), round(x["max"], 1)) for c, x in v.items()})
         tot_f += v["FETCH_SIZE"]["mean"] * v["FETCH_SIZE"]["launches"]
         tot_w += v["WRITE_SIZE"]["mean"] * v["WRITE_SIZE"]["launches"]
@@ -38,6 +39,7 @@ out = {"leg": sys.argv[2], "passes": np_, "k_search_hbm_bytes_per_pass": bench.c
        "uncalibrated_2xFETCH_plus_WRITE_bytes_per_pass": (2.0 * tot_f + tot_w) * 1024.0 / np_,
        "FETCH_SIZE_KiB_per_pass": tot_f / np_, "WRITE_SIZE_KiB_per_pass": tot_w / np_, "wide_read_bytes_per_pass": wide,
        "algorithmic_bytes_per_pass": leg["roofline"]["algorithmic_bytes_per_launch"] * leg["roofline"]["launches_per_step"],
+       "frames_per_pass": leg["frames_per_step"],
        "search_ms_under_pmc": leg["search_ms"], "source_hash": bench.kernel_source_hash(),
        "source": "tools/leg_pmc.sh: rocprofv3 --kernel-trace --pmc, FETCH_SIZE and WRITE_SIZE in separate runs of `python tools/run_leg.py %s 2`" % sys.argv[2]}
 json.dump(out, open(sys.argv[1] + "/leg_traffic.json", "w"), indent=1)
