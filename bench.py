@@ -1,44 +1,37 @@
 #!/usr/bin/env python
 """bench.py - frames/sec decoded on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path (dense GMM scoring + token-passing search)
-over one batch of synthetic utterances per GPU: BASELINE.json configs[1]
-(~1M-arc composed WFST, 3000 tied states x 16 mixtures, 64 utterances per GPU,
-mainBeam 150).  Features are resident in HBM before the timed region.
+One "step" = one pass of the hot path (dense GMM scoring + token-passing search) over one batch of synthetic utterances per
+GPU: BASELINE.json configs[1] (~1M-arc composed WFST, 3000 tied states x 16 mixtures, 64 utterances per GPU, mainBeam 150).
+Features are resident in HBM before the timed region.
 
-N>1: one rank per GPU, utterances sharded across ranks, no data-path collective;
-ONE RCCL all_gather of the padded 1-best records per step.  `python bench.py
---gpus N` spawns its own ranks (torch.distributed.run) when it was not started
-by torchrun; under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Scaling
-is weak by default (64 utterances per GPU); `--total-utts 512` is BASELINE.json
-configs[2]: ONE fixed batch dealt over the ranks by length (strong scaling).
+How the batches share the chip (`jd_dec_set_pipeline`): by default through the RESIDENT SLOT PIPELINE - a search
+kernel that stays on the device (csrc/jd_slot.h: 256 one-workgroup slots, two per CU on half of the chip), the other CUs scoring a
+likelihood table per announced batch; announcements run nine batches ahead (`jd_dec_prefetch_scores`), a slot takes the next
+queued utterance the moment its own is through, and every step hands back ITS batch's 64 results, decoded in full.  The announced
+batch is the same synthetic batch again, scored from its features every time: K timed steps hold K scorings and K batches' worth of
+search.  `value` = the stream-frames the slots REALLY advanced between the two brackets (`jd_dec_pipeline_stats`) / the bracketed
+time - a batch handed back inside the region was partly searched before it, batches announced inside it are partly searched behind
+it.  What ONE batch costs a caller that does not announce that far ahead is printed beside it (`single_batch`: nothing announced /
+one batch announced), measured behind the timed region.  --pipeline-depth 0: two batches in flight, one k_search launch per step.
 
-Batches follow each other, so by default every step announces the batch behind it
-(jd_dec_prefetch_scores) and that batch's likelihood table is scored on the CUs the
-current batch's search leaves idle as its utterances end; the announced batch is the
-same synthetic batch again, scored from its features every time.  The timed region
-of K steps therefore holds K searches and K scorings, like the serial order does: the
-table the first timed step searches was scored during the last warm-up step, the
-table scored during the last timed step is never searched.  --no-score-ahead times
-the serial order; one serial-order step is also run BEHIND the timed region and
-reported as roofline.serial_order / roofline.gmm.serial_order_* (not part of `value`).
+N > 1: one rank per GPU, utterances sharded across ranks, no data-path collective, every rank on the same path as N = 1.  A
+collective's kernels must not be queued on a device whose search kernel stays, so the 1-best records of the K timed steps travel in
+ONE RCCL all_gather at the end of the timed region (inside it), behind jd_dec_quiesce; a rank has its own results the moment its
+step returns.  --gather-every 1: one all_gather per step, two batches in flight instead of the pipeline.  `python bench.py --gpus N`
+spawns its own ranks (torch.distributed.run) when it was not started by torchrun; under torchrun it reads RANK / LOCAL_RANK /
+WORLD_SIZE.  Scaling is weak by default (64 utterances per GPU); `--total-utts 512` is BASELINE.json configs[2]: ONE fixed batch
+dealt over the ranks by length (strong scaling).
 
-Two batches in flight (default at weak scaling; --no-search-ahead: off).  A batch lasts
-as long as its longest utterance while the clusters of its shorter ones are long
-through, so the decoder is given streams for TWO batches and the announcements run two
-batches ahead: the batch behind the running one then has its table already and its
-utterances are started beside the running batch, one workgroup each.  Every step still
-returns its own batch's 64 results, decoded in full from frame 0; what a step does of
-the next batch's search the next step does not do again, so K timed steps hold K
-batches' worth of search (config.search_ahead_frames_per_step says how much of a
-batch had been searched when its step began).
+The timed region is bracketed by jd_dec_quiesce (the resident kernel lets its commands run out and leaves: a device-wide
+synchronisation waits for every kernel), barrier and torch.cuda.synchronize() on both sides; the kernel comes back with the first
+timed step, inside the brackets.
 
-After the timed region rank 0 of a 1-GPU run also times (1 warm-up + 3 timed
-passes each: median and minimum) the other single-GPU workloads of BASELINE.json
-and reports them under "legs": the north_star target (10M-arc class graph, beam
-200), configs[3] (~48M-arc trigram-shaped graph, beam 300), configs[4] (C.L and G
-composed on the device) and the maxHyps 6000 variant of configs[1] - each with
-its own roofline and a CPU-oracle sample.  --no-extra-legs skips them.
+After the timed region rank 0 of a 1-GPU run also times the other single-GPU workloads of BASELINE.json and reports them under
+"legs" (each with its own roofline and a CPU-oracle sample): configs[1] + maxHyps 6000, configs[1] with two batches in flight,
+configs[2]'s 512-utterance batch on one GPU (one launch of the slot kernel per pass), configs[1]'s graph with HMMs of 1-6 emitting
+states, the north_star target (14 M-arc graph, beam 200), configs[3] (~48M-arc trigram-shaped graph, beam 300), configs[4] (C.L and G
+composed on the device).  --no-extra-legs skips them.
 
 Prints ONE JSON line on rank 0.
 """
@@ -60,7 +53,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def search_bytes(st, max_n):
     """Algorithmic bytes of the search for the work in `st` (batch totals of jd_stats): SURVEY.md
-    8(d) / DESIGN.md 5.  Token read + write (16-B tokens) and arc->hmm lookup per instance,
+    8(d) / DESIGN.md 4.  Token read + write (16-B tokens) and arc->hmm lookup per instance,
     likelihood gather per emitting hypothesis, exit token + CSR bounds per end hypothesis,
     arc record + hook + entry-token read-modify-write per visited arc, one Path record per word end."""
     return ((32.0 * max_n + 4.0) * st["tot_insts_in"] + 4.0 * st["tot_proc_emit_hyps"]
@@ -411,7 +404,7 @@ def main():
         shards = parallel.shard_lpt([f.shape[0] for f in all_feats], world)
         shard = shards[rank]
         # what the 1-GPU measurements say every rank's share should take (the first real SCALE run can be read against it):
-        # a wave of at most 128 streams lasts as long as its longest utterance's chain of frames (33 us per frame, DESIGN.md
+        # a wave of at most 128 streams lasts as long as its longest utterance's chain of frames (33 us per frame, docs/DESIGN_HISTORY.md
         # 9) or as its frames take at the rate of the 512-utterances-on-one-GPU leg (1.44 M frames/s), whichever is more
         predicted_rank_ms = [round(max(max([all_feats[u].shape[0] for u in sh] or [0]) * 33e-3 + 1.5,
                                        sum(all_feats[u].shape[0] for u in sh) / 1.44e6 * 1e3), 2) for sh in shards]
@@ -427,10 +420,10 @@ def main():
     # (a rank that holds more than 128 utterances of a fixed batch decodes them in waves of 128 streams, each wave's table
     # scored beside the wave before it: measured faster than one stream per utterance from 256 utterances on)
     # (weak scaling: batches of U utterances follow each other, and a decoder with room for two of them starts the
-    # utterances of the batch behind the running one beside it - "two batches in flight", DESIGN.md 3.1)
+    # utterances of the batch behind the running one beside it - "two batches in flight", DESIGN.md 3.6)
     ahead = not args.no_score_ahead
     two_in_flight = ahead and not args.no_search_ahead and not strong
-    # ... or, deeper: the batches' utterances through the slots of a search kernel that stays (DESIGN.md 3.1, "batches through the
+    # ... or, deeper: the batches' utterances through the slots of a search kernel that stays (DESIGN.md 3.6, "batches through the
     # resident kernel"): a batch is scored whole when it is announced, a slot takes the next queued utterance the moment its own
     # is through, and a step hands back the oldest batch - still ITS 64 results, decoded in full
     # (several ranks: the same path.  What a collective needs - its kernels on a stream of the process - it must not get while a
@@ -444,7 +437,7 @@ def main():
     for depth in ((depth, 0) if depth else (0,)):                      # (should the pipeline fail: the same measurement, two batches in flight)
       try:
         dec = capi.Decoder(gnet, gam, main_beam=args.beam, max_hyps=args.max_hyps, device=local_rank,
-                           max_streams=min(U, 128) if strong else (args.pipeline_slots if depth else (2 * U if two_in_flight else U)))
+                           max_streams=min(U, 512) if strong else (args.pipeline_slots if depth else (2 * U if two_in_flight else U)))
         if depth:                                                      # the interface: jd_dec_set_pipeline (include/juicer_amd.h)
             dec.set_pipeline(capi.FLOW_RESIDENT, depth + 1, args.pipeline_slots)
         offs = np.zeros(len(feats) + 1, dtype=np.int64)
@@ -609,7 +602,7 @@ def main():
     gmm_bytes = G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / max(1, tm["gmm_launches"])
     roofline["search_ms_per_step"] = round(step_tm["search_ms"], 3)
     # the companion kernel is VALU-bound: per (frame pair, mixture) 4 packed fp32 instructions per dimension
-    # + ~116 for the two logAdd steps, 4 cycles each on 1024 SIMDs (DESIGN.md 3.3)
+    # + ~116 for the two logAdd steps, 4 cycles each on 1024 SIMDs (DESIGN.md 3.5)
     gmm_valu_ms = (frames_local / 128.0) * G * M * (4.0 * D + 116.0) * 4.0 / 1024.0 / 2.4e9 * 1e3
     gmm_ms = tm_serial["gmm_ms"]                                   # the kernel on its own (the serial step behind the timed region)
     n_ahead = acc["prefetched"]

@@ -288,7 +288,7 @@ def test_broker_throughput_at_configs1(built):
     ratio = (16 * frames / t_broker) / (frames / t_batch)
     print("16 callers through the broker: %.0f frames/s, one batch of 64: %.0f frames/s (host-inclusive) - ratio %.2f; %.1f streams, %.0f frames per tick"
           % (16 * frames / t_broker, frames / t_batch, ratio, st["stream_ticks"] / st["ticks"], st["frames"] / st["ticks"]))
-    assert ratio >= (0.4 if st["resident"] else 0.3)                  # (16 streams are latency-bound: DESIGN.md, "the drop-in seam's own throughput")
+    assert ratio >= (0.4 if st["resident"] else 0.3)                  # (16 streams are latency-bound: docs/DESIGN_HISTORY.md 6, "the drop-in seam's own throughput")
     broker.close()
     dec.close()
 

@@ -155,7 +155,7 @@ def test_fullsize_gmm_tile_parity(c2):
     if diff.any():                                        # (what to look at when it fails: the first offending entries)
         r, c = np.nonzero(diff)
         print([(int(a), int(b), float(g[a, b]), float(o[a, b])) for a, b in list(zip(r, c))[:8]])
-    assert not diff.any()                                 # bit for bit (DESIGN.md 3.3), 333 x 3000 x 16 evaluations
+    assert not diff.any()                                 # bit for bit (DESIGN.md 3.5), 333 x 3000 x 16 evaluations
 
 
 def test_fullsize_wide_beam(c2):

@@ -45,7 +45,7 @@ def test_gmm_kernel_matches_oracle(small):
     frac = diff.mean()
     ulp = np.abs(g.view(np.int32).astype(np.int64) - o.view(np.int32).astype(np.int64)).max()
     print("gmm mismatches: %d of %d (max ulp %d)" % (diff.sum(), diff.size, ulp))
-    assert ulp == 0 and frac == 0.0                       # bit for bit (DESIGN.md 3.3): a 1-ulp likelihood can flip a threshold decision
+    assert ulp == 0 and frac == 0.0                       # bit for bit (DESIGN.md 3.5): a 1-ulp likelihood can flip a threshold decision
 
 
 def test_gmm_kernel_generic_dim(built):
