@@ -27,6 +27,9 @@
 #define SLOT_WG_PER_CU (SLOT_WPE * 4 / SW)
 #define JDE_GEOM -47                 // a stream in the middle of an utterance whose lists were written with another geometry
 #define SLOT_TRP_MAX 2048            // floats of transition tables cached in LDS (else read from HBM)
+#ifndef SLOT_REC_AHEAD
+#define SLOT_REC_AHEAD 0             // development: the next chunk's record requested one pass ahead - measured: phase A 52.6 -> 62.6 us per frame
+#endif
 #define SLOT_LL_MAX 3072             // tied states whose likelihoods of the frame are staged in LDS (else gathered from HBM)
 
 struct SlotShared {
@@ -114,7 +117,25 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         for (int j = 1; j < SW; ++j) w += (gi >= sh.pfx[k][j]) ? 1 : 0;
         idx = gi - sh.pfx[k][w];
     };
+    // the record of a chunk of list 0.  (SLOT_REC_AHEAD: requested ONE PASS AHEAD, so that the first of a pass's dependent round trips
+    // runs beside the pass before it - what jd_search.h's phase A does at two waves per SIMD; at four it LOSES, 52.6 -> 62.6 us per
+    // frame: the pass is bound by the L1's line rate, not by the round trip, and twenty more live registers cost more than they hide)
+    auto load_rec = [&](int uu, bool &valid, v4i &h0, v4i &h1, v4i &h2, Tok (&tk)[NE + 1]) __attribute__((always_inline)) {
+        int w, idx;
+        locate(0, uu, n0, valid, w, idx);
+        const unsigned off = valid ? rcur + rec_chunk_off<NE>(g.seg_rec, w, idx >> 6) + (unsigned)(idx & 63) * 16u : OOB_OFF;
+        h0 = ld16(V.rec, off); h1 = ld16(V.rec, off + 1024u);
+        if (NE == 6) h2 = ld16(V.rec, off + 2048u);
+#pragma unroll
+        for (int j = 1; j <= NE; ++j) tk[j] = as_tok(ld16(V.rec, off + (unsigned)(HF + j - 1) * 1024u));
+    };
     int u = slot_grab(&sh.nextA);
+    // (80-byte records only: the nine fields of the 144-byte layout ahead cost 36 registers and 300 spilled ones)
+    constexpr bool AHEAD = SLOT_REC_AHEAD != 0 && NE == 3;
+    bool pvalid = false;
+    v4i ph0 = {0, 0, 0, 0}, ph1 = {0, 0, 0, 0}, ph2 = {0, 0, 0, 0};
+    Tok ptk[NE + 1];
+    if (AHEAD && u < Q0) load_rec(u, pvalid, ph0, ph1, ph2, ptk);
 #pragma nounroll
     while (u < Q01) {
         const int un = slot_grab(&sh.nextA);                           // (its LDS round trip runs beside this pass)
@@ -124,12 +145,12 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         v4i h0, h1, h2 = {0, 0, 0, 0};
         Tok tk[NE + 1];
         if (!is_new) {
-            locate(0, u, n0, valid, w, idx);
-            const unsigned off = valid ? rcur + rec_chunk_off<NE>(g.seg_rec, w, idx >> 6) + (unsigned)(idx & 63) * 16u : OOB_OFF;
-            h0 = ld16(V.rec, off); h1 = ld16(V.rec, off + 1024u);
-            if (NE == 6) h2 = ld16(V.rec, off + 2048u);
+            if constexpr (AHEAD) {
+                valid = pvalid; h0 = ph0; h1 = ph1; h2 = ph2;
 #pragma unroll
-            for (int j = 1; j <= NE; ++j) tk[j] = as_tok(ld16(V.rec, off + (unsigned)(HF + j - 1) * 1024u));
+                for (int j = 1; j <= NE; ++j) tk[j] = ptk[j];
+                if (un < Q0) load_rec(un, pvalid, ph0, ph1, ph2, ptk);
+            } else load_rec(u, valid, h0, h1, h2, tk);
         } else {                                                       // attachNetInst :751-774, from the arc's template
             locate(1, u - Q0, n1, valid, w, idx);
             const unsigned long long e = CL(V.newl + (valid ? (size_t)w * g.seg_new + (unsigned)idx : (size_t)0));
