@@ -129,7 +129,7 @@ def leg_traffic(leg, launches):
 
 
 def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, gnet=None, pmc_leg=None, oracle_feats=None,
-            oracle_net=None, ahead=True, max_streams=0, two=None, pipe=None):
+            oracle_net=None, ahead=True, max_streams=0, two=None, pipe=None, caps=None):
     """One extra workload: warm-up pass + timed passes on one GPU (value = the MEDIAN pass), its own roofline.
     gnet: a network that exists already (composed on the device); net is then only asked for its size.
     pmc_leg: the name the leg's PMC passes are filed under (leg_traffic).  oracle_utts: that many utterances are
@@ -150,7 +150,8 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
     if pipe:
         depth, max_streams, two = pipe[0], pipe[1], False
     dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam,
-                       max_hyps=max_hyps, device=dev.index, max_streams=(2 * U if two else U) if not max_streams else max_streams)
+                       max_hyps=max_hyps, device=dev.index, max_streams=(2 * U if two else U) if not max_streams else max_streams,
+                       **(dict(zip(("max_slots", "max_paths", "max_items"), caps)) if caps else {}))   # (caps: per-stream arena capacities, jd_dec_set_capacity)
     if depth:
         dec.set_pipeline(capi.FLOW_RESIDENT, depth + 1, max_streams)
     offs = np.zeros(U + 1, dtype=np.int64)

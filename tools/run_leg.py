@@ -17,6 +17,13 @@ dev = torch.device("cuda:0")
 if which == "north":
     a, n, f, _ = synth.config_c4(seed=0, n_utts=64, n_words=10000, n_tri_hist=100_000)
     out = bench.run_leg("north_star target (trigram-shaped)", a, n, f, 200.0, 0, dev, passes=passes, pmc_leg="north")
+elif which == "northpipe":                                            # (the north-star workload through the slot pipeline: LEG_DEPTH batches ahead, LEG_SLOTS slots)
+    a, n, f, _ = synth.config_c4(seed=0, n_utts=64, n_words=10000, n_tri_hist=100_000)
+    out = bench.run_leg("north_star target (trigram-shaped), through the slot pipeline", a, n, f, 200.0, 0, dev, passes=passes,
+                        pipe=(int(os.environ.get("LEG_DEPTH", "9")), int(os.environ.get("LEG_SLOTS", "448"))),
+                        caps=[int(x) for x in os.environ.get("LEG_CAPS", "1048576,4194304,1048576").split(",")])
+elif which == "clgpipe":
+    pass
 elif which == "clg":
     out = bench.compose_leg(0, dev)
 elif which == "c3":
