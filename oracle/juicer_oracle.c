@@ -1,8 +1,13 @@
 /*
  * juicer_oracle.c - CPU ORACLE (test infrastructure only; see juicer_oracle.h).
  *
- * PARITY UNPINNED (no reference tests/golden vectors exist for this path and
- * the reference is unbuildable in this image).  Plain C restatement of:
+ * PARITY UNPINNED: no reference tests / golden vectors exist for this path, and the
+ * reference cannot be built here in a way that pins anything - its hot-path sources DO
+ * compile against stand-ins for the absent Torch3 / Tracter headers (tools/refbase does
+ * that, in the build container, as a timing and differential aid: on the first 12
+ * configs[1] utterances the reference's own WFSTDecoderLite and WFSTDecoderLiteThreading
+ * give this file's words, times and scores bit for bit, profiles/cpu_reference_baseline.json),
+ * but a build against stand-ins is not a reference build.  Plain C restatement of:
  *   WFSTNetwork text-load arithmetic      src/WFSTNetwork.cpp:403-560, 709-721
  *   HTKModels parameter preparation       src/HTKModels.cpp:581-593, 600-676, 835-870, 873-974, 2330-2390
  *   HTKFlatModels flatten + GMM + logAdd  src/HTKFlatModels.cpp:94-177, 226-306

@@ -8,7 +8,10 @@
  * PARITY UNPINNED: the reference (idiap/juicer) ships no tests, fixtures or
  * golden vectors for this path, and its sources cannot be compiled in this
  * image (they need the absent Torch3 and Tracter headers plus a bison/flex
- * generated parser; writing stand-ins for those is not a reference build).
+ * generated parser; writing stand-ins for those is not a reference build -
+ * tools/refbase does write them, for TIMING the reference's classes and for a
+ * differential check of this restatement against them, which it passes bit for
+ * bit on the bench workload; that pins nothing).
  * This file is therefore a line-by-line *restatement* of the reference
  * algorithm, each function citing the reference file:line it follows.
  * Third-party constants it depends on (Torch3 >= 3.1, configure.ac:42, not in

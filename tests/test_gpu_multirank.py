@@ -57,7 +57,7 @@ def test_bench_spawns_its_own_ranks(built):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["gathered_hyps"] == 12 and d["value"] > 0
     assert d["config"]["pipeline"] and d["config"]["batches_in_flight"] == 10 and d["config"]["pipeline_error"] is None, d["config"]
-    assert "ONE all_gather" in d["config"]["gather"] and d["roofline"]["kernel"] == "k_resident"
+    assert "ONE all_gather" in d["config"]["gather"] and d["roofline"]["kernel"] == "k_slot"
     assert d["frames_timed"] > 0 and d["single_batch"]["serial_order"]["ms"] > 0 and d["single_batch"]["one_ahead"]["ms"] > 0
     out = _run(base + ["--gather-every", "1"], env, 400)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

@@ -342,6 +342,9 @@ def test_batch_test_cli(small, tmp_path):
     # all-gather of the 1-best records).  This box has one GPU, so N = 1 - the communicator, the
     # packing, the collective and the unpacking all run; the xmlf lines carry times and scores.
     assert run("-outputFormat", "xmlf", "-devices", "1", *mm) == run("-outputFormat", "xmlf", *mm)
+    # -residentSlots N: the list through N one-workgroup slots of the search kernel that stays (jd_dec_set_pipeline, JD_FLOW_RESIDENT:
+    # a slot takes the next utterance the moment its own is through) - more utterances than slots, the same output
+    assert run("-outputFormat", "xmlf", "-residentSlots", "3", "-batch", "3", *mm) == run("-outputFormat", "xmlf", *mm)
     lines = run("-outputFormat", "trans", *mm)
     assert all(lines[u].endswith("(trans-%d)" % want[u].n) for u in range(len(feats)))
     # mlf / xmlf
