@@ -22,8 +22,11 @@ elif which == "northpipe":                                            # (the nor
     out = bench.run_leg("north_star target (trigram-shaped), through the slot pipeline", a, n, f, 200.0, 0, dev, passes=passes,
                         pipe=(int(os.environ.get("LEG_DEPTH", "9")), int(os.environ.get("LEG_SLOTS", "448"))),
                         caps=[int(x) for x in os.environ.get("LEG_CAPS", "1048576,4194304,1048576").split(",")])
-elif which == "clgpipe":
-    pass
+elif which == "northslot":                                            # (the north-star workload, LEG_UTTS utterances in ONE call on as many streams: one launch of
+    nu = int(os.environ.get("LEG_UTTS", "320"))                       # the slot kernel per pass, a workgroup per utterance - jd_slot.h: k_slot_batch)
+    a, n, f, _ = synth.config_c4(seed=0, n_utts=nu, n_words=10000, n_tri_hist=100_000)
+    out = bench.run_leg("north_star target (trigram-shaped), %d utterances on %d streams" % (nu, nu), a, n, f, 200.0, 0, dev, passes=passes, max_streams=nu,
+                        caps=[int(x) for x in os.environ.get("LEG_CAPS", "1048576,2097152,1048576").split(",")])
 elif which == "clg":
     out = bench.compose_leg(0, dev)
 elif which == "c3":
