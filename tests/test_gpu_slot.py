@@ -119,3 +119,26 @@ def test_slot_kernel_partial_traces(slot_kernel):
         _, got = gd.stream_partial(0)
         assert got == final and h.n > 0, u
     gd.close()
+
+
+def test_pipeline_api_arguments(built):
+    """jd_dec_set_pipeline / jd_dec_pipeline_stats: the modes, the defaults derived from the slots, and what is refused."""
+    from juicer_amd import capi, synth
+    am, net, feats, _ = synth.config_toy()
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=4, main_beam=150.0)
+    assert gd.pipeline_stats()["mode"] == capi.FLOW_TWO_IN_FLIGHT                     # the default
+    gd.set_pipeline(capi.FLOW_SERIAL)
+    assert gd.pipeline_stats()["mode"] == capi.FLOW_SERIAL
+    gd.set_pipeline(capi.FLOW_RESIDENT)                                              # depth and slots by default
+    ps = gd.pipeline_stats()
+    assert ps["mode"] == capi.FLOW_RESIDENT and ps["slots"] == 4 and ps["depth"] == 8 and ps["resident"] == 0
+    for bad in ((2, 0, 0), (capi.FLOW_RESIDENT, 1, 0), (capi.FLOW_RESIDENT, 33, 0), (capi.FLOW_RESIDENT, 4, 5), (capi.FLOW_RESIDENT, 4, -1)):
+        with pytest.raises(capi.JuicerAmdError) as ei:
+            gd.set_pipeline(*bad)
+        assert ei.value.code == capi.JD_EINVAL, bad
+    assert gd.pipeline_stats()["mode"] == capi.FLOW_RESIDENT                          # (a refused call changes nothing)
+    h = gd.decode_batch(feats)[0]                                                    # one utterance, nothing announced: the usual way
+    gd.set_pipeline(capi.FLOW_TWO_IN_FLIGHT)
+    h2 = gd.decode_batch(feats)[0]
+    assert bit_exact(h, h2) and h.n > 0
+    gd.close()
