@@ -31,8 +31,14 @@ def _worker(rank, world, port, n_utts, q):
     shards = parallel.shard_lpt([f.shape[0] for f in feats], world)
     mine = [od.decode(feats[u]) for u in shards[rank]]
     balanced = parallel.gather_hyps(mine, max(len(x) for x in shards), max_words=3, index=shards[rank])
+    # the records of SEVERAL steps in one collective (what bench.py does with ranks: the K timed steps' records travel in one
+    # all_gather behind jd_dec_quiesce): three steps - the contiguous shards, the same reversed, the balanced shards with their
+    # index - and records of 3 words again, so that the one collective has to be repeated with longer records
+    contig = [od.decode(feats[u]) for u in range(lo, hi)]
+    steps = parallel.gather_hyps_steps([(contig, list(range(lo, hi))), (contig[::-1], list(range(lo, hi))[::-1]), (mine, shards[rank])],
+                                       max(per_rank, max(len(x) for x in shards)), max_words=3)
     if rank == 0:
-        q.put((ser(allh), ser(balanced)))
+        q.put((ser(allh), ser(balanced), [ser(x) for x in steps]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,7 +79,7 @@ def test_gather_world_size_2(built):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_utts, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, balanced = q.get(timeout=120)
+    got, balanced, steps = q.get(timeout=120)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -81,7 +87,8 @@ def test_gather_world_size_2(built):
     od = OracleDecoder(OracleNet(net), OracleAM(am), main_beam=150.0)
     want = [od.decode(f) for f in feats]
     assert max(w.n for w in want) > 3                                # (the balanced gather had to ask twice)
-    for res in (got, balanced):
+    assert len(steps) == 3
+    for res in [got, balanced] + steps:                              # (every step of the multi-step gather: global utterance order)
         assert len(res) == n_utts
         for g, w in zip(res, want):
             assert g[0] == w.n and g[1] == w.label.tolist() and g[2] == w.time.tolist()
