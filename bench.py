@@ -6,9 +6,10 @@ GPU: BASELINE.json configs[1] (~1M-arc composed WFST, 3000 tied states x 16 mixt
 Features are resident in HBM before the timed region.
 
 How the batches share the chip (`jd_dec_set_pipeline`): by default through the RESIDENT SLOT PIPELINE - a search
-kernel that stays on the device (csrc/jd_slot.h: 256 one-workgroup slots, two per CU on half of the chip), the other CUs scoring a
-likelihood table per announced batch; announcements run nine batches ahead (`jd_dec_prefetch_scores`), a slot takes the next
-queued utterance the moment its own is through, and every step hands back ITS batch's 64 results, decoded in full.  The announced
+kernel that stays on the device (csrc/jd_slot.h: 256 one-workgroup slots, ONE per CU - eight waves at 128 VGPRs, half a CU), the
+scoring kernel's workgroups on the other half of the same CUs, a likelihood table per announced batch; announcements run nine
+batches ahead (`jd_dec_prefetch_scores`), a slot takes the next queued utterance the moment its own is through, and every step
+hands back ITS batch's 64 results, decoded in full.  The announced
 batch is the same synthetic batch again, scored from its features every time: K timed steps hold K scorings and K batches' worth of
 search.  `value` = the stream-frames the slots REALLY advanced between the two brackets (`jd_dec_pipeline_stats`) / the bracketed
 time - a batch handed back inside the region was partly searched before it, batches announced inside it are partly searched behind
@@ -61,7 +62,7 @@ def search_bytes(st, max_n):
 
 
 def roofline_of(st, max_n, tm, traffic=None):
-    """Roofline of k_search, the persistent kernel every search launch is: achieved = algorithmic
+    """Roofline of a search launch (k_search unless the caller names another kernel): achieved = algorithmic
     bytes per launch / average launch duration (HIP events around each launch on the decoder's
     search stream, jd_dec_last_timing).  frac = achieved / peak prices the launch by SURVEY.md 8(d)'s
     algorithmic bytes; frac_measured by the HBM bytes the PMC passes counted (`traffic`), when there are any
@@ -217,6 +218,8 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
            "roofline": roofline_of(st, am.max_n, tm, leg_traffic(pmc_leg, max(1, tm["search_launches"])) if pmc_leg else None),
            "setup_s": round(time.perf_counter() - t0 - sum(r[0] for r in runs), 1)}
+    # (which kernel the leg's frames went through: the pipeline's slots, the slot kernel as a plain launch, else clusters of k_search)
+    out["roofline"]["kernel"] = "k_slot" if depth else ("k_slot_batch" if tm.get("slot_launches", 0) > 0 else "k_search")
     if oracle_utts > 0:
         from oracle.oracle import OracleAM, OracleDecoder, OracleNet
         od = OracleDecoder(oracle_net if oracle_net is not None else OracleNet(net), OracleAM(am), main_beam=beam, max_hyps=max_hyps)
@@ -344,9 +347,10 @@ def main():
                          "0 = two batches in flight, one launch per step (what runs with several ranks) - measured on one box, 20 steps: "
                          "30.7-30.8 ms per step against 26.7 with six batches ahead through 160 slots")
     ap.add_argument("--pipeline-slots", type=int, default=256,
-                    help="streams (= one-workgroup slots) of the resident pipeline: two slots per CU on half of the chip (the slot kernel, csrc/jd_slot.h), "
-                         "the other CUs score - measured on one box: 192 slots 1.68 M frames/s, 256 slots 1.80 M (nine batches ahead; 1.65 M with six), "
-                         "320 slots 1.72 M (the scoring starves them); round 4's 160 one-per-CU slots of k_resident: 1.60 M")
+                    help="streams (= one-workgroup slots) of the resident pipeline: dealt one per CU while there are CUs (the slot kernel, "
+                         "csrc/jd_slot.h, takes half a CU; the scoring kernel's workgroups run on the other half) - measured on one box, nine batches "
+                         "ahead: 192 slots 1.82 M frames/s, 224 2.05 M, 240 2.17 M, 256 2.27 M, 272 2.16 M, 288 2.12 M, 304 1.96 M (a CU that holds two "
+                         "slots has no room for the scoring); two slots per CU on half of the chip and the scoring on the other half: 1.93 M")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="several ranks: 0 = the 1-best records of all timed steps travel in ONE RCCL all_gather at the end of the timed "
                          "region, behind jd_dec_quiesce (a rank has its own results at once; a collective's kernels must not be queued on a "
@@ -693,7 +697,7 @@ def main():
                       "gather": None if world == 1 else ("one all_gather per step" if per_step_gather else
                                                          "ONE all_gather of the %d steps' records at the end of the timed region (inside it), behind jd_dec_quiesce" % steps),
                       "pipeline_error": pipeline_error,
-                      "pipeline": ("resident slot kernel: %d one-workgroup slots, two per CU, the other CUs score; announcements %d batches ahead, a slot takes "
+                      "pipeline": ("resident slot kernel: %d one-workgroup slots, one per CU (half of it; the scoring kernel runs on the other half of the same CUs); announcements %d batches ahead, a slot takes "
                                    "the next queued utterance (longest first) when its own is through" % (args.pipeline_slots, depth)) if depth else None,
                       "predicted_rank_ms": predicted_rank_ms if strong else None,
                       "search_ahead_frames_per_step": int(acc["ahead_frames"] // max(steps, 1)),

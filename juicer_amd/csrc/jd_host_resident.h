@@ -221,16 +221,19 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
     // (tools/resident_alias_probe.py: one fresh stream in fourteen lands behind the kernel), so the kernel is started, a
     // small kernel is sent down the side stream and the null stream, and if either has not come back in 150 ms the
     // resident kernel leaves again and comes back on a NEW search stream - a few times, then it is an error.
-    // Where the slots go (jd_slot.h, jd_park_kernel): the CUs the scoring keeps are parked while the slot kernel's grid is dealt.
+    // Where the slots go.  A grid of at most one workgroup per CU is dealt one per CU, and that is what the pipeline wants: a slot's eight
+    // waves take two of a SIMD's four wave slots and half its registers, the scoring kernel's waves (127 VGPRs, no LDS) take the other half
+    // of the SAME CU - a search that waits for memory beside arithmetic that does not: 256 slots on 256 CUs 18.1 ms per configs[1] batch,
+    // against 21.5 with the slots two per CU on half the chip and the scoring on the other half (jd_slot.h: jd_park_kernel, which is how
+    // such a split is made: JD_SLOT_KEEP_SE = CUs per shader engine the slots get, development), 19.1 with 272 and 21.1 with 304 slots
+    // dealt over all CUs (the CUs that hold two slots have no room for the scoring).
     R->st = d->s_search;
     int park_cus = 0, park_fill = 0;
     if (slot) {
-        int cus = std::min(d->n_cus, (R->n + SLOT_WG_PER_CU - 1) / SLOT_WG_PER_CU);
-        if (const char *e2 = jd_dev_env("JD_SLOT_CUS")) { const int v = atoi(e2); if (v >= 1 && v <= d->n_cus && v * SLOT_WG_PER_CU >= R->n) cus = v; if (v == 0) cus = d->n_cus; }
         // (whole CUs per shader engine: 32 engines of n_cus / 32 CUs each, every one keeps the same number for the slots)
         const int per_se = std::max(1, d->n_cus / 32);
-        int keep_se = std::min(per_se, (cus + 31) / 32);
-        if (const char *e2 = jd_dev_env("JD_SLOT_KEEP_SE")) { const int v = atoi(e2); if (v >= 1 && v <= per_se) keep_se = v; }   // development
+        int keep_se = per_se;
+        if (const char *e2 = jd_dev_env("JD_SLOT_KEEP_SE")) { const int v = atoi(e2); if (v >= 1 && v <= per_se && v * 32 * SLOT_WG_PER_CU >= R->n) keep_se = v; }
         park_cus = (per_se - keep_se) * 32;
         park_fill = std::min(R->n, keep_se * 32 * SLOT_WG_PER_CU);     // slots that find room while the others are parked
         if (park_cus > 0 && !d->h_park) {
