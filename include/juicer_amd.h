@@ -503,9 +503,12 @@ int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
  *                          announcements two batches ahead, each batch on at most half of the decoder's streams.
  *   JD_FLOW_RESIDENT       announced batches go through a search kernel that STAYS on the device, utterance by utterance:
  *                          every stream is a slot of one workgroup that takes the next queued utterance the moment its
- *                          own is through; the other CUs score.  depth = batches announced and not yet handed back, at
- *                          most (2..32; 0 = by the slots: 8, or slots / 32 + 2 - a likelihood table each); slots = one-workgroup
- *                          slots (1..max_streams; 0 = max_streams): two per CU on the CUs they fill, the others score.  jd_decode_batch_device must be called for the batches in the order they
+ *                          own is through; the scoring runs beside them.  depth = batches announced and not yet handed
+ *                          back, at most (2..32; 0 = by the slots: 8, or slots / 32 + 2 - a likelihood table each); slots =
+ *                          one-workgroup slots (1..max_streams; 0 = max_streams): a slot is half a CU and the slots are dealt
+ *                          one per CU while there are CUs - the scoring kernel's workgroups take the other half of the
+ *                          same CUs, so as many slots as the device has CUs is the count to ask for.
+ *                          jd_decode_batch_device must be called for the batches in the order they
  *                          were announced (anything else drops what is under way and decodes the usual way); a batch
  *                          larger than the decoder's slots goes through them without any announcement.  See
  *                          jd_dec_quiesce for what the resident kernel means for the rest of the process.

@@ -67,7 +67,7 @@ def test_fullsize_64_stream_batch_oracle_parity(built):
         assert bit_exact(gs[u], want[u]), u
     assert all(h.n > 0 for h in gs)
     gd.close()
-    # ... and the same batches the way bench.py runs them: through the slot kernel's 256 one-workgroup slots (two per CU),
+    # ... and the same batches the way bench.py runs them: through the slot kernel's 256 one-workgroup slots (one per CU, beside the scoring),
     # announcements nine batches ahead (jd_dec_set_pipeline: JD_FLOW_RESIDENT, ten deep) - every utterance of every
     # batch DIRECTLY against the oracle (words, times, the reference's statistics, scores bit for bit), not against the launch above
     gp = capi.Decoder(gnet, gam, max_streams=256, **kw)
