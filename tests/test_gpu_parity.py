@@ -1190,7 +1190,13 @@ def test_batches_through_the_resident_kernel(small, monkeypatch):
     buf = {n: resident(b) for n, b in batches.items()}
     monkeypatch.setenv("JD_DEV", "1")                                  # (development knob: 50-frame commands instead of 128)
     monkeypatch.setenv("JD_PIPE_CHUNK", "50")
-    for streams, extra in ((10, {}), (4, {}), (8, dict(max_paths=1 << 12))):
+    # (keep_se: the development knob that deals the slots two per CU on that many CUs of every shader engine and keeps the other CUs
+    # for the scoring - jd_park_kernel; the default deals them one per CU beside the scoring)
+    for streams, extra, keep_se in ((10, {}, 0), (4, {}, 0), (8, dict(max_paths=1 << 12), 0), (10, {}, 1)):
+        if keep_se:
+            monkeypatch.setenv("JD_SLOT_KEEP_SE", str(keep_se))
+        else:
+            monkeypatch.delenv("JD_SLOT_KEEP_SE", raising=False)
         gd = capi.Decoder(gnet, gam, max_streams=streams, **kw, **extra)
         gd.set_pipeline(capi.FLOW_RESIDENT, 4)                         # the interface: jd_dec_set_pipeline, four batches deep
         assert gd.pipeline_stats()["mode"] == capi.FLOW_RESIDENT and gd.pipeline_stats()["frames_searched"] == 0
@@ -1205,7 +1211,7 @@ def test_batches_through_the_resident_kernel(small, monkeypatch):
             if i == 4:
                 gd.quiesce()
                 torch.cuda.synchronize()                               # (returns: the kernel has left)
-            if i == 6 and streams == 10:
+            if i == 6 and streams == 10 and not keep_se:
                 import time
                 time.sleep(5.6)                                        # a caller that is away: the kernel leaves by itself after 5 s, and comes back
             gs = gd.decode_batch_device(buf[n][0].data_ptr(), buf[n][1], 0)
@@ -1233,6 +1239,7 @@ def test_batches_through_the_resident_kernel(small, monkeypatch):
         for u, g in enumerate(gs):
             assert bit_exact(g, want["A"][u])
         gd.close()
+    monkeypatch.delenv("JD_SLOT_KEEP_SE", raising=False)
     # more utterances than streams in ONE call, nothing announced: through the slots as well
     gd = capi.Decoder(gnet, gam, max_streams=4, **kw)
     gd.set_pipeline(capi.FLOW_RESIDENT, 4)
