@@ -373,6 +373,7 @@ struct jd_dec {
     AmDevBuf amb;
     // device copies of static data
     int *d_row_ptr = nullptr; JdArc *d_arcs = nullptr; float *d_fin_w = nullptr; int *d_aux = nullptr;
+    XState *d_xst = nullptr;              // per state: the decoder's arc order (DecConst::xst)
     int *d_se32 = nullptr;
     float *d_hmm_tee = nullptr, *d_trP = nullptr, *d_hmm_tmax0 = nullptr, *d_lrt = nullptr;
     int *d_pcount = nullptr;               // per state: Path objects of the reference per arriving token (DecConst::pcount)
@@ -590,22 +591,49 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         return jd_fail(JD_EINVAL, "jd_dec_create: the lazily composed network lives on device %d, not %d", net->lazy_device, device);
     }
     if (!lazy) TRY(dupload(d, &d->d_row_ptr, net->row_ptr.data(), net->row_ptr.size()));
+    std::vector<float> tmax0((size_t)am->n_hmm, LZ);   // largest log transition probability out of the entry state of every HMM
+    for (int h = 0; h < am->n_hmm; ++h) {
+        const float *t0 = am->trP.data() + (size_t)am->hmm_tm[(size_t)h] * am->max_n * am->max_n;
+        for (int j = 0; j < am->hmm_n[(size_t)h]; ++j) tmax0[(size_t)h] = std::max(tmax0[(size_t)h], t0[j]);
+    }
     if (!lazy) {   // device arc table: bit 30 of the in-label marks arcs whose HMM is a tee model
         std::vector<JdArc> darcs(net->arcs);
         for (JdArc &a : darcs)
             if (a.in > 0 && am->hmm_tee[(size_t)a.in - 1] > LZ) a.in |= TEE_FLAG;
+        // The decoder's OWN order of a state's arcs (XState, jd_search.h): what every arrival walks first, then the arcs that
+        // enter a model by descending w + tmax - phase X of the slot kernel walks a prefix of those.  Arc numbers never leave
+        // the device (results carry labels, times and scores), and every arc has an instance of its own, so the order changes no
+        // score; it can change which of two EQUAL-scored tokens a state keeps (the frontier item's number breaks the tie), which
+        // the reference's own traversal order decides no better (tests: decode_certified).  JD_NO_XSORT (development): the file's order.
+        const bool xsort = jd_dev_env("JD_NO_XSORT") == nullptr;
+        std::vector<XState> xst((size_t)net->n_states);
+        std::vector<std::pair<float, JdArc>> ent;
+        for (int q = 0; q < net->n_states; ++q) {
+            const int r0 = net->row_ptr[(size_t)q], r1 = net->row_ptr[(size_t)q + 1];
+            XState &X = xst[(size_t)q];
+            X.n_always = 0; X.n_entry = 0; X.wmax = LZ; X.n_model = 0;
+            for (int i = 0; i < XNCAND; ++i) X.k[i] = LZ;
+            ent.clear();
+            int at = r0;
+            for (int b = r0; b < r1; ++b) {
+                const JdArc a = darcs[(size_t)b];
+                const int inl = a.in & ~TEE_FLAG;
+                if (inl != 0) { ++X.n_model; X.wmax = std::max(X.wmax, a.w); }
+                if (xsort && inl != 0 && !(a.in & TEE_FLAG)) ent.push_back({a.w + tmax0[(size_t)inl - 1], a});
+                else darcs[(size_t)at++] = a;                          // (in place: `at` never passes b)
+            }
+            X.n_always = at - r0;
+            std::stable_sort(ent.begin(), ent.end(), [](const std::pair<float, JdArc> &x, const std::pair<float, JdArc> &y) { return x.first > y.first; });
+            X.n_entry = (int)ent.size();
+            for (size_t i = 0; i < ent.size(); ++i) darcs[(size_t)at + i] = ent[i].second;
+            for (int i = 0; i < XNCAND; ++i) if (xcand(i) < X.n_entry) X.k[i] = ent[(size_t)xcand(i)].first;
+        }
         TRY(dupload(d, &d->d_arcs, darcs.data(), darcs.size()));
+        TRY(dupload(d, &d->d_xst, xst.data(), xst.size()));
     }
     if (!lazy) TRY(dupload(d, &d->d_fin_w, net->fin_w.data(), net->fin_w.size()));
     TRY(dupload(d, &d->d_hmm_tee, am->hmm_tee.data(), am->hmm_tee.size()));
-    {   // largest log transition probability out of the entry state of every HMM (phase X, hopeless candidates)
-        std::vector<float> tmax((size_t)am->n_hmm, LZ);
-        for (int h = 0; h < am->n_hmm; ++h) {
-            const float *t0 = am->trP.data() + (size_t)am->hmm_tm[(size_t)h] * am->max_n * am->max_n;
-            for (int j = 0; j < am->hmm_n[(size_t)h]; ++j) tmax[(size_t)h] = std::max(tmax[(size_t)h], t0[j]);
-        }
-        TRY(dupload(d, &d->d_hmm_tmax0, tmax.data(), tmax.size()));
-    }
+    TRY(dupload(d, &d->d_hmm_tmax0, tmax0.data(), tmax0.size()));     // (phase X, hopeless candidates)
     TRY(dupload(d, &d->d_trP, am->trP.data(), am->trP.size()));
     std::vector<int> se32((size_t)am->n_tm * am->max_n);
     for (size_t i = 0; i < se32.size(); ++i)
@@ -613,6 +641,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     TRY(dupload(d, &d->d_se32, se32.data(), se32.size()));
     TRY(upload_am_gmm(am, d->amb));
     C.row_ptr = d->d_row_ptr; C.arcs = d->d_arcs; C.fin_w = d->d_fin_w; C.init_state = net->init; C.n_states = net->n_states;
+    C.xst = d->d_xst;
     C.G = am->n_gmm; C.max_n = am->max_n; C.n_tm = am->n_tm;
     C.hmm_tee = d->d_hmm_tee; C.n_hmm = am->n_hmm; C.hmm_tmax0 = d->d_hmm_tmax0;
     C.lazy = (const LazyDev *)net->lazy_dev; C.aux_h = nullptr;

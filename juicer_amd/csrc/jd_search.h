@@ -58,6 +58,7 @@ enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_LAZ
 struct DecConst {
     // network (CSR in HBM)
     const int *row_ptr; const JdArc *arcs; const float *fin_w; int init_state; int n_states;
+    const struct XState *xst;     // per state: the decoder's arc order and what the slot kernel's phase X needs to cut a walk short (null: lazily composed networks)
     // models
     int G, max_n, n_tm;
     const float *hmm_tee; int n_hmm;
@@ -115,6 +116,22 @@ template <int NE> struct RecLayout {
 // each a 64-byte sector for 8 useful bytes - the memory side carried out 13-15 G atomics / s on the heavy workloads,
 // about what it can do (tools/traffic_probe: 16-17 G / s).
 struct __align__(32) StateRec { unsigned long long key0, keyL, e[2]; };
+
+// per-state STATIC record of the decoder's own copy of the graph (shared by the streams; jd_dec_create).  The decoder keeps the
+// arcs of a state in an order of its own: first the arcs every arrival has to walk (epsilon inputs, tee models: n_always of
+// them), then the arcs that enter a model, by DESCENDING w + tmax (arc weight + the model's largest entry transition) - the
+// quantity phase X's "hopeless candidate" test runs on.  An arrival of score s can only enter the arcs of a PREFIX of that order;
+// k[] samples the order at the positions xcand() so that an item finds an upper bound of its prefix from this one record instead
+// of looking at every arc: the slot kernel (jd_slot.h: phase X) does not walk the arcs behind it at all.  What the walk did for
+// them besides is accounted from here: n_model (arcs that carry a model, tee models included) less the instance flags set in the
+// state's row (StreamDev::live: one byte per arc, a row's flags side by side) gives the arcs entered without an instance, wmax the
+// best entry-token candidate.  (k_search walks every arc, in this order, and does not read this record.)
+#define XNCAND 12
+struct __align__(64) XState { int n_always, n_entry; float wmax; int n_model; float k[XNCAND]; };
+__host__ __device__ __forceinline__ constexpr int xcand(int i)
+{
+    return i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 2 : i == 3 ? 3 : i == 4 ? 4 : i == 5 ? 6 : i == 6 ? 8 : i == 7 ? 12 : i == 8 ? 16 : i == 9 ? 24 : i == 10 ? 32 : 64;
+}
 
 // per-stream scalars.  Line 0 is written by the host-side helper kernels and by workgroup 0 of the
 // stream's cluster at the END of a launch (nobody reads it while a launch runs, except at its

@@ -21,6 +21,7 @@
 //     per SIMD (<= 128 VGPRs, <= 80 KB LDS: two workgroups per CU) and the other waves hide the round trips.
 #pragma once
 
+#define XLW 4                        // phase X: 8-byte words of a row's instance flags requested at once (XState)
 #ifndef SLOT_WPE
 #define SLOT_WPE 4                   // waves per SIMD the kernel is compiled for (2 workgroups of SW = 8 waves per CU)
 #endif
@@ -427,6 +428,9 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         const bool start_tok = valid && exit_kind && info.x < 0;       // recognitionStart's token: it has traversed no arc
         const bool real = valid && !start_tok && slice_no == 0;
         const int state = !valid ? 0 : start_tok ? C.init_state : info.z;
+        // the state's static record (XState): requested here, used when the item is known to go on
+        const int4 *xq = (const int4 *)(C.xst + state);
+        const int4 x0 = xq[0], x1 = xq[1], x2 = xq[2], x3 = xq[3];
         bool have = valid;
         if (real && exit_kind && !init) {                              // :952-962
             have = t.score > ((info.y != 0) ? wordTh : endTh);
@@ -485,6 +489,47 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         unsigned eo = exit_kind ? 0u : (unsigned)info.x;               // ordered score of the best arrival before this one (0: none)
         unsigned long long eold = 0ULL;
         const bool arrive = have && exit_kind;
+        // The arcs of the state that enter a model stand in descending order of w + tmax behind the ones every arrival walks (XState):
+        // this item can only enter a PREFIX of them - the rest fails the "hopeless candidate" test below whatever its flag says - and
+        // the prefix's upper bound comes from the samples in the state's record.  (Conservative by a margin far above the rounding of
+        // the sums: the test itself still decides inside the prefix.)  What the walk did for the arcs left out: they count as visited,
+        // the best entry-token candidate of the WHOLE row is score + wmax (float addition is monotone), and the arcs entered without
+        // an instance are the row's model arcs less the instance flags set in it - one byte per arc, the row's side by side: 32
+        // bytes in flight at once, the rest of a longer row in a loop - counted behind the arrival below.
+        int x_new = 0;
+        if (have && slice_no == 0) {
+            const int n_entry = x0.y, n_model = x0.w;
+            if (n_model > 0) {
+                const unsigned sw = f2o(t.score + __int_as_float(x0.z));
+                mo = sw > mo ? sw : mo;
+                const int a8 = rs & ~7;
+                const GAS unsigned long long *lw = (const GAS unsigned long long *)(V.live + a8);
+                unsigned long long w8[XLW];
+#pragma unroll
+                for (int i = 0; i < XLW; ++i) w8[i] = (a8 + 8 * i < rs1) ? CL(lw + i) : 0ULL;
+                auto in_row = [&](int base) __attribute__((always_inline)) {   // the bytes of the word at `base` that belong to the row
+                    const int lo = max(rs - base, 0), hi = min(rs1 - base, 8);
+                    const unsigned long long mh = hi >= 8 ? ~0ULL : ((1ULL << (8 * max(hi, 0))) - 1ULL);
+                    const unsigned long long ml = (1ULL << (8 * lo)) - 1ULL;
+                    return 0x0101010101010101ULL & mh & ~ml;
+                };
+                int lv_row = 0;
+#pragma unroll
+                for (int i = 0; i < XLW; ++i) lv_row += __popcll(w8[i] & in_row(a8 + 8 * i));
+                for (int b8 = a8 + 8 * XLW; b8 < rs1; b8 += 8) lv_row += __popcll(CL((const GAS unsigned long long *)(V.live + b8)) & in_row(b8));
+                x_new = n_model - lv_row;
+            }
+            if (can_filter && n_entry > 0 && rs1 - rs <= X_SLICE) {
+                const float lim = (bestA - C.emit_win) - (1.0f + 1e-5f * (fabsf(bestA) + fabsf(t.score)));
+                const int kx[XNCAND] = {x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+                int P = n_entry;
+#pragma unroll
+                for (int i = XNCAND - 1; i >= 0; --i)
+                    if (xcand(i) < n_entry && t.score + __int_as_float(kx[i]) <= lim) P = xcand(i);
+                c_arcs += n_entry - P;
+                rs1 -= n_entry - P;
+            }
+        }
         int alo = rs, ahi = rs1;
         if (slice_no > 0) { alo = rs + slice_no * X_SLICE; ahi = min(rs1, alo + X_SLICE); }
         int n_slices = 0;
@@ -506,6 +551,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         { const int bq = lane < tot ? b_nx : 0; Bk_nx = C.arcs[bq]; lv_nx = CL(V.live + bq); }
         if (arrive) { eold = GMAX(&V.srec[state].e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
         list_dirty(arrive && eold == 0ULL, state);
+        if (eo == 0u) c_new += x_new;                                  // (the first arrival at the state in this frame: :899-935 tries them all)
         if (__ballot(n_slices > 0)) {
             for (unsigned long long bs = __ballot(n_slices > 0); bs; bs &= bs - 1) {
                 const int src = __ffsll((long long)bs) - 1;
@@ -574,8 +620,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
             }
             if (entry) {                                               // :560-582 entry-token recombination: pulled by the next phase A
                 mo = so > mo ? so : mo;                                // :572-573
-                if (lv == 0) {                                         // no instance: attachNetInst :751-774
-                    if (eog == 0u) ++c_new;
+                if (lv == 0) {                                         // no instance: attachNetInst :751-774 (counted per state, above)
                     if (can_filter) {
                         const bool mine = (ns + tmax) - bestA > -C.emit_win;
                         const bool before = eog != 0u && ((o2f(eog) + Bk.w) + tmax) - bestA > -C.emit_win;
