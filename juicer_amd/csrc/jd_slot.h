@@ -494,32 +494,42 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         // the prefix's upper bound comes from the samples in the state's record.  (Conservative by a margin far above the rounding of
         // the sums: the test itself still decides inside the prefix.)  What the walk did for the arcs left out: they count as visited,
         // the best entry-token candidate of the WHOLE row is score + wmax (float addition is monotone), and the arcs entered without
-        // an instance are the row's model arcs less the instance flags set in it - one byte per arc, the row's side by side: 32
-        // bytes in flight at once, the rest of a longer row in a loop - counted behind the arrival below.
+        // an instance are the row's model arcs less the instance flags set in it - one byte per arc, the row's side by side -
+        // counted behind the arrival below.
         int x_new = 0;
-        if (have && slice_no == 0) {
+        // (rows of up to 8 * 2 * XLW - 7 arcs: their flags are one or two batches of loads; a longer row is walked whole and counted arc by arc)
+        const bool xitem = have && slice_no == 0 && rs1 - (rs & ~7) <= 16 * XLW;
+        if (xitem) {
             const int n_entry = x0.y, n_model = x0.w;
             if (n_model > 0) {
                 const unsigned sw = f2o(t.score + __int_as_float(x0.z));
                 mo = sw > mo ? sw : mo;
-                const int a8 = rs & ~7;
-                const GAS unsigned long long *lw = (const GAS unsigned long long *)(V.live + a8);
+            }
+            const int a8 = rs & ~7;
+            const GAS unsigned long long *lw = (const GAS unsigned long long *)(V.live + a8);
+            auto in_row = [&](int base) __attribute__((always_inline)) {   // the bytes of the word at `base` that belong to the row
+                const int lo = max(rs - base, 0), hi = min(rs1 - base, 8);
+                const unsigned long long mh = hi >= 8 ? ~0ULL : ((1ULL << (8 * max(hi, 0))) - 1ULL);
+                const unsigned long long ml = (1ULL << (8 * lo)) - 1ULL;
+                return 0x0101010101010101ULL & mh & ~ml;
+            };
+            int lv_row = 0;
+            {
                 unsigned long long w8[XLW];
 #pragma unroll
-                for (int i = 0; i < XLW; ++i) w8[i] = (a8 + 8 * i < rs1) ? CL(lw + i) : 0ULL;
-                auto in_row = [&](int base) __attribute__((always_inline)) {   // the bytes of the word at `base` that belong to the row
-                    const int lo = max(rs - base, 0), hi = min(rs1 - base, 8);
-                    const unsigned long long mh = hi >= 8 ? ~0ULL : ((1ULL << (8 * max(hi, 0))) - 1ULL);
-                    const unsigned long long ml = (1ULL << (8 * lo)) - 1ULL;
-                    return 0x0101010101010101ULL & mh & ~ml;
-                };
-                int lv_row = 0;
+                for (int i = 0; i < XLW; ++i) w8[i] = (n_model > 0 && a8 + 8 * i < rs1) ? CL(lw + i) : 0ULL;
 #pragma unroll
                 for (int i = 0; i < XLW; ++i) lv_row += __popcll(w8[i] & in_row(a8 + 8 * i));
-                for (int b8 = a8 + 8 * XLW; b8 < rs1; b8 += 8) lv_row += __popcll(CL((const GAS unsigned long long *)(V.live + b8)) & in_row(b8));
-                x_new = n_model - lv_row;
             }
-            if (can_filter && n_entry > 0 && rs1 - rs <= X_SLICE) {
+            if (__ballot(n_model > 0 && a8 + 8 * XLW < rs1)) {          // (some lane's row goes on: the second batch)
+                unsigned long long w8[XLW];
+#pragma unroll
+                for (int i = 0; i < XLW; ++i) w8[i] = (n_model > 0 && a8 + 8 * (XLW + i) < rs1) ? CL(lw + XLW + i) : 0ULL;
+#pragma unroll
+                for (int i = 0; i < XLW; ++i) lv_row += __popcll(w8[i] & in_row(a8 + 8 * (XLW + i)));
+            }
+            x_new = n_model - lv_row;
+            if (can_filter && n_entry > 0) {
                 const float lim = (bestA - C.emit_win) - (1.0f + 1e-5f * (fabsf(bestA) + fabsf(t.score)));
                 const int kx[XNCAND] = {x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
                 int P = n_entry;
@@ -584,7 +594,8 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
             tg.score = __shfl(t.score, gg); tg.ac = __shfl(t.ac, gg);
             tg.lm = __shfl(t.lm, gg); tg.path = __shfl(t.path, gg);
             const unsigned eog = (unsigned)__shfl((int)eo, gg);
-            const int sg = __shfl(state, gg);
+            const int sgx = __shfl(state | (xitem ? (int)0x80000000 : 0), gg);   // (+ the owner's "counted per state" flag)
+            const int sg = sgx & 0x7fffffff;
             bool mk = false, touch = false;
             Tok un = null_tok();
             const bool on = a < tot;
@@ -620,7 +631,8 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
             }
             if (entry) {                                               // :560-582 entry-token recombination: pulled by the next phase A
                 mo = so > mo ? so : mo;                                // :572-573
-                if (lv == 0) {                                         // no instance: attachNetInst :751-774 (counted per state, above)
+                if (lv == 0) {                                         // no instance: attachNetInst :751-774
+                    if (sgx >= 0 && eog == 0u) ++c_new;                // (long rows: counted arc by arc; else per state, above)
                     if (can_filter) {
                         const bool mine = (ns + tmax) - bestA > -C.emit_win;
                         const bool before = eog != 0u && ((o2f(eog) + Bk.w) + tmax) - bestA > -C.emit_win;
