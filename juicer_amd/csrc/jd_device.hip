@@ -614,12 +614,16 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
             X.n_always = 0; X.n_entry = 0; X.wmax = LZ; X.n_model = 0;
             for (int i = 0; i < XNCAND; ++i) X.k[i] = LZ;
             ent.clear();
+            // (only rows the cut can apply to - up to 57 arcs, jd_slot.h: the flags of a longer row do not fit an item's loads -
+            // change their order: the long rows of trigram-shaped graphs keep the file's, which the searches of such graphs
+            // are 2-3 % faster on; measured on the north-star graph)
+            const bool sort_row = xsort && r1 - r0 <= 57;
             int at = r0;
             for (int b = r0; b < r1; ++b) {
                 const JdArc a = darcs[(size_t)b];
                 const int inl = a.in & ~TEE_FLAG;
                 if (inl != 0) { ++X.n_model; X.wmax = std::max(X.wmax, a.w); }
-                if (xsort && inl != 0 && !(a.in & TEE_FLAG)) ent.push_back({a.w + tmax0[(size_t)inl - 1], a});
+                if (sort_row && inl != 0 && !(a.in & TEE_FLAG)) ent.push_back({a.w + tmax0[(size_t)inl - 1], a});
                 else darcs[(size_t)at++] = a;                          // (in place: `at` never passes b)
             }
             X.n_always = at - r0;

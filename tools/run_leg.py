@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One of bench.py's workloads on its own (GPU box): python tools/run_leg.py c2|north|c3|hyps|c512|clg [passes [utterances of the c3 leg]]"""
+"""One of bench.py's workloads on its own (GPU box): python tools/run_leg.py c2|north|c3|hyps|c512|clg|mixed|hypspipe|c512slot|... [passes [utterances of the c3 leg]]"""
 import json
 import os
 import sys
@@ -35,6 +35,12 @@ elif which == "c3":
 elif which == "c2pipe":                                               # (as the headline runs it: through the resident kernel, six batches ahead - not
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)                   # under --pmc: the profiler runs kernels one after the other, and this one waits for others)
     out = bench.run_leg("configs[1]", a, n, f, 150.0, 0, dev, passes=passes, pipe=(6, 160))
+elif which == "mixed":                                                # (configs[1]'s graph with HMMs of 1-6 emitting states, through the slot pipeline)
+    a, n, f, _ = synth.config_c2_mixed(seed=0, n_utts=64)
+    out = bench.run_leg("configs[1]'s graph with HMMs of 1-6 emitting states", a, n, f, 150.0, 0, dev, passes=max(passes, 8), pipe=(9, 256))
+elif which == "hypspipe":
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
+    out = bench.run_leg("configs[1] + histogram pruning, through the slot pipeline", a, n, f, 150.0, 6000, dev, passes=max(passes, 8), pipe=(9, 256))
 elif which in ("c2", "c2two"):                                        # (... with two batches in flight, one launch per step: what the counters can see)
     a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
     out = bench.run_leg("configs[1], two batches in flight", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c2", two=True)
