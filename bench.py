@@ -349,8 +349,9 @@ def main():
     ap.add_argument("--pipeline-slots", type=int, default=256,
                     help="streams (= one-workgroup slots) of the resident pipeline: dealt one per CU while there are CUs (the slot kernel, "
                          "csrc/jd_slot.h, takes half a CU; the scoring kernel's workgroups run on the other half) - measured on one box, nine batches "
-                         "ahead: 192 slots 1.82 M frames/s, 224 2.05 M, 240 2.17 M, 256 2.27 M, 272 2.16 M, 288 2.12 M, 304 1.96 M (a CU that holds two "
-                         "slots has no room for the scoring); two slots per CU on half of the chip and the scoring on the other half: 1.93 M")
+                         "ahead, before phase X's prefix walk: 192 slots 1.82 M frames/s, 224 2.05 M, 240 2.17 M, 256 2.27 M, 272 2.16 M, 288 2.12 M, 304 1.96 M "
+                         "(a CU that holds two slots has no room for the scoring); two slots per CU on half of the chip and the scoring on the other "
+                         "half: 1.93 M; with the prefix walk 240 / 256 / 272 / 288: 2.34 / 2.38 / 2.13 / 2.12 M")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="several ranks: 0 = the 1-best records of all timed steps travel in ONE RCCL all_gather at the end of the timed "
                          "region, behind jd_dec_quiesce (a rank has its own results at once; a collective's kernels must not be queued on a "
@@ -714,7 +715,7 @@ def main():
             no = 0 if args.no_cpu_baseline else 2                   # utterances the CPU oracle decodes per leg
             pipe = (depth, args.pipeline_slots) if depth else None
             legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev, oracle_utts=no,
-                                                   two=two_in_flight, pipe=pipe, passes=8 if pipe else 4, pmc_leg="hyps" if default_cfg else None)
+                                                   two=two_in_flight, pipe=pipe, passes=24 if pipe else 4, pmc_leg="hyps" if default_cfg else None)
             if depth:                                               # the headline's batches with TWO of them in flight, one launch per step
                 legs["configs1_two_batches_in_flight"] = run_leg("configs[1], two batches in flight (one k_search launch per step: what runs with "
                                                                  "several ranks, and what the counters see)", am, net, feats, args.beam, args.max_hyps, dev,
@@ -738,7 +739,7 @@ def main():
             # the search's other record layout at bench size: HMMs of 1 .. 6 emitting states with skips (k_slot<6>, general predecessor loop)
             am6, n6, f6, _ = synth.config_c2_mixed(seed=args.seed, n_utts=64, target_arcs=args.arcs)
             legs["configs1_mixed_topologies"] = run_leg("configs[1]'s graph with HMMs of 1-6 emitting states (144-byte records, general topologies)", am6, n6, f6,
-                                                        args.beam, 0, dev, oracle_utts=no, pipe=pipe, passes=8 if pipe else 4)
+                                                        args.beam, 0, dev, oracle_utts=no, pipe=pipe, passes=24 if pipe else 4)
             del am6, n6, f6
             a4, n4, f4, _ = synth.config_c4(seed=args.seed, n_utts=64, n_words=10000, n_tri_hist=100_000)
             legs["north_star_10M_beam200"] = run_leg("north_star target (trigram-shaped)", a4, n4, f4, 200.0, 0, dev,
