@@ -58,7 +58,8 @@ enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_LAZ
 struct DecConst {
     // network (CSR in HBM)
     const int *row_ptr; const JdArc *arcs; const float *fin_w; int init_state; int n_states;
-    const struct XState *xst;     // per state: the decoder's arc order and what the slot kernel's phase X needs to cut a walk short (null: lazily composed networks)
+    const struct XState *xst;     // per state: the decoder's arc order and what phase X needs to cut a walk short (null: lazily composed networks)
+    int xcut;                     // k_search cuts walks short too: most of the graph's model arcs sit in rows the cut applies to (jd_dec_create)
     // models
     int G, max_n, n_tm;
     const float *hmm_tee; int n_hmm;
@@ -1058,6 +1059,11 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         const bool start_tok = valid && exit_kind && info.x < 0;       // recognitionStart's token: it has traversed no arc
         const bool real = valid && !start_tok && slice_no == 0;        // an item that traversed an arc (a slice has been through all this)
         const int state = !valid ? 0 : start_tok ? C.init_state : info.z;
+        // (the state's static record, XState: requested here, used when the item is known to go on; graphs of long rows - C.xcut
+        // off - ask for state 0's every time: no branch around the loads, one cached line)
+        const bool xcut = !LZY && C.xcut != 0;
+        int4 x0 = make_int4(0, 0, 0, 0), x1 = x0, x2 = x0, x3 = x0;
+        if (!LZY) { const int4 *xq = (const int4 *)(C.xst + (xcut ? state : 0)); x0 = xq[0]; x1 = xq[1]; x2 = xq[2]; x3 = xq[3]; }
         // second level, in flight together: the state's keys, its CSR row, the word label
         // of an exit token's arc, the Path reservation.  A closure item this wave queued for itself brought its row
         // along - the record was read when it arrived - and has just been found the best arrival at its state: it
@@ -1153,6 +1159,49 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         unsigned long long eold = 0ULL;
         const bool arrive = have && exit_kind;                         // (the atomic itself: behind the first arcs' loads, below)
         XFINE(2);                                                      // winners: key reset, Path record, final state
+        // ---- The prefix walk of jd_slot.h's phase X (see there): a row of up to 57 arcs has its model arcs in descending order of
+        // w + tmax behind the arcs every arrival walks; the item walks the prefix it can enter, by the samples of the state's XState,
+        // and accounts for the rest from that record and the row's instance flags.
+        int x_new = 0;
+        const bool xitem = xcut && have && slice_no == 0 && rs1 - (rs & ~7) <= 64;
+        if (xitem) {
+            const int n_entry = x0.y, n_model = x0.w;
+            if (n_model > 0) { const unsigned sw = f2o(t.score + __int_as_float(x0.z)); mo = sw > mo ? sw : mo; }
+            const int a8 = rs & ~7;
+            const GAS unsigned long long *lw = (const GAS unsigned long long *)(V.live + a8);
+            auto in_row = [&](int base) __attribute__((always_inline)) {   // the bytes of the word at `base` that belong to the row
+                const int lo = max(rs - base, 0), hi = min(rs1 - base, 8);
+                const unsigned long long mh = hi >= 8 ? ~0ULL : ((1ULL << (8 * max(hi, 0))) - 1ULL);
+                const unsigned long long ml = (1ULL << (8 * lo)) - 1ULL;
+                return 0x0101010101010101ULL & mh & ~ml;
+            };
+            int lv_row = 0;
+            {
+                unsigned long long w8[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w8[i] = (n_model > 0 && a8 + 8 * i < rs1) ? CL(lw + i) : 0ULL;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lv_row += __popcll(w8[i] & in_row(a8 + 8 * i));
+            }
+            if (__ballot(n_model > 0 && a8 + 32 < rs1)) {               // (some lane's row goes on: the second batch)
+                unsigned long long w8[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w8[i] = (n_model > 0 && a8 + 8 * (4 + i) < rs1) ? CL(lw + 4 + i) : 0ULL;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lv_row += __popcll(w8[i] & in_row(a8 + 8 * (4 + i)));
+            }
+            x_new = n_model - lv_row;
+            if (can_filter && n_entry > 0) {
+                const float lim = (bestA - C.emit_win) - (1.0f + 1e-5f * (fabsf(bestA) + fabsf(t.score)));
+                const int kx[XNCAND] = {x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+                int P = n_entry;
+#pragma unroll
+                for (int i = XNCAND - 1; i >= 0; --i)
+                    if (xcand(i) < n_entry && t.score + __int_as_float(kx[i]) <= lim) P = xcand(i);
+                c_arcs += n_entry - P;
+                rs1 -= n_entry - P;
+            }
+        }
         // ---- A state with thousands of out-arcs (a history with 10^4 successors) would keep this wave busy
         // for hundreds of passes while the cluster waits at the barrier: the wave walks the first X_SLICE
         // arcs itself and hands the rest on as SLICES - items of the next round (flag 2 + slice number)
@@ -1189,6 +1238,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         // stands, so this way the two round trips are one
         if (arrive) { eold = GMAX(&V.srec[state].e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
         list_dirty(arrive && eold == 0ULL, state);
+        if (eo == 0u) c_new += x_new;                                  // (the first arrival at the state in this frame: :899-935 tries them all)
         if (__ballot(n_slices > 0)) {
             for (unsigned long long bs = __ballot(n_slices > 0); bs; bs &= bs - 1) {
                 const int src = __ffsll((long long)bs) - 1;
@@ -1225,7 +1275,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             tg.score = __shfl(t.score, g); tg.ac = __shfl(t.ac, g);
             tg.lm = __shfl(t.lm, g); tg.path = __shfl(t.path, g);
             const unsigned eog = (unsigned)__shfl((int)eo, g);         // best arrival at the owner's state before it (ordered; 0: none)
-            const int sg = __shfl(state, g);
+            const int sgx = __shfl(state | (xitem ? (int)0x80000000 : 0), g);   // (+ the owner's "counted per state" flag)
+            const int sg = sgx & 0x7fffffff;
             bool mk = false, touch = false;
             Tok un = null_tok();
             // Everything a pass READS is requested before anything is waited for - one memory round trip: the
@@ -1269,7 +1320,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             if (entry) {                                               // :560-582 entry-token recombination: pulled by the next phase A
                 mo = so > mo ? so : mo;                                // :572-573
                 if (lv == 0) {                                         // no instance: attachNetInst :751-774
-                    if (eog == 0u) ++c_new;                            // (counted once, by the first arrival at the state)
+                    if (sgx >= 0 && eog == 0u) ++c_new;                // (counted once, by the first arrival at the state; prefix walks: per state, above)
                     if (can_filter) {
                         const bool mine = (ns + tmax) - bestA > -C.emit_win;
                         const bool before = eog != 0u && ((o2f(eog) + Bk.w) + tmax) - bestA > -C.emit_win;
