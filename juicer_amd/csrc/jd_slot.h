@@ -1,4 +1,4 @@
-// jd_slot.h - the search of ONE utterance stream by ONE workgroup, two such workgroups per CU: the slot kernel
+// jd_slot.h - the search of ONE utterance stream by ONE workgroup that takes half a CU: the slot kernel
 // (included by jd_device.hip behind jd_search.h and jd_resident.h; gfx950 only).
 //
 // Reference: the same as jd_search.h - WFSTDecoderLite::processFrame (src/WFSTDecoderLite.cpp:311-372) =
@@ -18,7 +18,11 @@
 //     expansion - the readers of a list build its prefix themselves from eight counts in LDS;
 //   * phase A is NOT software-pipelined: the pipeline of jd_search.h (next record + next keys in flight behind the
 //     current chunk) is what two waves per SIMD need and what costs 60 VGPRs; here the kernel is compiled for FOUR waves
-//     per SIMD (<= 128 VGPRs, <= 80 KB LDS: two workgroups per CU) and the other waves hide the round trips.
+//     per SIMD (<= 128 VGPRs, <= 80 KB LDS: half a CU).  What runs on the other half: a second slot (k_slot_batch: batches of
+//     more streams than CUs) - or the scoring kernel's waves, arithmetic beside a search that waits for memory, which is how
+//     the pipeline's slots are dealt: one per CU (jd_host_resident.h: jd_res_start).
+//   * phase X walks only the arcs of a state that the arriving token can enter: the decoder keeps a state's model arcs in
+//     descending order of the bound the pruning test runs on (XState, jd_search.h).
 #pragma once
 
 #define XLW 4                        // phase X: 8-byte words of a row's instance flags requested at once (XState)
@@ -1114,11 +1118,12 @@ __global__ __launch_bounds__(SNT, SLOT_WPE) void k_slot(SearchArgs A, const ResP
     }
 }
 
-// Where the slots go.  Two slot workgroups fit a CU, but the dispatcher deals a grid smaller than twice the chip one workgroup
-// per CU first - and a CU that holds ONE slot is half empty for the search and half taken from the scoring kernel beside it
-// (measured, 320 slots dealt over all 256 CUs: the slots busy 54 % of the time, starved by a scoring that finds no whole CU).
-// A CU-masked stream would do it, but hipExtStreamCreateWithCUMask only makes BLOCKING streams, and the legacy default stream
-// then waits for a kernel that stays.  So the CUs the scoring is to keep are PARKED while the slots are dealt: this kernel asks
+// Where the slots go - a development tool now (JD_SLOT_KEEP_SE): the pipeline deals its slots ONE per CU and the scoring kernel's
+// workgroups take the other half of the same CUs, which is the dispatcher's own arrangement for a grid of at most one workgroup
+// per CU and measured 18 % faster than what this kernel is for (jd_host_resident.h: jd_res_start): TWO slots per CU on some
+// CUs, the other CUs left whole to the scoring.  The dispatcher deals a grid smaller than twice the chip one workgroup per CU
+// first; a CU-masked stream would change that, but hipExtStreamCreateWithCUMask only makes BLOCKING streams, and the legacy default
+// stream then waits for a kernel that stays.  So the CUs the scoring is to keep are PARKED while the slots are dealt: this kernel asks
 // for a CU's whole LDS - one workgroup per CU, nothing fits beside it - and of the workgroups that reach an XCD the first
 // quota[xcd] stay until the host releases them; the others leave at once.  The slot kernel, launched then, finds room on the
 // CUs that are left only - two workgroups each - and stays there for its life; the parked CUs are released when every slot
