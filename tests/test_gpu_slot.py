@@ -142,3 +142,30 @@ def test_pipeline_api_arguments(built):
     h2 = gd.decode_batch(feats)[0]
     assert bit_exact(h, h2) and h.n > 0
     gd.close()
+
+
+def test_slot_kernel_rows_of_every_length(monkeypatch, built):
+    """Phase X's prefix walk (XState, jd_slot.h) decides per row how it is walked: rows of up to 57 arcs by the sorted prefix and
+    their instance flags in one or two batches of loads, longer rows whole.  A trigram-shaped graph has rows of every length - from
+    one arc to thousands, epsilon back-off arcs among them - on both sides of every one of those limits: the slot kernel's results
+    AND the reference's statistics on it must be those of k_search (which the full-size tests hold against the oracle)."""
+    from helpers import STAT_KEYS
+    from juicer_amd import capi, synth
+    am, net, feats, _ = synth.config_c4(seed=0, n_utts=4, n_words=10000, n_tri_hist=100_000)
+    deg = np.bincount(net.src, minlength=net.n_states)
+    for lo, hi in ((1, 24), (25, 32), (33, 57), (58, 64), (65, 256), (257, 1 << 30)):      # the limits of jd_slot.h / X_SLICE
+        assert np.any((deg >= lo) & (deg <= hi)), (lo, hi)
+    models, network = capi.Models.from_htk(am), capi.Network.from_synth(net)
+    monkeypatch.setenv("JD_DEV", "1")
+    outs = []
+    for slot in (False, True):
+        monkeypatch.setenv("JD_SLOT_BATCH", "1" if slot else "0")
+        monkeypatch.setenv("JD_CW", "1" if slot else "64")
+        gd = capi.Decoder(network, models, main_beam=200.0, max_streams=len(feats))
+        outs.append(gd.decode_batch(feats))
+        assert (gd.last_timing()["slot_launches"] > 0) == slot
+        gd.close()
+    for u, (a, b) in enumerate(zip(*outs)):
+        assert a.n > 0 and bit_exact(b, a), u
+        for k in STAT_KEYS:
+            assert a.stats[k] == b.stats[k], (u, k, a.stats[k], b.stats[k])
