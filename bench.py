@@ -61,7 +61,7 @@ def search_bytes(st, max_n):
             + 24.0 * st["tot_proc_end_hyps"] + 52.0 * st["tot_arcs_visited"] + 20.0 * st["tot_paths"])
 
 
-def roofline_of(st, max_n, tm, traffic=None):
+def roofline_of(st, max_n, tm, traffic=None, design=None):
     """Roofline of a search launch (k_search unless the caller names another kernel): achieved = algorithmic
     bytes per launch / average launch duration (HIP events around each launch on the decoder's
     search stream, jd_dec_last_timing).  frac = achieved / peak prices the launch by SURVEY.md 8(d)'s
@@ -72,11 +72,104 @@ def roofline_of(st, max_n, tm, traffic=None):
     avg_us = 1e3 * tm["search_ms"] / launches
     achieved = per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
     measured = traffic / (avg_us * 1e-6) / 1e9 if (traffic and avg_us > 0) else None
-    return {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-            "frac_measured": round(measured / HBM_PEAK_GBS, 6) if measured else None,
-            "algorithmic_bytes_per_launch": round(per_launch, 1), "avg_launch_us": round(avg_us, 3),
-            "launches_per_step": launches, "workgroups_per_stream": tm["cluster_wgs"]}
+    out = {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+           "frac_measured": round(measured / HBM_PEAK_GBS, 6) if measured else None,
+           "algorithmic_bytes_per_launch": round(per_launch, 1), "avg_launch_us": round(avg_us, 3),
+           "launches_per_step": launches, "workgroups_per_stream": tm["cluster_wgs"]}
+    if design is not None:                                         # the bytes the design requests, by the kernels' own counters
+        dpl = design / launches
+        out["design_bytes_per_launch"] = round(dpl, 1)
+        out["frac_design"] = round(dpl / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6) if avg_us > 0 else None
+    return out
+
+
+def design_bytes(st, max_n, G, frames, row_in_lds):
+    """Bytes the DESIGN requests for the work in `st` (batch totals of jd_stats, the kernels' own counters tot_recs_read ..
+    tot_closure_items): what `search_bytes` prices is the REFERENCE's work - 11.7 k instances per configs[1]
+    frame at 164 B each, where the GPU keeps ~5 k records and the rest are candidates that never become one, and arcs a prefix
+    walk accounts for without reading them.  Sectors as requested (16-byte halves of a 32-byte StateRec, 32-byte items), not the
+    64 / 128-byte transactions the memory system makes of them - that is `traffic`.
+      phase A  record read R + the source state's arrival keys 16; a newly entered arc: list entry 8 + arc 16 + template 16 (32) +
+               keys 16; the winning item's token 16 per entry token pulled; record written R; exit token: item 32 + bid 8;
+               likelihoods: the frame's row into LDS (G x 4, the slot kernel) or 4 per emitting hypothesis (k_search)
+      phase X  item taken up: item 32 + state record XState 64 + bid keys 16 + CSR bounds 8 + the row's instance flags 32;
+               arrival: 8 (atomic max); arc walked: record 16 + flag 1; closure item: item 32 + atomic 8 + destination keys 16;
+               Path record 32"""
+    R = 80.0 if max_n <= 5 else 144.0
+    tmpl = 16.0 if max_n <= 5 else 32.0
+    a = (st["tot_recs_read"] * (R + 16.0) + st["tot_new_attached"] * (8.0 + 16.0 + tmpl + 16.0) + st["tot_entry_items"] * 16.0
+         + st["tot_recs_written"] * R + st["tot_active_end_hyps"] * 40.0
+         + (frames * G * 4.0 if row_in_lds else st["tot_proc_emit_hyps"] * 4.0))
+    x = (st["tot_items_expanded"] * (32.0 + 64.0 + 16.0 + 8.0 + 32.0) + st["tot_proc_end_hyps"] * 8.0 + st["tot_arcs_walked"] * 17.0
+         + st["tot_closure_items"] * 56.0 + st["tot_paths"] * 32.0)
+    return a + x
+
+
+def reference_cpu():
+    """BASELINE.md B1 / B2 as quoted constants: the reference's own WFSTDecoderLite / WFSTDecoderLiteThreading on configs[1],
+    measured in the BUILD container (tools/refbase -> profiles/cpu_reference_baseline.json; a build against stand-ins: a
+    timing and differential aid, not a reference build).  The GPU box has no /root/reference: nothing is run here."""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference_baseline.json")))
+        b1, b2 = r.get("WFSTDecoderLite", {}), r.get("WFSTDecoderLiteThreading", {})
+        d = r.get("differential", {})
+        return {"B1_WFSTDecoderLite_fps": b1.get("frames_per_s"), "B1_cores": 1,
+                "B2_WFSTDecoderLiteThreading_fps": b2.get("frames_per_s"), "B2_cores": 2,
+                "B1_identical_to_oracle": "%s/%s" % (b1.get("identical_to_oracle"), b1.get("utterances")),
+                "B2_identical_to_oracle": "%s/%s" % (b2.get("identical_to_oracle"), b2.get("utterances")),
+                "differential_cases_identical": "%s/%s" % (d.get("cases_identical"), d.get("cases_total")) if d else None,
+                "oracle_port_same_host_fps": r.get("oracle_port", {}).get("frames_per_s"),
+                "host": "%s, %s cores (build container)" % (r.get("host", {}).get("model"), r.get("host", {}).get("cores")),
+                "source": "profiles/cpu_reference_baseline.json (tools/refbase; stand-in build: pins nothing)"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def word_errors(hyp, ref):
+    """Levenshtein distance between two label sequences (substitutions + deletions + insertions, unit costs)."""
+    hyp, ref = list(hyp), list(ref)
+    prev = list(range(len(ref) + 1))
+    for i, h in enumerate(hyp, 1):
+        cur = [i] + [0] * len(ref)
+        for j, r in enumerate(ref, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (h != r))
+        prev = cur
+    return prev[-1]
+
+
+def wer_vs_oracle(net, am, feats, hyps, beam, max_hyps, first_done=None, workers=None):
+    """BASELINE.json's metric names "1-best WER vs ref": the GPU's 1-best of EVERY utterance of the step against the CPU
+    oracle's (the reference algorithm restated; oracle/ is the checker here, outside the timed region): word errors / the
+    oracle's words, and how many hypotheses are identical in words, times and - bit for bit - scores.  One oracle decoder per
+    host thread (the C library keeps its state in the decoder; ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    onet, oam = OracleNet(net), OracleAM(am)
+    n = len(feats)
+    workers = max(1, min(workers or (os.cpu_count() or 1), 32, n))
+    t0 = time.perf_counter()
+
+    def chunk(k):
+        od = OracleDecoder(onet, oam, main_beam=beam, max_hyps=max_hyps)
+        return [(u, od.decode(feats[u])) for u in range(k, n, workers)]
+    with ThreadPoolExecutor(workers) as ex:
+        res = dict(x for part in ex.map(chunk, range(workers)) for x in part)
+    errs = words = same = bits = found = 0
+    f32 = lambda a: np.asarray(a, np.float32).view(np.uint32)
+    for u in range(n):
+        o, g = res[u], hyps[u]
+        ow = list(o.label[::-1]) if o.n > 0 else []                # (chain order is newest first)
+        gw = list(g.label[::-1]) if g.n > 0 else []
+        errs += word_errors(gw, ow); words += len(ow); found += int(o.n > 0)
+        eq = g.n == o.n and np.array_equal(g.label, o.label) and np.array_equal(g.time, o.time)
+        same += int(eq)
+        bits += int(eq and (o.n <= 0 or (np.array_equal(f32(g.score), f32(o.score)) and np.array_equal(f32(g.ac), f32(o.ac))
+                                        and np.array_equal(f32(g.lm), f32(o.lm)))))
+    return {"wer": round(errs / max(words, 1), 6), "word_errors": int(errs), "ref_words": int(words), "utterances": n,
+            "identical_1best": same, "identical_scores_bitwise": bits, "oracle_hyps_found": found,
+            "oracle_threads": workers, "oracle_wall_s": round(time.perf_counter() - t0, 1),
+            "ref": "CPU oracle (restated reference algorithm, oracle/juicer_oracle.c), every utterance of rank 0's step"}
 
 
 def kernel_source_hash():
@@ -99,7 +192,7 @@ def calibrated_traffic(fetch_kib, write_kib, wide_read_bytes):
     return (fetch_kib + write_kib) * 1024.0 + 0.5 * wide_read_bytes
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def slot_traffic(frames):
@@ -130,7 +223,7 @@ def leg_traffic(leg, launches):
 
 
 def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, gnet=None, pmc_leg=None, oracle_feats=None,
-            oracle_net=None, ahead=True, max_streams=0, two=None, pipe=None, caps=None):
+            oracle_net=None, ahead=True, max_streams=0, two=None, pipe=None, caps=None, scoring="exact"):
     """One extra workload: warm-up pass + timed passes on one GPU (value = the MEDIAN pass), its own roofline.
     gnet: a network that exists already (composed on the device); net is then only asked for its size.
     pmc_leg: the name the leg's PMC passes are filed under (leg_traffic).  oracle_utts: that many utterances are
@@ -153,6 +246,8 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
     dec = capi.Decoder(gnet if gnet is not None else capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=beam,
                        max_hyps=max_hyps, device=dev.index, max_streams=(2 * U if two else U) if not max_streams else max_streams,
                        **(dict(zip(("max_slots", "max_paths", "max_items"), caps)) if caps else {}))   # (caps: per-stream arena capacities, jd_dec_set_capacity)
+    if scoring == "fast":                                              # jd_dec_set_scoring: FMA distance + fp32 logAdd (scores within 1e-4)
+        dec.set_scoring(capi.SCORE_FAST)
     if depth:
         dec.set_pipeline(capi.FLOW_RESIDENT, depth + 1, max_streams)
     offs = np.zeros(U + 1, dtype=np.int64)
@@ -216,10 +311,13 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
            "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
                                                                               "tot_proc_end_hyps", "tot_arcs_visited", "tot_paths")},
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
-           "roofline": roofline_of(st, am.max_n, tm, leg_traffic(pmc_leg, max(1, tm["search_launches"])) if pmc_leg else None),
            "setup_s": round(time.perf_counter() - t0 - sum(r[0] for r in runs), 1)}
     # (which kernel the leg's frames went through: the pipeline's slots, the slot kernel as a plain launch, else clusters of k_search)
-    out["roofline"]["kernel"] = "k_slot" if depth else ("k_slot_batch" if tm.get("slot_launches", 0) > 0 else "k_search")
+    kernel = "k_slot" if depth else ("k_slot_batch" if tm.get("slot_launches", 0) > 0 else "k_search")
+    out["roofline"] = roofline_of(st, am.max_n, tm, leg_traffic(pmc_leg, max(1, tm["search_launches"])) if pmc_leg else None,
+                                  design_bytes(st, am.max_n, am.n_gmm, frames, row_in_lds=kernel != "k_search" and am.n_gmm <= 3072))
+    out["roofline"]["kernel"] = kernel
+    out["scoring"] = scoring
     if oracle_utts > 0:
         from oracle.oracle import OracleAM, OracleDecoder, OracleNet
         od = OracleDecoder(oracle_net if oracle_net is not None else OracleNet(net), OracleAM(am), main_beam=beam, max_hyps=max_hyps)
@@ -342,21 +440,17 @@ def main():
     ap.add_argument("--no-search-ahead", action="store_true",
                     help="one batch in flight: the decoder gets streams for one batch only and the announcements run one batch ahead")
     ap.add_argument("--pipeline-depth", type=int, default=9,
-                    help="weak scaling: batches announced ahead of the one being decoded, through the resident search kernel "
-                         "(JD_PIPELINE=3: every stream a one-workgroup slot that takes the next queued utterance when its own is through); "
-                         "0 = two batches in flight, one launch per step (what runs with several ranks) - measured on one box, 20 steps: "
-                         "30.7-30.8 ms per step against 26.7 with six batches ahead through 160 slots")
+                    help="weak scaling: batches announced ahead of the one being decoded, through the resident slot kernel (DESIGN.md 3.6); "
+                         "0 = two batches in flight, one k_search launch per step")
     ap.add_argument("--pipeline-slots", type=int, default=256,
-                    help="streams (= one-workgroup slots) of the resident pipeline: dealt one per CU while there are CUs (the slot kernel, "
-                         "csrc/jd_slot.h, takes half a CU; the scoring kernel's workgroups run on the other half) - measured on one box, nine batches "
-                         "ahead, before phase X's prefix walk: 192 slots 1.82 M frames/s, 224 2.05 M, 240 2.17 M, 256 2.27 M, 272 2.16 M, 288 2.12 M, 304 1.96 M "
-                         "(a CU that holds two slots has no room for the scoring); two slots per CU on half of the chip and the scoring on the other "
-                         "half: 1.93 M; with the prefix walk 240 / 256 / 272 / 288: 2.34 / 2.38 / 2.13 / 2.12 M")
+                    help="one-workgroup slots of the resident pipeline, dealt one per CU (DESIGN.md 3.4 has the measured sweep: 240 / 256 / 272 / "
+                         "288 slots 2.34 / 2.38 / 2.13 / 2.12 M frames/s)")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="several ranks: 0 = the 1-best records of all timed steps travel in ONE RCCL all_gather at the end of the timed "
-                         "region, behind jd_dec_quiesce (a rank has its own results at once; a collective's kernels must not be queued on a "
-                         "device whose search kernel stays); 1 = one all_gather per step, which runs two batches in flight instead of "
-                         "the resident pipeline")
+                         "region, behind jd_dec_quiesce; 1 = one all_gather per step (two batches in flight instead of the resident pipeline)")
+    ap.add_argument("--scoring", choices=("exact", "fast"), default="exact",
+                    help="exact (default): the reference's roundings, log-likelihoods bit-identical to the CPU oracle; fast: fused multiply-add "
+                         "distance + fp32 logAdd on the hardware's exp / log (jd_dec_set_scoring: labels and times identical, scores within 1e-4)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -368,6 +462,7 @@ def main():
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
         sys.exit(spawn_ranks(args.gpus))
 
+    t_proc = time.perf_counter()
     import torch
     import torch.distributed as dist
     from juicer_amd import build as jbuild
@@ -384,68 +479,104 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    marks = [("start", t_proc)]                                    # wall-clock budget of the run, printed to stderr by rank 0
+
+    def mark(what):
+        marks.append((what, time.perf_counter()))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # stdout carries ONE JSON line: RCCL's version banner (NCCL_DEBUG=VERSION, exported on the GPU boxes) goes to stderr
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             del os.environ["NCCL_DEBUG"]
+        import datetime
+        # (a rank that dies leaves the others in a collective: they give up after ten minutes, not after RCCL's half hour)
         if share_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
     if rank == 0:
         jbuild.build()
     bar_kw = {} if share_gpu else {"device_ids": [local_rank]}
     if world > 1:
         dist.barrier(**bar_kw)
+    mark("import + process group")
 
     U = args.utts_per_gpu
     strong = args.total_utts > 0
     shard = None
+    refs = None
     if strong:
         # one fixed batch: every rank generates the same utterances (seeded) and takes the ones dealt to it by
         # length (parallel.shard_lpt: longest first, each to the rank with the fewest frames so far)
-        am, net, all_feats, _ = synth.config_c2(seed=args.seed, n_utts=args.total_utts, target_arcs=args.arcs)
+        am, net, all_feats, all_refs = synth.config_c2(seed=args.seed, n_utts=args.total_utts, target_arcs=args.arcs)
         shards = parallel.shard_lpt([f.shape[0] for f in all_feats], world)
         shard = shards[rank]
         # what the 1-GPU measurements say every rank's share should take (the first real SCALE run can be read against it):
-        # a wave of at most 128 streams lasts as long as its longest utterance's chain of frames (33 us per frame, docs/DESIGN_HISTORY.md
-        # 9) or as its frames take at the rate of the 512-utterances-on-one-GPU leg (1.44 M frames/s), whichever is more
-        predicted_rank_ms = [round(max(max([all_feats[u].shape[0] for u in sh] or [0]) * 33e-3 + 1.5,
-                                       sum(all_feats[u].shape[0] for u in sh) / 1.44e6 * 1e3), 2) for sh in shards]
+        # a rank's utterances through the slot kernel as a plain launch at the 512-utterances-on-one-GPU leg's rate (2.3 M frames/s),
+        # but no less than its longest utterance's chain of frames (100 us per frame on one slot)
+        predicted_rank_ms = [round(max(max([all_feats[u].shape[0] for u in sh] or [0]) * 100e-3 + 1.5,
+                                       sum(all_feats[u].shape[0] for u in sh) / 2.3e6 * 1e3), 2) for sh in shards]
         per_rank = max(len(x) for x in shards)
         feats = [all_feats[u] for u in shard]
+        refs = [all_refs[u] for u in shard]
         del all_feats
         U = max(1, len(feats))
     else:
-        am, net, feats, _ = synth.config_c2(seed=args.seed, n_utts=U, target_arcs=args.arcs, utt_offset=rank * U)
+        am, net, feats, refs = synth.config_c2(seed=args.seed, n_utts=U, target_arcs=args.arcs, utt_offset=rank * U)
         per_rank = U
     gnet = capi.Network.from_synth(net)
     gam = capi.Models.from_htk(am)
-    # (a rank that holds more than 128 utterances of a fixed batch decodes them in waves of 128 streams, each wave's table
-    # scored beside the wave before it: measured faster than one stream per utterance from 256 utterances on)
-    # (weak scaling: batches of U utterances follow each other, and a decoder with room for two of them starts the
-    # utterances of the batch behind the running one beside it - "two batches in flight")
+    mark("synthetic graph, models, utterances")
+    # How the batches share the chip.  Weak scaling: batches of U utterances follow each other - through the slots of
+    # a search kernel that stays (a batch is scored whole when it is announced, a slot takes the next queued utterance the moment its
+    # own is through, a step hands back the oldest batch: still ITS results, decoded in full), or with two batches in flight.
+    # Several ranks run the same path.  A collective's kernels must not be queued on a device whose search kernel STAYS (HIP maps
+    # streams onto a few hardware queues: tools/resident_alias_probe.py), so the 1-best records of the K steps travel in ONE RCCL
+    # all_gather at the end of the timed region, behind jd_dec_quiesce - utterances are independent, DecoderBatchTest.cpp:738-771: a
+    # rank has its own results the moment its step returns.  --gather-every 1 keeps a collective per step and two batches in flight.
     ahead = not args.no_score_ahead
     two_in_flight = ahead and not args.no_search_ahead and not strong
-    # ... or, deeper: the batches' utterances through the slots of a search kernel that stays ("batches through the
-    # resident kernel"): a batch is scored whole when it is announced, a slot takes the next queued utterance the moment its own
-    # is through, and a step hands back the oldest batch - still ITS 64 results, decoded in full
-    # (several ranks: the same path.  What a collective needs - its kernels on a stream of the process - it must not get while a
-    # kernel STAYS on the device: HIP maps streams onto a few hardware queues, tools/resident_alias_probe.py finds one fresh stream
-    # in fourteen queued BEHIND the resident kernel until it leaves.  So the 1-best records of the K steps travel in ONE RCCL
-    # all_gather at the end of the timed region, behind jd_dec_quiesce - utterances are independent, DecoderBatchTest.cpp:738-771:
-    # a rank has its own results the moment its step returns.  --gather-every 1 keeps a collective per step and two batches in flight.)
     per_step_gather = world > 1 and args.gather_every == 1
-    depth = args.pipeline_depth if (two_in_flight and args.pipeline_depth > 0 and not per_step_gather) else 0
+    depth0 = args.pipeline_depth if (two_in_flight and args.pipeline_depth > 0 and not per_step_gather) else 0
+    fail_spec = os.environ.get("JD_BENCH_FAIL", "")               # test knob "rank:phase" (phase: create | warmup | timed): that rank's pipeline attempt fails there
+    fail_rank, fail_phase = (int(fail_spec.split(":")[0]), fail_spec.split(":")[1]) if ":" in fail_spec else (-1, "")
+    empty_index = [] if shard is not None else None
+
+    def any_rank(flag):
+        """collective: did ANY rank raise?  (every rank takes the same decision, so the collectives that follow stay matched)"""
+        if world == 1:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0.0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(**bar_kw)
+
     pipeline_error = None
-    for depth in ((depth, 0) if depth else (0,)):                      # (should the pipeline fail: the same measurement, two batches in flight)
-      try:
-        dec = capi.Decoder(gnet, gam, main_beam=args.beam, max_hyps=args.max_hyps, device=local_rank,
-                           max_streams=min(U, 512) if strong else (args.pipeline_slots if depth else (2 * U if two_in_flight else U)))
-        if depth:                                                      # the interface: jd_dec_set_pipeline (include/juicer_amd.h)
-            dec.set_pipeline(capi.FLOW_RESIDENT, depth + 1, args.pipeline_slots)
+    dec = None
+    attempts = (depth0, 0) if depth0 else (0,)
+    for ai, depth in enumerate(attempts):                          # (should the pipeline fail on ANY rank: the same measurement, two batches in flight, on ALL)
+        err = None                                                 # this rank's first error of the attempt
+        pending = []                                               # several ranks: steps whose records have not travelled yet
+        hyps = allh = None
+        ph = {"phase": "create"}
+
+        def forced(phase):
+            if depth and rank == fail_rank and fail_phase == phase:
+                raise capi.JuicerAmdError(-5, "forced failure (JD_BENCH_FAIL=%s)" % fail_spec)
+        try:
+            forced("create")
+            dec = capi.Decoder(gnet, gam, main_beam=args.beam, max_hyps=args.max_hyps, device=local_rank,
+                               max_streams=min(U, 512) if strong else (args.pipeline_slots if depth else (2 * U if two_in_flight else U)))
+            if args.scoring == "fast":
+                dec.set_scoring(capi.SCORE_FAST)
+            if depth:                                              # the interface: jd_dec_set_pipeline (include/juicer_amd.h)
+                dec.set_pipeline(capi.FLOW_RESIDENT, depth + 1, args.pipeline_slots)
+        except capi.JuicerAmdError as e:
+            err = e
         offs = np.zeros(len(feats) + 1, dtype=np.int64)
         offs[1:] = np.cumsum([f.shape[0] for f in feats])
         frames_local = int(offs[-1])
@@ -453,82 +584,127 @@ def main():
         torch.cuda.synchronize()
         stream = torch.cuda.current_stream().cuda_stream
 
-        pending = []                                                   # several ranks: steps whose records have not travelled yet
-
-        def step():
-            # One step = one pass over one batch: its search, and one scoring of a batch's likelihood table.  Batches follow
-            # each other, so the table of a LATER batch (here: the same synthetic batch again) is scored on the CUs this
-            # batch's search leaves idle (jd_dec_prefetch_scores) - K timed steps hold K searches and K scorings either way.
-            # With two batches in flight the announcements run two batches ahead (one more before the first step, below):
-            # the batch behind the running one has its table already and its utterances are started beside it - every
-            # step still returns ITS batch's 64 results, decoded in full; what a step does of the next batch's search the
-            # next step does not have to do, and K steps hold K batches' worth of search.
+        def local_step():
+            # One step = one pass over one batch: its search, and one scoring of a batch's likelihood table.  Batches follow each other,
+            # so the table of a LATER batch (here: the same synthetic batch again, scored from its features every time) is scored beside
+            # this batch's search (jd_dec_prefetch_scores) - K timed steps hold K searches and K scorings either way, and every step
+            # returns ITS batch's results, decoded in full.
+            forced(ph["phase"])
             if ahead:
                 dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
-            hyps = dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
-            if world > 1 and per_step_gather:
-                return hyps, parallel.gather_hyps(hyps, per_rank, device=dev, index=shard)
-            if world > 1:
-                pending.append((hyps, shard))
-            return hyps, hyps
+            return dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
+
+        def run_steps(n, each=None, acc=None):
+            """n steps; a rank whose decoder failed keeps taking part in every collective (with empty records) - the others must
+            not be left waiting in an all_gather for a rank that has raised"""
+            nonlocal err, hyps, allh
+            tm = {}
+            for _ in range(n):
+                ts = time.perf_counter()
+                h = None
+                if err is None:
+                    try:
+                        h = local_step()
+                    except capi.JuicerAmdError as e:
+                        err = e
+                if world > 1:
+                    rec, ix = (h, shard) if h is not None else ([], empty_index)
+                    if per_step_gather:
+                        try:
+                            allh = parallel.gather_hyps(rec, per_rank, device=dev, index=ix)
+                        except ValueError as e:                    # (a rank sent empty records: its utterances are missing)
+                            err = err or capi.JuicerAmdError(-5, "gather: %s" % e)
+                    else:
+                        pending.append((rec, ix))
+                if h is not None:
+                    hyps = h
+                    if world == 1:
+                        allh = h
+                    if each is not None:
+                        each.append(round((time.perf_counter() - ts) * 1e3, 3))
+                    if acc is not None:
+                        tm = dec.last_timing()
+                        for k in acc:
+                            acc[k] += tm[k]
+            return tm
 
         def travel():
             """the records of the steps since the last exchange: ONE all_gather (the resident kernel has left: quiesce)"""
+            nonlocal err
             if not pending:
                 return None
-            got = parallel.gather_hyps_steps(pending, per_rank, device=dev)
-            del pending[:]
-            return got
+            try:
+                return parallel.gather_hyps_steps(pending, per_rank, device=dev)
+            except ValueError as e:
+                err = err or capi.JuicerAmdError(-5, "gather: %s" % e)
+                return None
+            finally:
+                del pending[:]
 
-        def barrier():
-            if world > 1:
-                dist.barrier(**bar_kw)
+        def quiesce():
+            nonlocal err
+            if err is None:
+                try:
+                    dec.quiesce()
+                except capi.JuicerAmdError as e:
+                    err = e
 
-        if depth:
-            for _ in range(depth):                                         # (the announcements run `depth` batches ahead)
-                dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
-            for _ in range(depth + 2):                                     # the pipeline fills: its first batches come back in a burst
-                step()
-        elif two_in_flight:
-            dec.prefetch_scores(d_feats.data_ptr(), offs, stream)          # (the announcements run two batches ahead)
-        for _ in range(args.warmup):
-            step()
+        # ---- fill + warm-up
+        ph["phase"] = "warmup"
+        if err is None:
+            try:
+                if depth:
+                    for _ in range(depth):                         # (the announcements run `depth` batches ahead)
+                        dec.prefetch_scores(d_feats.data_ptr(), offs, stream)
+                elif two_in_flight:
+                    dec.prefetch_scores(d_feats.data_ptr(), offs, stream)      # (the announcements run two batches ahead)
+            except capi.JuicerAmdError as e:
+                err = e
+        run_steps((depth + 2 if depth else 0) + args.warmup)       # (the pipeline fills: its first batches come back in a burst)
         # (a device-wide synchronisation waits for every kernel on the device: the pipeline's resident kernel lets its running
         # commands run out and leaves - jd_dec_quiesce - and comes back with the first timed step, inside the brackets)
-        dec.quiesce()
+        quiesce()
         travel()
-        barrier(); torch.cuda.synchronize()
-        ps0 = dec.pipeline_stats()
-        t0 = time.perf_counter()
-        acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0,
-               "ahead_frames": 0}
-        tm = {}
-        hyps = None
-        each = []
-        for _ in range(args.steps):
-            ts = time.perf_counter()
-            hyps, allh = step()
-            each.append(round((time.perf_counter() - ts) * 1e3, 3))
-            tm = dec.last_timing()
-            for k in acc:
-                acc[k] += tm[k]
-        dec.quiesce()
-        gathered = travel()                                            # (inside the timed region: the one collective of the K steps)
-        if gathered:
-            allh = gathered[-1]
-        torch.cuda.synchronize(); barrier()
-        elapsed = time.perf_counter() - t0
-        ps1 = dec.pipeline_stats()
-        break
-      except capi.JuicerAmdError as e:
-        if not depth:
-            raise
-        pipeline_error = str(e)
-        print("bench.py: the resident pipeline failed (%s): measuring with two batches in flight" % e, file=sys.stderr)
+        if not any_rank(err is not None):
+            mark("decoder, arenas, pipeline fill, warm-up (%d steps)" % ((depth + 2 if depth else 0) + args.warmup))
+            # ---- the timed region
+            ph["phase"] = "timed"
+            barrier(); torch.cuda.synchronize()
+            ps0 = dec.pipeline_stats()
+            t0 = time.perf_counter()
+            acc = {"gmm_ms": 0.0, "search_ms": 0.0, "gmm_wait_ms": 0.0, "search_launches": 0, "gmm_launches": 0, "relaunches": 0, "prefetched": 0,
+                   "ahead_frames": 0}
+            each = []
+            tm = run_steps(args.steps, each, acc)
+            quiesce()
+            gathered = travel()                                    # (inside the timed region: the one collective of the K steps)
+            if gathered:
+                allh = gathered[-1]
+            torch.cuda.synchronize(); barrier()
+            elapsed = time.perf_counter() - t0
+            if not any_rank(err is not None):
+                ps1 = dec.pipeline_stats()
+                mark("timed region (%d steps)" % args.steps)
+                break
+        # ---- some rank failed: every rank drops this attempt
+        msg = str(err) if err is not None else "another rank's decoder failed"
+        if rank == 0 or err is not None:
+            print("bench.py[rank %d]: %s failed (%s)%s" % (rank, "the resident pipeline" if depth else "the decoder", msg,
+                                                           ": measuring with two batches in flight on every rank" if ai + 1 < len(attempts) else ""),
+                  file=sys.stderr, flush=True)
         try:
-            dec.close()
+            if dec is not None:
+                dec.close()
         except Exception:
             pass
+        dec = None
+        del d_feats
+        torch.cuda.empty_cache()
+        if ai + 1 == len(attempts):
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit("bench.py: the decoder failed on rank %d: %s" % (rank, msg))
+        pipeline_error = msg
     # `value` counts the frames the device really searched between the two brackets: with batches through the resident kernel
     # that is what its slots report having advanced (jd_dec_pipeline_stats: a batch handed back inside the region was partly
     # searched before it, batches announced inside it are partly searched behind it); with one launch per step it is K batches
@@ -562,6 +738,7 @@ def main():
     dec.debug_cells(True)
     dec.decode_batch_device(d_feats.data_ptr(), offs, stream)
     cells_read, cells_total = dec.debug_cells(False)
+    mark("single-batch figures, cells read")
     if world > 1:
         t = torch.tensor([elapsed, float(frames_local), float(frames_timed)], dtype=torch.float64, device=dev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -582,37 +759,38 @@ def main():
     fps = frames_timed_total / elapsed
     D, G, M, MN = am.D, am.n_gmm, am.max_mix, am.max_n
     st = {k: sum(h.stats[k] for h in hyps) for k in hyps[0].stats}       # one step's batch totals (rank 0)
-    default_cfg = (args.arcs == 1_000_000 and args.beam == 150.0 and args.max_hyps == 0 and U == 64 and args.seed == 0 and not strong)
-    # HBM traffic per launch of k_search from the committed PMC passes of this command (profiles/r04_c2_traffic.json,
-    # tools/collect_profiles.sh: separate --pmc runs, calibrated as calibrated_traffic says) - reported only for the
-    # default workload and only while the kernel's sources are the ones the passes were taken on (else null)
+    default_cfg = (args.arcs == 1_000_000 and args.beam == 150.0 and args.max_hyps == 0 and U == 64 and args.seed == 0 and not strong
+                   and args.scoring == "exact")
+    # HBM traffic per launch from the committed PMC passes (profiles/<round>_*_traffic.json, tools/collect_r06.sh: separate --pmc
+    # runs, calibrated as calibrated_traffic says) - reported only for the default workload and only while the kernels' sources are
+    # the ones the passes were taken on (else null)
     step_tm = dict(tm)
     step_tm["search_ms"] = acc["search_ms"] / steps
     step_tm["search_launches"] = max(1, acc["search_launches"] // steps)
     traffic = leg_traffic("c2", step_tm["search_launches"]) if default_cfg else None
     if depth:
         traffic = slot_traffic(frames_local) if default_cfg else None
-    if depth:                                                      # (the resident kernel is busy all the time: a batch's share of it
-        # is the time the slots took for one batch's worth of the frames they really advanced inside the brackets)
+        # (the resident kernel is busy all the time: a batch's share of it is the time the slots took for one batch's worth of the
+        # frames they really advanced inside the brackets)
         step_tm["search_ms"] = elapsed * 1e3 * frames_local / max(1.0, float(frames_timed))
-    roofline = roofline_of(st, MN, step_tm, traffic)
+    slot_kernel = bool(depth) or tm.get("slot_launches", 0) > 0
+    roofline = roofline_of(st, MN, step_tm, traffic, design_bytes(st, MN, G, frames_local, row_in_lds=slot_kernel and G <= 3072))
     if depth:
         roofline["kernel"] = "k_slot"
-        roofline["traffic_is"] = "proxy: k_slot_batch (the slot kernel's per-stream code as a plain launch, counted on configs[2]'s 512-utterance batch; bytes per stream-frame x the batch's frames)"
-        roofline["launch"] = ("ONE launch spans the timed region (jd_resident.h): a batch's share of it = the region x (one batch's frames / "
-                              "the frames the slots advanced inside it, jd_dec_pipeline_stats); avg_launch_us is that share, "
-                              "algorithmic_bytes_per_launch one batch's bytes; traffic is a PROXY - the counted HBM bytes of one batch's frames through "
-                              "the same per-stream code launched as k_slot_batch (the profiler runs kernels one after the other under --pmc, and "
-                              "k_slot waits for the scoring, export and ready kernels beside it)")
+        roofline["traffic_is"] = "proxy: k_slot_batch counted on configs[2]'s 512-utterance batch, bytes per stream-frame x frames"
+        roofline["launch"] = "ONE launch spans the timed region; a batch's share = region x batch frames / frames the slots advanced"
+    roofline["frac_is"] = "SURVEY 8(d) bytes of the REFERENCE's work / time; frac_design: bytes this design requests; frac_measured: counted HBM bytes"
     gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
     gmm_bytes = G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / max(1, tm["gmm_launches"])
     roofline["search_ms_per_step"] = round(step_tm["search_ms"], 3)
     # the companion kernel is VALU-bound: per (frame pair, mixture) 4 packed fp32 instructions per dimension
-    # + ~116 for the two logAdd steps, 4 cycles each on 1024 SIMDs
-    gmm_valu_ms = (frames_local / 128.0) * G * M * (4.0 * D + 116.0) * 4.0 / 1024.0 / 2.4e9 * 1e3
+    # + ~116 for the two logAdd steps, 4 cycles each on 1024 SIMDs; fast scoring: 2 packed FMAs per dimension + ~24
+    per_mix = (4.0 * D + 116.0) if args.scoring == "exact" else (2.0 * D + 24.0)
+    gmm_valu_ms = (frames_local / 128.0) * G * M * per_mix * 4.0 / 1024.0 / 2.4e9 * 1e3
     gmm_ms = tm_serial["gmm_ms"]                                   # the kernel on its own (the serial step behind the timed region)
     n_ahead = acc["prefetched"]
-    roofline["gmm"] = {"kernel": "jd_gmm_kernel39" if D == 39 else "jd_gmm_kernel", "bound": "valu",
+    roofline["gmm"] = {"kernel": ("jd_gmm_kernel39" if args.scoring == "exact" else "jd_gmm_fast39") if D == 39 else "jd_gmm_kernel", "bound": "valu",
+                       "scoring": args.scoring,
                        "ms_per_step": round(gmm_ms, 3),
                        "valu_bound_ms": round(gmm_valu_ms, 3),
                        "frac": round(gmm_valu_ms / max(gmm_ms, 1e-9), 4),
@@ -624,21 +802,17 @@ def main():
                        "cells_read_frac": round(cells_read / max(cells_total, 1), 4),
                        "span_beside_search_ms": round(acc["gmm_ms"] / steps, 3) if n_ahead else None,
                        "serial_order_ms_per_step": round(serial_ms, 3),
-                       "serial_order_search_ms": round(tm_serial["search_ms"], 3),
-                       "note": ("the next batch's table is scored beside this batch's search, on the CUs its clusters leave "
-                                "(jd_dec_prefetch_scores): ms_per_step is the kernel on its own, measured in a serial-order step "
-                                "behind the timed region; search_waited is what a step still waited for its table")
-                               if n_ahead else "scored before the search starts: serial step time (k_search holds the register file)"}
+                       "serial_order_search_ms": round(tm_serial["search_ms"], 3)}
 
     # the same batch in the serial order (scored, then searched with re-planning at will): the kernel's own best figure
     ser = roofline_of(st, MN, tm_serial, leg_traffic("c2", max(1, tm_serial["search_launches"])) if default_cfg else None)
     roofline["serial_order"] = {"ms_per_step": round(serial_ms, 3), "search_ms": round(tm_serial["search_ms"], 3),
                                 "launches": tm_serial["search_launches"], "achieved": ser["achieved"], "frac": ser["frac"],
-                                "frac_measured": ser["frac_measured"],
-                                "note": "one step behind the timed region, nothing scored ahead: not part of `value`"}
+                                "frac_measured": ser["frac_measured"]}
 
-    # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample
+    # ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample, one core
     cpu = None
+    wer = None
     if not args.no_cpu_baseline and world == 1:                   # (rank 0 at N = 1 only: the other ranks would wait for it)
         from oracle.oracle import OracleAM, OracleDecoder, OracleNet
         ns = min(args.cpu_sample_utts, U)
@@ -650,9 +824,8 @@ def main():
             g = hyps[u]
             same += int(g.n == o.n and np.array_equal(g.label, o.label) and np.array_equal(g.time, o.time))
         cpu = {"value": round(fr / secs, 1), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "first %d utterances of rank 0's batch (%d frames), clock() CPU time around "
-                         "init..finish as DecoderSingleTest.cpp:259-300; GPU 1-best identical on %d/%d"
-                         % (ns, fr, same, ns)}
+               "sample": "first %d utterances of the batch (%d frames), clock() around init..finish (DecoderSingleTest.cpp:259-300)" % (ns, fr),
+               "identical_1best": "%d/%d" % (same, ns)}
         # the reference's two-thread organisation (WFSTDecoderLiteThreading + HTKFlatModelsThreading: a search
         # thread and a scoring thread), restated; wall time with two busy cores, on a third of the sample
         try:
@@ -664,46 +837,59 @@ def main():
                 g = hyps[u]
                 same_t += int(g.n == o.n and np.array_equal(g.label, o.label) and np.array_equal(g.time, o.time))
             cpu["two_thread_core"] = {"value": round(frt / wall, 1), "unit": "frames/s", "cores": 2, "kind": "port",
-                                      "sample": "first %d utterances (%d frames), wall time; GPU 1-best identical on %d/%d"
-                                                % (nt, frt, same_t, nt)}
+                                      "sample": "first %d utterances (%d frames), wall time" % (nt, frt), "identical_1best": "%d/%d" % (same_t, nt)}
         except RuntimeError as e:                                 # models with a skip into the exit state (refused like the reference)
             cpu["two_thread_core"] = {"error": str(e)}
+        # the reference's own classes, measured in the build container (quoted constants: the GPU box has no /root/reference)
+        cpu["reference_cpu"] = reference_cpu()
+        mark("cpu_baseline (%d utterances, one core)" % ns)
+        # BASELINE.json: "1-best WER vs ref" - every utterance of the step against the CPU oracle, and against the transcript the
+        # utterances were sampled from (after the timed region; the oracle on all host cores)
+        wer = wer_vs_oracle(net, am, feats, hyps, args.beam, args.max_hyps)
+        if refs is not None:
+            e_t = sum(word_errors(list(h.label[::-1]) if h.n > 0 else [], list(r)) for h, r in zip(hyps, refs))
+            wer["wer_vs_sampled_transcript"] = round(e_t / max(1, sum(len(r) for r in refs)), 6)
+        mark("wer_vs_oracle (%d utterances, %d threads)" % (wer["utterances"], wer["oracle_threads"]))
 
-    # what ONE batch of 64 costs a caller that does not announce six batches ahead - beside `value`, not inside it
+    # what ONE batch of 64 costs a caller that does not announce nine batches ahead - beside `value`, not inside it
     one = roofline_of(st, MN, tm_one, leg_traffic("c2", max(1, tm_one["search_launches"])) if default_cfg else None)
     single_batch = {"serial_order": {"ms": round(serial_ms, 3), "frames_per_s": round(frames_local / serial_ms * 1e3, 1), "frac": ser["frac"],
                                      "what": "nothing announced: the batch's table is scored, then it is searched"},
                     "one_ahead": {"ms": round(one_ahead_ms, 3), "frames_per_s": round(frames_local / one_ahead_ms * 1e3, 1), "frac": one["frac"],
-                                  "what": "the next batch announced before each decode (jd_dec_prefetch_scores): its table is scored beside "
-                                          "this batch's search; one batch on the chip at a time (JD_FLOW_SERIAL)"},
-                    "note": "measured behind the timed region on rank 0 (median of 3 / one pass); not part of `value`"}
-    name = "configs[1]" if default_cfg else "configs[1]-shaped (non-default size / pruning)"
+                                  "what": "the next batch announced before each decode (jd_dec_prefetch_scores); one batch on the chip at a time"},
+                    "note": "measured behind the timed region on rank 0 (one pass / median of 3); not part of `value`"}
+    name = "configs[1]" if default_cfg else "configs[1]-shaped (non-default size / pruning / scoring)"
+    # The line: what a reader needs first comes first, and every string inside config / roofline / cpu_baseline stays under 128
+    # characters (the driver's record keeps those objects and cuts longer strings)
     out = {"metric": "frames/sec decoded", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
            "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
-           "ms_each_step": each if steps <= 32 else None,
            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic", "xRT": round(fps / 100.0, 1),
-           "frames_timed": int(frames_timed_total),
-           "frames_timed_is": ("stream-frames the resident kernel's slots advanced between the two brackets (jd_dec_pipeline_stats), all ranks"
-                               if depth else "steps x the frames of a batch, all ranks"),
-           "single_batch": single_batch,
-           "config": {"workload": "%s: %d-arc composed C.L.G, %d tied states x %d mix, D=%d, "
-                                  "%s, mainBeam %g, maxHyps %d"
-                                  % (name, net.n_arcs, G, M, D, ("%d utterances in all" % args.total_utts) if strong else ("%d utterances per GPU" % U),
+           "config": {"workload": "%s: %d-arc C.L.G, %dx%d-mix GMMs, D=%d, %s, beam %g, maxHyps %d"
+                                  % (name, net.n_arcs, G, M, D, ("%d utts in all" % args.total_utts) if strong else ("%d utts/GPU" % U),
                                      args.beam, args.max_hyps),
                       "frames_per_step": int(frames_total), "utts_per_gpu": U, "gathered_hyps": n_gathered,
                       "parallelism": ("one batch of %d utterances dealt by length over %d rank(s)" % (args.total_utts, world)) if strong
                                      else "utterance-sharded x%d" % world,
+                      "scoring": args.scoring,
                       "batches_in_flight": (depth + 1) if depth else (2 if two_in_flight else 1),
+                      "pipeline": ("resident slot kernel: %d one-workgroup slots (one per CU, scoring beside them), %d batches announced ahead"
+                                   % (args.pipeline_slots, depth)) if depth else None,
+                      "pipeline_error": pipeline_error[:120] if pipeline_error else None,
                       "gather": None if world == 1 else ("one all_gather per step" if per_step_gather else
-                                                         "ONE all_gather of the %d steps' records at the end of the timed region (inside it), behind jd_dec_quiesce" % steps),
-                      "pipeline_error": pipeline_error,
-                      "pipeline": ("resident slot kernel: %d one-workgroup slots, one per CU (half of it; the scoring kernel runs on the other half of the same CUs); announcements %d batches ahead, a slot takes "
-                                   "the next queued utterance (longest first) when its own is through" % (args.pipeline_slots, depth)) if depth else None,
+                                                         "ONE all_gather of the %d steps' records, inside the timed region, behind jd_dec_quiesce" % steps),
+                      # ONE batch at a time (a caller that cannot announce nine batches ahead): measured behind the timed region
+                      "single_batch_serial_ms": round(serial_ms, 3), "single_batch_serial_fps": round(frames_local / serial_ms * 1e3, 1),
+                      "single_batch_one_ahead_ms": round(one_ahead_ms, 3), "single_batch_one_ahead_fps": round(frames_local / one_ahead_ms * 1e3, 1),
                       "predicted_rank_ms": predicted_rank_ms if strong else None,
                       "search_ahead_frames_per_step": int(acc["ahead_frames"] // max(steps, 1)),
                       "streams_per_gpu": dec.max_streams},
-           "roofline": roofline, "cpu_baseline": cpu}
+           "roofline": roofline, "cpu_baseline": cpu, "wer_vs_oracle": wer,
+           "single_batch": single_batch,
+           "frames_timed": int(frames_timed_total),
+           "frames_timed_is": ("stream-frames the resident kernel's slots advanced between the two brackets (jd_dec_pipeline_stats), all ranks"
+                               if depth else "steps x the frames of a batch, all ranks"),
+           "ms_each_step": each if steps <= 32 else None}
 
     # ---- the other single-GPU workloads of BASELINE.json (not part of `value`)
     if world == 1 and not args.no_extra_legs:
@@ -714,24 +900,22 @@ def main():
         try:
             no = 0 if args.no_cpu_baseline else 2                   # utterances the CPU oracle decodes per leg
             pipe = (depth, args.pipeline_slots) if depth else None
+            if args.scoring == "exact" and depth:                   # the headline with the scoring option: same search, cheaper table
+                legs["configs1_fast_scoring"] = run_leg("configs[1], jd_dec_set_scoring(JD_SCORE_FAST): FMA distance + fp32 logAdd (scores within 1e-4)",
+                                                        am, net, feats, args.beam, args.max_hyps, dev, oracle_utts=no, pipe=pipe, passes=24,
+                                                        scoring="fast")
             legs["configs1_maxhyps6000"] = run_leg("configs[1] + histogram pruning", am, net, feats, args.beam, 6000, dev, oracle_utts=no,
                                                    two=two_in_flight, pipe=pipe, passes=24 if pipe else 4, pmc_leg="hyps" if default_cfg else None)
             if depth:                                               # the headline's batches with TWO of them in flight, one launch per step
-                legs["configs1_two_batches_in_flight"] = run_leg("configs[1], two batches in flight (one k_search launch per step: what runs with "
-                                                                 "several ranks, and what the counters see)", am, net, feats, args.beam, args.max_hyps, dev,
+                legs["configs1_two_batches_in_flight"] = run_leg("configs[1], two batches in flight (one k_search launch per step)",
+                                                                 am, net, feats, args.beam, args.max_hyps, dev,
                                                                  two=True, pmc_leg="c2" if default_cfg else None)
-            elif two_in_flight:                                     # ... or through the resident search kernel, six of them ahead
-                legs["configs1_through_the_resident_kernel"] = run_leg("configs[1], batches through the resident kernel utterance by utterance "
-                                                                       "(JD_PIPELINE=3: 160 one-workgroup slots, six batches ahead)", am, net, feats,
+            elif two_in_flight:                                     # ... or through the resident search kernel
+                legs["configs1_through_the_resident_kernel"] = run_leg("configs[1], batches through the resident slot kernel", am, net, feats,
                                                                        args.beam, args.max_hyps, dev, pipe=(9, 256), passes=14)
-            # configs[2]'s batch (512 utterances) on ONE GPU: waves of 128 streams inside one call, each wave's table scored
-            # beside the wave before it - what the GPU does when a batch is not bounded by its longest utterance
+            # configs[2]'s batch (512 utterances) on ONE GPU: more streams than the chip has CUs, so every pass is ONE launch of the
+            # slot kernel, a workgroup per utterance, two per CU, the dispatcher dealing the next one when one leaves - k_slot_batch
             _, _, f512, _ = synth.config_c2(seed=args.seed, n_utts=512, target_arcs=args.arcs)
-            # (through the resident kernel's slots, two such batches ahead: 1.59 M frames/s against 1.43 M in waves of 128 streams - the
-            # counted bytes of the leg are those of the waves, tools/run_leg.py c512)
-            # (512 streams: more than the chip has CUs, so every pass is ONE launch of the slot kernel, a workgroup per utterance, two per CU,
-            # the dispatcher dealing the next one when one leaves - k_slot_batch; measured 2.12 M frames/s against 1.97 M through the
-            # pipeline's 256 slots two batches ahead, 1.43 M in waves of 128 streams on k_search)
             legs["configs2_batch_512_on_one_gpu"] = run_leg("configs[2]'s 512-utterance batch on one GPU, 512 streams: one launch of the slot kernel per pass",
                                                             am, net, f512, args.beam, 0, dev, oracle_utts=no, max_streams=512, passes=4,
                                                             pmc_leg="c512slot" if default_cfg else None)
@@ -755,6 +939,11 @@ def main():
         except Exception as e:                                    # a leg must never take the headline down
             legs["error"] = repr(e)
         out["legs"] = legs
+        mark("legs")
+    marks.append(("end", time.perf_counter()))
+    print("bench.py wall-clock budget (rank 0, %d rank(s)): %s; total %.1f s" % (
+        world, "; ".join("%s %.1f s" % (marks[i][0], marks[i][1] - marks[i - 1][1]) for i in range(1, len(marks) - 1)),
+        marks[-1][1] - marks[0][1]), file=sys.stderr, flush=True)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(**bar_kw)

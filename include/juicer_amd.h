@@ -247,6 +247,16 @@ typedef struct jd_stats {          /* WFSTDecoderLite.cpp:231-241 + build counte
     int64_t tot_paths;             /* Path records created (Wd)                    */
     int64_t tot_insts_in;          /* instances processed by internal propagation (Mdl) */
     int64_t ties;                  /* equal-score recombinations seen (oracle only; 0 on GPU) */
+    /* what the kernels really touched - the figures above are the REFERENCE's counts (tot_insts_in includes candidates that
+     * never become a record here, tot_arcs_visited the arcs a prefix walk accounts for without reading them); these price
+     * the bytes the DESIGN moves (bench.py: roofline.design_bytes_per_launch): */
+    int64_t tot_recs_read;         /* phase A: instance records read */
+    int64_t tot_new_attached;      /* phase A: newly entered arcs taken up from the new-arc list (attachNetInst) */
+    int64_t tot_recs_written;      /* phase A: records written to the next frame's list */
+    int64_t tot_entry_items;       /* phase A: entry tokens pulled (the winning frontier item is gathered) */
+    int64_t tot_items_expanded;    /* phase X: frontier items taken up (exit tokens, closure items, slices) */
+    int64_t tot_arcs_walked;       /* phase X: arc records loaded */
+    int64_t tot_closure_items;     /* phase X: closure items written (epsilon / tee arcs followed) */
 } jd_stats;
 
 /*

@@ -31,7 +31,10 @@ class Stats(C.Structure):
                 ("tot_active_emit_hyps", C.c_int64), ("tot_active_end_hyps", C.c_int64),
                 ("tot_active_models", C.c_int64), ("tot_proc_emit_hyps", C.c_int64),
                 ("tot_proc_end_hyps", C.c_int64), ("tot_arcs_visited", C.c_int64),
-                ("tot_paths", C.c_int64), ("tot_insts_in", C.c_int64), ("ties", C.c_int64)]
+                ("tot_paths", C.c_int64), ("tot_insts_in", C.c_int64), ("ties", C.c_int64),
+                # what the kernels really touched (include/juicer_amd.h: jd_stats)
+                ("tot_recs_read", C.c_int64), ("tot_new_attached", C.c_int64), ("tot_recs_written", C.c_int64), ("tot_entry_items", C.c_int64),
+                ("tot_items_expanded", C.c_int64), ("tot_arcs_walked", C.c_int64), ("tot_closure_items", C.c_int64)]
 
 
 class CHyp(C.Structure):

@@ -1027,6 +1027,10 @@ static int report_stream_error(jd_dec *d, int s_i, int error, int frame, int lst
         return jd_fail(JD_EHIP, "stream %d: a workgroup of the search cluster did not arrive at a barrier (frame %d)", s_i, frame);
     if (error == JDE_LAZY_INV)
         return jd_fail(JD_EHIP, "stream %d: internal error - a token reached a composed state that has not been expanded (frame %d)", s_i, frame);
+    if (error == JDE_GEOM)
+        return jd_fail(JD_ESTATE, "stream %d: the slot kernel was given a stream in the middle of an utterance (frame %d) whose lists were written by a "
+                       "cluster of %d wave segments, not its own %d: the utterance is lost, the stream is reset by its next jd_stream_init", s_i, frame,
+                       lst_nw, SW);
     if (error == JDE_LAZY) {
         d->lazy_failed = true;
         LazyDev L;
@@ -1087,6 +1091,8 @@ static int fetch_results_from(jd_dec *d, const StreamCtl *ctl_v, const int *resn
         H.stats.tot_arcs_visited = K.st[ST_ARCS];
         H.stats.tot_paths = K.st[ST_PATHS];
         H.stats.tot_insts_in = K.st[ST_INSTS];
+        H.stats.tot_recs_read = K.st[ST_RECS]; H.stats.tot_new_attached = K.st[ST_NEWL]; H.stats.tot_recs_written = K.st[ST_SURV]; H.stats.tot_entry_items = K.st[ST_KEYS];
+        H.stats.tot_items_expanded = K.st[ST_XITEMS]; H.stats.tot_arcs_walked = K.st[ST_WALK]; H.stats.tot_closure_items = K.st[ST_CLOS];
         d->load_sum += (double)K.st[ST_INSTS] + (double)K.st[ST_ARCS]; d->load_frames += (double)K.frame;
         H.stats.ties = 0;
         int k = S.res_n;
@@ -1476,15 +1482,30 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             const double est_search = d->search_ms_per_frame * frames_now;
             hold_replan = d->pf_rebalance == 0 || (d->pf_rebalance < 0 && est_gmm > 0.0 && est_search > 0.0 && est_gmm >= 0.1 * est_search);
         }
-        hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((A.n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, A.n_work, d->d_status,
-                           hold_replan ? 1 : 0);
-        HIPCHK(hipEventRecord(e0, st));
         // the kernel flavour: HMM size class x XCD-local x lazily composed graph
         // More streams than the chip has CUs, one workgroup each: the slot kernel as a plain launch (jd_slot.h: k_slot_batch) - a
         // workgroup per stream, two per CU, the dispatcher deals the next one when one leaves - instead of k_search's
         // one-per-CU workgroups that take their streams one after the other.  (JD_SLOT_BATCH=1 / 0, development: always / never.)
         bool slot_batch = A.n_slots > 0 && A.Cw == 1 && n_bg == 0 && n_work > nwg_all && !d->C.lazy && !A.cells;
         if (const char *e = jd_dev_env("JD_SLOT_BATCH")) slot_batch = atoi(e) != 0 && A.Cw == 1 && n_bg == 0 && !d->C.lazy && !A.cells && (A.n_slots > 0 || n_work == 1);
+        if (slot_batch) {
+            // The slot kernel reads lists of ITS geometry only (eight wave segments, slot_run: JDE_GEOM), k_search those of any.  A stream
+            // in the middle of an utterance whose last frames were written by a cluster of several workgroups - jd_streams_push or the
+            // broker's ticks served 100 streams with clusters of two, then more streams joined - stays with k_search for this launch:
+            // the shape of the launch alone does not decide.  (The streams' heads as they stand behind everything queued on `st`.)
+            std::vector<int> hd((size_t)d->max_streams * 10);
+            HIPCHK(hipMemcpy2DAsync(hd.data(), 40, d->d_ctl, sizeof(StreamCtl), 40, (size_t)d->max_streams, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (const int2 &w : work_in) {
+                const int *h = hd.data() + (size_t)w.x * 10;           // {frame, T, error, needs_init, started, lst_nw, n_rec_hint, best_emit, dirty_nw[2]}
+                if (h[4] && !h[3] && h[2] == 0 && (h[5] != SW || h[8] != SW || h[9] != SW)) { slot_batch = false; break; }
+            }
+            if (!slot_batch && getenv("JD_VERBOSE"))
+                fprintf(stderr, "k_slot_batch: a stream's lists were written by a cluster of several workgroups - this launch stays with k_search\n");
+        }
+        hipLaunchKernelGGL(jd_zero_bar_kernel, dim3((A.n_work + 255) / 256), dim3(256), 0, st, d->d_ctl, d->d_work, A.n_work, d->d_status,
+                           hold_replan ? 1 : 0);
+        HIPCHK(hipEventRecord(e0, st));
         if (slot_batch) {
             if (ne3) hipLaunchKernelGGL(k_slot_batch<3>, dim3((unsigned)n_work), dim3(SNT), 0, st, A);
             else hipLaunchKernelGGL(k_slot_batch<6>, dim3((unsigned)n_work), dim3(SNT), 0, st, A);
@@ -1497,7 +1518,8 @@ static int launch_search(jd_dec *d, const std::vector<int2> &work_first, const f
             // the search is resident - the last workgroup of the grid says so in a host-mapped word - so that scoring
             // blocks never sit on a CU a search workgroup is waiting for (2 ms: it goes ahead anyway)
             const auto tr0 = std::chrono::steady_clock::now();
-            while (__atomic_load_n(d->h_resident, __ATOMIC_ACQUIRE) != A.launch_seq &&
+            // (k_slot_batch: nothing has to be resident at once - its workgroups come and go - and nobody writes the word)
+            while (!slot_batch && __atomic_load_n(d->h_resident, __ATOMIC_ACQUIRE) != A.launch_seq &&
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count() < 2.0) { }
             const int pr = pf_launch(d);
             if (pr) { (void)hipStreamSynchronize(st); return pr; }       // (k_search is in flight: not left behind with the launch lock released)

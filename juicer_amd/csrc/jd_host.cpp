@@ -10,6 +10,7 @@
 //   HTKModels::createTrPandSEIndex      src/HTKModels.cpp:2330-2390
 //   HTKFlatModels::init                 src/HTKFlatModels.cpp:94-177
 // Compiled with -ffp-contract=off.
+#include <atomic>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -36,7 +37,16 @@ int jd_fail(int code, const char *fmt, ...)
 const char *jd_dev_env(const char *name)
 {
     const char *on = getenv("JD_DEV");
-    if (!on || on[0] == '\0' || (on[0] == '0' && on[1] == '\0')) return nullptr;
+    if (!on || on[0] == '\0' || (on[0] == '0' && on[1] == '\0')) {
+        // a knob that is set but not read changes nothing - said once per process, so that a deployment which exported
+        // JD_PIPELINE=0 or JD_BROKER_RESIDENT=0 for an earlier build hears that it no longer does anything
+        // (the interface: jd_dec_set_pipeline, jd_broker_create's arguments, include/juicer_amd.h)
+        static std::atomic<bool> said{false};
+        if (getenv(name) && !said.exchange(true))
+            fprintf(stderr, "juicer_amd: %s is set but ignored - JD_* development knobs are read only with JD_DEV=1 (the interface is "
+                            "include/juicer_amd.h: jd_dec_set_pipeline, jd_dec_set_capacity, jd_broker_create); further such knobs are not reported\n", name);
+        return nullptr;
+    }
     return getenv(name);
 }
 

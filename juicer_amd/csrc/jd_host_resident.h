@@ -183,6 +183,10 @@ int jd_res_start(jd_dec *d, int n_streams, int rows_per_buf)
                            per_cu, n_streams, d->n_cus, need);
     }
     if (!R->slot && R->Cw * n_streams > d->n_cus * WG_PER_CU) return jd_fail(JD_EINVAL, "jd_res_start: %d streams do not fit the device", n_streams);
+    // (the slot kernel's workgroups answer a mailbox: one that is never dispatched never answers - all of them resident, or none)
+    if (R->slot && n_streams > d->n_cus * SLOT_WG_PER_CU)
+        return jd_fail(JD_EINVAL, "jd_res_start: %d one-workgroup slots do not fit the device (%d CUs x %d workgroups of k_slot resident at once)",
+                       n_streams, d->n_cus, SLOT_WG_PER_CU);
     memset(R->h_done, 0, (size_t)R->n * sizeof(ResDone));
     memset(R->h_post, 0, (size_t)R->n * sizeof(ResPost));
     std::fill(R->seq.begin(), R->seq.end(), 0u);
@@ -696,6 +700,11 @@ extern "C" int jd_dec_set_pipeline(jd_dec *d, int32_t mode, int32_t depth, int32
         if (depth == 0) depth = std::min(32, std::max(8, slots / 32 + 2));
         if (depth < 2 || depth > 32) return jd_fail(JD_EINVAL, "jd_dec_set_pipeline: depth %d (2..32 batches announced and not handed back)", depth);
         if (slots < 1 || slots > d->max_streams) return jd_fail(JD_EINVAL, "jd_dec_set_pipeline: %d slots, the decoder has %d streams", slots, d->max_streams);
+        // the slots are workgroups of a mailbox kernel: ALL of them have to be on the device at once (SLOT_WG_PER_CU per CU at most) -
+        // a workgroup that never gets a CU never answers, and the batch whose utterance was posted to it never comes back
+        if (slots > d->n_cus * SLOT_WG_PER_CU)
+            return jd_fail(JD_EINVAL, "jd_dec_set_pipeline: %d slots, but the device holds %d at once (%d CUs x %d workgroups of the slot kernel); "
+                           "one per CU (%d) is what leaves the scoring room beside them", slots, d->n_cus * SLOT_WG_PER_CU, d->n_cus, SLOT_WG_PER_CU, d->n_cus);
         if (d->net->lazy_dev || d->am->hybrid)
             return jd_fail(JD_ESTATE, "jd_dec_set_pipeline: JD_FLOW_RESIDENT not with a lazily composed network / hybrid scoring");
     }

@@ -52,7 +52,26 @@
 #define TEE_LDS_MAX 2048             // HMMs whose tee log-probability is cached in LDS
 #endif
 
-enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_INSTS, ST_N };
+// the counters of what the kernels really touched (ST_RECS ..) can be compiled out (development: -DJD_COUNTERS=0, to measure what they cost)
+#ifndef JD_COUNTERS
+#define JD_COUNTERS 1
+#endif
+#if JD_COUNTERS
+#define JD_COUNT(...) __VA_ARGS__
+#else
+#define JD_COUNT(...)
+#endif
+enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_INSTS,
+       // what the kernels really touched (jd_stats: tot_recs_read ..): the reference's figures above price the REFERENCE's work -
+       // hopeless candidates that never become records, arcs a prefix walk accounts for without reading them
+       ST_RECS,     // phase A: instance records read
+       ST_NEWL,     // phase A: entries of the new-arc list taken up (attachNetInst from the arc's template)
+       ST_SURV,     // phase A: records written to the next list
+       ST_KEYS,     // phase A: entry tokens pulled (an arrival key that was set: the winning item is gathered)
+       ST_XITEMS,   // phase X: frontier items taken up (exit tokens, closure items, slices)
+       ST_WALK,     // phase X: arc records loaded by the walks
+       ST_CLOS,     // phase X: closure items written
+       ST_N };
 enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_LAZY = -45, JDE_LAZY_INV = -46, JDE_BARRIER = -50 };
 
 struct DecConst {
@@ -669,7 +688,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     const unsigned iprev = p ? 0u : V.item_par, icur = p ? V.item_par : 0u;
     const unsigned item_base = (unsigned)gw * gout.seg_item;
     const int Q01 = Q[0] + Q[1], Qall = Q01 + Q[2];
-    int c_insts = 0, c_pemit = 0, c_emit = 0, c_end = 0, c_surv = 0;
+    int c_insts = 0, c_pemit = 0, c_emit = 0, c_end = 0, c_surv = 0, c_recs = 0, c_keys = 0;
     unsigned mo = 0u;
     // The pass loop is software-pipelined two deep.  A pass is a chain of dependent memory round trips
     // (record -> source state's arrival key + likelihoods -> winning item) followed by arithmetic and stores, and with
@@ -874,6 +893,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         const bool slot_live = live_mask != 0;
         const unsigned long long bl = __ballot(slot_live), be = __ballot(has_exit);
         if (!is_new) c_insts += __popcll(__ballot(valid));             // (new arcs are counted when they are entered)
+        JD_COUNT(if (is_new) c_recs += __popcll(__ballot(valid)); c_keys += __popcll(__ballot(valid && kv != 0ULL)));
         // survivors: header + new tokens to this wave's segment of the next list
         {
             const int nsurv = __popcll(bl);
@@ -937,11 +957,13 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
     c_pemit = wave_sum(c_pemit); c_emit = wave_sum(c_emit);
     if (lane == 0) {
         if (mo) atomicMax(&sh.best, mo);
-        if (c_insts) atomicAdd(&sh.stat[ST_INSTS], c_insts);
+        if (c_insts) { atomicAdd(&sh.stat[ST_INSTS], c_insts); atomicAdd(&sh.stat[ST_RECS], c_insts); }
         if (c_pemit) atomicAdd(&sh.stat[ST_PEMIT], c_pemit);
         if (c_emit) atomicAdd(&sh.stat[ST_EMIT], c_emit);
         if (c_end) atomicAdd(&sh.stat[ST_END], c_end);
-        if (c_surv) atomicAdd(&sh.stat[ST_MODELS], c_surv);
+        if (c_surv) { atomicAdd(&sh.stat[ST_MODELS], c_surv); atomicAdd(&sh.stat[ST_SURV], c_surv); }
+        if (c_recs) atomicAdd(&sh.stat[ST_NEWL], c_recs);
+        if (c_keys) atomicAdd(&sh.stat[ST_KEYS], c_keys);
     }
 }
 
@@ -1004,7 +1026,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
     v4i *qtok = sh.qtok[wid], *qinfo = sh.qinfo[wid];
     int2 *qrow = sh.qrow[wid];
     int q_n = 0;                                                       // closure items waiting in this wave's queue
-    int c_arcs = 0, c_paths = 0, c_pend = 0, c_new = 0;
+    int c_arcs = 0, c_paths = 0, c_pend = 0, c_new = 0, c_xitems = 0, c_walk = 0, c_clos = 0;
     int c_ref = 0;                                                     // Path objects the reference creates for this wave's exit tokens
     unsigned mo = 0u;
     // states whose arrival key became non-zero: zeroed by the phase A of the frame after the next one
@@ -1057,6 +1079,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         XFINE(0);                                                      // hop 1: the items
         const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
         const bool start_tok = valid && exit_kind && info.x < 0;       // recognitionStart's token: it has traversed no arc
+        JD_COUNT(c_xitems += __popcll(__ballot(valid)));
         const bool real = valid && !start_tok && slice_no == 0;        // an item that traversed an arc (a slice has been through all this)
         const int state = !valid ? 0 : start_tok ? C.init_state : info.z;
         // (the state's static record, XState: requested here, used when the item is known to go on; graphs of long rows - C.xcut
@@ -1302,6 +1325,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
             }
             if (on) ++c_arcs;
+            JD_COUNT(c_walk += __popcll(__ballot(on)));
             if (on && inl == 0) {                                      // :533-540 epsilon input
                 un = tg;
                 un.score = ns;
@@ -1346,6 +1370,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                 const bool pass = mk && sou > (unsigned)(skc >> 32);   // cheap pre-filter before an index is spent
                 const unsigned long long bp = __ballot(pass);
                 const int np = __popcll(bp);
+                JD_COUNT(c_clos += np);
                 if (out.item_cnt + np > (int)gout.seg_item) { if (lane == 0) CS(&c.err[p], (int)JDE_ITEMS); }
                 else if (np) {
                     const unsigned k = item_base + (unsigned)(out.item_cnt + rank_in(bp));
@@ -1388,6 +1413,9 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         if (c_arcs) atomicAdd(&sh.stat[ST_ARCS], c_arcs);
         if (c_paths) atomicAdd(&sh.stat[ST_PATHS], c_paths);
         if (c_pend) atomicAdd(&sh.stat[ST_PEND], c_pend);
+        if (c_xitems) atomicAdd(&sh.stat[ST_XITEMS], c_xitems);
+        if (c_walk) atomicAdd(&sh.stat[ST_WALK], c_walk);
+        if (c_clos) atomicAdd(&sh.stat[ST_CLOS], c_clos);
         if (c_new) { atomicAdd(&sh.stat[ST_MODELS], c_new); atomicAdd(&sh.new_all, c_new); }   // attached instances are active models (:981)
     }
 }

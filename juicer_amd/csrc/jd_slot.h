@@ -61,6 +61,7 @@ struct SlotShared {
     int n_paths, n_paths_ref;                  // Path records in use (the reservation cursor) / the reference's count of its objects
     unsigned long long final_key;
     int stat[ST_N]; long long acc[ST_N];
+    unsigned long long cntA, cntX;             // per frame: new-arc entries taken up | entry items << 32; arcs loaded | closure items << 32 (ST_NEWL ..)
     long long clk[8];
 };
 
@@ -302,6 +303,7 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         const bool slot_live = live_mask != 0;
         const unsigned long long bl = __ballot(slot_live), be = __ballot(has_exit);
         if (!is_new) c_insts += __popcll(__ballot(valid));             // (new arcs are counted when they are entered)
+        JD_COUNT(if (lane == 0) atomicAdd(&sh.cntA, (unsigned long long)(is_new ? __popcll(__ballot(valid)) : 0) | ((unsigned long long)__popcll(__ballot(valid && kv != 0ULL)) << 32)));
         // survivors: header + new tokens to this wave's segment of the next list
         {
             const int nsurv = __popcll(bl);
@@ -352,11 +354,11 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
     c_pemit = wave_sum(c_pemit); c_emit = wave_sum(c_emit);
     if (lane == 0) {
         if (mo) atomicMax(&sh.bestA[p], mo);
-        if (c_insts) atomicAdd(&sh.stat[ST_INSTS], c_insts);
+        if (c_insts) { atomicAdd(&sh.stat[ST_INSTS], c_insts); atomicAdd(&sh.stat[ST_RECS], c_insts); }
         if (c_pemit) atomicAdd(&sh.stat[ST_PEMIT], c_pemit);
         if (c_emit) atomicAdd(&sh.stat[ST_EMIT], c_emit);
         if (c_end) atomicAdd(&sh.stat[ST_END], c_end);
-        if (c_surv) atomicAdd(&sh.stat[ST_MODELS], c_surv);
+        if (c_surv) { atomicAdd(&sh.stat[ST_MODELS], c_surv); atomicAdd(&sh.stat[ST_SURV], c_surv); }
     }
 }
 
@@ -430,6 +432,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         }
         const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
         const bool start_tok = valid && exit_kind && info.x < 0;       // recognitionStart's token: it has traversed no arc
+        JD_COUNT(if (lane == 0) atomicAdd(&sh.stat[ST_XITEMS], __popcll(__ballot(valid))));
         const bool real = valid && !start_tok && slice_no == 0;
         const int state = !valid ? 0 : start_tok ? C.init_state : info.z;
         // the state's static record (XState): requested here, used when the item is known to go on
@@ -619,6 +622,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
                 skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
             }
             if (on) ++c_arcs;
+            JD_COUNT(if (lane == 0) atomicAdd(&sh.cntX, (unsigned long long)__popcll(__ballot(on))));
             if (on && inl == 0) {                                      // :533-540 epsilon input
                 un = tg;
                 un.score = ns;
@@ -659,6 +663,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
                 const bool pass = mk && sou > (unsigned)(skc >> 32);
                 const unsigned long long bp = __ballot(pass);
                 const int np = __popcll(bp);
+                JD_COUNT(if (lane == 0 && np) atomicAdd(&sh.cntX, (unsigned long long)np << 32));
                 if (out.item_cnt + np > (int)g.seg_item) { if (lane == 0) slot_err(sh, (int)JDE_ITEMS); }
                 else if (np) {
                     const unsigned k = item_base + (unsigned)(out.item_cnt + rank_in(bp));
@@ -764,6 +769,7 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
         sh.n_paths = needs_init ? 0 : CL(&c.n_paths); sh.n_paths_ref = needs_init ? 0 : CL(&c.n_paths_ref);
         sh.new_all = needs_init ? 0 : CL(&c.new_all[(f & 1) ^ 1]);      // arcs entered in the last frame of the command before
         for (int k = 0; k < ST_N; ++k) { sh.stat[k] = 0; sh.acc[k] = 0; }
+        sh.cntA = 0ULL; sh.cntX = 0ULL;
         for (int k = 0; k < 8; ++k) sh.clk[k] = 0;
         // a stream in the middle of an utterance: its lists are this kernel's (eight wave segments)
         if (!needs_init && (old_nw != SW || dn0 != SW || dn1 != SW)) sh.err = (int)JDE_GEOM;
@@ -964,8 +970,13 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
             np_seen = RFL(sh.n_paths); npr_seen = RFL(sh.n_paths_ref);
             if (RFL(sh.err) != 0) failed = true;
         }
-        if (tid == 0)                                                  // totalActiveModels starts with frame 0 (:981)
+        if (tid == 0) {                                                // totalActiveModels starts with frame 0 (:981)
+            const unsigned long long ca = sh.cntA, cx = sh.cntX;
+            sh.cntA = 0ULL; sh.cntX = 0ULL;
+            sh.stat[ST_NEWL] = (int)(unsigned)ca; sh.stat[ST_KEYS] = (int)(unsigned)(ca >> 32);
+            sh.stat[ST_WALK] = (int)(unsigned)cx; sh.stat[ST_CLOS] = (int)(unsigned)(cx >> 32);
             for (int k = 0; k < ST_N; ++k) { if (!init || k != ST_MODELS) sh.acc[k] += sh.stat[k]; sh.stat[k] = 0; }
+        }
         if (last_frame && tid == 0) {                                  // bestFinalToken of this frame (:513-520)
             const unsigned long long fk = sh.final_key;
             Tok bf = null_tok();

@@ -99,6 +99,10 @@ class GatheredHyps(Sequence):
 
 def _padded_records(hyps, per_rank, max_words, index):
     """One step's records of this rank: exactly per_rank of them (short shards are padded with n = -2 records)."""
+    if len(hyps) > per_rank:                            # (a longer shard would shift every later step's rows on this rank)
+        raise ValueError("a step holds %d records, the gather was sized for %d per rank" % (len(hyps), per_rank))
+    if index is not None and len(index) != len(hyps):
+        raise ValueError("%d utterance indices for %d hypotheses" % (len(index), len(hyps)))
     ints, flts = pack_hyps(hyps, max_words, truncate=True)
     if index is not None:                               # (the index rides in a column of its own, behind the record)
         ints = np.concatenate([ints, np.asarray(index, np.int32).reshape(-1, 1)], axis=1)
@@ -165,6 +169,8 @@ def gather_hyps_steps(steps: Sequence, per_rank: int, max_words: int = 256, devi
     if S == 0:
         return []
     indexed = steps[0][1] is not None
+    if any((ix is not None) != indexed for _, ix in steps):        # (one decision for the whole exchange: the index column is there or not)
+        raise ValueError("gather_hyps_steps: steps with and without utterance indices in one exchange")
     for attempt in range(2):
         packed = [_padded_records(h, per_rank, max_words, ix) for h, ix in steps]
         ints = np.concatenate([p[0] for p in packed]); flts = np.concatenate([p[1] for p in packed])
@@ -174,6 +180,8 @@ def gather_hyps_steps(steps: Sequence, per_rank: int, max_words: int = 256, devi
             break
         max_words = longest                                        # (the same decision on every rank: all see the same records)
     world = gi.shape[0] // max(1, S * per_rank)
+    if gi.shape[0] != max(1, world) * S * per_rank:
+        raise ValueError("gathered %d records, expected a multiple of %d steps x %d per rank" % (gi.shape[0], S, per_rank))
     out = []
     for k in range(S):                                             # step k: rank after rank, per_rank records each
         rows = np.concatenate([np.arange(per_rank, dtype=np.int64) + (r * S + k) * per_rank for r in range(max(1, world))])

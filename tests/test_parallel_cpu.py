@@ -112,3 +112,20 @@ def test_length_balanced_shards():
     lpt = [sum(T[u] for u in s) for s in parallel.shard_lpt(T, 8)]
     cont = [sum(T[slice(*parallel.shard_range(512, r, 8))]) for r in range(8)]
     assert max(lpt) - min(lpt) < max(cont) - min(cont)
+
+
+def test_gather_refuses_inconsistent_steps(built):
+    """a step with more records than `per_rank`, or steps that disagree about carrying utterance indices, would shift
+    or misattribute every later step's rows - refused before anything travels (world size 1: no process group needed)."""
+    from juicer_amd import parallel, synth
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    am, net, feats, _ = synth.config_toy()
+    h = OracleDecoder(OracleNet(net), OracleAM(am)).decode(feats[0])
+    with pytest.raises(ValueError, match="sized for 1 per rank"):
+        parallel.gather_hyps_steps([([h, h], None)], per_rank=1)
+    with pytest.raises(ValueError, match="with and without"):
+        parallel.gather_hyps_steps([([h], [0]), ([h], None)], per_rank=1)
+    with pytest.raises(ValueError, match="utterance indices"):
+        parallel.gather_hyps_steps([([h], [0, 1])], per_rank=2)
+    ok = parallel.gather_hyps_steps([([h], [0]), ([h], [0])], per_rank=2)       # (short shards are padded, not refused)
+    assert [len(x) for x in ok] == [1, 1] and ok[1][0]["n"] == h.n

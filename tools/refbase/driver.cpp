@@ -1,11 +1,22 @@
-// tools/refbase/driver.cpp - times the REFERENCE's own WFSTDecoderLite / WFSTDecoderLiteThreading on this build's synthetic
-// workloads.  This file is this build's code; the decoder, network and model classes it drives are
+// tools/refbase/driver.cpp - drives the REFERENCE's own WFSTDecoderLite / WFSTDecoderLiteThreading on this build's synthetic
+// workloads: BASELINE.md B1 / B2 (timing) and the differential check of the CPU oracle (tests/test_refdiff_cpu.py,
+// tools/refbase/run_refbase.py).  This file is this build's code; the decoder, network and model classes it drives are
 // compiled from the sources where they lie under /root/reference/src, against the stand-ins of tools/refbase/standins for the
 // third-party headers the image lacks (Torch3 general.h / log_add.h, TracterObject.h).  Such a build is NOT a reference build
-// and pins nothing; it is a timing and differential aid, run in the build container only (tools/refbase/run_refbase.py).
+// and pins nothing; it is a timing and differential aid, run in the build container only.
 //
 // The loop around the decoder is DecoderSingleTest::decodeUtterance's (src/DecoderSingleTest.cpp:259-307): clock() around
 // init .. finish, 20 frames of look-ahead handed to processFrame, CPU time halved for the two-thread decoder.
+//
+//   refbase_driver key=value ...
+//     models=<file.jmbi>                       HTKModels::readBinary (the MMF text parser is generated code the image cannot make)
+//     net=<file.jwnt>                          WFSTNetwork::readBinary (src/WFSTNetwork.cpp:1228-1365), or
+//     fsm=<file.fsm> insyms=<file> outsyms=<file>   the TEXT constructor (src/WFSTNetwork.cpp:371-616)
+//     feats=<file>                             {n_utts, D} then per utterance {T, T x D floats}
+//     threading=0|1  main= start= end= word= maxhyps= lmscale= inspen=
+//     pti=<frames>                             PARTIAL_DECODING: setPartialDecodeOptions (src/WFSTDecoderLite.cpp:892-896)
+//   One JSON line per utterance: the DecHyp chain, the reference's five statistics (its protected totals, read through a
+//   subclass - src/WFSTDecoderLite.h:150-154), the frames of the partial paths it recovered.
 #include <cassert>
 #include <pthread.h>
 #include <time.h>
@@ -13,6 +24,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "HTKFlatModels.h"
@@ -24,6 +38,21 @@
 
 using namespace Juicer;
 
+// the reference keeps its statistics and the partial paths protected: a subclass may look
+template <class Base> struct Probe : public Base {
+    Probe(WFSTNetwork *n, IModels *m, real s, real e, real pe, real w, int mh) : Base(n, m, s, e, pe, w, mh) {}
+    void print_extras()
+    {
+        printf("\"stats\": {\"n_frames\": %d, \"tot_active_emit_hyps\": %d, \"tot_active_end_hyps\": %d, \"tot_active_models\": %d, "
+               "\"tot_proc_emit_hyps\": %d, \"tot_proc_end_hyps\": %d}, ", this->currFrame + 1, this->totalActiveEmitHyps, this->totalActiveEndHyps,
+               this->totalActiveModels, this->totalProcEmitHyps, this->totalProcEndHyps);
+        printf("\"partial\": [");
+        const char *sep = "";
+        for (size_t i = 0; i < this->partialPaths.size(); ++i) { printf("%s[%d, %d]", sep, this->partialPaths[i]->label, this->partialPaths[i]->frame); sep = ", "; }
+        printf("], ");
+    }
+};
+
 static void *gmm_thread(void *arg)
 {
     ((HTKFlatModelsThreading *)arg)->calcStates();                     // (src/juicer.cpp:79-85)
@@ -32,26 +61,40 @@ static void *gmm_thread(void *arg)
 
 int main(int argc, char **argv)
 {
-    if (argc < 12) {
-        fprintf(stderr, "usage: driver models.jmbi net.jwnt feats.bin threading mainBeam startBeam endBeam wordBeam maxHyps lmScale insPenalty\n");
+    std::map<std::string, std::string> kv;
+    for (int i = 1; i < argc; ++i) {
+        const char *eq = strchr(argv[i], '=');
+        if (!eq) { fprintf(stderr, "refbase_driver: argument '%s' is not key=value\n", argv[i]); return 2; }
+        kv[std::string(argv[i], eq - argv[i])] = eq + 1;
+    }
+    auto S = [&](const char *k, const char *d) { return kv.count(k) ? kv[k] : std::string(d); };
+    auto F = [&](const char *k, double d) { return kv.count(k) ? atof(kv[k].c_str()) : d; };
+    if (!kv.count("models") || !kv.count("feats") || (!kv.count("net") && !kv.count("fsm"))) {
+        fprintf(stderr, "usage: refbase_driver models=.. (net=.. | fsm=.. insyms=.. outsyms=..) feats=.. [threading= main= start= end= word= maxhyps= lmscale= inspen= pti=]\n");
         return 2;
     }
-    const char *jmbi = argv[1], *jwnt = argv[2], *featf = argv[3];
-    const int threading = atoi(argv[4]);
-    const float mainBeam = atof(argv[5]), startBeam = atof(argv[6]), endBeam = atof(argv[7]), wordBeam = atof(argv[8]);
-    const int maxHyps = atoi(argv[9]);
-    const float lmScale = atof(argv[10]), insPen = atof(argv[11]);
+    const int threading = (int)F("threading", 0);
+    const float mainBeam = F("main", 0), startBeam = F("start", 0), endBeam = F("end", 0), wordBeam = F("word", 0);
+    const int maxHyps = (int)F("maxhyps", 0), pti = (int)F("pti", 0);
+    const float lmScale = F("lmscale", 1), insPen = F("inspen", 0);
     HTKFlatModels *models = threading ? new HTKFlatModelsThreading() : new HTKFlatModels();
     models->setBlockSize(5);                                           // (before the models are there: HTKFlatModels.cpp:308-313)
-    models->readBinary(jmbi);
+    models->readBinary(S("models", "").c_str());
     pthread_t th;
     if (threading && pthread_create(&th, NULL, gmm_thread, models)) { fprintf(stderr, "pthread_create failed\n"); return 1; }
-    WFSTNetwork *net = new WFSTNetwork(lmScale, insPen);
-    net->readBinary(jwnt);
-    WFSTDecoderLite *dec = threading ? new WFSTDecoderLiteThreading(net, models, startBeam, mainBeam, endBeam, wordBeam, maxHyps)
-                                     : new WFSTDecoderLite(net, models, startBeam, mainBeam, endBeam, wordBeam, maxHyps);
-    FILE *f = fopen(featf, "rb");
-    if (!f) { perror(featf); return 1; }
+    WFSTNetwork *net;
+    if (kv.count("fsm"))                                               // the text constructor: scales and negates the weights itself (:371-616)
+        net = new WFSTNetwork(kv["fsm"].c_str(), S("insyms", "").c_str(), S("outsyms", "").c_str(), lmScale, insPen, REMOVEBOTH);
+    else {
+        net = new WFSTNetwork(lmScale, insPen);
+        net->readBinary(kv["net"].c_str());
+    }
+    Probe<WFSTDecoderLite> *d1 = threading ? NULL : new Probe<WFSTDecoderLite>(net, models, startBeam, mainBeam, endBeam, wordBeam, maxHyps);
+    Probe<WFSTDecoderLiteThreading> *d2 = threading ? new Probe<WFSTDecoderLiteThreading>(net, models, startBeam, mainBeam, endBeam, wordBeam, maxHyps) : NULL;
+    WFSTDecoderLite *dec = threading ? (WFSTDecoderLite *)d2 : (WFSTDecoderLite *)d1;
+    if (pti > 0) dec->setPartialDecodeOptions(pti);
+    FILE *f = fopen(S("feats", "").c_str(), "rb");
+    if (!f) { perror("feats"); return 1; }
     int n_utts = 0, D = 0;
     if (fread(&n_utts, 4, 1, f) != 1 || fread(&D, 4, 1, f) != 1) return 1;
     for (int u = 0; u < n_utts; ++u) {
@@ -73,7 +116,8 @@ int main(int argc, char **argv)
         double secs = (double)(clock() - t0) / CLOCKS_PER_SEC;
         if (threading) secs /= 2;                                      // :303-307
         printf("{\"u\": %d, \"T\": %d, \"cpu_s\": %.6f, ", u, T, secs);
-        if (!hyp) { printf("\"n\": -1}\n"); continue; }
+        if (d1) d1->print_extras(); else d2->print_extras();
+        if (!hyp) { printf("\"n\": -1}\n"); fflush(stdout); continue; }
         int n = 0;
         for (DecHypHist *h = hyp->hist; h; h = h->prev) ++n;
         printf("\"n\": %d, \"tot\": [%.9g, %.9g, %.9g], \"label\": [", n, hyp->score, hyp->acousticScore, hyp->lmScore);

@@ -1,0 +1,170 @@
+"""The differential check of the CPU oracle against the reference's OWN compiled classes (build container only).
+
+tools/refbase compiles the hot-path translation units of /root/reference/src where they lie - nothing of the reference is
+copied into this repository - against stand-ins for the third-party headers the image lacks (tools/refbase/standins) and
+drives them with tools/refbase/driver.cpp.  A build against stand-ins is NOT a reference build: it pins nothing, `parity`
+stays "partial" (DESIGN.md 2).  What it gives is a differential: the oracle (oracle/juicer_oracle.c, the restatement every
+GPU parity test is held against) and the reference's classes decode the same models, the same network and the same
+utterances and must agree on every word, time, score (bit for bit), on the reference's five statistics and on the partial
+paths PARTIAL_DECODING recovers.
+
+Used by tests/test_refdiff_cpu.py (every code path the GPU tests use, at sizes that take seconds) and by
+tools/refbase/run_refbase.py (the bench workloads at their sizes -> profiles/cpu_reference_baseline.json).
+"""
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+REF = "/root/reference/src"
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(ROOT, "gpurun_out", "refbase_build")          # scratch: not tracked, never sent to the GPU box
+TUS = ["WFSTDecoderLite", "WFSTDecoderLiteThreading", "WFSTNetwork", "WFSTLattice", "HTKFlatModels", "HTKFlatModelsThreading", "HTKModels",
+       "Histogram", "BlockMemPool", "DecHypHistPool", "LogFile"]
+# the reference's own definitions (src/CMakeLists.txt:3-5) and the oracle's compile discipline: -O2, no contraction
+FLAGS = ["-O2", "-ffp-contract=off", "-fpermissive", "-w", "-DOPT_FLATMODEL", "-DOPT_SINGLE_BEST", "-DPARTIAL_DECODING", "-include", "time.h",
+         "-I", os.path.join(HERE, "standins"), "-I", REF]
+REF_STATS = ("tot_active_emit_hyps", "tot_active_end_hyps", "tot_active_models", "tot_proc_emit_hyps", "tot_proc_end_hyps")
+
+
+def available() -> bool:
+    return os.path.isdir(REF)
+
+
+def build() -> str:
+    """g++ on the reference's sources where they lie + this build's driver and stand-ins -> gpurun_out/refbase_build/refbase_driver"""
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "refbase_driver")
+    own = [os.path.join(HERE, "driver.cpp"), os.path.join(HERE, "standins", "htkparse_stub.cpp")]
+    deps = own + [os.path.join(HERE, "standins", h) for h in ("general.h", "log_add.h", "TracterObject.h")] + [os.path.abspath(__file__)]
+    if os.path.exists(exe) and all(os.path.getmtime(p) <= os.path.getmtime(exe) for p in deps):
+        return exe
+    objs, jobs = [], []
+    for src in [os.path.join(REF, tu + ".cpp") for tu in TUS] + own:
+        o = os.path.join(BUILD, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        jobs.append(subprocess.Popen(["g++"] + FLAGS + ["-c", src, "-o", o]))
+        objs.append(o)
+    for j in jobs:
+        if j.wait() != 0:
+            raise RuntimeError("tools/refbase: compiling the reference's translation units failed")
+    subprocess.check_call(["g++", "-o", exe] + objs + ["-lpthread"])
+    return exe
+
+
+def write_feats(path, feats, D):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<ii", len(feats), D))
+        for x in feats:
+            f.write(struct.pack("<i", x.shape[0]))
+            f.write(np.ascontiguousarray(x, np.float32).tobytes())
+
+
+def write_symbols(path, prefix, n):
+    """an AT&T symbol table for labels 0 .. n (WFSTAlphabet, src/WFSTNetwork.cpp:48-112: "name id" lines; no '#' names: nothing is auxiliary)"""
+    with open(path, "w") as f:
+        f.write("<eps> 0\n")
+        for i in range(1, n + 1):
+            f.write("%s%d %d\n" % (prefix, i, i))
+
+
+def run_reference(am, net, feats, beams=None, loader="jwnt", lm_scale=1.0, ins_penalty=0.0, pti=0, threading=False, cpus=None,
+                  timeout=3600, workdir=None):
+    """The reference's decoder on (am, net, feats): one dict per utterance (the driver's JSON lines), plus (rc, stderr tail, wall).
+    loader: "jwnt" - the network through WFSTNetwork::readBinary from the file this build's jd_net_save_jwnt writes (weights as
+    stored: lm_scale / ins_penalty are applied by this build before the file is written) - or "fsm": the TEXT constructor
+    (src/WFSTNetwork.cpp:371-616) from an AT&T text file + two symbol tables, the reference applying scale and penalty itself.
+    Models always through HTKModels::readBinary from this build's jd_am_save_jmbi (the MMF text parser is bison / flex output)."""
+    from juicer_amd import capi
+    from juicer_amd import io as jio
+    exe = build()
+    beams = dict(beams or {})
+    tmp = workdir or tempfile.mkdtemp(prefix="refdiff_", dir=BUILD)
+    os.makedirs(tmp, exist_ok=True)
+    jmbi, featf = os.path.join(tmp, "models.jmbi"), os.path.join(tmp, "feats.bin")
+    capi.Models.from_htk(am).save_jmbi(jmbi)
+    write_feats(featf, feats, am.D)
+    args = ["models=" + jmbi, "feats=" + featf, "threading=%d" % int(bool(threading)), "main=%.9g" % beams.get("main_beam", 0.0),
+            "start=%.9g" % beams.get("start_beam", 0.0), "end=%.9g" % beams.get("end_beam", 0.0), "word=%.9g" % beams.get("word_beam", 0.0),
+            "maxhyps=%d" % beams.get("max_hyps", 0), "pti=%d" % pti]
+    if loader == "fsm":
+        fsm, ins, outs = (os.path.join(tmp, n) for n in ("net.fsm", "in.syms", "out.syms"))
+        jio.write_fsm(fsm, net)
+        write_symbols(ins, "m", int(am.n_hmm))
+        write_symbols(outs, "w", int(max(1, np.max(net.olab) if net.n_arcs else 1)))
+        args += ["fsm=" + fsm, "insyms=" + ins, "outsyms=" + outs, "lmscale=%.9g" % lm_scale, "inspen=%.9g" % ins_penalty]
+    else:
+        jwnt = os.path.join(tmp, "net.jwnt")
+        capi.Network.from_synth(net, lm_scale, ins_penalty).save_jwnt(jwnt)
+        args += ["net=" + jwnt, "lmscale=1", "inspen=0"]
+    cmd = ([] if cpus is None else ["taskset", "-c", cpus]) + [exe] + args
+    t0 = time.time()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = p.communicate(timeout=timeout)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:                                  # (a decoder that hangs: what it printed so far is kept)
+        p.kill()
+        so, se = p.communicate()
+        rc = -999
+    rows = [json.loads(l) for l in so.splitlines() if l.startswith("{") and l.rstrip().endswith("}")]
+    return rows, (rc, se[-600:], time.time() - t0)
+
+
+def same_hyp(row, o) -> bool:
+    """the reference's hypothesis against the oracle's: words, times, and every score bit for bit"""
+    if row["n"] != o.n:
+        return False
+    if o.n <= 0:
+        return True
+    f32 = lambda a: np.asarray(a, np.float32).view(np.uint32)
+    return bool(list(row["label"]) == list(o.label) and list(row["time"]) == list(o.time) and np.array_equal(f32(row["score"]), f32(o.score))
+                and np.array_equal(f32(row["ac"]), f32(o.ac)) and np.array_equal(f32(row["lm"]), f32(o.lm))
+                and np.array_equal(f32(row["tot"]), f32([o.tot_score, o.tot_ac, o.tot_lm])))
+
+
+def same_stats(row, o) -> bool:
+    """the reference's five statistics (WFSTDecoderLite.cpp:231-241: its protected totals) against the oracle's"""
+    return all(int(row["stats"][k]) == int(o.stats[k]) for k in REF_STATS)
+
+
+def diff_case(name, am, net, feats, beams=None, loader="jwnt", lm_scale=1.0, ins_penalty=0.0, pti=0, threading=False, cpus=None,
+              timeout=3600):
+    """One differential case: the reference's classes and the oracle on the same inputs.  Returns a summary dict
+    {name, utterances, identical_hyps, identical_stats, identical_partial (pti > 0), hyps_found, ref_cpu_seconds,
+    oracle_cpu_seconds, frames, ok} - ok = everything identical on every utterance."""
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    rows, (rc, err, wall) = run_reference(am, net, feats, beams, loader, lm_scale, ins_penalty, pti, threading, cpus, timeout)
+    od = OracleDecoder(OracleNet(net, lm_scale, ins_penalty), OracleAM(am), **(beams or {}))
+    out = {"name": name, "loader": loader, "beams": dict(beams or {}), "utterances": len(feats), "frames": int(sum(x.shape[0] for x in feats)),
+           "threading": bool(threading)}
+    if lm_scale != 1.0 or ins_penalty != 0.0:
+        out["lm_scale"], out["ins_penalty"] = lm_scale, ins_penalty
+    if rc != 0 or len(rows) != len(feats):
+        out.update(ok=False, error=("no result within %.0f s (killed)" % wall if rc == -999 else "exit code %d" % rc)
+                   + " after %d of %d utterances" % (len(rows), len(feats)), stderr=err)
+        return out
+    hyp_ok = st_ok = part_ok = found = 0
+    osec = 0.0
+    for r, x in zip(rows, feats):
+        if pti > 0:
+            _, final = od.decode_partial(x, interval=pti)
+            o = od.decode(x)
+            part_ok += int([list(p) for p in final] == [list(p) for p in r["partial"]])
+        else:
+            o = od.decode(x)
+        osec += o.cpu_seconds
+        hyp_ok += int(same_hyp(r, o)); st_ok += int(same_stats(r, o)); found += int(o.n > 0)
+    out.update(identical_hyps=hyp_ok, identical_stats=st_ok, hyps_found=found, ref_cpu_seconds=round(sum(r["cpu_s"] for r in rows), 3),
+               oracle_cpu_seconds=round(osec, 3))
+    if pti > 0:
+        out.update(partial_interval=pti, identical_partial=part_ok)
+    out["ok"] = hyp_ok == len(feats) and st_ok == len(feats) and (pti == 0 or part_ok == len(feats))
+    return out
