@@ -530,6 +530,21 @@ int jd_dec_last_timing(const jd_dec *d, jd_timing *out);
 #define JD_FLOW_RESIDENT       3
 int jd_dec_set_pipeline(jd_dec *d, int32_t mode, int32_t depth, int32_t slots);
 
+/*
+ * How the likelihood tables are scored - an OPTION beside the default, for a caller that wants throughput over bit equality.
+ *   JD_SCORE_EXACT  (default) HTKFlatModels::calcGMMOutput + logAdd with the reference's own roundings (src/HTKFlatModels.cpp:226-293: no
+ *                   contraction, the host libm's expf, log(1 + e) in double): every log-likelihood equals the reference's bit for bit.
+ *   JD_SCORE_FAST   fused multiply-add distance on pre-scaled parameters and an fp32 logAdd on the hardware's exp / log: a log-likelihood
+ *                   moves by ~1e-5 of its magnitude; hypotheses keep their words and times on every fixture of the test suite and their
+ *                   scores stay within 1e-4 relative (what BASELINE.json's north_star asks of the path; tests/test_gpu_fastscore.py).
+ *                   The table costs 0.4 of the exact one (csrc/jd_gmm.h: jd_gmm_fast39).  39-dimensional GMM models only.
+ * Call it between two decodes; whatever was scored or announced ahead is dropped.  jd_am_score_frames_mode: jd_am_score_frames with the option.
+ */
+#define JD_SCORE_EXACT 0
+#define JD_SCORE_FAST  1
+int jd_dec_set_scoring(jd_dec *d, int32_t mode);
+int jd_am_score_frames_mode(const jd_am *a, int32_t device, int32_t mode, const float *frames, int32_t n_frames, float *out);
+
 /* What JD_FLOW_RESIDENT has done so far (cumulative over the decoder's life; a bench reads it on either side of its
  * timed region: frames_searched is what the slots really advanced in between, whatever was announced or handed back). */
 typedef struct jd_pipe_stats {

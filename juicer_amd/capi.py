@@ -55,6 +55,7 @@ class Timing(C.Structure):
 
 
 FLOW_SERIAL, FLOW_TWO_IN_FLIGHT, FLOW_RESIDENT = 0, 1, 3      # jd_dec_set_pipeline
+SCORE_EXACT, SCORE_FAST = 0, 1                                # jd_dec_set_scoring
 
 
 class PipeStats(C.Structure):
@@ -95,6 +96,7 @@ EXPORTS = [
     "jd_dec_prefetch_scores", "jd_streams_push", "jd_dec_info",
     "jd_broker_create", "jd_broker_destroy", "jd_broker_open", "jd_broker_close", "jd_broker_init", "jd_broker_push",
     "jd_broker_finish", "jd_broker_get_stats", "jd_dec_debug_cells", "jd_dec_set_pipeline", "jd_dec_pipeline_stats",
+    "jd_dec_set_scoring", "jd_am_score_frames_mode",
 ]
 
 _lib = None
@@ -372,12 +374,12 @@ class Models:
         _check(lib().jd_am_create_hybrid(C.byref(h), C.c_int32(pr.shape[0]), _p(pr, C.c_float), C.c_int32(states_per_model)))
         return cls(h)
 
-    def score_frames(self, frames, device: int = 0):
-        """Companion GMM kernel on its own: [T, D] -> [T, n_gmm] log-likelihoods."""
+    def score_frames(self, frames, device: int = 0, mode: int = 0):
+        """Companion GMM kernel on its own: [T, D] -> [T, n_gmm] log-likelihoods (mode: SCORE_EXACT, the default, or SCORE_FAST)."""
         x = _f32(frames)
         out = np.zeros((x.shape[0], self.n_gmms), np.float32)
-        _check(lib().jd_am_score_frames(self.h, C.c_int32(device), _p(x, C.c_float), C.c_int32(x.shape[0]),
-                                        _p(out, C.c_float)))
+        _check(lib().jd_am_score_frames_mode(self.h, C.c_int32(device), C.c_int32(mode), _p(x, C.c_float), C.c_int32(x.shape[0]),
+                                             _p(out, C.c_float)))
         return out
 
     def __del__(self):
@@ -446,6 +448,11 @@ class Decoder:
         """How batches that follow each other share the chip (jd_dec_set_pipeline): FLOW_SERIAL, FLOW_TWO_IN_FLIGHT (default) or
         FLOW_RESIDENT (depth = batches announced and not handed back at most, slots = one-workgroup slots of the resident kernel)."""
         _check(lib().jd_dec_set_pipeline(self.h, C.c_int32(mode), C.c_int32(depth), C.c_int32(slots)))
+
+    def set_scoring(self, mode: int):
+        """How the likelihood tables are scored (jd_dec_set_scoring): SCORE_EXACT (default: the reference's roundings, bit-identical
+        log-likelihoods) or SCORE_FAST (fused multiply-add distance, fp32 logAdd: scores within 1e-4, the table at 0.4 of the cost)."""
+        _check(lib().jd_dec_set_scoring(self.h, C.c_int32(mode)))
 
     def pipeline_stats(self) -> dict:
         """What FLOW_RESIDENT has done so far, cumulative (jd_dec_pipeline_stats)."""

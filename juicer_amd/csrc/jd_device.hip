@@ -111,6 +111,8 @@ __global__ void jd_hybrid_kernel(const float *__restrict__ feats, const int *__r
 
 struct AmDevBuf {
     float *par = nullptr, *det = nullptr; int *n_mix = nullptr;
+    float *par_fast = nullptr;      // jd_dec_set_scoring(JD_SCORE_FAST): [g][m][D][2] = (sqrt(ivar), -mean sqrt(ivar)), made when first asked for
+    int fast = 0;                   // launch_gmm scores with jd_gmm_fast39
     float *log_prior = nullptr;
     JdLogTab *logtab = nullptr;
     int device = -1;
@@ -149,9 +151,27 @@ static int upload_am_gmm(const jd_am *a, AmDevBuf &b)
     return JD_OK;
 }
 
+// the parameters of the scoring option (jd_gmm.h: jd_gmm_fast39)
+static int upload_am_fast(const jd_am *a, AmDevBuf &b)
+{
+    if (b.par_fast) return JD_OK;
+    const size_t gm = (size_t)a->n_gmm * a->max_mix, D = (size_t)a->D;
+    std::vector<float> par(gm * D * 2);
+    for (size_t i = 0; i < gm; ++i)
+        for (size_t j = 0; j < D; ++j) {
+            const double s = sqrt((double)a->ivar[i * D + j]);
+            par[(i * D + j) * 2] = (float)s;
+            par[(i * D + j) * 2 + 1] = (float)(-(double)a->mean[i * D + j] * s);
+        }
+    HIPCHK(hipMalloc(&b.par_fast, par.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(b.par_fast, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice));
+    return JD_OK;
+}
+
 static void free_am_gmm(AmDevBuf &b)
 {
     if (b.par) (void)hipFree(b.par);
+    if (b.par_fast) (void)hipFree(b.par_fast);
     if (b.det) (void)hipFree(b.det);
     if (b.n_mix) (void)hipFree(b.n_mix);
     if (b.logtab) (void)hipFree(b.logtab);
@@ -186,7 +206,15 @@ static int launch_gmm(const jd_am *a, const AmDevBuf &b, const float *d_feats, c
     const bool small_tiles = a->D == 39 && (used_row_tiles >= 0 ? (long long)used_row_tiles * ((a->n_gmm + GMM_GT - 1) / GMM_GT) : tiles) < 1024;
     if (small_tiles) tiles = row_tiles * ((a->n_gmm + GMM_GT_SMALL - 1) / GMM_GT_SMALL);
     dim3 grid((unsigned)((max_blocks > 0 && tiles > max_blocks) ? max_blocks : tiles));
-    if (a->D == 39) {
+    if (a->D == 39 && b.fast && b.par_fast) {
+        const size_t sm = (size_t)GMM_ROWS2 * std::max(39, GMM_GT + 1) * sizeof(float);
+        if (small_tiles)
+            hipLaunchKernelGGL(jd_gmm_fast39<GMM_GT_SMALL>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par_fast, b.det,
+                               b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, rt_base, n_rt_list);
+        else
+            hipLaunchKernelGGL(jd_gmm_fast39<GMM_GT>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par_fast, b.det,
+                               b.n_mix, a->n_gmm, a->max_mix, d_ll, skip_unused, rt_base, n_rt_list);
+    } else if (a->D == 39) {
         const size_t sm = 130 * sizeof(JdLogTab) + 32 * sizeof(unsigned long long) + (size_t)GMM_ROWS2 * std::max(39, GMM_GT + 1) * sizeof(float);
         if (small_tiles)
             hipLaunchKernelGGL(jd_gmm_kernel39<GMM_GT_SMALL>, grid, dim3(256), sm, st, d_feats, d_row_src, n_rows, b.par, b.det,
@@ -216,16 +244,29 @@ static int check_device(int device)
     return JD_OK;
 }
 
+static int score_frames_mode(const jd_am *a, int32_t device, int32_t mode, const float *frames, int32_t n_frames, float *out);
 extern "C" int jd_am_score_frames(const jd_am *a, int32_t device, const float *frames, int32_t n_frames,
                                   float *out)
 {
+    return score_frames_mode(a, device, JD_SCORE_EXACT, frames, n_frames, out);
+}
+extern "C" int jd_am_score_frames_mode(const jd_am *a, int32_t device, int32_t mode, const float *frames, int32_t n_frames,
+                                       float *out)
+{
+    return score_frames_mode(a, device, mode, frames, n_frames, out);
+}
+static int score_frames_mode(const jd_am *a, int32_t device, int32_t mode, const float *frames, int32_t n_frames, float *out)
+{
     if (!a || !frames || !out || n_frames < 0) return jd_fail(JD_EINVAL, "jd_am_score_frames: bad argument");
+    if (mode != JD_SCORE_EXACT && mode != JD_SCORE_FAST) return jd_fail(JD_EINVAL, "jd_am_score_frames_mode: mode %d (JD_SCORE_EXACT or JD_SCORE_FAST)", mode);
+    if (mode == JD_SCORE_FAST && (a->D != 39 || a->hybrid)) return jd_fail(JD_EINVAL, "JD_SCORE_FAST: 39-dimensional GMM models only");
     int rc = check_device(device);
     if (rc) return rc;
     if (n_frames == 0) return JD_OK;
     AmDevBuf b;
     rc = upload_am_gmm(a, b);
     if (rc) return rc;
+    if (mode == JD_SCORE_FAST) { rc = upload_am_fast(a, b); if (rc) return rc; b.fast = 1; }
     float *d_x = nullptr, *d_ll = nullptr;
     int *d_src = nullptr;
     std::vector<int> src((size_t)n_frames);

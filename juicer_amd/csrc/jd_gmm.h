@@ -273,3 +273,86 @@ __global__ __launch_bounds__(256, 4) void jd_gmm_kernel39(const float *__restric
     }
 }
 
+
+// ---- the D = 39 kernel with the scoring OPTION of jd_dec_set_scoring(JD_SCORE_FAST): the same tiling (two frames per lane, a quarter of a
+// tile's tied states per wave, parameters through the scalar cache) without the reference's roundings.
+//   distance   s = sqrt(ivar), t = -mean s (prepared on the host: AmDevBuf::par_fast): u = fma(x, s, t), sum = fma(u, u, sum) - two packed
+//              fused multiply-adds per dimension and frame pair where the exact kernel issues four packed operations (sub, mul, mul, add)
+//   logAdd     max + log(1 + exp(min - max)) in fp32 on the hardware's exp2 / log2 (v_exp_f32 / v_log_f32), the reference's -18.42 cut kept:
+//              ~12 instructions per frame where the bit-exact replica (glibc's expf + an fp64 log(1 + e)) takes ~58
+// north_star asks for path / acoustic scores within 1e-4 relative of the reference and identical words and times; this kernel is held to that
+// (tests/test_gpu_fastscore.py: every fixture), not to bit equality - the DEFAULT stays jd_gmm_kernel39, whose table equals the CPU oracle's
+// bit for bit.  Error: a log-likelihood of magnitude ~50-100 moves by ~1e-5 (39 fused terms of relative error 2^-24 each and one logAdd per
+// mixture of absolute error ~1e-7).
+__device__ __forceinline__ float jd_log_add_fast(float a, float c)
+{
+    const float x = fmaxf(a, c), y = fminf(a, c);
+    const float d = y - x;
+    const float e = __builtin_amdgcn_exp2f(d * 1.44269504088896340736f);      // exp(d), d <= 0
+    const float l = __builtin_amdgcn_logf(1.0f + e) * 0.69314718055994530942f;
+    return d < -18.42f ? x : x + l;                                           // HTKFlatModels.cpp:276 (LOG_ZERO - anything: -inf < cut)
+}
+
+template <int GT>
+__global__ __launch_bounds__(256, 4) void jd_gmm_fast39(const float *__restrict__ feats, const int *__restrict__ row_src, int n_rows,
+                                                      const float *__restrict__ par_fast, const float *__restrict__ det,
+                                                      const int *__restrict__ n_mix, int G, int M, float *__restrict__ ll, int skip_unused,
+                                                      const int *__restrict__ rt_base, int n_rt_list)
+{
+    constexpr int DT = 39, DP = 39;
+    extern __shared__ __align__(16) char smem[];
+    float *sx = (float *)smem;                        // [128][DP]
+    float *so = sx;                                   // [128][GT+1]: the feature tile is in registers by then
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_rt = rt_base ? n_rt_list : (n_rows + GMM_ROWS2 - 1) / GMM_ROWS2, n_gt = (G + GT - 1) / GT;
+    for (int tile = blockIdx.x; tile < n_rt * n_gt; tile += gridDim.x) {
+        const int gt = tile / n_rt;                   // row tile skewed by the state group (see jd_gmm_kernel)
+        const int r0 = rt_base ? rt_base[(tile + gt) % n_rt] : ((tile + gt) % n_rt) * GMM_ROWS2;
+        const int g0 = gt * GT;
+        if (skip_unused && row_src[r0] < 0) continue;
+        __syncthreads();
+        for (int e = tid; e < GMM_ROWS2 * DT; e += 256) {
+            const int r = e / DT, j = e - r * DT;
+            const int src = (r0 + r < n_rows) ? row_src[r0 + r] : -1;
+            sx[r * DP + j] = (src >= 0) ? feats[(size_t)src * DT + j] : 0.0f;
+        }
+        __syncthreads();
+        jd_f2 x[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) { x[j].x = sx[lane * DP + j]; x[j].y = sx[(lane + 64) * DP + j]; }
+        __syncthreads();
+        constexpr int GPW = GT / 4;
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int gl = wid * GPW + gi;            // wave-uniform
+            const int g = g0 + gl;
+            float acc0 = LZ, acc1 = LZ;
+            if (g < G) {
+                const int nm = n_mix[g];
+                const float *pg = par_fast + (size_t)g * M * DT * 2;
+                const float *dg = det + (size_t)g * M;
+                for (int m = 0; m < nm; ++m) {
+                    const float *pm = pg + (size_t)m * DT * 2;
+                    jd_f2 sum = {0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) {
+                        const jd_f2 sj = {pm[2 * j], pm[2 * j]}, tj = {pm[2 * j + 1], pm[2 * j + 1]};
+                        const jd_f2 u = __builtin_elementwise_fma(x[j], sj, tj);
+                        sum = __builtin_elementwise_fma(u, u, sum);
+                    }
+                    const float dm = dg[m];
+                    const float c0 = __builtin_fmaf(-0.5f, sum.x, dm), c1 = __builtin_fmaf(-0.5f, sum.y, dm);
+                    if (m == 0) { acc0 = LZ < c0 ? c0 : LZ; acc1 = LZ < c1 ? c1 : LZ; }
+                    else { acc0 = jd_log_add_fast(acc0, c0); acc1 = jd_log_add_fast(acc1, c1); }
+                }
+            }
+            so[lane * (GT + 1) + gl] = acc0;
+            so[(lane + 64) * (GT + 1) + gl] = acc1;
+        }
+        __syncthreads();
+        for (int e = tid; e < GMM_ROWS2 * GT; e += 256) {
+            const int r = e / GT, c = e - r * GT;
+            if (r0 + r < n_rows && g0 + c < G) ll[(size_t)(r0 + r) * G + g0 + c] = so[r * (GT + 1) + c];
+        }
+    }
+}

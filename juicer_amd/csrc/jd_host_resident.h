@@ -720,6 +720,25 @@ extern "C" int jd_dec_set_pipeline(jd_dec *d, int32_t mode, int32_t depth, int32
     return JD_OK;
 }
 
+// How the likelihood tables are scored (include/juicer_amd.h).  Whatever was scored or announced under the other setting is dropped.
+extern "C" int jd_dec_set_scoring(jd_dec *d, int32_t mode)
+{
+    if (!d) return jd_fail(JD_EINVAL, "jd_dec_set_scoring: null");
+    if (mode != JD_SCORE_EXACT && mode != JD_SCORE_FAST) return jd_fail(JD_EINVAL, "jd_dec_set_scoring: mode %d (JD_SCORE_EXACT or JD_SCORE_FAST)", mode);
+    if (mode == JD_SCORE_FAST && (d->am->D != 39 || d->am->hybrid))
+        return jd_fail(JD_EINVAL, "jd_dec_set_scoring: JD_SCORE_FAST serves 39-dimensional GMM models (this decoder's: D = %d%s)", d->am->D,
+                       d->am->hybrid ? ", hybrid" : "");
+    if (d->res && d->res->on && !d->pipe_on) return jd_fail(JD_ESTATE, "jd_dec_set_scoring: a broker drives this decoder's resident kernel");
+    int rc = check_device(d->device);
+    if (rc) return rc;
+    if ((d->amb.fast != 0) == (mode == JD_SCORE_FAST)) return JD_OK;
+    pipe_drain(d);
+    pf_discard(d);
+    if (mode == JD_SCORE_FAST) { rc = upload_am_fast(d->am, d->amb); if (rc) return rc; }
+    d->amb.fast = mode == JD_SCORE_FAST ? 1 : 0;
+    return JD_OK;
+}
+
 extern "C" int jd_dec_pipeline_stats(const jd_dec *d, jd_pipe_stats *out)
 {
     if (!d || !out) return jd_fail(JD_EINVAL, "jd_dec_pipeline_stats: null");

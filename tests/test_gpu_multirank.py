@@ -77,3 +77,58 @@ def test_bench_strong_scaling_mode(built):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gathered_hyps"] == 11 and d["value"] > 0
+
+
+def test_bench_eight_ranks_share_one_gpu(built):
+    """`python bench.py --gpus 8` on the headline's own path - every rank a resident slot kernel (eight slots each here), nine batches
+    announced ahead, ONE all_gather of all steps' records behind jd_dec_quiesce - with all eight ranks on this box's one GPU over gloo
+    (JD_BENCH_SHARE_GPU=1: the numbers mean nothing, eight processes' kernels, arenas and collectives side by side do).  What the
+    driver's first real 8-GPU run will do is this, with RCCL in gloo's place."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--utts-per-gpu", "4",
+           "--arcs", "60000", "--no-cpu-baseline", "--no-extra-legs", "--pipeline-slots", "8"]
+    out = _run(cmd, env, 600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["config"]["gathered_hyps"] == 32 and d["value"] > 0
+    assert d["config"]["pipeline_error"] is None and d["config"]["batches_in_flight"] == 10 and d["roofline"]["kernel"] == "k_slot", d["config"]
+    assert "wall-clock budget" in out.stderr                    # (what the run's time went to, for the driver's limit)
+
+
+@pytest.mark.parametrize("phase", ["create", "warmup", "timed"])
+def test_bench_falls_back_on_every_rank_when_one_pipeline_fails(built, phase):
+    """One rank's resident pipeline fails (forced: JD_BENCH_FAIL=rank:phase - at decoder creation, while the pipeline fills, inside the
+    timed region).  The other ranks must not be left waiting in a collective: the failing rank keeps taking part (empty records), ALL
+    ranks agree that the attempt is void and repeat the measurement with two batches in flight; the line says so."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1", JD_BENCH_FAIL="1:" + phase)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--utts-per-gpu", "6",
+           "--arcs", "60000", "--no-cpu-baseline", "--no-extra-legs", "--pipeline-slots", "8"]
+    out = _run(cmd, env, 400)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["gathered_hyps"] == 12 and d["value"] > 0
+    assert d["config"]["pipeline"] is None and d["config"]["batches_in_flight"] == 2, d["config"]
+    assert d["config"]["pipeline_error"] and "measuring with two batches in flight on every rank" in out.stderr, (d["config"], out.stderr[-600:])
+
+
+def test_batch_test_fails_fast_without_the_devices(built):
+    """`jd_batch_test -devices N` with more devices than the box has: an error with jd_last_error()'s text within seconds, not a hang
+    in ncclCommInitAll (src/DecoderBatchTest.cpp:738-771 is a serial loop; the sharded counterpart must not be worse at failing)."""
+    import tempfile
+    import time
+    import torch
+    from juicer_amd import io as jio, synth
+    am, net, feats, _ = synth.config_toy()
+    n = torch.cuda.device_count() + 1
+    with tempfile.TemporaryDirectory() as td:
+        jio.write_fsm(os.path.join(td, "n.fsm"), net); jio.write_jdam(os.path.join(td, "m.jdam"), am); jio.write_jdf(os.path.join(td, "u.jdf"), feats[0])
+        with open(os.path.join(td, "list"), "w") as f:
+            f.write(os.path.join(td, "u.jdf") + "\n")
+        t0 = time.time()
+        out = subprocess.run([os.path.join(ROOT, "juicer_amd", "jd_batch_test"), "-fsmFName", os.path.join(td, "n.fsm"), "-modelsFName",
+                              os.path.join(td, "m.jdam"), "-inputFName", os.path.join(td, "list"), "-mainBeam", "150", "-devices", str(n)],
+                             capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and time.time() - t0 < 60
+    assert "visible" in out.stderr or "device" in out.stderr, out.stderr[-400:]

@@ -169,3 +169,60 @@ def test_slot_kernel_rows_of_every_length(monkeypatch, built):
         assert a.n > 0 and bit_exact(b, a), u
         for k in STAT_KEYS:
             assert a.stats[k] == b.stats[k], (u, k, a.stats[k], b.stats[k])
+
+
+def test_slot_launch_is_not_chosen_over_streams_with_cluster_lists(built):
+    """launch_search took k_slot_batch by the launch's shape alone (more streams than CUs, one workgroup each).  Streams in
+    the middle of an utterance whose lists were written by clusters of SEVERAL workgroups - 100 callers served with clusters of two,
+    then 200 more join - are not the slot kernel's to read (eight wave segments, JDE_GEOM): such a launch stays with k_search,
+    which reads lists of any geometry; nobody's utterance dies.  The next utterances, started together, do take the slot kernel."""
+    import torch
+    from juicer_amd import capi, synth
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n1, n2 = max(2, n_cus * 100 // 256), n_cus + 44                     # (100 and 300 on an MI355X)
+    am, net, feats, _ = synth.config_small(n_utts=4)
+    kw = dict(main_beam=150.0)
+    want = oracle_certified_many(net, am, feats, **kw)
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=n2, **kw)
+    for s in range(n2):
+        gd.stream_init(s)
+    gd.streams_push(list(range(n1)), [feats[s % 4][:60] for s in range(n1)])
+    tm = gd.last_timing()                                               # (the streaming calls add to the decoder's timing record)
+    assert tm["cluster_wgs"] >= 2 and tm["slot_launches"] == 0, tm      # clusters of several workgroups wrote these lists
+    gd.streams_push(list(range(n2)), [feats[s % 4][60:] if s < n1 else feats[s % 4] for s in range(n2)])
+    tm1 = gd.last_timing()
+    assert tm1["slot_launches"] == 0 and tm1["search_launches"] > tm["search_launches"], tm1   # by shape a slot launch; by the streams' lists not
+    for s in range(n2):
+        assert bit_exact(gd.stream_finish(s), want[s % 4]), s
+    for s in range(n2):                                                 # the next utterances start together: the slot kernel's
+        gd.stream_init(s)
+    gd.streams_push(list(range(n2)), [feats[(s + 1) % 4] for s in range(n2)])
+    tm2 = gd.last_timing()
+    assert tm2["slot_launches"] == tm2["search_launches"] - tm1["search_launches"] > 0, tm2
+    for s in range(n2):
+        assert bit_exact(gd.stream_finish(s), want[(s + 1) % 4]), s
+    gd.close()
+
+
+@pytest.mark.parametrize("slot", [False, True])
+def test_counters_of_what_the_kernels_touch(built, monkeypatch, slot):
+    """jd_stats' tot_recs_read .. tot_closure_items (bench.py's design-bytes roofline): what the kernels really took up, against the
+    reference's figures beside them - records read + arcs attached never exceed the reference's instance count (hopeless candidates
+    are counted there and never become a record), arcs walked never exceed arcs visited (a prefix walk accounts for the rest)."""
+    from juicer_amd import capi, synth
+    if slot:
+        monkeypatch.setenv("JD_DEV", "1"); monkeypatch.setenv("JD_CW", "1"); monkeypatch.setenv("JD_SLOT_BATCH", "1")
+    am, net, feats, _ = synth.config_small(n_utts=4)
+    gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=4, main_beam=150.0)
+    gs = gd.decode_batch(feats)
+    assert (gd.last_timing()["slot_launches"] > 0) == slot
+    for g in gs:
+        st = g.stats
+        assert 0 < st["tot_recs_read"] and 0 < st["tot_new_attached"]
+        assert st["tot_recs_read"] + st["tot_new_attached"] <= st["tot_insts_in"], st
+        assert 0 < st["tot_recs_written"] <= st["tot_recs_read"] + st["tot_new_attached"], st
+        assert 0 < st["tot_entry_items"] <= st["tot_recs_read"] + st["tot_new_attached"], st
+        assert 0 < st["tot_arcs_walked"] <= st["tot_arcs_visited"], st
+        assert st["tot_items_expanded"] >= st["tot_proc_end_hyps"] > 0, st
+        assert st["tot_closure_items"] > 0, st                          # (the tee model between words: closure items every word end)
+    gd.close()

@@ -150,6 +150,8 @@ def diff_case(name, am, net, feats, beams=None, loader="jwnt", lm_scale=1.0, ins
     if rc != 0 or len(rows) != len(feats):
         out.update(ok=False, error=("no result within %.0f s (killed)" % wall if rc == -999 else "exit code %d" % rc)
                    + " after %d of %d utterances" % (len(rows), len(feats)), stderr=err)
+        if rc in (-11, -6):                                            # SIGSEGV / abort INSIDE the reference's classes: nothing to compare
+            out["reference_crashed"] = True
         return out
     hyp_ok = st_ok = part_ok = found = 0
     osec = 0.0

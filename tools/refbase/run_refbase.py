@@ -116,6 +116,8 @@ def main():
         for kw in BEAMS:
             add("config_toy %s" % (kw or "no pruning"), a, n, f, kw)
         out["differential"] = {"cases": cases, "cases_total": len(cases), "cases_identical": sum(int(c["ok"]) for c in cases),
+                               "cases_reference_crashed": sum(int(bool(c.get("reference_crashed"))) for c in cases),
+                               "cases_different": sum(int(not c["ok"] and not c.get("reference_crashed")) for c in cases),
                                "utterances_total": sum(c["utterances"] for c in cases),
                                "what_identical_means": "every utterance: words, times, every score and the totals bit for bit; the reference's five statistics "
                                                        "(its protected totals, WFSTDecoderLite.h:150-154); with PartialTraceInterval the partial paths"}
