@@ -209,6 +209,24 @@ def slot_traffic(frames):
         return None
 
 
+def slot_l2_requests(fps):
+    """The slot kernel's other roofline: requests at the L2s.  TCC_REQ of k_slot_batch from the committed PMC pass (same proxy and
+    the same source-hash rule as slot_traffic) per stream-frame x the frames/s of this run, against what the chip's memory side was
+    probed to carry: 49 G scattered 64-byte loads / s that miss the L2 (tools/traffic_probe.hip, profiles/r03_traffic_probe.log;
+    requests that hit an L2 are cheaper, so the fraction is an upper bound of how near that wall the kernel runs)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "%s_c512slot_traffic.json" % PROFILE_ROUND)))
+        if t.get("source_hash") != kernel_source_hash():
+            return None
+        pm = json.load(open(os.path.join(ROOT, "profiles", "%s_slot_pmc_summary.json" % PROFILE_ROUND)))
+        k = [v for n, v in pm.items() if n.startswith("k_slot_batch")][0]
+        per_sf = k["TCC_REQ_sum"]["mean"] / t["frames_per_pass"]
+        return {"per_stream_frame": round(per_sf, 1), "G_per_s": round(per_sf * fps / 1e9, 2), "probe_scattered_miss_ceiling_G_per_s": 49.0,
+                "frac_of_probe": round(per_sf * fps / 49e9, 4), "from": "TCC_REQ_sum of k_slot_batch (proxy, as traffic) x this run's frames/s"}
+    except Exception:
+        return None
+
+
 def leg_traffic(leg, launches):
     """HBM bytes per k_search launch of a workload, from the committed PMC passes of that workload on its own
     (profiles/r05_<leg>_traffic.json, tools/leg_pmc.sh): the bytes of all k_search launches of one pass over the
@@ -308,8 +326,7 @@ def run_leg(name, am, net, feats, beam, max_hyps, dev, oracle_utts=0, passes=4, 
            "search_ms": round(tm["search_ms"], 3), "gmm_ms": round(gmm_alone if gmm_alone is not None else tm["gmm_ms"], 3),
            "scored_ahead": bool(tm["prefetched"]), "batches_in_flight": (depth + 1) if depth else (2 if two else 1),
            "searched_ahead_frames": int(tm["ahead_frames"]), "decode_calls": n_calls,
-           "per_stream_frame": {k: round(st[k] / max(1, frames), 1) for k in ("tot_insts_in", "tot_proc_emit_hyps",
-                                                                              "tot_proc_end_hyps", "tot_arcs_visited", "tot_paths")},
+           "per_stream_frame": {k: round(v / max(1, frames), 1) for k, v in st.items() if k.startswith("tot_")},
            "hyps_found": int(sum(int(h.n > 0) for h in hyps)),
            "setup_s": round(time.perf_counter() - t0 - sum(r[0] for r in runs), 1)}
     # (which kernel the leg's frames went through: the pipeline's slots, the slot kernel as a plain launch, else clusters of k_search)
@@ -642,12 +659,15 @@ def main():
                 del pending[:]
 
         def quiesce():
+            """the resident kernel leaves - ALSO on a rank whose decoder has failed: the collective that follows moves device
+            tensors, and anything queued on a device whose search kernel stays may wait for it for ever"""
             nonlocal err
-            if err is None:
-                try:
-                    dec.quiesce()
-                except capi.JuicerAmdError as e:
-                    err = e
+            if dec is None:
+                return
+            try:
+                dec.quiesce()
+            except capi.JuicerAmdError as e:
+                err = err or e
 
         # ---- fill + warm-up
         ph["phase"] = "warmup"
@@ -779,10 +799,13 @@ def main():
         roofline["kernel"] = "k_slot"
         roofline["traffic_is"] = "proxy: k_slot_batch counted on configs[2]'s 512-utterance batch, bytes per stream-frame x frames"
         roofline["launch"] = "ONE launch spans the timed region; a batch's share = region x batch frames / frames the slots advanced"
+        roofline["l2_requests"] = slot_l2_requests(fps) if default_cfg else None
     roofline["frac_is"] = "SURVEY 8(d) bytes of the REFERENCE's work / time; frac_design: bytes this design requests; frac_measured: counted HBM bytes"
     gmm_flops = frames_local * G * M * (3.0 * D + 4.0)
     gmm_bytes = G * M * (2 * D + 1) * 4.0 + frames_local * D * 4.0 / max(1, tm["gmm_launches"])
     roofline["search_ms_per_step"] = round(step_tm["search_ms"], 3)
+    # one batch's counters per stream-frame: the reference's figures (tot_insts_in .. tot_paths) and what the kernels took up (tot_recs_read ..)
+    roofline["per_stream_frame"] = {k: round(v / max(1, frames_local), 1) for k, v in st.items() if k.startswith("tot_")}
     # the companion kernel is VALU-bound: per (frame pair, mixture) 4 packed fp32 instructions per dimension
     # + ~116 for the two logAdd steps, 4 cycles each on 1024 SIMDs; fast scoring: 2 packed FMAs per dimension + ~24
     per_mix = (4.0 * D + 116.0) if args.scoring == "exact" else (2.0 * D + 24.0)

@@ -303,7 +303,8 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         const bool slot_live = live_mask != 0;
         const unsigned long long bl = __ballot(slot_live), be = __ballot(has_exit);
         if (!is_new) c_insts += __popcll(__ballot(valid));             // (new arcs are counted when they are entered)
-        JD_COUNT(if (lane == 0) atomicAdd(&sh.cntA, (unsigned long long)(is_new ? __popcll(__ballot(valid)) : 0) | ((unsigned long long)__popcll(__ballot(valid && kv != 0ULL)) << 32)));
+        JD_COUNT(const unsigned long long cnt_a_ = (unsigned long long)(is_new ? __popcll(__ballot(valid)) : 0) | ((unsigned long long)__popcll(__ballot(valid && kv != 0ULL)) << 32);
+                 if (lane == 0) atomicAdd(&sh.cntA, cnt_a_));         // (the ballots are the whole wave's: taken outside the one-lane branch)
         // survivors: header + new tokens to this wave's segment of the next list
         {
             const int nsurv = __popcll(bl);
@@ -432,7 +433,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         }
         const unsigned ioff = valid ? icur + ii * 32u : OOB_OFF;
         const bool start_tok = valid && exit_kind && info.x < 0;       // recognitionStart's token: it has traversed no arc
-        JD_COUNT(if (lane == 0) atomicAdd(&sh.stat[ST_XITEMS], __popcll(__ballot(valid))));
+        JD_COUNT(const int cnt_i_ = __popcll(__ballot(valid)); if (lane == 0) atomicAdd(&sh.stat[ST_XITEMS], cnt_i_));
         const bool real = valid && !start_tok && slice_no == 0;
         const int state = !valid ? 0 : start_tok ? C.init_state : info.z;
         // the state's static record (XState): requested here, used when the item is known to go on
@@ -622,7 +623,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
                 skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
             }
             if (on) ++c_arcs;
-            JD_COUNT(if (lane == 0) atomicAdd(&sh.cntX, (unsigned long long)__popcll(__ballot(on))));
+            JD_COUNT(const unsigned long long cnt_w_ = (unsigned long long)__popcll(__ballot(on)); if (lane == 0) atomicAdd(&sh.cntX, cnt_w_));
             if (on && inl == 0) {                                      // :533-540 epsilon input
                 un = tg;
                 un.score = ns;

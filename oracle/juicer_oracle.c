@@ -463,6 +463,7 @@ struct jo_dec {
     /* result */
     int32_t *r_label, *r_time; float *r_score, *r_ac, *r_lm; int32_t r_cap;
     float *trace; int32_t trace_cap;
+    uint8_t *cells; int32_t cells_frames;   /* jo_set_cells: cells[frame * n_gmm + g] = 1 for every calcGMMOutput(g) call of that frame */
 };
 
 void jo_dec_destroy(jo_dec *d)
@@ -512,6 +513,15 @@ int jo_dec_create(jo_dec **out, const jo_net *net, const jo_am *am,
     return 0;
 }
 
+/* diagnostics (tools/demand_stats.py): which (frame, tied state) cells does the search ask calcGMMOutput for?  cells: frames x n_gmm
+ * bytes, the caller's (or NULL: off); marked whether the value comes out of the block cache or is computed */
+int jo_set_cells(jo_dec *d, uint8_t *cells, int32_t frames)
+{
+    if (!d) return fail(-1, "jo_set_cells: null");
+    d->cells = cells; d->cells_frames = cells ? frames : 0;
+    return 0;
+}
+
 int jo_set_trace(jo_dec *d, float *best_emit_per_frame, int32_t cap)
 {
     d->trace = best_emit_per_frame; d->trace_cap = cap;
@@ -531,6 +541,7 @@ static int am_new_frame(jo_dec *d, int32_t frame, const float *const *input, int
 /* HTKFlatModels::calcGMMOutput, HTKFlatModels.cpp:226-262 (block cache) */
 static float am_calc_gmm(jo_dec *d, int32_t g)
 {
+    if (d->cells && d->amFrame >= 0 && d->amFrame < d->cells_frames) d->cells[(size_t)d->amFrame * d->am->n_gmm + g] = 1;
     int32_t n = d->amFrame - d->cacheT[g];
     if (n < d->fnBlock) return d->cache[(size_t)g * d->fnBlock + n];
     int32_t m = d->currInputLen < d->fnBlock ? d->currInputLen : d->fnBlock;

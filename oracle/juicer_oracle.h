@@ -86,6 +86,7 @@ int jo_finish(jo_dec *d, jo_hyp *out);
 int jo_decode_utt(jo_dec *d, const float *feats, int32_t n_frames, jo_hyp *out, double *cpu_seconds);
 /* per-frame trace for debugging parity: bestEmitScore after each frame */
 int jo_set_trace(jo_dec *d, float *best_emit_per_frame, int32_t cap);
+int jo_set_cells(jo_dec *d, uint8_t *cells, int32_t frames);   /* diagnostics: the (frame, tied state) cells calcGMMOutput is asked for */
 
 /* The reference's two-thread organisation (WFSTDecoderLiteThreading + HTKFlatModelsThreading): the
  * frame loop of jo_decode_utt over a search thread and a scoring thread.  Same results as

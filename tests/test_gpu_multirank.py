@@ -23,6 +23,16 @@ def _run(cmd, env, timeout):
         os.killpg(p.pid, signal.SIGKILL)
         out, err = p.communicate()
         raise AssertionError("timed out after %d s:\n%s\n%s" % (timeout, out[-2000:], err[-2000:]))
+    if p.returncode != 0:                                    # (what the ranks said, kept where a gpurun call brings it home; the assertion shows a tail)
+        try:
+            d = os.path.join(ROOT, "gpurun_out", "test_logs")
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "multirank_%d.err" % os.getpid()), "a") as f:
+                f.write("==== %s\n%s\n%s\n" % (" ".join(cmd), out[-20000:], err[-60000:]))
+        except OSError:
+            pass
+        said = [l for l in err.splitlines() if "bench.py" in l or "juicer_amd error" in l or "Error" in l]
+        err = err[-1500:] + "\n-- lines that name the failure:\n" + "\n".join(said[-20:])
     return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 

@@ -10,7 +10,7 @@ txt=sys.stdin.read()
 blocks=re.split(r'remark: [^\n]*Function Name: ',txt)
 for b in blocks[1:]:
     name=b.split('\n')[0].strip()
-    if not re.search(r"k_resident|k_search|k_slot|gmm_kernel39|gmm_fast39", name): continue
+    if not re.search(r'k_resident|k_search|k_slot|gmm_kernel39|gmm_fast39', name): continue
     def g(k):
         m=re.search(k+r': (\d+)',b); return m.group(1) if m else '?'
     print('%-60s VGPR %s AGPR %s spillV %s spillS %s scratch %s LDS %s occ %s'%(name[:60],g('VGPRs'),g('AGPRs'),g('VGPRs Spill'),g('SGPRs Spill'),g('ScratchSize \[bytes/lane\]'),g('LDS Size \[bytes/block\]'),g('Occupancy \[waves/SIMD\]')))

@@ -33,11 +33,14 @@ for k, v in d.items():
 # processed).  With two batches in flight the calls have also searched part of the batch behind the last one - as much
 # of a batch as a batch is ahead when its turn comes: that many batches' worth of search were counted.
 leg = json.load(open(sys.argv[1] + "/leg_under_pmc1.json"))
-wide = 80.0 * leg["per_stream_frame"]["tot_insts_in"] * leg["frames_per_step"]
+# (the records the kernel really READ - its own counter; tot_insts_in is the reference's instance count, which includes
+# candidates that never become a record: round 5 priced 11.7 k records per configs[1] frame where ~5 k are read)
+rec_bytes = 80.0 if "1-6 emitting" not in leg.get("workload", "") else 144.0
+wide = rec_bytes * leg["per_stream_frame"]["tot_recs_read"] * leg["frames_per_step"]
 np_ = float(leg.get("decode_calls", 2)) + (leg.get("searched_ahead_frames", 0) / float(leg["frames_per_step"]) if leg.get("batches_in_flight", 1) == 2 else 0.0)
 out = {"leg": sys.argv[2], "passes": np_, "k_search_hbm_bytes_per_pass": bench.calibrated_traffic(tot_f / np_, tot_w / np_, wide),
        "uncalibrated_2xFETCH_plus_WRITE_bytes_per_pass": (2.0 * tot_f + tot_w) * 1024.0 / np_,
-       "FETCH_SIZE_KiB_per_pass": tot_f / np_, "WRITE_SIZE_KiB_per_pass": tot_w / np_, "wide_read_bytes_per_pass": wide,
+       "FETCH_SIZE_KiB_per_pass": tot_f / np_, "WRITE_SIZE_KiB_per_pass": tot_w / np_, "wide_read_bytes_per_pass": wide, "wide_reads_are": "record bytes x tot_recs_read (records the kernel read)",
        "algorithmic_bytes_per_pass": leg["roofline"]["algorithmic_bytes_per_launch"] * leg["roofline"]["launches_per_step"],
        "frames_per_pass": leg["frames_per_step"],
        "search_ms_under_pmc": leg["search_ms"], "source_hash": bench.kernel_source_hash(),
