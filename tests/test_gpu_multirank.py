@@ -36,6 +36,18 @@ def _run(cmd, env, timeout):
     return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 
+def _free_this_process():
+    """Several ranks are about to share this box's ONE GPU with the pytest process itself, which by now holds what earlier tests left
+    cached on the device - the arena slab of the last decoder (most of the HBM: jd_release_cached_memory) and torch's allocator pool.
+    On a node with a GPU per rank none of this matters; here the ranks would size their arenas on what is left and run out."""
+    import gc
+    import torch
+    from juicer_amd import capi
+    gc.collect()
+    capi.lib().jd_release_cached_memory(0)
+    torch.cuda.empty_cache()
+
+
 def _port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -43,6 +55,7 @@ def _port():
 
 
 def test_two_ranks_gather_hip_hypotheses(built):
+    _free_this_process()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "tests", "mr_worker.py")]
@@ -57,6 +70,7 @@ def test_bench_spawns_its_own_ranks(built):
     headline's own path: batches through the resident slot kernel, nine announced ahead, the steps' 1-best records in ONE
     all_gather behind jd_dec_quiesce at the end of the timed region; --gather-every 1 keeps a collective per step and
     two batches in flight."""
+    _free_this_process()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--utts-per-gpu", "6",
@@ -79,6 +93,7 @@ def test_bench_spawns_its_own_ranks(built):
 def test_bench_strong_scaling_mode(built):
     """`--total-utts N` (BASELINE.json configs[2] with N = 512): ONE batch dealt over the ranks by length; every
     utterance comes back exactly once and the line says "strong"."""
+    _free_this_process()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--total-utts", "11",
@@ -94,6 +109,7 @@ def test_bench_eight_ranks_share_one_gpu(built):
     announced ahead, ONE all_gather of all steps' records behind jd_dec_quiesce - with all eight ranks on this box's one GPU over gloo
     (JD_BENCH_SHARE_GPU=1: the numbers mean nothing, eight processes' kernels, arenas and collectives side by side do).  What the
     driver's first real 8-GPU run will do is this, with RCCL in gloo's place."""
+    _free_this_process()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--utts-per-gpu", "4",
@@ -111,6 +127,7 @@ def test_bench_falls_back_on_every_rank_when_one_pipeline_fails(built, phase):
     """One rank's resident pipeline fails (forced: JD_BENCH_FAIL=rank:phase - at decoder creation, while the pipeline fills, inside the
     timed region).  The other ranks must not be left waiting in a collective: the failing rank keeps taking part (empty records), ALL
     ranks agree that the attempt is void and repeat the measurement with two batches in flight; the line says so."""
+    _free_this_process()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JD_BENCH_SHARE_GPU="1", JD_BENCH_FAIL="1:" + phase)
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--utts-per-gpu", "6",

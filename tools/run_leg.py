@@ -51,6 +51,13 @@ elif which == "c512pipe":                                             # (the 512
 elif which == "c512slot":                                             # (one launch of the slot kernel, a workgroup per utterance: what the counters see of jd_slot.h)
     a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
     out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, 512 streams: k_slot_batch", a, n, f, 150.0, 0, dev, passes=passes, max_streams=512)
+elif which == "c512slotfast":                                         # (... with the scoring option: what the dense table's cost is worth where scoring and search alternate)
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
+    out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, 512 streams: k_slot_batch, JD_SCORE_FAST", a, n, f, 150.0, 0, dev, passes=passes, max_streams=512,
+                        scoring="fast")
+elif which == "c2pipefast":
+    a, n, f, _ = synth.config_c2(seed=0, n_utts=64)
+    out = bench.run_leg("configs[1], JD_SCORE_FAST", a, n, f, 150.0, 0, dev, passes=max(passes, 24), pipe=(9, 256), scoring="fast")
 elif which == "c512":
     a, n, f, _ = synth.config_c2(seed=0, n_utts=512)
     out = bench.run_leg("configs[2]'s 512-utterance batch on one GPU, 128 streams", a, n, f, 150.0, 0, dev, passes=passes, pmc_leg="c512", max_streams=128)
