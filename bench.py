@@ -177,7 +177,8 @@ def kernel_source_hash():
     measurement of ONE build; it is reported only while the sources are the ones it was taken on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("jd_search.h", "jd_lazy.h", "jd_gmm.h", "jd_gc.h", "jd_resident.h", "jd_slot.h", "jd_host_resident.h", "jd_device.hip"):
+    for f in ("jd_search.h", "jd_lazy.h", "jd_gmm.h", "jd_gc.h", "jd_resident.h", "jd_slot.h", "jd_host_resident.h", "jd_host_scoring.h",
+              "jd_host_launch.h", "jd_host_stream.h", "jd_device.hip"):
         h.update(open(os.path.join(ROOT, "juicer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -20,7 +20,7 @@ BATCH_TEST = os.path.join(HERE, "jd_batch_test")
 BATCH_SRC = os.path.join(CSRC, "jd_batch_test.cpp")
 SOURCES = [os.path.join(CSRC, "jd_host.cpp"), os.path.join(CSRC, "jd_device.hip"), os.path.join(CSRC, "jd_multi.cpp"),
            os.path.join(CSRC, "jd_compose.hip"), os.path.join(CSRC, "jd_broker.cpp")]
-HEADERS_EXTRA = [os.path.join(CSRC, f) for f in ("jd_search.h", "jd_lazy.h", "jd_gmm.h", "jd_gc.h", "jd_resident.h", "jd_slot.h", "jd_host_resident.h")]
+HEADERS_EXTRA = [os.path.join(CSRC, f) for f in ("jd_search.h", "jd_lazy.h", "jd_gmm.h", "jd_gc.h", "jd_resident.h", "jd_slot.h", "jd_host_resident.h", "jd_host_scoring.h", "jd_host_launch.h", "jd_host_stream.h")]
 HEADERS = [os.path.join(CSRC, "jd_internal.h"), os.path.join(ROOT, "include", "juicer_amd.h"),
            os.path.join(ROOT, "include", "juicer_amd_decoder.hpp"), BATCH_SRC]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
