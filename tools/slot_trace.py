@@ -21,9 +21,12 @@ ap.add_argument("--utts", type=int, default=64)
 ap.add_argument("--beam", type=float, default=150.0)
 ap.add_argument("--max-hyps", type=int, default=0)
 ap.add_argument("--no-trace", action="store_true")
+ap.add_argument("--scoring", choices=("exact", "fast"), default="exact")
 args = ap.parse_args()
 am, net, feats, _ = synth.config_c2(n_utts=args.utts)
 dec = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), main_beam=args.beam, max_hyps=args.max_hyps, max_streams=args.slots)
+if args.scoring == "fast":
+    dec.set_scoring(capi.SCORE_FAST)
 dec.set_pipeline(capi.FLOW_RESIDENT, args.depth + 1, args.slots)
 offs = np.zeros(len(feats) + 1, dtype=np.int64)
 offs[1:] = np.cumsum([f.shape[0] for f in feats])
