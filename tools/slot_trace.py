@@ -68,3 +68,8 @@ if not args.no_trace:
         tot += us.mean()
         print("  %-11s mean %7.2f us/frame   min %7.2f   max %7.2f" % (n, us.mean(), us.min(), us.max()))
     print("  sum %.2f us/frame over %d slots that ran frames" % (tot, len(used)))
+    if used[:, 15].sum() > 0:                                          # a SLOT_FINE build: wave 0's passes over record chunks, every stage waited for
+        n = used[:, 15].astype(np.float64).sum()
+        for k, nm in enumerate(["record trip", "key trip", "item trip", "arithmetic", "store issue", "store drain"]):
+            print("  fine: %-12s %6.3f us per pass" % (nm, used[:, 9 + k].sum() / 100.0 / n))
+        print("  fine: %.1f record passes of wave 0 per frame" % (n / f.sum()))
