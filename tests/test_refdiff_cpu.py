@@ -15,6 +15,7 @@ Skipped where /root/reference is absent (the GPU box).  The bench workloads at t
 import os
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -122,3 +123,35 @@ def test_two_thread_decoder(driver):
     if r.get("error"):
         pytest.skip("the reference's two-thread decoder did not finish: %s" % r["error"])
     _clean(r)
+
+
+@pytest.mark.parametrize("cfg", ["small", "mixed", "c2"])
+def test_model_tables_prepared_by_the_reference(driver, cfg):
+    """Model preparation, the other half of the path's set-up: the PRODUCT's tables (csrc/jd_host.cpp: jd_am_create_htk - what the HIP kernels
+    read) and the oracle's (oracle/juicer_oracle.c) against what the reference's OWN code makes of the same models: HTKModels::readBinary +
+    HTKFlatModels::init (src/HTKFlatModels.cpp:94-177: det = gconst + log weight, inverse variances by a double division) and its IModels view
+    of the HMMs (log transition matrices, SEIndex ranges, tee log-probabilities, src/HTKModels.cpp:581-593).  Bit for bit.  (The JMBI file
+    carries the HTK-level parameters and two derived arrays this build computed - sumLogVarPlusNObsLog2Pi, logCompWeights; the sum, the
+    inverse variances and everything about transitions are the reference's arithmetic.)"""
+    from juicer_amd import capi, synth
+    from oracle.oracle import OracleAM
+    am = {"small": lambda: synth.config_small(n_utts=1)[0], "mixed": lambda: synth.config_mixed(n_utts=1)[0],
+          "c2": lambda: synth.make_models(0, n_gmm=300, n_hmm=800, n_mix=8, n_tm=48, sep=1.0)}[cfg]()
+    ref = refdiff.reference_model_tables(am)
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    for who, M in (("product", capi.Models.from_htk(am)), ("oracle", OracleAM(am))):
+        det, mean, ivar = M.flat()
+        trP, se, tee = M.trans()
+        assert ref["det"].shape == det.shape and np.array_equal(ref["n_mix"], np.asarray(am.n_mix, np.int32)), who
+        for g in range(det.shape[0]):
+            k = int(ref["n_mix"][g])                       # (beyond a state's mixtures the tables hold padding of each side's own)
+            assert np.array_equal(bits(ref["det"][g, :k]), bits(det[g, :k])), (who, "det", g)
+            assert np.array_equal(bits(ref["mean"][g, :k]), bits(mean[g, :k])), (who, "mean", g)
+            assert np.array_equal(bits(ref["ivar"][g, :k]), bits(ivar[g, :k])), (who, "ivar", g)
+        assert np.array_equal(bits(ref["tee"]), bits(tee)), who
+        for h in range(len(ref["trans"])):
+            n, tm = int(ref["hmm_n"][h]), int(am.hmm_tm[h])
+            assert n == int(am.hmm_nstates[h])
+            assert np.array_equal(bits(ref["trans"][h]), bits(trP[tm, :n, :n])), (who, "trP", h)
+            # (state 0 has no predecessor and nobody asks for its range: the reference leaves whatever its loop computed last there)
+            assert np.array_equal(ref["se"][h][1:], se[tm, 1:n]), (who, "SEIndex", h)

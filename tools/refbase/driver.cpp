@@ -15,6 +15,7 @@
 //     feats=<file>                             {n_utts, D} then per utterance {T, T x D floats}
 //     threading=0|1  main= start= end= word= maxhyps= lmscale= inspen=
 //     pti=<frames>                             PARTIAL_DECODING: setPartialDecodeOptions (src/WFSTDecoderLite.cpp:892-896)
+//     dumpmodels=<file>                        the reference's prepared model tables (without feats=: nothing is decoded)
 //   One JSON line per utterance: the DecHyp chain, the reference's five statistics (its protected totals, read through a
 //   subclass - src/WFSTDecoderLite.h:150-154), the frames of the partial paths it recovered.
 #include <cassert>
@@ -53,6 +54,38 @@ template <class Base> struct Probe : public Base {
     }
 };
 
+// ... and HTKFlatModels keeps its flat parameter tables protected (src/HTKFlatModels.h:42-58): dumpmodels=<file> writes what the
+// REFERENCE's own init() made of the loaded models (src/HTKFlatModels.cpp:94-177: fDets, fMeans, fVars = INVERSE variances) and what its
+// IModels interface says about every HMM (states, tee log-probability, log transition matrix, SEIndex: src/Models.h:57-64)
+struct FlatProbe : public HTKFlatModels {
+    int dump(const char *fn)
+    {
+        FILE *f = fopen(fn, "wb");
+        if (!f) return 1;
+        int nmax = fnMixtures4 > 0 ? fnGaussians / nMixtures : 0;
+        int hdr[4] = {nMixtures, nmax, vecSize, getNumHMMs()};
+        fwrite(hdr, 4, 4, f);
+        for (int g = 0; g < nMixtures; ++g) {
+            int nc = fMixtures[g].compNum;
+            fwrite(&nc, 4, 1, f);
+            fwrite(fDet(g), sizeof(real), (size_t)nmax, f);
+            fwrite(fMean(g), sizeof(real), (size_t)nmax * fvecSize4, f);
+            fwrite(fVar(g), sizeof(real), (size_t)nmax * fvecSize4, f);
+        }
+        for (int h = 0; h < getNumHMMs(); ++h) {
+            int n = getNumStates(h);
+            real tee = getTeeLogProb(h);
+            fwrite(&n, 4, 1, f); fwrite(&tee, sizeof(real), 1, f);
+            real **tm = getTransMat(h);
+            SEIndex *se = getSEIndex(h);
+            for (int i = 0; i < n; ++i) fwrite(tm[i], sizeof(real), (size_t)n, f);
+            for (int i = 0; i < n; ++i) { short v[2] = {se[i].start, se[i].end}; fwrite(v, 2, 2, f); }
+        }
+        fclose(f);
+        return 0;
+    }
+};
+
 static void *gmm_thread(void *arg)
 {
     ((HTKFlatModelsThreading *)arg)->calcStates();                     // (src/juicer.cpp:79-85)
@@ -69,7 +102,7 @@ int main(int argc, char **argv)
     }
     auto S = [&](const char *k, const char *d) { return kv.count(k) ? kv[k] : std::string(d); };
     auto F = [&](const char *k, double d) { return kv.count(k) ? atof(kv[k].c_str()) : d; };
-    if (!kv.count("models") || !kv.count("feats") || (!kv.count("net") && !kv.count("fsm"))) {
+    if (!kv.count("models") || (!kv.count("dumpmodels") && (!kv.count("feats") || (!kv.count("net") && !kv.count("fsm"))))) {
         fprintf(stderr, "usage: refbase_driver models=.. (net=.. | fsm=.. insyms=.. outsyms=..) feats=.. [threading= main= start= end= word= maxhyps= lmscale= inspen= pti=]\n");
         return 2;
     }
@@ -77,9 +110,14 @@ int main(int argc, char **argv)
     const float mainBeam = F("main", 0), startBeam = F("start", 0), endBeam = F("end", 0), wordBeam = F("word", 0);
     const int maxHyps = (int)F("maxhyps", 0), pti = (int)F("pti", 0);
     const float lmScale = F("lmscale", 1), insPen = F("inspen", 0);
-    HTKFlatModels *models = threading ? new HTKFlatModelsThreading() : new HTKFlatModels();
+    FlatProbe *probe = threading ? NULL : new FlatProbe();
+    HTKFlatModels *models = threading ? (HTKFlatModels *)new HTKFlatModelsThreading() : (HTKFlatModels *)probe;
     models->setBlockSize(5);                                           // (before the models are there: HTKFlatModels.cpp:308-313)
     models->readBinary(S("models", "").c_str());
+    if (kv.count("dumpmodels")) {
+        if (!probe || probe->dump(kv["dumpmodels"].c_str())) { fprintf(stderr, "refbase_driver: dumpmodels failed\n"); return 1; }
+        if (!kv.count("feats")) { fflush(stdout); _exit(0); }
+    }
     pthread_t th;
     if (threading && pthread_create(&th, NULL, gmm_thread, models)) { fprintf(stderr, "pthread_create failed\n"); return 1; }
     WFSTNetwork *net;

@@ -170,3 +170,36 @@ def diff_case(name, am, net, feats, beams=None, loader="jwnt", lm_scale=1.0, ins
         out.update(partial_interval=pti, identical_partial=part_ok)
     out["ok"] = hyp_ok == len(feats) and st_ok == len(feats) and (pti == 0 or part_ok == len(feats))
     return out
+
+
+def reference_model_tables(am, workdir=None):
+    """What the REFERENCE's own code makes of the models: HTKModels::readBinary on the file this build's jd_am_save_jmbi writes, then
+    HTKFlatModels::init (src/HTKFlatModels.cpp:94-177) - the flat tables it scores with (det = gconst + log weight, means, INVERSE
+    variances) - and its IModels view of every HMM (log transition matrix, SEIndex, tee log-probability).  Returns dict(det [G][M],
+    mean [G][M][D], ivar [G][M][D], n_mix [G], hmm_n [H], tee [H], trans: list of [n][n] arrays, se: list of [n][2])."""
+    from juicer_amd import capi
+    exe = build()
+    tmp = workdir or tempfile.mkdtemp(prefix="refmodels_", dir=BUILD)
+    os.makedirs(tmp, exist_ok=True)
+    jmbi, dump = os.path.join(tmp, "models.jmbi"), os.path.join(tmp, "models.dump")
+    capi.Models.from_htk(am).save_jmbi(jmbi)
+    subprocess.check_call([exe, "models=" + jmbi, "dumpmodels=" + dump], stdout=subprocess.DEVNULL)
+    raw = open(dump, "rb").read()
+    G, M, D, H = struct.unpack_from("<4i", raw, 0)
+    o = 16
+    det = np.zeros((G, M), np.float32); mean = np.zeros((G, M, D), np.float32); ivar = np.zeros((G, M, D), np.float32)
+    n_mix = np.zeros(G, np.int32)
+    for g in range(G):
+        n_mix[g] = struct.unpack_from("<i", raw, o)[0]; o += 4
+        det[g] = np.frombuffer(raw, np.float32, M, o); o += 4 * M
+        mean[g] = np.frombuffer(raw, np.float32, M * D, o).reshape(M, D); o += 4 * M * D
+        ivar[g] = np.frombuffer(raw, np.float32, M * D, o).reshape(M, D); o += 4 * M * D
+    hmm_n = np.zeros(H, np.int32); tee = np.zeros(H, np.float32); trans, se = [], []
+    for h in range(H):
+        hmm_n[h] = struct.unpack_from("<i", raw, o)[0]; o += 4
+        tee[h] = struct.unpack_from("<f", raw, o)[0]; o += 4
+        n = int(hmm_n[h])
+        trans.append(np.frombuffer(raw, np.float32, n * n, o).reshape(n, n).copy()); o += 4 * n * n
+        se.append(np.frombuffer(raw, np.int16, 2 * n, o).reshape(n, 2).copy()); o += 4 * n
+    assert o == len(raw), (o, len(raw))
+    return dict(det=det, mean=mean, ivar=ivar, n_mix=n_mix, hmm_n=hmm_n, tee=tee, trans=trans, se=se)
