@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools", "refbase"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import refdiff                                                   # noqa: E402
 from juicer_amd import synth                                    # noqa: E402
-from make_golden import input_digest                            # noqa: E402
+from make_golden import digest, input_digest                    # noqa: E402
 
 BEAMS = [dict(), dict(main_beam=200.0), dict(main_beam=150.0, end_beam=100.0, word_beam=80.0, start_beam=120.0), dict(main_beam=150.0, max_hyps=200),
          dict(max_hyps=300), dict(main_beam=120.0, end_beam=90.0, word_beam=70.0, start_beam=100.0, max_hyps=150)]
@@ -36,6 +36,7 @@ CASES = {
     "configs1_first8": (lambda: synth.config_c2(seed=0, n_utts=8), [dict(main_beam=150.0), dict(main_beam=150.0, max_hyps=6000)]),
 }
 f32hex = lambda v: np.float32(v).tobytes().hex()
+LL_FRAMES = 48
 
 
 def main():
@@ -44,6 +45,9 @@ def main():
     for name, (mk, beams) in CASES.items():
         am, net, feats, _ = mk()
         case = {"input_sha256": input_digest(am, net, feats), "n_arcs": int(net.n_arcs), "runs": []}
+        # the reference's own HTKFlatModels::calcOutput for every tied state of the first frames of utterance 0 (digest of the float bits)
+        ll = refdiff.reference_log_likelihoods(am, feats[0], LL_FRAMES)
+        case["ll_frames"] = int(ll.shape[0]); case["ll_sha256"] = digest(ll); case["ll_first"] = [f32hex(v) for v in ll[0, :8]]
         for kw in beams:
             rows, (rc, err, _) = refdiff.run_reference(am, net, feats, kw)
             assert rc == 0 and len(rows) == len(feats), (name, kw, rc, err)

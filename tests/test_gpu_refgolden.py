@@ -40,3 +40,15 @@ def test_hip_path_equals_the_reference_built_vectors(built, monkeypatch, case, s
             checked += 1
         gd.close()
     assert checked >= 6 and order_dependent == 0, (checked, order_dependent)
+
+
+@pytest.mark.parametrize("case", ["toy", "small", "mixed", "c2_small", "configs1_first8"])
+def test_scoring_kernel_equals_the_reference_built_log_likelihoods(built, case):
+    """the companion kernel's table cells against the reference's own HTKFlatModels::calcOutput (digest of the float bits in the golden file)"""
+    import numpy as np
+    import make_golden
+    from juicer_amd import capi
+    g, am, net, feats = load_case(case)
+    ll = capi.Models.from_htk(am).score_frames(feats[0][:g["ll_frames"]])
+    assert [np.float32(v).tobytes().hex() for v in ll[0, :8]] == g["ll_first"]
+    assert make_golden.digest(ll) == g["ll_sha256"]

@@ -51,3 +51,15 @@ def test_oracle_equals_the_reference_built_vectors(built, case):
                 assert int(o.stats[k]) == want["stats"][k], (case, run["beams"], u, k)
             n += 1
     assert n >= 6
+
+
+@pytest.mark.parametrize("case", ["toy", "small", "mixed", "c2_small", "configs1_first8"])
+def test_oracle_scoring_equals_the_reference_built_log_likelihoods(built, case):
+    """HTKFlatModels::calcOutput (calcGMMOutput + logAdd, src/HTKFlatModels.cpp:202-293) run by the reference's own object code on the first
+    frames of utterance 0, every tied state: the golden file holds a digest of the float bits"""
+    import make_golden
+    from oracle.oracle import OracleAM
+    g, am, net, feats = load_case(case)
+    ll = OracleAM(am).score_frames(feats[0][:g["ll_frames"]])
+    assert [np.float32(v).tobytes().hex() for v in ll[0, :8]] == g["ll_first"]
+    assert make_golden.digest(ll) == g["ll_sha256"]

@@ -16,6 +16,7 @@
 //     threading=0|1  main= start= end= word= maxhyps= lmscale= inspen=
 //     pti=<frames>                             PARTIAL_DECODING: setPartialDecodeOptions (src/WFSTDecoderLite.cpp:892-896)
 //     dumpmodels=<file>                        the reference's prepared model tables (without feats=: nothing is decoded)
+//     dumpll=<file> llframes=<n>               the reference's log-likelihoods of every tied state, first frames of the first utterance
 //   One JSON line per utterance: the DecHyp chain, the reference's five statistics (its protected totals, read through a
 //   subclass - src/WFSTDecoderLite.h:150-154), the frames of the partial paths it recovered.
 #include <cassert>
@@ -23,6 +24,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +60,7 @@ template <class Base> struct Probe : public Base {
 // REFERENCE's own init() made of the loaded models (src/HTKFlatModels.cpp:94-177: fDets, fMeans, fVars = INVERSE variances) and what its
 // IModels interface says about every HMM (states, tee log-probability, log transition matrix, SEIndex: src/Models.h:57-64)
 struct FlatProbe : public HTKFlatModels {
+    int nTiedStates() { return nGMMs; }
     int dump(const char *fn)
     {
         FILE *f = fopen(fn, "wb");
@@ -102,7 +105,8 @@ int main(int argc, char **argv)
     }
     auto S = [&](const char *k, const char *d) { return kv.count(k) ? kv[k] : std::string(d); };
     auto F = [&](const char *k, double d) { return kv.count(k) ? atof(kv[k].c_str()) : d; };
-    if (!kv.count("models") || (!kv.count("dumpmodels") && (!kv.count("feats") || (!kv.count("net") && !kv.count("fsm"))))) {
+    if (!kv.count("models") || (!kv.count("dumpmodels") && !kv.count("dumpll") && (!kv.count("feats") || (!kv.count("net") && !kv.count("fsm")))) ||
+        (kv.count("dumpll") && !kv.count("feats"))) {
         fprintf(stderr, "usage: refbase_driver models=.. (net=.. | fsm=.. insyms=.. outsyms=..) feats=.. [threading= main= start= end= word= maxhyps= lmscale= inspen= pti=]\n");
         return 2;
     }
@@ -117,6 +121,26 @@ int main(int argc, char **argv)
     if (kv.count("dumpmodels")) {
         if (!probe || probe->dump(kv["dumpmodels"].c_str())) { fprintf(stderr, "refbase_driver: dumpmodels failed\n"); return 1; }
         if (!kv.count("feats")) { fflush(stdout); _exit(0); }
+    }
+    if (kv.count("dumpll")) {
+        // the reference's own log-likelihoods: HTKFlatModels::newFrame + calcOutput(g) (src/HTKFlatModels.cpp:202-293: calcGMMOutput's
+        // five-frame blocks, logAdd) for every tied state of the first `llframes` frames of the first utterance -> float32 [frames][G]
+        FILE *ff = fopen(S("feats", "").c_str(), "rb"), *fo = fopen(kv["dumpll"].c_str(), "wb");
+        int nu = 0, D = 0, T = 0;
+        if (!ff || !fo || fread(&nu, 4, 1, ff) != 1 || fread(&D, 4, 1, ff) != 1 || fread(&T, 4, 1, ff) != 1) return 1;
+        std::vector<float> x((size_t)T * D);
+        if (fread(x.data(), 4, x.size(), ff) != x.size()) return 1;
+        std::vector<float *> rows((size_t)T);
+        for (int t = 0; t < T; ++t) rows[(size_t)t] = x.data() + (size_t)t * D;
+        const int nf = std::min(T, (int)F("llframes", 32)), G = probe ? probe->nTiedStates() : 0;
+        int hdr[2] = {nf, G};
+        fwrite(hdr, 4, 2, fo);
+        for (int t = 0; t < nf; ++t) {
+            models->newFrame(t, &rows[(size_t)t], std::min(20, T - t));
+            for (int g = 0; g < G; ++g) { const float v = models->calcOutput(g); fwrite(&v, 4, 1, fo); }
+        }
+        fclose(fo); fclose(ff);
+        fflush(stdout); _exit(0);
     }
     pthread_t th;
     if (threading && pthread_create(&th, NULL, gmm_thread, models)) { fprintf(stderr, "pthread_create failed\n"); return 1; }

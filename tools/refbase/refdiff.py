@@ -203,3 +203,19 @@ def reference_model_tables(am, workdir=None):
         se.append(np.frombuffer(raw, np.int16, 2 * n, o).reshape(n, 2).copy()); o += 4 * n
     assert o == len(raw), (o, len(raw))
     return dict(det=det, mean=mean, ivar=ivar, n_mix=n_mix, hmm_n=hmm_n, tee=tee, trans=trans, se=se)
+
+
+def reference_log_likelihoods(am, feats0, n_frames=32, workdir=None):
+    """The reference's own HTKFlatModels::calcOutput (calcGMMOutput + logAdd, src/HTKFlatModels.cpp:202-293) for every tied state of the
+    first n_frames frames of one utterance: float32 [frames][n_gmm]."""
+    from juicer_amd import capi
+    exe = build()
+    tmp = workdir or tempfile.mkdtemp(prefix="refll_", dir=BUILD)
+    os.makedirs(tmp, exist_ok=True)
+    jmbi, featf, dump = (os.path.join(tmp, n) for n in ("models.jmbi", "feats.bin", "ll.dump"))
+    capi.Models.from_htk(am).save_jmbi(jmbi)
+    write_feats(featf, [feats0], am.D)
+    subprocess.check_call([exe, "models=" + jmbi, "feats=" + featf, "dumpll=" + dump, "llframes=%d" % n_frames], stdout=subprocess.DEVNULL)
+    raw = open(dump, "rb").read()
+    nf, G = struct.unpack_from("<2i", raw, 0)
+    return np.frombuffer(raw, np.float32, nf * G, 8).reshape(nf, G).copy()
