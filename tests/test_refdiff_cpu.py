@@ -155,3 +155,29 @@ def test_model_tables_prepared_by_the_reference(driver, cfg):
             assert np.array_equal(bits(ref["trans"][h]), bits(trP[tm, :n, :n])), (who, "trP", h)
             # (state 0 has no predecessor and nobody asks for its range: the reference leaves whatever its loop computed last there)
             assert np.array_equal(ref["se"][h][1:], se[tm, 1:n]), (who, "SEIndex", h)
+
+
+@pytest.mark.parametrize("cfg", ["small", "c2"])
+def test_network_loaded_by_the_reference(driver, cfg):
+    """The static graph, row A1 of the path's scope: the PRODUCT's loaders - jd_net_load_fsm on the very text + symbol files, jd_net_load_jwnt
+    on the very binary file, jd_net_create_arcs from the arrays - against what the reference's own WFSTNetwork makes of them (text
+    constructor src/WFSTNetwork.cpp:371-616 with lmScale / insPenalty applied by the reference; readBinary :1228-1365): states, the
+    initial state, every arc {to, in, out} in the reference's order, every weight and final weight bit for bit."""
+    from juicer_amd import capi, synth
+    am, net, _, _ = synth.config_small(n_utts=1) if cfg == "small" else synth.config_c2(seed=0, n_utts=1, target_arcs=60_000, n_gmm=300, n_hmm=800,
+                                                                                        n_mix=8, n_words=500)
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    for loader, scale, pen in (("fsm", 1.0, 0.0), ("fsm", 7.5, -1.25), ("jwnt", 1.0, 0.0), ("jwnt", 7.5, -1.25)):
+        ref, files = refdiff.reference_network_tables(am, net, loader, scale, pen)
+        mine = [capi.Network.from_fsm_file(files[0], files[1], files[2], scale, pen) if loader == "fsm" else capi.Network.from_jwnt_file(files[0], scale, pen)]
+        if loader == "fsm" or (scale == 1.0 and pen == 0.0):            # (a JWNT round trip divides by the scale and multiplies again: only the loader of that file is held to it)
+            mine.append(capi.Network.from_synth(net, scale, pen))
+        for gnet in mine:
+            c = gnet.csr()
+            assert gnet.n_states == ref["n_states"] and gnet.n_arcs == ref["to"].shape[0] and gnet.init_state == ref["init"], (loader, scale)
+            assert np.array_equal(c["row_ptr"], ref["row_ptr"]) and np.array_equal(c["to"], ref["to"]), (loader, scale)
+            assert np.array_equal(c["ilab"], ref["ilab"]) and np.array_equal(c["olab"], ref["olab"]), (loader, scale)
+            assert np.array_equal(bits(c["w"]), bits(ref["w"])), (loader, scale, pen)
+            fin = ~np.isnan(ref["fin_w"])
+            assert np.array_equal(np.isfinite(c["fin_w"]), fin), (loader, scale)       # (this build marks "not final" with +inf)
+            assert np.array_equal(bits(c["fin_w"][fin]), bits(ref["fin_w"][fin])), (loader, scale, pen)

@@ -16,6 +16,7 @@
 //     threading=0|1  main= start= end= word= maxhyps= lmscale= inspen=
 //     pti=<frames>                             PARTIAL_DECODING: setPartialDecodeOptions (src/WFSTDecoderLite.cpp:892-896)
 //     dumpmodels=<file>                        the reference's prepared model tables (without feats=: nothing is decoded)
+//     dumpnet=<file>                           the network as the reference's loader left it (without feats=: nothing is decoded)
 //     dumpll=<file> llframes=<n>               the reference's log-likelihoods of every tied state, first frames of the first utterance
 //   One JSON line per utterance: the DecHyp chain, the reference's five statistics (its protected totals, read through a
 //   subclass - src/WFSTDecoderLite.h:150-154), the frames of the partial paths it recovered.
@@ -105,8 +106,8 @@ int main(int argc, char **argv)
     }
     auto S = [&](const char *k, const char *d) { return kv.count(k) ? kv[k] : std::string(d); };
     auto F = [&](const char *k, double d) { return kv.count(k) ? atof(kv[k].c_str()) : d; };
-    if (!kv.count("models") || (!kv.count("dumpmodels") && !kv.count("dumpll") && (!kv.count("feats") || (!kv.count("net") && !kv.count("fsm")))) ||
-        (kv.count("dumpll") && !kv.count("feats"))) {
+    if (!kv.count("models") || (!kv.count("dumpmodels") && !kv.count("dumpll") && !kv.count("dumpnet") && (!kv.count("feats") || (!kv.count("net") && !kv.count("fsm")))) ||
+        (kv.count("dumpll") && !kv.count("feats")) || (kv.count("dumpnet") && !kv.count("net") && !kv.count("fsm"))) {
         fprintf(stderr, "usage: refbase_driver models=.. (net=.. | fsm=.. insyms=.. outsyms=..) feats=.. [threading= main= start= end= word= maxhyps= lmscale= inspen= pti=]\n");
         return 2;
     }
@@ -150,6 +151,28 @@ int main(int argc, char **argv)
     else {
         net = new WFSTNetwork(lmScale, insPen);
         net->readBinary(kv["net"].c_str());
+    }
+    if (kv.count("dumpnet")) {
+        // what the REFERENCE's loader made of the network (text constructor or readBinary): per state its transitions in the order
+        // getTransitions walks them - {to, in, out, weight} - and the final weight (NaN: not final); src/WFSTNetwork.h:126-165
+        FILE *fo = fopen(kv["dumpnet"].c_str(), "wb");
+        if (!fo) return 1;
+        const int ns = net->getNumStates();
+        int hdr[3] = {ns, net->getNumTransitions(), net->getInitState()};
+        fwrite(hdr, 4, 3, fo);
+        for (int q = 0; q < ns; ++q) {
+            const int nt = net->getNumTransitionsOfOneState(q);
+            float fw = net->isFinalState(q) ? net->getFinalStateWeight(q) : __builtin_nanf("");
+            fwrite(&nt, 4, 1, fo); fwrite(&fw, 4, 1, fo);
+            for (int k = 0; k < nt; ++k) {
+                const WFSTTransition *t = net->getOneTransition(net->getTransID(q, k));
+                int v[3] = {t->toState, t->inLabel, t->outLabel};
+                float w = t->weight;
+                fwrite(v, 4, 3, fo); fwrite(&w, 4, 1, fo);
+            }
+        }
+        fclose(fo);
+        if (!kv.count("feats")) { fflush(stdout); _exit(0); }
     }
     Probe<WFSTDecoderLite> *d1 = threading ? NULL : new Probe<WFSTDecoderLite>(net, models, startBeam, mainBeam, endBeam, wordBeam, maxHyps);
     Probe<WFSTDecoderLiteThreading> *d2 = threading ? new Probe<WFSTDecoderLiteThreading>(net, models, startBeam, mainBeam, endBeam, wordBeam, maxHyps) : NULL;

@@ -219,3 +219,43 @@ def reference_log_likelihoods(am, feats0, n_frames=32, workdir=None):
     raw = open(dump, "rb").read()
     nf, G = struct.unpack_from("<2i", raw, 0)
     return np.frombuffer(raw, np.float32, nf * G, 8).reshape(nf, G).copy()
+
+
+def reference_network_tables(am, net, loader="fsm", lm_scale=1.0, ins_penalty=0.0, workdir=None):
+    """What the REFERENCE's own loader makes of a network - the TEXT constructor (src/WFSTNetwork.cpp:371-616: weights negated, scaled,
+    the insertion penalty added by the reference itself) or readBinary of the JWNT file this build writes: dict(n_states, init, row_ptr,
+    to, ilab, olab, w, fin_w (NaN: not final)), arcs in the order the reference's getTransitions walks them.  Also returns the files'
+    paths (fsm, insyms, outsyms or jwnt) so that the product's loaders can be given the very same files."""
+    from juicer_amd import capi
+    from juicer_amd import io as jio
+    exe = build()
+    tmp = workdir or tempfile.mkdtemp(prefix="refnet_", dir=BUILD)
+    os.makedirs(tmp, exist_ok=True)
+    jmbi, dump = os.path.join(tmp, "models.jmbi"), os.path.join(tmp, "net.dump")
+    capi.Models.from_htk(am).save_jmbi(jmbi)
+    if loader == "fsm":
+        files = tuple(os.path.join(tmp, n) for n in ("net.fsm", "in.syms", "out.syms"))
+        jio.write_fsm(files[0], net)
+        write_symbols(files[1], "m", int(am.n_hmm))
+        write_symbols(files[2], "w", int(max(1, np.max(net.olab) if net.n_arcs else 1)))
+        args = ["fsm=" + files[0], "insyms=" + files[1], "outsyms=" + files[2], "lmscale=%.9g" % lm_scale, "inspen=%.9g" % ins_penalty]
+    else:
+        files = (os.path.join(tmp, "net.jwnt"),)
+        # (writeBinary takes the penalty and the scale out again before it writes, src/WFSTNetwork.cpp:1106-1125; readBinary puts back
+        # the ones its constructor was given: the file holds unscaled weights whatever the writer's setting)
+        capi.Network.from_synth(net, lm_scale, ins_penalty).save_jwnt(files[0])
+        args = ["net=" + files[0], "lmscale=%.9g" % lm_scale, "inspen=%.9g" % ins_penalty]
+    subprocess.check_call([exe, "models=" + jmbi, "dumpnet=" + dump] + args, stdout=subprocess.DEVNULL)
+    raw = open(dump, "rb").read()
+    ns, na, init = struct.unpack_from("<3i", raw, 0)
+    o = 12
+    row_ptr = np.zeros(ns + 1, np.int32); fin_w = np.zeros(ns, np.float32)
+    to = np.zeros(na, np.int32); il = np.zeros(na, np.int32); ol = np.zeros(na, np.int32); w = np.zeros(na, np.float32)
+    k = 0
+    for q in range(ns):
+        nt = struct.unpack_from("<i", raw, o)[0]; fin_w[q] = struct.unpack_from("<f", raw, o + 4)[0]; o += 8
+        rec = np.frombuffer(raw, np.int32, 4 * nt, o).reshape(nt, 4); o += 16 * nt
+        to[k:k + nt] = rec[:, 0]; il[k:k + nt] = rec[:, 1]; ol[k:k + nt] = rec[:, 2]; w[k:k + nt] = rec[:, 3].copy().view(np.float32)
+        k += nt; row_ptr[q + 1] = k
+    assert k == na and o == len(raw), (k, na, o, len(raw))
+    return dict(n_states=ns, init=init, row_ptr=row_ptr, to=to, ilab=il, olab=ol, w=w, fin_w=fin_w), files
