@@ -181,3 +181,15 @@ def test_network_loaded_by_the_reference(driver, cfg):
             fin = ~np.isnan(ref["fin_w"])
             assert np.array_equal(np.isfinite(c["fin_w"]), fin), (loader, scale)       # (this build marks "not final" with +inf)
             assert np.array_equal(bits(c["fin_w"][fin]), bits(ref["fin_w"][fin])), (loader, scale, pen)
+
+
+@pytest.mark.parametrize("spm", [3, 5])
+def test_hybrid_models(driver, spm):
+    """Hybrid ANN / HMM scoring (row f4): HTKModels::Load(phonesList, priors, statesPerModel), src/HTKModels.cpp:74-218 - output = log posterior
+    - log prior (:481-512), one shared transition matrix - through the reference's plain HTKModels class (its HTKFlatModels never sets the
+    `currInput` its own hybrid branch reads, src/HTKFlatModels.cpp:196 / :295-306: with the flat class the reference itself cannot run this)."""
+    from juicer_amd import synth
+    am, net, feats, _ = synth.config_hybrid(seed=3 + spm, states_per_model=spm)
+    for kw in (dict(main_beam=200.0), dict(main_beam=150.0, max_hyps=100)):
+        r = _clean(refdiff.diff_case("hybrid", am, net, feats, kw, loader="fsm"))
+        assert r["hyps_found"] >= 1

@@ -9,7 +9,8 @@
 // init .. finish, 20 frames of look-ahead handed to processFrame, CPU time halved for the two-thread decoder.
 //
 //   refbase_driver key=value ...
-//     models=<file.jmbi>                       HTKModels::readBinary (the MMF text parser is generated code the image cannot make)
+//     models=<file.jmbi>                       HTKModels::readBinary (the MMF text parser is generated code the image cannot make), or
+//     phones=<list> priors=<file> spm=<n>      hybrid ANN / HMM models: HTKModels::Load(phonesList, priors, statesPerModel)
 //     net=<file.jwnt>                          WFSTNetwork::readBinary (src/WFSTNetwork.cpp:1228-1365), or
 //     fsm=<file.fsm> insyms=<file> outsyms=<file>   the TEXT constructor (src/WFSTNetwork.cpp:371-616)
 //     feats=<file>                             {n_utts, D} then per utterance {T, T x D floats}
@@ -106,7 +107,7 @@ int main(int argc, char **argv)
     }
     auto S = [&](const char *k, const char *d) { return kv.count(k) ? kv[k] : std::string(d); };
     auto F = [&](const char *k, double d) { return kv.count(k) ? atof(kv[k].c_str()) : d; };
-    if (!kv.count("models") || (!kv.count("dumpmodels") && !kv.count("dumpll") && !kv.count("dumpnet") && (!kv.count("feats") || (!kv.count("net") && !kv.count("fsm")))) ||
+    if ((!kv.count("models") && !kv.count("phones")) || (!kv.count("dumpmodels") && !kv.count("dumpll") && !kv.count("dumpnet") && (!kv.count("feats") || (!kv.count("net") && !kv.count("fsm")))) ||
         (kv.count("dumpll") && !kv.count("feats")) || (kv.count("dumpnet") && !kv.count("net") && !kv.count("fsm"))) {
         fprintf(stderr, "usage: refbase_driver models=.. (net=.. | fsm=.. insyms=.. outsyms=..) feats=.. [threading= main= start= end= word= maxhyps= lmscale= inspen= pti=]\n");
         return 2;
@@ -115,10 +116,21 @@ int main(int argc, char **argv)
     const float mainBeam = F("main", 0), startBeam = F("start", 0), endBeam = F("end", 0), wordBeam = F("word", 0);
     const int maxHyps = (int)F("maxhyps", 0), pti = (int)F("pti", 0);
     const float lmScale = F("lmscale", 1), insPen = F("inspen", 0);
-    FlatProbe *probe = threading ? NULL : new FlatProbe();
-    HTKFlatModels *models = threading ? (HTKFlatModels *)new HTKFlatModelsThreading() : (HTKFlatModels *)probe;
-    models->setBlockSize(5);                                           // (before the models are there: HTKFlatModels.cpp:308-313)
-    models->readBinary(S("models", "").c_str());
+    const bool hybrid = kv.count("phones") != 0;
+    FlatProbe *probe = (threading || hybrid) ? NULL : new FlatProbe();
+    IModels *models;
+    if (hybrid) {
+        // hybrid ANN / HMM models: HTKModels::Load(phonesList, priors, statesPerModel), src/HTKModels.cpp:74-218.  Through the plain HTKModels
+        // class: HTKFlatModels::newFrame never sets the `currInput` its own hybrid calcOutput reads (src/HTKFlatModels.cpp:196, 295-306)
+        HTKModels *hm = new HTKModels();
+        hm->Load(kv["phones"].c_str(), S("priors", "").c_str(), (int)F("spm", 5));
+        models = hm;
+    } else {
+        HTKFlatModels *fm = threading ? (HTKFlatModels *)new HTKFlatModelsThreading() : (HTKFlatModels *)probe;
+        fm->setBlockSize(5);                                           // (before the models are there: HTKFlatModels.cpp:308-313)
+        fm->readBinary(S("models", "").c_str());
+        models = fm;
+    }
     if (kv.count("dumpmodels")) {
         if (!probe || probe->dump(kv["dumpmodels"].c_str())) { fprintf(stderr, "refbase_driver: dumpmodels failed\n"); return 1; }
         if (!kv.count("feats")) { fflush(stdout); _exit(0); }
@@ -144,7 +156,7 @@ int main(int argc, char **argv)
         fflush(stdout); _exit(0);
     }
     pthread_t th;
-    if (threading && pthread_create(&th, NULL, gmm_thread, models)) { fprintf(stderr, "pthread_create failed\n"); return 1; }
+    if (threading && pthread_create(&th, NULL, gmm_thread, (HTKFlatModelsThreading *)models)) { fprintf(stderr, "pthread_create failed\n"); return 1; }
     WFSTNetwork *net;
     if (kv.count("fsm"))                                               // the text constructor: scales and negates the weights itself (:371-616)
         net = new WFSTNetwork(kv["fsm"].c_str(), S("insyms", "").c_str(), S("outsyms", "").c_str(), lmScale, insPen, REMOVEBOTH);

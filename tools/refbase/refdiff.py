@@ -89,15 +89,26 @@ def run_reference(am, net, feats, beams=None, loader="jwnt", lm_scale=1.0, ins_p
     tmp = workdir or tempfile.mkdtemp(prefix="refdiff_", dir=BUILD)
     os.makedirs(tmp, exist_ok=True)
     jmbi, featf = os.path.join(tmp, "models.jmbi"), os.path.join(tmp, "feats.bin")
-    capi.Models.from_htk(am).save_jmbi(jmbi)
-    write_feats(featf, feats, am.D)
-    args = ["models=" + jmbi, "feats=" + featf, "threading=%d" % int(bool(threading)), "main=%.9g" % beams.get("main_beam", 0.0),
+    if hasattr(am, "priors"):                                          # hybrid ANN / HMM models (synth.HybridAM): a phone list + a priors file
+        phones, priors = os.path.join(tmp, "phones.lst"), os.path.join(tmp, "priors.txt")
+        with open(phones, "w") as f:
+            f.write("".join("p%d\n" % i for i in range(len(am.priors))))
+        with open(priors, "w") as f:
+            f.write("".join("%.9g\n" % float(v) for v in am.priors))
+        margs = ["phones=" + phones, "priors=" + priors, "spm=%d" % am.states_per_model]
+        D = len(am.priors)
+    else:
+        capi.Models.from_htk(am).save_jmbi(jmbi)
+        margs = ["models=" + jmbi]
+        D = am.D
+    write_feats(featf, feats, D)
+    args = margs + ["feats=" + featf, "threading=%d" % int(bool(threading)), "main=%.9g" % beams.get("main_beam", 0.0),
             "start=%.9g" % beams.get("start_beam", 0.0), "end=%.9g" % beams.get("end_beam", 0.0), "word=%.9g" % beams.get("word_beam", 0.0),
             "maxhyps=%d" % beams.get("max_hyps", 0), "pti=%d" % pti]
     if loader == "fsm":
         fsm, ins, outs = (os.path.join(tmp, n) for n in ("net.fsm", "in.syms", "out.syms"))
         jio.write_fsm(fsm, net)
-        write_symbols(ins, "m", int(am.n_hmm))
+        write_symbols(ins, "m", int(len(am.priors) if hasattr(am, "priors") else am.n_hmm))
         write_symbols(outs, "w", int(max(1, np.max(net.olab) if net.n_arcs else 1)))
         args += ["fsm=" + fsm, "insyms=" + ins, "outsyms=" + outs, "lmscale=%.9g" % lm_scale, "inspen=%.9g" % ins_penalty]
     else:
@@ -142,7 +153,8 @@ def diff_case(name, am, net, feats, beams=None, loader="jwnt", lm_scale=1.0, ins
     oracle_cpu_seconds, frames, ok} - ok = everything identical on every utterance."""
     from oracle.oracle import OracleAM, OracleDecoder, OracleNet
     rows, (rc, err, wall) = run_reference(am, net, feats, beams, loader, lm_scale, ins_penalty, pti, threading, cpus, timeout)
-    od = OracleDecoder(OracleNet(net, lm_scale, ins_penalty), OracleAM(am), **(beams or {}))
+    oam = OracleAM.from_hybrid(am.priors, am.states_per_model) if hasattr(am, "priors") else OracleAM(am)
+    od = OracleDecoder(OracleNet(net, lm_scale, ins_penalty), oam, **(beams or {}))
     out = {"name": name, "loader": loader, "beams": dict(beams or {}), "utterances": len(feats), "frames": int(sum(x.shape[0] for x in feats)),
            "threading": bool(threading)}
     if lm_scale != 1.0 or ins_penalty != 0.0:
