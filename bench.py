@@ -874,6 +874,10 @@ def main():
             e_t = sum(word_errors(list(h.label[::-1]) if h.n > 0 else [], list(r)) for h, r in zip(hyps, refs))
             wer["wer_vs_sampled_transcript"] = round(e_t / max(1, sum(len(r) for r in refs)), 6)
         mark("wer_vs_oracle (%d utterances, %d threads)" % (wer["utterances"], wer["oracle_threads"]))
+        # (the essentials again where the driver's record keeps them: inside cpu_baseline)
+        cpu["wer_vs_oracle"] = wer["wer"]
+        cpu["identical_1best_whole_step"] = "%d/%d" % (wer["identical_1best"], wer["utterances"])
+        cpu["identical_scores_bitwise_whole_step"] = "%d/%d" % (wer["identical_scores_bitwise"], wer["utterances"])
 
     # what ONE batch of 64 costs a caller that does not announce nine batches ahead - beside `value`, not inside it
     one = roofline_of(st, MN, tm_one, leg_traffic("c2", max(1, tm_one["search_launches"])) if default_cfg else None)
