@@ -501,6 +501,22 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         if (getenv("JD_VERBOSE")) fprintf(stderr, "arc order: %lld of %lld model arcs in sorted rows (<= 57 arcs), %d states; k_search cuts walks: %d\n",
                                           (long long)n_sorted, (long long)n_model_all, net->n_states, C.xcut);
     }
+    {   // The layout of a stream's per-state words (jd_search.h: StateRec): split - the arrival keys of all states in an array of their own,
+        // four states to a 64-byte line - where the graph's numbering puts the states of a chain side by side (an arc to the NEXT state
+        // number: the lexicon chains of a composed C.L.G written state after state - 42 % of the arcs of the bench graphs), joint where it
+        // does not (a graph numbered by its composition: what neighbours in number have in common is nothing, and every exit token would
+        // pay a second line).  (JD_SREC_SPLIT, development: 1 / 0.)
+        int64_t n_next = 0;
+        if (!lazy)
+            for (int q = 0; q < net->n_states; ++q)
+                for (int b = net->row_ptr[(size_t)q]; b < net->row_ptr[(size_t)q + 1]; ++b) n_next += net->arcs[(size_t)b].to == q + 1;
+        bool split = !lazy && net->n_arcs > 0 && 4 * n_next >= (int64_t)net->n_arcs;
+        if (const char *e = jd_dev_env("JD_SREC_SPLIT")) split = atoi(e) != 0;
+        C.srec_stride = split ? 16u : 32u;
+        C.srec_arr = split ? 16u * (unsigned)net->n_states : 16u;
+        if (getenv("JD_VERBOSE")) fprintf(stderr, "per-state words: %s (%lld of %lld arcs lead to the next state number)\n", split ? "split (bids | arrival keys)" : "joint records",
+                                          (long long)n_next, (long long)net->n_arcs);
+    }
     if (!lazy) TRY(dupload(d, &d->d_fin_w, net->fin_w.data(), net->fin_w.size()));
     TRY(dupload(d, &d->d_hmm_tee, am->hmm_tee.data(), am->hmm_tee.size()));
     TRY(dupload(d, &d->d_hmm_tmax0, tmax0.data(), tmax0.size()));     // (phase X, hopeless candidates)

@@ -95,6 +95,7 @@ struct DecConst {
     int gc_threshold;   // a launch stops early (for the collection, k_gc_*) when more Path records than this are in use
     int x_chunks;       // phase X: chunks per wave the item lists are cut into (dynamic hand-out balances the arc walks)
     int exp;            // development experiments (JD_EXP)
+    unsigned srec_stride, srec_arr;   // the layout of a stream's per-state words (see StateRec): 32 / 16 joint, 16 / 16 * n_states split
     int path_rule;      // PARTIAL_DECODING is on: a stream also stops for a collection by the reference's count rule (path_rule_fires)
     const int *pcount;  // ... on the REFERENCE's Path counts: per state, the Path objects the reference creates for one token that
                         // arrives there (the labelled epsilon / tee arcs of its closure, with multiplicity; jd_dec_set_partial_interval).
@@ -136,7 +137,22 @@ template <int NE> struct RecLayout {
 // each a 64-byte sector for 8 useful bytes - the memory side carried out 13-15 G atomics / s on the heavy workloads,
 // about what it can do (tools/traffic_probe: 16-17 G / s).
 struct __align__(32) StateRec { unsigned long long key0, keyL, e[2]; };
-
+// Where a state's 32 bytes sit in the stream's StateRec allocation is the DECODER's choice (DecConst::srec_stride / srec_arr, round 6):
+//   joint  one 32-byte record per state (stride 32, arrival keys at +16): an exit token's bid and its arrival touch ONE line;
+//   split  two arrays - the bids {key0, keyL} of all states, then the arrival keys e[2] of all states (stride 16, arrival keys behind
+//          n_states bids): the arrival keys are what phase A gathers for every instance - the scattered HBM misses of the heavy
+//          graphs - and 16-byte records put four states' keys in a 64-byte line where the joint record puts two.
+// Which one pays is a property of the graph's numbering (jd_dec_create: the share of arcs that lead to the NEXT state number - the
+// chains of a lexicon laid out state after state): measured on one box, split against joint: the 14 M-arc trigram-shaped graph +5.5 %,
+// configs[3] +2.7 %, configs[1] with two batches in flight +2 %, the slot kernel's legs +-0, the device-composed configs[4] graph -3.4 %
+// (canonical numbering: neighbours in number are no neighbours in time, and every exit token pays a second line).  The other direction
+// was measured too: 64-byte records, -5 % (docs/state_pay_experiment.patch).
+struct __align__(16) SBid { unsigned long long key0, keyL; };
+struct __align__(16) SArr { unsigned long long e[2]; };
+#define SREC_BID_OFF(C, st) ((unsigned)(st) * (C).srec_stride)
+#define SREC_ARR_OFF(C, st) ((C).srec_arr + (unsigned)(st) * (C).srec_stride)
+#define SREC_BID(base, C, st) (*(GAS SBid *)((GAS char *)(base) + SREC_BID_OFF(C, st)))
+#define SREC_ARR(base, C, st) (*(GAS SArr *)((GAS char *)(base) + SREC_ARR_OFF(C, st)))
 // per-state STATIC record of the decoder's own copy of the graph (shared by the streams; jd_dec_create).  The decoder keeps the
 // arcs of a state in an order of its own: first the arcs every arrival has to walk (epsilon inputs, tee models: n_always of
 // them), then the arcs that enter a model, by DESCENDING w + tmax (arc weight + the model's largest entry transition) - the
@@ -746,7 +762,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         const int n = h0.y & 0xff;
         {   // the best arrival at the source state (StateRec::e[p ^ 1]) and the likelihoods: in flight together (no branch:
             // lanes without an instance read out of range)
-            const v4i ev = ld16(V.srec_r, valid ? (unsigned)h0.z * (unsigned)sizeof(StateRec) + 16u : OOB_OFF);
+            const v4i ev = ld16(V.srec_r, valid ? SREC_ARR_OFF(C, h0.z) : OOB_OFF);
             kv = ((unsigned long long)(unsigned)(p ? ev.y : ev.w) << 32) | (unsigned)(p ? ev.x : ev.z);
         }
 #pragma unroll
@@ -924,7 +940,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 st16(V.items, ioff, as_v4(ex));
                 const int lab = (h0.y & REC_LABELLED) ? 1 : 0;         // (the label itself is read from the arc when a Path record is written)
                 st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, 0});
-                if (has_exit) GMAX((lab ? &V.srec[h0.w].keyL : &V.srec[h0.w].key0), ((unsigned long long)f2o(ex.score) << 32) | k);
+                if (has_exit) GMAX((lab ? &SREC_BID(V.srec, C, h0.w).keyL : &SREC_BID(V.srec, C, h0.w).key0), ((unsigned long long)f2o(ex.score) << 32) | k);
                 exit_cnt += nex;
                 c_end += nex;
             }
@@ -949,7 +965,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         packed_lane(sh.pfx[3], sh.cnt[3], NS[2], LN[2], u - Q01, scratch, on, w, idx);
         if (on) {                                                      // (gd: the geometry this list was written with, two frames ago)
             const int b = CL(V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)w * gd.seg_new + (unsigned)idx);
-            CS(&V.srec[b].e[p], 0ULL);
+            CS(&SREC_ARR(V.srec, C, b).e[p], 0ULL);
         }
     }
     // per-wave totals -> workgroup counters (LDS)
@@ -1123,7 +1139,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         else {
             // (no load sits in a branch of its own: a load inside a branch is waited for at the branch's end, and these
             // would be three round trips one after the other instead of one)
-            const unsigned soff = (real || (valid && !LZY)) ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
+            const unsigned soff = (real || (valid && !LZY)) ? SREC_BID_OFF(C, state) : OOB_OFF;
             const v4i sk = ld16(V.srec_r, (real && exit_kind) ? soff : OOB_OFF);   // {key0, keyL}
             int2 srow = make_int2(0, 0);
             // (static, shared by the streams: cached loads)
@@ -1150,7 +1166,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const bool winner = !exit_kind || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
             // every state that received exit-token bids is cleaned up by its winner, expanded or not (an
             // item below its threshold still holds the key of its state if it was the best one there)
-            if (winner && exit_kind) CS(info.y != 0 ? &V.srec[state].keyL : &V.srec[state].key0, 0ULL);
+            if (winner && exit_kind) CS(info.y != 0 ? &SREC_BID(V.srec, C, state).keyL : &SREC_BID(V.srec, C, state).key0, 0ULL);
             have = have && winner;
         }
         if (have && real) {
@@ -1259,7 +1275,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         { const int bq = lane < tot ? b_nx : 0; Bk_nx = arc_at(bq); lv_nx = CL(V.live + bq); }
         // the arrival (see above), issued behind the first arcs' loads: the compiler waits for a returning atomic where it
         // stands, so this way the two round trips are one
-        if (arrive) { eold = GMAX(&V.srec[state].e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
+        if (arrive) { eold = GMAX(&SREC_ARR(V.srec, C, state).e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
         list_dirty(arrive && eold == 0ULL, state);
         if (eo == 0u) c_new += x_new;                                  // (the first arrival at the state in this frame: :899-935 tries them all)
         if (__ballot(n_slices > 0)) {
@@ -1316,8 +1332,8 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const float tmax = C.hmm_tmax0[entry ? inl - 1 : 0];       // (used for entry arcs without an instance; unconditional, see above)
             int2 nrow = make_int2(0, 0);
             {
-                const unsigned doff = ((on && inl == 0) || is_tee) ? (unsigned)Bk.to * (unsigned)sizeof(StateRec) : OOB_OFF;
-                const v4i se = ld16(V.srec_r, doff + 16u);
+                const unsigned doff = ((on && inl == 0) || is_tee) ? SREC_ARR_OFF(C, Bk.to) : OOB_OFF;
+                const v4i se = ld16(V.srec_r, doff);
                 if (!LZY) { const int ti = doff != OOB_OFF ? Bk.to : 0; const int r0 = C.row_ptr[ti]; nrow = make_int2(r0, C.row_ptr[ti + 1] - r0); }
                 // the next pass's arc records and flags: in flight during this pass, and - issued behind the loads this
                 // pass waits for (loads return in order) - not waited for before the next one
@@ -1378,7 +1394,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                     unsigned ceo = 0u;
                     if (pass) {
                         const unsigned long long key = ((unsigned long long)sou << 32) | k;
-                        const unsigned long long cold = GMAX(&V.srec[Bk.to].e[p], key);
+                        const unsigned long long cold = GMAX(&SREC_ARR(V.srec, C, Bk.to).e[p], key);
                         keep = key > cold; first = cold == 0ULL; ceo = (unsigned)(cold >> 32);
                     }
                     const unsigned long long bk = __ballot(keep);
@@ -1540,7 +1556,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 }
                 else {
                     const int b = CL(V.dirtyl + (kind == 2 ? V.dirty_par : 0u) + (size_t)w * gk.seg_new + (unsigned)(ci * 64 + lane));
-                    CS(&V.srec[b].e[0], 0ULL); CS(&V.srec[b].e[1], 0ULL);
+                    CS(&SREC_ARR(V.srec, C, b).e[0], 0ULL); CS(&SREC_ARR(V.srec, C, b).e[1], 0ULL);
                 }
             }
         }

@@ -177,7 +177,7 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         unsigned long long kv;
         float outp[NE];
         {
-            const v4i ev = ld16(V.srec_r, valid ? (unsigned)h0.z * (unsigned)sizeof(StateRec) + 16u : OOB_OFF);
+            const v4i ev = ld16(V.srec_r, valid ? SREC_ARR_OFF(C, h0.z) : OOB_OFF);
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const int gj = (j == 0) ? h1.x : (j == 1) ? h1.y : (j == 2) ? h1.z : (j == 3) ? h2.x : (j == 4) ? h2.y : h2.z;
@@ -333,7 +333,7 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
                 st16(V.items, ioff, as_v4(ex));
                 const int lab = (h0.y & REC_LABELLED) ? 1 : 0;
                 st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, 0});
-                if (has_exit) GMAX((lab ? &V.srec[h0.w].keyL : &V.srec[h0.w].key0), ((unsigned long long)f2o(ex.score) << 32) | k);
+                if (has_exit) GMAX((lab ? &SREC_BID(V.srec, C, h0.w).keyL : &SREC_BID(V.srec, C, h0.w).key0), ((unsigned long long)f2o(ex.score) << 32) | k);
                 exit_cnt += nex;
                 c_end += nex;
             }
@@ -348,7 +348,7 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         locate(2, u - Q01, n2, on, w, idx);
         if (on) {
             const int b = CL(V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)w * g.seg_new + (unsigned)idx);
-            CS(&V.srec[b].e[p], 0ULL);
+            CS(&SREC_ARR(V.srec, C, b).e[p], 0ULL);
         }
     }
     mo = wave_umax(mo);
@@ -460,7 +460,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         int label = exit_kind ? 0 : info.y;
         if (from_q) { rs = row_q.x; rs1 = row_q.x + row_q.y; }
         else {
-            const unsigned soff = valid ? (unsigned)state * (unsigned)sizeof(StateRec) : OOB_OFF;
+            const unsigned soff = valid ? SREC_BID_OFF(C, state) : OOB_OFF;
             const v4i sk = ld16(V.srec_r, (real && exit_kind) ? soff : OOB_OFF);   // {key0, keyL}
             const int sti = valid ? state : 0;
             const int2 srow = make_int2(C.row_ptr[sti], C.row_ptr[sti + 1]);
@@ -472,7 +472,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         }
         if (real) {
             const bool winner = !exit_kind || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
-            if (winner && exit_kind) CS(info.y != 0 ? &V.srec[state].keyL : &V.srec[state].key0, 0ULL);
+            if (winner && exit_kind) CS(info.y != 0 ? &SREC_BID(V.srec, C, state).keyL : &SREC_BID(V.srec, C, state).key0, 0ULL);
             have = have && winner;
         }
         if (have && real) {
@@ -567,7 +567,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         JdArc Bk_nx = {0, 0.0f, 0, 0};
         int lv_nx = 0;
         { const int bq = lane < tot ? b_nx : 0; Bk_nx = C.arcs[bq]; lv_nx = CL(V.live + bq); }
-        if (arrive) { eold = GMAX(&V.srec[state].e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
+        if (arrive) { eold = GMAX(&SREC_ARR(V.srec, C, state).e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
         list_dirty(arrive && eold == 0ULL, state);
         if (eo == 0u) c_new += x_new;                                  // (the first arrival at the state in this frame: :899-935 tries them all)
         if (__ballot(n_slices > 0)) {
@@ -616,8 +616,8 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
             const float tmax = tee_lds ? sh.tmax[entry ? inl - 1 : 0] : C.hmm_tmax0[entry ? inl - 1 : 0];
             int2 nrow = make_int2(0, 0);
             {
-                const unsigned doff = ((on && inl == 0) || is_tee) ? (unsigned)Bk.to * (unsigned)sizeof(StateRec) : OOB_OFF;
-                const v4i se = ld16(V.srec_r, doff + 16u);
+                const unsigned doff = ((on && inl == 0) || is_tee) ? SREC_ARR_OFF(C, Bk.to) : OOB_OFF;
+                const v4i se = ld16(V.srec_r, doff);
                 { const int ti = doff != OOB_OFF ? Bk.to : 0; const int r0 = C.row_ptr[ti]; nrow = make_int2(r0, C.row_ptr[ti + 1] - r0); }
                 Bk_nx = C.arcs[b_nx]; lv_nx = CL(V.live + b_nx);
                 skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
@@ -672,7 +672,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
                     unsigned ceo = 0u;
                     if (pass) {
                         const unsigned long long key = ((unsigned long long)sou << 32) | k;
-                        const unsigned long long cold = GMAX(&V.srec[Bk.to].e[p], key);
+                        const unsigned long long cold = GMAX(&SREC_ARR(V.srec, C, Bk.to).e[p], key);
                         keep = key > cold; first = cold == 0ULL; ceo = (unsigned)(cold >> 32);
                     }
                     const unsigned long long bk = __ballot(keep);
@@ -821,7 +821,7 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
                             CS(&V.live[ld16(V.rec, roff).x], (unsigned char)0);
                         } else {
                             const int b = CL(V.dirtyl + (kind == 2 ? V.dirty_par : 0u) + (size_t)w * gk.seg_new + (unsigned)(i0 + lane));
-                            CS(&V.srec[b].e[0], 0ULL); CS(&V.srec[b].e[1], 0ULL);
+                            CS(&SREC_ARR(V.srec, C, b).e[0], 0ULL); CS(&SREC_ARR(V.srec, C, b).e[1], 0ULL);
                         }
                     }
                 }
