@@ -510,11 +510,15 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
         if (!lazy)
             for (int q = 0; q < net->n_states; ++q)
                 for (int b = net->row_ptr[(size_t)q]; b < net->row_ptr[(size_t)q + 1]; ++b) n_next += net->arcs[(size_t)b].to == q + 1;
-        bool split = !lazy && net->n_arcs > 0 && 4 * n_next >= (int64_t)net->n_arcs;
-        if (const char *e = jd_dev_env("JD_SREC_SPLIT")) split = atoi(e) != 0;
+        int split = (!lazy && net->n_arcs > 0 && 4 * n_next >= (int64_t)net->n_arcs) ? 2 : 0;   // 0 joint, 1 split (both parities of a state together), 2 split by parity
+        if (const char *e = jd_dev_env("JD_SREC_SPLIT")) split = std::max(0, std::min(2, atoi(e)));
+        const unsigned ns = (unsigned)net->n_states;
         C.srec_stride = split ? 16u : 32u;
-        C.srec_arr = split ? 16u * (unsigned)net->n_states : 16u;
-        if (getenv("JD_VERBOSE")) fprintf(stderr, "per-state words: %s (%lld of %lld arcs lead to the next state number)\n", split ? "split (bids | arrival keys)" : "joint records",
+        C.srec_arr = split ? 16u * ns : 16u;
+        C.srec_estride = split == 2 ? 8u : (split ? 16u : 32u);
+        C.srec_par = split == 2 ? 8u * ns : 8u;
+        if (getenv("JD_VERBOSE")) fprintf(stderr, "per-state words: %s (%lld of %lld arcs lead to the next state number)\n",
+                                          split == 2 ? "split (bids | arrival keys of either frame parity)" : split ? "split (bids | arrival keys)" : "joint records",
                                           (long long)n_next, (long long)net->n_arcs);
     }
     if (!lazy) TRY(dupload(d, &d->d_fin_w, net->fin_w.data(), net->fin_w.size()));

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(1024) void k_gc_mark(DecConst C, StreamCtl *ctl, St
             const int n_d = min(S.tot[(size_t)(TOT_DIRTY0 + (x.p ^ 1)) * MAXW + w], (int)gd.seg_new);
             for (int q = lane; q < n_d; q += 64) {
                 const int st = dl[(size_t)w * gd.seg_new + q];
-                const unsigned long long kv = SREC_ARR(S.srec, C, st).e[x.p ^ 1];
+                const unsigned long long kv = SREC_E(S.srec, C, st, x.p ^ 1);
                 if (kv == 0ULL) continue;
                 bool has_model = false;
                 for (int a = C.row_ptr[st]; a < C.row_ptr[st + 1] && !has_model; ++a) has_model = (C.arcs[a].in & ~TEE_FLAG) != 0;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void jd_for_each_tip(const DecConst &C, const StreamC
     const int p = c.frame & 1;
     // the pending entry token of the arcs leaving state st: the best token that arrived there in the last frame
     auto entry_tip = [&](int st) -> int {
-        const unsigned long long kv = SREC_ARR(S.srec, C, st).e[p ^ 1];
+        const unsigned long long kv = SREC_E(S.srec, C, st, p ^ 1);
         if (kv == 0ULL) return -1;
         return S.items[2 * ((size_t)(p ^ 1) * C.cap_items + (size_t)(kv & 0xffffffffULL))].w;
     };

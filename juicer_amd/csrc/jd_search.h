@@ -95,7 +95,8 @@ struct DecConst {
     int gc_threshold;   // a launch stops early (for the collection, k_gc_*) when more Path records than this are in use
     int x_chunks;       // phase X: chunks per wave the item lists are cut into (dynamic hand-out balances the arc walks)
     int exp;            // development experiments (JD_EXP)
-    unsigned srec_stride, srec_arr;   // the layout of a stream's per-state words (see StateRec): 32 / 16 joint, 16 / 16 * n_states split
+    unsigned srec_stride, srec_arr, srec_estride, srec_par;   // the layout of a stream's per-state words (see StateRec): bytes between two states' bids; where e[0] of state 0
+                        // sits; bytes between two states' arrival keys; bytes from a state's e[0] to its e[1] - joint 32 / 16 / 32 / 8, split 16 / 16 n / 16 / 8, split8 16 / 16 n / 8 / 8 n
     int path_rule;      // PARTIAL_DECODING is on: a stream also stops for a collection by the reference's count rule (path_rule_fires)
     const int *pcount;  // ... on the REFERENCE's Path counts: per state, the Path objects the reference creates for one token that
                         // arrives there (the labelled epsilon / tee arcs of its closure, with multiplicity; jd_dec_set_partial_interval).
@@ -149,10 +150,12 @@ struct __align__(32) StateRec { unsigned long long key0, keyL, e[2]; };
 // was measured too: 64-byte records, -5 % (docs/state_pay_experiment.patch).
 struct __align__(16) SBid { unsigned long long key0, keyL; };
 struct __align__(16) SArr { unsigned long long e[2]; };
+//   split8 (the default where split pays) goes one step further: the arrival keys of each frame PARITY in an array of their own - 8 bytes per
+//          state, eight states to a line; a frame pulls from one parity and writes the other, never both of a state.
 #define SREC_BID_OFF(C, st) ((unsigned)(st) * (C).srec_stride)
-#define SREC_ARR_OFF(C, st) ((C).srec_arr + (unsigned)(st) * (C).srec_stride)
+#define SREC_E_OFF(C, st, q) ((C).srec_arr + (unsigned)(q) * (C).srec_par + (unsigned)(st) * (C).srec_estride)
 #define SREC_BID(base, C, st) (*(GAS SBid *)((GAS char *)(base) + SREC_BID_OFF(C, st)))
-#define SREC_ARR(base, C, st) (*(GAS SArr *)((GAS char *)(base) + SREC_ARR_OFF(C, st)))
+#define SREC_E(base, C, st, q) (*(GAS unsigned long long *)((GAS char *)(base) + SREC_E_OFF(C, st, q)))
 // per-state STATIC record of the decoder's own copy of the graph (shared by the streams; jd_dec_create).  The decoder keeps the
 // arcs of a state in an order of its own: first the arcs every arrival has to walk (epsilon inputs, tee models: n_always of
 // them), then the arcs that enter a model, by DESCENDING w + tmax (arc weight + the model's largest entry transition) - the
@@ -282,6 +285,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigne
 // The functions below are used through the macros st16 / CS / GMAX / GADD, which pick the flavour of
 // the enclosing function's `XL_`.
 __device__ __forceinline__ v4i ld16(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX_SC1); }
+typedef int v2i_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned long long ld8(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const v2i_ v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, AUX_SC1);
+    return ((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x;
+}
 template <typename T> __device__ __forceinline__ T CL(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // A pointer the kernel LOADS from memory (the per-stream arena pointers of StreamDev) is a generic pointer to the
 // compiler, and every access through it a FLAT instruction: one that may touch LDS, so it counts on the LDS counter
@@ -762,8 +771,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         const int n = h0.y & 0xff;
         {   // the best arrival at the source state (StateRec::e[p ^ 1]) and the likelihoods: in flight together (no branch:
             // lanes without an instance read out of range)
-            const v4i ev = ld16(V.srec_r, valid ? SREC_ARR_OFF(C, h0.z) : OOB_OFF);
-            kv = ((unsigned long long)(unsigned)(p ? ev.y : ev.w) << 32) | (unsigned)(p ? ev.x : ev.z);
+            kv = ld8(V.srec_r, valid ? SREC_E_OFF(C, h0.z, p ^ 1) : OOB_OFF);
         }
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
@@ -965,7 +973,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         packed_lane(sh.pfx[3], sh.cnt[3], NS[2], LN[2], u - Q01, scratch, on, w, idx);
         if (on) {                                                      // (gd: the geometry this list was written with, two frames ago)
             const int b = CL(V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)w * gd.seg_new + (unsigned)idx);
-            CS(&SREC_ARR(V.srec, C, b).e[p], 0ULL);
+            CS(&SREC_E(V.srec, C, b, p), 0ULL);
         }
     }
     // per-wave totals -> workgroup counters (LDS)
@@ -1275,7 +1283,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         { const int bq = lane < tot ? b_nx : 0; Bk_nx = arc_at(bq); lv_nx = CL(V.live + bq); }
         // the arrival (see above), issued behind the first arcs' loads: the compiler waits for a returning atomic where it
         // stands, so this way the two round trips are one
-        if (arrive) { eold = GMAX(&SREC_ARR(V.srec, C, state).e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
+        if (arrive) { eold = GMAX(&SREC_E(V.srec, C, state, p), ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
         list_dirty(arrive && eold == 0ULL, state);
         if (eo == 0u) c_new += x_new;                                  // (the first arrival at the state in this frame: :899-935 tries them all)
         if (__ballot(n_slices > 0)) {
@@ -1332,13 +1340,13 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             const float tmax = C.hmm_tmax0[entry ? inl - 1 : 0];       // (used for entry arcs without an instance; unconditional, see above)
             int2 nrow = make_int2(0, 0);
             {
-                const unsigned doff = ((on && inl == 0) || is_tee) ? SREC_ARR_OFF(C, Bk.to) : OOB_OFF;
-                const v4i se = ld16(V.srec_r, doff);
+                const unsigned doff = ((on && inl == 0) || is_tee) ? SREC_E_OFF(C, Bk.to, p) : OOB_OFF;
+                const unsigned long long se = ld8(V.srec_r, doff);
                 if (!LZY) { const int ti = doff != OOB_OFF ? Bk.to : 0; const int r0 = C.row_ptr[ti]; nrow = make_int2(r0, C.row_ptr[ti + 1] - r0); }
                 // the next pass's arc records and flags: in flight during this pass, and - issued behind the loads this
                 // pass waits for (loads return in order) - not waited for before the next one
                 Bk_nx = arc_at(b_nx); lv_nx = CL(V.live + b_nx);
-                skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
+                skc = se;
             }
             if (on) ++c_arcs;
             JD_COUNT(c_walk += __popcll(__ballot(on)));
@@ -1394,7 +1402,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
                     unsigned ceo = 0u;
                     if (pass) {
                         const unsigned long long key = ((unsigned long long)sou << 32) | k;
-                        const unsigned long long cold = GMAX(&SREC_ARR(V.srec, C, Bk.to).e[p], key);
+                        const unsigned long long cold = GMAX(&SREC_E(V.srec, C, Bk.to, p), key);
                         keep = key > cold; first = cold == 0ULL; ceo = (unsigned)(cold >> 32);
                     }
                     const unsigned long long bk = __ballot(keep);
@@ -1556,7 +1564,7 @@ __device__ __forceinline__ void run_stream(const SearchArgs &A, SearchShared &sh
                 }
                 else {
                     const int b = CL(V.dirtyl + (kind == 2 ? V.dirty_par : 0u) + (size_t)w * gk.seg_new + (unsigned)(ci * 64 + lane));
-                    CS(&SREC_ARR(V.srec, C, b).e[0], 0ULL); CS(&SREC_ARR(V.srec, C, b).e[1], 0ULL);
+                    CS(&SREC_E(V.srec, C, b, 0), 0ULL); CS(&SREC_E(V.srec, C, b, 1), 0ULL);
                 }
             }
         }

@@ -177,13 +177,13 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         unsigned long long kv;
         float outp[NE];
         {
-            const v4i ev = ld16(V.srec_r, valid ? SREC_ARR_OFF(C, h0.z) : OOB_OFF);
+            const unsigned long long ev = ld8(V.srec_r, valid ? SREC_E_OFF(C, h0.z, p ^ 1) : OOB_OFF);
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const int gj = (j == 0) ? h1.x : (j == 1) ? h1.y : (j == 2) ? h1.z : (j == 3) ? h2.x : (j == 4) ? h2.y : h2.z;
                 outp[j] = LLL ? sh.ll[(j + 1 < n - 1) ? gj : 0] : llrow[(j + 1 < n - 1) ? gj : 0];   // :411
             }
-            kv = ((unsigned long long)(unsigned)(p ? ev.y : ev.w) << 32) | (unsigned)(p ? ev.x : ev.z);
+            kv = ev;
         }
         // entry token = the best token that arrived at the arc's source state in the previous frame, over the arc (:560-582)
         const v4i itv = ld16(V.items, kv != 0ULL ? iprev + (unsigned)(kv & 0xffffffffULL) * 32u : OOB_OFF);
@@ -348,7 +348,7 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         locate(2, u - Q01, n2, on, w, idx);
         if (on) {
             const int b = CL(V.dirtyl + (p ? V.dirty_par : 0u) + (size_t)w * g.seg_new + (unsigned)idx);
-            CS(&SREC_ARR(V.srec, C, b).e[p], 0ULL);
+            CS(&SREC_E(V.srec, C, b, p), 0ULL);
         }
     }
     mo = wave_umax(mo);
@@ -567,7 +567,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         JdArc Bk_nx = {0, 0.0f, 0, 0};
         int lv_nx = 0;
         { const int bq = lane < tot ? b_nx : 0; Bk_nx = C.arcs[bq]; lv_nx = CL(V.live + bq); }
-        if (arrive) { eold = GMAX(&SREC_ARR(V.srec, C, state).e[p], ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
+        if (arrive) { eold = GMAX(&SREC_E(V.srec, C, state, p), ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
         list_dirty(arrive && eold == 0ULL, state);
         if (eo == 0u) c_new += x_new;                                  // (the first arrival at the state in this frame: :899-935 tries them all)
         if (__ballot(n_slices > 0)) {
@@ -616,11 +616,11 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
             const float tmax = tee_lds ? sh.tmax[entry ? inl - 1 : 0] : C.hmm_tmax0[entry ? inl - 1 : 0];
             int2 nrow = make_int2(0, 0);
             {
-                const unsigned doff = ((on && inl == 0) || is_tee) ? SREC_ARR_OFF(C, Bk.to) : OOB_OFF;
-                const v4i se = ld16(V.srec_r, doff);
+                const unsigned doff = ((on && inl == 0) || is_tee) ? SREC_E_OFF(C, Bk.to, p) : OOB_OFF;
+                const unsigned long long se = ld8(V.srec_r, doff);
                 { const int ti = doff != OOB_OFF ? Bk.to : 0; const int r0 = C.row_ptr[ti]; nrow = make_int2(r0, C.row_ptr[ti + 1] - r0); }
                 Bk_nx = C.arcs[b_nx]; lv_nx = CL(V.live + b_nx);
-                skc = ((unsigned long long)(unsigned)(p ? se.w : se.y) << 32) | (unsigned)(p ? se.z : se.x);
+                skc = se;
             }
             if (on) ++c_arcs;
             JD_COUNT(const unsigned long long cnt_w_ = (unsigned long long)__popcll(__ballot(on)); if (lane == 0) atomicAdd(&sh.cntX, cnt_w_));
@@ -672,7 +672,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
                     unsigned ceo = 0u;
                     if (pass) {
                         const unsigned long long key = ((unsigned long long)sou << 32) | k;
-                        const unsigned long long cold = GMAX(&SREC_ARR(V.srec, C, Bk.to).e[p], key);
+                        const unsigned long long cold = GMAX(&SREC_E(V.srec, C, Bk.to, p), key);
                         keep = key > cold; first = cold == 0ULL; ceo = (unsigned)(cold >> 32);
                     }
                     const unsigned long long bk = __ballot(keep);
@@ -821,7 +821,7 @@ __device__ __forceinline__ void slot_run(const SearchArgs &A, SlotShared &sh, in
                             CS(&V.live[ld16(V.rec, roff).x], (unsigned char)0);
                         } else {
                             const int b = CL(V.dirtyl + (kind == 2 ? V.dirty_par : 0u) + (size_t)w * gk.seg_new + (unsigned)(i0 + lane));
-                            CS(&SREC_ARR(V.srec, C, b).e[0], 0ULL); CS(&SREC_ARR(V.srec, C, b).e[1], 0ULL);
+                            CS(&SREC_E(V.srec, C, b, 0), 0ULL); CS(&SREC_E(V.srec, C, b, 1), 0ULL);
                         }
                     }
                 }
