@@ -312,6 +312,11 @@ extern "C" int jd_dec_set_partial_interval(jd_dec *d, int32_t interval)
             if (rc) return rc;
             std::vector<int> P;
             if (closure_path_counts(d->net, d->am, P)) {
+                if (!d->state_new.empty()) {                           // (the kernels index it by the decoder's own state numbers)
+                    std::vector<int> Q(P.size());
+                    for (size_t q = 0; q < P.size(); ++q) Q[(size_t)d->state_new[q]] = P[q];
+                    P.swap(Q);
+                }
                 rc = dupload(d, &d->d_pcount, P.data(), P.size());
                 if (rc) return rc;
             }
