@@ -449,11 +449,15 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     }
     // The decoder's OWN numbering of the states.  A stream's per-state words (jd_search.h: StateRec) are gathered by state number, eight
     // arrival keys to a 64-byte line, so which states are neighbours in NUMBER decides how many lines a frame fetches - and tokens
-    // move along chains: the state behind a state's first model arc is the one whose key is pulled next.  The states are numbered
-    // along those chains (follow the first arc that enters a model, else the first arc, until a numbered state is met; then the next
-    // unnumbered state in the network's order).  A network that is laid out like that already - a lexicon written chain after chain -
-    // keeps its numbering; one numbered by its composition (jd_net_compose: canonical, breadth first) gets one.  State numbers never
-    // leave the device and nothing breaks a tie by them (the frontier item's number does): results are bit-identical.
+    // move along chains.  The numbering: a state, then, arc by arc, the chain of one-arc states behind each of its arcs (the phones of
+    // a word, one state after the other; the chains that leave one state side by side, as their instances are attached in the same
+    // frame); the states the chains END in - the ones with a choice to make - get their number there and take their turn first come,
+    // first served.  That is how a lexicon written chain after chain is laid out already, and such a network keeps its numbering; one
+    // numbered by its composition (jd_net_compose: canonical, breadth first) gets this one.  State numbers never leave the device and
+    // nothing breaks a tie by them (the frontier item's number does): results are bit-identical.  Measured on the composed configs[4]
+    // graph (k frames/s, tools/r6_run21-24.sh): the network's numbers 36.7, along the chains of first model arcs 36.7 (round 6's first
+    // attempt), depth first 41.3, blocks of 16 filled breadth first 43.5, this 45.0; on the bench's generated graphs it equals the
+    // generator's own order (129.8 / 129.1 k, 5.60 / 5.65 k), every other order loses 1-4 % to it.
     // (JD_RENUMBER, development: 1 / 0 - always / never.)
     std::vector<int> rp_own;                                           // row_ptr in the decoder's numbering (empty: the network's)
     std::vector<JdArc> arcs_own;
@@ -461,25 +465,31 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (!lazy)
         for (int q = 0; q < net->n_states; ++q)
             for (int b = net->row_ptr[(size_t)q]; b < net->row_ptr[(size_t)q + 1]; ++b) n_next_net += net->arcs[(size_t)b].to == q + 1;
-    // (only a network whose own numbering is NOT along its chains gets the decoder's: measured, the generator's order of the bench graphs
-    // - 42 % of their arcs lead to the next number - is 1-2 % better than this walk's, the composed graph's 0 % is 3 % worse)
     bool renumber = !lazy && net->n_states > 0 && 4 * n_next_net < (int64_t)net->n_arcs;
     if (const char *e = jd_dev_env("JD_RENUMBER")) renumber = !lazy && net->n_states > 0 && atoi(e) != 0;
     if (renumber) {
         const int ns = net->n_states;
         std::vector<int> new_of((size_t)ns, -1), old_of((size_t)ns);
         int next = 0;
-        for (int s0 = 0; s0 < ns; ++s0) {
-            for (int q = s0; new_of[(size_t)q] < 0;) {
-                new_of[(size_t)q] = next; old_of[(size_t)next] = q; ++next;
-                const int r0 = net->row_ptr[(size_t)q], r1 = net->row_ptr[(size_t)q + 1];
-                int to = -1;
-                for (int b = r0; b < r1 && to < 0; ++b) if (net->arcs[(size_t)b].in != 0) to = net->arcs[(size_t)b].to;
-                if (to < 0 && r1 > r0) to = net->arcs[(size_t)r0].to;
-                if (to < 0) break;
-                q = to;
+        auto take = [&](int q) { new_of[(size_t)q] = next; old_of[(size_t)next] = q; ++next; };
+        std::vector<int> pend;                                         // numbered states whose arcs are still to be followed, in the order they were met
+        for (int pass = 0; pass < 2; ++pass)                           // (from the initial state; then whatever it does not reach, in the network's order)
+            for (int s0 = pass == 0 ? net->init : 0; s0 < (pass == 0 ? net->init + 1 : ns); ++s0) {
+                if (new_of[(size_t)s0] >= 0) continue;
+                take(s0);
+                pend.clear(); pend.push_back(s0);
+                for (size_t ph = 0; ph < pend.size(); ++ph) {
+                    const int q = pend[ph];
+                    for (int b = net->row_ptr[(size_t)q]; b < net->row_ptr[(size_t)q + 1]; ++b) {
+                        int t = net->arcs[(size_t)b].to;
+                        while (new_of[(size_t)t] < 0 && net->row_ptr[(size_t)t + 1] - net->row_ptr[(size_t)t] == 1) {
+                            take(t);
+                            t = net->arcs[(size_t)net->row_ptr[(size_t)t]].to;
+                        }
+                        if (new_of[(size_t)t] < 0) { take(t); pend.push_back(t); }
+                    }
+                }
             }
-        }
         bool same = true;
         for (int q = 0; q < ns && same; ++q) same = new_of[(size_t)q] == q;
         if (!same) {
@@ -496,7 +506,7 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
             }
             d->state_new.swap(new_of);
         }
-        if (getenv("JD_VERBOSE")) fprintf(stderr, "state numbers: %s\n", same ? "the network's (already along its chains)" : "the decoder's own (along the chains of first model arcs)");
+        if (getenv("JD_VERBOSE")) fprintf(stderr, "state numbers: %s\n", same ? "the network's (already along its chains)" : "the decoder's own (a state, the chains behind its arcs side by side)");
     }
     const std::vector<int> &row_ptr_h = rp_own.empty() ? net->row_ptr : rp_own;
     const std::vector<JdArc> &arcs_h = arcs_own.empty() ? net->arcs : arcs_own;

@@ -831,6 +831,59 @@ def test_partial_decoding_count_rule(built):
     gd.close()
 
 
+@pytest.mark.parametrize("cfg_name", ["small", "small_tree", "mixed"])
+def test_decoders_own_state_numbering_and_layouts(cfg_name, request, monkeypatch, capfd):
+    """Where a state's words sit and what number it has are the decoder's own business (jd_dec_create: the numbering along the
+    chains behind a state's arcs, the per-state words joint or split): forced on and off on graphs with tee models, epsilon
+    arcs inside a lexicon tree and HMMs of 1-6 emitting states, every combination gives the oracle's hypotheses, the
+    reference's statistics and the same bits as every other - through a whole-batch decode, through the stream calls with a
+    trace after every push (the per-state Path counts of the count rule are permuted with the states), and with final
+    weights on states that moved."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = request.getfixturevalue(cfg_name)
+    kw = dict(main_beam=150.0, max_hyps=200) if cfg_name != "mixed" else dict(main_beam=200.0)
+    od = OracleDecoder(onet, oam, **kw)
+    ora = [od.decode_certified(x) for x in feats]
+    x = np.concatenate([feats[0], feats[1]])
+    monkeypatch.setenv("JD_DEV", "1")
+    monkeypatch.setenv("JD_VERBOSE", "1")
+    base = None
+    said_own = 0
+    for renumber in ("0", "1"):
+        for split in ("0", "1", "2"):
+            monkeypatch.setenv("JD_RENUMBER", renumber)
+            monkeypatch.setenv("JD_SREC_SPLIT", split)
+            capfd.readouterr()
+            gd = capi.Decoder(gnet, gam, max_streams=len(feats), **kw)
+            err = capfd.readouterr().err
+            said_own += "state numbers: the decoder's own" in err
+            assert ("per-state words: " + ("joint", "split (bids | arrival keys)", "split (bids | arrival keys of either")[int(split)]) in err, err[-600:]
+            gs = gd.decode_batch(feats)
+            for u, g in enumerate(gs):
+                assert_hyp_matches(g, ora[u], "%s renumber %s split %s utt %d" % (cfg_name, renumber, split, u))
+            gd.set_partial_interval(1)
+            gd.stream_init(0)
+            trace = []
+            for pos in range(0, x.shape[0], 29):
+                gd.stream_push(0, x[pos:pos + 29])
+                pc = gd.stream_path_counts(0)
+                assert pc[2], "the count rule's exact counts are expected here (no end / word beam)"
+                trace.append((gd.stream_partial(0), gd.stream_collect_info(0), pc))
+            h = gd.stream_finish(0)
+            trace.append(gd.stream_partial(0))
+            gd.set_partial_interval(0)
+            # (tot_arcs_visited / tot_paths are left out: how many arcs a state's losers walked before the winner arrived is a matter of timing)
+            got = dict(hyps=[(g.n, g.label.tobytes(), g.time.tobytes(), g.score.tobytes()) for g in gs],
+                       stats=[[g.stats[k] for k in ("n_frames", "tot_active_emit_hyps", "tot_active_end_hyps", "tot_active_models", "tot_proc_emit_hyps", "tot_proc_end_hyps", "tot_insts_in")] for g in gs],
+                       stream=(h.n, h.label.tobytes(), h.time.tobytes(), h.score.tobytes()), trace=trace)
+            if base is None: base = got
+            for k in got:
+                assert got[k] == base[k], "%s: renumber %s split %s: %s differ from the network's numbers in joint records" % (cfg_name, renumber, split, k)
+            gd.close()
+    assert said_own == 3, "the decoder's own numbering never took effect on %s" % cfg_name
+
+
 def test_max_alloc_models(small):
     """setMaxAllocModels (WFSTDecoderLite.cpp:807-820) is a SOFT limit in the reference (it decides whether cached
     NetInst objects are dropped between utterances, :164-169): whatever its value - percentage / MB / count form,
