@@ -95,7 +95,10 @@ def design_bytes(st, max_n, G, frames, row_in_lds):
                likelihoods: the frame's row into LDS (G x 4, the slot kernel) or 4 per emitting hypothesis (k_search)
       phase X  item taken up: item 32 + state record XState 64 + bid keys 16 + CSR bounds 8 + the row's instance flags 32;
                arrival: 8 (atomic max); arc walked: record 16 + flag 1; closure item: item 32 + atomic 8 + destination key 8;
-               Path record 32"""
+               Path record 32
+    (An exit token of an arc that is the only one into its state - jd_search.h: REC_SOLE, most exit tokens of a chain-shaped graph -
+    places and reads no bid: 24 of the bytes priced here per exit token are not requested for it.  The kernels do not count those
+    tokens apart, so this figure is an upper bound of the requests: by 1.5 % on configs[1], by 3 % on configs[3].)"""
     R = 80.0 if max_n <= 5 else 144.0
     tmpl = 16.0 if max_n <= 5 else 32.0
     a = (st["tot_recs_read"] * (R + 8.0) + st["tot_new_attached"] * (8.0 + 16.0 + tmpl + 8.0) + st["tot_entry_items"] * 16.0

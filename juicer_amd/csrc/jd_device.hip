@@ -410,6 +410,8 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
     if (net->max_in > am->n_hmm)
         return jd_fail(JD_EINVAL, "network input label %d exceeds the number of HMMs %d", net->max_in, am->n_hmm);
     if (am->max_n > JD_MAXN) return jd_fail(JD_EINVAL, "HMMs with more than %d states unsupported", JD_MAXN);
+    if (am->n_hmm >= SOLE_FLAG || am->n_tm > 0x1fffff)                    // (the flag bits of a device arc's in-label and of a record's header)
+        return jd_fail(JD_EINVAL, "more than %d HMMs or %d transition matrices unsupported", SOLE_FLAG - 1, 0x1fffff);
     if ((int64_t)net->n_states * (int64_t)sizeof(StateRec) > 0xf0000000LL)   // (32-bit byte offsets of the buffer descriptor)
         return jd_fail(JD_EINVAL, "networks with more than %lld states unsupported", (long long)(0xf0000000LL / (int64_t)sizeof(StateRec)));
     int rc = check_device(device);
@@ -551,6 +553,16 @@ extern "C" int jd_dec_create(jd_dec **out, const jd_net *net, const jd_am *am, f
             X.n_entry = (int)ent.size();
             for (size_t i = 0; i < ent.size(); ++i) darcs[(size_t)at + i] = ent[i].second;
             for (int i = 0; i < XNCAND; ++i) if (xcand(i) < X.n_entry) X.k[i] = ent[(size_t)xcand(i)].first;
+        }
+        {   // SOLE_FLAG (jd_search.h: REC_SOLE): the arc that enters a model and is the only arc of the network that leads to its
+            // destination - its exit tokens recombine with nobody.  (JD_NO_SOLE, development: off.)
+            std::vector<int> indeg((size_t)net->n_states, 0);
+            for (const JdArc &a : darcs) ++indeg[(size_t)a.to];
+            int64_t n_sole = 0, n_model = 0;
+            const bool sole_on = jd_dev_env("JD_NO_SOLE") == nullptr;
+            for (JdArc &a : darcs)
+                if ((a.in & ~TEE_FLAG) != 0) { ++n_model; if (sole_on && indeg[(size_t)a.to] == 1 && !(a.in & TEE_FLAG)) { a.in |= SOLE_FLAG; ++n_sole; } }   // (a tee model's pass-through arrives beside its exit token)
+            if (getenv("JD_VERBOSE")) fprintf(stderr, "exit tokens that recombine with nobody: those of %lld of %lld model arcs (the only arc into their state)\n", (long long)n_sole, (long long)n_model);
         }
         TRY(dupload(d, &d->d_arcs, darcs.data(), darcs.size()));
         TRY(dupload(d, &d->d_xst, xst.data(), xst.size()));

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void k_gc_mark(DecConst C, StreamCtl *ctl, St
                 const unsigned long long kv = SREC_E(S.srec, C, st, x.p ^ 1);
                 if (kv == 0ULL) continue;
                 bool has_model = false;
-                for (int a = C.row_ptr[st]; a < C.row_ptr[st + 1] && !has_model; ++a) has_model = (C.arcs[a].in & ~TEE_FLAG) != 0;
+                for (int a = C.row_ptr[st]; a < C.row_ptr[st + 1] && !has_model; ++a) has_model = (C.arcs[a].in & ~ARC_FLAGS) != 0;
                 if (has_model) mark_ref(S.items[2 * ((size_t)(x.p ^ 1) * C.cap_items + (size_t)(kv & 0xffffffffULL))].w);
             }
         }
@@ -339,9 +339,9 @@ __device__ __forceinline__ void jd_for_each_tip(const DecConst &C, const StreamC
             bool has_model = false;
             if (C.lazy) {
                 const int4 row = C.lazy->rows[st];
-                for (int a = row.x; a < row.x + row.y && !has_model; ++a) has_model = (C.lazy->arcs[a].in & ~TEE_FLAG) != 0;
+                for (int a = row.x; a < row.x + row.y && !has_model; ++a) has_model = (C.lazy->arcs[a].in & ~ARC_FLAGS) != 0;
             } else
-                for (int a = C.row_ptr[st]; a < C.row_ptr[st + 1] && !has_model; ++a) has_model = (C.arcs[a].in & ~TEE_FLAG) != 0;
+                for (int a = C.row_ptr[st]; a < C.row_ptr[st + 1] && !has_model; ++a) has_model = (C.arcs[a].in & ~ARC_FLAGS) != 0;
             if (has_model) f(entry_tip(st));
         }
     }

@@ -47,6 +47,8 @@
 #define MAXW SNT                      // most waves one cluster may have (one thread per wave when the lists are set up)
 #define MAXCW (MAXW / SW)
 #define TEE_FLAG 0x40000000          // bit 30 of the device arc's in-label: the arc's HMM is a tee model
+#define SOLE_FLAG 0x20000000         // bit 29: the arc is the ONLY arc that leads to its destination state (jd_dec_create) - see REC_SOLE
+#define ARC_FLAGS (TEE_FLAG | SOLE_FLAG)
 #define TRP_LDS_MAX 4096             // floats of transition tables cached in LDS (else read from HBM)
 #ifndef TEE_LDS_MAX
 #define TEE_LDS_MAX 2048             // HMMs whose tee log-probability is cached in LDS
@@ -122,6 +124,12 @@ template <int NE> struct RecLayout {
 };
 #define OOB_OFF 0xf0000000u          // byte offset beyond every arena: buffer loads return 0, stores are dropped
 #define REC_LABELLED 0x40000000      // bit 30 of a record's second header word: the instance's arc carries a word label
+#define REC_SOLE 0x20000000          // bit 29: no other arc leads to the arc's destination state.  Its exit tokens have nobody to recombine
+                                     // with (:560-582 compares the tokens that ARRIVE at a state): they place no bid in phase A and read,
+                                     // win and reset none in phase X - an atomic, a load and a store less per exit token, each a 64-byte
+                                     // sector of a state's words for 8 useful bytes.  Most states of a C.L.G are such states (the inside
+                                     // of a word's chain, the nodes of a lexicon tree).  ITEM_SOLE: the same bit on the exit item.
+#define ITEM_SOLE 4
 
 // per-state search state, ONE 32-byte record (half a memory sector): the recombination keys of a state.
 //   key0  best exit token arriving at the state this frame (bid in phase A, reset by its winner in phase X)
@@ -757,12 +765,12 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 Bk = JdArc{r.x, __int_as_float(r.y), r.z, r.w};
             } else Bk = C.arcs[nb.x];
             {   // the template by HMM (a table of a few tens of KB: L2 hits; a per-arc copy would be a second random sector)
-                const int hm = max((Bk.in & ~TEE_FLAG) - 1, 0);        // (arcs on the new list carry a model; idle lanes read arc 0)
+                const int hm = max((Bk.in & ~ARC_FLAGS) - 1, 0);        // (arcs on the new list carry a model; idle lanes read arc 0)
                 a0 = ((const int4 *)C.aux_h)[(NE == 3) ? hm : 2 * hm];
                 if (NE == 6) a1 = ((const int4 *)C.aux_h)[2 * hm + 1];
             }
             // header: arc, nStates | transMat << 8 | (the arc carries a word label) << 30, source state, destination state
-            h0 = (v4i){nb.x, valid ? (a0.x | (Bk.out != 0 ? REC_LABELLED : 0)) : 0, nb.y, Bk.to};
+            h0 = (v4i){nb.x, valid ? (a0.x | (Bk.out != 0 ? REC_LABELLED : 0) | ((Bk.in & SOLE_FLAG) ? REC_SOLE : 0)) : 0, nb.y, Bk.to};
             h1 = (v4i){a0.y, a0.z, a0.w, __float_as_int(Bk.w)};
             if (NE == 6) h2 = (v4i){a1.x, a1.y, a1.z, 0};
 #pragma unroll
@@ -795,7 +803,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
         FINE(0);                                                       // (development build) the wait for stage K
         const int arc = h0.x;
         const int n = h0.y & 0xff;                                     // 0 for lanes without an instance
-        const int tm = (h0.y >> 8) & 0x3fffff;
+        const int tm = (h0.y >> 8) & 0x1fffff;
         // entry token = the best token that arrived at the arc's source state in the previous frame, over the arc (:560-582)
         const v4i itv = ld16(V.items, kv != 0ULL ? iprev + (unsigned)(kv & 0xffffffffULL) * 32u : OOB_OFF);   // (no branch, see stage_r)
         // stage R of the next chunk (issued after the item load: the wait for the item leaves it in flight)
@@ -947,8 +955,9 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 const unsigned ioff = has_exit ? icur + k * 32u : OOB_OFF;
                 st16(V.items, ioff, as_v4(ex));
                 const int lab = (h0.y & REC_LABELLED) ? 1 : 0;         // (the label itself is read from the arc when a Path record is written)
-                st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, 0});
-                if (has_exit) GMAX((lab ? &SREC_BID(V.srec, C, h0.w).keyL : &SREC_BID(V.srec, C, h0.w).key0), ((unsigned long long)f2o(ex.score) << 32) | k);
+                const int sole = (h0.y & REC_SOLE) ? ITEM_SOLE : 0;
+                st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, sole});
+                if (has_exit && !sole) GMAX((lab ? &SREC_BID(V.srec, C, h0.w).keyL : &SREC_BID(V.srec, C, h0.w).key0), ((unsigned long long)f2o(ex.score) << 32) | k);
                 exit_cnt += nex;
                 c_end += nex;
             }
@@ -1143,12 +1152,13 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         unsigned long long kv = 0ULL;
         int label = exit_kind ? 0 : info.y;
         const bool carried = !LZY && from_q;                           // (wave-uniform)
+        const bool sole = exit_kind && (info.w & ITEM_SOLE) != 0;      // (REC_SOLE: the only arc into its state - it placed no bid)
         if (carried) { rs = row_q.x; rs1 = row_q.x + row_q.y; reserve(); }
         else {
             // (no load sits in a branch of its own: a load inside a branch is waited for at the branch's end, and these
             // would be three round trips one after the other instead of one)
             const unsigned soff = (real || (valid && !LZY)) ? SREC_BID_OFF(C, state) : OOB_OFF;
-            const v4i sk = ld16(V.srec_r, (real && exit_kind) ? soff : OOB_OFF);   // {key0, keyL}
+            const v4i sk = ld16(V.srec_r, (real && exit_kind && !sole) ? soff : OOB_OFF);   // {key0, keyL}
             int2 srow = make_int2(0, 0);
             // (static, shared by the streams: cached loads)
             if (!LZY) { const int sti = valid ? state : 0; srow = make_int2(C.row_ptr[sti], C.row_ptr[sti + 1]); }
@@ -1171,10 +1181,10 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             // (a closure item was the best arrival at its state when it was produced - else it was never listed for a
             // later round - and that makes it responsible for the arcs its score was the first to make hopeful, see
             // above: it is expanded even if a better arrival has come since)
-            const bool winner = !exit_kind || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
+            const bool winner = !exit_kind || sole || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
             // every state that received exit-token bids is cleaned up by its winner, expanded or not (an
             // item below its threshold still holds the key of its state if it was the best one there)
-            if (winner && exit_kind) CS(info.y != 0 ? &SREC_BID(V.srec, C, state).keyL : &SREC_BID(V.srec, C, state).key0, 0ULL);
+            if (winner && exit_kind && !sole) CS(info.y != 0 ? &SREC_BID(V.srec, C, state).keyL : &SREC_BID(V.srec, C, state).key0, 0ULL);
             have = have && winner;
         }
         if (have && real) {
@@ -1283,7 +1293,12 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
         { const int bq = lane < tot ? b_nx : 0; Bk_nx = arc_at(bq); lv_nx = CL(V.live + bq); }
         // the arrival (see above), issued behind the first arcs' loads: the compiler waits for a returning atomic where it
         // stands, so this way the two round trips are one
-        if (arrive) { eold = GMAX(&SREC_E(V.srec, C, state, p), ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
+        if (arrive) {
+            const unsigned long long akey = ((unsigned long long)f2o(t.score) << 32) | ii;
+            if (sole) CS(&SREC_E(V.srec, C, state, p), akey);          // (REC_SOLE: the frame's only arrival at the state - a store, nothing to read back: +1-2 % on
+                                                                       // the heavy graphs; the slot kernel keeps the atomic - the branch cost its headline 1.5 %)
+            else { eold = GMAX(&SREC_E(V.srec, C, state, p), akey); eo = (unsigned)(eold >> 32); }
+        }
         list_dirty(arrive && eold == 0ULL, state);
         if (eo == 0u) c_new += x_new;                                  // (the first arrival at the state in this frame: :899-935 tries them all)
         if (__ballot(n_slices > 0)) {
@@ -1331,7 +1346,7 @@ __device__ __forceinline__ void phase_x(const DecConst &C, SearchShared &sh, Str
             // produce a closure item (its arrival key as a pre-filter: hot history states receive many arrivals,
             // and an atomic on a contended key costs far more than this load; its row for the item to carry).
             const bool on = a < tot;
-            const int inl = Bk.in & ~TEE_FLAG;
+            const int inl = Bk.in & ~ARC_FLAGS;
             const bool entry = on && inl != 0;
             const bool is_tee = entry && (Bk.in & TEE_FLAG) != 0;
             const float ns = tg.score + Bk.w;                          // (:535 / :562: the same sum either way)

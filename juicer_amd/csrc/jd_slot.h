@@ -162,9 +162,9 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
             const unsigned long long e = CL(V.newl + (valid ? (size_t)w * g.seg_new + (unsigned)idx : (size_t)0));
             const int2 nb = valid ? make_int2((int)(unsigned)e, (int)(unsigned)(e >> 32)) : make_int2(0, 0);   // {arc, source state}
             const JdArc Bk = C.arcs[nb.x];
-            const int hm = max((Bk.in & ~TEE_FLAG) - 1, 0);            // (arcs on the new list carry a model; idle lanes read arc 0)
+            const int hm = max((Bk.in & ~ARC_FLAGS) - 1, 0);            // (arcs on the new list carry a model; idle lanes read arc 0)
             const int4 a0 = ((const int4 *)C.aux_h)[(NE == 3) ? hm : 2 * hm];
-            h0 = (v4i){nb.x, valid ? (a0.x | (Bk.out != 0 ? REC_LABELLED : 0)) : 0, nb.y, Bk.to};
+            h0 = (v4i){nb.x, valid ? (a0.x | (Bk.out != 0 ? REC_LABELLED : 0) | ((Bk.in & SOLE_FLAG) ? REC_SOLE : 0)) : 0, nb.y, Bk.to};
             h1 = (v4i){a0.y, a0.z, a0.w, __float_as_int(Bk.w)};
             if (NE == 6) { const int4 a1 = ((const int4 *)C.aux_h)[2 * hm + 1]; h2 = (v4i){a1.x, a1.y, a1.z, 0}; }
 #pragma unroll
@@ -172,7 +172,7 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
         }
         const int arc = h0.x;
         const int n = h0.y & 0xff;                                     // 0 for lanes without an instance
-        const int tm = (h0.y >> 8) & 0x3fffff;
+        const int tm = (h0.y >> 8) & 0x1fffff;
         // the best arrival at the source state (StateRec::e[p ^ 1]) and the likelihoods: in flight together
         unsigned long long kv;
         float outp[NE];
@@ -332,8 +332,9 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
                 const unsigned ioff = has_exit ? icur + k * 32u : OOB_OFF;
                 st16(V.items, ioff, as_v4(ex));
                 const int lab = (h0.y & REC_LABELLED) ? 1 : 0;
-                st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, 0});
-                if (has_exit) GMAX((lab ? &SREC_BID(V.srec, C, h0.w).keyL : &SREC_BID(V.srec, C, h0.w).key0), ((unsigned long long)f2o(ex.score) << 32) | k);
+                const int sole = (h0.y & REC_SOLE) ? ITEM_SOLE : 0;      // (jd_search.h: REC_SOLE - nobody to recombine with, no bid)
+                st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, sole});
+                if (has_exit && !sole) GMAX((lab ? &SREC_BID(V.srec, C, h0.w).keyL : &SREC_BID(V.srec, C, h0.w).key0), ((unsigned long long)f2o(ex.score) << 32) | k);
                 exit_cnt += nex;
                 c_end += nex;
             }
@@ -458,10 +459,11 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         int rs, rs1;
         unsigned long long kv = 0ULL;
         int label = exit_kind ? 0 : info.y;
+        const bool sole = exit_kind && (info.w & ITEM_SOLE) != 0;
         if (from_q) { rs = row_q.x; rs1 = row_q.x + row_q.y; }
         else {
             const unsigned soff = valid ? SREC_BID_OFF(C, state) : OOB_OFF;
-            const v4i sk = ld16(V.srec_r, (real && exit_kind) ? soff : OOB_OFF);   // {key0, keyL}
+            const v4i sk = ld16(V.srec_r, (real && exit_kind && !sole) ? soff : OOB_OFF);   // {key0, keyL}
             const int sti = valid ? state : 0;
             const int2 srow = make_int2(C.row_ptr[sti], C.row_ptr[sti + 1]);
             const bool lab_on = exit_kind && real && info.y != 0;
@@ -471,8 +473,8 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
             kv = ((unsigned long long)(unsigned)(info.y != 0 ? sk.w : sk.y) << 32) | (unsigned)(info.y != 0 ? sk.z : sk.x);
         }
         if (real) {
-            const bool winner = !exit_kind || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
-            if (winner && exit_kind) CS(info.y != 0 ? &SREC_BID(V.srec, C, state).keyL : &SREC_BID(V.srec, C, state).key0, 0ULL);
+            const bool winner = !exit_kind || sole || ((unsigned)(kv & 0xffffffffULL) == ii && kv != 0ULL);
+            if (winner && exit_kind && !sole) CS(info.y != 0 ? &SREC_BID(V.srec, C, state).keyL : &SREC_BID(V.srec, C, state).key0, 0ULL);
             have = have && winner;
         }
         if (have && real) {
@@ -567,7 +569,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
         JdArc Bk_nx = {0, 0.0f, 0, 0};
         int lv_nx = 0;
         { const int bq = lane < tot ? b_nx : 0; Bk_nx = C.arcs[bq]; lv_nx = CL(V.live + bq); }
-        if (arrive) { eold = GMAX(&SREC_E(V.srec, C, state, p), ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
+if (arrive) { eold = GMAX(&SREC_E(V.srec, C, state, p), ((unsigned long long)f2o(t.score) << 32) | ii); eo = (unsigned)(eold >> 32); }
         list_dirty(arrive && eold == 0ULL, state);
         if (eo == 0u) c_new += x_new;                                  // (the first arrival at the state in this frame: :899-935 tries them all)
         if (__ballot(n_slices > 0)) {
@@ -607,7 +609,7 @@ __device__ __forceinline__ void slot_phase_x(const DecConst &C, SlotShared &sh, 
             bool mk = false, touch = false;
             Tok un = null_tok();
             const bool on = a < tot;
-            const int inl = Bk.in & ~TEE_FLAG;
+            const int inl = Bk.in & ~ARC_FLAGS;
             const bool entry = on && inl != 0;
             const bool is_tee = entry && (Bk.in & TEE_FLAG) != 0;
             const float ns = tg.score + Bk.w;                          // (:535 / :562: the same sum either way)

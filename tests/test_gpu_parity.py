@@ -884,6 +884,45 @@ def test_decoders_own_state_numbering_and_layouts(cfg_name, request, monkeypatch
     assert said_own == 3, "the decoder's own numbering never took effect on %s" % cfg_name
 
 
+@pytest.mark.parametrize("cfg_name", ["small", "small_tree", "mixed"])
+def test_exit_tokens_that_recombine_with_nobody(cfg_name, request, monkeypatch, capfd):
+    """REC_SOLE (jd_search.h): the exit tokens of an arc that is the only arc into its destination place no bid for the state and
+    read, win and reset none - the reference compares the tokens that arrive at a state (WFSTDecoderLite.cpp:560-582), and here
+    there is one.  Both kernels, with the shortcut and without it (JD_NO_SOLE): the oracle's hypotheses, the reference's
+    statistics, identical bits; the fixtures have arcs of both kinds, and tee arcs never take the shortcut (their pass-through
+    arrives beside their exit token)."""
+    import re
+    from juicer_amd import capi
+    from oracle.oracle import OracleDecoder
+    gnet, gam, onet, oam, feats, _ = request.getfixturevalue(cfg_name)
+    kw = dict(main_beam=150.0, end_beam=100.0, word_beam=80.0, start_beam=120.0) if cfg_name != "mixed" else dict(main_beam=200.0)
+    od = OracleDecoder(onet, oam, **kw)
+    ora = [od.decode_certified(x) for x in feats]
+    monkeypatch.setenv("JD_DEV", "1")
+    monkeypatch.setenv("JD_VERBOSE", "1")
+    base = None
+    for slot in (False, True):
+        if slot and gam.max_states > 8: continue
+        monkeypatch.setenv("JD_SLOT_BATCH", "1" if slot else "0")
+        monkeypatch.setenv("JD_CW", "1" if slot else "64")
+        for no_sole in (False, True):
+            if no_sole: monkeypatch.setenv("JD_NO_SOLE", "1")
+            else: monkeypatch.delenv("JD_NO_SOLE", raising=False)
+            capfd.readouterr()
+            gd = capi.Decoder(gnet, gam, max_streams=len(feats), **kw)
+            m = re.search(r"recombine with nobody: those of (\d+) of (\d+) model arcs", capfd.readouterr().err)
+            assert m, "jd_dec_create did not say how many arcs take the shortcut"
+            n_sole, n_model = int(m.group(1)), int(m.group(2))
+            assert (n_sole == 0) if no_sole else (0 < n_sole < n_model), (n_sole, n_model)
+            gs = gd.decode_batch(feats)
+            for u, g in enumerate(gs):
+                assert_hyp_matches(g, ora[u], "%s slot %d no_sole %d utt %d" % (cfg_name, slot, no_sole, u))
+            got = [(g.n, g.label.tobytes(), g.time.tobytes(), g.score.tobytes(), [g.stats[k] for k in ("tot_active_models", "tot_proc_emit_hyps", "tot_proc_end_hyps", "tot_insts_in")]) for g in gs]
+            if base is None: base = got
+            assert got == base, "%s: slot kernel %d, shortcut off %d" % (cfg_name, slot, no_sole)
+            gd.close()
+
+
 def test_max_alloc_models(small):
     """setMaxAllocModels (WFSTDecoderLite.cpp:807-820) is a SOFT limit in the reference (it decides whether cached
     NetInst objects are dropped between utterances, :164-169): whatever its value - percentage / MB / count form,
