@@ -91,20 +91,19 @@ def design_bytes(st, max_n, G, frames, row_in_lds):
     walk accounts for without reading them.  Sectors as requested (16-byte halves of a 32-byte StateRec, 32-byte items), not the
     64 / 128-byte transactions the memory system makes of them - that is `traffic`.
       phase A  record read R + the source state's arrival key 8; a newly entered arc: list entry 8 + arc 16 + template 16 (32) +
-               key 8; the winning item's token 16 per entry token pulled; record written R; exit token: item 32 + bid 8;
+               key 8; the winning item's token 16 per entry token pulled; record written R; exit token: item 32, + a bid 8 where one
+               is placed (tot_bids_placed: not by the exit tokens of an arc that is alone into its state, REC_SOLE);
                likelihoods: the frame's row into LDS (G x 4, the slot kernel) or 4 per emitting hypothesis (k_search)
-      phase X  item taken up: item 32 + state record XState 64 + bid keys 16 + CSR bounds 8 + the row's instance flags 32;
+      phase X  item taken up: item 32 + state record XState 64 + CSR bounds 8 + the row's instance flags 32, + the bid keys 16
+               where a bid was placed;
                arrival: 8 (atomic max); arc walked: record 16 + flag 1; closure item: item 32 + atomic 8 + destination key 8;
-               Path record 32
-    (An exit token of an arc that is the only one into its state - jd_search.h: REC_SOLE, most exit tokens of a chain-shaped graph -
-    places and reads no bid: 24 of the bytes priced here per exit token are not requested for it.  The kernels do not count those
-    tokens apart, so this figure is an upper bound of the requests: by 1.5 % on configs[1], by 3 % on configs[3].)"""
+               Path record 32"""
     R = 80.0 if max_n <= 5 else 144.0
     tmpl = 16.0 if max_n <= 5 else 32.0
     a = (st["tot_recs_read"] * (R + 8.0) + st["tot_new_attached"] * (8.0 + 16.0 + tmpl + 8.0) + st["tot_entry_items"] * 16.0
-         + st["tot_recs_written"] * R + st["tot_active_end_hyps"] * 40.0
+         + st["tot_recs_written"] * R + st["tot_active_end_hyps"] * 32.0 + st["tot_bids_placed"] * 8.0
          + (frames * G * 4.0 if row_in_lds else st["tot_proc_emit_hyps"] * 4.0))
-    x = (st["tot_items_expanded"] * (32.0 + 64.0 + 16.0 + 8.0 + 32.0) + st["tot_proc_end_hyps"] * 8.0 + st["tot_arcs_walked"] * 17.0
+    x = (st["tot_items_expanded"] * (32.0 + 64.0 + 8.0 + 32.0) + st["tot_bids_placed"] * 16.0 + st["tot_proc_end_hyps"] * 8.0 + st["tot_arcs_walked"] * 17.0
          + st["tot_closure_items"] * 48.0 + st["tot_paths"] * 32.0)
     return a + x
 

@@ -257,6 +257,8 @@ typedef struct jd_stats {          /* WFSTDecoderLite.cpp:231-241 + build counte
     int64_t tot_items_expanded;    /* phase X: frontier items taken up (exit tokens, closure items, slices) */
     int64_t tot_arcs_walked;       /* phase X: arc records loaded */
     int64_t tot_closure_items;     /* phase X: closure items written (epsilon / tee arcs followed) */
+    int64_t tot_bids_placed;       /* phase A: exit tokens that bid for their destination state - those of an arc that is the only
+                                    * arc into its state recombine with nobody and place none (csrc/jd_search.h: REC_SOLE) */
 } jd_stats;
 
 /*

@@ -34,7 +34,7 @@ class Stats(C.Structure):
                 ("tot_paths", C.c_int64), ("tot_insts_in", C.c_int64), ("ties", C.c_int64),
                 # what the kernels really touched (include/juicer_amd.h: jd_stats)
                 ("tot_recs_read", C.c_int64), ("tot_new_attached", C.c_int64), ("tot_recs_written", C.c_int64), ("tot_entry_items", C.c_int64),
-                ("tot_items_expanded", C.c_int64), ("tot_arcs_walked", C.c_int64), ("tot_closure_items", C.c_int64)]
+                ("tot_items_expanded", C.c_int64), ("tot_arcs_walked", C.c_int64), ("tot_closure_items", C.c_int64), ("tot_bids_placed", C.c_int64)]
 
 
 class CHyp(C.Structure):

@@ -1051,7 +1051,7 @@ static int fetch_results_from(jd_dec *d, const StreamCtl *ctl_v, const int *resn
         H.stats.tot_paths = K.st[ST_PATHS];
         H.stats.tot_insts_in = K.st[ST_INSTS];
         H.stats.tot_recs_read = K.st[ST_RECS]; H.stats.tot_new_attached = K.st[ST_NEWL]; H.stats.tot_recs_written = K.st[ST_SURV]; H.stats.tot_entry_items = K.st[ST_KEYS];
-        H.stats.tot_items_expanded = K.st[ST_XITEMS]; H.stats.tot_arcs_walked = K.st[ST_WALK]; H.stats.tot_closure_items = K.st[ST_CLOS];
+        H.stats.tot_items_expanded = K.st[ST_XITEMS]; H.stats.tot_arcs_walked = K.st[ST_WALK]; H.stats.tot_closure_items = K.st[ST_CLOS]; H.stats.tot_bids_placed = K.st[ST_BIDS];
         d->load_sum += (double)K.st[ST_INSTS] + (double)K.st[ST_ARCS]; d->load_frames += (double)K.frame;
         H.stats.ties = 0;
         int k = S.res_n;

@@ -73,6 +73,7 @@ enum { ST_EMIT = 0, ST_END, ST_MODELS, ST_PEMIT, ST_PEND, ST_ARCS, ST_PATHS, ST_
        ST_XITEMS,   // phase X: frontier items taken up (exit tokens, closure items, slices)
        ST_WALK,     // phase X: arc records loaded by the walks
        ST_CLOS,     // phase X: closure items written
+       ST_BIDS,     // phase A: bids placed for a destination state (exit tokens that are not alone into it, REC_SOLE)
        ST_N };
 enum { JDE_SLOTS = -41, JDE_ITEMS = -42, JDE_PATHS = -43, JDE_NEW = -44, JDE_LAZY = -45, JDE_LAZY_INV = -46, JDE_BARRIER = -50 };
 
@@ -958,6 +959,7 @@ __device__ __forceinline__ void phase_a(const DecConst &C, SearchShared &sh, Str
                 const int sole = (h0.y & REC_SOLE) ? ITEM_SOLE : 0;
                 st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, sole});
                 if (has_exit && !sole) GMAX((lab ? &SREC_BID(V.srec, C, h0.w).keyL : &SREC_BID(V.srec, C, h0.w).key0), ((unsigned long long)f2o(ex.score) << 32) | k);
+                JD_COUNT(const int nbid_ = __popcll(__ballot(has_exit && !sole)); if (lane == 0 && nbid_) atomicAdd(&sh.stat[ST_BIDS], nbid_));
                 exit_cnt += nex;
                 c_end += nex;
             }

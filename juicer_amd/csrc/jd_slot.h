@@ -335,6 +335,7 @@ __device__ __forceinline__ void slot_phase_a(const DecConst &C, SlotShared &sh, 
                 const int sole = (h0.y & REC_SOLE) ? ITEM_SOLE : 0;      // (jd_search.h: REC_SOLE - nobody to recombine with, no bid)
                 st16(V.items, ioff + 16u, (v4i){arc, lab, h0.w, sole});
                 if (has_exit && !sole) GMAX((lab ? &SREC_BID(V.srec, C, h0.w).keyL : &SREC_BID(V.srec, C, h0.w).key0), ((unsigned long long)f2o(ex.score) << 32) | k);
+                JD_COUNT(const int nbid_ = __popcll(__ballot(has_exit && !sole)); if (lane == 0 && nbid_) atomicAdd(&sh.stat[ST_BIDS], nbid_));
                 exit_cnt += nex;
                 c_end += nex;
             }

@@ -42,7 +42,7 @@ def test_wer_vs_oracle_against_itself(built):
 
 def test_design_bytes_prices_every_counter():
     keys = ["tot_recs_read", "tot_new_attached", "tot_entry_items", "tot_recs_written", "tot_active_end_hyps", "tot_proc_emit_hyps",
-            "tot_items_expanded", "tot_proc_end_hyps", "tot_arcs_walked", "tot_closure_items", "tot_paths"]
+            "tot_items_expanded", "tot_proc_end_hyps", "tot_arcs_walked", "tot_closure_items", "tot_paths", "tot_bids_placed"]
     zero = {k: 0 for k in keys}
     assert bench.design_bytes(zero, 5, 3000, 10, row_in_lds=False) == 0.0
     assert bench.design_bytes(zero, 5, 3000, 10, row_in_lds=True) == 10 * 3000 * 4.0          # the likelihood row, once per frame

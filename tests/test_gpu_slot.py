@@ -228,6 +228,7 @@ def test_counters_of_what_the_kernels_touch(built, monkeypatch):
             assert 0 < st["tot_arcs_walked"] <= st["tot_arcs_visited"], st
             assert st["tot_items_expanded"] >= st["tot_proc_end_hyps"] > 0, st
             assert st["tot_closure_items"] > 0, st                          # (the tee model between words: closure items every word end)
-        seen[slot] = [{k: g.stats[k] for k in ("tot_recs_read", "tot_new_attached", "tot_recs_written", "tot_entry_items")} for g in gs]
+            assert 0 < st["tot_bids_placed"] < st["tot_active_end_hyps"], st  # (REC_SOLE: the inside of a word's chain places none)
+        seen[slot] = [{k: g.stats[k] for k in ("tot_recs_read", "tot_new_attached", "tot_recs_written", "tot_entry_items", "tot_bids_placed")} for g in gs]
         gd.close()
     assert seen[False] == seen[True], (seen[False], seen[True])
