@@ -1,0 +1,67 @@
+"""GPU parity on random WFSTs of arbitrary shape (tests/random_topology.py): the HIP path against the certified oracle on graphs no
+lexicon / language-model generator makes - states of any in- and out-degree, parallel arcs, self loops, epsilon and tee arcs
+anywhere (forward only), labels on any arc, final weights on any state, arcs into the initial state.  These are the shapes the
+decoder's structural decisions look at (csrc/jd_search.h: REC_SOLE - exit tokens of an arc that is alone into its state skip the
+recombination; jd_dec_create: the decoder's own state numbering and the layout of the per-state words), so each case runs through
+both kernels and with every such decision forced on and off."""
+import numpy as np
+import pytest
+
+from helpers import STAT_KEYS, assert_hyp_matches, bit_exact
+
+pytestmark = pytest.mark.gpu
+
+BEAMS = [dict(main_beam=150.0), dict(main_beam=200.0, end_beam=120.0, word_beam=90.0), dict(main_beam=120.0, start_beam=100.0, max_hyps=120),
+         dict(max_hyps=300), dict(main_beam=250.0)]
+
+
+def _case(seed):
+    from juicer_amd import synth
+    import random_topology as rt
+    rng = np.random.default_rng(seed)
+    with_tee = bool(rng.random() < 0.6)
+    if rng.random() < 0.6:
+        am = synth.make_models(seed, n_gmm=60, n_hmm=25, n_mix=2, n_tm=6, sep=0.7, with_tee=with_tee)
+    else:
+        am = synth.make_models_mixed(seed, n_gmm=120, n_hmm=25, n_mix=2, with_tee=with_tee, sep=0.7)
+    net = rt.random_net(seed + 7, am, n_states=int(rng.integers(12, 70)), p_chain=float(rng.choice([0.2, 0.5, 0.8])))
+    feats = [rt.random_walk_features(seed + 9 + u, net, am, n_arcs=int(rng.integers(4, 16))) for u in range(int(rng.integers(1, 4)))]
+    return am, net, feats, dict(BEAMS[int(rng.integers(0, len(BEAMS)))])
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_topologies_vs_oracle(built, block, monkeypatch):
+    from juicer_amd import capi
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    monkeypatch.setenv("JD_DEV", "1")
+    checked = exact = with_hyp = 0
+    for seed in range(7000 + 12 * block, 7000 + 12 * (block + 1)):
+        am, net, feats, kw = _case(seed)
+        od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+        try:
+            ora = [od.decode_certified(x) for x in feats]
+        except AssertionError:
+            continue                                                   # (a tie-order sensitive fixture: nothing to hold an implementation to)
+        gnet, gam = capi.Network.from_synth(net), capi.Models.from_htk(am)
+        base = None
+        # the cluster kernel as it decides for itself; the slot kernel; every structural decision forced the other way
+        for env in (dict(), dict(JD_CW="1", JD_SLOT_BATCH="1"), dict(JD_NO_SOLE="1"), dict(JD_RENUMBER="1", JD_SREC_SPLIT="2"),
+                    dict(JD_RENUMBER="0", JD_SREC_SPLIT="0", JD_CW="1", JD_SLOT_BATCH="1")):
+            for k in ("JD_CW", "JD_SLOT_BATCH", "JD_NO_SOLE", "JD_RENUMBER", "JD_SREC_SPLIT"):
+                if k in env: monkeypatch.setenv(k, env[k])
+                else: monkeypatch.delenv(k, raising=False)
+            gd = capi.Decoder(gnet, gam, max_streams=len(feats), **kw)
+            gs = gd.decode_batch(feats)
+            for u, g in enumerate(gs):
+                what = "seed %d %s %s utt %d" % (seed, kw, env, u)
+                assert_hyp_matches(g, ora[u], what, check_stats=False)
+                for k in STAT_KEYS:
+                    assert g.stats[k] == ora[u].stats[k], "%s: stat %s %d vs oracle %d" % (what, k, g.stats[k], ora[u].stats[k])
+                if not env:
+                    checked += 1; exact += bit_exact(g, ora[u]); with_hyp += ora[u].n > 0
+            got = [(g.n, g.label.tobytes(), g.time.tobytes(), g.score.tobytes()) for g in gs]
+            if base is None: base = got
+            assert got == base, "seed %d %s: results differ with %s" % (seed, kw, env)
+            gd.close()
+    print("random topologies, block %d: %d utterances, %d bit-exact incl. scores, %d with a hypothesis" % (block, checked, exact, with_hyp))
+    assert checked >= 12 and exact >= checked - 1 and with_hyp >= 4

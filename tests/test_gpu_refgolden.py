@@ -52,3 +52,35 @@ def test_scoring_kernel_equals_the_reference_built_log_likelihoods(built, case):
     ll = capi.Models.from_htk(am).score_frames(feats[0][:g["ll_frames"]])
     assert [np.float32(v).tobytes().hex() for v in ll[0, :8]] == g["ll_first"]
     assert make_golden.digest(ll) == g["ll_sha256"]
+
+
+@pytest.mark.parametrize("slot", [False, True])
+def test_hip_path_equals_the_reference_built_vectors_on_random_topologies(built, monkeypatch, slot):
+    """tests/golden/refbase_random_golden.json: graphs of arbitrary shape (any in- and out-degree, parallel arcs, self loops, epsilon and
+    tee arcs anywhere, labels and final weights anywhere, arcs into the initial state), decoded by the reference's own compiled
+    WFSTDecoderLite in the build container; here by the HIP path, through both kernels: words, times, every score bit for bit, the
+    reference's five statistics."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    from test_refgolden_cpu import load_random_cases
+    if slot:
+        monkeypatch.setenv("JD_DEV", "1"); monkeypatch.setenv("JD_CW", "1"); monkeypatch.setenv("JD_SLOT_BATCH", "1")
+    checked = found = order_dependent = 0
+    for c, am, net, feats in load_random_cases():
+        kw = c["beams"]
+        gd = capi.Decoder(capi.Network.from_synth(net), capi.Models.from_htk(am), max_streams=len(feats), **kw)
+        hyps = gd.decode_batch(feats)
+        assert (gd.last_timing()["slot_launches"] > 0) == slot
+        for u, (h, want) in enumerate(zip(hyps, c["utts"])):
+            if not same_as_golden(h, want):                            # (the one licence, as above: an order-dependent tie inside the reference)
+                od = OracleDecoder(OracleNet(net), OracleAM(am), **kw)
+                assert od.decode(feats[u]).stats["ties"] > 0, (c["seed"], kw, u)
+                with pytest.raises(AssertionError):
+                    od.decode_certified(feats[u])
+                order_dependent += 1
+                continue
+            for k in REF_STATS:
+                assert int(h.stats[k]) == want["stats"][k], (c["seed"], kw, u, k)
+            checked += 1; found += want["n"] > 0
+        gd.close()
+    assert checked >= 40 and found >= 30 and order_dependent == 0, (checked, found, order_dependent)

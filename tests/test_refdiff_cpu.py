@@ -193,3 +193,21 @@ def test_hybrid_models(driver, spm):
     for kw in (dict(main_beam=200.0), dict(main_beam=150.0, max_hyps=100)):
         r = _clean(refdiff.diff_case("hybrid", am, net, feats, kw, loader="fsm"))
         assert r["hyps_found"] >= 1
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_topologies(driver, block):
+    """Graphs of arbitrary shape (tests/random_topology.py: any in- and out-degree, parallel arcs, self loops, epsilon and tee arcs
+    anywhere, labels and final weights anywhere, arcs into the initial state) - the cases tests/test_gpu_random_topology.py holds
+    the HIP path to the oracle on: here the oracle is held to the reference's own classes on the same graphs, both loaders."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_random_topology as trt
+    done = found = 0
+    for seed in range(7000 + 8 * block, 7000 + 8 * (block + 1)):
+        am, net, feats, kw = trt._case(seed)
+        r = refdiff.diff_case("random topology %d" % seed, am, net, feats, kw, loader=("fsm" if seed % 2 else "jwnt"))
+        if r.get("reference_crashed"):
+            continue                                               # (a shape the reference itself does not survive: nothing to compare)
+        _clean(r)
+        done += r["utterances"]; found += r["hyps_found"]
+    assert done >= 8 and found >= 4, (done, found)

@@ -63,3 +63,31 @@ def test_oracle_scoring_equals_the_reference_built_log_likelihoods(built, case):
     ll = OracleAM(am).score_frames(feats[0][:g["ll_frames"]])
     assert [np.float32(v).tobytes().hex() for v in ll[0, :8]] == g["ll_first"]
     assert make_golden.digest(ll) == g["ll_sha256"]
+
+
+def load_random_cases():
+    """tests/golden/refbase_random_golden.json: the reference's own outputs on random graphs of arbitrary shape (make_refbase_random_golden.py)"""
+    import make_golden
+    sys.path.insert(0, HERE)
+    import test_gpu_random_topology as trt
+    g = json.load(open(os.path.join(HERE, "golden", "refbase_random_golden.json")))
+    out = []
+    for c in g["cases"]:
+        am, net, feats, kw = trt._case(c["seed"])
+        assert make_golden.input_digest(am, net, feats) == c["input_sha256"] and kw == c["beams"], "random generator changed: regenerate the golden file"
+        out.append((c, am, net, feats))
+    return out
+
+
+def test_oracle_equals_the_reference_built_vectors_on_random_topologies(built):
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    n = found = 0
+    for c, am, net, feats in load_random_cases():
+        od = OracleDecoder(OracleNet(net), OracleAM(am), **c["beams"])
+        for u, (f, want) in enumerate(zip(feats, c["utts"])):
+            o = od.decode(f)
+            assert same_as_golden(o, want), (c["seed"], c["beams"], u)
+            for k in REF_STATS:
+                assert int(o.stats[k]) == want["stats"][k], (c["seed"], u, k)
+            n += 1; found += want["n"] > 0
+    assert n >= 40 and found >= 30
