@@ -9,7 +9,7 @@ import numpy as np
 from juicer_amd import synth
 
 
-def random_net(seed, am, n_states=40, arcs_per_state=2.2, p_eps=0.18, p_label=0.3, p_final=0.3, n_words=50, p_chain=0.5):
+def random_net(seed, am, n_states=40, arcs_per_state=2.2, p_eps=0.18, p_label=0.3, p_final=0.3, n_words=50, p_chain=0.5, hub_fanout=0):
     rng = np.random.default_rng(seed)
     n_model = am.n_hmm
     src, dst, il, ol, w = [], [], [], [], []
@@ -34,6 +34,9 @@ def random_net(seed, am, n_states=40, arcs_per_state=2.2, p_eps=0.18, p_label=0.
     for _ in range(max(0, n_extra)):
         s, d = int(rng.integers(0, n_states)), int(rng.integers(0, n_states))
         arc(s, d, eps=bool(rng.random() < p_eps and s < d))
+    if hub_fanout:                                                     # one state with thousands of arcs (the search slices such rows)
+        hub = int(order[min(2, n_states - 1)])
+        for _ in range(hub_fanout): arc(hub, int(rng.integers(0, n_states)), eps=False)
     # FSM convention: the arcs of a state stand together, and the source of the first arc is the initial state
     if init not in src: arc(init, int(order[1]), eps=False)
     sa = np.asarray(src)

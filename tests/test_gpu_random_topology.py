@@ -65,3 +65,69 @@ def test_random_topologies_vs_oracle(built, block, monkeypatch):
             gd.close()
     print("random topologies, block %d: %d utterances, %d bit-exact incl. scores, %d with a hypothesis" % (block, checked, exact, with_hyp))
     assert checked >= 12 and exact >= checked - 1 and with_hyp >= 4
+
+
+def _big_case(seed):
+    from juicer_amd import synth
+    import random_topology as rt
+    rng = np.random.default_rng(seed)
+    am = synth.make_models(seed, n_gmm=150, n_hmm=60, n_mix=3, n_tm=8, sep=0.7, with_tee=bool(rng.random() < 0.5))
+    net = rt.random_net(seed + 7, am, n_states=int(rng.integers(300, 3000)), arcs_per_state=float(rng.uniform(2.5, 6.0)), n_words=200,
+                        p_chain=float(rng.choice([0.3, 0.7])), hub_fanout=int(rng.choice([0, 700, 3000])))
+    feats = [rt.random_walk_features(seed + 9 + u, net, am, n_arcs=25) for u in range(3)]
+    kw = [dict(main_beam=200.0, max_hyps=2000), dict(main_beam=180.0, end_beam=150.0, word_beam=120.0), dict(main_beam=220.0)][int(rng.integers(0, 3))]
+    return am, net, feats, kw, float(rng.choice([1.0, 3.0])), float(rng.choice([0.0, -1.0]))
+
+
+def test_larger_random_topologies_through_every_call(built, monkeypatch):
+    """300-3000 states, 2.5-6 arcs per state, some with a state of 700 / 3000 arcs (rows the search hands on in slices), thousands of
+    active models per frame, a language-model scale and an insertion penalty: whole batches against the certified oracle through the
+    cluster kernel and the slot kernel, and - through the stream calls, pushed in ragged pieces, with a trace after every push -
+    against the oracle's partial paths (PARTIAL_DECODING, WFSTDecoderLite.cpp:824-890)."""
+    from juicer_amd import capi
+    from oracle.oracle import OracleAM, OracleDecoder, OracleNet
+    monkeypatch.setenv("JD_DEV", "1")
+    checked = found = traces = 0
+    for seed in range(8000, 8010):
+        am, net, feats, kw, lm, pen = _big_case(seed)
+        od = OracleDecoder(OracleNet(net, lm, pen), OracleAM(am), **kw)
+        try:
+            ora = [od.decode_certified(x) for x in feats]
+        except AssertionError:
+            continue
+        gnet, gam = capi.Network.from_synth(net, lm, pen), capi.Models.from_htk(am)
+        base = None
+        for env in (dict(), dict(JD_CW="1", JD_SLOT_BATCH="1"), dict(JD_NO_SOLE="1", JD_RENUMBER="1")):
+            for k in ("JD_CW", "JD_SLOT_BATCH", "JD_NO_SOLE", "JD_RENUMBER"):
+                if k in env: monkeypatch.setenv(k, env[k])
+                else: monkeypatch.delenv(k, raising=False)
+            gd = capi.Decoder(gnet, gam, max_streams=len(feats), **kw)
+            gs = gd.decode_batch(feats)
+            for u, g in enumerate(gs):
+                what = "seed %d %s lm %g pen %g %s utt %d" % (seed, kw, lm, pen, env, u)
+                assert_hyp_matches(g, ora[u], what, check_stats=False)
+                for k in STAT_KEYS:
+                    assert g.stats[k] == ora[u].stats[k], "%s: stat %s %d vs oracle %d" % (what, k, g.stats[k], ora[u].stats[k])
+                assert bit_exact(g, ora[u]), what
+                if not env:
+                    checked += 1; found += ora[u].n > 0
+            got = [(g.n, g.label.tobytes(), g.time.tobytes(), g.score.tobytes()) for g in gs]
+            if base is None: base = got
+            assert got == base, "seed %d: results differ with %s" % (seed, env)
+            if not env and ora[0].n > 0:                               # the stream calls: ragged pushes, a trace behind each
+                x = feats[0]
+                at = sorted(set(int(v) for v in np.random.default_rng(seed).integers(3, x.shape[0], size=5)))
+                snaps, _ = od.decode_partial(x, interval=0, trace_at=at)
+                gd.stream_init(0)
+                pos = 0
+                for f in at:
+                    gd.stream_push(0, x[pos:f + 1]); pos = f + 1
+                    assert gd.stream_partial(0, trace_now=True) == snaps[f], "seed %d: trace after frame %d" % (seed, f)
+                    traces += 1
+                gd.stream_push(0, x[pos:])
+                h = gd.stream_finish(0)
+                assert_hyp_matches(h, ora[0], "seed %d stream" % seed, check_stats=False)
+                assert bit_exact(h, ora[0])
+            gd.close()
+    print("larger random topologies: %d utterances, %d with a hypothesis, %d traces" % (checked, found, traces))
+    assert checked >= 21 and found >= 12 and traces >= 15

@@ -211,3 +211,25 @@ def test_random_topologies(driver, block):
         _clean(r)
         done += r["utterances"]; found += r["hyps_found"]
     assert done >= 8 and found >= 4, (done, found)
+
+
+def test_larger_random_topologies(driver):
+    """... at 300-3000 states with a language-model scale and an insertion penalty, states of 700 / 3000 arcs, histogram pruning, end and
+    word beams (tests/test_gpu_random_topology.py: _big_case), and the partial paths of PARTIAL_DECODING on the same graphs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_random_topology as trt
+    done = found = 0
+    for seed in range(8000, 8010):
+        am, net, feats, kw, lm, pen = trt._big_case(seed)
+        neutral = lm == 1.0 and pen == 0.0                             # (a scale / penalty: the reference applies it itself in its text constructor)
+        r = refdiff.diff_case("larger random topology %d" % seed, am, net, feats, kw, loader=("jwnt" if neutral and seed % 2 == 0 else "fsm"), lm_scale=lm, ins_penalty=pen)
+        if r.get("reference_crashed"):
+            continue
+        _clean(r)
+        done += r["utterances"]; found += r["hyps_found"]
+        if seed % 3 == 0 and kw.get("end_beam"):                       # (traces: with end / word beams on - the reference walks off its token array without, DESIGN.md 2)
+            rp = refdiff.diff_case("larger random topology %d, traces" % seed, am, net, feats, kw, loader="fsm", lm_scale=lm, ins_penalty=pen, pti=40)
+            if not rp.get("reference_crashed"):
+                _clean(rp)
+                assert rp["identical_partial"] == rp["utterances"], rp
+    assert done >= 21 and found >= 12, (done, found)

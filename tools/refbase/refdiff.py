@@ -78,12 +78,15 @@ def write_symbols(path, prefix, n):
 def run_reference(am, net, feats, beams=None, loader="jwnt", lm_scale=1.0, ins_penalty=0.0, pti=0, threading=False, cpus=None,
                   timeout=3600, workdir=None):
     """The reference's decoder on (am, net, feats): one dict per utterance (the driver's JSON lines), plus (rc, stderr tail, wall).
-    loader: "jwnt" - the network through WFSTNetwork::readBinary from the file this build's jd_net_save_jwnt writes (weights as
-    stored: lm_scale / ins_penalty are applied by this build before the file is written) - or "fsm": the TEXT constructor
+    loader: "jwnt" - the network through WFSTNetwork::readBinary from the file this build's jd_net_save_jwnt writes, read with scale 1
+    and penalty 0: ONLY for lm_scale == 1 and ins_penalty == 0 (the file holds the weights with the scale divided out, as the
+    reference's writeBinary leaves them, src/WFSTNetwork.cpp:1106-1125: another scale is the FSM route's business; the JWNT round
+    trip with a scale is held to the reference in tests/test_refdiff_cpu.py::test_network_loaded_by_the_reference) - or "fsm": the TEXT constructor
     (src/WFSTNetwork.cpp:371-616) from an AT&T text file + two symbol tables, the reference applying scale and penalty itself.
     Models always through HTKModels::readBinary from this build's jd_am_save_jmbi (the MMF text parser is bison / flex output)."""
     from juicer_amd import capi
     from juicer_amd import io as jio
+    assert loader != "jwnt" or (lm_scale == 1.0 and ins_penalty == 0.0), "a scale / penalty goes through the FSM text route (see above)"
     exe = build()
     beams = dict(beams or {})
     tmp = workdir or tempfile.mkdtemp(prefix="refdiff_", dir=BUILD)
