@@ -233,3 +233,21 @@ def test_larger_random_topologies(driver):
                 _clean(rp)
                 assert rp["identical_partial"] == rp["utterances"], rp
     assert done >= 21 and found >= 12, (done, found)
+
+
+def test_two_thread_decoder_on_random_topologies(driver):
+    """WFSTDecoderLiteThreading (the organisation DESIGN.md 3.7 compares the pipeline with) on graphs of arbitrary shape: where its
+    unsynchronised request queue lets a run finish, the result is the one-thread decoder's and the oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_random_topology as trt
+    done = skipped = 0
+    for seed in (8002, 8005, 8008):
+        am, net, feats, kw, lm, pen = trt._big_case(seed)
+        r = refdiff.diff_case("larger random topology %d, two threads" % seed, am, net, feats[:2], kw, loader="fsm", lm_scale=lm, ins_penalty=pen, threading=True, timeout=60)
+        if r.get("error"):
+            skipped += 1
+            continue
+        _clean(r)
+        done += r["utterances"]
+    if done == 0:
+        pytest.skip("the reference's two-thread decoder finished none of the %d runs" % skipped)
