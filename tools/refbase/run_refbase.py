@@ -33,6 +33,49 @@ BEAMS = [dict(), dict(main_beam=200.0), dict(main_beam=150.0, end_beam=100.0, wo
          dict(max_hyps=300), dict(main_beam=120.0, end_beam=90.0, word_beam=70.0, start_beam=100.0, max_hyps=150)]     # tests/test_gpu_parity.py
 
 
+def random_cases():
+    """The graphs of tests/test_gpu_random_topology.py (what the HIP path is held to the oracle on): 48 small ones, 10 of 300-3000 states."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_random_topology as trt
+    cases = []
+    for seed in range(7000, 7048):
+        am, net, feats, kw = trt._case(seed)
+        cases.append(refdiff.diff_case("random topology %d (%d states, %d arcs)" % (seed, net.n_states, net.n_arcs), am, net, feats, kw,
+                                       loader=("fsm" if seed % 2 else "jwnt")))
+    for seed in range(8000, 8010):
+        am, net, feats, kw, lm, pen = trt._big_case(seed)
+        neutral = lm == 1.0 and pen == 0.0
+        cases.append(refdiff.diff_case("random topology %d (%d states, %d arcs)" % (seed, net.n_states, net.n_arcs), am, net, feats, kw,
+                                       loader=("jwnt" if neutral and seed % 2 == 0 else "fsm"), lm_scale=lm, ins_penalty=pen))
+    return cases
+
+
+def summarise(cases):
+    return {"cases": cases, "cases_total": len(cases), "cases_identical": sum(int(c["ok"]) for c in cases),
+            "cases_reference_crashed": sum(int(bool(c.get("reference_crashed"))) for c in cases),
+            "cases_different": sum(int(not c["ok"] and not c.get("reference_crashed")) for c in cases),
+            "utterances_total": sum(c["utterances"] for c in cases),
+            "what_identical_means": "every utterance: words, times, every score and the totals bit for bit; the reference's five statistics "
+                                    "(its protected totals, WFSTDecoderLite.h:150-154); with PartialTraceInterval the partial paths"}
+
+
+def append_random(path):
+    from juicer_amd import build as jbuild
+    from oracle import oracle as orc
+    jbuild.build(); orc.build(); refdiff.build()
+    out = json.load(open(path))
+    old = [c for c in out["differential"]["cases"] if not c["name"].startswith("random topology")]
+    new = random_cases()
+    out["differential"] = summarise(old + new)
+    out["differential"]["random_topologies"] = {"cases": len(new), "identical": sum(int(c["ok"]) for c in new), "utterances": sum(c["utterances"] for c in new),
+                                                "hyps_found": sum(c.get("hyps_found", 0) for c in new), "appended": "python tools/refbase/run_refbase.py --append-random"}
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+        f.write("\n")
+    print(json.dumps({k: v for k, v in out["differential"].items() if k != "cases"}, indent=1))
+    print("not identical:", [c["name"] for c in new if not c["ok"]])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--utts", type=int, default=64, help="configs[1] utterances the two reference decoders are timed on (the whole batch)")
@@ -40,9 +83,14 @@ def main():
     ap.add_argument("--arcs", type=int, default=1_000_000)
     ap.add_argument("--quick", action="store_true", help="timing legs only (B1 / B2), no wider differential")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "cpu_reference_baseline.json"))
+    ap.add_argument("--append-random", action="store_true",
+                    help="only add the random graphs of arbitrary shape (tests/random_topology.py) to the differential of the existing --out file; "
+                         "the timing legs and the other cases stay as they were measured")
     args = ap.parse_args()
     if not refdiff.available():
         raise SystemExit("tools/refbase runs in the build container only: %s is not there" % refdiff.REF)
+    if args.append_random:
+        return append_random(args.out)
     from juicer_amd import build as jbuild
     from juicer_amd import synth
     from oracle import oracle as orc
@@ -115,12 +163,8 @@ def main():
         a, n, f, _ = synth.config_toy()
         for kw in BEAMS:
             add("config_toy %s" % (kw or "no pruning"), a, n, f, kw)
-        out["differential"] = {"cases": cases, "cases_total": len(cases), "cases_identical": sum(int(c["ok"]) for c in cases),
-                               "cases_reference_crashed": sum(int(bool(c.get("reference_crashed"))) for c in cases),
-                               "cases_different": sum(int(not c["ok"] and not c.get("reference_crashed")) for c in cases),
-                               "utterances_total": sum(c["utterances"] for c in cases),
-                               "what_identical_means": "every utterance: words, times, every score and the totals bit for bit; the reference's five statistics "
-                                                       "(its protected totals, WFSTDecoderLite.h:150-154); with PartialTraceInterval the partial paths"}
+        cases += random_cases()
+        out["differential"] = summarise(cases)
     out["wall_seconds_all"] = round(time.time() - t_all, 1)
     with open(args.out, "w") as f:
         json.dump(out, f, indent=1)
