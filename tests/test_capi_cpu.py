@@ -306,3 +306,41 @@ def test_closure_path_counts_against_the_recursion(built):
     am, _, _, _ = synth.config_toy()
     _, acyclic = cyc.closure_path_counts(capi.Models.from_htk(am))
     assert not acyclic
+
+
+def test_network_loaders_on_random_topologies(built, tmp_path):
+    """Graphs of arbitrary shape (tests/random_topology.py: parallel arcs, self loops, epsilon arcs with and without labels, arcs into the
+    initial state, finals anywhere) through every way into the library: arrays, the AT&T text file (with a scale and a penalty), the JWNT
+    file this build writes and reads - the same CSR each time, and the oracle's (what the parity tests on these graphs ride on)."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import random_topology as rt
+    from juicer_amd import capi, io as jio, synth
+    from oracle.oracle import OracleNet
+    bits = lambda a: a.view(np.uint32) if a.dtype == np.float32 else a
+    am = synth.make_models(3, n_gmm=40, n_hmm=20, n_mix=2, n_tm=4, with_tee=True)
+    n_parallel = n_self = 0
+    for seed in range(9000, 9012):
+        net = rt.random_net(seed, am, n_states=int(10 + 9 * (seed % 7)), arcs_per_state=3.0)
+        pairs = list(zip(net.src.tolist(), net.dst.tolist()))
+        n_parallel += len(pairs) - len(set(pairs)); n_self += sum(s == d for s, d in pairs)
+        for scale, pen in ((1.0, 0.0), (6.5, -1.75)):
+            c = capi.Network.from_synth(net, scale, pen).csr()
+            o = OracleNet(net, scale, pen).arrays()
+            assert np.array_equal(np.diff(c["row_ptr"]), o["cnt"])
+            # (the oracle keeps the file's order - the initial state's arcs first -, the CSR is by state number: row by row)
+            rows = np.concatenate([np.arange(o["first"][q], o["first"][q] + o["cnt"][q]) for q in range(net.n_states)]).astype(np.int64)
+            for k in ("to", "ilab", "olab"): assert np.array_equal(c[k], o[k][rows]), (seed, k)
+            assert np.array_equal(bits(c["w"]), bits(o["w"][rows])) and np.array_equal(np.isfinite(c["fin_w"]), o["final_ind"] >= 0)
+            p = str(tmp_path / ("n%d.fsm" % seed))
+            jio.write_fsm(p, net)
+            f = capi.Network.from_fsm_file(p, None, None, scale, pen).csr()
+            for k in c: assert np.array_equal(bits(f[k]), bits(c[k])), (seed, scale, k)
+        g0 = capi.Network.from_synth(net)
+        pj = str(tmp_path / ("n%d.jwnt" % seed))
+        g0.save_jwnt(pj)
+        j = capi.Network.from_jwnt_file(pj).csr()
+        c = g0.csr()
+        for k in c: assert np.array_equal(bits(j[k]), bits(c[k])), (seed, "jwnt", k)
+        assert g0.init_state == int(net.src[0])
+    assert n_parallel > 0 and n_self > 0, "the generator made no parallel arcs / self loops: nothing was tested"
