@@ -344,3 +344,31 @@ def test_network_loaders_on_random_topologies(built, tmp_path):
         for k in c: assert np.array_equal(bits(j[k]), bits(c[k])), (seed, "jwnt", k)
         assert g0.init_state == int(net.src[0])
     assert n_parallel > 0 and n_self > 0, "the generator made no parallel arcs / self loops: nothing was tested"
+
+
+def test_ctypes_mirrors_have_the_headers_layout(built, tmp_path):
+    """juicer_amd/capi.py mirrors five structs of include/juicer_amd.h by hand; jd_stats grew twice this round.  A C program compiled
+    against the header says what the sizes and the field offsets ARE (gcc, the compiler a caller of the C ABI uses)."""
+    import ctypes as C
+    import subprocess
+    from juicer_amd import capi
+    pairs = [("jd_stats", capi.Stats), ("jd_hyp", capi.CHyp), ("jd_timing", capi.Timing), ("jd_pipe_stats", capi.PipeStats), ("jd_broker_stats", capi.BrokerStats)]
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "juicer_amd.h"', "int main(void) {"]
+    for cname, cls in pairs:
+        src.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            src.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    src += ["  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src) + "\n")
+    exe = str(tmp_path / "layout")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"), "-o", exe, str(c)], check=True)   # (a field the header lacks does not compile)
+    want = {}
+    for line in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines():
+        a, b, v = line.split()
+        want[(a, b)] = int(v)
+    for cname, cls in pairs:
+        assert C.sizeof(cls) == want[(cname, "size")], (cname, C.sizeof(cls), want[(cname, "size")])
+        for f in cls._fields_:
+            assert getattr(cls, f[0]).offset == want[(cname, f[0])], (cname, f[0])
